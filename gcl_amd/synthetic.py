@@ -1,0 +1,294 @@
+"""Seeded synthetic KITTI-shaped inputs for the hot path (no dataset is reachable offline).
+
+Emits exactly the dictionaries the reference's collate functions hand to the hot path:
+
+* training batch  -- keys of ``collate_colocation_fn`` (lib/colocation_data_loader.py:462-475),
+  built the way ``ColocationKittiDataset.__getitem__`` does (:315-421): one centre scan +
+  ``num_neighborhood`` neighbour scans of the same scene from sensor poses 5..60 m away,
+  random rotation (<=45 deg) + scale U(0.8, 1.2), voxelise, radius-search groups
+  (``get_matching_indices_colocation``, util/pointcloud.py:69-132, K=5).
+* eval pair       -- keys of ``collate_debug_pair_fn`` (lib/complement_data_loader.py:1323-1333).
+
+The scene is an HDL-64-like ray cast (64 beams +2..-24.8 deg, 1800 azimuths, ground plane at
+z=-1.73 m, random boxes, 2 cm range noise, 80 m max range) -- SURVEY.md section 8.
+Everything here is CPU/numpy loader work (as it is in the reference) and is NOT timed by bench.py.
+"""
+import numpy as np
+import torch
+
+from gcl_amd.MinkowskiEngine import utils as me_utils
+
+N_BEAMS = 64
+N_AZIMUTH = 1800
+SENSOR_HEIGHT = 1.73
+MAX_RANGE = 80.0
+
+
+def make_scene(seed, n_boxes=60, extent=70.0):
+    """Axis-aligned boxes (cars / walls / poles) scattered on the ground plane, in WORLD frame."""
+    rng = np.random.RandomState(seed)
+    centers = np.stack([rng.uniform(-extent, extent + 60.0, n_boxes),
+                        rng.uniform(-extent, extent, n_boxes)], axis=1)
+    kind = rng.randint(0, 3, n_boxes)
+    size = np.where(kind[:, None] == 0, rng.uniform([3.5, 1.6, 1.4], [5.0, 2.1, 2.0], (n_boxes, 3)),
+                    np.where(kind[:, None] == 1, rng.uniform([6.0, 0.4, 2.5], [25.0, 1.0, 8.0], (n_boxes, 3)),
+                             rng.uniform([0.3, 0.3, 3.0], [0.8, 0.8, 9.0], (n_boxes, 3))))
+    swap = rng.rand(n_boxes) < 0.5
+    size[swap, 0], size[swap, 1] = size[swap, 1].copy(), size[swap, 0].copy()
+    lo = np.concatenate([centers - size[:, :2] / 2, np.full((n_boxes, 1), -SENSOR_HEIGHT)], axis=1)
+    hi = np.concatenate([centers + size[:, :2] / 2, (-SENSOR_HEIGHT + size[:, 2])[:, None]], axis=1)
+    # keep the road corridor around y=0 free so that every sensor pose along x sees something
+    keep = ~((lo[:, 1] < 2.5) & (hi[:, 1] > -2.5))
+    return {"lo": lo[keep], "hi": hi[keep]}
+
+
+def raycast(scene, sensor_xyz, seed, yaw=0.0):
+    """Cast the 64x1800 beam fan from ``sensor_xyz`` (world); return hits in the SENSOR frame [P,3] float32."""
+    rng = np.random.RandomState(seed)
+    elev = np.deg2rad(np.linspace(2.0, -24.8, N_BEAMS))
+    azim = np.linspace(-np.pi, np.pi, N_AZIMUTH, endpoint=False) + yaw
+    ce, se = np.cos(elev)[:, None], np.sin(elev)[:, None]
+    d = np.stack([ce * np.cos(azim)[None], ce * np.sin(azim)[None], se * np.ones_like(azim)[None]], axis=-1)
+    d = d.reshape(-1, 3)
+    o = np.asarray(sensor_xyz, dtype=np.float64)
+    t = np.full(len(d), np.inf)
+    # ground plane z = -SENSOR_HEIGHT (world)
+    down = d[:, 2] < -1e-6
+    tg = np.where(down, (-SENSOR_HEIGHT - o[2]) / np.where(down, d[:, 2], -1.0), np.inf)
+    t = np.minimum(t, tg)
+    lo, hi = scene["lo"], scene["hi"]
+    inv = 1.0 / np.where(np.abs(d) < 1e-9, 1e-9, d)
+    for b in range(len(lo)):
+        t0 = (lo[b] - o) * inv
+        t1 = (hi[b] - o) * inv
+        tn = np.minimum(t0, t1).max(axis=1)
+        tf = np.maximum(t0, t1).min(axis=1)
+        hit = (tn <= tf) & (tf > 0) & (tn > 0.5)
+        t = np.where(hit & (tn < t), tn, t)
+    ok = np.isfinite(t) & (t < MAX_RANGE)
+    t = t[ok] + rng.normal(0.0, 0.02, ok.sum())
+    pts_sensor = d[ok] * t[:, None]
+    if yaw != 0.0:
+        c, s = np.cos(-yaw), np.sin(-yaw)
+        R = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
+        pts_sensor = pts_sensor @ R.T
+    return pts_sensor.astype(np.float32)
+
+
+def _random_rotation(rng, max_angle):
+    axis = rng.normal(size=3)
+    axis /= np.linalg.norm(axis)
+    ang = rng.uniform(-max_angle, max_angle)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    R = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+    T = np.eye(4)
+    T[:3, :3] = R
+    return T
+
+
+def _apply(T, xyz):
+    return (xyz @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
+
+
+def colocation_groups(center_xyz, nghb_xyz, list_M, radius, K=5):
+    """Group builder with the semantics of ``get_matching_indices_colocation`` (util/pointcloud.py:69-132).
+
+    For every centre voxel: <=K centre-cloud radius hits (nearest first, i.e. itself first), then <=K hits
+    per neighbour cloud (neighbour aligned into the centre frame by ``list_M[j]``); a group exists only if
+    at least one neighbour cloud matched.  ``finest`` marks the member whose own sensor is closest.
+    Row ids: centre rows 0..Nc-1, neighbour j offset by Nc + sum_{i<j} N_i.
+    """
+    from scipy.spatial import cKDTree
+
+    Nc = len(center_xyz)
+    ctree = cKDTree(center_xyz)
+    dc, ic = ctree.query(center_xyz, k=K, distance_upper_bound=radius)
+    hits = []
+    for j, xyz in enumerate(nghb_xyz):
+        tree = cKDTree(_apply(list_M[j], xyz))
+        dj, ij = tree.query(center_xyz, k=K, distance_upper_bound=radius)
+        hits.append((dj, ij))
+    nghb_range = [np.linalg.norm(x, axis=1) for x in nghb_xyz]
+    offs = np.concatenate([[Nc], Nc + np.cumsum([len(x) for x in nghb_xyz])])
+    c_range = np.linalg.norm(center_xyz, axis=1)
+    group, index, finest = [], [], []
+    for i in range(Nc):
+        members = [int(v) for v, d in zip(ic[i], dc[i]) if np.isfinite(d)]
+        n0 = len(members)
+        best, pos = c_range[i], 0
+        for j, (dj, ij) in enumerate(hits):
+            idx = [int(v) for v, d in zip(ij[i], dj[i]) if np.isfinite(d)]
+            if idx:
+                r = nghb_range[j][idx[0]]
+                if r < best:
+                    best, pos = r, len(members)
+                members += [v + int(offs[j]) for v in idx]
+        if len(members) == n0:
+            continue
+        group.append(len(members))
+        index += members
+        flag = [False] * len(members)
+        flag[pos] = True
+        finest += flag
+    return group, index, finest
+
+
+def fixed_size_groups(center_xyz, nghb_xyz, list_M, radius, size=16, K=5):
+    """BASELINE.json's 'positive-group size 16' variant: keep radius groups with >= size members, cut to size
+    (the finest member is moved inside the kept prefix so that exactly one flag stays set)."""
+    group, index, finest = colocation_groups(center_xyz, nghb_xyz, list_M, radius, K=K)
+    g2, i2, f2 = [], [], []
+    p = 0
+    for g in group:
+        idx, fl = index[p:p + g], finest[p:p + g]
+        p += g
+        if g < size:
+            continue
+        fpos = fl.index(True)
+        if fpos >= size:
+            idx[size - 1], fl[size - 1] = idx[fpos], True
+        g2.append(size)
+        i2 += idx[:size]
+        f2 += fl[:size]
+    return g2, i2, f2
+
+
+def exhaustive_hash(index, group, M):
+    """Vectorised numpy equivalent of ``_exhaustive_hash`` (util/misc.py:29-36): the symmetric key
+    min(i + j*M, i*M + j) of every in-group pair, group by group, i-major."""
+    out = []
+    p = 0
+    index = np.asarray(index, dtype=np.int64)
+    for g in group:
+        idx = index[p:p + g]
+        p += g
+        for a in range(g - 1):
+            out.append(np.minimum(idx[a] + idx[a + 1:] * M, idx[a] * M + idx[a + 1:]))
+    if not out:
+        return np.zeros(0, dtype=np.int64)
+    return np.concatenate(out)
+
+
+def make_train_sample(seed, voxel_size=0.3, num_neighborhood=6, min_dist=5.0, max_dist=60.0,
+                      search_mult=1.5, random_rotation=True, random_scale=True, group_mode="radius",
+                      n_boxes=60):
+    """One ``__getitem__`` tuple (lib/colocation_data_loader.py:419-421) on the synthetic scene."""
+    rng = np.random.RandomState(seed + 7919)
+    scene = make_scene(seed, n_boxes=n_boxes)
+    center_pos = np.array([0.0, 0.0, 0.0])
+    xyz = raycast(scene, center_pos, seed * 101 + 1)
+    shifts = np.linspace(min_dist, max_dist, num_neighborhood)
+    xyz_cmpl, list_M = [], []
+    for j, s in enumerate(shifts):
+        pos = np.array([s, rng.uniform(-0.5, 0.5), 0.0])
+        xyz_cmpl.append(raycast(scene, pos, seed * 101 + 2 + j))
+        M = np.eye(4)
+        M[:3, 3] = pos - center_pos          # neighbour sensor frame -> centre sensor frame
+        list_M.append(M)
+    search = voxel_size * search_mult
+    if random_rotation:
+        T0 = _random_rotation(rng, np.pi / 4)
+        xyz = _apply(T0, xyz)
+        for j in range(len(xyz_cmpl)):
+            Tc = _random_rotation(rng, np.pi / 4)
+            xyz_cmpl[j] = _apply(Tc, xyz_cmpl[j])
+            list_M[j] = T0 @ list_M[j] @ np.linalg.inv(Tc)
+    if random_scale and rng.rand() < 0.95:
+        scale = 0.8 + 0.4 * rng.rand()
+        search *= scale
+        xyz = (scale * xyz).astype(np.float32)
+        for j in range(len(xyz_cmpl)):
+            xyz_cmpl[j] = (scale * xyz_cmpl[j]).astype(np.float32)
+            list_M[j][:3, 3] *= scale
+    _, sel = me_utils.sparse_quantize(xyz / voxel_size, return_index=True)
+    xyz_th = xyz[sel]
+    xyz_cmpl_th = []
+    for j in range(len(xyz_cmpl)):
+        _, s = me_utils.sparse_quantize(xyz_cmpl[j] / voxel_size, return_index=True)
+        xyz_cmpl_th.append(xyz_cmpl[j][s])
+    if group_mode == "radius":
+        group, index, finest = colocation_groups(xyz_th, xyz_cmpl_th, list_M, search)
+    elif group_mode == "fixed16":
+        group, index, finest = fixed_size_groups(xyz_th, xyz_cmpl_th, list_M, search, size=16)
+    else:
+        raise ValueError(group_mode)
+    coords = [np.floor(xyz_th / voxel_size).astype(np.int32)] + \
+             [np.floor(x / voxel_size).astype(np.int32) for x in xyz_cmpl_th]
+    feats = [np.ones((len(c), 1), dtype=np.float32) for c in coords]
+    # Jitter on the centre cloud only (lib/transforms.py:24-29): N(0, 0.01) with prob. 0.95
+    if rng.rand() < 0.95:
+        feats[0] = feats[0] + rng.normal(0.0, 0.01, feats[0].shape).astype(np.float32)
+    return (xyz_th, xyz_cmpl_th, coords, feats, group, index, finest, list_M)
+
+
+def collate_train(samples):
+    """``collate_colocation_fn`` (lib/colocation_data_loader.py:424-475) on ``make_train_sample`` tuples."""
+    index_batch, group_batch, finest_batch, batch_lengths = [], [], [], []
+    coords_all, feats_all = [], []
+    start = 0
+    for (_, _, coords, feats, group, index, finest, _) in samples:
+        if len(group):
+            index_batch.append(np.asarray(index, dtype=np.int64) + start)
+        n = int(sum(len(c) for c in coords))
+        start += n
+        batch_lengths.append(n)
+        coords_all += coords
+        feats_all += feats
+        group_batch += list(group)
+        finest_batch += list(finest)
+    C, F = me_utils.sparse_collate(coords_all, feats_all)
+    index = np.concatenate(index_batch) if index_batch else np.zeros(0, dtype=np.int64)
+    return {
+        "sinput_C": C,
+        "sinput_F": F.float(),
+        "group": torch.tensor(group_batch, dtype=torch.int32),
+        "index": torch.from_numpy(index).long(),
+        "finest_flag": torch.tensor(finest_batch, dtype=torch.bool),
+        "index_hash": exhaustive_hash(index, group_batch, len(C)),
+        "batch_lengths": batch_lengths,
+        "pcd_center": [s[0] for s in samples],
+    }
+
+
+def make_train_batch(seed, batch_size=4, voxel_size=0.3, group_mode="radius", **kw):
+    """The hot path's training input: ``batch_size`` samples x (1 + num_neighborhood) clouds."""
+    return collate_train([make_train_sample(seed * 1000 + b, voxel_size, group_mode=group_mode, **kw)
+                          for b in range(batch_size)])
+
+
+def make_eval_pair(seed, voxel_size=0.3, baseline=10.0, n_boxes=60):
+    """``collate_debug_pair_fn``-shaped dict (lib/complement_data_loader.py:1323-1333) for one pair."""
+    scene = make_scene(seed, n_boxes=n_boxes)
+    out = {}
+    xyzs = []
+    for k, x in enumerate([0.0, baseline]):
+        xyz = raycast(scene, np.array([x, 0.0, 0.0]), seed * 37 + k)
+        _, sel = me_utils.sparse_quantize(xyz / voxel_size, return_index=True)
+        xyz = xyz[sel]
+        xyzs.append(xyz)
+        coords = me_utils.batched_coordinates([np.floor(xyz / voxel_size).astype(np.int32)])
+        out[f"pcd{k}"] = (torch.from_numpy(xyz),)
+        out[f"sinput{k}_C"] = coords
+        out[f"sinput{k}_F"] = torch.ones((len(coords), 1), dtype=torch.float32)
+    T = np.eye(4, dtype=np.float32)
+    T[0, 3] = -baseline                     # maps cloud 0 (sensor-0 frame) into sensor-1 frame
+    out["T_gt"] = torch.from_numpy(T)
+    out["len_batch"] = [[len(xyzs[0]), len(xyzs[1])]]
+    return out
+
+
+def make_box_cloud(seed, n_points=5000, cube=10.0, n_boxes=8):
+    """configs[0] plumbing cloud: points uniform on the surfaces of random boxes in a ``cube`` metre cube."""
+    rng = np.random.RandomState(seed)
+    pts = []
+    per = n_points // n_boxes
+    for b in range(n_boxes):
+        c = rng.uniform(1.5, cube - 1.5, 3)
+        s = rng.uniform(0.8, 3.0, 3)
+        n = per if b < n_boxes - 1 else n_points - per * (n_boxes - 1)
+        u = rng.uniform(-0.5, 0.5, (n, 3)) * s
+        face = rng.randint(0, 3, n)
+        sign = rng.choice([-0.5, 0.5], n)
+        u[np.arange(n), face] = sign * s[face]
+        pts.append(c + u)
+    return np.concatenate(pts).astype(np.float32)
