@@ -1,0 +1,155 @@
+"""Generates tests/golden/*.npz by IMPORTING the reference's own Python (this container only).
+
+Run:  python tests/golden/make_golden.py        (needs /root/reference; writes small .npz fixtures)
+
+The reference never travels to the GPU box: only the arrays written here do (inputs, the exact RNG
+draws, outputs, gradients).  What is captured, and from where:
+
+* ``lib.metrics.pdist``                                    lib/metrics.py:22-29
+* ``lib.eval.find_nn_gpu``                                 lib/eval.py:18-48
+* ``util.misc._hash / _neg_hash / _exhaustive_hash``       util/misc.py:29-55
+* ``FinestContrastiveLossTrainer.finest_contrastive_loss`` lib/colocation_trainer.py:430-535
+  (instance built with ``__new__`` + the attributes the method reads; np.random seeded, and the
+  three ``np.random.choice`` draws re-drawn in the same order to record them)
+
+Third-party modules the reference imports but that are absent here (MinkowskiEngine, open3d,
+tensorboardX, easydict) are replaced by EMPTY stub modules -- none of their code is on this path.
+"""
+import codecs
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _import_reference():
+    # '# -*- coding: future_fstrings -*-' headers: decode as utf-8
+    codecs.register(lambda name: codecs.lookup("utf-8") if name in ("future_fstrings", "future-fstrings") else None)
+    for name in ["MinkowskiEngine", "MinkowskiEngine.MinkowskiFunctional", "open3d", "tensorboardX", "easydict"]:
+        m = types.ModuleType(name)
+        sys.modules[name] = m
+    me = sys.modules["MinkowskiEngine"]
+    me.MinkowskiFunctional = sys.modules["MinkowskiEngine.MinkowskiFunctional"]
+    me.MinkowskiNetwork = torch.nn.Module
+    sys.modules["tensorboardX"].SummaryWriter = object
+    sys.modules["easydict"].EasyDict = dict
+    sys.path.insert(0, REF)
+    from lib.metrics import pdist
+    from lib.eval import find_nn_gpu
+    from util.misc import _hash, _neg_hash, _exhaustive_hash
+    from lib.colocation_trainer import FinestContrastiveLossTrainer
+    return pdist, find_nn_gpu, _hash, _neg_hash, _exhaustive_hash, FinestContrastiveLossTrainer
+
+
+def _unit_rows(g, n, c):
+    f = torch.randn(n, c, generator=g)
+    return f / f.norm(dim=1, keepdim=True)
+
+
+def make_groups(rng, N, n_groups, sizes):
+    """Random positive groups whose members are near-duplicates of a shared anchor (so losses are non-trivial)."""
+    group = rng.choice(sizes, n_groups).astype(np.int32)
+    index = np.concatenate([rng.choice(N, g, replace=False) for g in group]).astype(np.int64)
+    finest = np.zeros(len(index), dtype=bool)
+    p = 0
+    for g in group:
+        finest[p + rng.randint(0, g)] = True
+        p += g
+    return group, index, finest
+
+
+def main():
+    pdist, find_nn_gpu, _hash, _neg_hash, _exhaustive_hash, Trainer = _import_reference()
+    torch.set_num_threads(4)
+
+    # ---- pdist ---------------------------------------------------------------------------------
+    g = torch.Generator().manual_seed(0)
+    A, B = _unit_rows(g, 1024, 32), _unit_rows(g, 1024, 32)
+    sub = slice(0, 96)
+    np.savez_compressed(os.path.join(HERE, "pdist.npz"), A=A.numpy(), B=B.numpy(),
+                        L2_sub=pdist(A[sub], B[sub], "L2").numpy(),
+                        Sq_sub=pdist(A[sub], B[sub], "SquareL2").numpy(),
+                        L2_rowmin=pdist(A, B, "L2").min(1)[0].numpy(),
+                        L2_rowarg=pdist(A, B, "L2").min(1)[1].numpy())
+
+    # ---- find_nn_gpu ---------------------------------------------------------------------------
+    F0, F1 = _unit_rows(g, 5000, 32), _unit_rows(g, 5000, 32)
+    F1[:700] = F0[100:800] + 0.01 * torch.randn(700, 32, generator=g)        # some true matches
+    out = {"F0": F0.numpy(), "F1": F1.numpy()}
+    for nn_max_n in (-1, 500, 2000):
+        # (-1 materialises [5000,5000,32] = 3.2 GB; fine here)
+        idx, dist = find_nn_gpu(F0, F1, nn_max_n=nn_max_n, return_distance=True)
+        out[f"idx_{nn_max_n}"] = idx.numpy()
+        out[f"dist_{nn_max_n}"] = dist.numpy()[:, 0]
+    np.savez_compressed(os.path.join(HERE, "find_nn.npz"), **out)
+
+    # ---- hashes --------------------------------------------------------------------------------
+    rng = np.random.RandomState(0)
+    M = 4000
+    group, index, _ = make_groups(rng, M, 40, [2, 3, 5, 16, 35])
+    split = torch.split(torch.from_numpy(index), tuple(group.tolist()))
+    i1, i2 = rng.randint(0, M, 500), rng.randint(0, M, 500)
+    arr = rng.randint(0, 50, (64, 3)).astype(np.int64)
+    np.savez_compressed(os.path.join(HERE, "hash.npz"), M=M, group=group, index=index,
+                        exhaustive=_exhaustive_hash(split, M), i1=i1, i2=i2, neg=_neg_hash(i1, i2, M),
+                        arr=arr, hash_arr=_hash(arr, 97), hash_list=_hash([arr[:, 0], arr[:, 1]], 97))
+
+    # ---- finest_contrastive_loss ---------------------------------------------------------------
+    cases = {
+        "var_s0": dict(seed=0, N=4000, n_groups=200, sizes=[2, 3, 5, 7, 16, 35], max_pos=64, max_hn=512),
+        "g16_s1": dict(seed=1, N=6000, n_groups=300, sizes=[16], max_pos=128, max_hn=1024),
+        "g16_s2": dict(seed=2, N=3000, n_groups=50, sizes=[16], max_pos=256, max_hn=4096),   # no subsampling
+        "var_s3": dict(seed=3, N=5000, n_groups=400, sizes=[2, 4, 9, 16, 30], max_pos=1024, max_hn=1024),
+    }
+    for name, c in cases.items():
+        rng = np.random.RandomState(c["seed"])
+        gt = torch.Generator().manual_seed(c["seed"])
+        N = c["N"]
+        Fo = _unit_rows(gt, N, 32)
+        group, index, finest = make_groups(rng, N, c["n_groups"], c["sizes"])
+        # make group members similar (anchor + noise) and plant near-duplicate NON-group rows so that the
+        # hardest negatives are below the 1.4 threshold and some of them hit the positive-pair mask
+        p = 0
+        for gsz in group:
+            rows = index[p:p + gsz]
+            Fo[rows] = Fo[rows[0]] + 0.25 * torch.randn(gsz, 32, generator=gt)
+            p += gsz
+        Fo = Fo / Fo.norm(dim=1, keepdim=True)
+        Fo = Fo.clone().requires_grad_(True)
+        split = torch.split(torch.from_numpy(index), tuple(group.tolist()))
+        index_hash = _exhaustive_hash(split, N)
+
+        tr = Trainer.__new__(Trainer)
+        tr.device = torch.device("cpu")
+        tr.pos_thresh, tr.neg_thresh, tr.finest_thresh = 0.1, 1.4, 0.2
+        tr.square_loss, tr.block_finest_gradient = True, False
+        tr.use_hard_negative, tr.use_pair_group_positive_loss = True, False
+
+        np.random.seed(c["seed"] + 100)
+        pos, fin, neg = tr.finest_contrastive_loss(
+            Fo, torch.from_numpy(group), torch.from_numpy(index), index_hash, torch.from_numpy(finest),
+            max_pos_cluster=c["max_pos"], max_hn_samples=c["max_hn"])
+        loss = pos + fin + neg
+        loss.backward()
+        # re-draw in the same order to record the RNG draws (lib/colocation_trainer.py:457,506-507)
+        np.random.seed(c["seed"] + 100)
+        G = len(group)
+        pos_sel = np.random.choice(G, c["max_pos"], replace=False) if G > c["max_pos"] else np.arange(G)
+        sel1 = np.random.choice(N, min(N, c["max_hn"]), replace=False)
+        sel2 = np.random.choice(N, min(N, c["max_hn"]), replace=False)
+        np.savez_compressed(os.path.join(HERE, f"finest_loss_{name}.npz"),
+                            F_out=Fo.detach().numpy(), group=group, index=index, finest_flag=finest,
+                            index_hash=index_hash, np_seed=c["seed"] + 100,
+                            max_pos_cluster=c["max_pos"], max_hn_samples=c["max_hn"],
+                            pos_sel=pos_sel, sel_hn1=sel1, sel_hn2=sel2,
+                            pos=pos.item(), finest=fin.item(), neg=neg.item(), grad=Fo.grad.numpy())
+        print(name, pos.item(), fin.item(), neg.item(), float(Fo.grad.abs().sum()))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,71 @@
+"""Pins oracle/loss_oracle.py against golden vectors captured from the reference's own code
+(tests/golden/make_golden.py imported lib/metrics.py, lib/eval.py, util/misc.py, lib/colocation_trainer.py)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import loss_oracle as L
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_pdist_golden():
+    z = np.load(os.path.join(G, "pdist.npz"))
+    A, B = torch.from_numpy(z["A"]), torch.from_numpy(z["B"])
+    assert np.array_equal(L.pdist(A[:96], B[:96], "L2").numpy(), z["L2_sub"])
+    assert np.array_equal(L.pdist(A[:96], B[:96], "SquareL2").numpy(), z["Sq_sub"])
+    d, i = L.pdist(A, B, "L2").min(1)
+    assert np.array_equal(d.numpy(), z["L2_rowmin"]) and np.array_equal(i.numpy(), z["L2_rowarg"])
+
+
+@pytest.mark.parametrize("nn_max_n", [500, 2000])
+def test_find_nn_golden(nn_max_n):
+    z = np.load(os.path.join(G, "find_nn.npz"))
+    F0, F1 = torch.from_numpy(z["F0"]), torch.from_numpy(z["F1"])
+    idx, dist = L.find_nn(F0, F1, nn_max_n=nn_max_n, return_distance=True)
+    assert np.array_equal(idx.numpy(), z[f"idx_{nn_max_n}"])
+    assert np.array_equal(dist.numpy()[:, 0], z[f"dist_{nn_max_n}"])
+    # chunking never changes the answer (the reference's three settings agree with each other)
+    assert np.array_equal(z["idx_-1"], z["idx_500"]) and np.array_equal(z["idx_-1"], z["idx_2000"])
+
+
+def test_hash_golden():
+    z = np.load(os.path.join(G, "hash.npz"))
+    M = int(z["M"])
+    split = np.split(z["index"], np.cumsum(z["group"])[:-1])
+    assert np.array_equal(L.exhaustive_hash(split, M), z["exhaustive"])
+    assert np.array_equal(L.neg_hash(z["i1"], z["i2"], M), z["neg"])
+    assert np.array_equal(L.positional_hash(z["arr"], 97), z["hash_arr"])
+    assert np.array_equal(L.positional_hash([z["arr"][:, 0], z["arr"][:, 1]], 97), z["hash_list"])
+    # the symmetric key is collision-free: key == min(i,j)*M + max(i,j)
+    lo, hi = np.minimum(z["i1"], z["i2"]), np.maximum(z["i1"], z["i2"])
+    assert np.array_equal(z["neg"], lo * M + hi)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "finest_loss_*.npz"))))
+def test_finest_contrastive_loss_golden(path):
+    z = np.load(path)
+    F = torch.from_numpy(z["F_out"]).requires_grad_(True)
+    # (a) replaying the recorded draws
+    pos, fin, neg = L.finest_contrastive_loss(
+        F, z["group"], z["index"], z["index_hash"], z["finest_flag"],
+        max_pos_cluster=int(z["max_pos_cluster"]), max_hn_samples=int(z["max_hn_samples"]),
+        draws=(z["pos_sel"], z["sel_hn1"], z["sel_hn2"]))
+    assert abs(pos.item() - float(z["pos"])) <= 1e-6 * max(1, abs(float(z["pos"])))
+    assert abs(fin.item() - float(z["finest"])) <= 1e-6 * max(1, abs(float(z["finest"])))
+    if np.isnan(float(z["neg"])):
+        assert np.isnan(neg.item())            # every hardest negative was a self match -> mean of empty
+        (pos + fin).backward()
+    else:
+        assert abs(neg.item() - float(z["neg"])) <= 1e-6
+        (pos + fin + neg).backward()
+        assert np.allclose(F.grad.numpy(), z["grad"], rtol=1e-5, atol=1e-7)
+    # (b) drawing from np.random in the reference's order gives the same selections
+    np.random.seed(int(z["np_seed"]))
+    p2, f2, n2 = L.finest_contrastive_loss(
+        F.detach(), z["group"], z["index"], z["index_hash"], z["finest_flag"],
+        max_pos_cluster=int(z["max_pos_cluster"]), max_hn_samples=int(z["max_hn_samples"]))
+    assert abs(p2.item() - float(z["pos"])) <= 1e-6 and abs(f2.item() - float(z["finest"])) <= 1e-6
