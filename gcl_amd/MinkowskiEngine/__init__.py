@@ -1,1 +1,144 @@
+"""MinkowskiEngine-compatible operator surface on top of libgcl_hip.so (MI355X only, no CPU fallback).
+
+Exports exactly the symbols the reference's hot path uses:
+``SparseTensor, MinkowskiConvolution, MinkowskiConvolutionTranspose, MinkowskiBatchNorm,
+MinkowskiInstanceNorm (declared, out of scope), MinkowskiFunctional.relu, cat, MinkowskiNetwork,
+utils.sparse_quantize / batched_coordinates / sparse_collate``
+with the call signatures found at model/resunet.py:38-171, model/residual_block.py:23-53, model/common.py:4-10,
+lib/colocation_trainer.py:843-845, scripts/test_kitti.py:143-147, util/misc.py:118-128.
+
+``sys.modules['MinkowskiEngine'] = gcl_amd.MinkowskiEngine`` makes the reference's model files run on it unchanged
+(INTEGRATION.md).  Semantics are those of oracle/me_oracle.py; every operator is a hand-written HIP kernel
+reached through the C ABI in include/gcl_amd.h.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
 from . import utils
+from . import MinkowskiFunctional  # noqa: F401  (import MinkowskiEngine.MinkowskiFunctional as MEF)
+from .core import CoordinateManager, CoordinateMapKey, SparseTensor, cat
+from .ops import batch_norm, sparse_conv
+
+__all__ = ["SparseTensor", "CoordinateManager", "CoordinateMapKey", "MinkowskiConvolution",
+           "MinkowskiConvolutionTranspose", "MinkowskiBatchNorm", "MinkowskiInstanceNorm", "MinkowskiNetwork",
+           "MinkowskiFunctional", "cat", "utils"]
+
+
+class MinkowskiNetwork(nn.Module):
+    """``ME.MinkowskiNetwork.__init__(self, D)`` (model/resunet.py:31)."""
+
+    def __init__(self, D):
+        super().__init__()
+        self.D = D
+
+
+class _ConvBase(nn.Module):
+    TRANSPOSE = False
+
+    def __init__(self, in_channels, out_channels, kernel_size=-1, stride=1, dilation=1, bias=False,
+                 kernel_generator=None, dimension=None):
+        super().__init__()
+        if dimension != 3:
+            raise NotImplementedError("gcl_amd implements dimension=3 only")
+        if kernel_generator is not None:
+            raise NotImplementedError("custom kernel generators are not supported")
+        if kernel_size not in (1, 3, 5):
+            raise NotImplementedError(f"kernel_size {kernel_size} not supported (1, 3, 5)")
+        if stride not in (1, 2) or dilation != 1:
+            raise NotImplementedError("supported: stride 1 or 2, dilation 1")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.dilation, self.dimension = kernel_size, stride, dilation, dimension
+        self.kernel_volume = kernel_size ** 3
+        shape = (self.kernel_volume, in_channels, out_channels) if self.kernel_volume > 1 else (in_channels, out_channels)
+        self.kernel = nn.Parameter(torch.empty(shape))
+        self.bias = nn.Parameter(torch.empty(1, out_channels)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # ME: uniform(-1/sqrt(n), 1/sqrt(n)) with n = (Cout if transposed else Cin) * kernel_volume
+        n = (self.out_channels if self.TRANSPOSE else self.in_channels) * self.kernel_volume
+        stdv = 1.0 / math.sqrt(n)
+        with torch.no_grad():
+            self.kernel.uniform_(-stdv, stdv)
+            if self.bias is not None:
+                self.bias.uniform_(-stdv, stdv)
+
+    def forward(self, x):
+        if not isinstance(x, SparseTensor):
+            raise TypeError("input must be a SparseTensor")
+        mgr = x.coordinate_manager
+        t_in = x.coordinate_map_key.tensor_stride
+        if self.TRANSPOSE:
+            if t_in % self.stride:
+                raise ValueError("transposed convolution below tensor stride 1")
+            t_out = t_in // self.stride
+        else:
+            t_out = t_in * self.stride
+        if self.kernel_volume == 1:
+            if self.stride != 1:
+                raise NotImplementedError("kernel_size 1 with stride > 1")
+            kmap = None
+            n_out = len(x)
+        elif self.TRANSPOSE:
+            kmap = mgr.get_kernel_map(t_out, self.kernel_size, self.stride)     # fine -> coarse map, used swapped
+            n_out = mgr.num_rows(t_out)
+        else:
+            kmap = mgr.get_kernel_map(t_in, self.kernel_size, self.stride)
+            n_out = mgr.num_rows(t_out)
+        F = sparse_conv(x.F, self.kernel, kmap, n_out, self.TRANSPOSE, self.bias, mgr)
+        return SparseTensor(F, coordinate_map_key=CoordinateMapKey(t_out), coordinate_manager=mgr)
+
+    def extra_repr(self):
+        return (f"in={self.in_channels}, out={self.out_channels}, kernel_size={self.kernel_size}, "
+                f"stride={self.stride}, dilation={self.dilation}")
+
+
+class MinkowskiConvolution(_ConvBase):
+    """Generalized sparse convolution (model/resunet.py:38-45 and the other forward convs)."""
+    TRANSPOSE = False
+
+
+class MinkowskiConvolutionTranspose(_ConvBase):
+    """Stride-2 up-convolution onto the existing finer coordinate map (model/resunet.py:101-134)."""
+    TRANSPOSE = True
+
+
+class MinkowskiBatchNorm(nn.Module):
+    """BatchNorm1d over the rows of ``x.F``; parameters live in the submodule ``bn`` (state_dict keys
+    ``*.bn.weight`` ... as in ME).  ``forward(x, residual=None, relu=False)`` additionally exposes the fused
+    residual-add / ReLU of BasicBlock (one kernel instead of three)."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True):
+        super().__init__()
+        if not (affine and track_running_stats):
+            raise NotImplementedError("affine=True, track_running_stats=True only")
+        self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum, affine=True, track_running_stats=True)
+
+    def forward(self, x, residual=None, relu=False):
+        bn = self.bn
+        res = residual.F if residual is not None else None
+        if residual is not None and residual.coordinate_map_key != x.coordinate_map_key:
+            raise ValueError("residual lives on a different coordinate map")
+        F = batch_norm(x.F, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training,
+                       bn.momentum, bn.eps, res, relu)
+        if self.training:
+            bn.num_batches_tracked += 1
+        out = SparseTensor(F, coordinate_map_key=x.coordinate_map_key, coordinate_manager=x.coordinate_manager)
+        out._nonneg = bool(relu)
+        return out
+
+
+class MinkowskiInstanceNorm(nn.Module):
+    """Declared for import parity (model/common.py:7-8); the *IN* model variants are out of scope."""
+
+    def __init__(self, num_features, dimension=-1):
+        super().__init__()
+        raise NotImplementedError("MinkowskiInstanceNorm is out of scope for the GCL hot path (BN variants only)")
+
+
+def _selfcheck():
+    """Fail loudly at first use when there is no GPU / no library."""
+    _lib.require_gpu()

@@ -1,0 +1,281 @@
+"""SparseTensor + coordinate manager (host side of the coordinate/kernel-map kernels in csrc/coords.hip)."""
+import torch
+
+from .. import _lib
+
+
+def _pow2_cap(n):
+    cap = 64
+    while cap < 2 * n:
+        cap *= 2
+    return cap
+
+
+class CoordinateMapKey:
+    """Identifies a coordinate map by its tensor stride (one map per stride per manager)."""
+
+    __slots__ = ("tensor_stride",)
+
+    def __init__(self, tensor_stride=1):
+        self.tensor_stride = int(tensor_stride)
+
+    def get_tensor_stride(self):
+        return [self.tensor_stride] * 3
+
+    def __eq__(self, other):
+        return isinstance(other, CoordinateMapKey) and other.tensor_stride == self.tensor_stride
+
+    def __hash__(self):
+        return hash(self.tensor_stride)
+
+    def __repr__(self):
+        return f"CoordinateMapKey(tensor_stride={self.tensor_stride})"
+
+
+class KernelMap:
+    """Forward kernel map (in stride t_in -> out stride t_in * stride), k-major neighbour tables.
+
+    nbr   [K, n_out] int32: input row of out row v at offset k, -1 if absent
+    nbr_t [K, n_in]  int32: out row reached from input row u through offset k (None when in == out map:
+                            there nbr_t[k] == nbr[K-1-k])
+    pair lists (built lazily, only the weight gradient needs them): per offset compacted (in, out) rows,
+    each offset segment padded with -1 to a multiple of GCL_PAIR_CHUNK.
+    """
+
+    def __init__(self, nbr, nbr_t, counts, n_in, n_out, K):
+        self.nbr, self.nbr_t, self.counts = nbr, nbr_t, counts
+        self.n_in, self.n_out, self.K = n_in, n_out, K
+        self.same_map = nbr_t is None
+        self._pairs = None
+
+    @property
+    def n_pairs(self):
+        return int(sum(self.counts))
+
+    def pairs(self):
+        if self._pairs is None:
+            lib = _lib.load()
+            ch = _lib.PAIR_CHUNK
+            seg = [0]
+            for c in self.counts:
+                seg.append(seg[-1] + (c + ch - 1) // ch * ch)
+            total = seg[-1]
+            dev = self.nbr.device
+            pair_in = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+            pair_out = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+            nb = (self.n_out + 1023) // 1024
+            scratch = torch.empty(self.K * nb + self.K + 1, dtype=torch.int32, device=dev)
+            seg_host = _lib.host_i64(seg)
+            _lib.check(lib.gcl_kernel_map_pairs(_lib.ptr(self.nbr), self.K, self.n_out, seg_host, _lib.ptr(scratch),
+                                                _lib.ptr(pair_in), _lib.ptr(pair_out), _lib.stream()),
+                       "gcl_kernel_map_pairs")
+            self._pairs = (pair_in, pair_out, seg, seg_host)
+        return self._pairs
+
+
+class CoordinateManager:
+    """Owns the coordinate maps (one per tensor stride) and caches kernel maps per (t_in, kernel_size, stride),
+    so the two convs of a residual block and matching encoder/decoder levels share one map."""
+
+    def __init__(self, coordinates):
+        lib = _lib.require_gpu()
+        if coordinates.dim() != 2 or coordinates.shape[1] != 4:
+            raise ValueError("coordinates must be [N, 4] = (batch, x, y, z)")
+        C = coordinates.to(torch.int32).contiguous()
+        n = C.shape[0]
+        if n == 0:
+            raise ValueError("empty SparseTensor")
+        self.device = C.device
+        cap = _pow2_cap(n)
+        table = torch.empty((cap, 2), dtype=torch.int64, device=self.device)
+        status = torch.empty(4, dtype=torch.int32, device=self.device)
+        _lib.check(lib.gcl_coords_insert(_lib.ptr(C), n, _lib.ptr(table), cap, _lib.ptr(status), _lib.stream()),
+                   "gcl_coords_insert")
+        self._maps = {1: (C, table, cap)}
+        self._status = {1: status}
+        self._checked = set()
+        self._kmaps = {}
+        self._identity = {}
+
+    # -- coordinate maps -----------------------------------------------------------------------------------
+    def _check_status(self, t):
+        if t in self._checked:
+            return
+        st = self._status[t].tolist()
+        if st[0]:
+            raise ValueError(f"{st[0]} coordinates outside the packable range (batch < 65535, |x|,|y|,|z| < 32768)")
+        if st[1]:
+            raise ValueError(f"{st[1]} duplicate coordinates: ME.SparseTensor expects unique rows "
+                             "(use ME.utils.sparse_quantize)")
+        self._checked.add(t)
+
+    def get_coords(self, t):
+        if t not in self._maps:
+            self._build_stride_map(t)
+        return self._maps[t][0]
+
+    def num_rows(self, t):
+        return self.get_coords(t).shape[0]
+
+    def _build_stride_map(self, t):
+        lib = _lib.load()
+        base_t = max(s for s in self._maps if s < t)
+        Cb, _, _ = self._maps[base_t]
+        n_in = Cb.shape[0]
+        cap = _pow2_cap(n_in)
+        table = torch.empty((cap, 2), dtype=torch.int64, device=self.device)
+        scratch = torch.empty(lib.gcl_scan_scratch_len(n_in), dtype=torch.int32, device=self.device)
+        out = torch.empty((n_in, 4), dtype=torch.int32, device=self.device)
+        meta = torch.empty(8, dtype=torch.int32, device=self.device)     # [0] = n_out, [4:8] = status
+        _lib.check(lib.gcl_stride_map(_lib.ptr(Cb), n_in, t, _lib.ptr(table), cap, _lib.ptr(scratch), _lib.ptr(out),
+                                      ctypes_offset(meta, 0), ctypes_offset(meta, 4), _lib.stream()),
+                   "gcl_stride_map")
+        m = meta.tolist()                                                # one D2H sync per level
+        if m[4]:
+            raise ValueError(f"{m[4]} strided coordinates outside the packable range")
+        self._maps[t] = (out[:m[0]], table, cap)
+        self._checked.add(t)
+
+    # -- kernel maps -----------------------------------------------------------------------------------------
+    def get_kernel_map(self, t_in, kernel_size, stride):
+        key = (t_in, kernel_size, stride)
+        if key in self._kmaps:
+            return self._kmaps[key]
+        lib = _lib.load()
+        self._check_status(1)
+        t_out = t_in * stride
+        self.get_coords(t_in)
+        C_in, table_in, cap_in = self._maps[t_in]
+        C_out = self.get_coords(t_out)
+        n_in, n_out = C_in.shape[0], C_out.shape[0]
+        K = kernel_size ** 3
+        nbr = torch.empty((K, n_out), dtype=torch.int32, device=self.device)
+        nbr_t = None if stride == 1 else torch.empty((K, n_in), dtype=torch.int32, device=self.device)
+        counts = torch.empty(K, dtype=torch.int32, device=self.device)
+        _lib.check(lib.gcl_kernel_map(_lib.ptr(C_out), n_out, _lib.ptr(table_in), cap_in, kernel_size, t_in,
+                                      _lib.ptr(nbr), _lib.ptr(nbr_t), n_in, _lib.ptr(counts), _lib.stream()),
+                   "gcl_kernel_map")
+        km = KernelMap(nbr, nbr_t, counts.tolist(), n_in, n_out, K)
+        self._kmaps[key] = km
+        return km
+
+    def identity_pairs(self, n):
+        """Pair lists of a kernel_size-1 convolution (row i <-> row i), padded to GCL_PAIR_CHUNK."""
+        if n not in self._identity:
+            ch = _lib.PAIR_CHUNK
+            total = (n + ch - 1) // ch * ch
+            p = torch.full((total,), -1, dtype=torch.int32, device=self.device)
+            p[:n] = torch.arange(n, dtype=torch.int32, device=self.device)
+            seg = [0, total]
+            self._identity[n] = (p, p, seg, _lib.host_i64(seg))
+        return self._identity[n]
+
+    def kernel_map_triples(self, t_in, kernel_size, stride):
+        """(k, in, out) triples on the host -- for parity tests against the oracle only."""
+        km = self.get_kernel_map(t_in, kernel_size, stride)
+        nbr = km.nbr.cpu()
+        k, v = torch.nonzero(nbr >= 0, as_tuple=True)
+        return torch.stack([k, nbr[k, v].long(), v], dim=1).numpy()
+
+
+def ctypes_offset(t, elem):
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr() + elem * t.element_size())
+
+
+class SparseTensor:
+    """``ME.SparseTensor``: features ``F`` [N, C] fp32 on coordinates ``C`` [N, 4] int32 (batch, x, y, z).
+
+    Constructors used by the reference:
+      SparseTensor(feats, coordinates=coords[, device=...])                  (lib/colocation_trainer.py:843-845)
+      SparseTensor(feats, coordinate_map_key=key, coordinate_manager=mgr)    (model/resunet.py:227-230)
+    Row i of ``F`` stays row i of ``C`` (the loss indexes F_out by loader row ids, :465).
+    """
+
+    def __init__(self, features, coordinates=None, coordinate_map_key=None, coordinate_manager=None, device=None,
+                 tensor_stride=1):
+        if coordinates is not None:
+            if device is not None:
+                features, coordinates = features.to(device), coordinates.to(device)
+            elif coordinates.is_cuda and not features.is_cuda:
+                features = features.to(coordinates.device)
+            elif features.is_cuda and not coordinates.is_cuda:
+                coordinates = coordinates.to(features.device)
+            if not features.is_cuda:
+                raise RuntimeError("gcl_amd.MinkowskiEngine has no CPU backend: move features/coordinates to the GPU "
+                                   "(ME.SparseTensor(feats.to(device), coordinates=coords.to(device)))")
+            if features.shape[0] != coordinates.shape[0]:
+                raise ValueError("features and coordinates differ in length")
+            coordinate_manager = CoordinateManager(coordinates)
+            coordinate_map_key = CoordinateMapKey(tensor_stride)
+        elif coordinate_map_key is None or coordinate_manager is None:
+            raise ValueError("either coordinates or (coordinate_map_key, coordinate_manager) is required")
+        if features.dtype != torch.float32:
+            features = features.float()
+        self._F = features
+        self.coordinate_map_key = coordinate_map_key
+        self.coordinate_manager = coordinate_manager
+        self._nonneg = False
+
+    @property
+    def F(self):
+        return self._F
+
+    @property
+    def C(self):
+        return self.coordinate_manager.get_coords(self.coordinate_map_key.tensor_stride)
+
+    @property
+    def coordinates(self):
+        return self.C
+
+    @property
+    def features(self):
+        return self._F
+
+    @property
+    def tensor_stride(self):
+        return self.coordinate_map_key.get_tensor_stride()
+
+    @property
+    def device(self):
+        return self._F.device
+
+    @property
+    def shape(self):
+        return self._F.shape
+
+    def __len__(self):
+        return self._F.shape[0]
+
+    def _same_map(self, other):
+        if (other.coordinate_manager is not self.coordinate_manager
+                or other.coordinate_map_key != self.coordinate_map_key):
+            raise ValueError("SparseTensors live on different coordinate maps")
+
+    def __iadd__(self, other):          # `out += residual` (model/residual_block.py:50)
+        self._same_map(other)
+        self._F = self._F + other.F
+        self._nonneg = False
+        return self
+
+    def __add__(self, other):
+        self._same_map(other)
+        return SparseTensor(self._F + other.F, coordinate_map_key=self.coordinate_map_key,
+                            coordinate_manager=self.coordinate_manager)
+
+    def __repr__(self):
+        return f"SparseTensor(F={tuple(self._F.shape)}, {self.coordinate_map_key})"
+
+
+def cat(*tensors):
+    """``ME.cat(a, b)``: channel concatenation of tensors on the same coordinate map (model/resunet.py:203)."""
+    if len(tensors) == 1 and isinstance(tensors[0], (list, tuple)):
+        tensors = tuple(tensors[0])
+    a = tensors[0]
+    for b in tensors[1:]:
+        a._same_map(b)
+    out = SparseTensor(torch.cat([t.F for t in tensors], dim=1), coordinate_map_key=a.coordinate_map_key,
+                       coordinate_manager=a.coordinate_manager)
+    out._nonneg = all(t._nonneg for t in tensors)
+    return out

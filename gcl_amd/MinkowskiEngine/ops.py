@@ -1,0 +1,155 @@
+"""torch.autograd wrappers around the C-ABI kernels (include/gcl_amd.h).  GPU tensors only."""
+import torch
+from torch.autograd.function import once_differentiable
+
+from .. import _lib
+
+
+def _conv_launch(lib, x, wp, tbl, n_out, K, cin, cout, bias):
+    y = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
+    _lib.check(lib.gcl_conv_fwd(_lib.ptr(x, torch.float32), _lib.ptr(wp), _lib.ptr(tbl), n_out, K, cin, cout,
+                                _lib.ptr(bias), _lib.ptr(y), _lib.stream()), "gcl_conv_fwd")
+    return y
+
+
+def _pack(lib, Wk, mode):
+    K, cin, cout = Wk.shape
+    wp = torch.empty(K * cin * cout, dtype=torch.float32, device=Wk.device)
+    _lib.check(lib.gcl_pack_weights(_lib.ptr(Wk, torch.float32), K, cin, cout, mode, _lib.ptr(wp), _lib.stream()),
+               "gcl_pack_weights")
+    return wp
+
+
+class _SparseConvFn(torch.autograd.Function):
+    """y[v] = sum_k x[u(k, v)] W_k (+ bias) -- forward, input gradient and weight gradient all in HIP."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias, kmap, n_out, transpose, mgr):
+        lib = _lib.require_gpu()
+        x = x.contiguous()
+        Wk = (W if W.dim() == 3 else W.unsqueeze(0)).contiguous()
+        K, cin, cout = Wk.shape
+        if x.shape[1] != cin:
+            raise ValueError(f"feature width {x.shape[1]} != in_channels {cin}")
+        ctx.stem = cin <= 4
+        if ctx.stem:
+            if transpose or kmap is None or bias is not None:
+                raise NotImplementedError("Cin <= 4 is supported for the first (non-transposed, bias-free) conv only")
+            y = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
+            _lib.check(lib.gcl_stem_fwd(_lib.ptr(x, torch.float32), _lib.ptr(Wk), _lib.ptr(kmap.nbr), n_out, K, cin,
+                                        cout, _lib.ptr(y), _lib.stream()), "gcl_stem_fwd")
+        else:
+            tbl = None if kmap is None else (kmap.nbr_t if transpose else kmap.nbr)
+            b = bias.detach().contiguous().view(-1) if bias is not None else None
+            y = _conv_launch(lib, x, _pack(lib, Wk, 0), tbl, n_out, K, cin, cout, b)
+        ctx.save_for_backward(x, Wk)
+        ctx.kmap, ctx.transpose, ctx.mgr, ctx.w_shape, ctx.has_bias = kmap, transpose, mgr, W.shape, bias is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, Wk = ctx.saved_tensors
+        K, cin, cout = Wk.shape
+        kmap, transpose = ctx.kmap, ctx.transpose
+        dy = dy.contiguous()
+        dx = dW = dbias = None
+        if ctx.needs_input_grad[0]:
+            if ctx.stem:
+                raise NotImplementedError("input gradient of the Cin <= 4 first conv is not needed by the hot path")
+            if kmap is None:
+                mode, tbl = 1, None
+            elif transpose:
+                mode, tbl = 1, kmap.nbr
+            elif kmap.same_map:
+                mode, tbl = 2, kmap.nbr
+            else:
+                mode, tbl = 1, kmap.nbr_t
+            dx = _conv_launch(lib, dy, _pack(lib, Wk, mode), tbl, x.shape[0], K, cout, cin, None)
+        if ctx.needs_input_grad[1]:
+            dW = torch.empty_like(Wk)
+            if ctx.stem:
+                n_out = dy.shape[0]
+                scratch = torch.empty(lib.gcl_stem_bwd_weight_scratch_len(K, cin, cout, n_out), dtype=torch.float32,
+                                      device=x.device)
+                _lib.check(lib.gcl_stem_bwd_weight(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(kmap.nbr), n_out, K, cin, cout,
+                                                   _lib.ptr(scratch), _lib.ptr(dW), _lib.stream()),
+                           "gcl_stem_bwd_weight")
+            else:
+                if kmap is None:
+                    pa, pb, seg, seg_host = ctx.mgr.identity_pairs(x.shape[0])
+                else:
+                    pin, pout, seg, seg_host = kmap.pairs()
+                    pa, pb = (pout, pin) if transpose else (pin, pout)
+                scratch = torch.empty(lib.gcl_conv_bwd_weight_scratch_len(K, cin, cout, seg[-1]), dtype=torch.float32,
+                                      device=x.device)
+                _lib.check(lib.gcl_conv_bwd_weight(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(pa), _lib.ptr(pb), seg_host, K,
+                                                   cin, cout, _lib.ptr(scratch), _lib.ptr(dW), _lib.stream()),
+                           "gcl_conv_bwd_weight")
+            dW = dW.view(ctx.w_shape)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            dbias = dy.sum(0, keepdim=True)
+        return dx, dW, dbias, None, None, None, None
+
+
+def sparse_conv(x, W, kmap, n_out, transpose, bias, mgr):
+    return _SparseConvFn.apply(x, W, bias, kmap, n_out, transpose, mgr)
+
+
+class _BatchNormFn(torch.autograd.Function):
+    """y = BN(x) (+ residual) (relu): statistics pass + fused apply pass; backward = reduce + fused apply."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, residual, relu):
+        lib = _lib.require_gpu()
+        x = x.contiguous()
+        n, c = x.shape
+        dev = x.device
+        if training:
+            mean = torch.empty(c, dtype=torch.float32, device=dev)
+            rstd = torch.empty(c, dtype=torch.float32, device=dev)
+            scratch = torch.empty(lib.gcl_bn_scratch_len(n, c), dtype=torch.float64, device=dev)
+            _lib.check(lib.gcl_bn_stats(_lib.ptr(x, torch.float32), n, c, float(eps), float(momentum),
+                                        _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(scratch),
+                                        _lib.ptr(mean), _lib.ptr(rstd), _lib.stream()), "gcl_bn_stats")
+        else:
+            mean = running_mean.detach().contiguous()
+            rstd = torch.rsqrt(running_var.detach() + eps).contiguous()
+        res = residual.contiguous() if residual is not None else None
+        y = torch.empty_like(x)
+        _lib.check(lib.gcl_bn_apply(_lib.ptr(x), n, c, _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(weight.detach()),
+                                    _lib.ptr(bias.detach()), _lib.ptr(res), int(relu), _lib.ptr(y), _lib.stream()),
+                   "gcl_bn_apply")
+        ctx.save_for_backward(x, y if relu else None, weight, mean, rstd)
+        ctx.relu, ctx.training, ctx.has_res = bool(relu), bool(training), residual is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, y, weight, mean, rstd = ctx.saved_tensors
+        n, c = x.shape
+        dev = x.device
+        dy = dy.contiguous()
+        sum_g = torch.empty(c, dtype=torch.float32, device=dev)
+        sum_gx = torch.empty(c, dtype=torch.float32, device=dev)
+        scratch = torch.empty(lib.gcl_bn_scratch_len(n, c), dtype=torch.float64, device=dev)
+        _lib.check(lib.gcl_bn_bwd_reduce(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(y), n, c, _lib.ptr(mean), _lib.ptr(rstd),
+                                         int(ctx.relu), _lib.ptr(scratch), _lib.ptr(sum_g), _lib.ptr(sum_gx),
+                                         _lib.stream()), "gcl_bn_bwd_reduce")
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if ctx.has_res else None
+        if ctx.training:
+            sg, sx = sum_g, sum_gx
+        else:                       # running statistics are constants: no batch-statistics terms
+            sg = sx = torch.zeros(c, dtype=torch.float32, device=dev)
+        _lib.check(lib.gcl_bn_bwd_apply(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(y), n, c, _lib.ptr(mean), _lib.ptr(rstd),
+                                        _lib.ptr(weight.detach()), _lib.ptr(sg), _lib.ptr(sx), int(ctx.relu),
+                                        _lib.ptr(dx), _lib.ptr(dres), _lib.stream()), "gcl_bn_bwd_apply")
+        return dx, sum_gx, sum_g, None, None, None, None, None, dres, None
+
+
+def batch_norm(x, weight, bias, running_mean, running_var, training, momentum, eps, residual=None, relu=False):
+    return _BatchNormFn.apply(x, weight, bias, running_mean, running_var, training, momentum, eps, residual, relu)

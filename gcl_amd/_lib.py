@@ -1,0 +1,116 @@
+"""ctypes binding of libgcl_hip.so (the C ABI declared in include/gcl_amd.h).
+
+The product path has NO CPU fallback: if the library is missing or no GPU is visible, every operator raises.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libgcl_hip.so")
+SOURCES = ["coords.hip", "conv.hip", "norm.hip", "loss.hip"]
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "gcl_amd.h")
+
+_vp, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+
+# name -> (restype, argtypes); mirrors include/gcl_amd.h one to one (tests/test_abi.py checks both directions)
+SIGNATURES = {
+    "gcl_last_error": (ctypes.c_char_p, []),
+    "gcl_version": (_i32, []),
+    "gcl_device_count": (_i32, []),
+    "gcl_coords_insert": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp]),
+    "gcl_scan_scratch_len": (_i64, [_i64]),
+    "gcl_stride_map": (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "gcl_kernel_map": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _vp]),
+    "gcl_kernel_map_pairs": (_i32, [_vp, _i32, _i64, ctypes.POINTER(_i64), _vp, _vp, _vp, _vp]),
+    "gcl_pack_weights": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "gcl_conv_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "gcl_conv_bwd_weight_scratch_len": (_i64, [_i32, _i32, _i32, _i64]),
+    "gcl_conv_bwd_weight": (_i32, [_vp, _vp, _vp, _vp, ctypes.POINTER(_i64), _i32, _i32, _i32, _vp, _vp, _vp]),
+    "gcl_stem_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
+    "gcl_stem_bwd_weight_scratch_len": (_i64, [_i32, _i32, _i32, _i64]),
+    "gcl_stem_bwd_weight": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "gcl_bn_scratch_len": (_i64, [_i64, _i32]),
+    "gcl_bn_stats": (_i32, [_vp, _i64, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gcl_bn_apply": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "gcl_bn_bwd_reduce": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "gcl_bn_bwd_apply": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "gcl_group_loss_fwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp]),
+    "gcl_group_loss_bwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),
+    "gcl_nn_rowmin": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "gcl_neg_mask": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp]),
+    "gcl_neg_loss_fwd": (_i32, [_vp, _vp, _i32, _f32, _vp, _vp]),
+    "gcl_neg_loss_bwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _vp, _vp, _vp, _vp]),
+}
+
+PAIR_CHUNK = 128   # GCL_PAIR_CHUNK
+
+_lib = None
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/*.hip for gfx950 into csrc/libgcl_hip.so (in-tree, so it travels to the GPU box)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, "common.h"), HEADER]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+def load():
+    """Load the library and bind every symbol of the header; raises if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(gcl_amd has no CPU fallback; the HIP library is the only product path)")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("gcl_amd needs an AMD GPU (gfx950); torch.cuda.is_available() is False and there is no CPU path")
+    return load()
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().gcl_last_error()
+        raise RuntimeError(f"libgcl_hip {what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t, dtype=None):
+    """Device pointer of a contiguous CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("gcl_amd operators take GPU tensors only (no CPU path)")
+    if not t.is_contiguous():
+        raise RuntimeError("gcl_amd: tensor must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"gcl_amd: expected {dtype}, got {t.dtype}")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def host_i64(values):
+    arr = (ctypes.c_int64 * len(values))(*[int(v) for v in values])
+    return arr

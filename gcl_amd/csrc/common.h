@@ -1,0 +1,93 @@
+// Internal helpers shared by the HIP translation units of libgcl_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/gcl_amd.h"
+
+namespace gcl {
+
+void set_error(const char* fmt, ...);
+
+#define GCL_CHECK_ARG(cond, ...)                 \
+  do {                                           \
+    if (!(cond)) {                               \
+      gcl::set_error(__VA_ARGS__);               \
+      return GCL_ERR_ARG;                        \
+    }                                            \
+  } while (0)
+
+#define GCL_CHECK_HIP(expr)                                                          \
+  do {                                                                               \
+    hipError_t e_ = (expr);                                                          \
+    if (e_ != hipSuccess) {                                                          \
+      gcl::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return GCL_ERR_HIP;                                                            \
+    }                                                                                \
+  } while (0)
+
+#define GCL_CHECK_LAUNCH() GCL_CHECK_HIP(hipGetLastError())
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- coordinate keys / hash table -----------------------------------------------------------------
+constexpr unsigned long long EMPTY_KEY = ~0ull;
+constexpr int COORD_OFF = 1 << 15;
+
+struct Slot {
+  unsigned long long key;
+  long long val;   // row index (kept 64-bit so that a slot is one aligned 16-byte access)
+};
+
+__device__ __forceinline__ bool pack_ok(int b, int x, int y, int z) {
+  return (unsigned)b < 65535u && (unsigned)(x + COORD_OFF) < 65536u && (unsigned)(y + COORD_OFF) < 65536u &&
+         (unsigned)(z + COORD_OFF) < 65536u;
+}
+__device__ __forceinline__ unsigned long long pack_key(int b, int x, int y, int z) {
+  return ((unsigned long long)(unsigned)b << 48) | ((unsigned long long)(unsigned)(x + COORD_OFF) << 32) |
+         ((unsigned long long)(unsigned)(y + COORD_OFF) << 16) | (unsigned long long)(unsigned)(z + COORD_OFF);
+}
+__device__ __forceinline__ unsigned long long mix64(unsigned long long h) {
+  h ^= h >> 33;
+  h *= 0xff51afd7ed558ccdull;
+  h ^= h >> 33;
+  h *= 0xc4ceb9fe1a85ec53ull;
+  h ^= h >> 33;
+  return h;
+}
+// returns the slot that holds `key` after the call (inserting it if absent)
+__device__ __forceinline__ long long table_insert(Slot* t, long long cap, unsigned long long key) {
+  long long s = (long long)(mix64(key) & (unsigned long long)(cap - 1));
+  while (true) {
+    unsigned long long prev = atomicCAS(&t[s].key, EMPTY_KEY, key);
+    if (prev == EMPTY_KEY || prev == key) return s;
+    s = (s + 1) & (cap - 1);
+  }
+}
+__device__ __forceinline__ long long table_find(const Slot* t, long long cap, unsigned long long key) {
+  long long s = (long long)(mix64(key) & (unsigned long long)(cap - 1));
+  while (true) {
+    unsigned long long k = t[s].key;
+    if (k == key) return s;
+    if (k == EMPTY_KEY) return -1;
+    s = (s + 1) & (cap - 1);
+  }
+}
+
+// ---- wave helpers ---------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+}  // namespace gcl

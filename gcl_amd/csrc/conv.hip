@@ -1,0 +1,450 @@
+// Sparse convolution forward / input-gradient / weight-gradient for gfx950 (exact-f32 MFMA).
+//
+// Replaces MinkowskiEngine's per-offset gather -> GEMM -> atomic scatter with an
+// OUTPUT-STATIONARY formulation over the k-major neighbour table built in coords.hip:
+//   * one wave owns 32 output rows x TN output channels and walks the K kernel offsets; offsets for which none
+//     of its 32 rows has a neighbour are skipped with one wave-wide ballot;
+//   * gathered input rows are fetched as whole 128-byte lines (8 lanes x 16 B per row), staged through a
+//     WAVE-PRIVATE LDS tile and read back as the A fragments of v_mfma_f32_32x32x2_f32 -- no workgroup barrier
+//     anywhere in the main loop, the four waves of a workgroup only share the L1-resident weights;
+//   * weights are pre-packed (gcl_pack_weights) into B-fragment order so that every wave-instruction reads
+//     1 KiB of contiguous L2-resident data (k index of the MFMA is re-mapped so that A and B fragments are
+//     float4 reads);
+//   * accumulation in registers, one plain store per output element: no atomics, bitwise reproducible.
+// The weight gradient runs over the compacted per-offset pair lists (exact sparse work) with per-wave partial
+// slabs and an ordered reduction (deterministic).
+#include "common.h"
+
+namespace gcl {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define WAVE_FENCE()                                              \
+  do {                                                            \
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");        \
+    __builtin_amdgcn_wave_barrier();                              \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------------
+// weight packing:  wp[(((k*TNB + nb)*Q + q)*2 + h)*32 + j][e] = W_eff[k][8q + 4h + e][32 nb + j]
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_pack_weights(const float* __restrict__ w, int K, int cin, int cout, int mode, float* wp) {
+  long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long total = (long long)K * cin * cout;
+  if (o >= total) return;
+  int cin_e = mode == 0 ? cin : cout;
+  int cout_e = mode == 0 ? cout : cin;
+  int Q = cin_e / 8, TNB = cout_e / 32;
+  int e = (int)(o & 3);
+  int l = (int)((o >> 2) & 63);
+  int h = l >> 5, j = l & 31;
+  long long rest = o >> 8;
+  int q = (int)(rest % Q);
+  int nb = (int)((rest / Q) % TNB);
+  int k = (int)(rest / ((long long)Q * TNB));
+  int c = 8 * q + 4 * h + e;   // effective input channel
+  int n = 32 * nb + j;         // effective output channel
+  float v;
+  if (mode == 0) {
+    v = w[((long long)k * cin + c) * cout + n];
+  } else {
+    int ks = (mode == 2) ? (K - 1 - k) : k;
+    v = w[((long long)ks * cin + n) * cout + c];
+  }
+  wp[o] = v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// forward / input-gradient
+// ---------------------------------------------------------------------------------------------------
+constexpr int CONV_ROWS = 128;   // output rows per workgroup (4 waves x 32)
+constexpr int LDS_STRIDE = 36;   // 32 floats + 4 pad: conflict-free ds_read_b128 (MI355X_MICROARCH LDS table)
+
+template <int NB>  // 32-column blocks per wave
+__global__ void __launch_bounds__(256) k_conv_fwd(const float* __restrict__ X, const float4* __restrict__ Wp,
+                                                  const int* __restrict__ tbl, long long n_out, int K, int cin,
+                                                  int cout, const float* __restrict__ bias,
+                                                  float* __restrict__ Y) {
+  __shared__ __attribute__((aligned(16))) float lds[4][32][LDS_STRIDE];
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = l & 31, h = l >> 5;
+  const long long row0 = (long long)blockIdx.x * CONV_ROWS + w * 32;
+  if (row0 >= n_out) return;   // whole wave out of range (no barriers below)
+  const int nb0 = blockIdx.y * NB;
+  const int TNB = cout >> 5, Q = cin >> 3, CC = cin >> 5;
+  const int p = l & 7, rsub = l >> 3;
+
+  f32x16 acc[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+
+  const bool row_ok = (l < 32) && (row0 + l < n_out);
+  for (int k = 0; k < K; ++k) {
+    int idx = -1;
+    if (row_ok) idx = tbl ? tbl[(long long)k * n_out + row0 + l] : (int)(row0 + l);
+    if (__ballot(idx >= 0) == 0ull) continue;
+    for (int cc = 0; cc < CC; ++cc) {
+      float4 st[4];
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        int ridx = __shfl(idx, rsub + 8 * ps);
+        st[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ridx >= 0) st[ps] = *reinterpret_cast<const float4*>(X + (long long)ridx * cin + cc * 32 + p * 4);
+      }
+      WAVE_FENCE();   // previous iteration's fragment reads are done before the tile is overwritten
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps)
+        *reinterpret_cast<float4*>(&lds[w][rsub + 8 * ps][p * 4]) = st[ps];
+      WAVE_FENCE();
+      float4 a[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const float4*>(&lds[w][i][8 * q + 4 * h]);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const float4* wb = Wp + (((long long)k * TNB + nb0 + b) * Q + cc * 4) * 64 + l;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float4 bv = wb[q * 64];
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, bv.x, acc[b], 0, 0, 0);
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, bv.y, acc[b], 0, 0, 0);
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, bv.z, acc[b], 0, 0, 0);
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, bv.w, acc[b], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // epilogue: acc[b][r] is element (row = (r&3) + 8*(r>>2) + 4*h, col = i) of the 32x32 block
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int col = (nb0 + b) * 32 + i;
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      long long row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (row < n_out) Y[row * cout + col] = acc[b][r] + bv;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// weight gradient over compacted pair lists
+// ---------------------------------------------------------------------------------------------------
+struct SegOffW {
+  long long off[130];
+};
+
+template <int TCA, int TCB>
+__global__ void __launch_bounds__(256) k_conv_bwd_weight(const float* __restrict__ A, const float* __restrict__ B,
+                                                         const int* __restrict__ pair_a,
+                                                         const int* __restrict__ pair_b, SegOffW seg, int K, int ca,
+                                                         int cb, long long n_chunks, int per, float* slabs) {
+  constexpr int NBI = TCA / 32, NBJ = TCB / 32;
+  constexpr int PA = TCA / 4, PB = TCB / 4;         // 16-byte pieces per row
+  constexpr int RA = 64 / PA, RB = 64 / PB;          // rows per load pass
+  __shared__ __attribute__((aligned(16))) float As[4][32][TCA];
+  __shared__ __attribute__((aligned(16))) float Bs[4][32][TCB];
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = l & 31, h = l >> 5;
+  const int tiles_b = cb / TCB;
+  const int ca0 = (blockIdx.y / tiles_b) * TCA, cb0 = (blockIdx.y % tiles_b) * TCB;
+  const long long c0 = (long long)blockIdx.x * per;
+  const long long c1 = (c0 + per < n_chunks) ? c0 + per : n_chunks;
+  if (c0 >= c1) return;
+
+  f32x16 acc[NBI][NBJ];
+#pragma unroll
+  for (int a = 0; a < NBI; ++a)
+#pragma unroll
+    for (int b = 0; b < NBJ; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  auto flush = [&](int k) {
+    float* s = slabs + ((long long)(blockIdx.x + k) * 4 + w) * ((long long)ca * cb);
+#pragma unroll
+    for (int a = 0; a < NBI; ++a)
+#pragma unroll
+      for (int b = 0; b < NBJ; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int row = ca0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          s[(long long)row * cb + cb0 + b * 32 + i] = acc[a][b][r];
+          acc[a][b][r] = 0.f;
+        }
+  };
+
+  int kcur = 0;
+  while (seg.off[kcur + 1] <= c0 * GCL_PAIR_CHUNK) ++kcur;
+  for (long long c = c0; c < c1; ++c) {
+    const long long pbase = c * GCL_PAIR_CHUNK;
+    if (pbase >= seg.off[kcur + 1]) {
+      flush(kcur);
+      while (seg.off[kcur + 1] <= pbase) ++kcur;
+    }
+    const long long p0 = pbase + w * 32;
+    int ia = -1, ib = -1;
+    if (l < 32) {
+      ia = pair_a[p0 + l];
+      ib = pair_b[p0 + l];
+    }
+    WAVE_FENCE();
+#pragma unroll
+    for (int ps = 0; ps < 32 / RA; ++ps) {
+      int r = l / PA + RA * ps;
+      int ridx = __shfl(ia, r);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ridx >= 0) v = *reinterpret_cast<const float4*>(A + (long long)ridx * ca + ca0 + (l % PA) * 4);
+      *reinterpret_cast<float4*>(&As[w][r][(l % PA) * 4]) = v;
+    }
+#pragma unroll
+    for (int ps = 0; ps < 32 / RB; ++ps) {
+      int r = l / PB + RB * ps;
+      int ridx = __shfl(ib, r);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ridx >= 0) v = *reinterpret_cast<const float4*>(B + (long long)ridx * cb + cb0 + (l % PB) * 4);
+      *reinterpret_cast<float4*>(&Bs[w][r][(l % PB) * 4]) = v;
+    }
+    WAVE_FENCE();
+#pragma unroll 4
+    for (int s = 0; s < 16; ++s) {
+      float av[NBI], bv[NBJ];
+#pragma unroll
+      for (int a = 0; a < NBI; ++a) av[a] = As[w][2 * s + h][a * 32 + i];
+#pragma unroll
+      for (int b = 0; b < NBJ; ++b) bv[b] = Bs[w][2 * s + h][b * 32 + i];
+#pragma unroll
+      for (int a = 0; a < NBI; ++a)
+#pragma unroll
+        for (int b = 0; b < NBJ; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
+  }
+  flush(kcur);
+}
+
+__global__ void __launch_bounds__(256) k_bwd_weight_reduce(const float* __restrict__ slabs, SegOffW seg, int per,
+                                                           long long mat, float* dw) {
+  const int k = blockIdx.y;
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= mat) return;
+  float s = 0.f;
+  if (seg.off[k + 1] > seg.off[k]) {
+    long long first = seg.off[k] / GCL_PAIR_CHUNK, last = seg.off[k + 1] / GCL_PAIR_CHUNK - 1;
+    long long lo = first / per, hi = last / per;
+    for (long long bx = lo; bx <= hi; ++bx)
+#pragma unroll
+      for (int w = 0; w < 4; ++w) s += slabs[((bx + k) * 4 + w) * mat + e];
+  }
+  dw[(long long)k * mat + e] = s;
+}
+
+static int bwd_weight_wgs(long long n_chunks) {
+  long long w = n_chunks / 8;
+  if (w < 1) w = 1;
+  if (w > 512) w = 512;
+  return (int)w;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// first layer (Cin <= 4 -> 32): VALU kernels over the neighbour table
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_stem_fwd(const float* __restrict__ x, const float* __restrict__ w,
+                                                  const int* __restrict__ nbr, long long n_out, int K, int cin,
+                                                  float* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];   // [K*cin][32]
+  for (int e = threadIdx.x; e < K * cin * 32; e += blockDim.x) wl[e] = w[e];
+  __syncthreads();
+  long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n_out) return;
+  float acc[32];
+#pragma unroll
+  for (int c = 0; c < 32; ++c) acc[c] = 0.f;
+  for (int k = 0; k < K; ++k) {
+    int idx = nbr[(long long)k * n_out + v];
+    if (idx < 0) continue;
+    for (int ci = 0; ci < cin; ++ci) {
+      float xv = x[(long long)idx * cin + ci];
+      const float4* wr = reinterpret_cast<const float4*>(wl + (k * cin + ci) * 32);
+#pragma unroll
+      for (int c4 = 0; c4 < 8; ++c4) {
+        float4 wv = wr[c4];
+        acc[4 * c4 + 0] = fmaf(xv, wv.x, acc[4 * c4 + 0]);
+        acc[4 * c4 + 1] = fmaf(xv, wv.y, acc[4 * c4 + 1]);
+        acc[4 * c4 + 2] = fmaf(xv, wv.z, acc[4 * c4 + 2]);
+        acc[4 * c4 + 3] = fmaf(xv, wv.w, acc[4 * c4 + 3]);
+      }
+    }
+  }
+  float4* yo = reinterpret_cast<float4*>(y + v * 32);
+#pragma unroll
+  for (int c4 = 0; c4 < 8; ++c4) yo[c4] = make_float4(acc[4 * c4], acc[4 * c4 + 1], acc[4 * c4 + 2], acc[4 * c4 + 3]);
+}
+
+constexpr int STEM_ROWS_PER_WG = 2048;
+constexpr int STEM_KMAX = 125;
+
+// dW[k][ci][c] = sum_v x[nbr[k][v]][ci] * dY[v][c];  thread = (c = t & 31, kg = t >> 5), k = kg + 8 * kk
+__global__ void __launch_bounds__(256) k_stem_bwd_weight(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         const int* __restrict__ nbr, long long n_out, int K,
+                                                         int cin, float* slabs) {
+  __shared__ float dys[64][32];
+  __shared__ float xg[STEM_KMAX][64];
+  const int t = threadIdx.x, c = t & 31, kg = t >> 5;
+  const long long r_begin = (long long)blockIdx.x * STEM_ROWS_PER_WG;
+  long long r_end = r_begin + STEM_ROWS_PER_WG;
+  if (r_end > n_out) r_end = n_out;
+  for (int ci = 0; ci < cin; ++ci) {
+    float acc[16];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) acc[kk] = 0.f;
+    for (long long r0 = r_begin; r0 < r_end; r0 += 64) {
+      __syncthreads();
+      for (int e = t; e < 64 * 32; e += 256) {
+        long long r = r0 + (e >> 5);
+        dys[e >> 5][e & 31] = (r < r_end) ? dy[r * 32 + (e & 31)] : 0.f;
+      }
+      for (int e = t; e < K * 64; e += 256) {
+        int k = e >> 6, rr = e & 63;
+        long long r = r0 + rr;
+        float xv = 0.f;
+        if (r < r_end) {
+          int idx = nbr[(long long)k * n_out + r];
+          if (idx >= 0) xv = x[(long long)idx * cin + ci];
+        }
+        xg[k][rr] = xv;
+      }
+      __syncthreads();
+      for (int rr = 0; rr < 64; ++rr) {
+        float d = dys[rr][c];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+          int k = kg + 8 * kk;
+          if (k < K) acc[kk] = fmaf(xg[k][rr], d, acc[kk]);
+        }
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      int k = kg + 8 * kk;
+      if (k < K) slabs[((long long)blockIdx.x * K * cin + (long long)k * cin + ci) * 32 + c] = acc[kk];
+    }
+  }
+}
+
+__global__ void k_stem_reduce(const float* __restrict__ slabs, int n_slabs, long long mat, float* dw) {
+  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= mat) return;
+  float s = 0.f;
+  for (int b = 0; b < n_slabs; ++b) s += slabs[(long long)b * mat + e];
+  dw[e] = s;
+}
+
+}  // namespace gcl
+
+using namespace gcl;
+
+extern "C" {
+
+int gcl_pack_weights(const float* w, int32_t K, int32_t cin, int32_t cout, int32_t mode, float* wp, void* stream) {
+  GCL_CHECK_ARG(w && wp, "gcl_pack_weights: null pointer");
+  GCL_CHECK_ARG(K >= 1 && cin % 32 == 0 && cout % 32 == 0 && cin > 0 && cout > 0,
+                "gcl_pack_weights: Cin (%d) and Cout (%d) must be positive multiples of 32", cin, cout);
+  GCL_CHECK_ARG(mode >= 0 && mode <= 2, "gcl_pack_weights: mode must be 0, 1 or 2");
+  long long total = (long long)K * cin * cout;
+  hipLaunchKernelGGL(k_pack_weights, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, K, cin,
+                     cout, mode, wp);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int gcl_conv_fwd(const float* x, const float* wp, const int32_t* tbl, int64_t n_out, int32_t K, int32_t cin,
+                 int32_t cout, const float* bias, float* y, void* stream) {
+  GCL_CHECK_ARG(x && wp && y, "gcl_conv_fwd: null pointer");
+  GCL_CHECK_ARG(n_out > 0 && K >= 1, "gcl_conv_fwd: n_out and K must be positive");
+  GCL_CHECK_ARG(tbl || K == 1, "gcl_conv_fwd: a neighbour table is required when K > 1");
+  GCL_CHECK_ARG(cin % 32 == 0 && cout % 32 == 0 && cin > 0 && cout > 0,
+                "gcl_conv_fwd: Cin (%d) and Cout (%d) must be positive multiples of 32", cin, cout);
+  hipStream_t st = (hipStream_t)stream;
+  unsigned gx = (unsigned)cdiv(n_out, CONV_ROWS);
+  if (cout % 64 == 0) {
+    hipLaunchKernelGGL(k_conv_fwd<2>, dim3(gx, cout / 64), dim3(256), 0, st, x, (const float4*)wp, tbl,
+                       (long long)n_out, K, cin, cout, bias, y);
+  } else {
+    hipLaunchKernelGGL(k_conv_fwd<1>, dim3(gx, cout / 32), dim3(256), 0, st, x, (const float4*)wp, tbl,
+                       (long long)n_out, K, cin, cout, bias, y);
+  }
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int64_t gcl_conv_bwd_weight_scratch_len(int32_t K, int32_t ca, int32_t cb, int64_t n_pairs_padded) {
+  long long nc = n_pairs_padded / GCL_PAIR_CHUNK;
+  return (long long)(bwd_weight_wgs(nc) + K) * 4 * ca * cb;
+}
+
+int gcl_conv_bwd_weight(const float* a, const float* b, const int32_t* pair_a, const int32_t* pair_b,
+                        const int64_t* seg_off_host, int32_t K, int32_t ca, int32_t cb, float* scratch, float* dw,
+                        void* stream) {
+  GCL_CHECK_ARG(a && b && pair_a && pair_b && seg_off_host && scratch && dw, "gcl_conv_bwd_weight: null pointer");
+  GCL_CHECK_ARG(K >= 1 && K <= 125, "gcl_conv_bwd_weight: bad K");
+  GCL_CHECK_ARG(ca % 32 == 0 && cb % 32 == 0 && ca > 0 && cb > 0,
+                "gcl_conv_bwd_weight: channel counts (%d, %d) must be positive multiples of 32", ca, cb);
+  hipStream_t st = (hipStream_t)stream;
+  SegOffW seg;
+  for (int k = 0; k <= K; ++k) seg.off[k] = seg_off_host[k];
+  long long nc = seg.off[K] / GCL_PAIR_CHUNK;
+  long long mat = (long long)ca * cb;
+  int W = bwd_weight_wgs(nc);
+  int per = (int)cdiv(nc > 0 ? nc : 1, W);
+  if (nc > 0) {
+    int tca = (ca % 64 == 0) ? 64 : 32, tcb = (cb % 64 == 0) ? 64 : 32;
+    dim3 grid(W, (ca / tca) * (cb / tcb));
+#define LAUNCH_BW(TA, TB)                                                                                       \
+  hipLaunchKernelGGL((k_conv_bwd_weight<TA, TB>), grid, dim3(256), 0, st, a, b, pair_a, pair_b, seg, K, ca, cb, \
+                     nc, per, scratch)
+    if (tca == 64 && tcb == 64) LAUNCH_BW(64, 64);
+    else if (tca == 64) LAUNCH_BW(64, 32);
+    else if (tcb == 64) LAUNCH_BW(32, 64);
+    else LAUNCH_BW(32, 32);
+#undef LAUNCH_BW
+  }
+  hipLaunchKernelGGL(k_bwd_weight_reduce, dim3((unsigned)cdiv(mat, 256), K), dim3(256), 0, st, (const float*)scratch,
+                     seg, per, mat, dw);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int gcl_stem_fwd(const float* x, const float* w, const int32_t* nbr, int64_t n_out, int32_t K, int32_t cin,
+                 int32_t cout, float* y, void* stream) {
+  GCL_CHECK_ARG(x && w && nbr && y, "gcl_stem_fwd: null pointer");
+  GCL_CHECK_ARG(cin >= 1 && cin <= 4 && cout == 32 && K >= 1 && K <= STEM_KMAX && n_out > 0,
+                "gcl_stem_fwd: supports Cin <= 4, Cout == 32, K <= 125 (got %d, %d, %d)", cin, cout, K);
+  size_t shm = (size_t)K * cin * 32 * sizeof(float);
+  hipLaunchKernelGGL(k_stem_fwd, dim3((unsigned)cdiv(n_out, 256)), dim3(256), shm, (hipStream_t)stream, x, w, nbr,
+                     (long long)n_out, K, cin, y);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int64_t gcl_stem_bwd_weight_scratch_len(int32_t K, int32_t cin, int32_t cout, int64_t n_out) {
+  return cdiv(n_out, STEM_ROWS_PER_WG) * (long long)K * cin * cout;
+}
+
+int gcl_stem_bwd_weight(const float* x, const float* dy, const int32_t* nbr, int64_t n_out, int32_t K, int32_t cin,
+                        int32_t cout, float* scratch, float* dw, void* stream) {
+  GCL_CHECK_ARG(x && dy && nbr && scratch && dw, "gcl_stem_bwd_weight: null pointer");
+  GCL_CHECK_ARG(cin >= 1 && cin <= 4 && cout == 32 && K >= 1 && K <= STEM_KMAX && n_out > 0,
+                "gcl_stem_bwd_weight: supports Cin <= 4, Cout == 32, K <= 125 (got %d, %d, %d)", cin, cout, K);
+  hipStream_t st = (hipStream_t)stream;
+  int nwg = (int)cdiv(n_out, STEM_ROWS_PER_WG);
+  long long mat = (long long)K * cin * 32;
+  hipLaunchKernelGGL(k_stem_bwd_weight, dim3(nwg), dim3(256), 0, st, x, dy, nbr, (long long)n_out, K, cin, scratch);
+  hipLaunchKernelGGL(k_stem_reduce, dim3((unsigned)cdiv(mat, 256)), dim3(256), 0, st, (const float*)scratch, nwg, mat,
+                     dw);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,372 @@
+// Coordinate maps, strided maps and kernel maps (integer work, bit-exact, deterministic).
+//
+// Replaces MinkowskiEngine's coordinate manager (hash-map insert -> stride map -> kernel map) for the calls
+// the reference makes through ME.SparseTensor / ME.MinkowskiConvolution.
+// Design for gfx950: one 16-byte slot per key (single aligned access per probe, the table of a 0.5 M voxel
+// batch is ~16 MB and lives in L2 / Infinity Cache); output row order is by FIRST OCCURRENCE (atomicMin of the
+// row id + flag + prefix sum), so it does not depend on insertion timing; neighbour tables are k-major
+// [K][N_out] so that every later gather reads its indices fully coalesced; per-offset pair lists are compacted
+// with wave ballots + block prefix sums (no atomics on the data path => deterministic).
+#include "common.h"
+
+#include <limits.h>
+
+namespace gcl {
+
+thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_table_fill(Slot* t, long long cap) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cap) {
+    t[i].key = EMPTY_KEY;
+    t[i].val = LLONG_MAX;
+  }
+}
+
+__global__ void k_coords_insert(const int4* __restrict__ coords, long long n, Slot* t, long long cap,
+                                int* status) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int4 c = coords[i];
+  if (!pack_ok(c.x, c.y, c.z, c.w)) {
+    atomicAdd(&status[0], 1);
+    return;
+  }
+  unsigned long long key = pack_key(c.x, c.y, c.z, c.w);
+  long long s = (long long)(mix64(key) & (unsigned long long)(cap - 1));
+  while (true) {
+    unsigned long long prev = atomicCAS(&t[s].key, EMPTY_KEY, key);
+    if (prev == EMPTY_KEY) break;
+    if (prev == key) {
+      atomicAdd(&status[1], 1);
+      break;
+    }
+    s = (s + 1) & (cap - 1);
+  }
+  atomicMin(&t[s].val, i);
+}
+
+__device__ __forceinline__ int floor_div(int a, int b) {
+  int q = a / b;
+  return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q;
+}
+
+__global__ void k_stride_insert(const int4* __restrict__ coords, long long n, int t_out, Slot* t, long long cap,
+                                int* status) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int4 c = coords[i];
+  c.y = floor_div(c.y, t_out) * t_out;
+  c.z = floor_div(c.z, t_out) * t_out;
+  c.w = floor_div(c.w, t_out) * t_out;
+  if (!pack_ok(c.x, c.y, c.z, c.w)) {
+    atomicAdd(&status[0], 1);
+    return;
+  }
+  long long s = table_insert(t, cap, pack_key(c.x, c.y, c.z, c.w));
+  atomicMin(&t[s].val, i);
+}
+
+__global__ void k_stride_flag(const int4* __restrict__ coords, long long n, int t_out, const Slot* t,
+                              long long cap, int* flag) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int4 c = coords[i];
+  c.y = floor_div(c.y, t_out) * t_out;
+  c.z = floor_div(c.z, t_out) * t_out;
+  c.w = floor_div(c.w, t_out) * t_out;
+  int f = 0;
+  if (pack_ok(c.x, c.y, c.z, c.w)) {
+    long long s = table_find(t, cap, pack_key(c.x, c.y, c.z, c.w));
+    f = (s >= 0 && t[s].val == i) ? 1 : 0;
+  }
+  flag[i] = f;
+}
+
+__global__ void k_stride_emit(const int4* __restrict__ coords, long long n, int t_out, Slot* t, long long cap,
+                              const int* __restrict__ flag, const int* __restrict__ pos, int4* coords_out,
+                              int* n_out) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (i == n - 1) *n_out = pos[i] + flag[i];
+  if (!flag[i]) return;
+  int4 c = coords[i];
+  c.y = floor_div(c.y, t_out) * t_out;
+  c.z = floor_div(c.z, t_out) * t_out;
+  c.w = floor_div(c.w, t_out) * t_out;
+  long long s = table_find(t, cap, pack_key(c.x, c.y, c.z, c.w));
+  t[s].val = pos[i];
+  coords_out[pos[i]] = c;
+}
+
+// ---- device-wide exclusive scan of int32 (3 launches) -----------------------------------------------
+constexpr int SCAN_T = 256;
+constexpr int SCAN_I = 8;
+constexpr int SCAN_B = SCAN_T * SCAN_I;
+
+// exclusive scan of one value per thread across the workgroup; returns the exclusive prefix, total in *tot
+__device__ __forceinline__ int block_excl_scan(int v, int* lds /*[5]*/, int* tot) {
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int y = __shfl_up(inc, o);
+    if (lane >= o) inc += y;
+  }
+  if (lane == 63) lds[w] = inc;
+  __syncthreads();
+  int base = 0, total = 0;
+  for (int j = 0; j < (int)(blockDim.x >> 6); ++j) {
+    int s = lds[j];
+    if (j < w) base += s;
+    total += s;
+  }
+  __syncthreads();
+  *tot = total;
+  return base + inc - v;
+}
+
+__global__ void __launch_bounds__(SCAN_T) k_scan_reduce(const int* __restrict__ in, long long n, int* bs) {
+  __shared__ int lds[8];
+  long long base = (long long)blockIdx.x * SCAN_B + threadIdx.x * SCAN_I;
+  int s = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_I; ++j)
+    if (base + j < n) s += in[base + j];
+  int tot;
+  block_excl_scan(s, lds, &tot);
+  if (threadIdx.x == 0) bs[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(SCAN_T) k_scan_blocksums(int* bs, long long nb) {
+  __shared__ int lds[8];
+  int carry = 0;
+  for (long long c = 0; c < nb; c += SCAN_T) {
+    long long i = c + threadIdx.x;
+    int v = (i < nb) ? bs[i] : 0;
+    int tot;
+    int ex = block_excl_scan(v, lds, &tot);
+    if (i < nb) bs[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) bs[nb] = carry;
+}
+
+__global__ void __launch_bounds__(SCAN_T) k_scan_final(const int* __restrict__ in, long long n,
+                                                       const int* __restrict__ bs, int* out) {
+  __shared__ int lds[8];
+  long long base = (long long)blockIdx.x * SCAN_B + threadIdx.x * SCAN_I;
+  int v[SCAN_I];
+  int s = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_I; ++j) {
+    v[j] = (base + j < n) ? in[base + j] : 0;
+    s += v[j];
+  }
+  int tot;
+  int ex = block_excl_scan(s, lds, &tot) + bs[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < SCAN_I; ++j) {
+    if (base + j < n) out[base + j] = ex;
+    ex += v[j];
+  }
+}
+
+static int device_scan(const int* in, long long n, int* out, int* bs, hipStream_t st) {
+  long long nb = cdiv(n, SCAN_B);
+  hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_T), 0, st, in, n, bs);
+  hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(SCAN_T), 0, st, bs, nb);
+  hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(SCAN_T), 0, st, in, n, (const int*)bs, out);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+// ---- kernel map ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_kernel_map(const int4* __restrict__ coords_out, long long n_out,
+                                                    const Slot* __restrict__ t, long long cap, int ks, int step,
+                                                    int* __restrict__ nbr, int* __restrict__ nbr_t,
+                                                    long long n_in, int* counts) {
+  long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  int k = blockIdx.y;
+  int r = ks / 2;
+  int ox = (k % ks - r) * step, oy = ((k / ks) % ks - r) * step, oz = (k / (ks * ks) - r) * step;
+  int u = -1;
+  if (v < n_out) {
+    int4 c = coords_out[v];
+    int x = c.y + ox, y = c.z + oy, z = c.w + oz;
+    if (pack_ok(c.x, x, y, z)) {
+      long long s = table_find(t, cap, pack_key(c.x, x, y, z));
+      if (s >= 0) u = (int)t[s].val;
+    }
+    nbr[(long long)k * n_out + v] = u;
+    if (nbr_t != nullptr && u >= 0) nbr_t[(long long)k * n_in + u] = (int)v;
+  }
+  unsigned long long m = __ballot(u >= 0);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&counts[k], __popcll(m));
+}
+
+struct SegOff {
+  long long off[130];
+};
+
+constexpr int PAIR_B = 1024;  // out rows per compaction block (256 threads x 4)
+
+__global__ void __launch_bounds__(256) k_pairs_count(const int* __restrict__ nbr, long long n_out, int nb,
+                                                     int* bc) {
+  __shared__ int lds[8];
+  int k = blockIdx.y;
+  long long base = (long long)blockIdx.x * PAIR_B + threadIdx.x * 4;
+  int s = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (base + j < n_out) s += (nbr[(long long)k * n_out + base + j] >= 0);
+  int tot;
+  block_excl_scan(s, lds, &tot);
+  if (threadIdx.x == 0) bc[(long long)k * nb + blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(256) k_pairs_scan(int* bc, int nb) {
+  __shared__ int lds[8];
+  int* row = bc + (long long)blockIdx.x * nb;
+  int carry = 0;
+  for (int c = 0; c < nb; c += 256) {
+    int i = c + threadIdx.x;
+    int v = (i < nb) ? row[i] : 0;
+    int tot;
+    int ex = block_excl_scan(v, lds, &tot);
+    if (i < nb) row[i] = carry + ex;
+    carry += tot;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_pairs_emit(const int* __restrict__ nbr, long long n_out, int nb,
+                                                    const int* __restrict__ bc, SegOff seg, int* pair_in,
+                                                    int* pair_out) {
+  __shared__ int lds[8];
+  int k = blockIdx.y;
+  long long base = (long long)blockIdx.x * PAIR_B + threadIdx.x * 4;
+  int u[4];
+  int s = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    u[j] = (base + j < n_out) ? nbr[(long long)k * n_out + base + j] : -1;
+    s += (u[j] >= 0);
+  }
+  int tot;
+  long long p = seg.off[k] + bc[(long long)k * nb + blockIdx.x] + block_excl_scan(s, lds, &tot);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (u[j] >= 0) {
+      pair_in[p] = u[j];
+      pair_out[p] = (int)(base + j);
+      ++p;
+    }
+}
+
+}  // namespace gcl
+
+using namespace gcl;
+
+extern "C" {
+
+const char* gcl_last_error(void) { return g_err; }
+int gcl_version(void) { return 100; }
+int gcl_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return GCL_ERR_NO_DEVICE;
+  return n;
+}
+
+static bool is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
+
+int gcl_coords_insert(const int32_t* coords, int64_t n, int64_t* table, int64_t cap, int32_t* status,
+                      void* stream) {
+  GCL_CHECK_ARG(coords && table && status, "gcl_coords_insert: null pointer");
+  GCL_CHECK_ARG(is_pow2(cap) && cap >= 2 * n && cap >= 64, "gcl_coords_insert: cap must be a power of two >= 2n");
+  hipStream_t st = (hipStream_t)stream;
+  GCL_CHECK_HIP(hipMemsetAsync(status, 0, 4 * sizeof(int32_t), st));
+  hipLaunchKernelGGL(k_table_fill, dim3((unsigned)cdiv(cap, 256)), dim3(256), 0, st, (Slot*)table, (long long)cap);
+  if (n > 0)
+    hipLaunchKernelGGL(k_coords_insert, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, (const int4*)coords,
+                       (long long)n, (Slot*)table, (long long)cap, status);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int64_t gcl_scan_scratch_len(int64_t n) { return 2 * n + cdiv(n, SCAN_B) + 64; }
+
+int gcl_stride_map(const int32_t* coords_in, int64_t n_in, int32_t t_out, int64_t* table_out, int64_t cap_out,
+                   int32_t* scratch, int32_t* coords_out, int32_t* n_out_dev, int32_t* status, void* stream) {
+  GCL_CHECK_ARG(coords_in && table_out && scratch && coords_out && n_out_dev && status, "gcl_stride_map: null pointer");
+  GCL_CHECK_ARG(n_in > 0 && t_out >= 1, "gcl_stride_map: n_in and t_out must be positive");
+  GCL_CHECK_ARG(is_pow2(cap_out) && cap_out >= 2 * n_in && cap_out >= 64, "gcl_stride_map: cap must be a power of two >= 2n");
+  hipStream_t st = (hipStream_t)stream;
+  int* flag = scratch;
+  int* pos = scratch + n_in;
+  int* bs = scratch + 2 * n_in;
+  unsigned g = (unsigned)cdiv(n_in, 256);
+  GCL_CHECK_HIP(hipMemsetAsync(status, 0, 4 * sizeof(int32_t), st));
+  hipLaunchKernelGGL(k_table_fill, dim3((unsigned)cdiv(cap_out, 256)), dim3(256), 0, st, (Slot*)table_out,
+                     (long long)cap_out);
+  hipLaunchKernelGGL(k_stride_insert, dim3(g), dim3(256), 0, st, (const int4*)coords_in, (long long)n_in, t_out,
+                     (Slot*)table_out, (long long)cap_out, status);
+  hipLaunchKernelGGL(k_stride_flag, dim3(g), dim3(256), 0, st, (const int4*)coords_in, (long long)n_in, t_out,
+                     (const Slot*)table_out, (long long)cap_out, flag);
+  GCL_CHECK_LAUNCH();
+  int rc = device_scan(flag, n_in, pos, bs, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_stride_emit, dim3(g), dim3(256), 0, st, (const int4*)coords_in, (long long)n_in, t_out,
+                     (Slot*)table_out, (long long)cap_out, (const int*)flag, (const int*)pos, (int4*)coords_out,
+                     n_out_dev);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int gcl_kernel_map(const int32_t* coords_out, int64_t n_out, const int64_t* table_in, int64_t cap_in, int32_t ks,
+                   int32_t step, int32_t* nbr, int32_t* nbr_t, int64_t n_in, int32_t* counts, void* stream) {
+  GCL_CHECK_ARG(coords_out && table_in && nbr && counts, "gcl_kernel_map: null pointer");
+  GCL_CHECK_ARG(ks >= 1 && (ks & 1) && ks <= 5, "gcl_kernel_map: kernel size must be 1, 3 or 5");
+  GCL_CHECK_ARG(n_out > 0 && step >= 1 && is_pow2(cap_in), "gcl_kernel_map: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  int K = ks * ks * ks;
+  GCL_CHECK_HIP(hipMemsetAsync(counts, 0, K * sizeof(int32_t), st));
+  if (nbr_t) GCL_CHECK_HIP(hipMemsetAsync(nbr_t, 0xFF, (size_t)K * n_in * sizeof(int32_t), st));
+  hipLaunchKernelGGL(k_kernel_map, dim3((unsigned)cdiv(n_out, 256), K), dim3(256), 0, st, (const int4*)coords_out,
+                     (long long)n_out, (const Slot*)table_in, (long long)cap_in, ks, step, nbr, nbr_t,
+                     (long long)n_in, counts);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int gcl_kernel_map_pairs(const int32_t* nbr, int32_t K, int64_t n_out, const int64_t* seg_off_host, int32_t* scratch,
+                         int32_t* pair_in, int32_t* pair_out, void* stream) {
+  GCL_CHECK_ARG(nbr && seg_off_host && scratch && pair_in && pair_out, "gcl_kernel_map_pairs: null pointer");
+  GCL_CHECK_ARG(K >= 1 && K <= 125 && n_out > 0, "gcl_kernel_map_pairs: bad K / n_out");
+  hipStream_t st = (hipStream_t)stream;
+  SegOff seg;
+  for (int k = 0; k <= K; ++k) {
+    seg.off[k] = seg_off_host[k];
+    GCL_CHECK_ARG(seg.off[k] % GCL_PAIR_CHUNK == 0, "gcl_kernel_map_pairs: segment offsets must be multiples of %d",
+                  GCL_PAIR_CHUNK);
+  }
+  int nb = (int)cdiv(n_out, PAIR_B);
+  if (seg.off[K] > 0) {
+    GCL_CHECK_HIP(hipMemsetAsync(pair_in, 0xFF, (size_t)seg.off[K] * sizeof(int32_t), st));
+    GCL_CHECK_HIP(hipMemsetAsync(pair_out, 0xFF, (size_t)seg.off[K] * sizeof(int32_t), st));
+  }
+  hipLaunchKernelGGL(k_pairs_count, dim3(nb, K), dim3(256), 0, st, nbr, (long long)n_out, nb, scratch);
+  hipLaunchKernelGGL(k_pairs_scan, dim3(K), dim3(256), 0, st, scratch, nb);
+  hipLaunchKernelGGL(k_pairs_emit, dim3(nb, K), dim3(256), 0, st, nbr, (long long)n_out, nb, (const int*)scratch, seg,
+                     pair_in, pair_out);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+}  // extern "C"

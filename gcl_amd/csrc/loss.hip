@@ -1,0 +1,344 @@
+// GCL group-wise contrastive loss kernels and feature-space 1-NN (fp32).
+//
+// Reference: lib/colocation_trainer.py:430-535 (finest_contrastive_loss, square_loss path), lib/metrics.py:22-29
+// (pdist), lib/eval.py:18-48 (find_nn_gpu).  The reference runs a Python loop of <=1024 groups x ~8 micro
+// launches, materialises an [M, M, C] broadcast tensor for pdist and returns to the host for the positive-pair
+// mask; here each selected group is one wavefront (lane = channel), the pairwise distance + row minimum never
+// leaves registers/LDS, and the positive-pair mask is evaluated on the device from (index, group) directly.
+#include "common.h"
+
+#include <limits.h>
+#include <math.h>
+
+namespace gcl {
+
+// ---- positive / finest loss: one wave per selected group, lane = channel ------------------------------
+__device__ __forceinline__ void group_stats(const float* __restrict__ f, int c, const long long* __restrict__ index,
+                                            const unsigned char* __restrict__ flag, long long b, long long e,
+                                            int lane, float& mean, float& ft, long long& tpos) {
+  float s = 0.f;
+  tpos = -1;
+  for (long long j = b; j < e; ++j) {
+    long long row = index[j];
+    if (lane < c) s += f[row * c + lane];
+    if (tpos < 0 && flag[j]) tpos = j;
+  }
+  mean = s / (float)(e - b);
+  if (tpos < 0) tpos = b;   // malformed input (no flag): fall back to the first member
+  ft = (lane < c) ? f[index[tpos] * c + lane] : 0.f;
+}
+
+__global__ void __launch_bounds__(64) k_group_loss_fwd(const float* __restrict__ f, int c,
+                                                       const long long* __restrict__ index,
+                                                       const long long* __restrict__ goff,
+                                                       const unsigned char* __restrict__ flag,
+                                                       const long long* __restrict__ sel, float pos_thresh,
+                                                       float finest_thresh, float* pos, float* fin) {
+  const int lane = threadIdx.x;
+  const long long g = sel[blockIdx.x];
+  const long long b = goff[g], e = goff[g + 1];
+  float mean, ft;
+  long long tpos;
+  group_stats(f, c, index, flag, b, e, lane, mean, ft, tpos);
+  float acc = 0.f;
+  for (long long j = b; j < e; ++j) {
+    float d = (lane < c) ? mean - f[index[j] * c + lane] : 0.f;
+    acc += d * d;
+  }
+  float var = wave_sum(acc) / (float)(e - b);
+  float dt = (lane < c) ? mean - ft : 0.f;
+  float dfin = wave_sum(dt * dt);
+  if (lane == 0) {
+    pos[blockIdx.x] = fmaxf(var - pos_thresh, 0.f);
+    fin[blockIdx.x] = fmaxf(dfin - finest_thresh, 0.f);
+  }
+}
+
+__global__ void __launch_bounds__(64) k_group_loss_bwd(const float* __restrict__ f, int c,
+                                                       const long long* __restrict__ index,
+                                                       const long long* __restrict__ goff,
+                                                       const unsigned char* __restrict__ flag,
+                                                       const long long* __restrict__ sel, float pos_thresh,
+                                                       float finest_thresh, const float* __restrict__ gpos,
+                                                       const float* __restrict__ gfin, float* df) {
+  const int lane = threadIdx.x;
+  const long long g = sel[blockIdx.x];
+  const long long b = goff[g], e = goff[g + 1];
+  const float inv_n = 1.f / (float)(e - b);
+  float mean, ft;
+  long long tpos;
+  group_stats(f, c, index, flag, b, e, lane, mean, ft, tpos);
+  float acc = 0.f;
+  for (long long j = b; j < e; ++j) {
+    float d = (lane < c) ? mean - f[index[j] * c + lane] : 0.f;
+    acc += d * d;
+  }
+  float var = wave_sum(acc) * inv_n;
+  float dt = (lane < c) ? mean - ft : 0.f;
+  float dfin = wave_sum(dt * dt);
+  const float gp = (var - pos_thresh > 0.f) ? gpos[blockIdx.x] : 0.f;
+  const float gf = (dfin - finest_thresh > 0.f) ? gfin[blockIdx.x] : 0.f;
+  if (lane >= c || (gp == 0.f && gf == 0.f)) return;
+  // d/df_j mean_i |m - f_i|^2 = (2/n)(f_j - m);   d/df_j |m - f_t|^2 = (2/n)(m - f_t) - [j == t] 2 (m - f_t)
+  for (long long j = b; j < e; ++j) {
+    long long row = index[j];
+    float fj = f[row * c + lane];
+    float gr = gp * 2.f * inv_n * (fj - mean) + gf * 2.f * inv_n * dt;
+    if (j == tpos) gr -= gf * 2.f * dt;
+    atomicAdd(&df[row * c + lane], gr);
+  }
+}
+
+// ---- pairwise squared distance + row minimum ----------------------------------------------------------
+constexpr int NN_TA = 64;    // A rows per workgroup
+constexpr int NN_TB = 128;   // B rows per LDS tile
+
+template <int C>
+__global__ void __launch_bounds__(256) k_nn_rowmin(const float* __restrict__ a, const long long* __restrict__ rows_a,
+                                                   int ma, const float* __restrict__ b,
+                                                   const long long* __restrict__ rows_b, int mb, int l2,
+                                                   float* dmin, int* argmin) {
+  __shared__ __attribute__((aligned(16))) float bt[NN_TB][C];
+  __shared__ float rv[4][NN_TA];
+  __shared__ int ri[4][NN_TA];
+  const int t = threadIdx.x, ar = t & 63, cg = t >> 6;
+  const int arow = blockIdx.x * NN_TA + ar;
+  float av[C];
+  {
+    long long src = (arow < ma) ? (rows_a ? rows_a[arow] : (long long)arow) : -1;
+#pragma unroll
+    for (int q = 0; q < C / 4; ++q) {
+      float4 v = make_float4(0, 0, 0, 0);
+      if (src >= 0) v = reinterpret_cast<const float4*>(a + src * C)[q];
+      av[4 * q] = v.x; av[4 * q + 1] = v.y; av[4 * q + 2] = v.z; av[4 * q + 3] = v.w;
+    }
+  }
+  float best = INFINITY;
+  int besti = 0;
+  for (int j0 = 0; j0 < mb; j0 += NN_TB) {
+    __syncthreads();
+    for (int e = t; e < NN_TB * (C / 4); e += 256) {
+      int r = e / (C / 4), q = e % (C / 4);
+      float4 v = make_float4(0, 0, 0, 0);
+      if (j0 + r < mb) {
+        long long src = rows_b ? rows_b[j0 + r] : (long long)(j0 + r);
+        v = reinterpret_cast<const float4*>(b + src * C)[q];
+      }
+      reinterpret_cast<float4*>(&bt[r][0])[q] = v;
+    }
+    __syncthreads();
+    int jn = (mb - j0 < NN_TB) ? mb - j0 : NN_TB;
+    for (int r = cg; r < jn; r += 4) {
+      float d2 = 0.f;
+#pragma unroll
+      for (int q = 0; q < C / 4; ++q) {
+        float4 v = reinterpret_cast<const float4*>(&bt[r][0])[q];
+        float d0 = av[4 * q] - v.x, d1 = av[4 * q + 1] - v.y, d2a = av[4 * q + 2] - v.z, d3 = av[4 * q + 3] - v.w;
+        d2 += d0 * d0;
+        d2 += d1 * d1;
+        d2 += d2a * d2a;
+        d2 += d3 * d3;
+      }
+      if (d2 < best) {   // strict: ascending j within a thread keeps the lowest index on ties
+        best = d2;
+        besti = j0 + r;
+      }
+    }
+  }
+  rv[cg][ar] = best;
+  ri[cg][ar] = besti;
+  __syncthreads();
+  if (cg == 0 && arow < ma) {
+    float bv = rv[0][ar];
+    int bi = ri[0][ar];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      float v = rv[w][ar];
+      int i2 = ri[w][ar];
+      if (v < bv || (v == bv && i2 < bi)) {
+        bv = v;
+        bi = i2;
+      }
+    }
+    dmin[arow] = l2 ? sqrtf(bv + 1e-7f) : bv;
+    argmin[arow] = bi;
+  }
+}
+
+// ---- negative-pair mask ---------------------------------------------------------------------------------
+__global__ void k_table_fill2(Slot* t, long long cap) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cap) {
+    t[i].key = EMPTY_KEY;
+    t[i].val = LLONG_MAX;
+  }
+}
+
+__global__ void k_neg_mask_init(const long long* __restrict__ sel1, const long long* __restrict__ sel2,
+                                const int* __restrict__ arg, int m, Slot* t, long long cap, unsigned char* keep) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= m) return;
+  long long a = sel1[r], bb = sel2[arg[r]];
+  keep[r] = (a != bb) ? 1 : 0;
+  long long s = table_insert(t, cap, (unsigned long long)a);
+  atomicMin(&t[s].val, (long long)r);   // sel1 is drawn without replacement; duplicates would keep the lowest r
+}
+
+__global__ void k_neg_mask_scan(const long long* __restrict__ sel1, const long long* __restrict__ sel2,
+                                const int* __restrict__ arg, const long long* __restrict__ index,
+                                const long long* __restrict__ goff, long long n_groups, long long n_index,
+                                const Slot* __restrict__ t, long long cap, unsigned char* keep) {
+  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_index) return;
+  long long row = index[e];
+  long long s = table_find(t, cap, (unsigned long long)row);
+  if (s < 0) return;
+  int r = (int)t[s].val;
+  long long target = sel2[arg[r]];
+  // group of entry e: largest g with goff[g] <= e
+  long long lo = 0, hi = n_groups;
+  while (hi - lo > 1) {
+    long long mid = (lo + hi) >> 1;
+    if (goff[mid] <= e) lo = mid; else hi = mid;
+  }
+  for (long long j = goff[lo]; j < goff[lo + 1]; ++j)
+    if (index[j] == target && target != row) {
+      keep[r] = 0;
+      break;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_neg_loss_fwd(const float* __restrict__ dmin,
+                                                      const unsigned char* __restrict__ keep, int m, float thresh,
+                                                      float* out) {
+  __shared__ float ss[256];
+  __shared__ int sc[256];
+  float s = 0.f;
+  int cnt = 0;
+  for (int r = threadIdx.x; r < m; r += 256)
+    if (keep[r]) {
+      float v = fmaxf(thresh - dmin[r], 0.f);
+      s += v * v;
+      ++cnt;
+    }
+  ss[threadIdx.x] = s;
+  sc[threadIdx.x] = cnt;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      ss[threadIdx.x] += ss[threadIdx.x + o];
+      sc[threadIdx.x] += sc[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = ss[0] / (float)sc[0];   // 0/0 = NaN, like torch's mean of an empty tensor
+    out[1] = (float)sc[0];
+  }
+}
+
+__global__ void __launch_bounds__(64) k_neg_loss_bwd(const float* __restrict__ f, int c,
+                                                     const long long* __restrict__ sel1,
+                                                     const long long* __restrict__ sel2,
+                                                     const int* __restrict__ arg, const float* __restrict__ dmin,
+                                                     const unsigned char* __restrict__ keep, float thresh,
+                                                     const float* __restrict__ out, const float* __restrict__ gneg,
+                                                     float* df) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  if (!keep[r] || lane >= c) return;
+  float D = dmin[r];
+  if (!(thresh - D > 0.f)) return;
+  long long ra = sel1[r], rb = sel2[arg[r]];
+  float coef = gneg[0] * (-2.f * (thresh - D) / out[1]) / D;   // dL/dD * dD/d(d2) * 2 == ... * (a - b) / D
+  float diff = f[ra * c + lane] - f[rb * c + lane];
+  atomicAdd(&df[ra * c + lane], coef * diff);
+  atomicAdd(&df[rb * c + lane], -coef * diff);
+}
+
+}  // namespace gcl
+
+using namespace gcl;
+
+extern "C" {
+
+int gcl_group_loss_fwd(const float* f, int32_t c, const int64_t* index, const int64_t* goff,
+                       const uint8_t* finest_flag, const int64_t* sel, int32_t n_sel, float pos_thresh,
+                       float finest_thresh, float* pos, float* fin, void* stream) {
+  GCL_CHECK_ARG(f && index && goff && finest_flag && sel && pos && fin, "gcl_group_loss_fwd: null pointer");
+  GCL_CHECK_ARG(c >= 1 && c <= 64, "gcl_group_loss_fwd: feature width must be <= 64 (got %d)", c);
+  if (n_sel <= 0) return GCL_OK;
+  hipLaunchKernelGGL(k_group_loss_fwd, dim3(n_sel), dim3(64), 0, (hipStream_t)stream, f, c, (const long long*)index,
+                     (const long long*)goff, finest_flag, (const long long*)sel, pos_thresh, finest_thresh, pos, fin);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int gcl_group_loss_bwd(const float* f, int32_t c, const int64_t* index, const int64_t* goff,
+                       const uint8_t* finest_flag, const int64_t* sel, int32_t n_sel, float pos_thresh,
+                       float finest_thresh, const float* gpos, const float* gfin, float* df, void* stream) {
+  GCL_CHECK_ARG(f && index && goff && finest_flag && sel && gpos && gfin && df, "gcl_group_loss_bwd: null pointer");
+  GCL_CHECK_ARG(c >= 1 && c <= 64, "gcl_group_loss_bwd: feature width must be <= 64 (got %d)", c);
+  if (n_sel <= 0) return GCL_OK;
+  hipLaunchKernelGGL(k_group_loss_bwd, dim3(n_sel), dim3(64), 0, (hipStream_t)stream, f, c, (const long long*)index,
+                     (const long long*)goff, finest_flag, (const long long*)sel, pos_thresh, finest_thresh, gpos, gfin,
+                     df);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int gcl_nn_rowmin(const float* a, const int64_t* rows_a, int32_t ma, const float* b, const int64_t* rows_b,
+                  int32_t mb, int32_t c, int32_t l2, float* dmin, int32_t* argmin, void* stream) {
+  GCL_CHECK_ARG(a && b && dmin && argmin, "gcl_nn_rowmin: null pointer");
+  GCL_CHECK_ARG(ma > 0 && mb > 0, "gcl_nn_rowmin: empty input");
+  GCL_CHECK_ARG(c == 16 || c == 32 || c == 64, "gcl_nn_rowmin: feature width must be 16, 32 or 64 (got %d)", c);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)cdiv(ma, NN_TA));
+#define LAUNCH_NN(CC)                                                                                     \
+  hipLaunchKernelGGL(k_nn_rowmin<CC>, grid, dim3(256), 0, st, a, (const long long*)rows_a, ma, b,         \
+                     (const long long*)rows_b, mb, l2, dmin, argmin)
+  if (c == 16) LAUNCH_NN(16);
+  else if (c == 32) LAUNCH_NN(32);
+  else LAUNCH_NN(64);
+#undef LAUNCH_NN
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int gcl_neg_mask(const int64_t* sel1, const int64_t* sel2, const int32_t* arg, int32_t m, const int64_t* index,
+                 const int64_t* goff, int64_t n_groups, int64_t n_index, int64_t* table, int64_t cap, uint8_t* keep,
+                 void* stream) {
+  GCL_CHECK_ARG(sel1 && sel2 && arg && table && keep, "gcl_neg_mask: null pointer");
+  GCL_CHECK_ARG(m > 0 && cap >= 2 * (int64_t)m && (cap & (cap - 1)) == 0, "gcl_neg_mask: cap must be a power of two >= 2m");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_table_fill2, dim3((unsigned)cdiv(cap, 256)), dim3(256), 0, st, (Slot*)table, (long long)cap);
+  hipLaunchKernelGGL(k_neg_mask_init, dim3((unsigned)cdiv(m, 256)), dim3(256), 0, st, (const long long*)sel1,
+                     (const long long*)sel2, arg, m, (Slot*)table, (long long)cap, keep);
+  if (n_index > 0 && n_groups > 0) {
+    GCL_CHECK_ARG(index && goff, "gcl_neg_mask: null index / goff");
+    hipLaunchKernelGGL(k_neg_mask_scan, dim3((unsigned)cdiv(n_index, 256)), dim3(256), 0, st, (const long long*)sel1,
+                       (const long long*)sel2, arg, (const long long*)index, (const long long*)goff,
+                       (long long)n_groups, (long long)n_index, (const Slot*)table, (long long)cap, keep);
+  }
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int gcl_neg_loss_fwd(const float* dmin, const uint8_t* keep, int32_t m, float thresh, float* out, void* stream) {
+  GCL_CHECK_ARG(dmin && keep && out && m > 0, "gcl_neg_loss_fwd: bad argument");
+  hipLaunchKernelGGL(k_neg_loss_fwd, dim3(1), dim3(256), 0, (hipStream_t)stream, dmin, keep, m, thresh, out);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int gcl_neg_loss_bwd(const float* f, int32_t c, const int64_t* sel1, const int64_t* sel2, const int32_t* arg,
+                     const float* dmin, const uint8_t* keep, int32_t m, float thresh, const float* out,
+                     const float* gneg, float* df, void* stream) {
+  GCL_CHECK_ARG(f && sel1 && sel2 && arg && dmin && keep && out && gneg && df && m > 0, "gcl_neg_loss_bwd: bad argument");
+  GCL_CHECK_ARG(c >= 1 && c <= 64, "gcl_neg_loss_bwd: feature width must be <= 64");
+  hipLaunchKernelGGL(k_neg_loss_bwd, dim3(m), dim3(64), 0, (hipStream_t)stream, f, c, (const long long*)sel1,
+                     (const long long*)sel2, arg, dmin, keep, thresh, out, gneg, df);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+}  // extern "C"

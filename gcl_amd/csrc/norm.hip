@@ -1,0 +1,231 @@
+// BatchNorm over the rows of [n, c] fused with BasicBlock's residual add and ReLU (HBM-bound, float4 access).
+//
+// Reference path: model/common.py:4-6 (ME.MinkowskiBatchNorm == BatchNorm1d on the feature matrix),
+// model/residual_block.py:37-53 (norm -> relu, norm -> += residual -> relu).  One statistics pass (double
+// accumulators, per-workgroup partials, ordered finalisation => deterministic) and one apply pass that also
+// performs the residual add / ReLU, instead of the reference's separate BN, add and ReLU launches.
+#include "common.h"
+
+namespace gcl {
+
+constexpr int BN_ROWS_PER_WG = 1024;
+
+// thread t -> channel quad cq = t % (c/4), row lane rl = t / (c/4)
+template <bool BWD>
+__global__ void __launch_bounds__(256) k_bn_reduce(const float* __restrict__ x, const float* __restrict__ dy,
+                                                   const float* __restrict__ y, long long n, int c,
+                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                   int relu, double* partial) {
+  __shared__ double red[2][256][4];
+  const int cq_n = c >> 2;
+  const int cq = threadIdx.x % cq_n, rl = threadIdx.x / cq_n, rstep = 256 / cq_n;
+  const long long r_begin = (long long)blockIdx.x * BN_ROWS_PER_WG;
+  long long r_end = r_begin + BN_ROWS_PER_WG;
+  if (r_end > n) r_end = n;
+  double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+  float4 mu = make_float4(0, 0, 0, 0), rs = make_float4(1, 1, 1, 1);
+  if (BWD) {
+    mu = reinterpret_cast<const float4*>(mean)[cq];
+    rs = reinterpret_cast<const float4*>(rstd)[cq];
+  }
+  for (long long r = r_begin + rl; r < r_end; r += rstep) {
+    float4 xv = reinterpret_cast<const float4*>(x + r * c)[cq];
+    if (!BWD) {
+      s0[0] += xv.x; s0[1] += xv.y; s0[2] += xv.z; s0[3] += xv.w;
+      s1[0] += (double)xv.x * xv.x; s1[1] += (double)xv.y * xv.y;
+      s1[2] += (double)xv.z * xv.z; s1[3] += (double)xv.w * xv.w;
+    } else {
+      float4 g = reinterpret_cast<const float4*>(dy + r * c)[cq];
+      if (relu) {
+        float4 yv = reinterpret_cast<const float4*>(y + r * c)[cq];
+        g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
+        g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+      }
+      s0[0] += g.x; s0[1] += g.y; s0[2] += g.z; s0[3] += g.w;
+      s1[0] += (double)g.x * ((xv.x - mu.x) * rs.x); s1[1] += (double)g.y * ((xv.y - mu.y) * rs.y);
+      s1[2] += (double)g.z * ((xv.z - mu.z) * rs.z); s1[3] += (double)g.w * ((xv.w - mu.w) * rs.w);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    red[0][threadIdx.x][j] = s0[j];
+    red[1][threadIdx.x][j] = s1[j];
+  }
+  __syncthreads();
+  if (rl == 0) {
+    double* out = partial + (long long)blockIdx.x * 2 * c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      double a = 0, b = 0;
+      for (int q = 0; q < rstep; ++q) {
+        a += red[0][q * cq_n + cq][j];
+        b += red[1][q * cq_n + cq][j];
+      }
+      out[cq * 4 + j] = a;
+      out[c + cq * 4 + j] = b;
+    }
+  }
+}
+
+__global__ void k_bn_stats_final(const double* __restrict__ partial, int nwg, long long n, int c, float eps,
+                                 float momentum, float* running_mean, float* running_var, float* mean,
+                                 float* rstd) {
+  int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  double s = 0, ss = 0;
+  for (int b = 0; b < nwg; ++b) {
+    s += partial[(long long)b * 2 * c + ch];
+    ss += partial[(long long)b * 2 * c + c + ch];
+  }
+  double m = s / (double)n;
+  double var = ss / (double)n - m * m;
+  if (var < 0) var = 0;
+  mean[ch] = (float)m;
+  rstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    double unb = (n > 1) ? var * (double)n / (double)(n - 1) : var;
+    running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * m);
+    running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unb);
+  }
+}
+
+__global__ void k_bn_bwd_final(const double* __restrict__ partial, int nwg, int c, float* sum_g, float* sum_gx) {
+  int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  double s = 0, ss = 0;
+  for (int b = 0; b < nwg; ++b) {
+    s += partial[(long long)b * 2 * c + ch];
+    ss += partial[(long long)b * 2 * c + c + ch];
+  }
+  sum_g[ch] = (float)s;
+  sum_gx[ch] = (float)ss;
+}
+
+__global__ void __launch_bounds__(256) k_bn_apply(const float* __restrict__ x, long long total4, int c,
+                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                  const float* __restrict__ weight, const float* __restrict__ bias,
+                                                  const float* __restrict__ residual, int relu,
+                                                  float* __restrict__ y) {
+  const int cq_n = c >> 2;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total4;
+       e += (long long)gridDim.x * blockDim.x) {
+    int cq = (int)(e % cq_n);
+    float4 mu = reinterpret_cast<const float4*>(mean)[cq], rs = reinterpret_cast<const float4*>(rstd)[cq];
+    float4 wv = reinterpret_cast<const float4*>(weight)[cq], bv = reinterpret_cast<const float4*>(bias)[cq];
+    float4 xv = reinterpret_cast<const float4*>(x)[e];
+    float4 o;
+    o.x = (xv.x - mu.x) * rs.x * wv.x + bv.x;
+    o.y = (xv.y - mu.y) * rs.y * wv.y + bv.y;
+    o.z = (xv.z - mu.z) * rs.z * wv.z + bv.z;
+    o.w = (xv.w - mu.w) * rs.w * wv.w + bv.w;
+    if (residual) {
+      float4 rv = reinterpret_cast<const float4*>(residual)[e];
+      o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+    }
+    if (relu) {
+      o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+    }
+    reinterpret_cast<float4*>(y)[e] = o;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_bn_bwd_apply(const float* __restrict__ x, const float* __restrict__ dy,
+                                                      const float* __restrict__ y, long long total4, int c,
+                                                      float inv_n, const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd,
+                                                      const float* __restrict__ weight,
+                                                      const float* __restrict__ sum_g,
+                                                      const float* __restrict__ sum_gx, int relu,
+                                                      float* __restrict__ dx, float* __restrict__ dres) {
+  const int cq_n = c >> 2;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total4;
+       e += (long long)gridDim.x * blockDim.x) {
+    int cq = (int)(e % cq_n);
+    float4 mu = reinterpret_cast<const float4*>(mean)[cq], rs = reinterpret_cast<const float4*>(rstd)[cq];
+    float4 wv = reinterpret_cast<const float4*>(weight)[cq];
+    float4 sg = reinterpret_cast<const float4*>(sum_g)[cq], sx = reinterpret_cast<const float4*>(sum_gx)[cq];
+    float4 xv = reinterpret_cast<const float4*>(x)[e];
+    float4 g = reinterpret_cast<const float4*>(dy)[e];
+    if (relu) {
+      float4 yv = reinterpret_cast<const float4*>(y)[e];
+      g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
+      g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+    }
+    float4 o;
+    o.x = wv.x * rs.x * (g.x - sg.x * inv_n - (xv.x - mu.x) * rs.x * sx.x * inv_n);
+    o.y = wv.y * rs.y * (g.y - sg.y * inv_n - (xv.y - mu.y) * rs.y * sx.y * inv_n);
+    o.z = wv.z * rs.z * (g.z - sg.z * inv_n - (xv.z - mu.z) * rs.z * sx.z * inv_n);
+    o.w = wv.w * rs.w * (g.w - sg.w * inv_n - (xv.w - mu.w) * rs.w * sx.w * inv_n);
+    reinterpret_cast<float4*>(dx)[e] = o;
+    if (dres) reinterpret_cast<float4*>(dres)[e] = g;
+  }
+}
+
+static bool bn_c_ok(int c) { return c >= 4 && c % 4 == 0 && (256 % (c / 4)) == 0; }
+
+}  // namespace gcl
+
+using namespace gcl;
+
+extern "C" {
+
+int64_t gcl_bn_scratch_len(int64_t n, int32_t c) { return cdiv(n, BN_ROWS_PER_WG) * 2 * c; }
+
+int gcl_bn_stats(const float* x, int64_t n, int32_t c, float eps, float momentum, float* running_mean,
+                 float* running_var, double* scratch, float* mean, float* rstd, void* stream) {
+  GCL_CHECK_ARG(x && scratch && mean && rstd, "gcl_bn_stats: null pointer");
+  GCL_CHECK_ARG(n > 0 && bn_c_ok(c), "gcl_bn_stats: unsupported shape n=%lld c=%d (c/4 must divide 256)", (long long)n, c);
+  hipStream_t st = (hipStream_t)stream;
+  int nwg = (int)cdiv(n, BN_ROWS_PER_WG);
+  hipLaunchKernelGGL(k_bn_reduce<false>, dim3(nwg), dim3(256), 0, st, x, (const float*)nullptr,
+                     (const float*)nullptr, (long long)n, c, (const float*)nullptr, (const float*)nullptr, 0, scratch);
+  hipLaunchKernelGGL(k_bn_stats_final, dim3((unsigned)cdiv(c, 64)), dim3(64), 0, st, (const double*)scratch, nwg,
+                     (long long)n, c, eps, momentum, running_mean, running_var, mean, rstd);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int gcl_bn_apply(const float* x, int64_t n, int32_t c, const float* mean, const float* rstd, const float* weight,
+                 const float* bias, const float* residual, int32_t relu, float* y, void* stream) {
+  GCL_CHECK_ARG(x && mean && rstd && weight && bias && y, "gcl_bn_apply: null pointer");
+  GCL_CHECK_ARG(n > 0 && c >= 4 && c % 4 == 0, "gcl_bn_apply: unsupported shape");
+  long long total4 = n * (c / 4);
+  long long g = cdiv(total4, 256);
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(k_bn_apply, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, total4, c, mean, rstd,
+                     weight, bias, residual, relu, y);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int gcl_bn_bwd_reduce(const float* x, const float* dy, const float* y, int64_t n, int32_t c, const float* mean,
+                      const float* rstd, int32_t relu, double* scratch, float* sum_g, float* sum_gx, void* stream) {
+  GCL_CHECK_ARG(x && dy && mean && rstd && scratch && sum_g && sum_gx, "gcl_bn_bwd_reduce: null pointer");
+  GCL_CHECK_ARG(!relu || y, "gcl_bn_bwd_reduce: y is required when relu is set");
+  GCL_CHECK_ARG(n > 0 && bn_c_ok(c), "gcl_bn_bwd_reduce: unsupported shape n=%lld c=%d", (long long)n, c);
+  hipStream_t st = (hipStream_t)stream;
+  int nwg = (int)cdiv(n, BN_ROWS_PER_WG);
+  hipLaunchKernelGGL(k_bn_reduce<true>, dim3(nwg), dim3(256), 0, st, x, dy, y, (long long)n, c, mean, rstd, relu,
+                     scratch);
+  hipLaunchKernelGGL(k_bn_bwd_final, dim3((unsigned)cdiv(c, 64)), dim3(64), 0, st, (const double*)scratch, nwg, c,
+                     sum_g, sum_gx);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int gcl_bn_bwd_apply(const float* x, const float* dy, const float* y, int64_t n, int32_t c, const float* mean,
+                     const float* rstd, const float* weight, const float* sum_g, const float* sum_gx, int32_t relu,
+                     float* dx, float* dres, void* stream) {
+  GCL_CHECK_ARG(x && dy && mean && rstd && weight && sum_g && sum_gx && dx, "gcl_bn_bwd_apply: null pointer");
+  GCL_CHECK_ARG(!relu || y, "gcl_bn_bwd_apply: y is required when relu is set");
+  GCL_CHECK_ARG(n > 0 && c >= 4 && c % 4 == 0, "gcl_bn_bwd_apply: unsupported shape");
+  long long total4 = n * (c / 4);
+  long long g = cdiv(total4, 256);
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, dy, y, total4, c,
+                     1.0f / (float)n, mean, rstd, weight, sum_g, sum_gx, relu, dx, dres);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,79 @@
+"""Data-parallel training over the GPUs of one node: one process per GPU, RCCL (backend "nccl") over xGMI.
+
+The reference is single-GPU; this is the new capability BASELINE.json asks for.  The path shards
+naturally: every rank takes its own samples, builds its own coordinate maps, mines negatives inside its own batch
+(the reference's bs=4 semantics per rank) and keeps its own BatchNorm statistics (the reference has no SyncBN).
+The only exchange is the gradient: all parameters are re-seated as views of ONE flat fp32 buffer, so a step issues
+a single 35 MB all-reduce (xGMI rings are per-link bound: one large collective beats many small buckets) followed
+by a scale by 1/world_size.  Parameters and BN buffers are broadcast from rank 0 once.
+Works with any torch.distributed backend (gloo on CPU in tests/test_ddp_gloo.py).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_indices(n_items, rank, world):
+    """Sample ids of this rank (strided, like DistributedSampler without shuffling)."""
+    return list(range(rank, n_items, world))
+
+
+class FlatDDP:
+    """Flat-buffer gradient all-reduce for a module (no autograd hooks, no per-parameter collectives)."""
+
+    def __init__(self, process_group=None):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.flat_param = self.flat_grad = None
+        self.params = []
+
+    def attach(self, module):
+        params = [p for p in module.parameters() if p.requires_grad]
+        if not params:
+            raise ValueError("module has no trainable parameter")
+        dev, dt = params[0].device, params[0].dtype
+        total = sum(p.numel() for p in params)
+        self.flat_param = torch.empty(total, dtype=dt, device=dev)
+        self.flat_grad = torch.zeros(total, dtype=dt, device=dev)
+        off = 0
+        with torch.no_grad():
+            for p in params:
+                n = p.numel()
+                self.flat_param[off:off + n].copy_(p.reshape(-1))
+                p.data = self.flat_param[off:off + n].view_as(p)
+                p.grad = self.flat_grad[off:off + n].view_as(p)
+                off += n
+        self.params = params
+        if self.world > 1:
+            dist.broadcast(self.flat_param, src=0, group=self.group)
+            for b in module.buffers():
+                dist.broadcast(b, src=0, group=self.group)
+        return self
+
+    def all_reduce_gradients(self):
+        """Average gradients over ranks: ONE collective on the flat buffer (optimizer.zero_grad(set_to_none=False)
+        keeps p.grad seated in it)."""
+        for p in self.params:        # autograd may have replaced .grad if zero_grad(set_to_none=True) was used
+            if p.grad is None or p.grad.data_ptr() < self.flat_grad.data_ptr() or \
+                    p.grad.data_ptr() >= self.flat_grad.data_ptr() + self.flat_grad.numel() * self.flat_grad.element_size():
+                raise RuntimeError("parameter gradient left the flat buffer: call optimizer.zero_grad(set_to_none=False)")
+        if self.world > 1:
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat_grad.div_(self.world)

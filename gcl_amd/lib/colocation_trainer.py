@@ -1,0 +1,186 @@
+"""GCL training step: sparse U-Net forward, group-wise contrastive loss, backward, SGD
+(interface of lib/colocation_trainer.py: AlignmentTrainer :29-174, FinestContrastiveLossTrainer :403-535,
+_train_epoch :811-916).
+
+What differs from the reference, by design:
+* the loss never loops over groups in Python and never returns to the host: one wave per selected group for the
+  positive / finest terms, one fused pdist+row-min kernel and an on-device positive-pair mask for the negatives
+  (csrc/loss.hip).  The three ``np.random.choice`` draws are made on the host in the reference's order (:457,
+  :506-507), so a seeded run selects the same groups / rows.
+* ``index_hash`` is accepted for signature parity but not needed: a pair is masked iff both rows share a positive
+  group, which is what membership of its (collision-free) symmetric key in ``index_hash`` means (:521-529).
+* data-parallel training (absent from the reference) shards samples over ranks and all-reduces one flat gradient
+  buffer (gcl_amd/ddp.py).
+"""
+import types
+
+import numpy as np
+import torch
+from torch.autograd.function import once_differentiable
+
+import gcl_amd.MinkowskiEngine as ME
+from gcl_amd import _lib
+from gcl_amd.model import load_model
+
+# defaults = config.py of the reference overridden by scripts/train_gcl_kitti.sh
+DEFAULT_CONFIG = dict(
+    model="ResUNetBN2C", model_n_out=32, conv1_kernel_size=5, normalize_feature=True, bn_momentum=0.05,
+    optimizer="SGD", lr=0.1, momentum=0.8, weight_decay=1e-4, exp_gamma=0.99,
+    batch_size=4, num_pos_per_batch=256, num_hn_samples_per_batch=256, iter_size=1,
+    pos_thresh=0.1, neg_thresh=1.4, finest_thresh=0.2, pos_weight=1.0, neg_weight=1.0, finest_weight=1.0,
+    square_loss=True, block_finest_gradient=False, use_hard_negative=True, use_pair_group_positive_loss=False,
+    use_group_circle_loss=False, voxel_size=0.3,
+)
+
+
+def make_config(**overrides):
+    cfg = dict(DEFAULT_CONFIG)
+    cfg.update(overrides)
+    return types.SimpleNamespace(**cfg)
+
+
+class _GCLLossFn(torch.autograd.Function):
+    """(pos[s], fin[s], neg) of finest_contrastive_loss for fixed selections; one gradient buffer for all terms."""
+
+    @staticmethod
+    def forward(ctx, F, index, goff, flag, sel, sel1, sel2, pos_thresh, fin_thresh, neg_thresh):
+        lib = _lib.require_gpu()
+        F = F.contiguous()
+        n, c = F.shape
+        dev = F.device
+        n_sel, m = sel.shape[0], sel1.shape[0]
+        pos = torch.empty(n_sel, dtype=torch.float32, device=dev)
+        fin = torch.empty(n_sel, dtype=torch.float32, device=dev)
+        st = _lib.stream()
+        _lib.check(lib.gcl_group_loss_fwd(_lib.ptr(F, torch.float32), c, _lib.ptr(index, torch.int64),
+                                          _lib.ptr(goff, torch.int64), _lib.ptr(flag, torch.uint8),
+                                          _lib.ptr(sel, torch.int64), n_sel, pos_thresh, fin_thresh, _lib.ptr(pos),
+                                          _lib.ptr(fin), st), "gcl_group_loss_fwd")
+        dmin = torch.empty(m, dtype=torch.float32, device=dev)
+        arg = torch.empty(m, dtype=torch.int32, device=dev)
+        _lib.check(lib.gcl_nn_rowmin(_lib.ptr(F), _lib.ptr(sel1, torch.int64), m, _lib.ptr(F),
+                                     _lib.ptr(sel2, torch.int64), m, c, 1, _lib.ptr(dmin), _lib.ptr(arg), st),
+                   "gcl_nn_rowmin")
+        cap = 64
+        while cap < 2 * m:
+            cap *= 2
+        table = torch.empty((cap, 2), dtype=torch.int64, device=dev)
+        keep = torch.empty(m, dtype=torch.uint8, device=dev)
+        _lib.check(lib.gcl_neg_mask(_lib.ptr(sel1), _lib.ptr(sel2), _lib.ptr(arg), m, _lib.ptr(index), _lib.ptr(goff),
+                                    goff.shape[0] - 1, index.shape[0], _lib.ptr(table), cap, _lib.ptr(keep), st),
+                   "gcl_neg_mask")
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+        _lib.check(lib.gcl_neg_loss_fwd(_lib.ptr(dmin), _lib.ptr(keep), m, neg_thresh, _lib.ptr(out), st),
+                   "gcl_neg_loss_fwd")
+        ctx.save_for_backward(F, index, goff, flag, sel, sel1, sel2, dmin, arg, keep, out)
+        ctx.th = (pos_thresh, fin_thresh, neg_thresh)
+        return pos, fin, out[0]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gpos, gfin, gneg):
+        lib = _lib.load()
+        F, index, goff, flag, sel, sel1, sel2, dmin, arg, keep, out = ctx.saved_tensors
+        pos_thresh, fin_thresh, neg_thresh = ctx.th
+        n, c = F.shape
+        st = _lib.stream()
+        dF = torch.zeros_like(F)
+        _lib.check(lib.gcl_group_loss_bwd(_lib.ptr(F), c, _lib.ptr(index), _lib.ptr(goff), _lib.ptr(flag),
+                                          _lib.ptr(sel), sel.shape[0], pos_thresh, fin_thresh,
+                                          _lib.ptr(gpos.contiguous()), _lib.ptr(gfin.contiguous()), _lib.ptr(dF), st),
+                   "gcl_group_loss_bwd")
+        g = gneg.reshape(1).contiguous()
+        _lib.check(lib.gcl_neg_loss_bwd(_lib.ptr(F), c, _lib.ptr(sel1), _lib.ptr(sel2), _lib.ptr(arg), _lib.ptr(dmin),
+                                        _lib.ptr(keep), sel1.shape[0], neg_thresh, _lib.ptr(out), _lib.ptr(g),
+                                        _lib.ptr(dF), st), "gcl_neg_loss_bwd")
+        return (dF,) + (None,) * 9
+
+
+def finest_contrastive_loss(F_out, group, index, index_hash, finest_flag, max_pos_cluster=256, max_hn_samples=2048,
+                            points=None, batch_lengths=None, pos_thresh=0.1, neg_thresh=1.4, finest_thresh=0.2,
+                            draws=None):
+    """(pos_loss, finest_loss, neg_loss) of lib/colocation_trainer.py:430-535 (square_loss, hard negatives).
+
+    ``draws=(pos_sel, sel_hn1, sel_hn2)`` replays recorded selections; otherwise they are drawn from ``np.random``
+    in the reference's order.  ``index_hash``, ``points`` and ``batch_lengths`` are unused (see module docstring).
+    """
+    dev = F_out.device
+    n_out = F_out.shape[0]
+    group = torch.as_tensor(group)
+    n_groups = int(group.shape[0])
+    if draws is None:
+        if n_groups > max_pos_cluster:
+            pos_sel = np.random.choice(n_groups, max_pos_cluster, replace=False)
+        else:
+            pos_sel = np.arange(n_groups)
+        sel_hn1 = np.random.choice(n_out, min(n_out, max_hn_samples), replace=False)
+        sel_hn2 = np.random.choice(n_out, min(n_out, max_hn_samples), replace=False)
+    else:
+        pos_sel, sel_hn1, sel_hn2 = draws
+    if len(pos_sel) == 0:
+        raise ZeroDivisionError("no positive group in the batch")
+    goff = torch.zeros(n_groups + 1, dtype=torch.int64)
+    goff[1:] = torch.cumsum(group.to(torch.int64).cpu(), 0)
+    goff = goff.to(dev, non_blocking=True)
+    index = torch.as_tensor(index).to(dev, torch.int64, non_blocking=True).contiguous()
+    flag = torch.as_tensor(finest_flag).to(dev, non_blocking=True).to(torch.uint8).contiguous()
+    to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64)).to(dev, non_blocking=True)
+    pos, fin, neg = _GCLLossFn.apply(F_out, index, goff, flag, to_dev(pos_sel), to_dev(sel_hn1), to_dev(sel_hn2),
+                                     float(pos_thresh), float(finest_thresh), float(neg_thresh))
+    return pos.sum() / len(pos_sel), fin.sum() / len(pos_sel), neg
+
+
+class FinestContrastiveLossTrainer:
+    """The GCL trainer's hot loop body (``_train_epoch`` :811-916) without the dataset / logging / checkpoint shell."""
+
+    def __init__(self, config=None, model=None, device=None, ddp=None):
+        self.config = config or make_config()
+        cfg = self.config
+        self.device = torch.device(device if device is not None else "cuda:0")
+        if cfg.use_group_circle_loss or not cfg.square_loss or cfg.block_finest_gradient \
+                or cfg.use_pair_group_positive_loss or not cfg.use_hard_negative or cfg.finest_weight == 0:
+            raise NotImplementedError("only the script-selected finest_contrastive_loss configuration is built "
+                                      "(scripts/train_gcl_kitti.sh:96-105)")
+        if model is None:
+            Model = load_model(cfg.model)
+            model = Model(1, cfg.model_n_out, bn_momentum=cfg.bn_momentum, normalize_feature=cfg.normalize_feature,
+                          conv1_kernel_size=cfg.conv1_kernel_size, D=3)
+        self.model = model.to(self.device)
+        self.ddp = ddp
+        if ddp is not None:
+            ddp.attach(self.model)          # flat parameter/gradient buffers + initial broadcast
+        # lib/colocation_trainer.py:73-77: SGD(lr, momentum, weight_decay), dampening left at its default
+        self.optimizer = torch.optim.SGD(self.model.parameters(), lr=cfg.lr, momentum=cfg.momentum,
+                                         weight_decay=cfg.weight_decay)
+        self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, cfg.exp_gamma)
+        self.pos_weight, self.neg_weight, self.finest_weight = cfg.pos_weight, cfg.neg_weight, cfg.finest_weight
+
+    def location_loss(self, F_out, group, index, index_hash, finest_flag, max_pos_cluster, max_hn_samples,
+                      points=None, batch_lengths=None, draws=None):
+        cfg = self.config
+        return finest_contrastive_loss(F_out, group, index, index_hash, finest_flag, max_pos_cluster, max_hn_samples,
+                                       points, batch_lengths, cfg.pos_thresh, cfg.neg_thresh, cfg.finest_thresh, draws)
+
+    def forward_loss(self, input_dict, draws=None):
+        cfg = self.config
+        sinput = ME.SparseTensor(input_dict["sinput_F"].to(self.device, non_blocking=True),
+                                 coordinates=input_dict["sinput_C"].to(self.device, non_blocking=True))
+        F_out = self.model(sinput).F
+        pos, fin, neg = self.location_loss(
+            F_out, input_dict["group"], input_dict["index"], input_dict.get("index_hash"), input_dict["finest_flag"],
+            max_pos_cluster=cfg.num_pos_per_batch * cfg.batch_size,
+            max_hn_samples=cfg.num_hn_samples_per_batch * cfg.batch_size,
+            points=None, batch_lengths=input_dict.get("batch_lengths"), draws=draws)
+        loss = self.pos_weight * pos + self.finest_weight * fin + self.neg_weight * neg
+        return loss, (pos, fin, neg), F_out
+
+    def train_step(self, input_dict, draws=None):
+        """One optimizer step on one batch (iter_size == 1).  Returns device scalars (no host sync here)."""
+        self.model.train()
+        self.optimizer.zero_grad(set_to_none=False)
+        loss, parts, F_out = self.forward_loss(input_dict, draws)
+        loss.backward()
+        if self.ddp is not None:
+            self.ddp.all_reduce_gradients()
+        self.optimizer.step()
+        return loss.detach(), tuple(p.detach() for p in parts), F_out.shape[0]

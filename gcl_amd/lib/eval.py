@@ -1,0 +1,31 @@
+"""Feature-space nearest neighbour + correspondence search (interfaces of lib/eval.py:18-48 and
+scripts/test_kitti.py:29-43 / lib/colocation_trainer.py:381-395)."""
+import numpy as np
+import torch
+
+from gcl_amd.lib.metrics import pdist_min
+
+
+def find_nn_gpu(F0, F1, nn_max_n=-1, return_distance=False, dist_type="SquareL2"):
+    """1-NN of every F0 row in F1.  Returns CPU int64 indices (and CPU [N, 1] distances) like the reference.
+    ``nn_max_n`` (the reference's chunk size against its [n, N, C] temporary) is accepted and irrelevant here:
+    the HIP kernel keeps the running minimum in registers.  Ties resolve to the lowest index."""
+    dmin, arg = pdist_min(F0, F1, dist_type)
+    inds = arg.long().cpu()
+    if return_distance:
+        return inds, dmin.unsqueeze(1).cpu()
+    return inds
+
+
+def find_corr(xyz0, xyz1, F0, F1, subsample_size=-1, nn_max_n=500):
+    """scripts/test_kitti.py:29-43: random subsample (np.random.choice, same call order), kNN, matched points."""
+    subsample = len(F0) > subsample_size
+    if subsample_size > 0 and subsample:
+        N0, N1 = min(len(F0), subsample_size), min(len(F1), subsample_size)
+        inds0 = np.random.choice(len(F0), N0, replace=False)
+        inds1 = np.random.choice(len(F1), N1, replace=False)
+        F0, F1 = F0[torch.from_numpy(inds0).to(F0.device)], F1[torch.from_numpy(inds1).to(F1.device)]
+    nn_inds = find_nn_gpu(F0, F1, nn_max_n=nn_max_n)
+    if subsample_size > 0 and subsample:
+        return xyz0[inds0], xyz1[inds1[nn_inds.numpy()]]
+    return xyz0, xyz1[nn_inds]

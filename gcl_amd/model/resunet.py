@@ -1,0 +1,96 @@
+"""ResUNet2 family -- the sparse 4-level residual U-Net of GCL/FCGF on the MI355X operator surface.
+
+Interface and parameter names follow model/resunet.py (constructor :24-30, forward :173-232, widths :235-266), so a
+``state_dict`` is interchangeable with the reference's.  Layers are generated from the width tables instead of being
+spelled out; BN + ReLU (+ residual) sites use the fused kernels of gcl_amd.MinkowskiEngine.MinkowskiBatchNorm.
+The ``KERNEL_SIZES[0]`` "extra" branch (:48-57, :141-151) and the IN variants are not built (unused by GCL's scripts).
+"""
+import torch
+
+import gcl_amd.MinkowskiEngine as ME
+import gcl_amd.MinkowskiEngine.MinkowskiFunctional as MEF
+from gcl_amd.model.common import get_norm
+from gcl_amd.model.residual_block import get_block
+
+
+class ResUNet2(ME.MinkowskiNetwork):
+    NORM_TYPE = None
+    BLOCK_NORM_TYPE = "BN"
+    CHANNELS = [None, 32, 64, 128, 256]
+    TR_CHANNELS = [None, 32, 64, 64, 128]
+    STRIDES = [1, 2, 2, 2]
+    KERNEL_SIZES = [None, 3, 3, 3]
+    DILATIONS = [1, 1, 1, 1]
+
+    def __init__(self, in_channels=3, out_channels=32, bn_momentum=0.1, normalize_feature=None,
+                 conv1_kernel_size=None, D=3):
+        super().__init__(D)
+        if self.KERNEL_SIZES[0] is not None:
+            raise NotImplementedError("the conv1_extra variants (ResUNetFatBNEXP_V2) are outside the GCL hot path")
+        ch, tr = self.CHANNELS, self.TR_CHANNELS
+        self.normalize_feature = normalize_feature
+
+        def conv(cin, cout, ks, level, transpose=False):
+            cls = ME.MinkowskiConvolutionTranspose if transpose else ME.MinkowskiConvolution
+            return cls(in_channels=cin, out_channels=cout, kernel_size=ks, stride=self.STRIDES[level],
+                       dilation=self.DILATIONS[level], bias=False, dimension=D)
+
+        def norm(c):
+            return get_norm(self.NORM_TYPE, c, bn_momentum=bn_momentum, D=D)
+
+        def block(c):
+            return get_block(self.BLOCK_NORM_TYPE, c, c, bn_momentum=bn_momentum, D=D)
+
+        # encoder: conv{l}, norm{l}, block{l}
+        enc_in = [None, in_channels, ch[1], ch[2], ch[3]]
+        for l in (1, 2, 3, 4):
+            ks = conv1_kernel_size if l == 1 else self.KERNEL_SIZES[l - 1]
+            setattr(self, f"conv{l}", conv(enc_in[l], ch[l], ks, l - 1))
+            setattr(self, f"norm{l}", norm(ch[l]))
+            setattr(self, f"block{l}", block(ch[l]))
+        # decoder: conv{l}_tr, norm{l}_tr, block{l}_tr ; input = previous decoder output (+ skip)
+        dec_in = {4: ch[4], 3: ch[3] + tr[4], 2: ch[2] + tr[3]}
+        for l in (4, 3, 2):
+            setattr(self, f"conv{l}_tr", conv(dec_in[l], tr[l], self.KERNEL_SIZES[l - 1], l - 1, transpose=True))
+            setattr(self, f"norm{l}_tr", norm(tr[l]))
+            setattr(self, f"block{l}_tr", block(tr[l]))
+        self.conv1_tr = ME.MinkowskiConvolution(in_channels=ch[1] + tr[2], out_channels=tr[1], kernel_size=1,
+                                                stride=self.STRIDES[0], dilation=self.DILATIONS[0], bias=False,
+                                                dimension=D)
+        self.final = ME.MinkowskiConvolution(in_channels=tr[1], out_channels=out_channels, kernel_size=1, stride=1,
+                                             dilation=1, bias=True, dimension=D)
+
+    def forward(self, x):
+        skips = {}
+        out = x
+        for l in (1, 2, 3, 4):
+            out = getattr(self, f"norm{l}")(getattr(self, f"conv{l}")(out))
+            out = getattr(self, f"block{l}")(out)          # ends in a fused relu
+            skips[l] = out
+            out = MEF.relu(out)
+        for l in (4, 3, 2):
+            out = getattr(self, f"norm{l}_tr")(getattr(self, f"conv{l}_tr")(out))
+            out = MEF.relu(getattr(self, f"block{l}_tr")(out))
+            out = ME.cat(out, skips[l - 1])
+        out = self.final(MEF.relu(self.conv1_tr(out)))
+        if self.normalize_feature:
+            return ME.SparseTensor(out.F / torch.norm(out.F, p=2, dim=1, keepdim=True),
+                                   coordinate_map_key=out.coordinate_map_key,
+                                   coordinate_manager=out.coordinate_manager)
+        return out
+
+
+def _variant(name, tr_channels, channels=None, doc=""):
+    attrs = {"NORM_TYPE": "BN", "TR_CHANNELS": tr_channels, "__doc__": doc}
+    if channels is not None:
+        attrs["CHANNELS"] = channels
+    return type(name, (ResUNet2,), attrs)
+
+
+ResUNetBN2 = _variant("ResUNetBN2", [None, 32, 64, 64, 128], doc="model/resunet.py:235-236")
+ResUNetBN2B = _variant("ResUNetBN2B", [None, 64, 64, 64, 64], doc="model/resunet.py:239-242")
+ResUNetBN2C = _variant("ResUNetBN2C", [None, 64, 64, 64, 128], doc="model/resunet.py:245-248 (north-star model)")
+ResUNetBN2D = _variant("ResUNetBN2D", [None, 64, 64, 128, 128], doc="model/resunet.py:251-254")
+ResUNetBN2E = _variant("ResUNetBN2E", [None, 64, 128, 128, 128], [None, 128, 128, 128, 256],
+                       doc="model/resunet.py:257-260")
+ResUNetFatBN = _variant("ResUNetFatBN", [None, 128, 128, 128, 256], doc="model/resunet.py:263-266 (script default)")

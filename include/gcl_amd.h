@@ -1,0 +1,176 @@
+/*
+ * gcl_amd.h -- C ABI of libgcl_hip.so, the MI355X (gfx950) native library under the
+ * MinkowskiEngine-compatible operator surface used by liuQuan98/GCL's hot path.
+ *
+ * Boundary.  The reference reaches its native code only through the third-party
+ * Python module `MinkowskiEngine` (model/resunet.py:3-4); the entry points below are what that module's
+ * native half has to provide for the calls the reference makes:
+ *
+ *   ME.SparseTensor(feats, coordinates=...)          lib/colocation_trainer.py:843-845,
+ *                                                    scripts/test_kitti.py:143-147, util/misc.py:128
+ *        -> gcl_coords_insert                        (coordinate map of the stride-1 tensor)
+ *   ME.MinkowskiConvolution / ...Transpose           model/resunet.py:38-171, model/residual_block.py:23-33
+ *        -> gcl_stride_map, gcl_kernel_map, gcl_kernel_map_pairs   (coordinate manager, cached per key)
+ *        -> gcl_pack_weights, gcl_conv_fwd (forward AND input-gradient), gcl_conv_bwd_weight,
+ *           gcl_stem_fwd / gcl_stem_bwd_weight       (Cin <= 4 first layer, model/resunet.py:38-45)
+ *   ME.MinkowskiBatchNorm + MEF.relu + `out += residual`   model/common.py:4-6, model/residual_block.py:37-53
+ *        -> gcl_bn_stats, gcl_bn_apply, gcl_bn_bwd_reduce, gcl_bn_bwd_apply
+ *   finest_contrastive_loss                          lib/colocation_trainer.py:430-535
+ *        -> gcl_group_loss_fwd/bwd, gcl_nn_rowmin (pdist + min, lib/metrics.py:22-25),
+ *           gcl_neg_mask, gcl_neg_loss_fwd/bwd
+ *   find_nn_gpu                                      lib/eval.py:18-48  -> gcl_nn_rowmin
+ *
+ * Conventions
+ *   - plain C types only; every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - the caller owns all memory (the Python host allocates torch tensors); the library never allocates
+ *     persistent device memory and never synchronises the stream;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *   - return 0 on success, <0 on error; gcl_last_error() gives the message of the calling thread's last error;
+ *   - row-major contiguous matrices; features are fp32, indices int32, coordinates int32 [N,4] = (batch,x,y,z).
+ */
+#ifndef GCL_AMD_H
+#define GCL_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GCL_OK 0
+#define GCL_ERR_ARG (-1)       /* bad argument (shape not supported, null pointer, ...) */
+#define GCL_ERR_HIP (-2)       /* a HIP runtime call failed */
+#define GCL_ERR_NO_DEVICE (-3) /* no gfx950 device visible */
+
+#define GCL_PAIR_CHUNK 128     /* pair lists are padded per kernel offset to a multiple of this */
+
+const char* gcl_last_error(void);
+int gcl_version(void);
+/* number of visible devices, or <0; never throws -- used by the host to fail loudly without a GPU */
+int gcl_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Coordinate maps.  A map is an open-addressing hash table the CALLER allocates:
+ *   table: int64 [cap, 2]  (slot = {packed key, row index}), cap = power of two >= 2 * n.
+ * Keys pack (batch, x, y, z) into 16 bits each (x,y,z offset by 2^15).
+ * status (int32[4], device): [0] = #rows with a coordinate outside the packable range,
+ *                            [1] = #duplicate rows met by gcl_coords_insert.
+ * ---------------------------------------------------------------------------------------------- */
+int gcl_coords_insert(const int32_t* coords, int64_t n, int64_t* table, int64_t cap,
+                      int32_t* status, void* stream);
+
+/* Strided coordinate map: out = unique(floor(c / t_out) * t_out), rows ordered by first occurrence in
+ * `coords_in` (deterministic).  Writes coords_out (capacity n_in rows), n_out_dev (device int32) and
+ * fills `table_out` (cap_out >= 2 * n_in) with out-key -> out-row.  scratch: int32[gcl_scan_scratch_len(n_in)]. */
+int64_t gcl_scan_scratch_len(int64_t n);
+int gcl_stride_map(const int32_t* coords_in, int64_t n_in, int32_t t_out,
+                   int64_t* table_out, int64_t cap_out, int32_t* scratch,
+                   int32_t* coords_out, int32_t* n_out_dev, int32_t* status, void* stream);
+
+/* Kernel map for kernel size ks^3 (x fastest in k), offsets scaled by `step` (= input tensor stride x dilation),
+ * region centred on the OUTPUT coordinate:  nbr[k * n_out + v] = input row at c_out[v] + o_k * step, or -1.
+ * If nbr_t != NULL (n_in rows): nbr_t[k * n_in + u] = v for every pair (caller need not pre-fill; the call
+ * fills it with -1 first).  counts[k] (int32[K], device) = number of pairs of offset k. */
+int gcl_kernel_map(const int32_t* coords_out, int64_t n_out, const int64_t* table_in, int64_t cap_in,
+                   int32_t ks, int32_t step, int32_t* nbr, int32_t* nbr_t, int64_t n_in,
+                   int32_t* counts, void* stream);
+
+/* Compact per-offset pair lists from nbr (out-major, ascending out row inside an offset), each offset's
+ * segment padded with -1 to a multiple of GCL_PAIR_CHUNK:
+ *   seg_off_host: int64[K+1] HOST array computed by the caller from `counts` (padded prefix sums);
+ *   pair_in / pair_out: int32[seg_off_host[K]].  scratch: int32[K * ceil(n_out/1024) + K + 1]. */
+int gcl_kernel_map_pairs(const int32_t* nbr, int32_t K, int64_t n_out, const int64_t* seg_off_host,
+                         int32_t* scratch, int32_t* pair_in, int32_t* pair_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Sparse convolution (fp32, exact-f32 MFMA).
+ * gcl_pack_weights: W [K, Cin, Cout] -> MFMA B-fragment order.
+ *   mode 0: forward weights            (Cin_eff = Cin,  Cout_eff = Cout, k kept)
+ *   mode 1: transposed per offset      (Cin_eff = Cout, Cout_eff = Cin,  k kept)     input-gradient, in != out map
+ *   mode 2: transposed + offsets mirrored (k -> K-1-k)                               input-gradient, same map
+ *   wp: float[K * Cin * Cout].  Cin, Cout multiples of 32.
+ * gcl_conv_fwd: Y[v] = sum_k X[tbl[k*n_out+v]] . Wp_k (+ bias); tbl == NULL means K == 1, identity.
+ *   Output-stationary (no atomics, deterministic).  The same entry computes the input gradient when given
+ *   the opposite table and mode-1/2 weights. */
+int gcl_pack_weights(const float* w, int32_t K, int32_t cin, int32_t cout, int32_t mode, float* wp, void* stream);
+int gcl_conv_fwd(const float* x, const float* wp, const int32_t* tbl, int64_t n_out, int32_t K,
+                 int32_t cin, int32_t cout, const float* bias, float* y, void* stream);
+
+/* dW[k] = sum over pairs of offset k of  A[pair_a]^T . B[pair_b]   (A: [*, ca], B: [*, cb]) -> dw [K, ca, cb].
+ * Forward conv: A = X, pair_a = pair_in, B = dY, pair_b = pair_out.  Transposed conv: roles swapped.
+ * Deterministic: per-workgroup partial slabs + ordered reduction.
+ * scratch: float[gcl_conv_bwd_weight_scratch_len(...)]. */
+int64_t gcl_conv_bwd_weight_scratch_len(int32_t K, int32_t ca, int32_t cb, int64_t n_pairs_padded);
+int gcl_conv_bwd_weight(const float* a, const float* b, const int32_t* pair_a, const int32_t* pair_b,
+                        const int64_t* seg_off_host, int32_t K, int32_t ca, int32_t cb,
+                        float* scratch, float* dw, void* stream);
+
+/* First layer (Cin <= 4, Cout == 32, any ks): VALU kernels over the nbr table. */
+int gcl_stem_fwd(const float* x, const float* w, const int32_t* nbr, int64_t n_out, int32_t K,
+                 int32_t cin, int32_t cout, float* y, void* stream);
+int64_t gcl_stem_bwd_weight_scratch_len(int32_t K, int32_t cin, int32_t cout, int64_t n_out);
+int gcl_stem_bwd_weight(const float* x, const float* dy, const int32_t* nbr, int64_t n_out, int32_t K,
+                        int32_t cin, int32_t cout, float* scratch, float* dw, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * BatchNorm over rows of [n, c] fused with the residual add and ReLU of BasicBlock.
+ *   gcl_bn_stats:  mean[c], rstd[c] (biased variance, eps) and running-stat update (momentum, unbiased var).
+ *                  scratch: double[gcl_bn_scratch_len(n, c)].
+ *   gcl_bn_apply:  y = x * scale + shift (+ residual) (relu);   scale = w * rstd, shift = b - mean * scale.
+ *                  In eval mode the host passes running stats as mean / rstd.
+ *   backward:      g = dy * (relu ? y > 0 : 1);  gcl_bn_bwd_reduce -> sum_g[c], sum_gx[c] (xhat-weighted);
+ *                  gcl_bn_bwd_apply -> dx, (dres = g).
+ * ---------------------------------------------------------------------------------------------- */
+int64_t gcl_bn_scratch_len(int64_t n, int32_t c);
+int gcl_bn_stats(const float* x, int64_t n, int32_t c, float eps, float momentum,
+                 float* running_mean, float* running_var, double* scratch,
+                 float* mean, float* rstd, void* stream);
+int gcl_bn_apply(const float* x, int64_t n, int32_t c, const float* mean, const float* rstd,
+                 const float* weight, const float* bias, const float* residual, int32_t relu,
+                 float* y, void* stream);
+int gcl_bn_bwd_reduce(const float* x, const float* dy, const float* y, int64_t n, int32_t c,
+                      const float* mean, const float* rstd, int32_t relu, double* scratch,
+                      float* sum_g, float* sum_gx, void* stream);
+int gcl_bn_bwd_apply(const float* x, const float* dy, const float* y, int64_t n, int32_t c,
+                     const float* mean, const float* rstd, const float* weight,
+                     const float* sum_g, const float* sum_gx, int32_t relu,
+                     float* dx, float* dres, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GCL loss (lib/colocation_trainer.py:430-535, square_loss path) and feature-space 1-NN.
+ *   group g = rows index[goff[g] .. goff[g+1]) of F [n, c] (c <= 64); sel[s] = selected group ids.
+ *   pos[s]    = relu(mean_j |mean - f_j|^2 - pos_thresh)          (:474)
+ *   fin[s]    = relu(|mean - f_finest|^2 - finest_thresh)         (:484-485)
+ *   backward adds  gpos * dpos[s]/dF + gfin * dfin[s]/dF  into dF with float atomics (dF pre-zeroed by caller).
+ * ---------------------------------------------------------------------------------------------- */
+int gcl_group_loss_fwd(const float* f, int32_t c, const int64_t* index, const int64_t* goff,
+                       const uint8_t* finest_flag, const int64_t* sel, int32_t n_sel,
+                       float pos_thresh, float finest_thresh, float* pos, float* fin, void* stream);
+int gcl_group_loss_bwd(const float* f, int32_t c, const int64_t* index, const int64_t* goff,
+                       const uint8_t* finest_flag, const int64_t* sel, int32_t n_sel,
+                       float pos_thresh, float finest_thresh, const float* gpos, const float* gfin,
+                       float* df, void* stream);
+
+/* Row-wise nearest neighbour: for every row i of A[rows_a[i]] (rows_a may be NULL = identity) the column j
+ * minimising sum_c (a - b)^2 over B[rows_b[j]]; ties -> lowest j.  dmin = that squared distance, or
+ * sqrt(d2 + 1e-7) when l2 != 0 (lib/metrics.py:24-25). */
+int gcl_nn_rowmin(const float* a, const int64_t* rows_a, int32_t ma, const float* b, const int64_t* rows_b,
+                  int32_t mb, int32_t c, int32_t l2, float* dmin, int32_t* argmin, void* stream);
+
+/* keep[r] = (sel1[r] != sel2[arg[r]]) && the pair {sel1[r], sel2[arg[r]]} shares no positive group
+ * (equivalent to the reference's `~np.isin(_neg_hash(...), index_hash)` :521-529: the symmetric key is
+ * collision-free).  table: int64[cap,2] scratch hash table (cap = pow2 >= 2*m). */
+int gcl_neg_mask(const int64_t* sel1, const int64_t* sel2, const int32_t* arg, int32_t m,
+                 const int64_t* index, const int64_t* goff, int64_t n_groups, int64_t n_index,
+                 int64_t* table, int64_t cap, uint8_t* keep, void* stream);
+/* neg = mean over kept rows of relu(thresh - dmin)^2 (NaN when nothing is kept, as torch's mean of empty);
+ * out[0] = neg, out[1] = #kept.  Backward scatters into dF (atomics). */
+int gcl_neg_loss_fwd(const float* dmin, const uint8_t* keep, int32_t m, float thresh, float* out, void* stream);
+int gcl_neg_loss_bwd(const float* f, int32_t c, const int64_t* sel1, const int64_t* sel2, const int32_t* arg,
+                     const float* dmin, const uint8_t* keep, int32_t m, float thresh, const float* out,
+                     const float* gneg, float* df, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCL_AMD_H */

@@ -1,0 +1,76 @@
+"""Host-side (CPU) logic of the product package: ME.utils, hashes, synthetic input contracts, model registry."""
+import os
+
+import numpy as np
+import torch
+
+from gcl_amd import synthetic
+from gcl_amd.MinkowskiEngine import utils as U
+from gcl_amd.util import misc
+from oracle import loss_oracle as LO
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_sparse_quantize_first_occurrence_and_floor():
+    xyz = np.array([[0.2, 0.2, 0.2], [-0.1, 0.0, 0.0], [0.9, 0.9, 0.9], [-0.9, 0.5, 0.5], [1.0, 0.0, 0.0]])
+    c, idx = U.sparse_quantize(xyz, return_index=True)
+    assert idx.tolist() == [0, 1, 4]                      # rows 2 and 3 fall into voxels seen earlier
+    assert c.tolist() == [[0, 0, 0], [-1, 0, 0], [1, 0, 0]] and c.dtype == np.int32
+    ct, it = U.sparse_quantize(torch.from_numpy(xyz), return_index=True)
+    assert it.tolist() == [0, 1, 4] and ct.dtype == torch.int32
+    assert U.sparse_quantize(np.zeros((0, 3))).shape == (0, 3)
+
+
+def test_collate_and_batched_coordinates():
+    a, b = np.array([[1, 2, 3]]), np.array([[4, 5, 6], [7, 8, 9]])
+    C = U.batched_coordinates([a, b])
+    assert C.dtype == torch.int32 and C.tolist() == [[0, 1, 2, 3], [1, 4, 5, 6], [1, 7, 8, 9]]
+    C2, F2 = U.sparse_collate([a, b], [np.ones((1, 1)), np.zeros((2, 1))])
+    assert torch.equal(C, C2) and F2[:, 0].tolist() == [1.0, 0.0, 0.0]
+
+
+def test_hashes_match_reference_goldens():
+    z = np.load(os.path.join(G, "hash.npz"))
+    M = int(z["M"])
+    split = np.split(z["index"], np.cumsum(z["group"])[:-1])
+    assert np.array_equal(misc._exhaustive_hash(split, M), z["exhaustive"])
+    assert np.array_equal(misc._neg_hash(z["i1"], z["i2"], M), z["neg"])
+    assert np.array_equal(misc._hash(z["arr"], 97), z["hash_arr"])
+    assert np.array_equal(synthetic.exhaustive_hash(z["index"], z["group"], M), z["exhaustive"])
+
+
+def test_synthetic_train_batch_contract():
+    s = synthetic.make_train_sample(5, num_neighborhood=2, n_boxes=10)
+    b = synthetic.collate_train([s, synthetic.make_train_sample(6, num_neighborhood=2, n_boxes=10)])
+    C = b["sinput_C"]
+    assert C.dtype == torch.int32 and C.shape[1] == 4 and b["sinput_F"].shape == (len(C), 1)
+    assert C[:, 0].max().item() == 2 * 3 - 1                       # batch id increments per cloud
+    key = O_pack(C.numpy())
+    assert len(np.unique(key)) == len(key), "coordinates are unique within the batch"
+    g, idx, fl = b["group"].numpy(), b["index"].numpy(), b["finest_flag"].numpy()
+    assert g.sum() == len(idx) == len(fl) and g.min() >= 2 and g.max() <= 5 + 5 * 2
+    starts = np.concatenate([[0], np.cumsum(g)[:-1]])
+    assert (np.add.reduceat(fl.astype(int), starts) == 1).all(), "exactly one finest member per group"
+    assert idx.max() < len(C) and sum(b["batch_lengths"]) == len(C)
+    split = np.split(idx, np.cumsum(g)[:-1])
+    assert np.array_equal(b["index_hash"], LO.exhaustive_hash(split, len(C)))
+    f16 = synthetic.collate_train([synthetic.make_train_sample(5, num_neighborhood=6, n_boxes=10, group_mode="fixed16")])
+    assert (f16["group"] == 16).all() and len(f16["group"]) > 0
+
+
+def O_pack(C):
+    from oracle.me_oracle import pack_keys
+    return pack_keys(C)
+
+
+def test_eval_pair_contract_and_registry():
+    p = synthetic.make_eval_pair(0, n_boxes=10)
+    for k in (0, 1):
+        assert p[f"sinput{k}_C"].shape[1] == 4 and (p[f"sinput{k}_C"][:, 0] == 0).all()
+        assert len(p[f"pcd{k}"][0]) == len(p[f"sinput{k}_C"]) == len(p[f"sinput{k}_F"])
+    from gcl_amd.model import load_model
+    m = load_model("ResUNetBN2C")(1, 32, bn_momentum=0.05, normalize_feature=True, conv1_kernel_size=5, D=3)
+    assert sum(p.numel() for p in m.parameters()) == 8753408
+    fat = load_model("ResUNetFatBN")(1, 32, bn_momentum=0.05, normalize_feature=True, conv1_kernel_size=5, D=3)
+    assert fat.conv1_tr.kernel.shape == (32 + 128, 128)
