@@ -1,0 +1,167 @@
+"""Headline benchmark: active voxels / second through ResUNetBN2C fwd + GCL loss + bwd + SGD step
+(BASELINE.json metric; workload = configs[2], the GCL training step at KITTI 0.3 m, bs = 4 x 7 clouds).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL gradient all-reduce over xGMI)
+
+One "step" = one pass of the hot path over one synthetic batch that is ALREADY RESIDENT IN HBM: SparseTensor /
+coordinate-map build, kernel maps, 23 sparse convs + 21 BNs forward, finest-contrastive loss, backward, (gradient
+all-reduce,) SGD step.  Rank 0 prints ONE JSON line; `roofline` prices the dominant HIP kernel against HBM peak with
+per-launch times measured by events on the launch stream inside the timed region; `cpu_baseline` times the CPU oracle
+(a torch-CPU restatement, kind "port") on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch-size", type=int, default=4)
+    ap.add_argument("--group-mode", default="fixed16", choices=["fixed16", "radius"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The CPU oracle (oracle/: gather -> GEMM -> scatter per offset, torch-CPU fp32, all host cores) on a bounded
+    sample: ONE sample of 1 + 2 clouds (same generator, same model, same loss), forward + loss + backward."""
+    from gcl_amd import synthetic
+    from oracle import loss_oracle, me_oracle
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    batch = synthetic.collate_train([synthetic.make_train_sample(900, num_neighborhood=2, group_mode="radius")])
+    C, F = batch["sinput_C"].numpy(), batch["sinput_F"].float()
+    st = me_oracle.random_state(0, dtype=torch.float32)
+    n_done, t_total = 0, 0.0
+    np.random.seed(0)
+    while t_total < seconds_budget and n_done < 3:
+        leaves = {k: v.clone().requires_grad_("running" not in k) for k, v in st.items()}
+        t0 = time.perf_counter()
+        mgr = me_oracle.CoordinateManager(C)          # coordinate + kernel maps are part of the step
+        out = me_oracle.resunet_forward(leaves, C, F, 5, True, True, 0.05, mgr=mgr)
+        pos, fin, neg = loss_oracle.finest_contrastive_loss(out, batch["group"].numpy(), batch["index"].numpy(),
+                                                            batch["index_hash"], batch["finest_flag"].numpy(),
+                                                            max_pos_cluster=256, max_hn_samples=256)
+        (pos + fin + neg).backward()
+        t_total += time.perf_counter() - t0
+        n_done += 1
+    return {"value": len(C) * n_done / t_total, "unit": "active voxels/s", "cores": cores, "kind": "port",
+            "sample": f"{n_done} step(s) of 1 sample x 3 clouds ({len(C)} voxels), fwd+loss+bwd, torch-CPU fp32 "
+                      f"restatement of ME's gather-GEMM-scatter (oracle/me_oracle.py), {t_total:.1f} s"}
+
+
+def main():
+    args = parse()
+    from gcl_amd import ddp, synthetic
+    rank, world, local = ddp.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+    import torch.distributed as dist
+    from gcl_amd.lib.colocation_trainer import FinestContrastiveLossTrainer, make_config
+    from gcl_amd.MinkowskiEngine import ops
+
+    # ---- synthetic batch of this rank (weak scaling: every rank gets its own bs=4 batch), moved to HBM --------
+    torch.manual_seed(0)
+    np.random.seed(rank)
+    batch = synthetic.make_train_batch(100 + rank, batch_size=args.batch_size, group_mode=args.group_mode)
+    n_vox = len(batch["sinput_C"])
+    dbatch = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in batch.items() if k != "index_hash"}
+    cfg = make_config(batch_size=args.batch_size)
+    trainer = FinestContrastiveLossTrainer(cfg, device=dev, ddp=ddp.FlatDDP() if world > 1 else None)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss, _, _ = trainer.train_step(dbatch)
+    sync()
+    ops.PROFILE = None if args.no_kernel_events else []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, parts, _ = trainer.train_step(dbatch)
+    sync()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    stats = torch.tensor([dt, float(n_vox)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = stats[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        vox = stats[1:].clone()
+        dist.all_reduce(vox, op=dist.ReduceOp.SUM)
+        dt, total_vox = tmax.item(), vox.item()
+    else:
+        total_vox = float(n_vox)
+    if not torch.isfinite(loss).item():
+        raise SystemExit("non-finite loss in the benchmark")
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+        return
+
+    # ---- roofline of the dominant kernel (per-launch event timings from the timed region) -----------------------
+    roofline = None
+    if prof:
+        agg = {}
+        for name, e0, e1, pairs, cin, cout in prof:
+            ms = e0.elapsed_time(e1)
+            a = agg.setdefault(name, [0.0, 0.0, 0.0, 0])
+            a[0] += ms
+            a[1] += pairs * (cin + cout) * 4.0 + pairs * 8.0          # algorithmic bytes of a launch
+            a[2] += 2.0 * pairs * cin * cout
+            a[3] += 1
+        dom = max(agg, key=lambda k: agg[k][0])
+        ms, by, fl, cnt = agg[dom]
+        achieved = by / (ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "launches": cnt, "avg_launch_us": round(ms * 1e3 / cnt, 2),
+                    "avg_algorithmic_MB_per_launch": round(by / cnt / 1e6, 3),
+                    "mfma_tflops_sparse": round(fl / (ms * 1e-3) / 1e12, 2),
+                    "kernel_time_share_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in agg.items()}}
+    out = {
+        "metric": "active voxels/sec thru ResUNetBN2C fwd+bwd+GCL loss, KITTI 0.3m",
+        "value": round(total_vox * args.steps / dt, 1), "unit": "active voxels/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[2]: GCL training step (finest_contrastive_loss), ResUNetBN2C-32 conv1 k=5, "
+                               f"KITTI-shaped ray-cast clouds @0.3 m, bs={args.batch_size} x 7 clouds per GPU, "
+                               f"positive groups '{args.group_mode}'",
+                   "voxels_per_step_rank0": n_vox, "global_batch": args.batch_size * world,
+                   "parallelism": f"dp{world}", "loss": float(loss.item())},
+        "roofline": roofline,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+
+
+if __name__ == "__main__":
+    main()

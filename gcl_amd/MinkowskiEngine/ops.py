@@ -4,11 +4,35 @@ from torch.autograd.function import once_differentiable
 
 from .. import _lib
 
+# bench.py sets this to a list to time individual launches with events on the launch stream:
+# entries are (kernel name, start event, end event, pairs, cin, cout)
+PROFILE = None
 
-def _conv_launch(lib, x, wp, tbl, n_out, K, cin, cout, bias):
+
+class _Timed:
+    """Brackets one launch with events on torch's current stream (the stream the kernel is launched on)."""
+
+    def __init__(self, name, pairs, cin, cout):
+        self.rec = None
+        if PROFILE is not None:
+            self.rec = (name, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
+                        int(pairs), cin, cout)
+
+    def __enter__(self):
+        if self.rec is not None:
+            self.rec[1].record()
+
+    def __exit__(self, *exc):
+        if self.rec is not None:
+            self.rec[2].record()
+            PROFILE.append(self.rec)
+
+
+def _conv_launch(lib, x, wp, tbl, n_out, K, cin, cout, bias, pairs=0):
     y = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
-    _lib.check(lib.gcl_conv_fwd(_lib.ptr(x, torch.float32), _lib.ptr(wp), _lib.ptr(tbl), n_out, K, cin, cout,
-                                _lib.ptr(bias), _lib.ptr(y), _lib.stream()), "gcl_conv_fwd")
+    with _Timed("k_conv_fwd<2>" if cout % 64 == 0 else "k_conv_fwd<1>", pairs, cin, cout):
+        _lib.check(lib.gcl_conv_fwd(_lib.ptr(x, torch.float32), _lib.ptr(wp), _lib.ptr(tbl), n_out, K, cin, cout,
+                                    _lib.ptr(bias), _lib.ptr(y), _lib.stream()), "gcl_conv_fwd")
     return y
 
 
@@ -41,7 +65,8 @@ class _SparseConvFn(torch.autograd.Function):
         else:
             tbl = None if kmap is None else (kmap.nbr_t if transpose else kmap.nbr)
             b = bias.detach().contiguous().view(-1) if bias is not None else None
-            y = _conv_launch(lib, x, _pack(lib, Wk, 0), tbl, n_out, K, cin, cout, b)
+            ctx.pairs = kmap.n_pairs if kmap is not None else n_out
+            y = _conv_launch(lib, x, _pack(lib, Wk, 0), tbl, n_out, K, cin, cout, b, ctx.pairs)
         ctx.save_for_backward(x, Wk)
         ctx.kmap, ctx.transpose, ctx.mgr, ctx.w_shape, ctx.has_bias = kmap, transpose, mgr, W.shape, bias is not None
         return y
@@ -66,7 +91,7 @@ class _SparseConvFn(torch.autograd.Function):
                 mode, tbl = 2, kmap.nbr
             else:
                 mode, tbl = 1, kmap.nbr_t
-            dx = _conv_launch(lib, dy, _pack(lib, Wk, mode), tbl, x.shape[0], K, cout, cin, None)
+            dx = _conv_launch(lib, dy, _pack(lib, Wk, mode), tbl, x.shape[0], K, cout, cin, None, ctx.pairs)
         if ctx.needs_input_grad[1]:
             dW = torch.empty_like(Wk)
             if ctx.stem:
@@ -84,9 +109,11 @@ class _SparseConvFn(torch.autograd.Function):
                     pa, pb = (pout, pin) if transpose else (pin, pout)
                 scratch = torch.empty(lib.gcl_conv_bwd_weight_scratch_len(K, cin, cout, seg[-1]), dtype=torch.float32,
                                       device=x.device)
-                _lib.check(lib.gcl_conv_bwd_weight(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(pa), _lib.ptr(pb), seg_host, K,
-                                                   cin, cout, _lib.ptr(scratch), _lib.ptr(dW), _lib.stream()),
-                           "gcl_conv_bwd_weight")
+                name = f"k_conv_bwd_weight<{64 if cin % 64 == 0 else 32},{64 if cout % 64 == 0 else 32}>"
+                with _Timed(name, ctx.pairs, cin, cout):
+                    _lib.check(lib.gcl_conv_bwd_weight(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(pa), _lib.ptr(pb), seg_host,
+                                                       K, cin, cout, _lib.ptr(scratch), _lib.ptr(dW), _lib.stream()),
+                               "gcl_conv_bwd_weight")
             dW = dW.view(ctx.w_shape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             dbias = dy.sum(0, keepdim=True)

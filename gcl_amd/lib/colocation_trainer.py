@@ -119,9 +119,8 @@ def finest_contrastive_loss(F_out, group, index, index_hash, finest_flag, max_po
         pos_sel, sel_hn1, sel_hn2 = draws
     if len(pos_sel) == 0:
         raise ZeroDivisionError("no positive group in the batch")
-    goff = torch.zeros(n_groups + 1, dtype=torch.int64)
-    goff[1:] = torch.cumsum(group.to(torch.int64).cpu(), 0)
-    goff = goff.to(dev, non_blocking=True)
+    goff = torch.zeros(n_groups + 1, dtype=torch.int64, device=dev)       # no host sync when group is on the GPU
+    goff[1:] = torch.cumsum(group.to(dev, torch.int64, non_blocking=True), 0)
     index = torch.as_tensor(index).to(dev, torch.int64, non_blocking=True).contiguous()
     flag = torch.as_tensor(finest_flag).to(dev, non_blocking=True).to(torch.uint8).contiguous()
     to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64)).to(dev, non_blocking=True)

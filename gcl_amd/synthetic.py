@@ -95,42 +95,36 @@ def colocation_groups(center_xyz, nghb_xyz, list_M, radius, K=5):
 
     For every centre voxel: <=K centre-cloud radius hits (nearest first, i.e. itself first), then <=K hits
     per neighbour cloud (neighbour aligned into the centre frame by ``list_M[j]``); a group exists only if
-    at least one neighbour cloud matched.  ``finest`` marks the member whose own sensor is closest.
-    Row ids: centre rows 0..Nc-1, neighbour j offset by Nc + sum_{i<j} N_i.
+    at least one neighbour cloud matched.  ``finest`` marks the member whose own sensor is closest
+    (sequential strict-< update in the reference == first arg-min).
+    Row ids: centre rows 0..Nc-1, neighbour j offset by Nc + sum_{i<j} N_i.  Vectorised over centre voxels.
     """
     from scipy.spatial import cKDTree
 
     Nc = len(center_xyz)
-    ctree = cKDTree(center_xyz)
-    dc, ic = ctree.query(center_xyz, k=K, distance_upper_bound=radius)
-    hits = []
+    offs = np.concatenate([[0, Nc], Nc + np.cumsum([len(x) for x in nghb_xyz])]).astype(np.int64)
+    d, i = cKDTree(center_xyz).query(center_xyz, k=K, distance_upper_bound=radius)
+    cols_idx, cols_ok = [i.astype(np.int64)], [np.isfinite(d)]
+    first_range = [np.linalg.norm(center_xyz, axis=1)]           # the centre voxel's own sensor range
     for j, xyz in enumerate(nghb_xyz):
-        tree = cKDTree(_apply(list_M[j], xyz))
-        dj, ij = tree.query(center_xyz, k=K, distance_upper_bound=radius)
-        hits.append((dj, ij))
-    nghb_range = [np.linalg.norm(x, axis=1) for x in nghb_xyz]
-    offs = np.concatenate([[Nc], Nc + np.cumsum([len(x) for x in nghb_xyz])])
-    c_range = np.linalg.norm(center_xyz, axis=1)
-    group, index, finest = [], [], []
-    for i in range(Nc):
-        members = [int(v) for v, d in zip(ic[i], dc[i]) if np.isfinite(d)]
-        n0 = len(members)
-        best, pos = c_range[i], 0
-        for j, (dj, ij) in enumerate(hits):
-            idx = [int(v) for v, d in zip(ij[i], dj[i]) if np.isfinite(d)]
-            if idx:
-                r = nghb_range[j][idx[0]]
-                if r < best:
-                    best, pos = r, len(members)
-                members += [v + int(offs[j]) for v in idx]
-        if len(members) == n0:
-            continue
-        group.append(len(members))
-        index += members
-        flag = [False] * len(members)
-        flag[pos] = True
-        finest += flag
-    return group, index, finest
+        dj, ij = cKDTree(_apply(list_M[j], xyz)).query(center_xyz, k=K, distance_upper_bound=radius)
+        ok = np.isfinite(dj)
+        rng_j = np.linalg.norm(xyz, axis=1)
+        first = np.where(ok[:, 0], rng_j[np.minimum(ij[:, 0], len(xyz) - 1)], np.inf)
+        cols_idx.append(ij.astype(np.int64) + offs[j + 1])
+        cols_ok.append(ok)
+        first_range.append(first)
+    idx = np.concatenate(cols_idx, axis=1)                       # [Nc, K * (1 + n_nghb)], reference member order
+    ok = np.concatenate(cols_ok, axis=1)
+    has_nghb = ok[:, K:].any(axis=1)
+    best = np.argmin(np.stack(first_range, axis=1), axis=1)      # 0 = centre, j + 1 = neighbour j
+    before = np.cumsum(ok, axis=1) - ok                          # members listed before each column
+    fpos = np.where(best == 0, 0, before[np.arange(Nc), best * K])
+    rank = before                                                # position of a valid column inside its group
+    flag = ok & (rank == fpos[:, None])
+    keep = ok & has_nghb[:, None]
+    group = ok.sum(axis=1)[has_nghb]
+    return group.tolist(), idx[keep].tolist(), flag[keep].tolist()
 
 
 def fixed_size_groups(center_xyz, nghb_xyz, list_M, radius, size=16, K=5):

@@ -140,12 +140,16 @@ def sparse_conv(x, W, triples, n_out, transpose=False, bias=None):
     """
     Wk = W if W.dim() == 3 else W.unsqueeze(0)
     out = x.new_zeros((n_out, Wk.shape[2]))
-    t = torch.as_tensor(triples)
+    tn = np.asarray(triples)
+    if len(tn) and (np.diff(tn[:, 0]) < 0).any():
+        tn = tn[np.argsort(tn[:, 0], kind="stable")]
+    bounds = np.searchsorted(tn[:, 0], np.arange(Wk.shape[0] + 1))      # triples are grouped by k
+    t = torch.as_tensor(tn)
     ci, co = (2, 1) if transpose else (1, 2)
     for k in range(Wk.shape[0]):
-        sel = t[:, 0] == k
-        if sel.any():
-            out = out.index_add(0, t[sel, co], x[t[sel, ci]] @ Wk[k])
+        a, b = int(bounds[k]), int(bounds[k + 1])
+        if b > a:
+            out = out.index_add(0, t[a:b, co], x[t[a:b, ci]] @ Wk[k])
     if bias is not None:
         out = out + bias
     return out

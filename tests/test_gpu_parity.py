@@ -391,7 +391,7 @@ def test_full_size_properties():
     # checksum of checksums: sum_v y[v] = sum_k count_k * colsum(W_k)
     cnt = torch.tensor(km.counts, dtype=torch.float64)
     ref = (cnt[:, None] * conv.kernel.detach().cpu().double().sum(1)).sum(0)
-    assert rel_l2(y.double().sum(0).cpu(), ref) < 1e-5
+    assert rel_l2(y.detach().double().sum(0).cpu(), ref) < 1e-5
     # linearity + adjointness <conv(x), g> = <x, conv^T(g)> through the input-gradient kernel
     x = torch.randn(n, 32, device=DEV, requires_grad=True)
     gy = torch.randn(n, 64, device=DEV)
