@@ -35,22 +35,42 @@ def parse():
     ap.add_argument("--group-mode", default="fixed16", choices=["fixed16", "radius"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """The CPU oracle (oracle/: gather -> GEMM -> scatter per offset, torch-CPU fp32, all host cores) on a bounded
-    sample: ONE sample of 1 + 2 clouds (same generator, same model, same loss), forward + loss + backward."""
+def usable_cores():
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota (os.cpu_count() reports the
+    whole host and over-subscribes a quota-limited container by an order of magnitude)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline_worker():
+    """The CPU oracle (oracle/: gather -> GEMM -> scatter per offset, torch-CPU fp32, all usable host cores) on a
+    bounded sample: ONE sample of 1 + 2 clouds (same generator, same model, same loss), forward + loss + backward."""
     from gcl_amd import synthetic
     from oracle import loss_oracle, me_oracle
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     batch = synthetic.collate_train([synthetic.make_train_sample(900, num_neighborhood=2, group_mode="radius")])
     C, F = batch["sinput_C"].numpy(), batch["sinput_F"].float()
     st = me_oracle.random_state(0, dtype=torch.float32)
     n_done, t_total = 0, 0.0
     np.random.seed(0)
-    while t_total < seconds_budget and n_done < 3:
+    while t_total < 20.0 and n_done < 3:
         leaves = {k: v.clone().requires_grad_("running" not in k) for k, v in st.items()}
         t0 = time.perf_counter()
         mgr = me_oracle.CoordinateManager(C)          # coordinate + kernel maps are part of the step
@@ -61,13 +81,32 @@ def cpu_baseline(seconds_budget=25.0):
         (pos + fin + neg).backward()
         t_total += time.perf_counter() - t0
         n_done += 1
-    return {"value": len(C) * n_done / t_total, "unit": "active voxels/s", "cores": cores, "kind": "port",
+    return {"value": round(len(C) * n_done / t_total, 1), "unit": "active voxels/s", "cores": cores, "kind": "port",
             "sample": f"{n_done} step(s) of 1 sample x 3 clouds ({len(C)} voxels), fwd+loss+bwd, torch-CPU fp32 "
                       f"restatement of ME's gather-GEMM-scatter (oracle/me_oracle.py), {t_total:.1f} s"}
 
 
+def cpu_baseline(timeout_s=240):
+    """Runs the worker in a child process (never touches the GPU) under a hard wall-clock limit."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker"], capture_output=True,
+                           text=True, timeout=timeout_s, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:   # report, never hang the benchmark line
+        return {"value": None, "unit": "active voxels/s", "cores": usable_cores(), "kind": "port",
+                "sample": f"CPU baseline did not finish within {timeout_s} s ({type(e).__name__})"}
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     args = parse()
+    if args.cpu_baseline_worker:
+        print(json.dumps(cpu_baseline_worker()), flush=True)
+        return
     from gcl_amd import ddp, synthetic
     rank, world, local = ddp.init_from_env()
     if world != args.gpus and world > 1:
@@ -83,6 +122,7 @@ def main():
     np.random.seed(rank)
     batch = synthetic.make_train_batch(100 + rank, batch_size=args.batch_size, group_mode=args.group_mode)
     n_vox = len(batch["sinput_C"])
+    log(f"rank {rank}: batch ready, {n_vox} voxels, {len(batch['group'])} groups")
     dbatch = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in batch.items() if k != "index_hash"}
     cfg = make_config(batch_size=args.batch_size)
     trainer = FinestContrastiveLossTrainer(cfg, device=dev, ddp=ddp.FlatDDP() if world > 1 else None)
@@ -96,12 +136,14 @@ def main():
     for _ in range(args.warmup):
         loss, _, _ = trainer.train_step(dbatch)
     sync()
+    log("warmup done")
     ops.PROFILE = None if args.no_kernel_events else []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, parts, _ = trainer.train_step(dbatch)
     sync()
     dt = time.perf_counter() - t0
+    log(f"timed region done: {dt / args.steps * 1e3:.2f} ms/step")
     prof, ops.PROFILE = ops.PROFILE, None
     stats = torch.tensor([dt, float(n_vox)], dtype=torch.float64, device=dev)
     if world > 1:
