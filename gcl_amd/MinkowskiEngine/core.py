@@ -47,10 +47,33 @@ class KernelMap:
         self.n_in, self.n_out, self.K = n_in, n_out, K
         self.same_map = nbr_t is None
         self._pairs = None
+        self._sorted = {}
 
     @property
     def n_pairs(self):
         return int(sum(self.counts))
+
+    def sorted_table(self, transposed=False):
+        """(tbl_sorted, order, tile_mask) of ``nbr`` (or ``nbr_t``): rows re-ordered by neighbour-presence mask so
+        that every 32-row wave tile of the convolution kernel visits few offsets (gcl_table_sort).  K <= 27 only."""
+        key = "t" if transposed else "n"
+        if key not in self._sorted:
+            tbl = self.nbr_t if transposed else self.nbr
+            if self.K > 27:
+                self._sorted[key] = (tbl, None, None)
+            else:
+                lib = _lib.load()
+                n = tbl.shape[1]
+                dev = tbl.device
+                scratch = torch.empty(lib.gcl_table_sort_scratch_len(n), dtype=torch.int32, device=dev)
+                order = torch.empty(n, dtype=torch.int32, device=dev)
+                tbl_sorted = torch.empty_like(tbl)
+                tile_mask = torch.empty((n + 31) // 32, dtype=torch.int32, device=dev)
+                _lib.check(lib.gcl_table_sort(_lib.ptr(tbl), self.K, n, _lib.ptr(scratch), _lib.ptr(order),
+                                              _lib.ptr(tbl_sorted), _lib.ptr(tile_mask), _lib.stream()),
+                           "gcl_table_sort")
+                self._sorted[key] = (tbl_sorted, order, tile_mask)
+        return self._sorted[key]
 
     def pairs(self):
         if self._pairs is None:

@@ -28,11 +28,15 @@ class _Timed:
             PROFILE.append(self.rec)
 
 
-def _conv_launch(lib, x, wp, tbl, n_out, K, cin, cout, bias, pairs=0):
+def _conv_launch(lib, x, wp, table, n_out, K, cin, cout, bias, pairs=0):
+    """``table`` = (tbl, order, tile_mask) from KernelMap.sorted_table(), or None for a kernel_size-1 conv."""
+    tbl, order, tile_mask = table if table is not None else (None, None, None)
     y = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
-    with _Timed("k_conv_fwd<2>" if cout % 64 == 0 else "k_conv_fwd<1>", pairs, cin, cout):
-        _lib.check(lib.gcl_conv_fwd(_lib.ptr(x, torch.float32), _lib.ptr(wp), _lib.ptr(tbl), n_out, K, cin, cout,
-                                    _lib.ptr(bias), _lib.ptr(y), _lib.stream()), "gcl_conv_fwd")
+    name = "k_conv_fwd<4>" if cout % 128 == 0 else ("k_conv_fwd<2>" if cout % 64 == 0 else "k_conv_fwd<1>")
+    with _Timed(name, pairs, cin, cout):
+        _lib.check(lib.gcl_conv_fwd(_lib.ptr(x, torch.float32), _lib.ptr(wp), _lib.ptr(tbl), _lib.ptr(order),
+                                    _lib.ptr(tile_mask), n_out, K, cin, cout, _lib.ptr(bias), _lib.ptr(y),
+                                    _lib.stream()), "gcl_conv_fwd")
     return y
 
 
@@ -63,7 +67,7 @@ class _SparseConvFn(torch.autograd.Function):
             _lib.check(lib.gcl_stem_fwd(_lib.ptr(x, torch.float32), _lib.ptr(Wk), _lib.ptr(kmap.nbr), n_out, K, cin,
                                         cout, _lib.ptr(y), _lib.stream()), "gcl_stem_fwd")
         else:
-            tbl = None if kmap is None else (kmap.nbr_t if transpose else kmap.nbr)
+            tbl = None if kmap is None else kmap.sorted_table(transposed=transpose)
             b = bias.detach().contiguous().view(-1) if bias is not None else None
             ctx.pairs = kmap.n_pairs if kmap is not None else n_out
             y = _conv_launch(lib, x, _pack(lib, Wk, 0), tbl, n_out, K, cin, cout, b, ctx.pairs)
@@ -86,11 +90,11 @@ class _SparseConvFn(torch.autograd.Function):
             if kmap is None:
                 mode, tbl = 1, None
             elif transpose:
-                mode, tbl = 1, kmap.nbr
+                mode, tbl = 1, kmap.sorted_table(transposed=False)
             elif kmap.same_map:
-                mode, tbl = 2, kmap.nbr
+                mode, tbl = 2, kmap.sorted_table(transposed=False)
             else:
-                mode, tbl = 1, kmap.nbr_t
+                mode, tbl = 1, kmap.sorted_table(transposed=True)
             dx = _conv_launch(lib, dy, _pack(lib, Wk, mode), tbl, x.shape[0], K, cout, cin, None, ctx.pairs)
         if ctx.needs_input_grad[1]:
             dW = torch.empty_like(Wk)

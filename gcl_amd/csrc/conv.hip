@@ -62,17 +62,20 @@ constexpr int LDS_STRIDE = 36;   // 32 floats + 4 pad: conflict-free ds_read_b12
 
 template <int NB>  // 32-column blocks per wave
 __global__ void __launch_bounds__(256) k_conv_fwd(const float* __restrict__ X, const float4* __restrict__ Wp,
-                                                  const int* __restrict__ tbl, long long n_out, int K, int cin,
-                                                  int cout, const float* __restrict__ bias,
+                                                  const int* __restrict__ tbl, const int* __restrict__ order,
+                                                  const int* __restrict__ tile_mask, long long n_out, int K,
+                                                  int cin, int cout, const float* __restrict__ bias,
                                                   float* __restrict__ Y) {
   __shared__ __attribute__((aligned(16))) float lds[4][32][LDS_STRIDE];
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = l & 31, h = l >> 5;
-  const long long row0 = (long long)blockIdx.x * CONV_ROWS + w * 32;
-  if (row0 >= n_out) return;   // whole wave out of range (no barriers below)
+  const long long tile = (long long)blockIdx.x * 4 + w;
+  const long long row0 = tile * 32;
+  if (row0 >= n_out) return;   // whole wave out of range (no workgroup barriers below)
   const int nb0 = blockIdx.y * NB;
   const int TNB = cout >> 5, Q = cin >> 3, CC = cin >> 5;
   const int p = l & 7, rsub = l >> 3;
+  const bool row_ok = (l < 32) && (row0 + l < n_out);
 
   f32x16 acc[NB];
 #pragma unroll
@@ -80,50 +83,87 @@ __global__ void __launch_bounds__(256) k_conv_fwd(const float* __restrict__ X, c
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
 
-  const bool row_ok = (l < 32) && (row0 + l < n_out);
-  for (int k = 0; k < K; ++k) {
-    int idx = -1;
-    if (row_ok) idx = tbl ? tbl[(long long)k * n_out + row0 + l] : (int)(row0 + l);
-    if (__ballot(idx >= 0) == 0ull) continue;
-    for (int cc = 0; cc < CC; ++cc) {
-      float4 st[4];
+  // offsets this tile has to visit (wave-uniform)
+  unsigned kmask = tile_mask ? (unsigned)tile_mask[tile] : ((K >= 32) ? ~0u : ((1u << K) - 1u));
+  kmask = __builtin_amdgcn_readfirstlane(kmask);
+
+  auto load_idx = [&](int k) -> int {
+    int v = -1;
+    if (row_ok) v = tbl ? tbl[(long long)k * n_out + row0 + l] : (int)(row0 + l);
+    return v;
+  };
+  auto gather = [&](int idx, int cc, float4* st) {
 #pragma unroll
-      for (int ps = 0; ps < 4; ++ps) {
-        int ridx = __shfl(idx, rsub + 8 * ps);
-        st[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ridx >= 0) st[ps] = *reinterpret_cast<const float4*>(X + (long long)ridx * cin + cc * 32 + p * 4);
+    for (int ps = 0; ps < 4; ++ps) {
+      int ridx = __shfl(idx, rsub + 8 * ps);
+      st[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ridx >= 0) st[ps] = *reinterpret_cast<const float4*>(X + (long long)ridx * cin + cc * 32 + p * 4);
+    }
+  };
+
+  if (kmask != 0u) {
+    // software pipeline over the steps (k, cc): the gather of step s+1 is in flight while step s computes
+    int k_cur = __builtin_ctz(kmask), cc_cur = 0;
+    unsigned m_rest = kmask & (kmask - 1);
+    int idx_cur = load_idx(k_cur);
+    float4 st[4];
+    gather(idx_cur, 0, st);
+    while (true) {
+      // next step
+      int k_nxt = k_cur, cc_nxt = cc_cur + 1;
+      bool has_nxt = true;
+      if (cc_nxt == CC) {
+        cc_nxt = 0;
+        if (m_rest) {
+          k_nxt = __builtin_ctz(m_rest);
+          m_rest &= m_rest - 1;
+        } else {
+          has_nxt = false;
+        }
       }
-      WAVE_FENCE();   // previous iteration's fragment reads are done before the tile is overwritten
+      WAVE_FENCE();   // the previous step's fragment reads are done before the tile is overwritten
 #pragma unroll
-      for (int ps = 0; ps < 4; ++ps)
-        *reinterpret_cast<float4*>(&lds[w][rsub + 8 * ps][p * 4]) = st[ps];
+      for (int ps = 0; ps < 4; ++ps) *reinterpret_cast<float4*>(&lds[w][rsub + 8 * ps][p * 4]) = st[ps];
+      int idx_nxt = idx_cur;
+      if (has_nxt) {
+        if (k_nxt != k_cur) idx_nxt = load_idx(k_nxt);
+        gather(idx_nxt, cc_nxt, st);
+      }
       WAVE_FENCE();
       float4 a[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const float4*>(&lds[w][i][8 * q + 4 * h]);
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
-        const float4* wb = Wp + (((long long)k * TNB + nb0 + b) * Q + cc * 4) * 64 + l;
+        const float4* wb = Wp + (((long long)k_cur * TNB + nb0 + b) * Q + cc_cur * 4) * 64 + l;
+        float4 bv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bv[q] = wb[q * 64];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          float4 bv = wb[q * 64];
-          acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, bv.x, acc[b], 0, 0, 0);
-          acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, bv.y, acc[b], 0, 0, 0);
-          acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, bv.z, acc[b], 0, 0, 0);
-          acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, bv.w, acc[b], 0, 0, 0);
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, bv[q].x, acc[b], 0, 0, 0);
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, bv[q].y, acc[b], 0, 0, 0);
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, bv[q].z, acc[b], 0, 0, 0);
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, bv[q].w, acc[b], 0, 0, 0);
         }
       }
+      if (!has_nxt) break;
+      k_cur = k_nxt;
+      cc_cur = cc_nxt;
+      idx_cur = idx_nxt;
     }
   }
-  // epilogue: acc[b][r] is element (row = (r&3) + 8*(r>>2) + 4*h, col = i) of the 32x32 block
+  // epilogue: acc[b][r] is element (row = (r&3) + 8*(r>>2) + 4*h, col = i) of the wave's 32 x 32 block b
+  int orow_l = -1;
+  if (row_ok) orow_l = order ? order[row0 + l] : (int)(row0 + l);
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     const int col = (nb0 + b) * 32 + i;
-    const float bv = bias ? bias[col] : 0.f;
+    const float bvv = bias ? bias[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      long long row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (row < n_out) Y[row * cout + col] = acc[b][r] + bv;
+      int orow = __shfl(orow_l, (r & 3) + 8 * (r >> 2) + 4 * h);
+      if (orow >= 0) Y[(long long)orow * cout + col] = acc[b][r] + bvv;
     }
   }
 }
@@ -359,21 +399,25 @@ int gcl_pack_weights(const float* w, int32_t K, int32_t cin, int32_t cout, int32
   return GCL_OK;
 }
 
-int gcl_conv_fwd(const float* x, const float* wp, const int32_t* tbl, int64_t n_out, int32_t K, int32_t cin,
-                 int32_t cout, const float* bias, float* y, void* stream) {
+int gcl_conv_fwd(const float* x, const float* wp, const int32_t* tbl, const int32_t* order, const int32_t* tile_mask,
+                 int64_t n_out, int32_t K, int32_t cin, int32_t cout, const float* bias, float* y, void* stream) {
   GCL_CHECK_ARG(x && wp && y, "gcl_conv_fwd: null pointer");
-  GCL_CHECK_ARG(n_out > 0 && K >= 1, "gcl_conv_fwd: n_out and K must be positive");
+  GCL_CHECK_ARG(n_out > 0 && K >= 1 && K <= 32, "gcl_conv_fwd: n_out must be positive and 1 <= K <= 32");
   GCL_CHECK_ARG(tbl || K == 1, "gcl_conv_fwd: a neighbour table is required when K > 1");
+  GCL_CHECK_ARG((order == nullptr) == (tile_mask == nullptr), "gcl_conv_fwd: order and tile_mask go together");
   GCL_CHECK_ARG(cin % 32 == 0 && cout % 32 == 0 && cin > 0 && cout > 0,
                 "gcl_conv_fwd: Cin (%d) and Cout (%d) must be positive multiples of 32", cin, cout);
   hipStream_t st = (hipStream_t)stream;
   unsigned gx = (unsigned)cdiv(n_out, CONV_ROWS);
-  if (cout % 64 == 0) {
-    hipLaunchKernelGGL(k_conv_fwd<2>, dim3(gx, cout / 64), dim3(256), 0, st, x, (const float4*)wp, tbl,
-                       (long long)n_out, K, cin, cout, bias, y);
+  if (cout % 128 == 0) {
+    hipLaunchKernelGGL(k_conv_fwd<4>, dim3(gx, cout / 128), dim3(256), 0, st, x, (const float4*)wp, tbl, order,
+                       tile_mask, (long long)n_out, K, cin, cout, bias, y);
+  } else if (cout % 64 == 0) {
+    hipLaunchKernelGGL(k_conv_fwd<2>, dim3(gx, cout / 64), dim3(256), 0, st, x, (const float4*)wp, tbl, order,
+                       tile_mask, (long long)n_out, K, cin, cout, bias, y);
   } else {
-    hipLaunchKernelGGL(k_conv_fwd<1>, dim3(gx, cout / 32), dim3(256), 0, st, x, (const float4*)wp, tbl,
-                       (long long)n_out, K, cin, cout, bias, y);
+    hipLaunchKernelGGL(k_conv_fwd<1>, dim3(gx, cout / 32), dim3(256), 0, st, x, (const float4*)wp, tbl, order,
+                       tile_mask, (long long)n_out, K, cin, cout, bias, y);
   }
   GCL_CHECK_LAUNCH();
   return GCL_OK;

@@ -67,16 +67,37 @@ __global__ void __launch_bounds__(256) k_bn_reduce(const float* __restrict__ x, 
   }
 }
 
-__global__ void k_bn_stats_final(const double* __restrict__ partial, int nwg, long long n, int c, float eps,
-                                 float momentum, float* running_mean, float* running_var, float* mean,
-                                 float* rstd) {
-  int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= c) return;
-  double s = 0, ss = 0;
-  for (int b = 0; b < nwg; ++b) {
-    s += partial[(long long)b * 2 * c + ch];
-    ss += partial[(long long)b * 2 * c + c + ch];
-  }
+// ordered (deterministic) sum of the per-workgroup partials of 16 channels by one 256-thread workgroup:
+// thread = (channel ch = t & 15, slice sl = t >> 4) sums partials sl, sl+16, ...; slices are then added in order.
+__device__ __forceinline__ void reduce_partials16(const double* __restrict__ partial, int nwg, int c, int ch,
+                                                  double& s, double& ss) {
+  __shared__ double red[2][16][17];
+  const int sl = threadIdx.x >> 4, cl = threadIdx.x & 15;
+  double a = 0, b = 0;
+  if (ch < c)
+    for (int w = sl; w < nwg; w += 16) {
+      a += partial[(long long)w * 2 * c + ch];
+      b += partial[(long long)w * 2 * c + c + ch];
+    }
+  red[0][sl][cl] = a;
+  red[1][sl][cl] = b;
+  __syncthreads();
+  s = 0;
+  ss = 0;
+  if (sl == 0)
+    for (int q = 0; q < 16; ++q) {
+      s += red[0][q][cl];
+      ss += red[1][q][cl];
+    }
+}
+
+__global__ void __launch_bounds__(256) k_bn_stats_final(const double* __restrict__ partial, int nwg, long long n,
+                                                        int c, float eps, float momentum, float* running_mean,
+                                                        float* running_var, float* mean, float* rstd) {
+  int ch = blockIdx.x * 16 + (threadIdx.x & 15);
+  double s, ss;
+  reduce_partials16(partial, nwg, c, ch, s, ss);
+  if ((threadIdx.x >> 4) != 0 || ch >= c) return;
   double m = s / (double)n;
   double var = ss / (double)n - m * m;
   if (var < 0) var = 0;
@@ -89,14 +110,12 @@ __global__ void k_bn_stats_final(const double* __restrict__ partial, int nwg, lo
   }
 }
 
-__global__ void k_bn_bwd_final(const double* __restrict__ partial, int nwg, int c, float* sum_g, float* sum_gx) {
-  int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= c) return;
-  double s = 0, ss = 0;
-  for (int b = 0; b < nwg; ++b) {
-    s += partial[(long long)b * 2 * c + ch];
-    ss += partial[(long long)b * 2 * c + c + ch];
-  }
+__global__ void __launch_bounds__(256) k_bn_bwd_final(const double* __restrict__ partial, int nwg, int c,
+                                                      float* sum_g, float* sum_gx) {
+  int ch = blockIdx.x * 16 + (threadIdx.x & 15);
+  double s, ss;
+  reduce_partials16(partial, nwg, c, ch, s, ss);
+  if ((threadIdx.x >> 4) != 0 || ch >= c) return;
   sum_g[ch] = (float)s;
   sum_gx[ch] = (float)ss;
 }
@@ -179,7 +198,7 @@ int gcl_bn_stats(const float* x, int64_t n, int32_t c, float eps, float momentum
   int nwg = (int)cdiv(n, BN_ROWS_PER_WG);
   hipLaunchKernelGGL(k_bn_reduce<false>, dim3(nwg), dim3(256), 0, st, x, (const float*)nullptr,
                      (const float*)nullptr, (long long)n, c, (const float*)nullptr, (const float*)nullptr, 0, scratch);
-  hipLaunchKernelGGL(k_bn_stats_final, dim3((unsigned)cdiv(c, 64)), dim3(64), 0, st, (const double*)scratch, nwg,
+  hipLaunchKernelGGL(k_bn_stats_final, dim3((unsigned)cdiv(c, 16)), dim3(256), 0, st, (const double*)scratch, nwg,
                      (long long)n, c, eps, momentum, running_mean, running_var, mean, rstd);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
@@ -207,7 +226,7 @@ int gcl_bn_bwd_reduce(const float* x, const float* dy, const float* y, int64_t n
   int nwg = (int)cdiv(n, BN_ROWS_PER_WG);
   hipLaunchKernelGGL(k_bn_reduce<true>, dim3(nwg), dim3(256), 0, st, x, dy, y, (long long)n, c, mean, rstd, relu,
                      scratch);
-  hipLaunchKernelGGL(k_bn_bwd_final, dim3((unsigned)cdiv(c, 64)), dim3(64), 0, st, (const double*)scratch, nwg, c,
+  hipLaunchKernelGGL(k_bn_bwd_final, dim3((unsigned)cdiv(c, 16)), dim3(256), 0, st, (const double*)scratch, nwg, c,
                      sum_g, sum_gx);
   GCL_CHECK_LAUNCH();
   return GCL_OK;

@@ -82,6 +82,14 @@ int gcl_kernel_map(const int32_t* coords_out, int64_t n_out, const int64_t* tabl
 int gcl_kernel_map_pairs(const int32_t* nbr, int32_t K, int64_t n_out, const int64_t* seg_off_host,
                          int32_t* scratch, int32_t* pair_in, int32_t* pair_out, void* stream);
 
+/* Row ordering for the output-stationary convolution: sorts the rows of a [K][n] neighbour table (K <= 27) by
+ * their K-bit presence mask (stable radix sort), so that the rows of a 32-row wave tile need nearly the same
+ * offsets.  order[j] = original row at sorted position j; tbl_sorted[k*n + j] = tbl[k*n + order[j]];
+ * tile_mask[t] = OR of the masks of sorted rows 32t .. 32t+31.  scratch: int32[gcl_table_sort_scratch_len(n)]. */
+int64_t gcl_table_sort_scratch_len(int64_t n);
+int gcl_table_sort(const int32_t* tbl, int32_t K, int64_t n, int32_t* scratch, int32_t* order,
+                   int32_t* tbl_sorted, int32_t* tile_mask, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Sparse convolution (fp32, exact-f32 MFMA).
  * gcl_pack_weights: W [K, Cin, Cout] -> MFMA B-fragment order.
@@ -89,12 +97,14 @@ int gcl_kernel_map_pairs(const int32_t* nbr, int32_t K, int64_t n_out, const int
  *   mode 1: transposed per offset      (Cin_eff = Cout, Cout_eff = Cin,  k kept)     input-gradient, in != out map
  *   mode 2: transposed + offsets mirrored (k -> K-1-k)                               input-gradient, same map
  *   wp: float[K * Cin * Cout].  Cin, Cout multiples of 32.
- * gcl_conv_fwd: Y[v] = sum_k X[tbl[k*n_out+v]] . Wp_k (+ bias); tbl == NULL means K == 1, identity.
+ * gcl_conv_fwd: Y[row(j)] = sum_k X[tbl[k*n_out+j]] . Wp_k (+ bias); tbl == NULL means K == 1, identity.
+ *   With (order, tile_mask) from gcl_table_sort, `tbl` is the PERMUTED table, row(j) = order[j] and each 32-row
+ *   wave tile visits only the offsets of tile_mask; with NULLs, row(j) = j and every offset is visited.
  *   Output-stationary (no atomics, deterministic).  The same entry computes the input gradient when given
- *   the opposite table and mode-1/2 weights. */
+ *   the opposite table and mode-1/2 weights.  K <= 32. */
 int gcl_pack_weights(const float* w, int32_t K, int32_t cin, int32_t cout, int32_t mode, float* wp, void* stream);
-int gcl_conv_fwd(const float* x, const float* wp, const int32_t* tbl, int64_t n_out, int32_t K,
-                 int32_t cin, int32_t cout, const float* bias, float* y, void* stream);
+int gcl_conv_fwd(const float* x, const float* wp, const int32_t* tbl, const int32_t* order, const int32_t* tile_mask,
+                 int64_t n_out, int32_t K, int32_t cin, int32_t cout, const float* bias, float* y, void* stream);
 
 /* dW[k] = sum over pairs of offset k of  A[pair_a]^T . B[pair_b]   (A: [*, ca], B: [*, cb]) -> dw [K, ca, cb].
  * Forward conv: A = X, pair_a = pair_in, B = dY, pair_b = pair_out.  Transposed conv: roles swapped.
