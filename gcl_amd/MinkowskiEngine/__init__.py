@@ -20,11 +20,11 @@ from .. import _lib
 from . import utils
 from . import MinkowskiFunctional  # noqa: F401  (import MinkowskiEngine.MinkowskiFunctional as MEF)
 from .core import CoordinateManager, CoordinateMapKey, SparseTensor, cat
-from .ops import batch_norm, sparse_conv
+from .ops import batch_norm, set_conv_precision, sparse_conv
 
 __all__ = ["SparseTensor", "CoordinateManager", "CoordinateMapKey", "MinkowskiConvolution",
            "MinkowskiConvolutionTranspose", "MinkowskiBatchNorm", "MinkowskiInstanceNorm", "MinkowskiNetwork",
-           "MinkowskiFunctional", "cat", "utils"]
+           "MinkowskiFunctional", "cat", "utils", "set_conv_precision"]
 
 
 class MinkowskiNetwork(nn.Module):

@@ -1,8 +1,28 @@
 """torch.autograd wrappers around the C-ABI kernels (include/gcl_amd.h).  GPU tensors only."""
+import os
+
 import torch
 from torch.autograd.function import once_differentiable
 
 from .. import _lib
+
+# Arithmetic of the MFMA convolution kernels (forward and input gradient):
+#   "f32"    exact-f32 MFMA (v_mfma_f32_32x32x2_f32)
+#   "bf16x6" fp32 operands split into 3 bf16 planes, 6 MFMA terms, fp32 accumulate -- error vs the fp64 oracle equal
+#            to native fp32 (tests/test_gpu_parity.py), 2.7x the MFMA rate  [default]
+#   "bf16x3" 2 planes, 3 terms (~1.5e-5 relative), 5.3x the MFMA rate
+_PREC_CODES = {"f32": 0, "bf16x3": 2, "bf16x6": 3}
+PRECISION = os.environ.get("GCL_CONV_PRECISION", "bf16x6")
+if PRECISION not in _PREC_CODES:
+    raise ValueError(f"GCL_CONV_PRECISION must be one of {sorted(_PREC_CODES)}")
+
+
+def set_conv_precision(name):
+    global PRECISION
+    if name not in _PREC_CODES:
+        raise ValueError(f"precision must be one of {sorted(_PREC_CODES)}")
+    PRECISION = name
+
 
 # bench.py sets this to a list to time individual launches with events on the launch stream:
 # entries are (kernel name, start event, end event, pairs, cin, cout)
@@ -28,24 +48,24 @@ class _Timed:
             PROFILE.append(self.rec)
 
 
-def _conv_launch(lib, x, wp, table, n_out, K, cin, cout, bias, pairs=0):
-    """``table`` = (tbl, order, tile_mask) from KernelMap.sorted_table(), or None for a kernel_size-1 conv."""
+def _conv_launch(lib, x, Wk, mode, table, n_out, cin, cout, bias, pairs=0):
+    """One output-stationary convolution launch.  ``Wk`` [K, *, *] is packed for ``mode`` (0 forward, 1 transposed,
+    2 transposed + mirrored offsets) in the current precision; ``table`` = (tbl, order, tile_mask) from
+    KernelMap.sorted_table(), or None for a kernel_size-1 conv; (cin, cout) are the EFFECTIVE widths of the launch."""
+    prec = _PREC_CODES[PRECISION]
+    K, wc_in, wc_out = Wk.shape
+    wp = torch.empty(lib.gcl_pack_weights_bytes(K, wc_in, wc_out, prec), dtype=torch.uint8, device=Wk.device)
+    _lib.check(lib.gcl_pack_weights(_lib.ptr(Wk, torch.float32), K, wc_in, wc_out, mode, prec, _lib.ptr(wp),
+                                    _lib.stream()), "gcl_pack_weights")
     tbl, order, tile_mask = table if table is not None else (None, None, None)
     y = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
-    name = "k_conv_fwd<4>" if cout % 128 == 0 else ("k_conv_fwd<2>" if cout % 64 == 0 else "k_conv_fwd<1>")
+    nb = 4 if cout % 128 == 0 else (2 if cout % 64 == 0 else 1)
+    name = f"k_conv_fwd<{nb}>" if prec == 0 else f"k_conv_fwd_split<{nb},{prec}>"
     with _Timed(name, pairs, cin, cout):
-        _lib.check(lib.gcl_conv_fwd(_lib.ptr(x, torch.float32), _lib.ptr(wp), _lib.ptr(tbl), _lib.ptr(order),
+        _lib.check(lib.gcl_conv_fwd(_lib.ptr(x, torch.float32), _lib.ptr(wp), prec, _lib.ptr(tbl), _lib.ptr(order),
                                     _lib.ptr(tile_mask), n_out, K, cin, cout, _lib.ptr(bias), _lib.ptr(y),
                                     _lib.stream()), "gcl_conv_fwd")
     return y
-
-
-def _pack(lib, Wk, mode):
-    K, cin, cout = Wk.shape
-    wp = torch.empty(K * cin * cout, dtype=torch.float32, device=Wk.device)
-    _lib.check(lib.gcl_pack_weights(_lib.ptr(Wk, torch.float32), K, cin, cout, mode, _lib.ptr(wp), _lib.stream()),
-               "gcl_pack_weights")
-    return wp
 
 
 class _SparseConvFn(torch.autograd.Function):
@@ -70,7 +90,7 @@ class _SparseConvFn(torch.autograd.Function):
             tbl = None if kmap is None else kmap.sorted_table(transposed=transpose)
             b = bias.detach().contiguous().view(-1) if bias is not None else None
             ctx.pairs = kmap.n_pairs if kmap is not None else n_out
-            y = _conv_launch(lib, x, _pack(lib, Wk, 0), tbl, n_out, K, cin, cout, b, ctx.pairs)
+            y = _conv_launch(lib, x, Wk, 0, tbl, n_out, cin, cout, b, ctx.pairs)
         ctx.save_for_backward(x, Wk)
         ctx.kmap, ctx.transpose, ctx.mgr, ctx.w_shape, ctx.has_bias = kmap, transpose, mgr, W.shape, bias is not None
         return y
@@ -95,7 +115,7 @@ class _SparseConvFn(torch.autograd.Function):
                 mode, tbl = 2, kmap.sorted_table(transposed=False)
             else:
                 mode, tbl = 1, kmap.sorted_table(transposed=True)
-            dx = _conv_launch(lib, dy, _pack(lib, Wk, mode), tbl, x.shape[0], K, cout, cin, None, ctx.pairs)
+            dx = _conv_launch(lib, dy, Wk, mode, tbl, x.shape[0], cout, cin, None, ctx.pairs)
         if ctx.needs_input_grad[1]:
             dW = torch.empty_like(Wk)
             if ctx.stem:

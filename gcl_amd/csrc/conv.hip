@@ -169,6 +169,213 @@ __global__ void __launch_bounds__(256) k_conv_fwd(const float* __restrict__ X, c
 }
 
 // ---------------------------------------------------------------------------------------------------
+// split-precision forward / input-gradient: fp32 operands split into PL bf16 planes (hi, mid[, lo]) and multiplied
+// with v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  PL = 3 keeps 24 significand bits: hh + hm + mh + mm + hl + lh,
+// 6 MFMA terms -- measured error against the fp64 oracle equals native fp32 at 2.7x the MFMA rate of
+// the exact-f32 instruction; PL = 2 (hh + hm + mh, ~1.5e-5) runs at 5.3x.
+// Structure: 128 output rows per workgroup (wave w owns rows 32w..32w+31 and gathers them into its private LDS tile
+// exactly as in k_conv_fwd), but the weight block of step (k, cc) is staged ONCE per workgroup in LDS and shared by
+// the four waves (L2 -> CU weight traffic / 4: with the faster MFMA the per-wave weight stream of k_conv_fwd would
+// exceed the L2 bandwidth share of a CU).  A wave whose own rows lack offset k skips its gather and MFMAs.
+// ---------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int PL>
+__device__ __forceinline__ void split8(const float4& f0, const float4& f1, bf16x8* pl) {
+  float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    __bf16 hi = (__bf16)v[j];
+    float r = v[j] - (float)hi;
+    __bf16 mid = (__bf16)r;
+    pl[0][j] = hi;
+    pl[1][j] = mid;
+    if (PL == 3) pl[2][j] = (__bf16)(r - (float)mid);
+  }
+}
+
+// wp16 (bf16x8 units): [(((k*CC + cc)*TNB + nb)*2 + m)*PL + pl][lane = h*32 + j][jj]
+//                      = plane pl of W_eff[k][cc*32 + 16m + 8h + jj][32 nb + j]
+template <int PL>
+__global__ void k_pack_weights_split(const float* __restrict__ w, int K, int cin, int cout, int mode, __bf16* wp) {
+  long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long total = (long long)K * cin * cout;
+  if (o >= total) return;
+  int cin_e = mode == 0 ? cin : cout;
+  int cout_e = mode == 0 ? cout : cin;
+  int CC = cin_e / 32, TNB = cout_e / 32;
+  int jj = (int)(o & 7);
+  int l = (int)((o >> 3) & 63);
+  int h = l >> 5, j = l & 31;
+  long long rest = o >> 9;
+  int m = (int)(rest & 1);
+  rest >>= 1;
+  int nb = (int)(rest % TNB);
+  int cc = (int)((rest / TNB) % CC);
+  int k = (int)(rest / ((long long)TNB * CC));
+  int c = cc * 32 + 16 * m + 8 * h + jj;
+  int n = 32 * nb + j;
+  float v;
+  if (mode == 0) {
+    v = w[((long long)k * cin + c) * cout + n];
+  } else {
+    int ks = (mode == 2) ? (K - 1 - k) : k;
+    v = w[((long long)ks * cin + n) * cout + c];
+  }
+  __bf16 hi = (__bf16)v;
+  float r = v - (float)hi;
+  __bf16 mid = (__bf16)r;
+  long long blk = ((((long long)k * CC + cc) * TNB + nb) * 2 + m) * PL;
+  wp[((blk + 0) * 64 + l) * 8 + jj] = hi;
+  wp[((blk + 1) * 64 + l) * 8 + jj] = mid;
+  if (PL == 3) wp[((blk + 2) * 64 + l) * 8 + jj] = (__bf16)(r - (float)mid);
+}
+
+template <int NB, int PL>
+__global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict__ X, const u32x4* __restrict__ Wp,
+                                                        const int* __restrict__ tbl, const int* __restrict__ order,
+                                                        const int* __restrict__ tile_mask, long long n_out, int K,
+                                                        int cin, int cout, const float* __restrict__ bias,
+                                                        float* __restrict__ Y) {
+  constexpr int BLK = NB * 2 * PL * 64;                 // uint4 per (k, cc) weight block of this workgroup
+  constexpr int BREG = (BLK + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float Asm[4][32][LDS_STRIDE];
+  __shared__ __attribute__((aligned(16))) u32x4 Bsm[BLK];
+  __shared__ unsigned wmask[4];
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  const int i = l & 31, h = l >> 5;
+  const long long tile = (long long)blockIdx.x * 4 + w;
+  const long long row0 = tile * 32;
+  const bool active = row0 < n_out;
+  const int nb0 = blockIdx.y * NB;
+  const int TNB = cout >> 5, CC = cin >> 5;
+  const int p = l & 7, rsub = l >> 3;
+  const bool row_ok = active && (l < 32) && (row0 + l < n_out);
+
+  f32x16 acc[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+
+  unsigned mymask = 0u;
+  if (active) mymask = tile_mask ? (unsigned)tile_mask[tile] : ((K >= 32) ? ~0u : ((1u << K) - 1u));
+  mymask = __builtin_amdgcn_readfirstlane(mymask);
+  if (l == 0) wmask[w] = mymask;
+  __syncthreads();
+  const unsigned wgmask = wmask[0] | wmask[1] | wmask[2] | wmask[3];
+
+  auto load_idx = [&](int k) -> int {
+    int v = -1;
+    if (row_ok) v = tbl ? tbl[(long long)k * n_out + row0 + l] : (int)(row0 + l);
+    return v;
+  };
+  auto gather = [&](int idx, int cc, float4* st) {
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      int ridx = __shfl(idx, rsub + 8 * ps);
+      st[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ridx >= 0) st[ps] = *reinterpret_cast<const float4*>(X + (long long)ridx * cin + cc * 32 + p * 4);
+    }
+  };
+#define GCL_LOAD_B(KK, CCV)                                                                       \
+  {                                                                                              \
+    const u32x4* src_ = Wp + (((long long)(KK)*CC + (CCV)) * TNB + nb0) * (2 * PL * 64);         \
+    _Pragma("unroll") for (int e = 0; e < BREG; ++e) {                                           \
+      if ((BLK % 256 == 0) || (e * 256 + t < BLK)) br[e] = src_[e * 256 + t];                    \
+    }                                                                                            \
+  }
+
+  if (wgmask != 0u) {
+    int k_cur = __builtin_ctz(wgmask), cc_cur = 0;
+    unsigned m_rest = wgmask & (wgmask - 1);
+    bool mine_cur = (mymask >> k_cur) & 1u;
+    int idx_cur = -1;
+    float4 st[4];
+    u32x4 br[BREG];
+    if (mine_cur) {
+      idx_cur = load_idx(k_cur);
+      gather(idx_cur, 0, st);
+    }
+    GCL_LOAD_B(k_cur, 0);
+    while (true) {
+      int k_nxt = k_cur, cc_nxt = cc_cur + 1;
+      bool has_nxt = true;
+      if (cc_nxt == CC) {
+        cc_nxt = 0;
+        if (m_rest) {
+          k_nxt = __builtin_ctz(m_rest);
+          m_rest &= m_rest - 1;
+        } else {
+          has_nxt = false;
+        }
+      }
+      __syncthreads();   // #1: every wave is done reading Bsm (and its own A tile) of the previous step
+      if (mine_cur) {
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) *reinterpret_cast<float4*>(&Asm[w][rsub + 8 * ps][p * 4]) = st[ps];
+      }
+#pragma unroll
+      for (int e = 0; e < BREG; ++e)
+        if ((BLK % 256 == 0) || (e * 256 + t < BLK)) Bsm[e * 256 + t] = br[e];
+      bool mine_nxt = false;
+      int idx_nxt = idx_cur;
+      if (has_nxt) {
+        mine_nxt = (mymask >> k_nxt) & 1u;
+        if (mine_nxt) {
+          if (k_nxt != k_cur || !mine_cur) idx_nxt = load_idx(k_nxt);
+          gather(idx_nxt, cc_nxt, st);
+        }
+        GCL_LOAD_B(k_nxt, cc_nxt);
+      }
+      __syncthreads();   // #2: A tiles and the shared weight block are in LDS
+      if (mine_cur) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          float4 f0 = *reinterpret_cast<const float4*>(&Asm[w][i][16 * m + 8 * h]);
+          float4 f1 = *reinterpret_cast<const float4*>(&Asm[w][i][16 * m + 8 * h + 4]);
+          bf16x8 ap[3];
+          split8<PL>(f0, f1, ap);
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            const u32x4* bb = Bsm + ((b * 2 + m) * PL) * 64 + l;
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, bb[0]), bm = __builtin_bit_cast(bf16x8, bb[64]);
+            if (PL == 3) {
+              const bf16x8 bl = __builtin_bit_cast(bf16x8, bb[128]);
+              acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[2], bh, acc[b], 0, 0, 0);
+              acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], bl, acc[b], 0, 0, 0);
+              acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], bm, acc[b], 0, 0, 0);
+            }
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], bh, acc[b], 0, 0, 0);
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], bm, acc[b], 0, 0, 0);
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], bh, acc[b], 0, 0, 0);
+          }
+        }
+      }
+      if (!has_nxt) break;
+      k_cur = k_nxt;
+      cc_cur = cc_nxt;
+      idx_cur = idx_nxt;
+      mine_cur = mine_nxt;
+    }
+  }
+  if (!active) return;
+  int orow_l = -1;
+  if (row_ok) orow_l = order ? order[row0 + l] : (int)(row0 + l);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int col = (nb0 + b) * 32 + i;
+    const float bvv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int orow = __shfl(orow_l, (r & 3) + 8 * (r >> 2) + 4 * h);
+      if (orow >= 0) Y[(long long)orow * cout + col] = acc[b][r] + bvv;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // weight gradient over compacted pair lists
 // ---------------------------------------------------------------------------------------------------
 struct SegOffW {
@@ -387,38 +594,57 @@ using namespace gcl;
 
 extern "C" {
 
-int gcl_pack_weights(const float* w, int32_t K, int32_t cin, int32_t cout, int32_t mode, float* wp, void* stream) {
+int64_t gcl_pack_weights_bytes(int32_t K, int32_t cin, int32_t cout, int32_t prec) {
+  long long n = (long long)K * cin * cout;
+  return prec == 0 ? n * 4 : n * 2 * prec;
+}
+
+int gcl_pack_weights(const float* w, int32_t K, int32_t cin, int32_t cout, int32_t mode, int32_t prec, void* wp,
+                     void* stream) {
   GCL_CHECK_ARG(w && wp, "gcl_pack_weights: null pointer");
   GCL_CHECK_ARG(K >= 1 && cin % 32 == 0 && cout % 32 == 0 && cin > 0 && cout > 0,
                 "gcl_pack_weights: Cin (%d) and Cout (%d) must be positive multiples of 32", cin, cout);
   GCL_CHECK_ARG(mode >= 0 && mode <= 2, "gcl_pack_weights: mode must be 0, 1 or 2");
+  GCL_CHECK_ARG(prec == 0 || prec == 2 || prec == 3, "gcl_pack_weights: prec must be 0 (f32), 2 (bf16x3) or 3 (bf16x6)");
   long long total = (long long)K * cin * cout;
-  hipLaunchKernelGGL(k_pack_weights, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, K, cin,
-                     cout, mode, wp);
+  dim3 grid((unsigned)cdiv(total, 256));
+  hipStream_t st = (hipStream_t)stream;
+  if (prec == 0) hipLaunchKernelGGL(k_pack_weights, grid, dim3(256), 0, st, w, K, cin, cout, mode, (float*)wp);
+  else if (prec == 2) hipLaunchKernelGGL(k_pack_weights_split<2>, grid, dim3(256), 0, st, w, K, cin, cout, mode, (__bf16*)wp);
+  else hipLaunchKernelGGL(k_pack_weights_split<3>, grid, dim3(256), 0, st, w, K, cin, cout, mode, (__bf16*)wp);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }
 
-int gcl_conv_fwd(const float* x, const float* wp, const int32_t* tbl, const int32_t* order, const int32_t* tile_mask,
-                 int64_t n_out, int32_t K, int32_t cin, int32_t cout, const float* bias, float* y, void* stream) {
+int gcl_conv_fwd(const float* x, const void* wp, int32_t prec, const int32_t* tbl, const int32_t* order,
+                 const int32_t* tile_mask, int64_t n_out, int32_t K, int32_t cin, int32_t cout, const float* bias,
+                 float* y, void* stream) {
   GCL_CHECK_ARG(x && wp && y, "gcl_conv_fwd: null pointer");
   GCL_CHECK_ARG(n_out > 0 && K >= 1 && K <= 32, "gcl_conv_fwd: n_out must be positive and 1 <= K <= 32");
   GCL_CHECK_ARG(tbl || K == 1, "gcl_conv_fwd: a neighbour table is required when K > 1");
   GCL_CHECK_ARG((order == nullptr) == (tile_mask == nullptr), "gcl_conv_fwd: order and tile_mask go together");
   GCL_CHECK_ARG(cin % 32 == 0 && cout % 32 == 0 && cin > 0 && cout > 0,
                 "gcl_conv_fwd: Cin (%d) and Cout (%d) must be positive multiples of 32", cin, cout);
+  GCL_CHECK_ARG(prec == 0 || prec == 2 || prec == 3, "gcl_conv_fwd: prec must be 0 (f32), 2 (bf16x3) or 3 (bf16x6)");
   hipStream_t st = (hipStream_t)stream;
   unsigned gx = (unsigned)cdiv(n_out, CONV_ROWS);
-  if (cout % 128 == 0) {
-    hipLaunchKernelGGL(k_conv_fwd<4>, dim3(gx, cout / 128), dim3(256), 0, st, x, (const float4*)wp, tbl, order,
-                       tile_mask, (long long)n_out, K, cin, cout, bias, y);
-  } else if (cout % 64 == 0) {
-    hipLaunchKernelGGL(k_conv_fwd<2>, dim3(gx, cout / 64), dim3(256), 0, st, x, (const float4*)wp, tbl, order,
-                       tile_mask, (long long)n_out, K, cin, cout, bias, y);
+  const int nb = (cout % 128 == 0) ? 4 : ((cout % 64 == 0) ? 2 : 1);
+  dim3 grid(gx, cout / (32 * nb));
+#define LAUNCH_F32(NBV)                                                                                          \
+  hipLaunchKernelGGL(k_conv_fwd<NBV>, grid, dim3(256), 0, st, x, (const float4*)wp, tbl, order, tile_mask,       \
+                     (long long)n_out, K, cin, cout, bias, y)
+#define LAUNCH_SPLIT(NBV, PLV)                                                                                   \
+  hipLaunchKernelGGL((k_conv_fwd_split<NBV, PLV>), grid, dim3(256), 0, st, x, (const u32x4*)wp, tbl, order,      \
+                     tile_mask, (long long)n_out, K, cin, cout, bias, y)
+  if (prec == 0) {
+    if (nb == 4) LAUNCH_F32(4); else if (nb == 2) LAUNCH_F32(2); else LAUNCH_F32(1);
+  } else if (prec == 2) {
+    if (nb == 4) LAUNCH_SPLIT(4, 2); else if (nb == 2) LAUNCH_SPLIT(2, 2); else LAUNCH_SPLIT(1, 2);
   } else {
-    hipLaunchKernelGGL(k_conv_fwd<1>, dim3(gx, cout / 32), dim3(256), 0, st, x, (const float4*)wp, tbl, order,
-                       tile_mask, (long long)n_out, K, cin, cout, bias, y);
+    if (nb == 4) LAUNCH_SPLIT(4, 3); else if (nb == 2) LAUNCH_SPLIT(2, 3); else LAUNCH_SPLIT(1, 3);
   }
+#undef LAUNCH_F32
+#undef LAUNCH_SPLIT
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }

@@ -96,15 +96,21 @@ int gcl_table_sort(const int32_t* tbl, int32_t K, int64_t n, int32_t* scratch, i
  *   mode 0: forward weights            (Cin_eff = Cin,  Cout_eff = Cout, k kept)
  *   mode 1: transposed per offset      (Cin_eff = Cout, Cout_eff = Cin,  k kept)     input-gradient, in != out map
  *   mode 2: transposed + offsets mirrored (k -> K-1-k)                               input-gradient, same map
- *   wp: float[K * Cin * Cout].  Cin, Cout multiples of 32.
+ *   prec 0: exact-f32 MFMA (v_mfma_f32_32x32x2_f32), wp = float[K * Cin * Cout];
+ *   prec 3: fp32 operands split into 3 bf16 planes, 6 bf16-MFMA terms, fp32 accumulate ("bf16x6": error vs fp64
+ *           equal to native fp32, 2.7x the MFMA rate);  prec 2: 2 planes, 3 terms ("bf16x3", ~1.5e-5, 5.3x);
+ *           wp = gcl_pack_weights_bytes(...) bytes of bf16 planes.  Cin, Cout multiples of 32.
  * gcl_conv_fwd: Y[row(j)] = sum_k X[tbl[k*n_out+j]] . Wp_k (+ bias); tbl == NULL means K == 1, identity.
  *   With (order, tile_mask) from gcl_table_sort, `tbl` is the PERMUTED table, row(j) = order[j] and each 32-row
  *   wave tile visits only the offsets of tile_mask; with NULLs, row(j) = j and every offset is visited.
  *   Output-stationary (no atomics, deterministic).  The same entry computes the input gradient when given
  *   the opposite table and mode-1/2 weights.  K <= 32. */
-int gcl_pack_weights(const float* w, int32_t K, int32_t cin, int32_t cout, int32_t mode, float* wp, void* stream);
-int gcl_conv_fwd(const float* x, const float* wp, const int32_t* tbl, const int32_t* order, const int32_t* tile_mask,
-                 int64_t n_out, int32_t K, int32_t cin, int32_t cout, const float* bias, float* y, void* stream);
+int64_t gcl_pack_weights_bytes(int32_t K, int32_t cin, int32_t cout, int32_t prec);
+int gcl_pack_weights(const float* w, int32_t K, int32_t cin, int32_t cout, int32_t mode, int32_t prec, void* wp,
+                     void* stream);
+int gcl_conv_fwd(const float* x, const void* wp, int32_t prec, const int32_t* tbl, const int32_t* order,
+                 const int32_t* tile_mask, int64_t n_out, int32_t K, int32_t cin, int32_t cout, const float* bias,
+                 float* y, void* stream);
 
 /* dW[k] = sum over pairs of offset k of  A[pair_a]^T . B[pair_b]   (A: [*, ca], B: [*, cb]) -> dw [K, ca, cb].
  * Forward conv: A = X, pair_a = pair_in, B = dY, pair_b = pair_out.  Transposed conv: roles swapped.
