@@ -119,6 +119,7 @@ class CoordinateManager:
         self._checked = set()
         self._kmaps = {}
         self._identity = {}
+        self._bitmap = None
 
     # -- coordinate maps -----------------------------------------------------------------------------------
     def _check_status(self, t):
@@ -173,11 +174,14 @@ class CoordinateManager:
         n_in, n_out = C_in.shape[0], C_out.shape[0]
         K = kernel_size ** 3
         nbr = torch.empty((K, n_out), dtype=torch.int32, device=self.device)
-        nbr_t = None if stride == 1 else torch.empty((K, n_in), dtype=torch.int32, device=self.device)
+        same = stride == 1
+        nbr_t = None if same else torch.empty((K, n_in), dtype=torch.int32, device=self.device)
         counts = torch.empty(K, dtype=torch.int32, device=self.device)
+        if self._bitmap is None:
+            self._bitmap = torch.empty(lib.gcl_kernel_map_bitmap_len(), dtype=torch.int32, device=self.device)
         _lib.check(lib.gcl_kernel_map(_lib.ptr(C_out), n_out, _lib.ptr(table_in), cap_in, kernel_size, t_in,
-                                      _lib.ptr(nbr), _lib.ptr(nbr_t), n_in, _lib.ptr(counts), _lib.stream()),
-                   "gcl_kernel_map")
+                                      int(same), _lib.ptr(self._bitmap), _lib.ptr(nbr), _lib.ptr(nbr_t), n_in,
+                                      _lib.ptr(counts), _lib.stream()), "gcl_kernel_map")
         km = KernelMap(nbr, nbr_t, counts.tolist(), n_in, n_out, K)
         self._kmaps[key] = km
         return km

@@ -133,11 +133,13 @@ class _SparseConvFn(torch.autograd.Function):
                     pa, pb = (pout, pin) if transpose else (pin, pout)
                 scratch = torch.empty(lib.gcl_conv_bwd_weight_scratch_len(K, cin, cout, seg[-1]), dtype=torch.float32,
                                       device=x.device)
-                name = f"k_conv_bwd_weight<{64 if cin % 64 == 0 else 32},{64 if cout % 64 == 0 else 32}>"
+                prec = _PREC_CODES[PRECISION]
+                tile = f"{64 if cin % 64 == 0 else 32},{64 if cout % 64 == 0 else 32}"
+                name = f"k_conv_bwd_weight<{tile}>" if prec == 0 else f"k_conv_bwd_weight_split<{tile},{prec}>"
                 with _Timed(name, ctx.pairs, cin, cout):
                     _lib.check(lib.gcl_conv_bwd_weight(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(pa), _lib.ptr(pb), seg_host,
-                                                       K, cin, cout, _lib.ptr(scratch), _lib.ptr(dW), _lib.stream()),
-                               "gcl_conv_bwd_weight")
+                                                       K, cin, cout, prec, _lib.ptr(scratch), _lib.ptr(dW),
+                                                       _lib.stream()), "gcl_conv_bwd_weight")
             dW = dW.view(ctx.w_shape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             dbias = dy.sum(0, keepdim=True)

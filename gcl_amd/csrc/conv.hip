@@ -102,21 +102,27 @@ __global__ void __launch_bounds__(256) k_conv_fwd(const float* __restrict__ X, c
   };
 
   if (kmask != 0u) {
-    // software pipeline over the steps (k, cc): the gather of step s+1 is in flight while step s computes
+    // software pipeline over the steps (k, cc): the gather of step s+1 is in flight while step s computes, and the
+    // neighbour indices of the NEXT offset are loaded a whole offset ahead (no index -> gather dependency stall)
     int k_cur = __builtin_ctz(kmask), cc_cur = 0;
     unsigned m_rest = kmask & (kmask - 1);
+    int kq = -1;
+    if (m_rest) {
+      kq = __builtin_ctz(m_rest);
+      m_rest &= m_rest - 1;
+    }
     int idx_cur = load_idx(k_cur);
+    int idx_q = (kq >= 0) ? load_idx(kq) : -1;
     float4 st[4];
     gather(idx_cur, 0, st);
     while (true) {
-      // next step
       int k_nxt = k_cur, cc_nxt = cc_cur + 1;
-      bool has_nxt = true;
+      bool has_nxt = true, kchange = false;
       if (cc_nxt == CC) {
         cc_nxt = 0;
-        if (m_rest) {
-          k_nxt = __builtin_ctz(m_rest);
-          m_rest &= m_rest - 1;
+        if (kq >= 0) {
+          k_nxt = kq;
+          kchange = true;
         } else {
           has_nxt = false;
         }
@@ -126,8 +132,16 @@ __global__ void __launch_bounds__(256) k_conv_fwd(const float* __restrict__ X, c
       for (int ps = 0; ps < 4; ++ps) *reinterpret_cast<float4*>(&lds[w][rsub + 8 * ps][p * 4]) = st[ps];
       int idx_nxt = idx_cur;
       if (has_nxt) {
-        if (k_nxt != k_cur) idx_nxt = load_idx(k_nxt);
+        if (kchange) idx_nxt = idx_q;
         gather(idx_nxt, cc_nxt, st);
+        if (kchange) {
+          kq = -1;
+          if (m_rest) {
+            kq = __builtin_ctz(m_rest);
+            m_rest &= m_rest - 1;
+          }
+          idx_q = (kq >= 0) ? load_idx(kq) : -1;
+        }
       }
       WAVE_FENCE();
       float4 a[4];
@@ -290,23 +304,26 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
   if (wgmask != 0u) {
     int k_cur = __builtin_ctz(wgmask), cc_cur = 0;
     unsigned m_rest = wgmask & (wgmask - 1);
+    int kq = -1;
+    if (m_rest) {
+      kq = __builtin_ctz(m_rest);
+      m_rest &= m_rest - 1;
+    }
     bool mine_cur = (mymask >> k_cur) & 1u;
-    int idx_cur = -1;
+    int idx_cur = mine_cur ? load_idx(k_cur) : -1;
+    int idx_q = (kq >= 0 && ((mymask >> kq) & 1u)) ? load_idx(kq) : -1;   // one offset ahead of its use
     float4 st[4];
     u32x4 br[BREG];
-    if (mine_cur) {
-      idx_cur = load_idx(k_cur);
-      gather(idx_cur, 0, st);
-    }
+    if (mine_cur) gather(idx_cur, 0, st);
     GCL_LOAD_B(k_cur, 0);
     while (true) {
       int k_nxt = k_cur, cc_nxt = cc_cur + 1;
-      bool has_nxt = true;
+      bool has_nxt = true, kchange = false;
       if (cc_nxt == CC) {
         cc_nxt = 0;
-        if (m_rest) {
-          k_nxt = __builtin_ctz(m_rest);
-          m_rest &= m_rest - 1;
+        if (kq >= 0) {
+          k_nxt = kq;
+          kchange = true;
         } else {
           has_nxt = false;
         }
@@ -323,11 +340,17 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
       int idx_nxt = idx_cur;
       if (has_nxt) {
         mine_nxt = (mymask >> k_nxt) & 1u;
-        if (mine_nxt) {
-          if (k_nxt != k_cur || !mine_cur) idx_nxt = load_idx(k_nxt);
-          gather(idx_nxt, cc_nxt, st);
-        }
+        if (kchange) idx_nxt = idx_q;
+        if (mine_nxt) gather(idx_nxt, cc_nxt, st);
         GCL_LOAD_B(k_nxt, cc_nxt);
+        if (kchange) {
+          kq = -1;
+          if (m_rest) {
+            kq = __builtin_ctz(m_rest);
+            m_rest &= m_rest - 1;
+          }
+          idx_q = (kq >= 0 && ((mymask >> kq) & 1u)) ? load_idx(kq) : -1;
+        }
       }
       __syncthreads();   // #2: A tiles and the shared weight block are in LDS
       if (mine_cur) {
@@ -469,6 +492,133 @@ __global__ void __launch_bounds__(256) k_conv_bwd_weight(const float* __restrict
     }
   }
   flush(kcur);
+}
+
+// split-precision weight gradient: both operands are gathered activations, split on the fly into PL bf16 planes.
+// Same decomposition as k_conv_bwd_weight (wave-private LDS tiles, per-wave slabs, no workgroup barrier), plus a
+// two-deep software pipeline: pair indices are fetched two chunks ahead and rows one chunk ahead of their use.
+template <int TCA, int TCB, int PL>
+__global__ void __launch_bounds__(256) k_conv_bwd_weight_split(const float* __restrict__ A, const float* __restrict__ B,
+                                                               const int* __restrict__ pair_a,
+                                                               const int* __restrict__ pair_b, SegOffW seg, int K,
+                                                               int ca, int cb, long long n_chunks, int per,
+                                                               float* slabs) {
+  constexpr int NBI = TCA / 32, NBJ = TCB / 32;
+  constexpr int PA = TCA / 4, PB = TCB / 4;         // 16-byte pieces per row
+  constexpr int RA = 64 / PA, RB = 64 / PB;          // rows per load pass
+  constexpr int NPA = 32 / RA, NPB = 32 / RB;        // load passes per 32-pair tile
+  __shared__ __attribute__((aligned(16))) float As[4][32][TCA];
+  __shared__ __attribute__((aligned(16))) float Bs[4][32][TCB];
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = l & 31, h = l >> 5;
+  const int tiles_b = cb / TCB;
+  const int ca0 = (blockIdx.y / tiles_b) * TCA, cb0 = (blockIdx.y % tiles_b) * TCB;
+  const long long c0 = (long long)blockIdx.x * per;
+  const long long c1 = (c0 + per < n_chunks) ? c0 + per : n_chunks;
+  if (c0 >= c1) return;
+
+  f32x16 acc[NBI][NBJ];
+#pragma unroll
+  for (int a = 0; a < NBI; ++a)
+#pragma unroll
+    for (int b = 0; b < NBJ; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  auto flush = [&](int k) {
+    float* s = slabs + ((long long)(blockIdx.x + k) * 4 + w) * ((long long)ca * cb);
+#pragma unroll
+    for (int a = 0; a < NBI; ++a)
+#pragma unroll
+      for (int b = 0; b < NBJ; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int row = ca0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          s[(long long)row * cb + cb0 + b * 32 + i] = acc[a][b][r];
+          acc[a][b][r] = 0.f;
+        }
+  };
+  auto load_pairs = [&](long long c, int& ia, int& ib) {
+    ia = -1;
+    ib = -1;
+    if (c < c1 && l < 32) {
+      long long p0 = c * GCL_PAIR_CHUNK + w * 32 + l;
+      ia = pair_a[p0];
+      ib = pair_b[p0];
+    }
+  };
+
+  float4 ga[NPA], gb[NPB];
+#define GCL_GATHER(IA, IB)                                                                              \
+  {                                                                                                     \
+    _Pragma("unroll") for (int ps = 0; ps < NPA; ++ps) {                                                \
+      int ridx = __shfl(IA, l / PA + RA * ps);                                                          \
+      ga[ps] = make_float4(0.f, 0.f, 0.f, 0.f);                                                         \
+      if (ridx >= 0) ga[ps] = *reinterpret_cast<const float4*>(A + (long long)ridx * ca + ca0 + (l % PA) * 4); \
+    }                                                                                                   \
+    _Pragma("unroll") for (int ps = 0; ps < NPB; ++ps) {                                                \
+      int ridx = __shfl(IB, l / PB + RB * ps);                                                          \
+      gb[ps] = make_float4(0.f, 0.f, 0.f, 0.f);                                                         \
+      if (ridx >= 0) gb[ps] = *reinterpret_cast<const float4*>(B + (long long)ridx * cb + cb0 + (l % PB) * 4); \
+    }                                                                                                   \
+  }
+
+  int kcur = 0;
+  while (seg.off[kcur + 1] <= c0 * GCL_PAIR_CHUNK) ++kcur;
+  int ia1, ib1, ia2, ib2;
+  load_pairs(c0, ia1, ib1);
+  load_pairs(c0 + 1, ia2, ib2);
+  GCL_GATHER(ia1, ib1);
+  for (long long c = c0; c < c1; ++c) {
+    const long long pbase = c * GCL_PAIR_CHUNK;
+    if (pbase >= seg.off[kcur + 1]) {
+      flush(kcur);
+      while (seg.off[kcur + 1] <= pbase) ++kcur;
+    }
+    WAVE_FENCE();
+#pragma unroll
+    for (int ps = 0; ps < NPA; ++ps) *reinterpret_cast<float4*>(&As[w][l / PA + RA * ps][(l % PA) * 4]) = ga[ps];
+#pragma unroll
+    for (int ps = 0; ps < NPB; ++ps) *reinterpret_cast<float4*>(&Bs[w][l / PB + RB * ps][(l % PB) * 4]) = gb[ps];
+    // rows of chunk c+1 (indices arrived a chunk ago), indices of chunk c+2
+    ia1 = ia2;
+    ib1 = ib2;
+    if (c + 1 < c1) GCL_GATHER(ia1, ib1);
+    load_pairs(c + 2, ia2, ib2);
+    WAVE_FENCE();
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      bf16x8 pa[NBI][3];
+#pragma unroll
+      for (int a = 0; a < NBI; ++a) {
+        float v[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) v[jj] = As[w][16 * half + 8 * h + jj][a * 32 + i];
+        split8<PL>(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), pa[a]);
+      }
+#pragma unroll
+      for (int b = 0; b < NBJ; ++b) {
+        float v[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) v[jj] = Bs[w][16 * half + 8 * h + jj][b * 32 + i];
+        bf16x8 pb[3];
+        split8<PL>(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), pb);
+#pragma unroll
+        for (int a = 0; a < NBI; ++a) {
+          if (PL == 3) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[a][2], pb[0], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[a][0], pb[2], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[a][1], pb[1], acc[a][b], 0, 0, 0);
+          }
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[a][1], pb[0], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[a][0], pb[1], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[a][0], pb[0], acc[a][b], 0, 0, 0);
+        }
+      }
+    }
+  }
+  flush(kcur);
+#undef GCL_GATHER
 }
 
 __global__ void __launch_bounds__(256) k_bwd_weight_reduce(const float* __restrict__ slabs, SegOffW seg, int per,
@@ -655,12 +805,13 @@ int64_t gcl_conv_bwd_weight_scratch_len(int32_t K, int32_t ca, int32_t cb, int64
 }
 
 int gcl_conv_bwd_weight(const float* a, const float* b, const int32_t* pair_a, const int32_t* pair_b,
-                        const int64_t* seg_off_host, int32_t K, int32_t ca, int32_t cb, float* scratch, float* dw,
-                        void* stream) {
+                        const int64_t* seg_off_host, int32_t K, int32_t ca, int32_t cb, int32_t prec, float* scratch,
+                        float* dw, void* stream) {
   GCL_CHECK_ARG(a && b && pair_a && pair_b && seg_off_host && scratch && dw, "gcl_conv_bwd_weight: null pointer");
   GCL_CHECK_ARG(K >= 1 && K <= 125, "gcl_conv_bwd_weight: bad K");
   GCL_CHECK_ARG(ca % 32 == 0 && cb % 32 == 0 && ca > 0 && cb > 0,
                 "gcl_conv_bwd_weight: channel counts (%d, %d) must be positive multiples of 32", ca, cb);
+  GCL_CHECK_ARG(prec == 0 || prec == 2 || prec == 3, "gcl_conv_bwd_weight: prec must be 0, 2 or 3");
   hipStream_t st = (hipStream_t)stream;
   SegOffW seg;
   for (int k = 0; k <= K; ++k) seg.off[k] = seg_off_host[k];
@@ -671,13 +822,22 @@ int gcl_conv_bwd_weight(const float* a, const float* b, const int32_t* pair_a, c
   if (nc > 0) {
     int tca = (ca % 64 == 0) ? 64 : 32, tcb = (cb % 64 == 0) ? 64 : 32;
     dim3 grid(W, (ca / tca) * (cb / tcb));
-#define LAUNCH_BW(TA, TB)                                                                                       \
-  hipLaunchKernelGGL((k_conv_bwd_weight<TA, TB>), grid, dim3(256), 0, st, a, b, pair_a, pair_b, seg, K, ca, cb, \
-                     nc, per, scratch)
-    if (tca == 64 && tcb == 64) LAUNCH_BW(64, 64);
-    else if (tca == 64) LAUNCH_BW(64, 32);
-    else if (tcb == 64) LAUNCH_BW(32, 64);
-    else LAUNCH_BW(32, 32);
+#define LAUNCH_BW(TA, TB)                                                                                          \
+  {                                                                                                                \
+    if (prec == 0)                                                                                                 \
+      hipLaunchKernelGGL((k_conv_bwd_weight<TA, TB>), grid, dim3(256), 0, st, a, b, pair_a, pair_b, seg, K, ca, cb, \
+                         nc, per, scratch);                                                                        \
+    else if (prec == 2)                                                                                            \
+      hipLaunchKernelGGL((k_conv_bwd_weight_split<TA, TB, 2>), grid, dim3(256), 0, st, a, b, pair_a, pair_b, seg,  \
+                         K, ca, cb, nc, per, scratch);                                                             \
+    else                                                                                                           \
+      hipLaunchKernelGGL((k_conv_bwd_weight_split<TA, TB, 3>), grid, dim3(256), 0, st, a, b, pair_a, pair_b, seg,  \
+                         K, ca, cb, nc, per, scratch);                                                             \
+  }
+    if (tca == 64 && tcb == 64) LAUNCH_BW(64, 64)
+    else if (tca == 64) LAUNCH_BW(64, 32)
+    else if (tcb == 64) LAUNCH_BW(32, 64)
+    else LAUNCH_BW(32, 32)
 #undef LAUNCH_BW
   }
   hipLaunchKernelGGL(k_bwd_weight_reduce, dim3((unsigned)cdiv(mat, 256), K), dim3(256), 0, st, (const float*)scratch,

@@ -69,11 +69,15 @@ int gcl_stride_map(const int32_t* coords_in, int64_t n_in, int32_t t_out,
 
 /* Kernel map for kernel size ks^3 (x fastest in k), offsets scaled by `step` (= input tensor stride x dilation),
  * region centred on the OUTPUT coordinate:  nbr[k * n_out + v] = input row at c_out[v] + o_k * step, or -1.
- * If nbr_t != NULL (n_in rows): nbr_t[k * n_in + u] = v for every pair (caller need not pre-fill; the call
- * fills it with -1 first).  counts[k] (int32[K], device) = number of pairs of offset k. */
+ * same_map != 0: coords_out IS the input map (stride-1 conv): only offsets k <= K/2 are looked up, the mirror
+ *   entries nbr[(K-1-k) * n + u] = v are written from the hits; nbr_t must be NULL.
+ * same_map == 0 and nbr_t != NULL (n_in rows): nbr_t[k * n_in + u] = v for every pair (filled with -1 first).
+ * bitmap: optional int32[gcl_kernel_map_bitmap_len()] scratch: a presence bit per hashed key lets most absent
+ *   neighbours return without probing the table.  counts[k] (int32[K], device) = number of pairs of offset k. */
+int64_t gcl_kernel_map_bitmap_len(void);
 int gcl_kernel_map(const int32_t* coords_out, int64_t n_out, const int64_t* table_in, int64_t cap_in,
-                   int32_t ks, int32_t step, int32_t* nbr, int32_t* nbr_t, int64_t n_in,
-                   int32_t* counts, void* stream);
+                   int32_t ks, int32_t step, int32_t same_map, int32_t* bitmap, int32_t* nbr, int32_t* nbr_t,
+                   int64_t n_in, int32_t* counts, void* stream);
 
 /* Compact per-offset pair lists from nbr (out-major, ascending out row inside an offset), each offset's
  * segment padded with -1 to a multiple of GCL_PAIR_CHUNK:
@@ -114,11 +118,12 @@ int gcl_conv_fwd(const float* x, const void* wp, int32_t prec, const int32_t* tb
 
 /* dW[k] = sum over pairs of offset k of  A[pair_a]^T . B[pair_b]   (A: [*, ca], B: [*, cb]) -> dw [K, ca, cb].
  * Forward conv: A = X, pair_a = pair_in, B = dY, pair_b = pair_out.  Transposed conv: roles swapped.
- * Deterministic: per-workgroup partial slabs + ordered reduction.
+ * Deterministic: per-wave partial slabs + ordered reduction.  prec as in gcl_conv_fwd (both operands are split
+ * on the fly for prec 2 / 3).
  * scratch: float[gcl_conv_bwd_weight_scratch_len(...)]. */
 int64_t gcl_conv_bwd_weight_scratch_len(int32_t K, int32_t ca, int32_t cb, int64_t n_pairs_padded);
 int gcl_conv_bwd_weight(const float* a, const float* b, const int32_t* pair_a, const int32_t* pair_b,
-                        const int64_t* seg_off_host, int32_t K, int32_t ca, int32_t cb,
+                        const int64_t* seg_off_host, int32_t K, int32_t ca, int32_t cb, int32_t prec,
                         float* scratch, float* dw, void* stream);
 
 /* First layer (Cin <= 4, Cout == 32, any ks): VALU kernels over the nbr table. */

