@@ -42,12 +42,27 @@ class KernelMap:
     each offset segment padded with -1 to a multiple of GCL_PAIR_CHUNK.
     """
 
-    def __init__(self, nbr, nbr_t, counts, n_in, n_out, K):
-        self.nbr, self.nbr_t, self.counts = nbr, nbr_t, counts
+    def __init__(self, nbr, nbr_t, counts_dev, n_in, n_out, K):
+        self.nbr, self.nbr_t = nbr, nbr_t
         self.n_in, self.n_out, self.K = n_in, n_out, K
         self.same_map = nbr_t is None
         self._pairs = None
         self._sorted = {}
+        # per-offset pair counts: asynchronous copy into pinned memory; the host only waits for it when the weight
+        # gradient first needs the pair lists (long after the copy has completed) -- no sync in the forward pass
+        self._counts_dev = counts_dev
+        self._counts_host = torch.empty(K, dtype=torch.int32, pin_memory=True)
+        self._counts_host.copy_(counts_dev, non_blocking=True)
+        self._counts_event = torch.cuda.Event()
+        self._counts_event.record()
+        self._counts = None
+
+    @property
+    def counts(self):
+        if self._counts is None:
+            self._counts_event.synchronize()
+            self._counts = self._counts_host.tolist()
+        return self._counts
 
     @property
     def n_pairs(self):
@@ -125,40 +140,65 @@ class CoordinateManager:
     def _check_status(self, t):
         if t in self._checked:
             return
-        st = self._status[t].tolist()
+        self._raise_on_status(self._status[t].tolist())
+        self._checked.add(t)
+
+    @staticmethod
+    def _raise_on_status(st):
         if st[0]:
             raise ValueError(f"{st[0]} coordinates outside the packable range (batch < 65535, |x|,|y|,|z| < 32768)")
         if st[1]:
             raise ValueError(f"{st[1]} duplicate coordinates: ME.SparseTensor expects unique rows "
                              "(use ME.utils.sparse_quantize)")
-        self._checked.add(t)
 
     def get_coords(self, t):
         if t not in self._maps:
-            self._build_stride_map(t)
+            self._build_stride_maps(t)
         return self._maps[t][0]
 
     def num_rows(self, t):
         return self.get_coords(t).shape[0]
 
-    def _build_stride_map(self, t):
+    def _build_stride_maps(self, t):
+        """Builds every missing power-of-two level up to max(t, 8) in ONE chain of launches: level 2s is built from
+        level s with the row count of level s still on the device, and all counts come back in a single D2H read
+        (one host sync per SparseTensor instead of one per level)."""
         lib = _lib.load()
-        base_t = max(s for s in self._maps if s < t)
-        Cb, _, _ = self._maps[base_t]
-        n_in = Cb.shape[0]
-        cap = _pow2_cap(n_in)
-        table = torch.empty((cap, 2), dtype=torch.int64, device=self.device)
-        scratch = torch.empty(lib.gcl_scan_scratch_len(n_in), dtype=torch.int32, device=self.device)
-        out = torch.empty((n_in, 4), dtype=torch.int32, device=self.device)
-        meta = torch.empty(8, dtype=torch.int32, device=self.device)     # [0] = n_out, [4:8] = status
-        _lib.check(lib.gcl_stride_map(_lib.ptr(Cb), n_in, t, _lib.ptr(table), cap, _lib.ptr(scratch), _lib.ptr(out),
-                                      ctypes_offset(meta, 0), ctypes_offset(meta, 4), _lib.stream()),
-                   "gcl_stride_map")
-        m = meta.tolist()                                                # one D2H sync per level
-        if m[4]:
-            raise ValueError(f"{m[4]} strided coordinates outside the packable range")
-        self._maps[t] = (out[:m[0]], table, cap)
-        self._checked.add(t)
+        levels = []
+        s = max(self._maps)
+        while s < max(t, 8):
+            s *= 2
+            levels.append(s)
+        if t not in levels:
+            raise ValueError(f"tensor stride {t} is not a power-of-two multiple of the existing maps")
+        base_t = max(self._maps)
+        Cb = self._maps[base_t][0]
+        n_bound = Cb.shape[0]
+        meta = torch.zeros(8 * len(levels), dtype=torch.int32, device=self.device)   # per level: [0]=n_out, [4:8]=status
+        built = []
+        n_dev = None
+        for li, lv in enumerate(levels):
+            cap = _pow2_cap(n_bound)
+            table = torch.empty((cap, 2), dtype=torch.int64, device=self.device)
+            scratch = torch.empty(lib.gcl_scan_scratch_len(n_bound), dtype=torch.int32, device=self.device)
+            out = torch.empty((n_bound, 4), dtype=torch.int32, device=self.device)
+            _lib.check(lib.gcl_stride_map(_lib.ptr(Cb), n_bound, n_dev, lv, _lib.ptr(table), cap, _lib.ptr(scratch),
+                                          _lib.ptr(out), ctypes_offset(meta, 8 * li), ctypes_offset(meta, 8 * li + 4),
+                                          _lib.stream()), "gcl_stride_map")
+            built.append((lv, out, table, cap))
+            Cb, n_dev = out, ctypes_offset(meta, 8 * li)
+        first = 1 not in self._checked
+        vals = (torch.cat([self._status[1], meta]) if first else meta).tolist()   # the ONE D2H sync of the maps
+        if first:
+            self._raise_on_status(vals[:4])
+            self._checked.add(1)
+            vals = vals[4:]
+        m = vals
+        for li, (lv, out, table, cap) in enumerate(built):
+            if m[8 * li + 4]:
+                raise ValueError(f"{m[8 * li + 4]} strided coordinates outside the packable range")
+            self._maps[lv] = (out[:m[8 * li]], table, cap)
+            self._checked.add(lv)
 
     # -- kernel maps -----------------------------------------------------------------------------------------
     def get_kernel_map(self, t_in, kernel_size, stride):
@@ -166,7 +206,10 @@ class CoordinateManager:
         if key in self._kmaps:
             return self._kmaps[key]
         lib = _lib.load()
-        self._check_status(1)
+        if 1 not in self._checked:
+            # first map of this tensor: build the whole stride pyramid now, so that the validity check of the input
+            # coordinates and all level sizes share ONE host sync
+            self._build_stride_maps(max(8, t_in * stride))
         t_out = t_in * stride
         self.get_coords(t_in)
         C_in, table_in, cap_in = self._maps[t_in]
@@ -179,10 +222,11 @@ class CoordinateManager:
         counts = torch.empty(K, dtype=torch.int32, device=self.device)
         if self._bitmap is None:
             self._bitmap = torch.empty(lib.gcl_kernel_map_bitmap_len(), dtype=torch.int32, device=self.device)
+        scratch = torch.empty(lib.gcl_kernel_map_scratch_len(kernel_size, n_out), dtype=torch.int32, device=self.device)
         _lib.check(lib.gcl_kernel_map(_lib.ptr(C_out), n_out, _lib.ptr(table_in), cap_in, kernel_size, t_in,
-                                      int(same), _lib.ptr(self._bitmap), _lib.ptr(nbr), _lib.ptr(nbr_t), n_in,
-                                      _lib.ptr(counts), _lib.stream()), "gcl_kernel_map")
-        km = KernelMap(nbr, nbr_t, counts.tolist(), n_in, n_out, K)
+                                      int(same), _lib.ptr(self._bitmap), _lib.ptr(scratch), _lib.ptr(nbr),
+                                      _lib.ptr(nbr_t), n_in, _lib.ptr(counts), _lib.stream()), "gcl_kernel_map")
+        km = KernelMap(nbr, nbr_t, counts, n_in, n_out, K)
         self._kmaps[key] = km
         return km
 

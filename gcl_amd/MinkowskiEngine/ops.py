@@ -89,7 +89,8 @@ class _SparseConvFn(torch.autograd.Function):
         else:
             tbl = None if kmap is None else kmap.sorted_table(transposed=transpose)
             b = bias.detach().contiguous().view(-1) if bias is not None else None
-            ctx.pairs = kmap.n_pairs if kmap is not None else n_out
+            # pair counts reach the host asynchronously; only the profiler needs them in the forward pass
+            ctx.pairs = (kmap.n_pairs if kmap is not None else n_out) if PROFILE is not None else 0
             y = _conv_launch(lib, x, Wk, 0, tbl, n_out, cin, cout, b, ctx.pairs)
         ctx.save_for_backward(x, Wk)
         ctx.kmap, ctx.transpose, ctx.mgr, ctx.w_shape, ctx.has_bias = kmap, transpose, mgr, W.shape, bias is not None
@@ -104,6 +105,8 @@ class _SparseConvFn(torch.autograd.Function):
         kmap, transpose = ctx.kmap, ctx.transpose
         dy = dy.contiguous()
         dx = dW = dbias = None
+        if not ctx.stem and PROFILE is not None:
+            ctx.pairs = kmap.n_pairs if kmap is not None else x.shape[0]
         if ctx.needs_input_grad[0]:
             if ctx.stem:
                 raise NotImplementedError("input gradient of the Cin <= 4 first conv is not needed by the hot path")

@@ -23,9 +23,10 @@ SIGNATURES = {
     "gcl_device_count": (_i32, []),
     "gcl_coords_insert": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp]),
     "gcl_scan_scratch_len": (_i64, [_i64]),
-    "gcl_stride_map": (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "gcl_stride_map": (_i32, [_vp, _i64, _vp, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "gcl_kernel_map_bitmap_len": (_i64, []),
-    "gcl_kernel_map": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "gcl_kernel_map_scratch_len": (_i64, [_i32, _i64]),
+    "gcl_kernel_map": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "gcl_kernel_map_pairs": (_i32, [_vp, _i32, _i64, ctypes.POINTER(_i64), _vp, _vp, _vp, _vp]),
     "gcl_pack_weights_bytes": (_i64, [_i32, _i32, _i32, _i32]),
     "gcl_pack_weights": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),

@@ -405,6 +405,34 @@ struct SegOffW {
   long long off[130];
 };
 
+// Flush of the weight-gradient accumulators: the four waves of a workgroup hold partial sums over disjoint pairs;
+// they are added in wave order through LDS (deterministic) and ONE slab per (workgroup, offset) goes to memory.
+template <int TCA, int TCB>
+__device__ __forceinline__ void bwd_weight_flush(f32x16 (&acc)[TCA / 32][TCB / 32], float* lds, float* slab, int ca0,
+                                                 int cb0, int cb) {
+  constexpr int NBI = TCA / 32, NBJ = TCB / 32;
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();   // every wave is done with its gather tiles
+#pragma unroll
+  for (int a = 0; a < NBI; ++a)
+#pragma unroll
+    for (int b = 0; b < NBJ; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        lds[w * (TCA * TCB) + ((a * NBJ + b) * 16 + r) * 64 + l] = acc[a][b][r];
+        acc[a][b][r] = 0.f;
+      }
+  __syncthreads();
+  for (int e = threadIdx.x; e < TCA * TCB; e += 256) {
+    float v = lds[e] + lds[TCA * TCB + e] + lds[2 * TCA * TCB + e] + lds[3 * TCA * TCB + e];
+    int ll = e & 63, r = (e >> 6) & 15, blk = e >> 10;
+    int a = blk / NBJ, b = blk % NBJ;
+    int row = ca0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ll >> 5);
+    slab[(long long)row * cb + cb0 + b * 32 + (ll & 31)] = v;
+  }
+  __syncthreads();   // LDS goes back to the gather tiles
+}
+
 template <int TCA, int TCB>
 __global__ void __launch_bounds__(256) k_conv_bwd_weight(const float* __restrict__ A, const float* __restrict__ B,
                                                          const int* __restrict__ pair_a,
@@ -413,15 +441,16 @@ __global__ void __launch_bounds__(256) k_conv_bwd_weight(const float* __restrict
   constexpr int NBI = TCA / 32, NBJ = TCB / 32;
   constexpr int PA = TCA / 4, PB = TCB / 4;         // 16-byte pieces per row
   constexpr int RA = 64 / PA, RB = 64 / PB;          // rows per load pass
-  __shared__ __attribute__((aligned(16))) float As[4][32][TCA];
-  __shared__ __attribute__((aligned(16))) float Bs[4][32][TCB];
+  __shared__ __attribute__((aligned(16))) float lds_all[4 * 32 * (TCA + TCB)];
+  float (*As)[32][TCA] = reinterpret_cast<float (*)[32][TCA]>(lds_all);
+  float (*Bs)[32][TCB] = reinterpret_cast<float (*)[32][TCB]>(lds_all + 4 * 32 * TCA);
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = l & 31, h = l >> 5;
   const int tiles_b = cb / TCB;
   const int ca0 = (blockIdx.y / tiles_b) * TCA, cb0 = (blockIdx.y % tiles_b) * TCB;
   const long long c0 = (long long)blockIdx.x * per;
   const long long c1 = (c0 + per < n_chunks) ? c0 + per : n_chunks;
-  if (c0 >= c1) return;
+  if (c0 >= c1) return;   // uniform over the workgroup
 
   f32x16 acc[NBI][NBJ];
 #pragma unroll
@@ -432,17 +461,7 @@ __global__ void __launch_bounds__(256) k_conv_bwd_weight(const float* __restrict
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   auto flush = [&](int k) {
-    float* s = slabs + ((long long)(blockIdx.x + k) * 4 + w) * ((long long)ca * cb);
-#pragma unroll
-    for (int a = 0; a < NBI; ++a)
-#pragma unroll
-      for (int b = 0; b < NBJ; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          int row = ca0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          s[(long long)row * cb + cb0 + b * 32 + i] = acc[a][b][r];
-          acc[a][b][r] = 0.f;
-        }
+    bwd_weight_flush<TCA, TCB>(acc, lds_all, slabs + (long long)(blockIdx.x + k) * ((long long)ca * cb), ca0, cb0, cb);
   };
 
   int kcur = 0;
@@ -507,15 +526,16 @@ __global__ void __launch_bounds__(256) k_conv_bwd_weight_split(const float* __re
   constexpr int PA = TCA / 4, PB = TCB / 4;         // 16-byte pieces per row
   constexpr int RA = 64 / PA, RB = 64 / PB;          // rows per load pass
   constexpr int NPA = 32 / RA, NPB = 32 / RB;        // load passes per 32-pair tile
-  __shared__ __attribute__((aligned(16))) float As[4][32][TCA];
-  __shared__ __attribute__((aligned(16))) float Bs[4][32][TCB];
+  __shared__ __attribute__((aligned(16))) float lds_all[4 * 32 * (TCA + TCB)];
+  float (*As)[32][TCA] = reinterpret_cast<float (*)[32][TCA]>(lds_all);
+  float (*Bs)[32][TCB] = reinterpret_cast<float (*)[32][TCB]>(lds_all + 4 * 32 * TCA);
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = l & 31, h = l >> 5;
   const int tiles_b = cb / TCB;
   const int ca0 = (blockIdx.y / tiles_b) * TCA, cb0 = (blockIdx.y % tiles_b) * TCB;
   const long long c0 = (long long)blockIdx.x * per;
   const long long c1 = (c0 + per < n_chunks) ? c0 + per : n_chunks;
-  if (c0 >= c1) return;
+  if (c0 >= c1) return;   // uniform over the workgroup
 
   f32x16 acc[NBI][NBJ];
 #pragma unroll
@@ -526,17 +546,7 @@ __global__ void __launch_bounds__(256) k_conv_bwd_weight_split(const float* __re
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   auto flush = [&](int k) {
-    float* s = slabs + ((long long)(blockIdx.x + k) * 4 + w) * ((long long)ca * cb);
-#pragma unroll
-    for (int a = 0; a < NBI; ++a)
-#pragma unroll
-      for (int b = 0; b < NBJ; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          int row = ca0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          s[(long long)row * cb + cb0 + b * 32 + i] = acc[a][b][r];
-          acc[a][b][r] = 0.f;
-        }
+    bwd_weight_flush<TCA, TCB>(acc, lds_all, slabs + (long long)(blockIdx.x + k) * ((long long)ca * cb), ca0, cb0, cb);
   };
   auto load_pairs = [&](long long c, int& ia, int& ib) {
     ia = -1;
@@ -630,9 +640,7 @@ __global__ void __launch_bounds__(256) k_bwd_weight_reduce(const float* __restri
   if (seg.off[k + 1] > seg.off[k]) {
     long long first = seg.off[k] / GCL_PAIR_CHUNK, last = seg.off[k + 1] / GCL_PAIR_CHUNK - 1;
     long long lo = first / per, hi = last / per;
-    for (long long bx = lo; bx <= hi; ++bx)
-#pragma unroll
-      for (int w = 0; w < 4; ++w) s += slabs[((bx + k) * 4 + w) * mat + e];
+    for (long long bx = lo; bx <= hi; ++bx) s += slabs[(bx + k) * mat + e];
   }
   dw[(long long)k * mat + e] = s;
 }
@@ -679,53 +687,56 @@ __global__ void __launch_bounds__(256) k_stem_fwd(const float* __restrict__ x, c
   for (int c4 = 0; c4 < 8; ++c4) yo[c4] = make_float4(acc[4 * c4], acc[4 * c4 + 1], acc[4 * c4 + 2], acc[4 * c4 + 3]);
 }
 
-constexpr int STEM_ROWS_PER_WG = 2048;
+constexpr int STEM_ROWS_PER_WG = 1024;
 constexpr int STEM_KMAX = 125;
 
-// dW[k][ci][c] = sum_v x[nbr[k][v]][ci] * dY[v][c];  thread = (c = t & 31, kg = t >> 5), k = kg + 8 * kk
+// dW[k][ci][c] = sum_v x[nbr[k][v]][ci] * dY[v][c]  as an exact-f32 MFMA GEMM: M = K offsets (4 blocks of 32),
+// N = 32 channels, reduction over the output rows v.  A[i = offset][kk = row] is gathered through the neighbour
+// table, B[kk = row][j = channel] is a coalesced row of dY.  Per-workgroup slabs + ordered reduction (k_stem_reduce).
 __global__ void __launch_bounds__(256) k_stem_bwd_weight(const float* __restrict__ x, const float* __restrict__ dy,
                                                          const int* __restrict__ nbr, long long n_out, int K,
                                                          int cin, float* slabs) {
-  __shared__ float dys[64][32];
-  __shared__ float xg[STEM_KMAX][64];
-  const int t = threadIdx.x, c = t & 31, kg = t >> 5;
+  __shared__ float red[4][4 * 16 * 64];
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = l & 31, h = l >> 5;
   const long long r_begin = (long long)blockIdx.x * STEM_ROWS_PER_WG;
   long long r_end = r_begin + STEM_ROWS_PER_WG;
   if (r_end > n_out) r_end = n_out;
   for (int ci = 0; ci < cin; ++ci) {
-    float acc[16];
+    f32x16 acc[4];
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) acc[kk] = 0.f;
-    for (long long r0 = r_begin; r0 < r_end; r0 += 64) {
-      __syncthreads();
-      for (int e = t; e < 64 * 32; e += 256) {
-        long long r = r0 + (e >> 5);
-        dys[e >> 5][e & 31] = (r < r_end) ? dy[r * 32 + (e & 31)] : 0.f;
-      }
-      for (int e = t; e < K * 64; e += 256) {
-        int k = e >> 6, rr = e & 63;
-        long long r = r0 + rr;
-        float xv = 0.f;
-        if (r < r_end) {
-          int idx = nbr[(long long)k * n_out + r];
-          if (idx >= 0) xv = x[(long long)idx * cin + ci];
-        }
-        xg[k][rr] = xv;
-      }
-      __syncthreads();
-      for (int rr = 0; rr < 64; ++rr) {
-        float d = dys[rr][c];
+    for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-          int k = kg + 8 * kk;
-          if (k < K) acc[kk] = fmaf(xg[k][rr], d, acc[kk]);
+      for (int r = 0; r < 16; ++r) acc[kb][r] = 0.f;
+    for (long long r0 = r_begin + w * 32; r0 < r_end; r0 += 128) {
+#pragma unroll 4
+      for (int s = 0; s < 16; ++s) {
+        const long long row = r0 + 2 * s + h;
+        const bool valid = row < r_end;
+        const float b = valid ? dy[row * 32 + i] : 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+          const int k = kb * 32 + i;
+          float a = 0.f;
+          if (valid && k < K) {
+            int idx = nbr[(long long)k * n_out + row];
+            if (idx >= 0) a = x[(long long)idx * cin + ci];
+          }
+          acc[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[kb], 0, 0, 0);
         }
       }
     }
+    __syncthreads();
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      int k = kg + 8 * kk;
-      if (k < K) slabs[((long long)blockIdx.x * K * cin + (long long)k * cin + ci) * 32 + c] = acc[kk];
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[w][(kb * 16 + r) * 64 + l] = acc[kb][r];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 4 * 16 * 64; e += 256) {
+      float v = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+      int ll = e & 63, r = (e >> 6) & 15, kb = e >> 10;
+      int k = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ll >> 5);
+      if (k < K) slabs[((long long)blockIdx.x * K * cin + (long long)k * cin + ci) * 32 + (ll & 31)] = v;
     }
   }
 }
@@ -801,7 +812,7 @@ int gcl_conv_fwd(const float* x, const void* wp, int32_t prec, const int32_t* tb
 
 int64_t gcl_conv_bwd_weight_scratch_len(int32_t K, int32_t ca, int32_t cb, int64_t n_pairs_padded) {
   long long nc = n_pairs_padded / GCL_PAIR_CHUNK;
-  return (long long)(bwd_weight_wgs(nc) + K) * 4 * ca * cb;
+  return (long long)(bwd_weight_wgs(nc) + K) * ca * cb;
 }
 
 int gcl_conv_bwd_weight(const float* a, const float* b, const int32_t* pair_a, const int32_t* pair_b,

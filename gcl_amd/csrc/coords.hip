@@ -58,9 +58,10 @@ __device__ __forceinline__ int floor_div(int a, int b) {
   return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q;
 }
 
-__global__ void k_stride_insert(const int4* __restrict__ coords, long long n, int t_out, Slot* t, long long cap,
-                                int* status) {
+__global__ void k_stride_insert(const int4* __restrict__ coords, long long n, const int* __restrict__ n_dev,
+                                int t_out, Slot* t, long long cap, int* status) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n_dev) n = *n_dev;
   if (i >= n) return;
   int4 c = coords[i];
   c.y = floor_div(c.y, t_out) * t_out;
@@ -74,10 +75,14 @@ __global__ void k_stride_insert(const int4* __restrict__ coords, long long n, in
   atomicMin(&t[s].val, i);
 }
 
-__global__ void k_stride_flag(const int4* __restrict__ coords, long long n, int t_out, const Slot* t,
-                              long long cap, int* flag) {
+__global__ void k_stride_flag(const int4* __restrict__ coords, long long n_max, const int* __restrict__ n_dev,
+                              int t_out, const Slot* t, long long cap, int* flag) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i >= n_max) return;
+  if (n_dev && i >= *n_dev) {
+    flag[i] = 0;
+    return;
+  }
   int4 c = coords[i];
   c.y = floor_div(c.y, t_out) * t_out;
   c.z = floor_div(c.z, t_out) * t_out;
@@ -90,12 +95,12 @@ __global__ void k_stride_flag(const int4* __restrict__ coords, long long n, int 
   flag[i] = f;
 }
 
-__global__ void k_stride_emit(const int4* __restrict__ coords, long long n, int t_out, Slot* t, long long cap,
+__global__ void k_stride_emit(const int4* __restrict__ coords, long long n_max, int t_out, Slot* t, long long cap,
                               const int* __restrict__ flag, const int* __restrict__ pos, int4* coords_out,
                               int* n_out) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if (i == n - 1) *n_out = pos[i] + flag[i];
+  if (i >= n_max) return;
+  if (i == n_max - 1) *n_out = pos[i] + flag[i];
   if (!flag[i]) return;
   int4 c = coords[i];
   c.y = floor_div(c.y, t_out) * t_out;
@@ -222,11 +227,20 @@ __device__ __forceinline__ int lookup_row(const Slot* __restrict__ t, long long 
   return s >= 0 ? (int)t[s].val : -1;
 }
 
+// number of threads of the 256-thread block with `pred`, written by thread 0 (one plain store per block)
+__device__ __forceinline__ void block_count(bool pred, int* dst) {
+  __shared__ int wc[4];
+  unsigned long long m = __ballot(pred);
+  if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) *dst = wc[0] + wc[1] + wc[2] + wc[3];
+}
+
 __global__ void __launch_bounds__(256) k_kernel_map(const int4* __restrict__ coords_out, long long n_out,
                                                     const Slot* __restrict__ t, long long cap,
                                                     const unsigned* __restrict__ bitmap, int ks, int step,
                                                     int* __restrict__ nbr, int* __restrict__ nbr_t,
-                                                    long long n_in, int* counts) {
+                                                    long long n_in, int* blockcnt) {
   long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   int k = blockIdx.y;
   int r = ks / 2;
@@ -238,15 +252,14 @@ __global__ void __launch_bounds__(256) k_kernel_map(const int4* __restrict__ coo
     nbr[(long long)k * n_out + v] = u;
     if (nbr_t != nullptr && u >= 0) nbr_t[(long long)k * n_in + u] = (int)v;
   }
-  unsigned long long m = __ballot(u >= 0);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&counts[k], __popcll(m));
+  block_count(u >= 0, blockcnt + (long long)k * gridDim.x + blockIdx.x);
 }
 
 // same-map variant: blockIdx.y = k in [0, K/2]; the mirror half [K/2+1, K) was pre-filled with -1
 __global__ void __launch_bounds__(256) k_kernel_map_sym(const int4* __restrict__ coords, long long n,
                                                         const Slot* __restrict__ t, long long cap,
                                                         const unsigned* __restrict__ bitmap, int ks, int step,
-                                                        int* __restrict__ nbr, int* counts) {
+                                                        int* __restrict__ nbr, int* blockcnt) {
   long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int K = ks * ks * ks;
   int k = blockIdx.y;
@@ -266,11 +279,25 @@ __global__ void __launch_bounds__(256) k_kernel_map_sym(const int4* __restrict__
       if (u >= 0) nbr[(long long)(K - 1 - k) * n + u] = (int)v;   // c_u + o_{K-1-k} = c_v
     }
   }
-  unsigned long long m = __ballot(u >= 0);
-  if ((threadIdx.x & 63) == 0 && m) {
-    int c = __popcll(m);
-    atomicAdd(&counts[k], c);
-    if (k != K / 2) atomicAdd(&counts[K - 1 - k], c);
+  block_count(u >= 0, blockcnt + (long long)k * gridDim.x + blockIdx.x);
+}
+
+// counts[k] = sum of the per-block counts (ordered, no atomics); mirror offsets share the count in a same-map
+__global__ void __launch_bounds__(256) k_count_reduce(const int* __restrict__ blockcnt, int nblk, int K, int sym,
+                                                      int* counts) {
+  __shared__ int red[256];
+  const int k = blockIdx.x;
+  int s = 0;
+  for (int b = threadIdx.x; b < nblk; b += 256) s += blockcnt[(long long)k * nblk + b];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    counts[k] = red[0];
+    if (sym && k != K / 2) counts[K - 1 - k] = red[0];
   }
 }
 
@@ -450,8 +477,9 @@ int gcl_coords_insert(const int32_t* coords, int64_t n, int64_t* table, int64_t 
 
 int64_t gcl_scan_scratch_len(int64_t n) { return 2 * n + cdiv(n, SCAN_B) + 64; }
 
-int gcl_stride_map(const int32_t* coords_in, int64_t n_in, int32_t t_out, int64_t* table_out, int64_t cap_out,
-                   int32_t* scratch, int32_t* coords_out, int32_t* n_out_dev, int32_t* status, void* stream) {
+int gcl_stride_map(const int32_t* coords_in, int64_t n_in, const int32_t* n_in_dev, int32_t t_out, int64_t* table_out,
+                   int64_t cap_out, int32_t* scratch, int32_t* coords_out, int32_t* n_out_dev, int32_t* status,
+                   void* stream) {
   GCL_CHECK_ARG(coords_in && table_out && scratch && coords_out && n_out_dev && status, "gcl_stride_map: null pointer");
   GCL_CHECK_ARG(n_in > 0 && t_out >= 1, "gcl_stride_map: n_in and t_out must be positive");
   GCL_CHECK_ARG(is_pow2(cap_out) && cap_out >= 2 * n_in && cap_out >= 64, "gcl_stride_map: cap must be a power of two >= 2n");
@@ -463,10 +491,10 @@ int gcl_stride_map(const int32_t* coords_in, int64_t n_in, int32_t t_out, int64_
   GCL_CHECK_HIP(hipMemsetAsync(status, 0, 4 * sizeof(int32_t), st));
   hipLaunchKernelGGL(k_table_fill, dim3((unsigned)cdiv(cap_out, 256)), dim3(256), 0, st, (Slot*)table_out,
                      (long long)cap_out);
-  hipLaunchKernelGGL(k_stride_insert, dim3(g), dim3(256), 0, st, (const int4*)coords_in, (long long)n_in, t_out,
-                     (Slot*)table_out, (long long)cap_out, status);
-  hipLaunchKernelGGL(k_stride_flag, dim3(g), dim3(256), 0, st, (const int4*)coords_in, (long long)n_in, t_out,
-                     (const Slot*)table_out, (long long)cap_out, flag);
+  hipLaunchKernelGGL(k_stride_insert, dim3(g), dim3(256), 0, st, (const int4*)coords_in, (long long)n_in,
+                     (const int*)n_in_dev, t_out, (Slot*)table_out, (long long)cap_out, status);
+  hipLaunchKernelGGL(k_stride_flag, dim3(g), dim3(256), 0, st, (const int4*)coords_in, (long long)n_in,
+                     (const int*)n_in_dev, t_out, (const Slot*)table_out, (long long)cap_out, flag);
   GCL_CHECK_LAUNCH();
   int rc = device_scan(flag, n_in, pos, bs, st);
   if (rc) return rc;
@@ -478,17 +506,18 @@ int gcl_stride_map(const int32_t* coords_in, int64_t n_in, int32_t t_out, int64_
 }
 
 int64_t gcl_kernel_map_bitmap_len(void) { return BITMAP_WORDS; }
+int64_t gcl_kernel_map_scratch_len(int32_t ks, int64_t n_out) { return (long long)ks * ks * ks * cdiv(n_out, 256); }
 
 int gcl_kernel_map(const int32_t* coords_out, int64_t n_out, const int64_t* table_in, int64_t cap_in, int32_t ks,
-                   int32_t step, int32_t same_map, int32_t* bitmap, int32_t* nbr, int32_t* nbr_t, int64_t n_in,
-                   int32_t* counts, void* stream) {
-  GCL_CHECK_ARG(coords_out && table_in && nbr && counts, "gcl_kernel_map: null pointer");
+                   int32_t step, int32_t same_map, int32_t* bitmap, int32_t* scratch, int32_t* nbr, int32_t* nbr_t,
+                   int64_t n_in, int32_t* counts, void* stream) {
+  GCL_CHECK_ARG(coords_out && table_in && nbr && counts && scratch, "gcl_kernel_map: null pointer");
   GCL_CHECK_ARG(ks >= 1 && (ks & 1) && ks <= 5, "gcl_kernel_map: kernel size must be 1, 3 or 5");
   GCL_CHECK_ARG(n_out > 0 && step >= 1 && is_pow2(cap_in), "gcl_kernel_map: bad sizes");
   GCL_CHECK_ARG(!same_map || (nbr_t == nullptr && n_in == n_out), "gcl_kernel_map: same_map excludes nbr_t");
   hipStream_t st = (hipStream_t)stream;
   int K = ks * ks * ks;
-  GCL_CHECK_HIP(hipMemsetAsync(counts, 0, K * sizeof(int32_t), st));
+  int nblk = (int)cdiv(n_out, 256);
   if (bitmap) {
     GCL_CHECK_HIP(hipMemsetAsync(bitmap, 0, BITMAP_WORDS * sizeof(int32_t), st));
     hipLaunchKernelGGL(k_bitmap_fill, dim3((unsigned)cdiv(cap_in, 256)), dim3(256), 0, st, (const Slot*)table_in,
@@ -497,14 +526,16 @@ int gcl_kernel_map(const int32_t* coords_out, int64_t n_out, const int64_t* tabl
   if (same_map) {
     if (K > 1)
       GCL_CHECK_HIP(hipMemsetAsync(nbr + (size_t)(K / 2 + 1) * n_out, 0xFF, (size_t)(K / 2) * n_out * sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_kernel_map_sym, dim3((unsigned)cdiv(n_out, 256), K / 2 + 1), dim3(256), 0, st,
-                       (const int4*)coords_out, (long long)n_out, (const Slot*)table_in, (long long)cap_in,
-                       (const unsigned*)bitmap, ks, step, nbr, counts);
+    hipLaunchKernelGGL(k_kernel_map_sym, dim3(nblk, K / 2 + 1), dim3(256), 0, st, (const int4*)coords_out,
+                       (long long)n_out, (const Slot*)table_in, (long long)cap_in, (const unsigned*)bitmap, ks, step,
+                       nbr, scratch);
+    hipLaunchKernelGGL(k_count_reduce, dim3(K / 2 + 1), dim3(256), 0, st, (const int*)scratch, nblk, K, 1, counts);
   } else {
     if (nbr_t) GCL_CHECK_HIP(hipMemsetAsync(nbr_t, 0xFF, (size_t)K * n_in * sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_kernel_map, dim3((unsigned)cdiv(n_out, 256), K), dim3(256), 0, st, (const int4*)coords_out,
-                       (long long)n_out, (const Slot*)table_in, (long long)cap_in, (const unsigned*)bitmap, ks, step,
-                       nbr, nbr_t, (long long)n_in, counts);
+    hipLaunchKernelGGL(k_kernel_map, dim3(nblk, K), dim3(256), 0, st, (const int4*)coords_out, (long long)n_out,
+                       (const Slot*)table_in, (long long)cap_in, (const unsigned*)bitmap, ks, step, nbr, nbr_t,
+                       (long long)n_in, scratch);
+    hipLaunchKernelGGL(k_count_reduce, dim3(K), dim3(256), 0, st, (const int*)scratch, nblk, K, 0, counts);
   }
   GCL_CHECK_LAUNCH();
   return GCL_OK;

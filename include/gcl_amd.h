@@ -61,9 +61,11 @@ int gcl_coords_insert(const int32_t* coords, int64_t n, int64_t* table, int64_t 
 
 /* Strided coordinate map: out = unique(floor(c / t_out) * t_out), rows ordered by first occurrence in
  * `coords_in` (deterministic).  Writes coords_out (capacity n_in rows), n_out_dev (device int32) and
- * fills `table_out` (cap_out >= 2 * n_in) with out-key -> out-row.  scratch: int32[gcl_scan_scratch_len(n_in)]. */
+ * fills `table_out` (cap_out >= 2 * n_in) with out-key -> out-row.  scratch: int32[gcl_scan_scratch_len(n_in)].
+ * n_in_dev (optional, device int32): the true row count when n_in is only an upper bound -- lets the host chain
+ * the maps of several levels without reading a count back in between. */
 int64_t gcl_scan_scratch_len(int64_t n);
-int gcl_stride_map(const int32_t* coords_in, int64_t n_in, int32_t t_out,
+int gcl_stride_map(const int32_t* coords_in, int64_t n_in, const int32_t* n_in_dev, int32_t t_out,
                    int64_t* table_out, int64_t cap_out, int32_t* scratch,
                    int32_t* coords_out, int32_t* n_out_dev, int32_t* status, void* stream);
 
@@ -73,11 +75,13 @@ int gcl_stride_map(const int32_t* coords_in, int64_t n_in, int32_t t_out,
  *   entries nbr[(K-1-k) * n + u] = v are written from the hits; nbr_t must be NULL.
  * same_map == 0 and nbr_t != NULL (n_in rows): nbr_t[k * n_in + u] = v for every pair (filled with -1 first).
  * bitmap: optional int32[gcl_kernel_map_bitmap_len()] scratch: a presence bit per hashed key lets most absent
- *   neighbours return without probing the table.  counts[k] (int32[K], device) = number of pairs of offset k. */
+ *   neighbours return without probing the table.  scratch: int32[gcl_kernel_map_scratch_len(ks, n_out)] (per-block
+ *   pair counts, summed in order -- no contended atomics).  counts[k] (int32[K], device) = #pairs of offset k. */
 int64_t gcl_kernel_map_bitmap_len(void);
+int64_t gcl_kernel_map_scratch_len(int32_t ks, int64_t n_out);
 int gcl_kernel_map(const int32_t* coords_out, int64_t n_out, const int64_t* table_in, int64_t cap_in,
-                   int32_t ks, int32_t step, int32_t same_map, int32_t* bitmap, int32_t* nbr, int32_t* nbr_t,
-                   int64_t n_in, int32_t* counts, void* stream);
+                   int32_t ks, int32_t step, int32_t same_map, int32_t* bitmap, int32_t* scratch, int32_t* nbr,
+                   int32_t* nbr_t, int64_t n_in, int32_t* counts, void* stream);
 
 /* Compact per-offset pair lists from nbr (out-major, ascending out row inside an offset), each offset's
  * segment padded with -1 to a multiple of GCL_PAIR_CHUNK:
