@@ -67,6 +67,7 @@ __global__ void __launch_bounds__(256) k_conv_fwd(const float* __restrict__ X, c
                                                   int cin, int cout, const float* __restrict__ bias,
                                                   float* __restrict__ Y) {
   __shared__ __attribute__((aligned(16))) float lds[4][32][LDS_STRIDE];
+  __shared__ int idxs[4][32][32];   // [wave][k][row]
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = l & 31, h = l >> 5;
   const long long tile = (long long)blockIdx.x * 4 + w;
@@ -87,42 +88,37 @@ __global__ void __launch_bounds__(256) k_conv_fwd(const float* __restrict__ X, c
   unsigned kmask = tile_mask ? (unsigned)tile_mask[tile] : ((K >= 32) ? ~0u : ((1u << K) - 1u));
   kmask = __builtin_amdgcn_readfirstlane(kmask);
 
-  auto load_idx = [&](int k) -> int {
+  // all neighbour indices of the tile go to (wave-private) LDS once: no index -> gather dependency in the loop
+  for (int e = l; e < K * 32; e += 64) {
+    int k = e >> 5, r = e & 31;
     int v = -1;
-    if (row_ok) v = tbl ? tbl[(long long)k * n_out + row0 + l] : (int)(row0 + l);
-    return v;
-  };
-  auto gather = [&](int idx, int cc, float4* st) {
+    if (row0 + r < n_out) v = tbl ? tbl[(long long)k * n_out + row0 + r] : (int)(row0 + r);
+    idxs[w][k][r] = v;
+  }
+  WAVE_FENCE();
+  auto gather = [&](int k, int cc, float4* st) {
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
-      int ridx = __shfl(idx, rsub + 8 * ps);
+      int ridx = idxs[w][k][rsub + 8 * ps];
       st[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (ridx >= 0) st[ps] = *reinterpret_cast<const float4*>(X + (long long)ridx * cin + cc * 32 + p * 4);
     }
   };
 
   if (kmask != 0u) {
-    // software pipeline over the steps (k, cc): the gather of step s+1 is in flight while step s computes, and the
-    // neighbour indices of the NEXT offset are loaded a whole offset ahead (no index -> gather dependency stall)
+    // software pipeline over the steps (k, cc): the gather of step s+1 is in flight while step s computes
     int k_cur = __builtin_ctz(kmask), cc_cur = 0;
     unsigned m_rest = kmask & (kmask - 1);
-    int kq = -1;
-    if (m_rest) {
-      kq = __builtin_ctz(m_rest);
-      m_rest &= m_rest - 1;
-    }
-    int idx_cur = load_idx(k_cur);
-    int idx_q = (kq >= 0) ? load_idx(kq) : -1;
     float4 st[4];
-    gather(idx_cur, 0, st);
+    gather(k_cur, 0, st);
     while (true) {
       int k_nxt = k_cur, cc_nxt = cc_cur + 1;
-      bool has_nxt = true, kchange = false;
+      bool has_nxt = true;
       if (cc_nxt == CC) {
         cc_nxt = 0;
-        if (kq >= 0) {
-          k_nxt = kq;
-          kchange = true;
+        if (m_rest) {
+          k_nxt = __builtin_ctz(m_rest);
+          m_rest &= m_rest - 1;
         } else {
           has_nxt = false;
         }
@@ -130,19 +126,7 @@ __global__ void __launch_bounds__(256) k_conv_fwd(const float* __restrict__ X, c
       WAVE_FENCE();   // the previous step's fragment reads are done before the tile is overwritten
 #pragma unroll
       for (int ps = 0; ps < 4; ++ps) *reinterpret_cast<float4*>(&lds[w][rsub + 8 * ps][p * 4]) = st[ps];
-      int idx_nxt = idx_cur;
-      if (has_nxt) {
-        if (kchange) idx_nxt = idx_q;
-        gather(idx_nxt, cc_nxt, st);
-        if (kchange) {
-          kq = -1;
-          if (m_rest) {
-            kq = __builtin_ctz(m_rest);
-            m_rest &= m_rest - 1;
-          }
-          idx_q = (kq >= 0) ? load_idx(kq) : -1;
-        }
-      }
+      if (has_nxt) gather(k_nxt, cc_nxt, st);
       WAVE_FENCE();
       float4 a[4];
 #pragma unroll
@@ -164,7 +148,6 @@ __global__ void __launch_bounds__(256) k_conv_fwd(const float* __restrict__ X, c
       if (!has_nxt) break;
       k_cur = k_nxt;
       cc_cur = cc_nxt;
-      idx_cur = idx_nxt;
     }
   }
   // epilogue: acc[b][r] is element (row = (r&3) + 8*(r>>2) + 4*h, col = i) of the wave's 32 x 32 block b
@@ -173,7 +156,9 @@ __global__ void __launch_bounds__(256) k_conv_fwd(const float* __restrict__ X, c
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     const int col = (nb0 + b) * 32 + i;
-    const float bvv = bias ? bias[col] : 0.f;
+    float bvv = bias ? bias[col] : 0.f;
+    // consume the (conditional) bias load HERE: otherwise every store below waits for all earlier stores (vmcnt(0))
+    asm volatile("v_mov_b32 %0, %1" : "=v"(bvv) : "v"(bvv));
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       int orow = __shfl(orow_l, (r & 3) + 8 * (r >> 2) + 4 * h);
@@ -256,6 +241,7 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
   constexpr int BREG = (BLK + 255) / 256;
   __shared__ __attribute__((aligned(16))) float Asm[4][32][LDS_STRIDE];
   __shared__ __attribute__((aligned(16))) u32x4 Bsm[BLK];
+  __shared__ int Ism[4][32][32];                        // neighbour rows of the wave's tile: [wave][k][row]
   __shared__ unsigned wmask[4];
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   const int i = l & 31, h = l >> 5;
@@ -265,7 +251,6 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
   const int nb0 = blockIdx.y * NB;
   const int TNB = cout >> 5, CC = cin >> 5;
   const int p = l & 7, rsub = l >> 3;
-  const bool row_ok = active && (l < 32) && (row0 + l < n_out);
 
   f32x16 acc[NB];
 #pragma unroll
@@ -277,23 +262,25 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
   if (active) mymask = tile_mask ? (unsigned)tile_mask[tile] : ((K >= 32) ? ~0u : ((1u << K) - 1u));
   mymask = __builtin_amdgcn_readfirstlane(mymask);
   if (l == 0) wmask[w] = mymask;
+  // all neighbour indices of the tile go to LDS once: no index load (and no index -> gather dependency) in the loop
+  for (int e = l; e < K * 32; e += 64) {
+    int k = e >> 5, r = e & 31;
+    int v = -1;
+    if (active && row0 + r < n_out) v = tbl ? tbl[(long long)k * n_out + row0 + r] : (int)(row0 + r);
+    Ism[w][k][r] = v;
+  }
   __syncthreads();
   const unsigned wgmask = wmask[0] | wmask[1] | wmask[2] | wmask[3];
 
-  auto load_idx = [&](int k) -> int {
-    int v = -1;
-    if (row_ok) v = tbl ? tbl[(long long)k * n_out + row0 + l] : (int)(row0 + l);
-    return v;
-  };
-  auto gather = [&](int idx, int cc, float4* st) {
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-      int ridx = __shfl(idx, rsub + 8 * ps);
-      st[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ridx >= 0) st[ps] = *reinterpret_cast<const float4*>(X + (long long)ridx * cin + cc * 32 + p * 4);
-    }
-  };
-#define GCL_LOAD_B(KK, CCV)                                                                       \
+#define GCL_GATHER_A(KK, CCV)                                                                                  \
+  {                                                                                                            \
+    _Pragma("unroll") for (int ps = 0; ps < 4; ++ps) {                                                         \
+      int ridx = Ism[w][(KK)][rsub + 8 * ps];                                                                  \
+      st[ps] = make_float4(0.f, 0.f, 0.f, 0.f);                                                                \
+      if (ridx >= 0) st[ps] = *reinterpret_cast<const float4*>(X + (long long)ridx * cin + (CCV)*32 + p * 4);  \
+    }                                                                                                          \
+  }
+#define GCL_LOAD_B(KK, CCV)                                                                      \
   {                                                                                              \
     const u32x4* src_ = Wp + (((long long)(KK)*CC + (CCV)) * TNB + nb0) * (2 * PL * 64);         \
     _Pragma("unroll") for (int e = 0; e < BREG; ++e) {                                           \
@@ -304,26 +291,19 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
   if (wgmask != 0u) {
     int k_cur = __builtin_ctz(wgmask), cc_cur = 0;
     unsigned m_rest = wgmask & (wgmask - 1);
-    int kq = -1;
-    if (m_rest) {
-      kq = __builtin_ctz(m_rest);
-      m_rest &= m_rest - 1;
-    }
     bool mine_cur = (mymask >> k_cur) & 1u;
-    int idx_cur = mine_cur ? load_idx(k_cur) : -1;
-    int idx_q = (kq >= 0 && ((mymask >> kq) & 1u)) ? load_idx(kq) : -1;   // one offset ahead of its use
     float4 st[4];
     u32x4 br[BREG];
-    if (mine_cur) gather(idx_cur, 0, st);
+    if (mine_cur) GCL_GATHER_A(k_cur, 0);
     GCL_LOAD_B(k_cur, 0);
     while (true) {
       int k_nxt = k_cur, cc_nxt = cc_cur + 1;
-      bool has_nxt = true, kchange = false;
+      bool has_nxt = true;
       if (cc_nxt == CC) {
         cc_nxt = 0;
-        if (kq >= 0) {
-          k_nxt = kq;
-          kchange = true;
+        if (m_rest) {
+          k_nxt = __builtin_ctz(m_rest);
+          m_rest &= m_rest - 1;
         } else {
           has_nxt = false;
         }
@@ -337,20 +317,10 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
       for (int e = 0; e < BREG; ++e)
         if ((BLK % 256 == 0) || (e * 256 + t < BLK)) Bsm[e * 256 + t] = br[e];
       bool mine_nxt = false;
-      int idx_nxt = idx_cur;
-      if (has_nxt) {
+      if (has_nxt) {   // loads of the next step stay in flight across barrier #2 and the MFMA phase
         mine_nxt = (mymask >> k_nxt) & 1u;
-        if (kchange) idx_nxt = idx_q;
-        if (mine_nxt) gather(idx_nxt, cc_nxt, st);
+        if (mine_nxt) GCL_GATHER_A(k_nxt, cc_nxt);
         GCL_LOAD_B(k_nxt, cc_nxt);
-        if (kchange) {
-          kq = -1;
-          if (m_rest) {
-            kq = __builtin_ctz(m_rest);
-            m_rest &= m_rest - 1;
-          }
-          idx_q = (kq >= 0 && ((mymask >> kq) & 1u)) ? load_idx(kq) : -1;
-        }
       }
       __syncthreads();   // #2: A tiles and the shared weight block are in LDS
       if (mine_cur) {
@@ -379,17 +349,20 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
       if (!has_nxt) break;
       k_cur = k_nxt;
       cc_cur = cc_nxt;
-      idx_cur = idx_nxt;
       mine_cur = mine_nxt;
     }
   }
+#undef GCL_GATHER_A
+#undef GCL_LOAD_B
   if (!active) return;
   int orow_l = -1;
-  if (row_ok) orow_l = order ? order[row0 + l] : (int)(row0 + l);
+  if ((l < 32) && (row0 + l < n_out)) orow_l = order ? order[row0 + l] : (int)(row0 + l);
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     const int col = (nb0 + b) * 32 + i;
-    const float bvv = bias ? bias[col] : 0.f;
+    float bvv = bias ? bias[col] : 0.f;
+    // consume the (conditional) bias load HERE: otherwise every store below waits for all earlier stores (vmcnt(0))
+    asm volatile("v_mov_b32 %0, %1" : "=v"(bvv) : "v"(bvv));
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       int orow = __shfl(orow_l, (r & 3) + 8 * (r >> 2) + 4 * h);
