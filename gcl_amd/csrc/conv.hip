@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(256) k_conv_fwd(const float* __restrict__ X, c
                                                   int cin, int cout, const float* __restrict__ bias,
                                                   float* __restrict__ Y) {
   __shared__ __attribute__((aligned(16))) float lds[4][32][LDS_STRIDE];
-  __shared__ int idxs[4][32][32];   // [wave][k][row]
+  __shared__ int idxs[4][27][32];   // [wave][k][row] (K <= 27)
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = l & 31, h = l >> 5;
   const long long tile = (long long)blockIdx.x * 4 + w;
@@ -174,7 +174,8 @@ __global__ void __launch_bounds__(256) k_conv_fwd(const float* __restrict__ X, c
 // the exact-f32 instruction; PL = 2 (hh + hm + mh, ~1.5e-5) runs at 5.3x.
 // Structure: 128 output rows per workgroup (wave w owns rows 32w..32w+31 and gathers them into its private LDS tile
 // exactly as in k_conv_fwd), but the weight block of step (k, cc) is staged ONCE per workgroup in LDS and shared by
-// the four waves (L2 -> CU weight traffic / 4: with the faster MFMA the per-wave weight stream of k_conv_fwd would
+// the four waves [measured alternatives, all slower on the KITTI batch: 256 rows per workgroup (two tiles per wave)
+// +6 %, every wave streaming its own weight fragments from L2 without barriers +13..20 %] (L2 -> CU weight traffic / 4: with the faster MFMA the per-wave weight stream of k_conv_fwd would
 // exceed the L2 bandwidth share of a CU).  A wave whose own rows lack offset k skips its gather and MFMAs.
 // ---------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -241,7 +242,7 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
   constexpr int BREG = (BLK + 255) / 256;
   __shared__ __attribute__((aligned(16))) float Asm[4][32][LDS_STRIDE];
   __shared__ __attribute__((aligned(16))) u32x4 Bsm[BLK];
-  __shared__ int Ism[4][32][32];                        // neighbour rows of the wave's tile: [wave][k][row]
+  __shared__ int Ism[4][27][32];                        // neighbour rows of the wave's tile: [wave][k][row] (K <= 27)
   __shared__ unsigned wmask[4];
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   const int i = l & 31, h = l >> 5;
@@ -754,7 +755,7 @@ int gcl_conv_fwd(const float* x, const void* wp, int32_t prec, const int32_t* tb
                  const int32_t* tile_mask, int64_t n_out, int32_t K, int32_t cin, int32_t cout, const float* bias,
                  float* y, void* stream) {
   GCL_CHECK_ARG(x && wp && y, "gcl_conv_fwd: null pointer");
-  GCL_CHECK_ARG(n_out > 0 && K >= 1 && K <= 32, "gcl_conv_fwd: n_out must be positive and 1 <= K <= 32");
+  GCL_CHECK_ARG(n_out > 0 && K >= 1 && K <= 27, "gcl_conv_fwd: n_out must be positive and 1 <= K <= 27");
   GCL_CHECK_ARG(tbl || K == 1, "gcl_conv_fwd: a neighbour table is required when K > 1");
   GCL_CHECK_ARG((order == nullptr) == (tile_mask == nullptr), "gcl_conv_fwd: order and tile_mask go together");
   GCL_CHECK_ARG(cin % 32 == 0 && cout % 32 == 0 && cin > 0 && cout > 0,

@@ -112,7 +112,7 @@ int gcl_table_sort(const int32_t* tbl, int32_t K, int64_t n, int32_t* scratch, i
  *   With (order, tile_mask) from gcl_table_sort, `tbl` is the PERMUTED table, row(j) = order[j] and each 32-row
  *   wave tile visits only the offsets of tile_mask; with NULLs, row(j) = j and every offset is visited.
  *   Output-stationary (no atomics, deterministic).  The same entry computes the input gradient when given
- *   the opposite table and mode-1/2 weights.  K <= 32. */
+ *   the opposite table and mode-1/2 weights.  K <= 27. */
 int64_t gcl_pack_weights_bytes(int32_t K, int32_t cin, int32_t cout, int32_t prec);
 int gcl_pack_weights(const float* w, int32_t K, int32_t cin, int32_t cout, int32_t mode, int32_t prec, void* wp,
                      void* stream);
