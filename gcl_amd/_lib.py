@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libgcl_hip.so")
+LIB_PATH = os.environ.get("GCL_LIB_PATH", os.path.join(CSRC, "libgcl_hip.so"))   # override: diagnostic builds only
 SOURCES = ["coords.hip", "conv.hip", "norm.hip", "loss.hip"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "gcl_amd.h")
 

@@ -178,6 +178,19 @@ __global__ void __launch_bounds__(256) k_conv_fwd(const float* __restrict__ X, c
 // +6 %, every wave streaming its own weight fragments from L2 without barriers +13..20 %] (L2 -> CU weight traffic / 4: with the faster MFMA the per-wave weight stream of k_conv_fwd would
 // exceed the L2 bandwidth share of a CU).  A wave whose own rows lack offset k skips its gather and MFMAs.
 // ---------------------------------------------------------------------------------------------------
+#ifdef GCL_STAMPS
+// DIAGNOSTIC BUILD ONLY (tools/stamp_conv.py): per-phase cycle sums of k_conv_fwd_split, added up over all waves.
+// [0] wait at barrier #1  [1] LDS writes + next-step load issue  [2] wait at barrier #2  [3] LDS reads + split + MFMA
+// [4] prologue  [5] epilogue  [6] wave-steps  [7] wave-steps with MFMA work
+__device__ unsigned long long g_stamps[8];
+#define STAMP(V)                                  \
+  __builtin_amdgcn_sched_barrier(0);              \
+  unsigned long long V = __builtin_amdgcn_s_memtime(); \
+  __builtin_amdgcn_sched_barrier(0);
+#else
+#define STAMP(V)
+#endif
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -240,6 +253,10 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
                                                         float* __restrict__ Y) {
   constexpr int BLK = NB * 2 * PL * 64;                 // uint4 per (k, cc) weight block of this workgroup
   constexpr int BREG = (BLK + 255) / 256;
+  STAMP(ts_begin)
+#ifdef GCL_STAMPS
+  unsigned long long acc_t[4] = {0, 0, 0, 0}, n_steps = 0, n_mine = 0;
+#endif
   __shared__ __attribute__((aligned(16))) float Asm[4][32][LDS_STRIDE];
   __shared__ __attribute__((aligned(16))) u32x4 Bsm[BLK];
   __shared__ int Ism[4][27][32];                        // neighbour rows of the wave's tile: [wave][k][row] (K <= 27)
@@ -289,6 +306,7 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
     }                                                                                            \
   }
 
+  STAMP(ts_loop)
   if (wgmask != 0u) {
     int k_cur = __builtin_ctz(wgmask), cc_cur = 0;
     unsigned m_rest = wgmask & (wgmask - 1);
@@ -309,7 +327,9 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
           has_nxt = false;
         }
       }
+      STAMP(t0)
       __syncthreads();   // #1: every wave is done reading Bsm (and its own A tile) of the previous step
+      STAMP(t1)
       if (mine_cur) {
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) *reinterpret_cast<float4*>(&Asm[w][rsub + 8 * ps][p * 4]) = st[ps];
@@ -323,7 +343,9 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
         if (mine_nxt) GCL_GATHER_A(k_nxt, cc_nxt);
         GCL_LOAD_B(k_nxt, cc_nxt);
       }
+      STAMP(t2)
       __syncthreads();   // #2: A tiles and the shared weight block are in LDS
+      STAMP(t3)
       if (mine_cur) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
@@ -347,6 +369,11 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
           }
         }
       }
+      STAMP(t4)
+#ifdef GCL_STAMPS
+      acc_t[0] += t1 - t0; acc_t[1] += t2 - t1; acc_t[2] += t3 - t2; acc_t[3] += t4 - t3;
+      n_steps += 1; n_mine += mine_cur ? 1 : 0;
+#endif
       if (!has_nxt) break;
       k_cur = k_nxt;
       cc_cur = cc_nxt;
@@ -355,6 +382,15 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
   }
 #undef GCL_GATHER_A
 #undef GCL_LOAD_B
+  STAMP(ts_epi)
+#ifdef GCL_STAMPS
+  if (l == 0) {
+    for (int q = 0; q < 4; ++q) atomicAdd(&g_stamps[q], acc_t[q]);
+    atomicAdd(&g_stamps[4], ts_loop - ts_begin);
+    atomicAdd(&g_stamps[6], n_steps);
+    atomicAdd(&g_stamps[7], n_mine);
+  }
+#endif
   if (!active) return;
   int orow_l = -1;
   if ((l < 32) && (row0 + l < n_out)) orow_l = order ? order[row0 + l] : (int)(row0 + l);
@@ -728,6 +764,17 @@ __global__ void k_stem_reduce(const float* __restrict__ slabs, int n_slabs, long
 using namespace gcl;
 
 extern "C" {
+
+#ifdef GCL_STAMPS
+int gcl_debug_stamps(unsigned long long* out_host, int reset) {
+  if (out_host) GCL_CHECK_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 8));
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    GCL_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)));
+  }
+  return GCL_OK;
+}
+#endif
 
 int64_t gcl_pack_weights_bytes(int32_t K, int32_t cin, int32_t cout, int32_t prec) {
   long long n = (long long)K * cin * cout;
