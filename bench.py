@@ -109,7 +109,12 @@ def main():
         print(json.dumps(cpu_baseline_worker()), flush=True)
         return
     from gcl_amd import ddp, synthetic
-    rank, world, local = ddp.init_from_env()
+    # test hooks for a 1-GPU box (never set by the driver): run the N>1 code path with every rank on cuda:0 and gloo
+    if os.environ.get("GCL_BENCH_SINGLE_DEVICE") == "1":
+        rank, world, local = ddp.init_from_env(backend="gloo")
+        local = 0
+    else:
+        rank, world, local = ddp.init_from_env()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
