@@ -1,7 +1,13 @@
 """SparseTensor + coordinate manager (host side of the coordinate/kernel-map kernels in csrc/coords.hip)."""
+import os
+
 import torch
 
 from .. import _lib
+
+
+# rows are mask-sorted inside windows of this many consecutive rows (0 = one global sort); tuning knob
+SORT_WINDOW = int(os.environ.get("GCL_SORT_WINDOW", "0"))
 
 
 def _pow2_cap(n):
@@ -84,7 +90,7 @@ class KernelMap:
                 order = torch.empty(n, dtype=torch.int32, device=dev)
                 tbl_sorted = torch.empty_like(tbl)
                 tile_mask = torch.empty((n + 31) // 32, dtype=torch.int32, device=dev)
-                _lib.check(lib.gcl_table_sort(_lib.ptr(tbl), self.K, n, _lib.ptr(scratch), _lib.ptr(order),
+                _lib.check(lib.gcl_table_sort(_lib.ptr(tbl), self.K, n, SORT_WINDOW, _lib.ptr(scratch), _lib.ptr(order),
                                               _lib.ptr(tbl_sorted), _lib.ptr(tile_mask), _lib.stream()),
                            "gcl_table_sort")
                 self._sorted[key] = (tbl_sorted, order, tile_mask)

@@ -58,6 +58,15 @@ __global__ void k_pack_weights(const float* __restrict__ w, int K, int cin, int 
 // forward / input-gradient
 // ---------------------------------------------------------------------------------------------------
 constexpr int CONV_ROWS = 128;   // output rows per workgroup (4 waves x 32)
+
+// XCD-aware tile index: workgroups are dealt round-robin over the 8 XCDs (blockIdx b and b+8 share an L2), so the
+// bijective remap below gives every XCD a CONTIGUOUS range of row tiles -- tiles that are neighbours in the (windowed)
+// sort order gather overlapping input rows and then hit the same L2.  Speed only, never correctness.
+__device__ __forceinline__ unsigned xcd_tile(unsigned bid, unsigned nwg, int swizzle) {
+  if (!swizzle || nwg < 16) return bid;
+  unsigned q = nwg >> 3, r = nwg & 7u, xcd = bid & 7u;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
 constexpr int LDS_STRIDE = 36;   // 32 floats + 4 pad: conflict-free ds_read_b128 (MI355X_MICROARCH LDS table)
 
 template <int NB>  // 32-column blocks per wave
@@ -65,12 +74,12 @@ __global__ void __launch_bounds__(256) k_conv_fwd(const float* __restrict__ X, c
                                                   const int* __restrict__ tbl, const int* __restrict__ order,
                                                   const int* __restrict__ tile_mask, long long n_out, int K,
                                                   int cin, int cout, const float* __restrict__ bias,
-                                                  float* __restrict__ Y) {
+                                                  float* __restrict__ Y, int swizzle) {
   __shared__ __attribute__((aligned(16))) float lds[4][32][LDS_STRIDE];
   __shared__ int idxs[4][27][32];   // [wave][k][row] (K <= 27)
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = l & 31, h = l >> 5;
-  const long long tile = (long long)blockIdx.x * 4 + w;
+  const long long tile = (long long)xcd_tile(blockIdx.x, gridDim.x, swizzle) * 4 + w;
   const long long row0 = tile * 32;
   if (row0 >= n_out) return;   // whole wave out of range (no workgroup barriers below)
   const int nb0 = blockIdx.y * NB;
@@ -250,7 +259,7 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
                                                         const int* __restrict__ tbl, const int* __restrict__ order,
                                                         const int* __restrict__ tile_mask, long long n_out, int K,
                                                         int cin, int cout, const float* __restrict__ bias,
-                                                        float* __restrict__ Y) {
+                                                        float* __restrict__ Y, int swizzle) {
   constexpr int BLK = NB * 2 * PL * 64;                 // uint4 per (k, cc) weight block of this workgroup
   constexpr int BREG = (BLK + 255) / 256;
   STAMP(ts_begin)
@@ -263,7 +272,7 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
   __shared__ unsigned wmask[4];
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   const int i = l & 31, h = l >> 5;
-  const long long tile = (long long)blockIdx.x * 4 + w;
+  const long long tile = (long long)xcd_tile(blockIdx.x, gridDim.x, swizzle) * 4 + w;
   const long long row0 = tile * 32;
   const bool active = row0 < n_out;
   const int nb0 = blockIdx.y * NB;
@@ -809,15 +818,19 @@ int gcl_conv_fwd(const float* x, const void* wp, int32_t prec, const int32_t* tb
                 "gcl_conv_fwd: Cin (%d) and Cout (%d) must be positive multiples of 32", cin, cout);
   GCL_CHECK_ARG(prec == 0 || prec == 2 || prec == 3, "gcl_conv_fwd: prec must be 0 (f32), 2 (bf16x3) or 3 (bf16x6)");
   hipStream_t st = (hipStream_t)stream;
+  static const int swz = [] {   // tuning knob, default on
+    const char* e = getenv("GCL_XCD_SWIZZLE");
+    return e ? atoi(e) : 1;
+  }();
   unsigned gx = (unsigned)cdiv(n_out, CONV_ROWS);
   const int nb = (cout % 128 == 0) ? 4 : ((cout % 64 == 0) ? 2 : 1);
   dim3 grid(gx, cout / (32 * nb));
 #define LAUNCH_F32(NBV)                                                                                          \
   hipLaunchKernelGGL(k_conv_fwd<NBV>, grid, dim3(256), 0, st, x, (const float4*)wp, tbl, order, tile_mask,       \
-                     (long long)n_out, K, cin, cout, bias, y)
+                     (long long)n_out, K, cin, cout, bias, y, swz)
 #define LAUNCH_SPLIT(NBV, PLV)                                                                                   \
   hipLaunchKernelGGL((k_conv_fwd_split<NBV, PLV>), grid, dim3(256), 0, st, x, (const u32x4*)wp, tbl, order,      \
-                     tile_mask, (long long)n_out, K, cin, cout, bias, y)
+                     tile_mask, (long long)n_out, K, cin, cout, bias, y, swz)
   if (prec == 0) {
     if (nb == 4) LAUNCH_F32(4); else if (nb == 2) LAUNCH_F32(2); else LAUNCH_F32(1);
   } else if (prec == 2) {

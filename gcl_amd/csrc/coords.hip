@@ -426,6 +426,51 @@ __global__ void __launch_bounds__(64) k_radix_scatter(const unsigned* __restrict
   }
 }
 
+// Windowed variant: rows are mask-sorted only INSIDE windows of WIN consecutive rows of the loader's order, which is
+// spatially coherent (scan order) -- a wave tile then gathers from a compact region (L2 reuse of the gathered rows)
+// at the price of more distinct masks per tile.  One workgroup sorts one window in LDS (bitonic on (mask, row)
+// pairs: unique keys, so the result equals a stable sort); no global passes.
+template <int WIN>
+__global__ void __launch_bounds__(256) k_window_sort(const int* __restrict__ tbl, int K, long long n, int* order,
+                                                     unsigned* keys_sorted) {
+  __shared__ unsigned long long kv[WIN];
+  const long long base = (long long)blockIdx.x * WIN;
+  for (int e = threadIdx.x; e < WIN; e += 256) {
+    long long v = base + e;
+    unsigned long long key = ~0ull;            // padding sorts last
+    if (v < n) {
+      unsigned m = 0;
+      for (int k = 0; k < K; ++k) m |= (tbl[(long long)k * n + v] >= 0 ? 1u : 0u) << k;
+      key = ((unsigned long long)m << 32) | (unsigned)e;
+    }
+    kv[e] = key;
+  }
+  __syncthreads();
+  for (int size = 2; size <= WIN; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int e = threadIdx.x; e < WIN / 2; e += 256) {
+        int lo = 2 * e - (e & (stride - 1));   // index of the lower element of the pair
+        int hi = lo + stride;
+        bool up = ((lo & size) == 0);
+        unsigned long long a = kv[lo], b = kv[hi];
+        if ((a > b) == up) {
+          kv[lo] = b;
+          kv[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int e = threadIdx.x; e < WIN; e += 256) {
+    long long j = base + e;
+    if (j < n) {
+      unsigned long long key = kv[e];
+      order[j] = (int)(base + (unsigned)(key & 0xffffffffu));
+      keys_sorted[j] = (unsigned)(key >> 32);
+    }
+  }
+}
+
 __global__ void k_permute_table(const int* __restrict__ tbl, const int* __restrict__ order, long long n,
                                 int* tbl_sorted) {
   long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -571,32 +616,42 @@ int64_t gcl_table_sort_scratch_len(int64_t n) {
   return 4 * n + 2 * hist + cdiv(hist, SCAN_B) + 64;
 }
 
-int gcl_table_sort(const int32_t* tbl, int32_t K, int64_t n, int32_t* scratch, int32_t* order, int32_t* tbl_sorted,
-                   int32_t* tile_mask, void* stream) {
+int gcl_table_sort(const int32_t* tbl, int32_t K, int64_t n, int32_t window, int32_t* scratch, int32_t* order,
+                   int32_t* tbl_sorted, int32_t* tile_mask, void* stream) {
   GCL_CHECK_ARG(tbl && scratch && order && tbl_sorted && tile_mask, "gcl_table_sort: null pointer");
   GCL_CHECK_ARG(K >= 1 && K <= 27 && n > 0, "gcl_table_sort: K must be <= 27 (3^3 kernels), n > 0");
+  GCL_CHECK_ARG(window == 0 || window == 2048 || window == 4096, "gcl_table_sort: window must be 0, 2048 or 4096");
   hipStream_t st = (hipStream_t)stream;
-  int nblk = (int)cdiv(n, RS_BLOCK);
-  long long hist_len = 256ll * nblk;
   unsigned* ka = (unsigned*)scratch;
-  unsigned* kb = ka + n;
-  int* va = scratch + 2 * n;
-  int* vb = scratch + 3 * n;
-  int* hist = scratch + 4 * n;
-  int* offs = hist + hist_len;
-  int* bs = offs + hist_len;
-  hipLaunchKernelGGL(k_row_masks, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, tbl, K, (long long)n, ka, va);
-  int passes = (K + 7) / 8;
-  for (int p = 0; p < passes; ++p) {
-    hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(64), 0, st, (const unsigned*)ka, (long long)n, 8 * p, nblk, hist);
-    GCL_CHECK_LAUNCH();
-    int rc = device_scan(hist, hist_len, offs, bs, st);
-    if (rc) return rc;
-    int* vout = (p == passes - 1) ? order : vb;
-    hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(64), 0, st, (const unsigned*)ka, (const int*)va, (long long)n,
-                       8 * p, nblk, (const int*)offs, kb, vout);
-    unsigned* tk = ka; ka = kb; kb = tk;
-    if (p != passes - 1) { int* tv = va; va = vb; vb = tv; }
+  if (window) {
+    if (window == 2048)
+      hipLaunchKernelGGL(k_window_sort<2048>, dim3((unsigned)cdiv(n, 2048)), dim3(256), 0, st, tbl, K, (long long)n,
+                         order, ka);
+    else
+      hipLaunchKernelGGL(k_window_sort<4096>, dim3((unsigned)cdiv(n, 4096)), dim3(256), 0, st, tbl, K, (long long)n,
+                         order, ka);
+  } else {
+    int nblk = (int)cdiv(n, RS_BLOCK);
+    long long hist_len = 256ll * nblk;
+    unsigned* kb = ka + n;
+    int* va = scratch + 2 * n;
+    int* vb = scratch + 3 * n;
+    int* hist = scratch + 4 * n;
+    int* offs = hist + hist_len;
+    int* bs = offs + hist_len;
+    hipLaunchKernelGGL(k_row_masks, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, tbl, K, (long long)n, ka, va);
+    int passes = (K + 7) / 8;
+    for (int p = 0; p < passes; ++p) {
+      hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(64), 0, st, (const unsigned*)ka, (long long)n, 8 * p, nblk, hist);
+      GCL_CHECK_LAUNCH();
+      int rc = device_scan(hist, hist_len, offs, bs, st);
+      if (rc) return rc;
+      int* vout = (p == passes - 1) ? order : vb;
+      hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(64), 0, st, (const unsigned*)ka, (const int*)va, (long long)n,
+                         8 * p, nblk, (const int*)offs, kb, vout);
+      unsigned* tk = ka; ka = kb; kb = tk;
+      if (p != passes - 1) { int* tv = va; va = vb; vb = tv; }
+    }
   }
   long long n_tiles = cdiv(n, 32);
   hipLaunchKernelGGL(k_tile_masks, dim3((unsigned)cdiv(n_tiles, 256)), dim3(256), 0, st, (const unsigned*)ka,

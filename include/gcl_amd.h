@@ -93,9 +93,11 @@ int gcl_kernel_map_pairs(const int32_t* nbr, int32_t K, int64_t n_out, const int
 /* Row ordering for the output-stationary convolution: sorts the rows of a [K][n] neighbour table (K <= 27) by
  * their K-bit presence mask (stable radix sort), so that the rows of a 32-row wave tile need nearly the same
  * offsets.  order[j] = original row at sorted position j; tbl_sorted[k*n + j] = tbl[k*n + order[j]];
- * tile_mask[t] = OR of the masks of sorted rows 32t .. 32t+31.  scratch: int32[gcl_table_sort_scratch_len(n)]. */
+ * tile_mask[t] = OR of the masks of sorted rows 32t .. 32t+31.  scratch: int32[gcl_table_sort_scratch_len(n)].
+ * window = 0: one global sort.  window = 2048 | 4096: rows are sorted only inside windows of that many consecutive
+ * rows (one LDS bitonic sort per window): keeps the loader's spatial coherence for the gathers. */
 int64_t gcl_table_sort_scratch_len(int64_t n);
-int gcl_table_sort(const int32_t* tbl, int32_t K, int64_t n, int32_t* scratch, int32_t* order,
+int gcl_table_sort(const int32_t* tbl, int32_t K, int64_t n, int32_t window, int32_t* scratch, int32_t* order,
                    int32_t* tbl_sorted, int32_t* tile_mask, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

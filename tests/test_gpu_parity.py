@@ -428,23 +428,31 @@ def test_full_size_properties():
     assert torch.equal(y1.detach(), y2.detach()) and torch.equal(x.grad, x2.grad)
 
 
-def test_table_sort_is_a_stable_mask_sort():
-    """gcl_table_sort: order is a permutation sorted by presence mask (stable), the permuted table and the tile
-    masks are consistent with it."""
+@pytest.mark.parametrize("window", [0, 2048, 4096])
+def test_table_sort_is_a_stable_mask_sort(window):
+    """gcl_table_sort: order is a permutation sorted by presence mask (stable; inside windows of consecutive rows when
+    a window is given), the permuted table and the tile masks are consistent with it."""
+    from gcl_amd.MinkowskiEngine import core
     C = random_cloud(9, n=5000, batch=2)
-    mgr = make_mgr(C)
-    for key in [(1, 3, 1), (1, 3, 2)]:
-        km = mgr.get_kernel_map(*key)
-        for transposed in ([False, True] if km.nbr_t is not None else [False]):
-            tbl = (km.nbr_t if transposed else km.nbr).cpu().numpy()
-            ts, order, tmask = (t.cpu().numpy() for t in km.sorted_table(transposed))
-            n = tbl.shape[1]
-            mask = np.zeros(n, dtype=np.int64)
-            for k in range(km.K):
-                mask |= (tbl[k] >= 0).astype(np.int64) << k
-            ref_order = np.argsort(mask, kind="stable")
-            assert np.array_equal(order, ref_order)
-            assert np.array_equal(ts, tbl[:, order])
-            pad = (-n) % 32
-            mt = np.concatenate([mask[order], np.zeros(pad, np.int64)]).reshape(-1, 32)
-            assert np.array_equal(tmask.astype(np.int64), np.bitwise_or.reduce(mt, axis=1))
+    old = core.SORT_WINDOW
+    core.SORT_WINDOW = window
+    try:
+        mgr = make_mgr(C)
+        for key in [(1, 3, 1), (1, 3, 2)]:
+            km = mgr.get_kernel_map(*key)
+            for transposed in ([False, True] if km.nbr_t is not None else [False]):
+                tbl = (km.nbr_t if transposed else km.nbr).cpu().numpy()
+                ts, order, tmask = (t.cpu().numpy() for t in km.sorted_table(transposed))
+                n = tbl.shape[1]
+                mask = np.zeros(n, dtype=np.int64)
+                for k in range(km.K):
+                    mask |= (tbl[k] >= 0).astype(np.int64) << k
+                win = np.arange(n) // window if window else np.zeros(n, dtype=np.int64)
+                ref_order = np.lexsort((np.arange(n), mask, win))
+                assert np.array_equal(order, ref_order)
+                assert np.array_equal(ts, tbl[:, order])
+                pad = (-n) % 32
+                mt = np.concatenate([mask[order], np.zeros(pad, np.int64)]).reshape(-1, 32)
+                assert np.array_equal(tmask.astype(np.int64), np.bitwise_or.reduce(mt, axis=1))
+    finally:
+        core.SORT_WINDOW = old
