@@ -88,8 +88,12 @@ class _ConvBase(nn.Module):
         else:
             kmap = mgr.get_kernel_map(t_in, self.kernel_size, self.stride)
             n_out = mgr.num_rows(t_out)
-        F = sparse_conv(x.F, self.kernel, kmap, n_out, self.TRANSPOSE, self.bias, mgr)
-        return SparseTensor(F, coordinate_map_key=CoordinateMapKey(t_out), coordinate_manager=mgr)
+        # in training mode the epilogue also emits per-tile column sums, which a following MinkowskiBatchNorm consumes
+        F, stats = sparse_conv(x.F, self.kernel, kmap, n_out, self.TRANSPOSE, self.bias, mgr,
+                               want_stats=self.training and self.bias is None and self.in_channels > 4)
+        out = SparseTensor(F, coordinate_map_key=CoordinateMapKey(t_out), coordinate_manager=mgr)
+        out._bn_stats = stats
+        return out
 
     def extra_repr(self):
         return (f"in={self.in_channels}, out={self.out_channels}, kernel_size={self.kernel_size}, "
@@ -123,7 +127,7 @@ class MinkowskiBatchNorm(nn.Module):
         if residual is not None and residual.coordinate_map_key != x.coordinate_map_key:
             raise ValueError("residual lives on a different coordinate map")
         F = batch_norm(x.F, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training,
-                       bn.momentum, bn.eps, res, relu)
+                       bn.momentum, bn.eps, res, relu, getattr(x, "_bn_stats", None))
         if self.training:
             bn.num_batches_tracked += 1
         out = SparseTensor(F, coordinate_map_key=x.coordinate_map_key, coordinate_manager=x.coordinate_manager)

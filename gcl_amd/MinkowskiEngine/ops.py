@@ -48,10 +48,11 @@ class _Timed:
             PROFILE.append(self.rec)
 
 
-def _conv_launch(lib, x, Wk, mode, table, n_out, cin, cout, bias, pairs=0):
+def _conv_launch(lib, x, Wk, mode, table, n_out, cin, cout, bias, pairs=0, want_stats=False):
     """One output-stationary convolution launch.  ``Wk`` [K, *, *] is packed for ``mode`` (0 forward, 1 transposed,
     2 transposed + mirrored offsets) in the current precision; ``table`` = (tbl, order, tile_mask) from
-    KernelMap.sorted_table(), or None for a kernel_size-1 conv; (cin, cout) are the EFFECTIVE widths of the launch."""
+    KernelMap.sorted_table(), or None for a kernel_size-1 conv; (cin, cout) are the EFFECTIVE widths of the launch.
+    ``want_stats``: also return the per-tile column sums [ceil(n_out/32), 2, cout] for a following BatchNorm."""
     prec = _PREC_CODES[PRECISION]
     K, wc_in, wc_out = Wk.shape
     wp = torch.empty(lib.gcl_pack_weights_bytes(K, wc_in, wc_out, prec), dtype=torch.uint8, device=Wk.device)
@@ -59,21 +60,25 @@ def _conv_launch(lib, x, Wk, mode, table, n_out, cin, cout, bias, pairs=0):
                                     _lib.stream()), "gcl_pack_weights")
     tbl, order, tile_mask = table if table is not None else (None, None, None)
     y = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
+    stats = None
+    if want_stats and prec != 0:
+        stats = torch.empty(((n_out + 31) // 32, 2, cout), dtype=torch.float32, device=x.device)
     nb = 4 if cout % 128 == 0 else (2 if cout % 64 == 0 else 1)
     name = f"k_conv_fwd<{nb}>" if prec == 0 else f"k_conv_fwd_split<{nb},{prec}>"
     with _Timed(name, pairs, cin, cout):
         _lib.check(lib.gcl_conv_fwd(_lib.ptr(x, torch.float32), _lib.ptr(wp), prec, _lib.ptr(tbl), _lib.ptr(order),
                                     _lib.ptr(tile_mask), n_out, K, cin, cout, _lib.ptr(bias), _lib.ptr(y),
-                                    _lib.stream()), "gcl_conv_fwd")
-    return y
+                                    _lib.ptr(stats), _lib.stream()), "gcl_conv_fwd")
+    return (y, stats) if want_stats else y
 
 
 class _SparseConvFn(torch.autograd.Function):
     """y[v] = sum_k x[u(k, v)] W_k (+ bias) -- forward, input gradient and weight gradient all in HIP."""
 
     @staticmethod
-    def forward(ctx, x, W, bias, kmap, n_out, transpose, mgr):
+    def forward(ctx, x, W, bias, kmap, n_out, transpose, mgr, want_stats):
         lib = _lib.require_gpu()
+        stats = None
         x = x.contiguous()
         Wk = (W if W.dim() == 3 else W.unsqueeze(0)).contiguous()
         K, cin, cout = Wk.shape
@@ -91,14 +96,18 @@ class _SparseConvFn(torch.autograd.Function):
             b = bias.detach().contiguous().view(-1) if bias is not None else None
             # pair counts reach the host asynchronously; only the profiler needs them in the forward pass
             ctx.pairs = (kmap.n_pairs if kmap is not None else n_out) if PROFILE is not None else 0
-            y = _conv_launch(lib, x, Wk, 0, tbl, n_out, cin, cout, b, ctx.pairs)
+            y, stats = _conv_launch(lib, x, Wk, 0, tbl, n_out, cin, cout, b, ctx.pairs, want_stats=True) \
+                if want_stats else (_conv_launch(lib, x, Wk, 0, tbl, n_out, cin, cout, b, ctx.pairs), None)
         ctx.save_for_backward(x, Wk)
         ctx.kmap, ctx.transpose, ctx.mgr, ctx.w_shape, ctx.has_bias = kmap, transpose, mgr, W.shape, bias is not None
-        return y
+        if stats is None:
+            stats = y.new_empty(0)
+        ctx.mark_non_differentiable(stats)
+        return y, stats
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dstats):
         lib = _lib.load()
         x, Wk = ctx.saved_tensors
         K, cin, cout = Wk.shape
@@ -146,18 +155,21 @@ class _SparseConvFn(torch.autograd.Function):
             dW = dW.view(ctx.w_shape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             dbias = dy.sum(0, keepdim=True)
-        return dx, dW, dbias, None, None, None, None
+        return dx, dW, dbias, None, None, None, None, None
 
 
-def sparse_conv(x, W, kmap, n_out, transpose, bias, mgr):
-    return _SparseConvFn.apply(x, W, bias, kmap, n_out, transpose, mgr)
+def sparse_conv(x, W, kmap, n_out, transpose, bias, mgr, want_stats=False):
+    """Returns (y, stats): ``stats`` = per-tile column sums for a following BatchNorm (None unless requested and
+    available in the current precision)."""
+    y, stats = _SparseConvFn.apply(x, W, bias, kmap, n_out, transpose, mgr, want_stats)
+    return y, (stats if stats.numel() else None)
 
 
 class _BatchNormFn(torch.autograd.Function):
     """y = BN(x) (+ residual) (relu): statistics pass + fused apply pass; backward = reduce + fused apply."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, residual, relu):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, residual, relu, tile_stats):
         lib = _lib.require_gpu()
         x = x.contiguous()
         n, c = x.shape
@@ -165,10 +177,16 @@ class _BatchNormFn(torch.autograd.Function):
         if training:
             mean = torch.empty(c, dtype=torch.float32, device=dev)
             rstd = torch.empty(c, dtype=torch.float32, device=dev)
-            scratch = torch.empty(lib.gcl_bn_scratch_len(n, c), dtype=torch.float64, device=dev)
-            _lib.check(lib.gcl_bn_stats(_lib.ptr(x, torch.float32), n, c, float(eps), float(momentum),
-                                        _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(scratch),
-                                        _lib.ptr(mean), _lib.ptr(rstd), _lib.stream()), "gcl_bn_stats")
+            if tile_stats is not None:      # column sums already produced by the convolution epilogue
+                _lib.check(lib.gcl_bn_stats_from_tiles(_lib.ptr(tile_stats, torch.float32), tile_stats.shape[0], n, c,
+                                                       float(eps), float(momentum), _lib.ptr(running_mean),
+                                                       _lib.ptr(running_var), _lib.ptr(mean), _lib.ptr(rstd),
+                                                       _lib.stream()), "gcl_bn_stats_from_tiles")
+            else:
+                scratch = torch.empty(lib.gcl_bn_scratch_len(n, c), dtype=torch.float64, device=dev)
+                _lib.check(lib.gcl_bn_stats(_lib.ptr(x, torch.float32), n, c, float(eps), float(momentum),
+                                            _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(scratch),
+                                            _lib.ptr(mean), _lib.ptr(rstd), _lib.stream()), "gcl_bn_stats")
         else:
             mean = running_mean.detach().contiguous()
             rstd = torch.rsqrt(running_var.detach() + eps).contiguous()
@@ -204,8 +222,10 @@ class _BatchNormFn(torch.autograd.Function):
         _lib.check(lib.gcl_bn_bwd_apply(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(y), n, c, _lib.ptr(mean), _lib.ptr(rstd),
                                         _lib.ptr(weight.detach()), _lib.ptr(sg), _lib.ptr(sx), int(ctx.relu),
                                         _lib.ptr(dx), _lib.ptr(dres), _lib.stream()), "gcl_bn_bwd_apply")
-        return dx, sum_gx, sum_g, None, None, None, None, None, dres, None
+        return dx, sum_gx, sum_g, None, None, None, None, None, dres, None, None
 
 
-def batch_norm(x, weight, bias, running_mean, running_var, training, momentum, eps, residual=None, relu=False):
-    return _BatchNormFn.apply(x, weight, bias, running_mean, running_var, training, momentum, eps, residual, relu)
+def batch_norm(x, weight, bias, running_mean, running_var, training, momentum, eps, residual=None, relu=False,
+               tile_stats=None):
+    return _BatchNormFn.apply(x, weight, bias, running_mean, running_var, training, momentum, eps, residual, relu,
+                              tile_stats)

@@ -365,7 +365,10 @@ __global__ void __launch_bounds__(256) k_pairs_emit(const int* __restrict__ nbr,
 // (the offsets the wave must visit) is close to each row's own mask.  On LiDAR sheets this halves the MFMA work
 // relative to the loader's row order (measured on the synthetic KITTI batch: 2.8x -> 1.4x the exact sparse work).
 // Stable LSD radix sort, 8-bit digits, one wave per 2048-element block (wave-local ranking by ballots).
-constexpr int RS_BLOCK = 2048;
+#ifndef GCL_RS_BLOCK
+#define GCL_RS_BLOCK 512
+#endif
+constexpr int RS_BLOCK = GCL_RS_BLOCK;   // one wave per block: small blocks => >= 4 waves per CU at 0.5 M rows
 
 __global__ void k_row_masks(const int* __restrict__ tbl, int K, long long n, unsigned* keys, int* vals) {
   long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;

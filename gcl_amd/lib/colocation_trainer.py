@@ -12,6 +12,7 @@ What differs from the reference, by design:
 * data-parallel training (absent from the reference) shards samples over ranks and all-reduces one flat gradient
   buffer (gcl_amd/ddp.py).
 """
+import os
 import types
 
 import numpy as np
@@ -176,7 +177,10 @@ class FinestContrastiveLossTrainer:
     def train_step(self, input_dict, draws=None):
         """One optimizer step on one batch (iter_size == 1).  Returns device scalars (no host sync here)."""
         self.model.train()
-        self.optimizer.zero_grad(set_to_none=False)
+        if self.ddp is not None:
+            self.ddp.flat_grad.zero_()                     # one memset; gradients stay seated in the flat buffer
+        else:
+            self.optimizer.zero_grad(set_to_none=os.environ.get("GCL_ZERO_NONE", "1") == "1")   # assign, not 66 adds + fills
         loss, parts, F_out = self.forward_loss(input_dict, draws)
         loss.backward()
         if self.ddp is not None:

@@ -114,13 +114,15 @@ int gcl_table_sort(const int32_t* tbl, int32_t K, int64_t n, int32_t window, int
  *   With (order, tile_mask) from gcl_table_sort, `tbl` is the PERMUTED table, row(j) = order[j] and each 32-row
  *   wave tile visits only the offsets of tile_mask; with NULLs, row(j) = j and every offset is visited.
  *   Output-stationary (no atomics, deterministic).  The same entry computes the input gradient when given
- *   the opposite table and mode-1/2 weights.  K <= 27. */
+ *   the opposite table and mode-1/2 weights.  K <= 27.
+ *   stats (optional, prec 2/3): float[ceil(n_out/32)][2][cout] -- per 32-row tile column sums of y and y^2, consumed
+ *   by gcl_bn_stats_from_tiles (the BatchNorm that follows then needs no statistics pass over y). */
 int64_t gcl_pack_weights_bytes(int32_t K, int32_t cin, int32_t cout, int32_t prec);
 int gcl_pack_weights(const float* w, int32_t K, int32_t cin, int32_t cout, int32_t mode, int32_t prec, void* wp,
                      void* stream);
 int gcl_conv_fwd(const float* x, const void* wp, int32_t prec, const int32_t* tbl, const int32_t* order,
                  const int32_t* tile_mask, int64_t n_out, int32_t K, int32_t cin, int32_t cout, const float* bias,
-                 float* y, void* stream);
+                 float* y, float* stats, void* stream);
 
 /* dW[k] = sum over pairs of offset k of  A[pair_a]^T . B[pair_b]   (A: [*, ca], B: [*, cb]) -> dw [K, ca, cb].
  * Forward conv: A = X, pair_a = pair_in, B = dY, pair_b = pair_out.  Transposed conv: roles swapped.
@@ -152,6 +154,8 @@ int64_t gcl_bn_scratch_len(int64_t n, int32_t c);
 int gcl_bn_stats(const float* x, int64_t n, int32_t c, float eps, float momentum,
                  float* running_mean, float* running_var, double* scratch,
                  float* mean, float* rstd, void* stream);
+int gcl_bn_stats_from_tiles(const float* partial, int64_t n_tiles, int64_t n, int32_t c, float eps, float momentum,
+                            float* running_mean, float* running_var, float* mean, float* rstd, void* stream);
 int gcl_bn_apply(const float* x, int64_t n, int32_t c, const float* mean, const float* rstd,
                  const float* weight, const float* bias, const float* residual, int32_t relu,
                  float* y, void* stream);
