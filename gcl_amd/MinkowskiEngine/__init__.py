@@ -12,6 +12,7 @@ lib/colocation_trainer.py:843-845, scripts/test_kitti.py:143-147, util/misc.py:1
 reached through the C ABI in include/gcl_amd.h.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -25,6 +26,10 @@ from .ops import batch_norm, set_conv_precision, sparse_conv
 __all__ = ["SparseTensor", "CoordinateManager", "CoordinateMapKey", "MinkowskiConvolution",
            "MinkowskiConvolutionTranspose", "MinkowskiBatchNorm", "MinkowskiInstanceNorm", "MinkowskiNetwork",
            "MinkowskiFunctional", "cat", "utils", "set_conv_precision"]
+
+
+# tuning knob: let convolutions emit the column sums a following BatchNorm needs (saves its statistics pass)
+FUSED_BN_STATS = os.environ.get("GCL_FUSED_BN_STATS", "1") == "1"
 
 
 class MinkowskiNetwork(nn.Module):
@@ -90,7 +95,8 @@ class _ConvBase(nn.Module):
             n_out = mgr.num_rows(t_out)
         # in training mode the epilogue also emits per-tile column sums, which a following MinkowskiBatchNorm consumes
         F, stats = sparse_conv(x.F, self.kernel, kmap, n_out, self.TRANSPOSE, self.bias, mgr,
-                               want_stats=self.training and self.bias is None and self.in_channels > 4)
+                               want_stats=FUSED_BN_STATS and self.training and self.bias is None
+                               and self.in_channels > 4)
         out = SparseTensor(F, coordinate_map_key=CoordinateMapKey(t_out), coordinate_manager=mgr)
         out._bn_stats = stats
         return out
