@@ -178,9 +178,11 @@ class _BatchNormFn(torch.autograd.Function):
             mean = torch.empty(c, dtype=torch.float32, device=dev)
             rstd = torch.empty(c, dtype=torch.float32, device=dev)
             if tile_stats is not None:      # column sums already produced by the convolution epilogue
-                _lib.check(lib.gcl_bn_stats_from_tiles(_lib.ptr(tile_stats, torch.float32), tile_stats.shape[0], n, c,
-                                                       float(eps), float(momentum), _lib.ptr(running_mean),
-                                                       _lib.ptr(running_var), _lib.ptr(mean), _lib.ptr(rstd),
+                nt = tile_stats.shape[0]
+                scratch = torch.empty(lib.gcl_bn_tiles_scratch_len(nt, c), dtype=torch.float64, device=dev)
+                _lib.check(lib.gcl_bn_stats_from_tiles(_lib.ptr(tile_stats, torch.float32), nt, n, c, float(eps),
+                                                       float(momentum), _lib.ptr(running_mean), _lib.ptr(running_var),
+                                                       _lib.ptr(scratch), _lib.ptr(mean), _lib.ptr(rstd),
                                                        _lib.stream()), "gcl_bn_stats_from_tiles")
             else:
                 scratch = torch.empty(lib.gcl_bn_scratch_len(n, c), dtype=torch.float64, device=dev)

@@ -111,38 +111,19 @@ __global__ void __launch_bounds__(256) k_bn_stats_final(const double* __restrict
 }
 
 // statistics from the per-tile column sums written by the convolution epilogue: partial [n_tiles][2][c] (fp32 sums of
-// <= 32 rows each), added in fp64 in a fixed order
-__global__ void __launch_bounds__(256) k_bn_stats_final_tiles(const float* __restrict__ partial, long long n_tiles,
-                                                              long long n, int c, float eps, float momentum,
-                                                              float* running_mean, float* running_var, float* mean,
-                                                              float* rstd) {
-  __shared__ double red[2][16][17];
-  const int sl = threadIdx.x >> 4, cl = threadIdx.x & 15;
-  const int ch = blockIdx.x * 16 + cl;
-  double a = 0, b = 0;
-  if (ch < c)
-    for (long long t = sl; t < n_tiles; t += 16) {
-      a += (double)partial[(t * 2 + 0) * c + ch];
-      b += (double)partial[(t * 2 + 1) * c + ch];
-    }
-  red[0][sl][cl] = a;
-  red[1][sl][cl] = b;
-  __syncthreads();
-  if (sl != 0 || ch >= c) return;
-  double s = 0, ss = 0;
-  for (int q = 0; q < 16; ++q) {
-    s += red[0][q][cl];
-    ss += red[1][q][cl];
-  }
-  double m = s / (double)n;
-  double var = ss / (double)n - m * m;
-  if (var < 0) var = 0;
-  mean[ch] = (float)m;
-  rstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
-  if (running_mean) {
-    double unb = (n > 1) ? var * (double)n / (double)(n - 1) : var;
-    running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * m);
-    running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unb);
+// <= 32 rows each).  Stage 1 adds 128 tiles per workgroup in fp64 (coalesced: thread = column), stage 2 is the
+// ordinary ordered finalisation over the per-workgroup partials.
+constexpr int BN_TILES_PER_WG = 128;
+
+__global__ void __launch_bounds__(256) k_bn_tiles_reduce(const float* __restrict__ partial, long long n_tiles, int c,
+                                                         double* out) {
+  const long long t0 = (long long)blockIdx.x * BN_TILES_PER_WG;
+  long long t1 = t0 + BN_TILES_PER_WG;
+  if (t1 > n_tiles) t1 = n_tiles;
+  for (int j = threadIdx.x; j < 2 * c; j += 256) {
+    double s = 0;
+    for (long long t = t0; t < t1; ++t) s += (double)partial[t * 2 * c + j];
+    out[(long long)blockIdx.x * 2 * c + j] = s;
   }
 }
 
@@ -240,12 +221,18 @@ int gcl_bn_stats(const float* x, int64_t n, int32_t c, float eps, float momentum
   return GCL_OK;
 }
 
+int64_t gcl_bn_tiles_scratch_len(int64_t n_tiles, int32_t c) { return cdiv(n_tiles, BN_TILES_PER_WG) * 2 * c; }
+
 int gcl_bn_stats_from_tiles(const float* partial, int64_t n_tiles, int64_t n, int32_t c, float eps, float momentum,
-                            float* running_mean, float* running_var, float* mean, float* rstd, void* stream) {
-  GCL_CHECK_ARG(partial && mean && rstd, "gcl_bn_stats_from_tiles: null pointer");
+                            float* running_mean, float* running_var, double* scratch, float* mean, float* rstd,
+                            void* stream) {
+  GCL_CHECK_ARG(partial && scratch && mean && rstd, "gcl_bn_stats_from_tiles: null pointer");
   GCL_CHECK_ARG(n > 0 && n_tiles > 0 && c > 0, "gcl_bn_stats_from_tiles: bad sizes");
-  hipLaunchKernelGGL(k_bn_stats_final_tiles, dim3((unsigned)cdiv(c, 16)), dim3(256), 0, (hipStream_t)stream, partial,
-                     (long long)n_tiles, (long long)n, c, eps, momentum, running_mean, running_var, mean, rstd);
+  hipStream_t st = (hipStream_t)stream;
+  int nwg = (int)cdiv(n_tiles, BN_TILES_PER_WG);
+  hipLaunchKernelGGL(k_bn_tiles_reduce, dim3(nwg), dim3(256), 0, st, partial, (long long)n_tiles, c, scratch);
+  hipLaunchKernelGGL(k_bn_stats_final, dim3((unsigned)cdiv(c, 16)), dim3(256), 0, st, (const double*)scratch, nwg,
+                     (long long)n, c, eps, momentum, running_mean, running_var, mean, rstd);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }

@@ -154,8 +154,10 @@ int64_t gcl_bn_scratch_len(int64_t n, int32_t c);
 int gcl_bn_stats(const float* x, int64_t n, int32_t c, float eps, float momentum,
                  float* running_mean, float* running_var, double* scratch,
                  float* mean, float* rstd, void* stream);
+int64_t gcl_bn_tiles_scratch_len(int64_t n_tiles, int32_t c);   /* doubles */
 int gcl_bn_stats_from_tiles(const float* partial, int64_t n_tiles, int64_t n, int32_t c, float eps, float momentum,
-                            float* running_mean, float* running_var, float* mean, float* rstd, void* stream);
+                            float* running_mean, float* running_var, double* scratch, float* mean, float* rstd,
+                            void* stream);
 int gcl_bn_apply(const float* x, int64_t n, int32_t c, const float* mean, const float* rstd,
                  const float* weight, const float* bias, const float* residual, int32_t relu,
                  float* y, void* stream);
