@@ -30,8 +30,8 @@ F32_MATRIX_PEAK_TFS = 157.3   # MI355X_MICROARCH.md: dense f32 matrix peak (spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch-size", type=int, default=4)
     ap.add_argument("--group-mode", default="fixed16", choices=["fixed16", "radius"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -150,9 +150,11 @@ def main():
         if it == args.steps - 1 and not args.no_kernel_events:
             ops.PROFILE = []
         loss, parts, _ = trainer.train_step(dbatch)
+    t_enqueue = time.perf_counter() - t0
     sync()
     dt = time.perf_counter() - t0
-    log(f"timed region done: {dt / args.steps * 1e3:.2f} ms/step")
+    log(f"timed region done: {dt / args.steps * 1e3:.2f} ms/step (host finished enqueuing after "
+        f"{t_enqueue / args.steps * 1e3:.2f} ms/step)")
     prof, ops.PROFILE = ops.PROFILE, None
     stats = torch.tensor([dt, float(n_vox)], dtype=torch.float64, device=dev)
     if world > 1:

@@ -97,6 +97,20 @@ class _GCLLossFn(torch.autograd.Function):
         return (dF,) + (None,) * 9
 
 
+def draw_selections(n_groups, n_out, max_pos_cluster, max_hn_samples):
+    """The three host-side ``np.random.choice`` draws of finest_contrastive_loss, in the reference's order
+    (lib/colocation_trainer.py:457, :506-507): selected positive groups, then the two negative row subsets.
+    ``np.random.choice(n, k, replace=False)`` permutes all n rows (~4 ms at n = 0.5 M): the trainer therefore draws at
+    the START of a step, while the GPU is still busy with the previous step's backward pass."""
+    if n_groups > max_pos_cluster:
+        pos_sel = np.random.choice(n_groups, max_pos_cluster, replace=False)
+    else:
+        pos_sel = np.arange(n_groups)
+    sel_hn1 = np.random.choice(n_out, min(n_out, max_hn_samples), replace=False)
+    sel_hn2 = np.random.choice(n_out, min(n_out, max_hn_samples), replace=False)
+    return pos_sel, sel_hn1, sel_hn2
+
+
 def finest_contrastive_loss(F_out, group, index, index_hash, finest_flag, max_pos_cluster=256, max_hn_samples=2048,
                             points=None, batch_lengths=None, pos_thresh=0.1, neg_thresh=1.4, finest_thresh=0.2,
                             draws=None):
@@ -110,14 +124,8 @@ def finest_contrastive_loss(F_out, group, index, index_hash, finest_flag, max_po
     group = torch.as_tensor(group)
     n_groups = int(group.shape[0])
     if draws is None:
-        if n_groups > max_pos_cluster:
-            pos_sel = np.random.choice(n_groups, max_pos_cluster, replace=False)
-        else:
-            pos_sel = np.arange(n_groups)
-        sel_hn1 = np.random.choice(n_out, min(n_out, max_hn_samples), replace=False)
-        sel_hn2 = np.random.choice(n_out, min(n_out, max_hn_samples), replace=False)
-    else:
-        pos_sel, sel_hn1, sel_hn2 = draws
+        draws = draw_selections(n_groups, n_out, max_pos_cluster, max_hn_samples)
+    pos_sel, sel_hn1, sel_hn2 = draws
     if len(pos_sel) == 0:
         raise ZeroDivisionError("no positive group in the batch")
     goff = torch.zeros(n_groups + 1, dtype=torch.int64, device=dev)       # no host sync when group is on the GPU
@@ -177,6 +185,11 @@ class FinestContrastiveLossTrainer:
     def train_step(self, input_dict, draws=None):
         """One optimizer step on one batch (iter_size == 1).  Returns device scalars (no host sync here)."""
         self.model.train()
+        if draws is None:     # host RNG first: overlaps with the GPU work still queued from the previous step
+            cfg = self.config
+            draws = draw_selections(len(input_dict["group"]), len(input_dict["sinput_C"]),
+                                    cfg.num_pos_per_batch * cfg.batch_size,
+                                    cfg.num_hn_samples_per_batch * cfg.batch_size)
         if self.ddp is not None:
             self.ddp.flat_grad.zero_()                     # one memset; gradients stay seated in the flat buffer
         else:
