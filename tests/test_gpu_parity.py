@@ -456,3 +456,60 @@ def test_table_sort_is_a_stable_mask_sort(window):
                 assert np.array_equal(tmask.astype(np.int64), np.bitwise_or.reduce(mt, axis=1))
     finally:
         core.SORT_WINDOW = old
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# callers either side of the kernels: extract_features, find_corr / eval step, training step with DDP wrapper
+# ---------------------------------------------------------------------------------------------------------------
+def test_extract_features_and_eval_pair_vs_oracle():
+    """util/misc.extract_features (:58-130) and the eval-loop body (scripts/test_kitti.py:141-161): voxelise ->
+    SparseTensor -> model(eval) -> F; find_corr with seeded subsampling returns the oracle's correspondences."""
+    import gcl_amd.MinkowskiEngine as ME
+    from gcl_amd import synthetic
+    from gcl_amd.lib.eval import find_corr
+    from gcl_amd.util.misc import extract_features
+    m, st = _model_and_state(3, 5)
+    xyz = synthetic.raycast(synthetic.make_scene(2, n_boxes=15), np.zeros(3), 3)[::4]
+    ret_xyz, F = extract_features(m, xyz, voxel_size=0.3, device=torch.device(DEV), skip_check=True)
+    coords, inds = ME.utils.sparse_quantize(np.floor(xyz / 0.3), return_index=True)
+    assert np.array_equal(ret_xyz, xyz[inds]) and F.shape == (len(inds), 32)
+    C = ME.utils.batched_coordinates([coords]).numpy()
+    Fo = O.resunet_forward(st, C, torch.ones(len(C), 1, dtype=torch.float64), 5, True, False, 0.05)
+    assert rel_l2(F.detach().cpu(), Fo) < 1e-4
+    # a second, shifted view of the same scene: correspondences through feature 1-NN
+    xyz1 = synthetic.raycast(synthetic.make_scene(2, n_boxes=15), np.array([4.0, 0, 0]), 4)[::4]
+    ret1, F1 = extract_features(m, xyz1, voxel_size=0.3, device=torch.device(DEV), skip_check=True)
+    np.random.seed(5)
+    a0, a1 = find_corr(ret_xyz, ret1, F.detach(), F1.detach(), subsample_size=1500)
+    np.random.seed(5)
+    i0 = np.random.choice(len(F), 1500, replace=False)
+    i1 = np.random.choice(len(F1), 1500, replace=False)
+    nn = LO.find_nn(F.detach().cpu()[i0], F1.detach().cpu()[i1], nn_max_n=500)
+    assert np.array_equal(a0, ret_xyz[i0])
+    same = (a1 == ret1[i1[nn.numpy()]]).all(axis=1)
+    assert same.mean() > 0.995          # an index may differ only on fp32 near-ties of the distance
+
+
+def test_train_step_matches_oracle_and_flat_ddp_is_transparent():
+    """One optimizer step (a10): loss triple vs the oracle, and the flat-buffer DDP wrapper (world size 1) leaves the
+    update unchanged (up to the last-bit order dependence of the loss backward's float atomics)."""
+    from gcl_amd import ddp, synthetic
+    from gcl_amd.lib.colocation_trainer import FinestContrastiveLossTrainer, make_config
+    batch = synthetic.collate_train([synthetic.make_train_sample(21, num_neighborhood=2, n_boxes=10)])
+    N, G = len(batch["sinput_C"]), len(batch["group"])
+    rng = np.random.RandomState(0)
+    draws = (rng.choice(G, min(G, 64), replace=False), rng.choice(N, 256, replace=False), rng.choice(N, 256, replace=False))
+    cfg = make_config(batch_size=1, num_pos_per_batch=64, num_hn_samples_per_batch=256)
+    outs = []
+    for use_ddp in (False, True):
+        torch.manual_seed(11)
+        tr = FinestContrastiveLossTrainer(cfg, device=DEV, ddp=ddp.FlatDDP() if use_ddp else None)
+        st0 = {k: v.detach().cpu().double().clone() for k, v in tr.model.state_dict().items() if "num_batches" not in k}
+        loss, parts, n = tr.train_step(batch, draws=draws)
+        outs.append((loss.item(), [p.item() for p in parts],
+                     torch.cat([p.detach().reshape(-1) for p in tr.model.parameters()]).cpu()))
+    assert outs[0][0] == outs[1][0] and torch.allclose(outs[0][2], outs[1][2], rtol=1e-4, atol=1e-6)
+    Fo = O.resunet_forward(st0, batch["sinput_C"].numpy(), batch["sinput_F"].double(), 5, True, True, 0.05)
+    ref = LO.finest_contrastive_loss(Fo, batch["group"].numpy(), batch["index"].numpy(), batch["index_hash"],
+                                     batch["finest_flag"].numpy(), draws=draws)
+    assert np.allclose(outs[0][1], [r.item() for r in ref], rtol=2e-4, atol=2e-5)
