@@ -11,7 +11,9 @@ from .. import _lib
 #   "bf16x6" fp32 operands split into 3 bf16 planes, 6 MFMA terms, fp32 accumulate -- error vs the fp64 oracle equal
 #            to native fp32 (tests/test_gpu_parity.py), 2.7x the MFMA rate  [default]
 #   "bf16x3" 2 planes, 3 terms (~1.5e-5 relative), 5.3x the MFMA rate
-_PREC_CODES = {"f32": 0, "bf16x3": 2, "bf16x6": 3}
+#   "fp16x3" 2 fp16 planes of operands pre-scaled by a per-tensor power of two (max-abs), 3 terms: 24 significand
+#            bits like fp32, 5.3x the MFMA rate; costs one max-abs pass per operand tensor
+_PREC_CODES = {"f32": 0, "bf16x3": 2, "bf16x6": 3, "fp16x3": 4}
 PRECISION = os.environ.get("GCL_CONV_PRECISION", "bf16x6")
 if PRECISION not in _PREC_CODES:
     raise ValueError(f"GCL_CONV_PRECISION must be one of {sorted(_PREC_CODES)}")
@@ -48,16 +50,27 @@ class _Timed:
             PROFILE.append(self.rec)
 
 
-def _conv_launch(lib, x, Wk, mode, table, n_out, cin, cout, bias, pairs=0, want_stats=False):
+def tensor_amax(lib, t):
+    """Device int32[1] holding the bit pattern of max|t| (only the fp16x3 mode needs it)."""
+    out = torch.empty(1, dtype=torch.int32, device=t.device)
+    _lib.check(lib.gcl_amax(_lib.ptr(t, torch.float32), t.numel(), _lib.ptr(out), _lib.stream()), "gcl_amax")
+    return out
+
+
+def _conv_launch(lib, x, Wk, mode, table, n_out, cin, cout, bias, pairs=0, want_stats=False, x_amax=None,
+                 w_amax=None):
     """One output-stationary convolution launch.  ``Wk`` [K, *, *] is packed for ``mode`` (0 forward, 1 transposed,
     2 transposed + mirrored offsets) in the current precision; ``table`` = (tbl, order, tile_mask) from
     KernelMap.sorted_table(), or None for a kernel_size-1 conv; (cin, cout) are the EFFECTIVE widths of the launch.
     ``want_stats``: also return the per-tile column sums [ceil(n_out/32), 2, cout] for a following BatchNorm."""
     prec = _PREC_CODES[PRECISION]
     K, wc_in, wc_out = Wk.shape
+    if prec == 4:
+        x_amax = x_amax if x_amax is not None else tensor_amax(lib, x)
+        w_amax = w_amax if w_amax is not None else tensor_amax(lib, Wk)
     wp = torch.empty(lib.gcl_pack_weights_bytes(K, wc_in, wc_out, prec), dtype=torch.uint8, device=Wk.device)
-    _lib.check(lib.gcl_pack_weights(_lib.ptr(Wk, torch.float32), K, wc_in, wc_out, mode, prec, _lib.ptr(wp),
-                                    _lib.stream()), "gcl_pack_weights")
+    _lib.check(lib.gcl_pack_weights(_lib.ptr(Wk, torch.float32), K, wc_in, wc_out, mode, prec, _lib.ptr(w_amax),
+                                    _lib.ptr(wp), _lib.stream()), "gcl_pack_weights")
     tbl, order, tile_mask = table if table is not None else (None, None, None)
     y = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
     stats = None
@@ -66,9 +79,10 @@ def _conv_launch(lib, x, Wk, mode, table, n_out, cin, cout, bias, pairs=0, want_
     nb = 4 if cout % 128 == 0 else (2 if cout % 64 == 0 else 1)
     name = f"k_conv_fwd<{nb}>" if prec == 0 else f"k_conv_fwd_split<{nb},{prec}>"
     with _Timed(name, pairs, cin, cout):
-        _lib.check(lib.gcl_conv_fwd(_lib.ptr(x, torch.float32), _lib.ptr(wp), prec, _lib.ptr(tbl), _lib.ptr(order),
-                                    _lib.ptr(tile_mask), n_out, K, cin, cout, _lib.ptr(bias), _lib.ptr(y),
-                                    _lib.ptr(stats), _lib.stream()), "gcl_conv_fwd")
+        _lib.check(lib.gcl_conv_fwd(_lib.ptr(x, torch.float32), _lib.ptr(wp), prec, _lib.ptr(x_amax),
+                                    _lib.ptr(w_amax), _lib.ptr(tbl), _lib.ptr(order), _lib.ptr(tile_mask), n_out, K,
+                                    cin, cout, _lib.ptr(bias), _lib.ptr(y), _lib.ptr(stats), _lib.stream()),
+                   "gcl_conv_fwd")
     return (y, stats) if want_stats else y
 
 
@@ -85,6 +99,7 @@ class _SparseConvFn(torch.autograd.Function):
         if x.shape[1] != cin:
             raise ValueError(f"feature width {x.shape[1]} != in_channels {cin}")
         ctx.stem = cin <= 4
+        ctx.x_amax = ctx.w_amax = None
         if ctx.stem:
             if transpose or kmap is None or bias is not None:
                 raise NotImplementedError("Cin <= 4 is supported for the first (non-transposed, bias-free) conv only")
@@ -96,8 +111,12 @@ class _SparseConvFn(torch.autograd.Function):
             b = bias.detach().contiguous().view(-1) if bias is not None else None
             # pair counts reach the host asynchronously; only the profiler needs them in the forward pass
             ctx.pairs = (kmap.n_pairs if kmap is not None else n_out) if PROFILE is not None else 0
-            y, stats = _conv_launch(lib, x, Wk, 0, tbl, n_out, cin, cout, b, ctx.pairs, want_stats=True) \
-                if want_stats else (_conv_launch(lib, x, Wk, 0, tbl, n_out, cin, cout, b, ctx.pairs), None)
+            if _PREC_CODES[PRECISION] == 4:
+                ctx.x_amax, ctx.w_amax = tensor_amax(lib, x), tensor_amax(lib, Wk)
+            y, stats = _conv_launch(lib, x, Wk, 0, tbl, n_out, cin, cout, b, ctx.pairs, want_stats=True,
+                                    x_amax=ctx.x_amax, w_amax=ctx.w_amax) \
+                if want_stats else (_conv_launch(lib, x, Wk, 0, tbl, n_out, cin, cout, b, ctx.pairs,
+                                                 x_amax=ctx.x_amax, w_amax=ctx.w_amax), None)
         ctx.save_for_backward(x, Wk)
         ctx.kmap, ctx.transpose, ctx.mgr, ctx.w_shape, ctx.has_bias = kmap, transpose, mgr, W.shape, bias is not None
         if stats is None:
@@ -114,6 +133,10 @@ class _SparseConvFn(torch.autograd.Function):
         kmap, transpose = ctx.kmap, ctx.transpose
         dy = dy.contiguous()
         dx = dW = dbias = None
+        prec = _PREC_CODES[PRECISION]
+        dy_amax = tensor_amax(lib, dy) if (prec == 4 and not ctx.stem) else None
+        x_amax = ctx.x_amax if (prec != 4 or ctx.x_amax is not None or ctx.stem) else tensor_amax(lib, x)
+        w_amax = ctx.w_amax if (prec != 4 or ctx.w_amax is not None or ctx.stem) else tensor_amax(lib, Wk)
         if not ctx.stem and PROFILE is not None:
             ctx.pairs = kmap.n_pairs if kmap is not None else x.shape[0]
         if ctx.needs_input_grad[0]:
@@ -127,7 +150,8 @@ class _SparseConvFn(torch.autograd.Function):
                 mode, tbl = 2, kmap.sorted_table(transposed=False)
             else:
                 mode, tbl = 1, kmap.sorted_table(transposed=True)
-            dx = _conv_launch(lib, dy, Wk, mode, tbl, x.shape[0], cout, cin, None, ctx.pairs)
+            dx = _conv_launch(lib, dy, Wk, mode, tbl, x.shape[0], cout, cin, None, ctx.pairs, x_amax=dy_amax,
+                              w_amax=w_amax)
         if ctx.needs_input_grad[1]:
             dW = torch.empty_like(Wk)
             if ctx.stem:
@@ -145,13 +169,13 @@ class _SparseConvFn(torch.autograd.Function):
                     pa, pb = (pout, pin) if transpose else (pin, pout)
                 scratch = torch.empty(lib.gcl_conv_bwd_weight_scratch_len(K, cin, cout, seg[-1]), dtype=torch.float32,
                                       device=x.device)
-                prec = _PREC_CODES[PRECISION]
                 tile = f"{64 if cin % 64 == 0 else 32},{64 if cout % 64 == 0 else 32}"
                 name = f"k_conv_bwd_weight<{tile}>" if prec == 0 else f"k_conv_bwd_weight_split<{tile},{prec}>"
                 with _Timed(name, ctx.pairs, cin, cout):
                     _lib.check(lib.gcl_conv_bwd_weight(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(pa), _lib.ptr(pb), seg_host,
-                                                       K, cin, cout, prec, _lib.ptr(scratch), _lib.ptr(dW),
-                                                       _lib.stream()), "gcl_conv_bwd_weight")
+                                                       K, cin, cout, prec, _lib.ptr(x_amax), _lib.ptr(dy_amax),
+                                                       _lib.ptr(scratch), _lib.ptr(dW), _lib.stream()),
+                               "gcl_conv_bwd_weight")
             dW = dW.view(ctx.w_shape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             dbias = dy.sum(0, keepdim=True)

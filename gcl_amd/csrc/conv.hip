@@ -201,26 +201,100 @@ __device__ unsigned long long g_stamps[8];
 #endif
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// Arithmetic modes of the split kernels (template parameter PL):
+//   2 = "bf16x3": 2 bf16 planes, 3 MFMA terms            (~1.5e-5)
+//   3 = "bf16x6": 3 bf16 planes, 6 MFMA terms            (= native fp32)
+//   4 = "fp16x3": 2 fp16 planes (11 + 11 significand bits, round-to-nearest => 24 bits), 3 MFMA terms, operands
+//       pre-scaled by a per-tensor power of two so that |x| * scale < 2^14 (fp16 range); = native fp32 at half the
+//       MFMA work of bf16x6.  The scale comes from the tensor's max-abs (gcl_amax), the result is un-scaled exactly.
 template <int PL>
-__device__ __forceinline__ void split8(const float4& f0, const float4& f1, bf16x8* pl) {
+struct Prec {
+  static constexpr int planes = (PL == 3) ? 3 : 2;
+};
+
+// power-of-two scale that maps amax into [2^13, 2^14)
+__device__ __forceinline__ float amax_scale(const int* __restrict__ amax_bits) {
+  float amax = __int_as_float(*amax_bits);
+  if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.f;
+  int e;
+  frexpf(amax, &e);   // amax = m * 2^e, m in [0.5, 1)
+  return ldexpf(1.f, 14 - e);
+}
+
+template <int PL>
+__device__ __forceinline__ void split8(const float4& f0, const float4& f1, float scale, u32x4* pl) {
   float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+  if (PL == 4) {
+    f16x8 hi, lo;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    __bf16 hi = (__bf16)v[j];
-    float r = v[j] - (float)hi;
-    __bf16 mid = (__bf16)r;
-    pl[0][j] = hi;
-    pl[1][j] = mid;
-    if (PL == 3) pl[2][j] = (__bf16)(r - (float)mid);
+    for (int j = 0; j < 8; ++j) {
+      float sv = v[j] * scale;
+      _Float16 hh = (_Float16)sv;
+      hi[j] = hh;
+      lo[j] = (_Float16)(sv - (float)hh);
+    }
+    pl[0] = __builtin_bit_cast(u32x4, hi);
+    pl[1] = __builtin_bit_cast(u32x4, lo);
+  } else {
+    bf16x8 p0, p1, p2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      __bf16 hi = (__bf16)v[j];
+      float r = v[j] - (float)hi;
+      __bf16 mid = (__bf16)r;
+      p0[j] = hi;
+      p1[j] = mid;
+      if (PL == 3) p2[j] = (__bf16)(r - (float)mid);
+    }
+    pl[0] = __builtin_bit_cast(u32x4, p0);
+    pl[1] = __builtin_bit_cast(u32x4, p1);
+    if (PL == 3) pl[2] = __builtin_bit_cast(u32x4, p2);
   }
 }
 
-// wp16 (bf16x8 units): [(((k*CC + cc)*TNB + nb)*2 + m)*PL + pl][lane = h*32 + j][jj]
-//                      = plane pl of W_eff[k][cc*32 + 16m + 8h + jj][32 nb + j]
 template <int PL>
-__global__ void k_pack_weights_split(const float* __restrict__ w, int K, int cin, int cout, int mode, __bf16* wp) {
+__device__ __forceinline__ f32x16 mfma16(const u32x4& a, const u32x4& b, const f32x16& c) {
+  if (PL == 4)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// all product terms of one (A planes, B planes) pair, small terms first
+template <int PL>
+__device__ __forceinline__ void mfma_terms(const u32x4* a, const u32x4* b, f32x16& acc) {
+  if (PL == 3) {
+    acc = mfma16<PL>(a[2], b[0], acc);
+    acc = mfma16<PL>(a[0], b[2], acc);
+    acc = mfma16<PL>(a[1], b[1], acc);
+  }
+  acc = mfma16<PL>(a[1], b[0], acc);
+  acc = mfma16<PL>(a[0], b[1], acc);
+  acc = mfma16<PL>(a[0], b[0], acc);
+}
+
+// max |x| of a tensor as the bit pattern of a non-negative float (integer atomicMax is order-independent)
+__global__ void __launch_bounds__(256) k_amax(const float4* __restrict__ x, long long n4, const float* __restrict__ tail,
+                                              int n_tail, int* amax_bits) {
+  float m = 0.f;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (long long)gridDim.x * blockDim.x) {
+    float4 v = x[e];
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+  }
+  if (blockIdx.x == 0 && (int)threadIdx.x < n_tail) m = fmaxf(m, fabsf(tail[threadIdx.x]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(amax_bits, __float_as_int(m));
+}
+
+// wp16 (8 x 16-bit units): [(((k*CC + cc)*TNB + nb)*2 + m)*planes + pl][lane = h*32 + j][jj]
+//                         = plane pl of W_eff[k][cc*32 + 16m + 8h + jj][32 nb + j]   (fp16 mode: of W_eff * scale)
+template <int PL>
+__global__ void k_pack_weights_split(const float* __restrict__ w, int K, int cin, int cout, int mode,
+                                     const int* __restrict__ w_amax, unsigned short* wp) {
+  constexpr int NPL = Prec<PL>::planes;
   long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   long long total = (long long)K * cin * cout;
   if (o >= total) return;
@@ -245,13 +319,21 @@ __global__ void k_pack_weights_split(const float* __restrict__ w, int K, int cin
     int ks = (mode == 2) ? (K - 1 - k) : k;
     v = w[((long long)ks * cin + n) * cout + c];
   }
-  __bf16 hi = (__bf16)v;
-  float r = v - (float)hi;
-  __bf16 mid = (__bf16)r;
-  long long blk = ((((long long)k * CC + cc) * TNB + nb) * 2 + m) * PL;
-  wp[((blk + 0) * 64 + l) * 8 + jj] = hi;
-  wp[((blk + 1) * 64 + l) * 8 + jj] = mid;
-  if (PL == 3) wp[((blk + 2) * 64 + l) * 8 + jj] = (__bf16)(r - (float)mid);
+  long long blk = ((((long long)k * CC + cc) * TNB + nb) * 2 + m) * NPL;
+  if (PL == 4) {
+    float sv = v * amax_scale(w_amax);
+    _Float16 hi = (_Float16)sv;
+    _Float16 lo = (_Float16)(sv - (float)hi);
+    wp[((blk + 0) * 64 + l) * 8 + jj] = __builtin_bit_cast(unsigned short, hi);
+    wp[((blk + 1) * 64 + l) * 8 + jj] = __builtin_bit_cast(unsigned short, lo);
+  } else {
+    __bf16 hi = (__bf16)v;
+    float r = v - (float)hi;
+    __bf16 mid = (__bf16)r;
+    wp[((blk + 0) * 64 + l) * 8 + jj] = __builtin_bit_cast(unsigned short, hi);
+    wp[((blk + 1) * 64 + l) * 8 + jj] = __builtin_bit_cast(unsigned short, mid);
+    if (PL == 3) wp[((blk + 2) * 64 + l) * 8 + jj] = __builtin_bit_cast(unsigned short, (__bf16)(r - (float)mid));
+  }
 }
 
 template <int NB, int PL>
@@ -260,8 +342,12 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
                                                         const int* __restrict__ tile_mask, long long n_out, int K,
                                                         int cin, int cout, const float* __restrict__ bias,
                                                         float* __restrict__ Y, int swizzle,
-                                                        float* __restrict__ stats) {
-  constexpr int BLK = NB * 2 * PL * 64;                 // uint4 per (k, cc) weight block of this workgroup
+                                                        float* __restrict__ stats, const int* __restrict__ x_amax,
+                                                        const int* __restrict__ w_amax) {
+  constexpr int NPL = Prec<PL>::planes;
+  constexpr int BLK = NB * 2 * NPL * 64;                // uint4 per (k, cc) weight block of this workgroup
+  const float a_scale = (PL == 4) ? amax_scale(x_amax) : 1.f;
+  const float out_scale = (PL == 4) ? 1.f / (a_scale * amax_scale(w_amax)) : 1.f;   // exact: powers of two
   constexpr int BREG = (BLK + 255) / 256;
   STAMP(ts_begin)
 #ifdef GCL_STAMPS
@@ -310,7 +396,7 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
   }
 #define GCL_LOAD_B(KK, CCV)                                                                      \
   {                                                                                              \
-    const u32x4* src_ = Wp + (((long long)(KK)*CC + (CCV)) * TNB + nb0) * (2 * PL * 64);         \
+    const u32x4* src_ = Wp + (((long long)(KK)*CC + (CCV)) * TNB + nb0) * (2 * NPL * 64);        \
     _Pragma("unroll") for (int e = 0; e < BREG; ++e) {                                           \
       if ((BLK % 256 == 0) || (e * 256 + t < BLK)) br[e] = src_[e * 256 + t];                    \
     }                                                                                            \
@@ -361,21 +447,16 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
         for (int m = 0; m < 2; ++m) {
           float4 f0 = *reinterpret_cast<const float4*>(&Asm[w][i][16 * m + 8 * h]);
           float4 f1 = *reinterpret_cast<const float4*>(&Asm[w][i][16 * m + 8 * h + 4]);
-          bf16x8 ap[3];
-          split8<PL>(f0, f1, ap);
+          u32x4 ap[3];
+          split8<PL>(f0, f1, a_scale, ap);
 #pragma unroll
           for (int b = 0; b < NB; ++b) {
-            const u32x4* bb = Bsm + ((b * 2 + m) * PL) * 64 + l;
-            const bf16x8 bh = __builtin_bit_cast(bf16x8, bb[0]), bm = __builtin_bit_cast(bf16x8, bb[64]);
-            if (PL == 3) {
-              const bf16x8 bl = __builtin_bit_cast(bf16x8, bb[128]);
-              acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[2], bh, acc[b], 0, 0, 0);
-              acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], bl, acc[b], 0, 0, 0);
-              acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], bm, acc[b], 0, 0, 0);
-            }
-            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], bh, acc[b], 0, 0, 0);
-            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], bm, acc[b], 0, 0, 0);
-            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], bh, acc[b], 0, 0, 0);
+            const u32x4* bb = Bsm + ((b * 2 + m) * NPL) * 64 + l;
+            u32x4 bp[3];
+            bp[0] = bb[0];
+            bp[1] = bb[64];
+            if (NPL == 3) bp[2] = bb[128];
+            mfma_terms<PL>(ap, bp, acc[b]);
           }
         }
       }
@@ -415,7 +496,7 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
     for (int r = 0; r < 16; ++r) {
       int orow = __shfl(orow_l, (r & 3) + 8 * (r >> 2) + 4 * h);
       if (orow >= 0) {
-        float v = acc[b][r] + bvv;
+        float v = acc[b][r] * out_scale + bvv;
         Y[(long long)orow * cout + col] = v;
         s1 += v;
         s2 += v * v;
@@ -555,11 +636,14 @@ __global__ void __launch_bounds__(256) k_conv_bwd_weight_split(const float* __re
                                                                const int* __restrict__ pair_a,
                                                                const int* __restrict__ pair_b, SegOffW seg, int K,
                                                                int ca, int cb, long long n_chunks, int per,
-                                                               float* slabs) {
+                                                               float* slabs, const int* __restrict__ a_amax,
+                                                               const int* __restrict__ b_amax) {
   constexpr int NBI = TCA / 32, NBJ = TCB / 32;
   constexpr int PA = TCA / 4, PB = TCB / 4;         // 16-byte pieces per row
   constexpr int RA = 64 / PA, RB = 64 / PB;          // rows per load pass
   constexpr int NPA = 32 / RA, NPB = 32 / RB;        // load passes per 32-pair tile
+  const float sa = (PL == 4) ? amax_scale(a_amax) : 1.f, sb = (PL == 4) ? amax_scale(b_amax) : 1.f;
+  const float out_scale = 1.f / (sa * sb);
   __shared__ __attribute__((aligned(16))) float lds_all[4 * 32 * (TCA + TCB)];
   float (*As)[32][TCA] = reinterpret_cast<float (*)[32][TCA]>(lds_all);
   float (*Bs)[32][TCB] = reinterpret_cast<float (*)[32][TCB]>(lds_all + 4 * 32 * TCA);
@@ -580,6 +664,14 @@ __global__ void __launch_bounds__(256) k_conv_bwd_weight_split(const float* __re
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   auto flush = [&](int k) {
+    if (PL == 4) {
+#pragma unroll
+      for (int a = 0; a < NBI; ++a)
+#pragma unroll
+        for (int b = 0; b < NBJ; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][b][r] *= out_scale;
+    }
     bwd_weight_flush<TCA, TCB>(acc, lds_all, slabs + (long long)(blockIdx.x + k) * ((long long)ca * cb), ca0, cb0, cb);
   };
   auto load_pairs = [&](long long c, int& ia, int& ib) {
@@ -632,32 +724,23 @@ __global__ void __launch_bounds__(256) k_conv_bwd_weight_split(const float* __re
     WAVE_FENCE();
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-      bf16x8 pa[NBI][3];
+      u32x4 pa[NBI][3];
 #pragma unroll
       for (int a = 0; a < NBI; ++a) {
         float v[8];
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) v[jj] = As[w][16 * half + 8 * h + jj][a * 32 + i];
-        split8<PL>(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), pa[a]);
+        split8<PL>(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), sa, pa[a]);
       }
 #pragma unroll
       for (int b = 0; b < NBJ; ++b) {
         float v[8];
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) v[jj] = Bs[w][16 * half + 8 * h + jj][b * 32 + i];
-        bf16x8 pb[3];
-        split8<PL>(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), pb);
+        u32x4 pb[3];
+        split8<PL>(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), sb, pb);
 #pragma unroll
-        for (int a = 0; a < NBI; ++a) {
-          if (PL == 3) {
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[a][2], pb[0], acc[a][b], 0, 0, 0);
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[a][0], pb[2], acc[a][b], 0, 0, 0);
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[a][1], pb[1], acc[a][b], 0, 0, 0);
-          }
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[a][1], pb[0], acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[a][0], pb[1], acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[a][0], pb[0], acc[a][b], 0, 0, 0);
-        }
+        for (int a = 0; a < NBI; ++a) mfma_terms<PL>(pa[a], pb, acc[a][b]);
       }
     }
   }
@@ -802,37 +885,55 @@ int gcl_debug_stamps(unsigned long long* out_host, int reset) {
 
 int64_t gcl_pack_weights_bytes(int32_t K, int32_t cin, int32_t cout, int32_t prec) {
   long long n = (long long)K * cin * cout;
-  return prec == 0 ? n * 4 : n * 2 * prec;
+  return prec == 0 ? n * 4 : n * 2 * (prec == 3 ? 3 : 2);
 }
 
-int gcl_pack_weights(const float* w, int32_t K, int32_t cin, int32_t cout, int32_t mode, int32_t prec, void* wp,
-                     void* stream) {
-  GCL_CHECK_ARG(w && wp, "gcl_pack_weights: null pointer");
-  GCL_CHECK_ARG(K >= 1 && cin % 32 == 0 && cout % 32 == 0 && cin > 0 && cout > 0,
-                "gcl_pack_weights: Cin (%d) and Cout (%d) must be positive multiples of 32", cin, cout);
-  GCL_CHECK_ARG(mode >= 0 && mode <= 2, "gcl_pack_weights: mode must be 0, 1 or 2");
-  GCL_CHECK_ARG(prec == 0 || prec == 2 || prec == 3, "gcl_pack_weights: prec must be 0 (f32), 2 (bf16x3) or 3 (bf16x6)");
-  long long total = (long long)K * cin * cout;
-  dim3 grid((unsigned)cdiv(total, 256));
+static bool prec_ok(int prec) { return prec == 0 || prec == 2 || prec == 3 || prec == 4; }
+
+int gcl_amax(const float* x, int64_t n, int32_t* amax_bits, void* stream) {
+  GCL_CHECK_ARG(x && amax_bits && n > 0, "gcl_amax: bad argument");
   hipStream_t st = (hipStream_t)stream;
-  if (prec == 0) hipLaunchKernelGGL(k_pack_weights, grid, dim3(256), 0, st, w, K, cin, cout, mode, (float*)wp);
-  else if (prec == 2) hipLaunchKernelGGL(k_pack_weights_split<2>, grid, dim3(256), 0, st, w, K, cin, cout, mode, (__bf16*)wp);
-  else hipLaunchKernelGGL(k_pack_weights_split<3>, grid, dim3(256), 0, st, w, K, cin, cout, mode, (__bf16*)wp);
+  GCL_CHECK_HIP(hipMemsetAsync(amax_bits, 0, sizeof(int32_t), st));
+  long long n4 = n / 4;
+  long long g = cdiv(n4 > 0 ? n4 : 1, 256);
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(k_amax, dim3((unsigned)g), dim3(256), 0, st, (const float4*)x, n4, x + n4 * 4, (int)(n - n4 * 4),
+                     amax_bits);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }
 
-int gcl_conv_fwd(const float* x, const void* wp, int32_t prec, const int32_t* tbl, const int32_t* order,
-                 const int32_t* tile_mask, int64_t n_out, int32_t K, int32_t cin, int32_t cout, const float* bias,
-                 float* y, float* stats, void* stream) {
+int gcl_pack_weights(const float* w, int32_t K, int32_t cin, int32_t cout, int32_t mode, int32_t prec,
+                     const int32_t* w_amax, void* wp, void* stream) {
+  GCL_CHECK_ARG(w && wp, "gcl_pack_weights: null pointer");
+  GCL_CHECK_ARG(K >= 1 && cin % 32 == 0 && cout % 32 == 0 && cin > 0 && cout > 0,
+                "gcl_pack_weights: Cin (%d) and Cout (%d) must be positive multiples of 32", cin, cout);
+  GCL_CHECK_ARG(mode >= 0 && mode <= 2, "gcl_pack_weights: mode must be 0, 1 or 2");
+  GCL_CHECK_ARG(prec_ok(prec), "gcl_pack_weights: prec must be 0 (f32), 2 (bf16x3), 3 (bf16x6) or 4 (fp16x3)");
+  GCL_CHECK_ARG(prec != 4 || w_amax, "gcl_pack_weights: fp16x3 needs the weight tensor's gcl_amax");
+  long long total = (long long)K * cin * cout;
+  dim3 grid((unsigned)cdiv(total, 256));
+  hipStream_t st = (hipStream_t)stream;
+  if (prec == 0) hipLaunchKernelGGL(k_pack_weights, grid, dim3(256), 0, st, w, K, cin, cout, mode, (float*)wp);
+  else if (prec == 2) hipLaunchKernelGGL(k_pack_weights_split<2>, grid, dim3(256), 0, st, w, K, cin, cout, mode, w_amax, (unsigned short*)wp);
+  else if (prec == 3) hipLaunchKernelGGL(k_pack_weights_split<3>, grid, dim3(256), 0, st, w, K, cin, cout, mode, w_amax, (unsigned short*)wp);
+  else hipLaunchKernelGGL(k_pack_weights_split<4>, grid, dim3(256), 0, st, w, K, cin, cout, mode, w_amax, (unsigned short*)wp);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int gcl_conv_fwd(const float* x, const void* wp, int32_t prec, const int32_t* x_amax, const int32_t* w_amax,
+                 const int32_t* tbl, const int32_t* order, const int32_t* tile_mask, int64_t n_out, int32_t K,
+                 int32_t cin, int32_t cout, const float* bias, float* y, float* stats, void* stream) {
   GCL_CHECK_ARG(x && wp && y, "gcl_conv_fwd: null pointer");
-  GCL_CHECK_ARG(!stats || prec != 0, "gcl_conv_fwd: fused BN statistics need prec 2 or 3");
   GCL_CHECK_ARG(n_out > 0 && K >= 1 && K <= 27, "gcl_conv_fwd: n_out must be positive and 1 <= K <= 27");
   GCL_CHECK_ARG(tbl || K == 1, "gcl_conv_fwd: a neighbour table is required when K > 1");
   GCL_CHECK_ARG((order == nullptr) == (tile_mask == nullptr), "gcl_conv_fwd: order and tile_mask go together");
   GCL_CHECK_ARG(cin % 32 == 0 && cout % 32 == 0 && cin > 0 && cout > 0,
                 "gcl_conv_fwd: Cin (%d) and Cout (%d) must be positive multiples of 32", cin, cout);
-  GCL_CHECK_ARG(prec == 0 || prec == 2 || prec == 3, "gcl_conv_fwd: prec must be 0 (f32), 2 (bf16x3) or 3 (bf16x6)");
+  GCL_CHECK_ARG(prec_ok(prec), "gcl_conv_fwd: prec must be 0 (f32), 2 (bf16x3), 3 (bf16x6) or 4 (fp16x3)");
+  GCL_CHECK_ARG(!stats || prec != 0, "gcl_conv_fwd: fused BN statistics need a split-precision mode");
+  GCL_CHECK_ARG(prec != 4 || (x_amax && w_amax), "gcl_conv_fwd: fp16x3 needs gcl_amax of x and of the weights");
   hipStream_t st = (hipStream_t)stream;
   static const int swz = [] {   // tuning knob, default off (measured: -5 % with the global sort, +7 % with the windowed sort)
     const char* e = getenv("GCL_XCD_SWIZZLE");
@@ -846,16 +947,19 @@ int gcl_conv_fwd(const float* x, const void* wp, int32_t prec, const int32_t* tb
                      (long long)n_out, K, cin, cout, bias, y, swz)
 #define LAUNCH_SPLIT(NBV, PLV)                                                                                   \
   hipLaunchKernelGGL((k_conv_fwd_split<NBV, PLV>), grid, dim3(256), 0, st, x, (const u32x4*)wp, tbl, order,      \
-                     tile_mask, (long long)n_out, K, cin, cout, bias, y, swz, stats)
+                     tile_mask, (long long)n_out, K, cin, cout, bias, y, swz, stats, x_amax, w_amax)
+#define LAUNCH_SPLIT_NB(PLV)                                                             \
+  {                                                                                      \
+    if (nb == 4) LAUNCH_SPLIT(4, PLV); else if (nb == 2) LAUNCH_SPLIT(2, PLV); else LAUNCH_SPLIT(1, PLV); \
+  }
   if (prec == 0) {
     if (nb == 4) LAUNCH_F32(4); else if (nb == 2) LAUNCH_F32(2); else LAUNCH_F32(1);
-  } else if (prec == 2) {
-    if (nb == 4) LAUNCH_SPLIT(4, 2); else if (nb == 2) LAUNCH_SPLIT(2, 2); else LAUNCH_SPLIT(1, 2);
-  } else {
-    if (nb == 4) LAUNCH_SPLIT(4, 3); else if (nb == 2) LAUNCH_SPLIT(2, 3); else LAUNCH_SPLIT(1, 3);
-  }
+  } else if (prec == 2) LAUNCH_SPLIT_NB(2)
+  else if (prec == 3) LAUNCH_SPLIT_NB(3)
+  else LAUNCH_SPLIT_NB(4)
 #undef LAUNCH_F32
 #undef LAUNCH_SPLIT
+#undef LAUNCH_SPLIT_NB
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }
@@ -866,13 +970,14 @@ int64_t gcl_conv_bwd_weight_scratch_len(int32_t K, int32_t ca, int32_t cb, int64
 }
 
 int gcl_conv_bwd_weight(const float* a, const float* b, const int32_t* pair_a, const int32_t* pair_b,
-                        const int64_t* seg_off_host, int32_t K, int32_t ca, int32_t cb, int32_t prec, float* scratch,
-                        float* dw, void* stream) {
+                        const int64_t* seg_off_host, int32_t K, int32_t ca, int32_t cb, int32_t prec,
+                        const int32_t* a_amax, const int32_t* b_amax, float* scratch, float* dw, void* stream) {
   GCL_CHECK_ARG(a && b && pair_a && pair_b && seg_off_host && scratch && dw, "gcl_conv_bwd_weight: null pointer");
   GCL_CHECK_ARG(K >= 1 && K <= 125, "gcl_conv_bwd_weight: bad K");
   GCL_CHECK_ARG(ca % 32 == 0 && cb % 32 == 0 && ca > 0 && cb > 0,
                 "gcl_conv_bwd_weight: channel counts (%d, %d) must be positive multiples of 32", ca, cb);
-  GCL_CHECK_ARG(prec == 0 || prec == 2 || prec == 3, "gcl_conv_bwd_weight: prec must be 0, 2 or 3");
+  GCL_CHECK_ARG(prec_ok(prec), "gcl_conv_bwd_weight: prec must be 0, 2, 3 or 4");
+  GCL_CHECK_ARG(prec != 4 || (a_amax && b_amax), "gcl_conv_bwd_weight: fp16x3 needs gcl_amax of both operands");
   hipStream_t st = (hipStream_t)stream;
   SegOffW seg;
   for (int k = 0; k <= K; ++k) seg.off[k] = seg_off_host[k];
@@ -883,23 +988,24 @@ int gcl_conv_bwd_weight(const float* a, const float* b, const int32_t* pair_a, c
   if (nc > 0) {
     int tca = (ca % 64 == 0) ? 64 : 32, tcb = (cb % 64 == 0) ? 64 : 32;
     dim3 grid(W, (ca / tca) * (cb / tcb));
+#define LAUNCH_BWS(TA, TB, PLV)                                                                                     \
+  hipLaunchKernelGGL((k_conv_bwd_weight_split<TA, TB, PLV>), grid, dim3(256), 0, st, a, b, pair_a, pair_b, seg, K, \
+                     ca, cb, nc, per, scratch, a_amax, b_amax)
 #define LAUNCH_BW(TA, TB)                                                                                          \
   {                                                                                                                \
     if (prec == 0)                                                                                                 \
       hipLaunchKernelGGL((k_conv_bwd_weight<TA, TB>), grid, dim3(256), 0, st, a, b, pair_a, pair_b, seg, K, ca, cb, \
                          nc, per, scratch);                                                                        \
-    else if (prec == 2)                                                                                            \
-      hipLaunchKernelGGL((k_conv_bwd_weight_split<TA, TB, 2>), grid, dim3(256), 0, st, a, b, pair_a, pair_b, seg,  \
-                         K, ca, cb, nc, per, scratch);                                                             \
-    else                                                                                                           \
-      hipLaunchKernelGGL((k_conv_bwd_weight_split<TA, TB, 3>), grid, dim3(256), 0, st, a, b, pair_a, pair_b, seg,  \
-                         K, ca, cb, nc, per, scratch);                                                             \
+    else if (prec == 2) LAUNCH_BWS(TA, TB, 2);                                                                     \
+    else if (prec == 3) LAUNCH_BWS(TA, TB, 3);                                                                     \
+    else LAUNCH_BWS(TA, TB, 4);                                                                                    \
   }
     if (tca == 64 && tcb == 64) LAUNCH_BW(64, 64)
     else if (tca == 64) LAUNCH_BW(64, 32)
     else if (tcb == 64) LAUNCH_BW(32, 64)
     else LAUNCH_BW(32, 32)
 #undef LAUNCH_BW
+#undef LAUNCH_BWS
   }
   hipLaunchKernelGGL(k_bwd_weight_reduce, dim3((unsigned)cdiv(mat, 256), K), dim3(256), 0, st, (const float*)scratch,
                      seg, per, mat, dw);

@@ -109,6 +109,9 @@ int gcl_table_sort(const int32_t* tbl, int32_t K, int64_t n, int32_t window, int
  *   prec 0: exact-f32 MFMA (v_mfma_f32_32x32x2_f32), wp = float[K * Cin * Cout];
  *   prec 3: fp32 operands split into 3 bf16 planes, 6 bf16-MFMA terms, fp32 accumulate ("bf16x6": error vs fp64
  *           equal to native fp32, 2.7x the MFMA rate);  prec 2: 2 planes, 3 terms ("bf16x3", ~1.5e-5, 5.3x);
+ *   prec 4: 2 fp16 planes of the operands scaled by a per-tensor power of two (gcl_amax), 3 fp16-MFMA terms
+ *           ("fp16x3": 11+11 significand bits with round-to-nearest = 24 bits, i.e. native-fp32 accuracy at half the
+ *           MFMA work of bf16x6); x_amax / w_amax are required in this mode only;
  *           wp = gcl_pack_weights_bytes(...) bytes of bf16 planes.  Cin, Cout multiples of 32.
  * gcl_conv_fwd: Y[row(j)] = sum_k X[tbl[k*n_out+j]] . Wp_k (+ bias); tbl == NULL means K == 1, identity.
  *   With (order, tile_mask) from gcl_table_sort, `tbl` is the PERMUTED table, row(j) = order[j] and each 32-row
@@ -118,11 +121,14 @@ int gcl_table_sort(const int32_t* tbl, int32_t K, int64_t n, int32_t window, int
  *   stats (optional, prec 2/3): float[ceil(n_out/32)][2][cout] -- per 32-row tile column sums of y and y^2, consumed
  *   by gcl_bn_stats_from_tiles (the BatchNorm that follows then needs no statistics pass over y). */
 int64_t gcl_pack_weights_bytes(int32_t K, int32_t cin, int32_t cout, int32_t prec);
-int gcl_pack_weights(const float* w, int32_t K, int32_t cin, int32_t cout, int32_t mode, int32_t prec, void* wp,
-                     void* stream);
-int gcl_conv_fwd(const float* x, const void* wp, int32_t prec, const int32_t* tbl, const int32_t* order,
-                 const int32_t* tile_mask, int64_t n_out, int32_t K, int32_t cin, int32_t cout, const float* bias,
-                 float* y, float* stats, void* stream);
+/* max |x| of a tensor as the bit pattern of a float in amax_bits[0] (device int32); the fp16x3 mode derives its
+ * exact power-of-two operand scales from it */
+int gcl_amax(const float* x, int64_t n, int32_t* amax_bits, void* stream);
+int gcl_pack_weights(const float* w, int32_t K, int32_t cin, int32_t cout, int32_t mode, int32_t prec,
+                     const int32_t* w_amax, void* wp, void* stream);
+int gcl_conv_fwd(const float* x, const void* wp, int32_t prec, const int32_t* x_amax, const int32_t* w_amax,
+                 const int32_t* tbl, const int32_t* order, const int32_t* tile_mask, int64_t n_out, int32_t K,
+                 int32_t cin, int32_t cout, const float* bias, float* y, float* stats, void* stream);
 
 /* dW[k] = sum over pairs of offset k of  A[pair_a]^T . B[pair_b]   (A: [*, ca], B: [*, cb]) -> dw [K, ca, cb].
  * Forward conv: A = X, pair_a = pair_in, B = dY, pair_b = pair_out.  Transposed conv: roles swapped.
@@ -132,7 +138,7 @@ int gcl_conv_fwd(const float* x, const void* wp, int32_t prec, const int32_t* tb
 int64_t gcl_conv_bwd_weight_scratch_len(int32_t K, int32_t ca, int32_t cb, int64_t n_pairs_padded);
 int gcl_conv_bwd_weight(const float* a, const float* b, const int32_t* pair_a, const int32_t* pair_b,
                         const int64_t* seg_off_host, int32_t K, int32_t ca, int32_t cb, int32_t prec,
-                        float* scratch, float* dw, void* stream);
+                        const int32_t* a_amax, const int32_t* b_amax, float* scratch, float* dw, void* stream);
 
 /* First layer (Cin <= 4, Cout == 32, any ks): VALU kernels over the nbr table. */
 int gcl_stem_fwd(const float* x, const float* w, const int32_t* nbr, int64_t n_out, int32_t K,

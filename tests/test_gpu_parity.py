@@ -150,10 +150,10 @@ CONV_CASES = [
 
 # per-operator tolerance (relative L2 vs the fp64 oracle) of each MFMA arithmetic: exact f32 and the 3-plane bf16
 # split are indistinguishable from fp32 rounding; the 2-plane split drops ~2^-17 of each product
-PREC_TOL = {"f32": 2e-6, "bf16x6": 2e-6, "bf16x3": 3e-5}
+PREC_TOL = {"f32": 2e-6, "bf16x6": 2e-6, "bf16x3": 3e-5, "fp16x3": 2e-6}
 
 
-@pytest.fixture(params=["bf16x6", "f32", "bf16x3"])
+@pytest.fixture(params=["bf16x6", "f32", "bf16x3", "fp16x3"])
 def precision(request):
     import gcl_amd.MinkowskiEngine as ME
     from gcl_amd.MinkowskiEngine import ops
