@@ -202,13 +202,14 @@ def main():
                     "algorithmic_GBps": round(gbs, 1), "algorithmic_fp32_TFLOPs": round(tfs, 2),
                     "avg_algorithmic_MB_per_launch": round(by / cnt / 1e6, 3),
                     "note": "algorithmic = exact sparse work of the layer (pairs*(Cin+Cout)*4+8 B, 2*pairs*Cin*Cout flop); "
-                            "peak = dense f32 matrix peak (results are fp32-equivalent: bf16x6 split) or HBM3E spec",
+                            "peak = dense f32 matrix peak (results are fp32-equivalent: fp16x3 / bf16x6 split MFMA) or HBM3E spec",
                     "kernel_ms_last_step": {k: round(v[0], 3) for k, v in agg.items()}}
     out = {
         "metric": "active voxels/sec thru ResUNetBN2C fwd+bwd+GCL loss, KITTI 0.3m",
         "value": round(total_vox * args.steps / dt, 1), "unit": "active voxels/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if ops.PRECISION != "bf16x3" else "f32 via bf16x3 split (reduced: ~1.5e-5)", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if ops.PRECISION != "bf16x3" else "f32 via bf16x3 split (reduced: ~1.5e-5)",
+        "arithmetic": ops.PRECISION, "data": "synthetic",
         "config": {"workload": "configs[2]: GCL training step (finest_contrastive_loss), ResUNetBN2C-32 conv1 k=5, "
                                f"KITTI-shaped ray-cast clouds @0.3 m, bs={args.batch_size} x 7 clouds per GPU, "
                                f"positive groups '{args.group_mode}'",

@@ -286,7 +286,11 @@ __global__ void __launch_bounds__(256) k_amax(const float4* __restrict__ x, long
   if (blockIdx.x == 0 && (int)threadIdx.x < n_tail) m = fmaxf(m, fabsf(tail[threadIdx.x]));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) atomicMax(amax_bits, __float_as_int(m));
+  __shared__ float wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0)   // one atomic per workgroup: contended same-address atomics serialise (~10 ns each)
+    atomicMax(amax_bits, __float_as_int(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
 }
 
 // wp16 (8 x 16-bit units): [(((k*CC + cc)*TNB + nb)*2 + m)*planes + pl][lane = h*32 + j][jj]
@@ -896,7 +900,7 @@ int gcl_amax(const float* x, int64_t n, int32_t* amax_bits, void* stream) {
   GCL_CHECK_HIP(hipMemsetAsync(amax_bits, 0, sizeof(int32_t), st));
   long long n4 = n / 4;
   long long g = cdiv(n4 > 0 ? n4 : 1, 256);
-  if (g > 2048) g = 2048;
+  if (g > 512) g = 512;
   hipLaunchKernelGGL(k_amax, dim3((unsigned)g), dim3(256), 0, st, (const float4*)x, n4, x + n4 * 4, (int)(n - n4 * 4),
                      amax_bits);
   GCL_CHECK_LAUNCH();

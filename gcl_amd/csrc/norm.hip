@@ -111,9 +111,9 @@ __global__ void __launch_bounds__(256) k_bn_stats_final(const double* __restrict
 }
 
 // statistics from the per-tile column sums written by the convolution epilogue: partial [n_tiles][2][c] (fp32 sums of
-// <= 32 rows each).  Stage 1 adds 128 tiles per workgroup in fp64 (coalesced: thread = column), stage 2 is the
+// <= 32 rows each).  Stage 1 adds 32 tiles per workgroup in fp64 (coalesced: thread = column), stage 2 is the
 // ordinary ordered finalisation over the per-workgroup partials.
-constexpr int BN_TILES_PER_WG = 128;
+constexpr int BN_TILES_PER_WG = 32;
 
 __global__ void __launch_bounds__(256) k_bn_tiles_reduce(const float* __restrict__ partial, long long n_tiles, int c,
                                                          double* out) {

@@ -153,7 +153,7 @@ CONV_CASES = [
 PREC_TOL = {"f32": 2e-6, "bf16x6": 2e-6, "bf16x3": 3e-5, "fp16x3": 2e-6}
 
 
-@pytest.fixture(params=["bf16x6", "f32", "bf16x3", "fp16x3"])
+@pytest.fixture(params=["fp16x3", "bf16x6", "f32", "bf16x3"])
 def precision(request):
     import gcl_amd.MinkowskiEngine as ME
     from gcl_amd.MinkowskiEngine import ops
