@@ -1,0 +1,71 @@
+"""Turns the rocprofv3 CSVs merged into gpurun_out/ into the small summaries committed under profiles/.
+
+  gpurun_out/prof_final/*/…_kernel_stats.csv           (rocprofv3 --kernel-trace --stats -- python3 bench.py …)
+  gpurun_out/pmc_final{1,2,3}/*/…_counter_collection.csv (separate --pmc passes: SQ_*, FETCH_SIZE, WRITE_SIZE)
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+
+
+def short(name):
+    n = name.split("(")[0]
+    return re.sub(r"^void ", "", n).replace("gcl::", "").replace(" ", "")
+
+
+ks = glob.glob(os.path.join(G, "prof_final", "*", "*_kernel_stats.csv"))[0]
+shutil.copy(ks, os.path.join(P, f"{tag}_kernel_stats.csv"))
+rows = list(csv.DictReader(open(ks)))
+n_steps = 5          # bench.py --steps 4 --warmup 1
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+with open(os.path.join(P, f"{tag}_kernel_stats_summary.txt"), "w") as fh:
+    fh.write("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-kernel-events\n")
+    fh.write(f"GPU busy per training step: {tot / 1e6 / n_steps:.2f} ms ({n_steps} steps incl. warm-up)\n\n")
+    for r in rows[:40]:
+        fh.write(f"{short(r['Name'])[:60]:60s} calls/step={int(r['Calls']) / n_steps:7.1f} ms/step={float(r['TotalDurationNs']) / 1e6 / n_steps:7.3f} "
+                 f"avg_us={float(r['AverageNs']) / 1e3:8.1f} share={float(r['TotalDurationNs']) / tot * 100:5.1f}%\n")
+
+
+def load(path):
+    d = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(glob.glob(path)[0])):
+        d[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return d
+
+
+sq = load(os.path.join(G, "pmc_final1", "*", "*_counter_collection.csv"))
+with open(os.path.join(P, f"{tag}_pmc_sq.txt"), "w") as fh:
+    fh.write("rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU "
+             "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT -- python3 bench.py --steps 4 --warmup 1 (sums over all dispatches;\n"
+             "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* in quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES in cycles)\n\n")
+    for n, c in sorted(sq.items(), key=lambda kv: -sum(kv[1]["SQ_WAVE_CYCLES"])):
+        wc = sum(c["SQ_WAVE_CYCLES"])
+        if wc < 1e7:
+            continue
+        fh.write(f"{n[:52]:52s} dispatches={len(c['SQ_WAVE_CYCLES']):4d} wave_cycles={wc:.3e} wait_any={sum(c['SQ_WAIT_ANY']) / wc:.2f} "
+                 f"wait_inst={sum(c['SQ_WAIT_INST_ANY']) / wc:.2f} active={sum(c['SQ_ACTIVE_INST_ANY']) / wc:.2f} "
+                 f"mfma_busy_cycles={sum(c['SQ_VALU_MFMA_BUSY_CYCLES']):.3e} valu_insts={sum(c['SQ_INSTS_VALU']):.3e} "
+                 f"lds_bank_conflict={sum(c['SQ_LDS_BANK_CONFLICT']):.3e}\n")
+fe = load(os.path.join(G, "pmc_final2", "*", "*_counter_collection.csv"))
+wr = load(os.path.join(G, "pmc_final3", "*", "*_counter_collection.csv"))
+out = {"_source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) on `bench.py --steps 4 --warmup 1`; "
+                  "hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 averaged over launches (gfx950: FETCH_SIZE "
+                  "counts half of a 16-B/lane stream -- MI355X_MICROARCH.md 'HBM'; Infinity-Cache hits are included)"}
+for n in fe:
+    if n.startswith(("k_conv", "k_bn", "k_stem", "k_amax")):
+        f = sum(fe[n]["FETCH_SIZE"]) / len(fe[n]["FETCH_SIZE"])
+        w = sum(wr[n]["WRITE_SIZE"]) / len(wr[n]["WRITE_SIZE"]) if n in wr else 0.0
+        out[n] = {"launches": len(fe[n]["FETCH_SIZE"]), "fetch_size_kb_avg": round(f, 1), "write_size_kb_avg": round(w, 1),
+                  "hbm_bytes_per_launch": round((2 * f + w) * 1024)}
+json.dump(out, open(os.path.join(P, "pmc_summary.json"), "w"), indent=1)
+print(open(os.path.join(P, f"{tag}_kernel_stats_summary.txt")).read())
+print(open(os.path.join(P, f"{tag}_pmc_sq.txt")).read()[:2500])
