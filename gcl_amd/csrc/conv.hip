@@ -221,7 +221,9 @@ __device__ __forceinline__ float amax_scale(const int* __restrict__ amax_bits) {
   if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.f;
   int e;
   frexpf(amax, &e);   // amax = m * 2^e, m in [0.5, 1)
-  return ldexpf(1.f, 14 - e);
+  int sh = 14 - e;
+  sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);   // keep scale and 1/scale finite for degenerate tensors
+  return ldexpf(1.f, sh);
 }
 
 template <int PL>

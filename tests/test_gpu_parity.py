@@ -513,3 +513,68 @@ def test_train_step_matches_oracle_and_flat_ddp_is_transparent():
     ref = LO.finest_contrastive_loss(Fo, batch["group"].numpy(), batch["index"].numpy(), batch["index_hash"],
                                      batch["finest_flag"].numpy(), draws=draws)
     assert np.allclose(outs[0][1], [r.item() for r in ref], rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("kind", ["heavy_tail", "tiny", "huge", "zero"])
+def test_fp16x3_dynamic_range(kind):
+    """The default arithmetic scales every operand tensor by a power of two derived from its max-abs before splitting
+    it into two fp16 planes: inputs with a wide dynamic range / extreme magnitudes must stay at fp32-level accuracy
+    (error measured against the fp64 oracle, relative to the OUTPUT norm)."""
+    import gcl_amd.MinkowskiEngine as ME
+    from gcl_amd.MinkowskiEngine import ops
+    assert ops.PRECISION == "fp16x3"
+    C = random_cloud(13, n=2000, batch=1)
+    mgr, omgr = make_mgr(C), O.CoordinateManager(C)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(len(C), 64, generator=g, dtype=torch.float64)
+    if kind == "heavy_tail":
+        x = x * torch.exp(3.0 * torch.randn(len(C), 64, generator=g, dtype=torch.float64))     # ~ 8 decades
+    elif kind == "tiny":
+        x = x * 1e-30
+    elif kind == "huge":
+        x = x * 1e25
+    elif kind == "zero":
+        x = x * 0
+    conv = ME.MinkowskiConvolution(64, 64, kernel_size=3, stride=1, dimension=3).to(DEV)
+    xs = x.float().to(DEV).requires_grad_(True)
+    y = conv(ME.SparseTensor(xs, coordinate_map_key=ME.CoordinateMapKey(1), coordinate_manager=mgr)).F
+    W = conv.kernel.detach().cpu().double().requires_grad_(True)
+    xo = x.float().double().requires_grad_(True)
+    yo = O.sparse_conv(xo, W, omgr.get_kernel_map(1, 3, 1), len(C))
+    gy = torch.randn(yo.shape, generator=g, dtype=torch.float64) * (1e-12 if kind != "zero" else 1.0)
+    yo.backward(gy)
+    y.backward(gy.float().to(DEV))
+    assert torch.isfinite(y).all() and torch.isfinite(xs.grad).all() and torch.isfinite(conv.kernel.grad).all()
+    if kind == "zero":
+        assert (y == 0).all() and (conv.kernel.grad == 0).all()
+        assert rel_l2(xs.grad.cpu(), xo.grad) < 2e-6
+        return
+    assert rel_l2(y.detach().cpu(), yo.detach()) < 2e-6
+    assert rel_l2(xs.grad.cpu(), xo.grad) < 2e-6
+    assert rel_l2(conv.kernel.grad.cpu(), W.grad) < 2e-6
+
+
+def test_resunet_fat_variant_vs_oracle():
+    """ResUNetFatBN (the reference script's default model, scripts/train_gcl_kitti.sh:13; model/resunet.py:263-266)
+    runs through the same kernels: wider decoder (TR_CHANNELS 128,128,128,256), concat widths 160 / 192 / 384."""
+    import gcl_amd.MinkowskiEngine as ME
+    from gcl_amd import synthetic
+    from gcl_amd.model import load_model
+    xyz = synthetic.raycast(synthetic.make_scene(4, n_boxes=12), np.zeros(3), 9)[::6]
+    coords, _ = ME.utils.sparse_quantize(xyz / 0.3, return_index=True)
+    C = ME.utils.batched_coordinates([coords])
+    torch.manual_seed(2)
+    m = load_model("ResUNetFatBN")(1, 32, bn_momentum=0.05, normalize_feature=True, conv1_kernel_size=5, D=3).to(DEV)
+    st = {k: v.detach().cpu().double().clone() for k, v in m.state_dict().items() if "num_batches" not in k}
+    m.train()
+    F = m(ME.SparseTensor(torch.ones(len(C), 1).to(DEV), coordinates=C.to(DEV))).F
+    so = {k: v.clone().requires_grad_("running" not in k) for k, v in st.items()}
+    saved = (O.CHANNELS, O.TR_CHANNELS)
+    Fo = O.resunet_forward(so, C.numpy(), torch.ones(len(C), 1, dtype=torch.float64), 5, True, True, 0.05)
+    assert rel_l2(F.detach().cpu(), Fo.detach()) < 1e-4
+    g = torch.Generator().manual_seed(3)
+    gy = torch.randn(Fo.shape, generator=g, dtype=torch.float64)
+    Fo.backward(gy)
+    F.backward(gy.float().to(DEV))
+    for name, p_ in m.named_parameters():
+        assert rel_l2(p_.grad.cpu(), so[name].grad) < 2e-3, name
