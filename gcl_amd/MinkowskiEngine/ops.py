@@ -51,10 +51,17 @@ class _Timed:
             PROFILE.append(self.rec)
 
 
+_AMAX_POOL = {}      # device -> [zero-filled int32 tensor, cursor]: slots are used once, one fill per 4096 calls
+
+
 def tensor_amax(lib, t):
     """Device int32[1] holding the bit pattern of max|t| (only the fp16x3 mode needs it)."""
-    out = torch.empty(1, dtype=torch.int32, device=t.device)
-    _lib.check(lib.gcl_amax(_lib.ptr(t, torch.float32), t.numel(), _lib.ptr(out), _lib.stream()), "gcl_amax")
+    pool = _AMAX_POOL.get(t.device)
+    if pool is None or pool[1] >= pool[0].numel():
+        pool = _AMAX_POOL[t.device] = [torch.zeros(4096, dtype=torch.int32, device=t.device), 0]
+    out = pool[0][pool[1]:pool[1] + 1]
+    pool[1] += 1
+    _lib.check(lib.gcl_amax(_lib.ptr(t, torch.float32), t.numel(), _lib.ptr(out), 1, _lib.stream()), "gcl_amax")
     return out
 
 
@@ -78,6 +85,8 @@ def _conv_launch(lib, x, Wk, mode, table, n_out, cin, cout, bias, pairs=0, want_
     if want_stats and prec != 0:
         stats = torch.empty(((n_out + 31) // 32, 2, cout), dtype=torch.float32, device=x.device)
     nb = 4 if cout % 128 == 0 else (2 if cout % 64 == 0 else 1)
+    if prec == 3:
+        nb = min(nb, 2)
     name = f"k_conv_fwd<{nb}>" if prec == 0 else f"k_conv_fwd_split<{nb},{prec}>"
     with _Timed(name, pairs, cin, cout):
         _lib.check(lib.gcl_conv_fwd(_lib.ptr(x, torch.float32), _lib.ptr(wp), prec, _lib.ptr(x_amax),

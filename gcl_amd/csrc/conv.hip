@@ -352,15 +352,11 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
                                                         const int* __restrict__ w_amax) {
   constexpr int NPL = Prec<PL>::planes;
   constexpr int BLK = NB * 2 * NPL * 64;                // uint4 per (k, cc) weight block of this workgroup
+  constexpr int BREG = (BLK + 255) / 256;
   const float a_scale = (PL == 4) ? amax_scale(x_amax) : 1.f;
   const float out_scale = (PL == 4) ? 1.f / (a_scale * amax_scale(w_amax)) : 1.f;   // exact: powers of two
-  constexpr int BREG = (BLK + 255) / 256;
-  STAMP(ts_begin)
-#ifdef GCL_STAMPS
-  unsigned long long acc_t[4] = {0, 0, 0, 0}, n_steps = 0, n_mine = 0;
-#endif
-  __shared__ __attribute__((aligned(16))) float Asm[4][32][LDS_STRIDE];
-  __shared__ __attribute__((aligned(16))) u32x4 Bsm[BLK];
+  __shared__ __attribute__((aligned(16))) float Asm[4][32][LDS_STRIDE];   // wave-private A tiles
+  __shared__ __attribute__((aligned(16))) u32x4 Bsm[2][BLK];              // weight block, double-buffered
   __shared__ int Ism[4][27][32];                        // neighbour rows of the wave's tile: [wave][k][row] (K <= 27)
   __shared__ unsigned wmask[4];
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
@@ -392,6 +388,10 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
   __syncthreads();
   const unsigned wgmask = wmask[0] | wmask[1] | wmask[2] | wmask[3];
 
+  // Step (k, cc) = one kernel offset x one 32-channel slice.  Pipeline (ONE workgroup barrier per step):
+  //   loads of step s+2 are issued at the end of step s and land in registers during step s+1,
+  //   they are written to LDS at the end of step s+1 (A: wave-private tile; B: the buffer not being read),
+  //   the barrier closing step s+1 publishes B(s+2).
 #define GCL_GATHER_A(KK, CCV)                                                                                  \
   {                                                                                                            \
     _Pragma("unroll") for (int ps = 0; ps < 4; ++ps) {                                                         \
@@ -407,48 +407,56 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
       if ((BLK % 256 == 0) || (e * 256 + t < BLK)) br[e] = src_[e * 256 + t];                    \
     }                                                                                            \
   }
+#define GCL_STORE_LDS(MINE, BUF)                                                                             \
+  {                                                                                                          \
+    if (MINE) {                                                                                              \
+      _Pragma("unroll") for (int ps = 0; ps < 4; ++ps)                                                       \
+          *reinterpret_cast<float4*>(&Asm[w][rsub + 8 * ps][p * 4]) = st[ps];                                \
+    }                                                                                                        \
+    _Pragma("unroll") for (int e = 0; e < BREG; ++e) {                                                       \
+      if ((BLK % 256 == 0) || (e * 256 + t < BLK)) Bsm[BUF][e * 256 + t] = br[e];                           \
+    }                                                                                                        \
+  }
+#define GCL_ADVANCE(KV, CV, HAS)             \
+  {                                          \
+    CV += 1;                                 \
+    if (CV == CC) {                          \
+      CV = 0;                                \
+      if (m_rest) {                          \
+        KV = __builtin_ctz(m_rest);          \
+        m_rest &= m_rest - 1;                \
+      } else {                               \
+        HAS = false;                         \
+      }                                      \
+    }                                        \
+  }
 
-  STAMP(ts_loop)
   if (wgmask != 0u) {
-    int k_cur = __builtin_ctz(wgmask), cc_cur = 0;
     unsigned m_rest = wgmask & (wgmask - 1);
-    bool mine_cur = (mymask >> k_cur) & 1u;
     float4 st[4];
     u32x4 br[BREG];
-    if (mine_cur) GCL_GATHER_A(k_cur, 0);
-    GCL_LOAD_B(k_cur, 0);
+    // step 0 -> LDS, step 1 -> registers
+    int k0 = __builtin_ctz(wgmask), c0 = 0;
+    bool mine0 = (mymask >> k0) & 1u;
+    if (mine0) GCL_GATHER_A(k0, 0);
+    GCL_LOAD_B(k0, 0);
+    int k1 = k0, c1 = 0;
+    bool has1 = true;
+    GCL_ADVANCE(k1, c1, has1);
+    GCL_STORE_LDS(mine0, 0);
+    bool mine1 = false;
+    if (has1) {
+      mine1 = (mymask >> k1) & 1u;
+      if (mine1) GCL_GATHER_A(k1, c1);
+      GCL_LOAD_B(k1, c1);
+    }
+    __syncthreads();
+    int buf = 0;
+    bool mine_cur = mine0;
     while (true) {
-      int k_nxt = k_cur, cc_nxt = cc_cur + 1;
-      bool has_nxt = true;
-      if (cc_nxt == CC) {
-        cc_nxt = 0;
-        if (m_rest) {
-          k_nxt = __builtin_ctz(m_rest);
-          m_rest &= m_rest - 1;
-        } else {
-          has_nxt = false;
-        }
-      }
-      STAMP(t0)
-      __syncthreads();   // #1: every wave is done reading Bsm (and its own A tile) of the previous step
-      STAMP(t1)
+      // ---- compute the current step from Asm[w] (own tile) and Bsm[buf]
       if (mine_cur) {
-#pragma unroll
-        for (int ps = 0; ps < 4; ++ps) *reinterpret_cast<float4*>(&Asm[w][rsub + 8 * ps][p * 4]) = st[ps];
-      }
-#pragma unroll
-      for (int e = 0; e < BREG; ++e)
-        if ((BLK % 256 == 0) || (e * 256 + t < BLK)) Bsm[e * 256 + t] = br[e];
-      bool mine_nxt = false;
-      if (has_nxt) {   // loads of the next step stay in flight across barrier #2 and the MFMA phase
-        mine_nxt = (mymask >> k_nxt) & 1u;
-        if (mine_nxt) GCL_GATHER_A(k_nxt, cc_nxt);
-        GCL_LOAD_B(k_nxt, cc_nxt);
-      }
-      STAMP(t2)
-      __syncthreads();   // #2: A tiles and the shared weight block are in LDS
-      STAMP(t3)
-      if (mine_cur) {
+        WAVE_FENCE();
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
           float4 f0 = *reinterpret_cast<const float4*>(&Asm[w][i][16 * m + 8 * h]);
@@ -457,7 +465,7 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
           split8<PL>(f0, f1, a_scale, ap);
 #pragma unroll
           for (int b = 0; b < NB; ++b) {
-            const u32x4* bb = Bsm + ((b * 2 + m) * NPL) * 64 + l;
+            const u32x4* bb = &Bsm[buf][((b * 2 + m) * NPL) * 64 + l];
             u32x4 bp[3];
             bp[0] = bb[0];
             bp[1] = bb[64];
@@ -466,28 +474,32 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
           }
         }
       }
-      STAMP(t4)
-#ifdef GCL_STAMPS
-      acc_t[0] += t1 - t0; acc_t[1] += t2 - t1; acc_t[2] += t3 - t2; acc_t[3] += t4 - t3;
-      n_steps += 1; n_mine += mine_cur ? 1 : 0;
-#endif
-      if (!has_nxt) break;
-      k_cur = k_nxt;
-      cc_cur = cc_nxt;
-      mine_cur = mine_nxt;
+      if (!has1) break;   // no step staged in registers: done
+      // ---- next step: registers -> LDS (A: own tile, after this wave's reads; B: the buffer nobody reads)
+      WAVE_FENCE();
+      GCL_STORE_LDS(mine1, buf ^ 1);
+      // ---- the step after: issue its loads (in flight across the barrier and the next compute phase)
+      int k2 = k1, c2 = c1;
+      bool has2 = true, mine2 = false;
+      GCL_ADVANCE(k2, c2, has2);
+      if (has2) {
+        mine2 = (mymask >> k2) & 1u;
+        if (mine2) GCL_GATHER_A(k2, c2);
+        GCL_LOAD_B(k2, c2);
+      }
+      __syncthreads();   // publishes the weight block just written; its buffer was last read two steps ago
+      buf ^= 1;
+      mine_cur = mine1;
+      mine1 = mine2;
+      k1 = k2;
+      c1 = c2;
+      has1 = has2;
     }
   }
 #undef GCL_GATHER_A
 #undef GCL_LOAD_B
-  STAMP(ts_epi)
-#ifdef GCL_STAMPS
-  if (l == 0) {
-    for (int q = 0; q < 4; ++q) atomicAdd(&g_stamps[q], acc_t[q]);
-    atomicAdd(&g_stamps[4], ts_loop - ts_begin);
-    atomicAdd(&g_stamps[6], n_steps);
-    atomicAdd(&g_stamps[7], n_mine);
-  }
-#endif
+#undef GCL_STORE_LDS
+#undef GCL_ADVANCE
   if (!active) return;
   int orow_l = -1;
   if ((l < 32) && (row0 + l < n_out)) orow_l = order ? order[row0 + l] : (int)(row0 + l);
@@ -896,10 +908,10 @@ int64_t gcl_pack_weights_bytes(int32_t K, int32_t cin, int32_t cout, int32_t pre
 
 static bool prec_ok(int prec) { return prec == 0 || prec == 2 || prec == 3 || prec == 4; }
 
-int gcl_amax(const float* x, int64_t n, int32_t* amax_bits, void* stream) {
+int gcl_amax(const float* x, int64_t n, int32_t* amax_bits, int32_t zeroed, void* stream) {
   GCL_CHECK_ARG(x && amax_bits && n > 0, "gcl_amax: bad argument");
   hipStream_t st = (hipStream_t)stream;
-  GCL_CHECK_HIP(hipMemsetAsync(amax_bits, 0, sizeof(int32_t), st));
+  if (!zeroed) GCL_CHECK_HIP(hipMemsetAsync(amax_bits, 0, sizeof(int32_t), st));
   long long n4 = n / 4;
   long long g = cdiv(n4 > 0 ? n4 : 1, 256);
   if (g > 512) g = 512;
@@ -958,14 +970,21 @@ int gcl_conv_fwd(const float* x, const void* wp, int32_t prec, const int32_t* x_
   {                                                                                      \
     if (nb == 4) LAUNCH_SPLIT(4, PLV); else if (nb == 2) LAUNCH_SPLIT(2, PLV); else LAUNCH_SPLIT(1, PLV); \
   }
+#define LAUNCH_SPLIT_NB2(PLV)                                                            \
+  {                                                                                      \
+    if (nb >= 2) LAUNCH_SPLIT(2, PLV); else LAUNCH_SPLIT(1, PLV);                        \
+  }
   if (prec == 0) {
     if (nb == 4) LAUNCH_F32(4); else if (nb == 2) LAUNCH_F32(2); else LAUNCH_F32(1);
   } else if (prec == 2) LAUNCH_SPLIT_NB(2)
-  else if (prec == 3) LAUNCH_SPLIT_NB(3)
-  else LAUNCH_SPLIT_NB(4)
+  else if (prec == 3) {   // three planes: the double-buffered weight block of NB = 4 would not leave room for 2 WGs/CU
+    if (nb == 4) grid = dim3(gx, cout / 64);
+    LAUNCH_SPLIT_NB2(3)
+  } else LAUNCH_SPLIT_NB(4)
 #undef LAUNCH_F32
 #undef LAUNCH_SPLIT
 #undef LAUNCH_SPLIT_NB
+#undef LAUNCH_SPLIT_NB2
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }

@@ -184,7 +184,56 @@ __global__ void __launch_bounds__(SCAN_T) k_scan_final(const int* __restrict__ i
   }
 }
 
+// single-workgroup exclusive scan for short arrays (one launch instead of three): tiles of 4096 elements, coalesced
+// int4 loads, wave-shuffle scan + LDS carry between tiles
+constexpr int SCAN1_T = 1024;
+__global__ void __launch_bounds__(SCAN1_T) k_scan_single(const int* __restrict__ in, long long n, int* out) {
+  __shared__ int wsum[SCAN1_T / 64];
+  __shared__ int tile_total;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  int carry = 0;
+  for (long long base = 0; base < n; base += SCAN1_T * 4) {
+    long long i0 = base + (long long)t * 4;
+    int v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (i0 + j < n) ? in[i0 + j] : 0;
+    int s = v[0] + v[1] + v[2] + v[3];
+    int inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      int y = __shfl_up(inc, o);
+      if (lane >= o) inc += y;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    if (t < SCAN1_T / 64) {          // 16 wave totals: exclusive scan by the first 16 lanes of wave 0
+      int x = wsum[t], incw = x;
+#pragma unroll
+      for (int o = 1; o < SCAN1_T / 64; o <<= 1) {
+        int y = __shfl_up(incw, o);
+        if (t >= o) incw += y;
+      }
+      wsum[t] = incw - x;
+      if (t == SCAN1_T / 64 - 1) tile_total = incw;
+    }
+    __syncthreads();
+    int ex = carry + wsum[w] + inc - s;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (i0 + j < n) out[i0 + j] = ex;
+      ex += v[j];
+    }
+    carry += tile_total;
+    __syncthreads();
+  }
+}
+
 static int device_scan(const int* in, long long n, int* out, int* bs, hipStream_t st) {
+  if (n <= 16384) {
+    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(SCAN1_T), 0, st, in, n, out);
+    GCL_CHECK_LAUNCH();
+    return GCL_OK;
+  }
   long long nb = cdiv(n, SCAN_B);
   hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_T), 0, st, in, n, bs);
   hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(SCAN_T), 0, st, bs, nb);

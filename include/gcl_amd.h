@@ -122,8 +122,9 @@ int gcl_table_sort(const int32_t* tbl, int32_t K, int64_t n, int32_t window, int
  *   by gcl_bn_stats_from_tiles (the BatchNorm that follows then needs no statistics pass over y). */
 int64_t gcl_pack_weights_bytes(int32_t K, int32_t cin, int32_t cout, int32_t prec);
 /* max |x| of a tensor as the bit pattern of a float in amax_bits[0] (device int32); the fp16x3 mode derives its
- * exact power-of-two operand scales from it */
-int gcl_amax(const float* x, int64_t n, int32_t* amax_bits, void* stream);
+ * exact power-of-two operand scales from it.  zeroed != 0: the caller guarantees amax_bits[0] == 0 on the stream
+ * (slots handed out from a zero-filled pool), so no memset is issued. */
+int gcl_amax(const float* x, int64_t n, int32_t* amax_bits, int32_t zeroed, void* stream);
 int gcl_pack_weights(const float* w, int32_t K, int32_t cin, int32_t cout, int32_t mode, int32_t prec,
                      const int32_t* w_amax, void* wp, void* stream);
 int gcl_conv_fwd(const float* x, const void* wp, int32_t prec, const int32_t* x_amax, const int32_t* w_amax,
