@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("GCL_LIB_PATH", os.path.join(CSRC, "libgcl_hip.so"))   # override: diagnostic builds only
-SOURCES = ["coords.hip", "conv.hip", "norm.hip", "loss.hip"]
+SOURCES = ["coords.hip", "conv.hip", "norm.hip", "loss.hip", "data.hip"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "gcl_amd.h")
 
 _vp, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
@@ -24,6 +24,12 @@ SIGNATURES = {
     "gcl_coords_insert": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp]),
     "gcl_scan_scratch_len": (_i64, [_i64]),
     "gcl_stride_map": (_i32, [_vp, _i64, _vp, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "gcl_exclusive_scan_i32": (_i32, [_vp, _i64, _vp, _vp, _vp]),
+    "gcl_voxel_coords": (_i32, [_vp, _i64, _f32, _i32, _vp, _vp]),
+    "gcl_unique_coords": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gcl_colocation_hits": (_i32, [_vp, _vp, _i64, _i32, ctypes.POINTER(ctypes.c_double), _vp, _i64, _f32,
+                                    ctypes.c_double, _i32, _vp, _vp, _vp, _vp]),
+    "gcl_colocation_emit": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gcl_kernel_map_bitmap_len": (_i64, []),
     "gcl_kernel_map_scratch_len": (_i64, [_i32, _i64]),
     "gcl_kernel_map": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),

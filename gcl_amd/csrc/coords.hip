@@ -97,10 +97,11 @@ __global__ void k_stride_flag(const int4* __restrict__ coords, long long n_max, 
 
 __global__ void k_stride_emit(const int4* __restrict__ coords, long long n_max, int t_out, Slot* t, long long cap,
                               const int* __restrict__ flag, const int* __restrict__ pos, int4* coords_out,
-                              int* n_out) {
+                              int* n_out, long long* index_out) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_max) return;
   if (i == n_max - 1) *n_out = pos[i] + flag[i];
+  if (index_out && flag[i]) index_out[pos[i]] = i;
   if (!flag[i]) return;
   int4 c = coords[i];
   c.y = floor_div(c.y, t_out) * t_out;
@@ -574,9 +575,9 @@ int gcl_coords_insert(const int32_t* coords, int64_t n, int64_t* table, int64_t 
 
 int64_t gcl_scan_scratch_len(int64_t n) { return 2 * n + cdiv(n, SCAN_B) + 64; }
 
-int gcl_stride_map(const int32_t* coords_in, int64_t n_in, const int32_t* n_in_dev, int32_t t_out, int64_t* table_out,
-                   int64_t cap_out, int32_t* scratch, int32_t* coords_out, int32_t* n_out_dev, int32_t* status,
-                   void* stream) {
+static int stride_map_impl(const int32_t* coords_in, int64_t n_in, const int32_t* n_in_dev, int32_t t_out,
+                           int64_t* table_out, int64_t cap_out, int32_t* scratch, int32_t* coords_out,
+                           int32_t* n_out_dev, int32_t* status, int64_t* index_out, void* stream) {
   GCL_CHECK_ARG(coords_in && table_out && scratch && coords_out && n_out_dev && status, "gcl_stride_map: null pointer");
   GCL_CHECK_ARG(n_in > 0 && t_out >= 1, "gcl_stride_map: n_in and t_out must be positive");
   GCL_CHECK_ARG(is_pow2(cap_out) && cap_out >= 2 * n_in && cap_out >= 64, "gcl_stride_map: cap must be a power of two >= 2n");
@@ -597,9 +598,28 @@ int gcl_stride_map(const int32_t* coords_in, int64_t n_in, const int32_t* n_in_d
   if (rc) return rc;
   hipLaunchKernelGGL(k_stride_emit, dim3(g), dim3(256), 0, st, (const int4*)coords_in, (long long)n_in, t_out,
                      (Slot*)table_out, (long long)cap_out, (const int*)flag, (const int*)pos, (int4*)coords_out,
-                     n_out_dev);
+                     n_out_dev, (long long*)index_out);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
+}
+
+int gcl_stride_map(const int32_t* coords_in, int64_t n_in, const int32_t* n_in_dev, int32_t t_out, int64_t* table_out,
+                   int64_t cap_out, int32_t* scratch, int32_t* coords_out, int32_t* n_out_dev, int32_t* status,
+                   void* stream) {
+  return stride_map_impl(coords_in, n_in, n_in_dev, t_out, table_out, cap_out, scratch, coords_out, n_out_dev, status,
+                         nullptr, stream);
+}
+
+int gcl_unique_coords(const int32_t* coords_in, int64_t n_in, int64_t* table_out, int64_t cap_out, int32_t* scratch,
+                      int32_t* coords_out, int64_t* index_out, int32_t* n_out_dev, int32_t* status, void* stream) {
+  GCL_CHECK_ARG(index_out, "gcl_unique_coords: null pointer");
+  return stride_map_impl(coords_in, n_in, nullptr, 1, table_out, cap_out, scratch, coords_out, n_out_dev, status,
+                         index_out, stream);
+}
+
+int gcl_exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out, int32_t* scratch, void* stream) {
+  GCL_CHECK_ARG(in && out && scratch && n > 0, "gcl_exclusive_scan_i32: bad argument");
+  return device_scan(in, n, out, scratch, (hipStream_t)stream);
 }
 
 int64_t gcl_kernel_map_bitmap_len(void) { return BITMAP_WORDS; }

@@ -1,0 +1,212 @@
+// "Next" rows of the scope table: the loader work either side of the hot path, on the GPU.
+//
+//  * gcl_voxelize            = ME.utils.sparse_quantize (util/misc.py:118, lib/colocation_data_loader.py:379,388):
+//                              floor(xyz / voxel) -> one row per voxel (first occurrence, ascending row order).
+//  * gcl_colocation_hits/emit = get_matching_indices_colocation (util/pointcloud.py:69-132): for every centre voxel,
+//                              the <= K nearest points within `radius` in the centre cloud (itself first) and in every
+//                              neighbour cloud, the group size, the member rows and the "finest" flag.
+//    The reference runs one open3d KD-tree radius query per point per cloud in a Python loop; here every voxelised
+//    cloud already has a coordinate hash map (one point per voxel), so a radius query is a scan of the (2R+1)^3
+//    voxels around the query point, R = floor(radius / voxel) + 1.
+// Integer / index work: results are compared bit-exactly with the CPU oracle (distances are evaluated in fp64 from the
+// same fp32 inputs and without fused multiply-add, like the oracle's KD-tree).
+#include "common.h"
+
+#include <limits.h>
+
+namespace gcl {
+
+__device__ __forceinline__ int floor_to_int(float v) { return (int)floorf(v); }
+
+__global__ void k_voxel_coords(const float* __restrict__ xyz, long long p, float voxel, int batch_id, int4* coords) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p) return;
+  // floor(xyz / voxel_size) with the correctly rounded fp32 division numpy performs (util/misc.py:117)
+  coords[i] = make_int4(batch_id, floor_to_int(__fdiv_rn(xyz[3 * i], voxel)), floor_to_int(__fdiv_rn(xyz[3 * i + 1], voxel)),
+                        floor_to_int(__fdiv_rn(xyz[3 * i + 2], voxel)));
+}
+
+// ---- co-location groups ------------------------------------------------------------------------------------------
+constexpr int KMAX = 8;
+
+struct Affine {
+  double m[12];   // row-major 3x4: q = R p + t
+};
+struct Affines {
+  Affine a[16];
+};
+
+// hits of centre point i in cloud c: up to K nearest within radius, ascending (d2, row)
+__global__ void __launch_bounds__(256) k_colocation_hits(const float* __restrict__ xyz_own,   // [Ntot,3] own frames
+                                                         const float* __restrict__ xyz_cf,    // [Ntot,3] centre frame
+                                                         long long n_center, int n_clouds, Affines to_cloud,
+                                                         const Slot* __restrict__ table, long long cap,
+                                                         float inv_voxel, double radius, int R, int K,
+                                                         int* __restrict__ hits,        // [n_center, n_clouds, K]
+                                                         int* __restrict__ cnt,         // [n_center, n_clouds]
+                                                         double* __restrict__ first_rng) {  // [n_center, n_clouds]
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  int c = blockIdx.y;
+  if (i >= n_center) return;
+  const double px = xyz_cf[3 * i], py = xyz_cf[3 * i + 1], pz = xyz_cf[3 * i + 2];
+  // query point in the frame of cloud c (only to find candidate voxels)
+  const double* m = to_cloud.a[c].m;
+  float qx = (float)(m[0] * px + m[1] * py + m[2] * pz + m[3]);
+  float qy = (float)(m[4] * px + m[5] * py + m[6] * pz + m[7]);
+  float qz = (float)(m[8] * px + m[9] * py + m[10] * pz + m[11]);
+  int bx = floor_to_int(qx * inv_voxel), by = floor_to_int(qy * inv_voxel), bz = floor_to_int(qz * inv_voxel);
+  double bd[KMAX];
+  int bi[KMAX];
+  int n = 0;
+  const double r2 = __dmul_rn(radius, radius);
+  for (int dz = -R; dz <= R; ++dz)
+    for (int dy = -R; dy <= R; ++dy)
+      for (int dx = -R; dx <= R; ++dx) {
+        int x = bx + dx, y = by + dy, z = bz + dz;
+        if (!pack_ok(c, x, y, z)) continue;
+        long long s = table_find(table, cap, pack_key(c, x, y, z));
+        if (s < 0) continue;
+        int q = (int)table[s].val;
+        double ex = __dsub_rn((double)xyz_cf[3 * (long long)q], px);
+        double ey = __dsub_rn((double)xyz_cf[3 * (long long)q + 1], py);
+        double ez = __dsub_rn((double)xyz_cf[3 * (long long)q + 2], pz);
+        double d2 = __dadd_rn(__dadd_rn(__dmul_rn(ex, ex), __dmul_rn(ey, ey)), __dmul_rn(ez, ez));
+        if (!(d2 < r2)) continue;   // strictly inside, as a KD-tree query with distance_upper_bound
+        // keep the K best, ascending (d2, row)
+        if (n == K && !(d2 < bd[K - 1] || (d2 == bd[K - 1] && q < bi[K - 1]))) continue;
+        int pos = (n < K) ? n : K - 1;
+        while (pos > 0 && (bd[pos - 1] > d2 || (bd[pos - 1] == d2 && bi[pos - 1] > q))) {
+          bd[pos] = bd[pos - 1];
+          bi[pos] = bi[pos - 1];
+          --pos;
+        }
+        bd[pos] = d2;
+        bi[pos] = q;
+        if (n < K) ++n;
+      }
+  long long o = (i * n_clouds + c);
+  cnt[o] = n;
+  for (int j = 0; j < K; ++j) hits[o * K + j] = j < n ? bi[j] : -1;
+  double rng = 1e300;
+  if (c == 0) {
+    double a = xyz_own[3 * i], b = xyz_own[3 * i + 1], d = xyz_own[3 * i + 2];
+    rng = sqrt(__dadd_rn(__dadd_rn(__dmul_rn(a, a), __dmul_rn(b, b)), __dmul_rn(d, d)));   // centre voxel's sensor range
+  } else if (n > 0) {
+    long long q = bi[0];
+    double a = xyz_own[3 * q], b = xyz_own[3 * q + 1], d = xyz_own[3 * q + 2];
+    rng = sqrt(__dadd_rn(__dadd_rn(__dmul_rn(a, a), __dmul_rn(b, b)), __dmul_rn(d, d)));   // nearest hit, ITS frame
+  }
+  first_rng[o] = rng;
+}
+
+// group size of every centre point (0 = no neighbour-cloud match => no group) and its kept flag
+__global__ void k_colocation_sizes(const int* __restrict__ cnt, long long n_center, int n_clouds, int* gsize, int* kept) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_center) return;
+  int tot = 0, ng = 0;
+  for (int c = 0; c < n_clouds; ++c) {
+    int v = cnt[i * n_clouds + c];
+    tot += v;
+    if (c > 0) ng += v;
+  }
+  gsize[i] = ng > 0 ? tot : 0;
+  kept[i] = ng > 0 ? 1 : 0;
+}
+
+__global__ void k_colocation_emit(const int* __restrict__ hits, const int* __restrict__ cnt,
+                                  const double* __restrict__ first_rng, long long n_center, int n_clouds, int K,
+                                  const int* __restrict__ gsize, const int* __restrict__ goff,
+                                  const int* __restrict__ gidx, int* group, long long* index, unsigned char* finest,
+                                  int* totals) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_center) return;
+  if (i == n_center - 1) {
+    totals[0] = gidx[i] + (gsize[i] > 0 ? 1 : 0);   // number of groups
+    totals[1] = goff[i] + gsize[i];                 // number of index entries
+  }
+  if (gsize[i] == 0) return;
+  // finest member: first arg-min over [centre range, nearest-hit range of cloud 1, 2, ...] (strict < in the reference)
+  int best = 0;
+  double bv = first_rng[i * n_clouds];
+  for (int c = 1; c < n_clouds; ++c) {
+    double v = first_rng[i * n_clouds + c];
+    if (cnt[i * n_clouds + c] > 0 && v < bv) {
+      bv = v;
+      best = c;
+    }
+  }
+  long long o = goff[i];
+  int fpos = 0, run = 0;
+  for (int c = 0; c < n_clouds; ++c) {
+    int n = cnt[i * n_clouds + c];
+    if (c == best) fpos = (c == 0) ? 0 : run;
+    for (int j = 0; j < n; ++j) index[o + run + j] = hits[(i * n_clouds + c) * K + j];
+    run += n;
+  }
+  for (int j = 0; j < run; ++j) finest[o + j] = (j == fpos) ? 1 : 0;
+  group[gidx[i]] = run;
+}
+
+}  // namespace gcl
+
+using namespace gcl;
+
+// device-wide scan lives in coords.hip
+
+
+extern "C" {
+
+int gcl_voxel_coords(const float* xyz, int64_t p, float voxel, int32_t batch_id, int32_t* coords, void* stream) {
+  GCL_CHECK_ARG(xyz && coords && p > 0 && voxel > 0, "gcl_voxel_coords: bad argument");
+  hipLaunchKernelGGL(k_voxel_coords, dim3((unsigned)cdiv(p, 256)), dim3(256), 0, (hipStream_t)stream, xyz,
+                     (long long)p, voxel, batch_id, (int4*)coords);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int gcl_colocation_hits(const float* xyz_own, const float* xyz_cf, int64_t n_center, int32_t n_clouds,
+                        const double* to_cloud_host, const int64_t* table, int64_t cap, float inv_voxel, double radius,
+                        int32_t K, int32_t* hits, int32_t* cnt, double* first_rng, void* stream) {
+  GCL_CHECK_ARG(xyz_own && xyz_cf && to_cloud_host && table && hits && cnt && first_rng, "gcl_colocation_hits: null pointer");
+  GCL_CHECK_ARG(n_center > 0 && n_clouds >= 1 && n_clouds <= 16 && K >= 1 && K <= KMAX,
+                "gcl_colocation_hits: need 1 <= clouds <= 16 and 1 <= K <= %d", KMAX);
+  GCL_CHECK_ARG(radius > 0 && inv_voxel > 0, "gcl_colocation_hits: radius and voxel size must be positive");
+  Affines aff;
+  for (int c = 0; c < n_clouds; ++c)
+    for (int j = 0; j < 12; ++j) aff.a[c].m[j] = to_cloud_host[c * 12 + j];
+  int R = (int)(radius * (double)inv_voxel) + 1;
+  GCL_CHECK_ARG(R <= 4, "gcl_colocation_hits: radius / voxel too large (R = %d)", R);
+  hipLaunchKernelGGL(k_colocation_hits, dim3((unsigned)cdiv(n_center, 256), n_clouds), dim3(256), 0, (hipStream_t)stream,
+                     xyz_own, xyz_cf, (long long)n_center, n_clouds, aff, (const Slot*)table, (long long)cap, inv_voxel,
+                     radius, R, K, hits, cnt, first_rng);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+/* scratch: int32[4 * n_center + gcl_scan_scratch_len(n_center)]; totals: device int32[2] = {#groups, #index entries};
+ * group / index / finest need capacity n_center / n_center * n_clouds * K. */
+int gcl_colocation_emit(const int32_t* hits, const int32_t* cnt, const double* first_rng, int64_t n_center,
+                        int32_t n_clouds, int32_t K, int32_t* scratch, int32_t* group, int64_t* index, uint8_t* finest,
+                        int32_t* totals, void* stream) {
+  GCL_CHECK_ARG(hits && cnt && first_rng && scratch && group && index && finest && totals, "gcl_colocation_emit: null pointer");
+  GCL_CHECK_ARG(n_center > 0 && n_clouds >= 1 && K >= 1 && K <= KMAX, "gcl_colocation_emit: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  int* gsize = scratch;
+  int* kept = scratch + n_center;
+  int* goff = scratch + 2 * n_center;
+  int* gidx = scratch + 3 * n_center;
+  int* sc = scratch + 4 * n_center;
+  unsigned g = (unsigned)cdiv(n_center, 256);
+  hipLaunchKernelGGL(k_colocation_sizes, dim3(g), dim3(256), 0, st, cnt, (long long)n_center, n_clouds, gsize, kept);
+  GCL_CHECK_LAUNCH();
+  int rc = gcl_exclusive_scan_i32(gsize, n_center, goff, sc, stream);
+  if (rc) return rc;
+  rc = gcl_exclusive_scan_i32(kept, n_center, gidx, sc, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_colocation_emit, dim3(g), dim3(256), 0, st, hits, cnt, first_rng, (long long)n_center, n_clouds, K,
+                     (const int*)gsize, (const int*)goff, (const int*)gidx, group, (long long*)index, finest, totals);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+}  // extern "C"

@@ -105,11 +105,11 @@ def colocation_groups(center_xyz, nghb_xyz, list_M, radius, K=5):
     offs = np.concatenate([[0, Nc], Nc + np.cumsum([len(x) for x in nghb_xyz])]).astype(np.int64)
     d, i = cKDTree(center_xyz).query(center_xyz, k=K, distance_upper_bound=radius)
     cols_idx, cols_ok = [i.astype(np.int64)], [np.isfinite(d)]
-    first_range = [np.linalg.norm(center_xyz, axis=1)]           # the centre voxel's own sensor range
+    first_range = [np.linalg.norm(center_xyz.astype(np.float64), axis=1)]   # centre voxel's own sensor range (fp64, as o3d)
     for j, xyz in enumerate(nghb_xyz):
         dj, ij = cKDTree(_apply(list_M[j], xyz)).query(center_xyz, k=K, distance_upper_bound=radius)
         ok = np.isfinite(dj)
-        rng_j = np.linalg.norm(xyz, axis=1)
+        rng_j = np.linalg.norm(xyz.astype(np.float64), axis=1)
         first = np.where(ok[:, 0], rng_j[np.minimum(ij[:, 0], len(xyz) - 1)], np.inf)
         cols_idx.append(ij.astype(np.int64) + offs[j + 1])
         cols_ok.append(ok)
@@ -213,6 +213,21 @@ def make_train_sample(seed, voxel_size=0.3, num_neighborhood=6, min_dist=5.0, ma
     if rng.rand() < 0.95:
         feats[0] = feats[0] + rng.normal(0.0, 0.01, feats[0].shape).astype(np.float32)
     return (xyz_th, xyz_cmpl_th, coords, feats, group, index, finest, list_M)
+
+
+def sample_search_radius(seed, voxel_size=0.3, num_neighborhood=6, search_mult=1.5, random_rotation=True,
+                         random_scale=True):
+    """The (scaled) matching radius make_train_sample used for ``seed`` (it replays the generator's draws)."""
+    rng = np.random.RandomState(seed + 7919)
+    for _ in range(num_neighborhood):
+        rng.uniform(-0.5, 0.5)
+    if random_rotation:
+        for _ in range(1 + num_neighborhood):
+            _random_rotation(rng, np.pi / 4)
+    search = voxel_size * search_mult
+    if random_scale and rng.rand() < 0.95:
+        search *= 0.8 + 0.4 * rng.rand()
+    return search
 
 
 def collate_train(samples):

@@ -69,6 +69,33 @@ int gcl_stride_map(const int32_t* coords_in, int64_t n_in, const int32_t* n_in_d
                    int64_t* table_out, int64_t cap_out, int32_t* scratch,
                    int32_t* coords_out, int32_t* n_out_dev, int32_t* status, void* stream);
 
+/* Device-wide exclusive prefix sum of int32 (scratch: int32[n / 2048 + 64]); used by the map builders. */
+int gcl_exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out, int32_t* scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * "Next" rows: the loader work either side of the hot path, on the device.
+ * gcl_voxel_coords + gcl_unique_coords = ME.utils.sparse_quantize(xyz / voxel, return_index=True)
+ *   (util/misc.py:117-118, lib/colocation_data_loader.py:379,388): coords = floor(xyz / voxel) (correctly rounded
+ *   fp32 division, floor toward -inf), one row per voxel = first occurrence, kept rows in ascending order;
+ *   index_out[j] = input row of output row j; table_out maps the kept coordinates to their output rows.
+ * gcl_colocation_hits + gcl_colocation_emit = get_matching_indices_colocation (util/pointcloud.py:69-132):
+ *   xyz_own [Ntot,3]: voxel-representative points of the centre cloud followed by the neighbour clouds, each in its
+ *   OWN sensor frame; xyz_cf: the same points in the CENTRE frame (neighbours transformed by list_M, fp32);
+ *   table: coordinate map of floor(xyz_own / voxel) with batch id = cloud id; to_cloud_host: double[n_clouds][12],
+ *   row-major 3x4 transforms centre frame -> cloud frame (identity for cloud 0), used only to find candidate voxels.
+ *   hits [n_center, n_clouds, K] (rows into xyz_*, ascending distance, -1 padded), cnt, first_rng: per (centre point,
+ *   cloud).  emit: group [G], index [sum], finest [sum] (exactly one 1 per group), totals = {G, sum} on the device.
+ * ---------------------------------------------------------------------------------------------- */
+int gcl_voxel_coords(const float* xyz, int64_t p, float voxel, int32_t batch_id, int32_t* coords, void* stream);
+int gcl_unique_coords(const int32_t* coords_in, int64_t n_in, int64_t* table_out, int64_t cap_out, int32_t* scratch,
+                      int32_t* coords_out, int64_t* index_out, int32_t* n_out_dev, int32_t* status, void* stream);
+int gcl_colocation_hits(const float* xyz_own, const float* xyz_cf, int64_t n_center, int32_t n_clouds,
+                        const double* to_cloud_host, const int64_t* table, int64_t cap, float inv_voxel, double radius,
+                        int32_t K, int32_t* hits, int32_t* cnt, double* first_rng, void* stream);
+int gcl_colocation_emit(const int32_t* hits, const int32_t* cnt, const double* first_rng, int64_t n_center,
+                        int32_t n_clouds, int32_t K, int32_t* scratch, int32_t* group, int64_t* index, uint8_t* finest,
+                        int32_t* totals, void* stream);
+
 /* Kernel map for kernel size ks^3 (x fastest in k), offsets scaled by `step` (= input tensor stride x dilation),
  * region centred on the OUTPUT coordinate:  nbr[k * n_out + v] = input row at c_out[v] + o_k * step, or -1.
  * same_map != 0: coords_out IS the input map (stride-1 conv): only offsets k <= K/2 are looked up, the mirror

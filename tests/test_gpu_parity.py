@@ -578,3 +578,62 @@ def test_resunet_fat_variant_vs_oracle():
     F.backward(gy.float().to(DEV))
     for name, p_ in m.named_parameters():
         assert rel_l2(p_.grad.cpu(), so[name].grad) < 2e-3, name
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# "next" rows: voxelisation and co-location group building on the device -- bit-exact
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("voxel", [0.3, 0.025])
+def test_sparse_quantize_gpu_bit_exact(voxel):
+    import gcl_amd.MinkowskiEngine as ME
+    from gcl_amd import synthetic
+    from gcl_amd.lib.colocation_data_gpu import sparse_quantize_gpu
+    xyz = synthetic.raycast(synthetic.make_scene(5, n_boxes=15), np.zeros(3), 1)
+    if voxel < 0.1:
+        xyz = synthetic.make_box_cloud(1, 5000)            # demo.py's 2.5 cm voxels
+    xyz[:50] = xyz[50:100]                                  # exact duplicates
+    ref_c, ref_i = ME.utils.sparse_quantize(xyz / np.float32(voxel), return_index=True)
+    c, i = sparse_quantize_gpu(torch.from_numpy(xyz).to(DEV), voxel, batch_id=3)
+    assert np.array_equal(i.cpu().numpy(), ref_i)
+    assert np.array_equal(c.cpu().numpy()[:, 1:], ref_c) and (c[:, 0] == 3).all()
+
+
+@pytest.mark.parametrize("seed,nn", [(31, 6), (32, 2)])
+def test_colocation_groups_gpu_bit_exact(seed, nn):
+    """Group sizes, member rows (nearest first, centre cloud first) and finest flags equal the CPU restatement of
+    get_matching_indices_colocation (util/pointcloud.py:69-132) on a rotated + scaled synthetic sample."""
+    from gcl_amd import synthetic
+    from gcl_amd.lib.colocation_data_gpu import colocation_groups_gpu
+    xyz_th, xyz_cmpl_th, coords, feats, group, index, finest, list_M = synthetic.make_train_sample(
+        seed, 0.3, num_neighborhood=nn, n_boxes=20)
+    # the generator scales the search radius 1.5 * 0.3 with the random scale it draws: replay it
+    radius = synthetic.sample_search_radius(seed, 0.3, nn)
+    xyz_own = np.concatenate([xyz_th] + xyz_cmpl_th).astype(np.float32)
+    xyz_cf = np.concatenate([xyz_th] + [synthetic._apply(list_M[j], x) for j, x in enumerate(xyz_cmpl_th)])
+    C = np.concatenate([np.concatenate([np.full((len(c), 1), b, np.int32), c], 1) for b, c in enumerate(coords)])
+    g, idx, fl = colocation_groups_gpu(torch.from_numpy(xyz_own).to(DEV), torch.from_numpy(xyz_cf).to(DEV),
+                                       torch.from_numpy(C).to(DEV), len(xyz_th), 1 + nn, list_M, 0.3, radius)
+    assert np.array_equal(g.cpu().numpy(), np.asarray(group, dtype=np.int32))
+    assert np.array_equal(idx.cpu().numpy(), np.asarray(index, dtype=np.int64))
+    assert np.array_equal(fl.cpu().numpy(), np.asarray(finest, dtype=bool))
+    assert len(group) > 100
+
+
+def test_gpu_built_batch_trains():
+    """End to end on the device: raw clouds -> voxelise -> groups -> collate -> training step (finite loss)."""
+    from gcl_amd import synthetic
+    from gcl_amd.lib.colocation_data_gpu import build_sample_gpu, collate_gpu
+    from gcl_amd.lib.colocation_trainer import FinestContrastiveLossTrainer, make_config
+    samples = []
+    for s in (41, 42):
+        scene = synthetic.make_scene(s, n_boxes=15)
+        clouds = [synthetic.raycast(scene, np.array([x, 0.0, 0.0]), s * 7 + k)[::3] for k, x in enumerate((0.0, 6.0, 12.0))]
+        Ms = [np.eye(4), np.eye(4)]
+        Ms[0][0, 3], Ms[1][0, 3] = 6.0, 12.0
+        samples.append(build_sample_gpu(clouds, Ms, 0.3, 0.45, DEV))
+    batch = collate_gpu(samples)
+    assert batch["group"].numel() > 50 and batch["finest_flag"].sum().item() == batch["group"].numel()
+    tr = FinestContrastiveLossTrainer(make_config(batch_size=2, num_pos_per_batch=64, num_hn_samples_per_batch=128), device=DEV)
+    np.random.seed(0)
+    loss, parts, n = tr.train_step(batch)
+    assert torch.isfinite(loss).item() and n == len(batch["sinput_C"])
