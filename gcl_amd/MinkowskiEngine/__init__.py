@@ -21,6 +21,7 @@ from .. import _lib
 from . import utils
 from . import MinkowskiFunctional  # noqa: F401  (import MinkowskiEngine.MinkowskiFunctional as MEF)
 from .core import CoordinateManager, CoordinateMapKey, SparseTensor, cat
+from . import ops
 from .ops import batch_norm, set_conv_precision, sparse_conv
 
 __all__ = ["SparseTensor", "CoordinateManager", "CoordinateMapKey", "MinkowskiConvolution",
@@ -38,6 +39,15 @@ class MinkowskiNetwork(nn.Module):
     def __init__(self, D):
         super().__init__()
         self.D = D
+        self._amax_group = None
+        self.register_forward_pre_hook(MinkowskiNetwork._ensure_amax_group)
+
+    @staticmethod
+    def _ensure_amax_group(self, _args):
+        # fp16x3: max|W| of every convolution kernel of the network is refreshed by ONE launch per optimizer step
+        if self._amax_group is None:
+            ws = [m.kernel for m in self.modules() if isinstance(m, _ConvBase) and m.in_channels > 4]
+            self._amax_group = ops.WeightAmaxGroup(ws) if ws else False
 
 
 class _ConvBase(nn.Module):
@@ -126,6 +136,18 @@ class MinkowskiBatchNorm(nn.Module):
         if not (affine and track_running_stats):
             raise NotImplementedError("affine=True, track_running_stats=True only")
         self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum, affine=True, track_running_stats=True)
+        self._pending_batches = 0                # training forwards not yet added to bn.num_batches_tracked (device)
+        self.register_state_dict_pre_hook(MinkowskiBatchNorm._flush_batches)
+
+    @staticmethod
+    def _flush_batches(self, *_):
+        if self._pending_batches:
+            self.bn.num_batches_tracked += self._pending_batches
+            self._pending_batches = 0
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._pending_batches = 0
+        return super()._load_from_state_dict(*args, **kwargs)
 
     def forward(self, x, residual=None, relu=False):
         bn = self.bn
@@ -135,7 +157,7 @@ class MinkowskiBatchNorm(nn.Module):
         F = batch_norm(x.F, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training,
                        bn.momentum, bn.eps, res, relu, getattr(x, "_bn_stats", None))
         if self.training:
-            bn.num_batches_tracked += 1
+            self._pending_batches += 1           # flushed into bn.num_batches_tracked when the state is read
         out = SparseTensor(F, coordinate_map_key=x.coordinate_map_key, coordinate_manager=x.coordinate_manager)
         out._nonneg = bool(relu)
         return out

@@ -1,4 +1,5 @@
 """torch.autograd wrappers around the C-ABI kernels (include/gcl_amd.h).  GPU tensors only."""
+import ctypes
 import os
 
 import torch
@@ -51,18 +52,99 @@ class _Timed:
             PROFILE.append(self.rec)
 
 
-_AMAX_POOL = {}      # device -> [zero-filled int32 tensor, cursor]: slots are used once, one fill per 4096 calls
+_LAST_BN_AMAX = None
+_AMAX_POOL = {}      # device -> [zero-filled int32 [1024, 512], cursor]: slots are used once
+
+
+AMAX_WORDS = 512        # GCL_AMAX_WORDS (include/gcl_amd.h): 16 entries on separate 128-byte lines
+
+
+def amax_slot(device):
+    """A zero-initialised amax slot (device int32[GCL_AMAX_WORDS], used once); one 2 MB fill per 1024 slots."""
+    pool = _AMAX_POOL.get(device)
+    if pool is None or pool[1] >= pool[0].shape[0]:
+        pool = _AMAX_POOL[device] = [torch.zeros((1024, AMAX_WORDS), dtype=torch.int32, device=device), 0]
+    out = pool[0][pool[1]]
+    pool[1] += 1
+    return out
+
+
+def amax_value(slot):
+    """The float held by an amax slot, as a device tensor (tests / diagnostics)."""
+    return slot.view(-1, 32)[:, 0].max().view(1).view(torch.float32)
+
+
+_AMAX_EPOCH = 0
+
+
+def invalidate_amax():
+    """Void every amax tag.  Needed only after writing a tagged tensor through an alias torch does not version
+    together with it (e.g. updating FlatDDP.flat_param directly instead of stepping the parameters)."""
+    global _AMAX_EPOCH
+    _AMAX_EPOCH += 1
+
+
+def tag_amax(t, slot):
+    """Remember that ``slot`` holds gcl_amax of ``t`` as it is now (in-place writes bump _version and void the tag)."""
+    t._gcl_amax = (slot, t._version, _AMAX_EPOCH)
+
+
+def known_amax(t):
+    tag = getattr(t, "_gcl_amax", None)
+    return tag[0] if tag is not None and tag[1] == t._version and tag[2] == _AMAX_EPOCH else None
 
 
 def tensor_amax(lib, t):
-    """Device int32[1] holding the bit pattern of max|t| (only the fp16x3 mode needs it)."""
-    pool = _AMAX_POOL.get(t.device)
-    if pool is None or pool[1] >= pool[0].numel():
-        pool = _AMAX_POOL[t.device] = [torch.zeros(4096, dtype=torch.int32, device=t.device), 0]
-    out = pool[0][pool[1]:pool[1] + 1]
-    pool[1] += 1
+    """Device int32[1] holding the bit pattern of max|t| (only the fp16x3 mode needs it).  Producers that already
+    stream the tensor (BatchNorm apply / backward apply) publish it themselves and tag the tensor; parameters of a
+    WeightAmaxGroup are refreshed together in one launch."""
+    out = known_amax(t)
+    if out is not None:
+        return out
+    group = getattr(t, "_gcl_amax_group", None)
+    if group is not None:
+        return group.refresh(lib, t)
+    out = amax_slot(t.device)
     _lib.check(lib.gcl_amax(_lib.ptr(t, torch.float32), t.numel(), _lib.ptr(out), 1, _lib.stream()), "gcl_amax")
+    tag_amax(t, out)
     return out
+
+
+class WeightAmaxGroup:
+    """gcl_amax of all convolution kernels of a network in ONE launch per optimizer step (gcl_amax_multi)."""
+
+    def __init__(self, params):
+        self.params = [p for p in params]
+        for p in self.params:
+            p._gcl_amax_group = self
+        self.ptrs = None
+
+    def refresh(self, lib, want):
+        ps = self.params
+        dev = ps[0].device
+        ptrs = [p.data_ptr() for p in ps]
+        if self.ptrs != ptrs:
+            if any((not p.is_contiguous()) or p.dtype != torch.float32 or p.device != dev for p in ps):
+                raise ValueError("WeightAmaxGroup: parameters must be contiguous fp32 tensors on one device")
+            self.ptrs = ptrs
+            self.table = torch.tensor(ptrs + [p.numel() for p in ps], dtype=torch.int64).to(dev)
+            self.out = torch.empty((len(ps), AMAX_WORDS), dtype=torch.int32, device=dev)
+        else:
+            self.out = torch.empty_like(self.out)       # earlier slots may still be referenced by saved contexts
+        n = len(ps)
+        _lib.check(lib.gcl_amax_multi(_lib.ptr(self.table), ctypes_offset(self.table, n), n, _lib.ptr(self.out),
+                                      _lib.stream()), "gcl_amax_multi")
+        found = None
+        for i, p in enumerate(ps):
+            slot = self.out[i]
+            tag_amax(p, slot)
+            if p is want:
+                found = slot
+        return found
+
+
+def ctypes_offset(t, elem):
+    return ctypes.c_void_p(t.data_ptr() + elem * t.element_size())
 
 
 def _conv_launch(lib, x, Wk, mode, table, n_out, cin, cout, bias, pairs=0, want_stats=False, x_amax=None,
@@ -103,6 +185,9 @@ class _SparseConvFn(torch.autograd.Function):
     def forward(ctx, x, W, bias, kmap, n_out, transpose, mgr, want_stats):
         lib = _lib.require_gpu()
         stats = None
+        fp16x3 = _PREC_CODES[PRECISION] == 4
+        x_known = known_amax(x) if fp16x3 else None
+        w_known = tensor_amax(lib, W) if (fp16x3 and W.is_contiguous() and W.shape[-2] > 4) else None
         x = x.contiguous()
         Wk = (W if W.dim() == 3 else W.unsqueeze(0)).contiguous()
         K, cin, cout = Wk.shape
@@ -121,8 +206,9 @@ class _SparseConvFn(torch.autograd.Function):
             b = bias.detach().contiguous().view(-1) if bias is not None else None
             # pair counts reach the host asynchronously; only the profiler needs them in the forward pass
             ctx.pairs = (kmap.n_pairs if kmap is not None else n_out) if PROFILE is not None else 0
-            if _PREC_CODES[PRECISION] == 4:
-                ctx.x_amax, ctx.w_amax = tensor_amax(lib, x), tensor_amax(lib, Wk)
+            if fp16x3:
+                ctx.x_amax = x_known if x_known is not None else tensor_amax(lib, x)
+                ctx.w_amax = w_known if w_known is not None else tensor_amax(lib, Wk)
             y, stats = _conv_launch(lib, x, Wk, 0, tbl, n_out, cin, cout, b, ctx.pairs, want_stats=True,
                                     x_amax=ctx.x_amax, w_amax=ctx.w_amax) \
                 if want_stats else (_conv_launch(lib, x, Wk, 0, tbl, n_out, cin, cout, b, ctx.pairs,
@@ -141,10 +227,12 @@ class _SparseConvFn(torch.autograd.Function):
         x, Wk = ctx.saved_tensors
         K, cin, cout = Wk.shape
         kmap, transpose = ctx.kmap, ctx.transpose
+        prec = _PREC_CODES[PRECISION]
+        dy_amax = known_amax(dy) if (prec == 4 and not ctx.stem) else None
         dy = dy.contiguous()
         dx = dW = dbias = None
-        prec = _PREC_CODES[PRECISION]
-        dy_amax = tensor_amax(lib, dy) if (prec == 4 and not ctx.stem) else None
+        if dy_amax is None and prec == 4 and not ctx.stem:
+            dy_amax = tensor_amax(lib, dy)
         x_amax = ctx.x_amax if (prec != 4 or ctx.x_amax is not None or ctx.stem) else tensor_amax(lib, x)
         w_amax = ctx.w_amax if (prec != 4 or ctx.w_amax is not None or ctx.stem) else tensor_amax(lib, Wk)
         if not ctx.stem and PROFILE is not None:
@@ -228,9 +316,11 @@ class _BatchNormFn(torch.autograd.Function):
             rstd = torch.rsqrt(running_var.detach() + eps).contiguous()
         res = residual.contiguous() if residual is not None else None
         y = torch.empty_like(x)
+        global _LAST_BN_AMAX
+        _LAST_BN_AMAX = slot = amax_slot(dev) if PRECISION == "fp16x3" else None
         _lib.check(lib.gcl_bn_apply(_lib.ptr(x), n, c, _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(weight.detach()),
-                                    _lib.ptr(bias.detach()), _lib.ptr(res), int(relu), _lib.ptr(y), _lib.stream()),
-                   "gcl_bn_apply")
+                                    _lib.ptr(bias.detach()), _lib.ptr(res), int(relu), _lib.ptr(y), _lib.ptr(slot),
+                                    _lib.stream()), "gcl_bn_apply")
         ctx.save_for_backward(x, y if relu else None, weight, mean, rstd)
         ctx.relu, ctx.training, ctx.has_res = bool(relu), bool(training), residual is not None
         return y
@@ -251,17 +341,24 @@ class _BatchNormFn(torch.autograd.Function):
                                          _lib.stream()), "gcl_bn_bwd_reduce")
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.has_res else None
+        slot = amax_slot(dev) if PRECISION == "fp16x3" else None
         if ctx.training:
             sg, sx = sum_g, sum_gx
         else:                       # running statistics are constants: no batch-statistics terms
             sg = sx = torch.zeros(c, dtype=torch.float32, device=dev)
         _lib.check(lib.gcl_bn_bwd_apply(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(y), n, c, _lib.ptr(mean), _lib.ptr(rstd),
                                         _lib.ptr(weight.detach()), _lib.ptr(sg), _lib.ptr(sx), int(ctx.relu),
-                                        _lib.ptr(dx), _lib.ptr(dres), _lib.stream()), "gcl_bn_bwd_apply")
+                                        _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(slot), _lib.stream()),
+                   "gcl_bn_bwd_apply")
+        if slot is not None:
+            tag_amax(dx, slot)
         return dx, sum_gx, sum_g, None, None, None, None, None, dres, None, None
 
 
 def batch_norm(x, weight, bias, running_mean, running_var, training, momentum, eps, residual=None, relu=False,
                tile_stats=None):
-    return _BatchNormFn.apply(x, weight, bias, running_mean, running_var, training, momentum, eps, residual, relu,
-                              tile_stats)
+    y = _BatchNormFn.apply(x, weight, bias, running_mean, running_var, training, momentum, eps, residual, relu,
+                           tile_stats)
+    if _LAST_BN_AMAX is not None:
+        tag_amax(y, _LAST_BN_AMAX)
+    return y

@@ -36,6 +36,7 @@ SIGNATURES = {
     "gcl_kernel_map_pairs": (_i32, [_vp, _i32, _i64, ctypes.POINTER(_i64), _vp, _vp, _vp, _vp]),
     "gcl_pack_weights_bytes": (_i64, [_i32, _i32, _i32, _i32]),
     "gcl_amax": (_i32, [_vp, _i64, _vp, _i32, _vp]),
+    "gcl_amax_multi": (_i32, [_vp, _vp, _i32, _vp, _vp]),
     "gcl_pack_weights": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "gcl_table_sort_scratch_len": (_i64, [_i64]),
     "gcl_table_sort": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
@@ -50,9 +51,9 @@ SIGNATURES = {
     "gcl_bn_stats": (_i32, [_vp, _i64, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gcl_bn_tiles_scratch_len": (_i64, [_i64, _i32]),
     "gcl_bn_stats_from_tiles": (_i32, [_vp, _i64, _i64, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "gcl_bn_apply": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "gcl_bn_apply": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "gcl_bn_bwd_reduce": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
-    "gcl_bn_bwd_apply": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "gcl_bn_bwd_apply": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "gcl_group_loss_fwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp]),
     "gcl_group_loss_bwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),
     "gcl_nn_rowmin": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),

@@ -90,4 +90,21 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// ---- max|x| slots ("gcl_amax") --------------------------------------------------------------------------------
+// A slot is GCL_AMAX_WORDS = 512 int32: 16 entries on separate 128-byte lines (entry i at word 32 i); the value is the
+// maximum over the entries (bit patterns of non-negative floats order like ints).  Same-line atomics serialise at
+// ~12 ns each on gfx950 (tools/micro/atomic_contention.hip: 4096 workgroups on one line 50 us, on 16 lines 1 us),
+// so the workgroups of a producer spread over the 16 lines and skip the atomic when the line already covers them.
+constexpr int AMAX_ENTRIES = 16, AMAX_STRIDE = 32, AMAX_WORDS = AMAX_ENTRIES * AMAX_STRIDE;
+__device__ __forceinline__ int amax_slot_bits(const int* __restrict__ slot) {
+  int m = 0;
+#pragma unroll
+  for (int i = 0; i < AMAX_ENTRIES; ++i) m = max(m, slot[i * AMAX_STRIDE]);
+  return m;
+}
+__device__ __forceinline__ void amax_slot_publish(int* slot, int bits, unsigned wg) {
+  int* p = slot + (wg & (AMAX_ENTRIES - 1)) * AMAX_STRIDE;
+  if (bits > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, bits);
+}
+
 }  // namespace gcl

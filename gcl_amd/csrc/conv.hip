@@ -217,7 +217,7 @@ struct Prec {
 
 // power-of-two scale that maps amax into [2^13, 2^14)
 __device__ __forceinline__ float amax_scale(const int* __restrict__ amax_bits) {
-  float amax = __int_as_float(*amax_bits);
+  float amax = __int_as_float(amax_slot_bits(amax_bits));
   if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.f;
   int e;
   frexpf(amax, &e);   // amax = m * 2^e, m in [0.5, 1)
@@ -292,7 +292,34 @@ __global__ void __launch_bounds__(256) k_amax(const float4* __restrict__ x, long
   if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0)   // one atomic per workgroup: contended same-address atomics serialise (~10 ns each)
-    atomicMax(amax_bits, __float_as_int(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
+    amax_slot_publish(amax_bits, __float_as_int(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))), blockIdx.x);
+}
+
+// the same for a list of tensors in one launch (all convolution kernels of a model): grid = (chunks, tensors)
+__global__ void __launch_bounds__(256) k_amax_multi(const float* const* __restrict__ ptrs,
+                                                    const long long* __restrict__ sizes, int* amax_bits) {
+  const float* x = ptrs[blockIdx.y];
+  const long long n = sizes[blockIdx.y];
+  float m = 0.f;
+  if ((reinterpret_cast<unsigned long long>(x) & 15) == 0) {
+    const long long n4 = n >> 2;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (long long)gridDim.x * blockDim.x) {
+      float4 v = reinterpret_cast<const float4*>(x)[e];
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    if (blockIdx.x == 0 && (long long)threadIdx.x < n - n4 * 4) m = fmaxf(m, fabsf(x[n4 * 4 + threadIdx.x]));
+  } else {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x)
+      m = fmaxf(m, fabsf(x[e]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  __shared__ float wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    amax_slot_publish(amax_bits + (size_t)blockIdx.y * AMAX_WORDS,
+                      __float_as_int(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))), blockIdx.x);
 }
 
 // wp16 (8 x 16-bit units): [(((k*CC + cc)*TNB + nb)*2 + m)*planes + pl][lane = h*32 + j][jj]
@@ -911,11 +938,23 @@ static bool prec_ok(int prec) { return prec == 0 || prec == 2 || prec == 3 || pr
 int gcl_amax(const float* x, int64_t n, int32_t* amax_bits, int32_t zeroed, void* stream) {
   GCL_CHECK_ARG(x && amax_bits && n > 0, "gcl_amax: bad argument");
   hipStream_t st = (hipStream_t)stream;
-  if (!zeroed) GCL_CHECK_HIP(hipMemsetAsync(amax_bits, 0, sizeof(int32_t), st));
+  if (!zeroed) GCL_CHECK_HIP(hipMemsetAsync(amax_bits, 0, AMAX_WORDS * sizeof(int32_t), st));
   long long n4 = n / 4;
   long long g = cdiv(n4 > 0 ? n4 : 1, 256);
   if (g > 512) g = 512;
   hipLaunchKernelGGL(k_amax, dim3((unsigned)g), dim3(256), 0, st, (const float4*)x, n4, x + n4 * 4, (int)(n - n4 * 4),
+                     amax_bits);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int gcl_amax_multi(const float* const* ptrs, const int64_t* sizes, int32_t n_tensors, int32_t* amax_bits,
+                   void* stream) {
+  GCL_CHECK_ARG(ptrs && sizes && amax_bits, "gcl_amax_multi: null pointer");
+  GCL_CHECK_ARG(n_tensors > 0 && n_tensors <= 65535, "gcl_amax_multi: 1 <= n_tensors <= 65535");
+  hipStream_t st = (hipStream_t)stream;
+  GCL_CHECK_HIP(hipMemsetAsync(amax_bits, 0, (size_t)n_tensors * AMAX_WORDS * sizeof(int32_t), st));
+  hipLaunchKernelGGL(k_amax_multi, dim3(32, (unsigned)n_tensors), dim3(256), 0, st, ptrs, (const long long*)sizes,
                      amax_bits);
   GCL_CHECK_LAUNCH();
   return GCL_OK;

@@ -8,19 +8,26 @@
 
 namespace gcl {
 
-constexpr int BN_ROWS_PER_WG = 1024;
+// rows per workgroup of the statistics passes: 1024, halved (down to 64) until the launch has >= 1024 workgroups --
+// the deep levels have few, wide rows.  A function of (n, c) only, so the summation order is reproducible.
+static inline int bn_rows_per_wg(long long n, int c) {
+  int rows = 1024;
+  while (rows > 64 && n / rows < 1024) rows >>= 1;
+  (void)c;
+  return rows;
+}
 
 // thread t -> channel quad cq = t % (c/4), row lane rl = t / (c/4)
 template <bool BWD>
 __global__ void __launch_bounds__(256) k_bn_reduce(const float* __restrict__ x, const float* __restrict__ dy,
                                                    const float* __restrict__ y, long long n, int c,
                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                   int relu, double* partial) {
+                                                   int relu, int rows_per_wg, double* partial) {
   __shared__ double red[2][256][4];
   const int cq_n = c >> 2;
   const int cq = threadIdx.x % cq_n, rl = threadIdx.x / cq_n, rstep = 256 / cq_n;
-  const long long r_begin = (long long)blockIdx.x * BN_ROWS_PER_WG;
-  long long r_end = r_begin + BN_ROWS_PER_WG;
+  const long long r_begin = (long long)blockIdx.x * rows_per_wg;
+  long long r_end = r_begin + rows_per_wg;
   if (r_end > n) r_end = n;
   double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
   float4 mu = make_float4(0, 0, 0, 0), rs = make_float4(1, 1, 1, 1);
@@ -28,24 +35,48 @@ __global__ void __launch_bounds__(256) k_bn_reduce(const float* __restrict__ x, 
     mu = reinterpret_cast<const float4*>(mean)[cq];
     rs = reinterpret_cast<const float4*>(rstd)[cq];
   }
-  for (long long r = r_begin + rl; r < r_end; r += rstep) {
-    float4 xv = reinterpret_cast<const float4*>(x + r * c)[cq];
-    if (!BWD) {
-      s0[0] += xv.x; s0[1] += xv.y; s0[2] += xv.z; s0[3] += xv.w;
-      s1[0] += (double)xv.x * xv.x; s1[1] += (double)xv.y * xv.y;
-      s1[2] += (double)xv.z * xv.z; s1[3] += (double)xv.w * xv.w;
-    } else {
-      float4 g = reinterpret_cast<const float4*>(dy + r * c)[cq];
-      if (relu) {
-        float4 yv = reinterpret_cast<const float4*>(y + r * c)[cq];
-        g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
-        g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
-      }
-      s0[0] += g.x; s0[1] += g.y; s0[2] += g.z; s0[3] += g.w;
-      s1[0] += (double)g.x * ((xv.x - mu.x) * rs.x); s1[1] += (double)g.y * ((xv.y - mu.y) * rs.y);
-      s1[2] += (double)g.z * ((xv.z - mu.z) * rs.z); s1[3] += (double)g.w * ((xv.w - mu.w) * rs.w);
-    }
+#define BN_ACC(xv, g, yv)                                                                                     \
+  if (!BWD) {                                                                                                 \
+    s0[0] += xv.x; s0[1] += xv.y; s0[2] += xv.z; s0[3] += xv.w;                                               \
+    s1[0] += (double)xv.x * xv.x; s1[1] += (double)xv.y * xv.y;                                               \
+    s1[2] += (double)xv.z * xv.z; s1[3] += (double)xv.w * xv.w;                                               \
+  } else {                                                                                                    \
+    if (relu) {                                                                                               \
+      g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;                                             \
+      g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;                                             \
+    }                                                                                                         \
+    s0[0] += g.x; s0[1] += g.y; s0[2] += g.z; s0[3] += g.w;                                                   \
+    s1[0] += (double)g.x * ((xv.x - mu.x) * rs.x); s1[1] += (double)g.y * ((xv.y - mu.y) * rs.y);             \
+    s1[2] += (double)g.z * ((xv.z - mu.z) * rs.z); s1[3] += (double)g.w * ((xv.w - mu.w) * rs.w);             \
   }
+  // two rows in flight per thread (all loads of an iteration are issued before the first use)
+  const float4 z4 = make_float4(0, 0, 0, 0);
+  long long r = r_begin + rl;
+  for (; r + rstep < r_end; r += 2 * rstep) {
+    const long long q = r + rstep;
+    float4 xa = reinterpret_cast<const float4*>(x + r * c)[cq], xb = reinterpret_cast<const float4*>(x + q * c)[cq];
+    float4 ga = z4, gb = z4, ya = z4, yb = z4;
+    if (BWD) {
+      ga = reinterpret_cast<const float4*>(dy + r * c)[cq];
+      gb = reinterpret_cast<const float4*>(dy + q * c)[cq];
+      if (relu) {
+        ya = reinterpret_cast<const float4*>(y + r * c)[cq];
+        yb = reinterpret_cast<const float4*>(y + q * c)[cq];
+      }
+    }
+    BN_ACC(xa, ga, ya)
+    BN_ACC(xb, gb, yb)
+  }
+  if (r < r_end) {
+    float4 xa = reinterpret_cast<const float4*>(x + r * c)[cq];
+    float4 ga = z4, ya = z4;
+    if (BWD) {
+      ga = reinterpret_cast<const float4*>(dy + r * c)[cq];
+      if (relu) ya = reinterpret_cast<const float4*>(y + r * c)[cq];
+    }
+    BN_ACC(xa, ga, ya)
+  }
+#undef BN_ACC
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     red[0][threadIdx.x][j] = s0[j];
@@ -137,12 +168,28 @@ __global__ void __launch_bounds__(256) k_bn_bwd_final(const double* __restrict__
   sum_gx[ch] = (float)ss;
 }
 
+// max |v| of the values a workgroup produced -> the gcl_amax slot (common.h)
+__device__ __forceinline__ void publish_amax(float m, int* amax_bits) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  __shared__ float wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    amax_slot_publish(amax_bits, __float_as_int(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))), blockIdx.x);
+  }
+}
+__device__ __forceinline__ float amax4(float m, const float4& v) {
+  return fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+}
+
 __global__ void __launch_bounds__(256) k_bn_apply(const float* __restrict__ x, long long total4, int c,
                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
                                                   const float* __restrict__ weight, const float* __restrict__ bias,
                                                   const float* __restrict__ residual, int relu,
-                                                  float* __restrict__ y) {
+                                                  float* __restrict__ y, int* amax_bits) {
   const int cq_n = c >> 2;
+  float am = 0.f;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total4;
        e += (long long)gridDim.x * blockDim.x) {
     int cq = (int)(e % cq_n);
@@ -162,7 +209,9 @@ __global__ void __launch_bounds__(256) k_bn_apply(const float* __restrict__ x, l
       o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
     }
     reinterpret_cast<float4*>(y)[e] = o;
+    am = amax4(am, o);
   }
+  if (amax_bits) publish_amax(am, amax_bits);
 }
 
 __global__ void __launch_bounds__(256) k_bn_bwd_apply(const float* __restrict__ x, const float* __restrict__ dy,
@@ -172,8 +221,10 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const float* __restrict__ 
                                                       const float* __restrict__ weight,
                                                       const float* __restrict__ sum_g,
                                                       const float* __restrict__ sum_gx, int relu,
-                                                      float* __restrict__ dx, float* __restrict__ dres) {
+                                                      float* __restrict__ dx, float* __restrict__ dres,
+                                                      int* amax_bits) {
   const int cq_n = c >> 2;
+  float am = 0.f;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total4;
        e += (long long)gridDim.x * blockDim.x) {
     int cq = (int)(e % cq_n);
@@ -193,8 +244,10 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const float* __restrict__ 
     o.z = wv.z * rs.z * (g.z - sg.z * inv_n - (xv.z - mu.z) * rs.z * sx.z * inv_n);
     o.w = wv.w * rs.w * (g.w - sg.w * inv_n - (xv.w - mu.w) * rs.w * sx.w * inv_n);
     reinterpret_cast<float4*>(dx)[e] = o;
+    am = amax4(am, o);
     if (dres) reinterpret_cast<float4*>(dres)[e] = g;
   }
+  if (amax_bits) publish_amax(am, amax_bits);
 }
 
 static bool bn_c_ok(int c) { return c >= 4 && c % 4 == 0 && (256 % (c / 4)) == 0; }
@@ -205,16 +258,18 @@ using namespace gcl;
 
 extern "C" {
 
-int64_t gcl_bn_scratch_len(int64_t n, int32_t c) { return cdiv(n, BN_ROWS_PER_WG) * 2 * c; }
+int64_t gcl_bn_scratch_len(int64_t n, int32_t c) { return cdiv(n, bn_rows_per_wg(n, c)) * 2 * c; }
 
 int gcl_bn_stats(const float* x, int64_t n, int32_t c, float eps, float momentum, float* running_mean,
                  float* running_var, double* scratch, float* mean, float* rstd, void* stream) {
   GCL_CHECK_ARG(x && scratch && mean && rstd, "gcl_bn_stats: null pointer");
   GCL_CHECK_ARG(n > 0 && bn_c_ok(c), "gcl_bn_stats: unsupported shape n=%lld c=%d (c/4 must divide 256)", (long long)n, c);
   hipStream_t st = (hipStream_t)stream;
-  int nwg = (int)cdiv(n, BN_ROWS_PER_WG);
+  const int rows = bn_rows_per_wg(n, c);
+  int nwg = (int)cdiv(n, rows);
   hipLaunchKernelGGL(k_bn_reduce<false>, dim3(nwg), dim3(256), 0, st, x, (const float*)nullptr,
-                     (const float*)nullptr, (long long)n, c, (const float*)nullptr, (const float*)nullptr, 0, scratch);
+                     (const float*)nullptr, (long long)n, c, (const float*)nullptr, (const float*)nullptr, 0, rows,
+                     scratch);
   hipLaunchKernelGGL(k_bn_stats_final, dim3((unsigned)cdiv(c, 16)), dim3(256), 0, st, (const double*)scratch, nwg,
                      (long long)n, c, eps, momentum, running_mean, running_var, mean, rstd);
   GCL_CHECK_LAUNCH();
@@ -238,14 +293,14 @@ int gcl_bn_stats_from_tiles(const float* partial, int64_t n_tiles, int64_t n, in
 }
 
 int gcl_bn_apply(const float* x, int64_t n, int32_t c, const float* mean, const float* rstd, const float* weight,
-                 const float* bias, const float* residual, int32_t relu, float* y, void* stream) {
+                 const float* bias, const float* residual, int32_t relu, float* y, int32_t* y_amax, void* stream) {
   GCL_CHECK_ARG(x && mean && rstd && weight && bias && y, "gcl_bn_apply: null pointer");
   GCL_CHECK_ARG(n > 0 && c >= 4 && c % 4 == 0, "gcl_bn_apply: unsupported shape");
   long long total4 = n * (c / 4);
   long long g = cdiv(total4, 256);
   if (g > 4096) g = 4096;
   hipLaunchKernelGGL(k_bn_apply, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, total4, c, mean, rstd,
-                     weight, bias, residual, relu, y);
+                     weight, bias, residual, relu, y, y_amax);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }
@@ -256,9 +311,10 @@ int gcl_bn_bwd_reduce(const float* x, const float* dy, const float* y, int64_t n
   GCL_CHECK_ARG(!relu || y, "gcl_bn_bwd_reduce: y is required when relu is set");
   GCL_CHECK_ARG(n > 0 && bn_c_ok(c), "gcl_bn_bwd_reduce: unsupported shape n=%lld c=%d", (long long)n, c);
   hipStream_t st = (hipStream_t)stream;
-  int nwg = (int)cdiv(n, BN_ROWS_PER_WG);
+  const int rows = bn_rows_per_wg(n, c);
+  int nwg = (int)cdiv(n, rows);
   hipLaunchKernelGGL(k_bn_reduce<true>, dim3(nwg), dim3(256), 0, st, x, dy, y, (long long)n, c, mean, rstd, relu,
-                     scratch);
+                     rows, scratch);
   hipLaunchKernelGGL(k_bn_bwd_final, dim3((unsigned)cdiv(c, 16)), dim3(256), 0, st, (const double*)scratch, nwg, c,
                      sum_g, sum_gx);
   GCL_CHECK_LAUNCH();
@@ -267,7 +323,7 @@ int gcl_bn_bwd_reduce(const float* x, const float* dy, const float* y, int64_t n
 
 int gcl_bn_bwd_apply(const float* x, const float* dy, const float* y, int64_t n, int32_t c, const float* mean,
                      const float* rstd, const float* weight, const float* sum_g, const float* sum_gx, int32_t relu,
-                     float* dx, float* dres, void* stream) {
+                     float* dx, float* dres, int32_t* dx_amax, void* stream) {
   GCL_CHECK_ARG(x && dy && mean && rstd && weight && sum_g && sum_gx && dx, "gcl_bn_bwd_apply: null pointer");
   GCL_CHECK_ARG(!relu || y, "gcl_bn_bwd_apply: y is required when relu is set");
   GCL_CHECK_ARG(n > 0 && c >= 4 && c % 4 == 0, "gcl_bn_bwd_apply: unsupported shape");
@@ -275,7 +331,7 @@ int gcl_bn_bwd_apply(const float* x, const float* dy, const float* y, int64_t n,
   long long g = cdiv(total4, 256);
   if (g > 4096) g = 4096;
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, dy, y, total4, c,
-                     1.0f / (float)n, mean, rstd, weight, sum_g, sum_gx, relu, dx, dres);
+                     1.0f / (float)n, mean, rstd, weight, sum_g, sum_gx, relu, dx, dres, dx_amax);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }

@@ -61,6 +61,8 @@ class FlatDDP:
                 p.grad = self.flat_grad[off:off + n].view_as(p)
                 off += n
         self.params = params
+        from .MinkowskiEngine import ops
+        ops.invalidate_amax()                    # parameter storage moved (and is about to be broadcast into)
         if self.world > 1:
             dist.broadcast(self.flat_param, src=0, group=self.group)
             for b in module.buffers():

@@ -148,10 +148,17 @@ int gcl_table_sort(const int32_t* tbl, int32_t K, int64_t n, int32_t window, int
  *   stats (optional, prec 2/3): float[ceil(n_out/32)][2][cout] -- per 32-row tile column sums of y and y^2, consumed
  *   by gcl_bn_stats_from_tiles (the BatchNorm that follows then needs no statistics pass over y). */
 int64_t gcl_pack_weights_bytes(int32_t K, int32_t cin, int32_t cout, int32_t prec);
-/* max |x| of a tensor as the bit pattern of a float in amax_bits[0] (device int32); the fp16x3 mode derives its
- * exact power-of-two operand scales from it.  zeroed != 0: the caller guarantees amax_bits[0] == 0 on the stream
- * (slots handed out from a zero-filled pool), so no memset is issued. */
+/* max |x| of a tensor in an "amax slot": GCL_AMAX_WORDS device int32, 16 entries on separate 128-byte lines (entry i
+ * at word 32 i), value = max over the entries, each the bit pattern of a non-negative float.  (Workgroups publish to
+ * different lines: same-line atomics serialise on gfx950.)  The fp16x3 mode derives its exact power-of-two operand
+ * scales from it.  zeroed != 0: the caller guarantees the slot is all zero on the stream (slots handed out from a
+ * zero-filled pool), so no memset is issued. */
+#define GCL_AMAX_WORDS 512
 int gcl_amax(const float* x, int64_t n, int32_t* amax_bits, int32_t zeroed, void* stream);
+/* gcl_amax of n_tensors tensors in one launch: ptrs / sizes are DEVICE arrays (float* and element counts),
+ * amax_bits[n_tensors * GCL_AMAX_WORDS] (one slot per tensor) is cleared here.  Used once per step for all convolution kernels of a model. */
+int gcl_amax_multi(const float* const* ptrs, const int64_t* sizes, int32_t n_tensors, int32_t* amax_bits,
+                   void* stream);
 int gcl_pack_weights(const float* w, int32_t K, int32_t cin, int32_t cout, int32_t mode, int32_t prec,
                      const int32_t* w_amax, void* wp, void* stream);
 int gcl_conv_fwd(const float* x, const void* wp, int32_t prec, const int32_t* x_amax, const int32_t* w_amax,
@@ -183,6 +190,8 @@ int gcl_stem_bwd_weight(const float* x, const float* dy, const int32_t* nbr, int
  *                  In eval mode the host passes running stats as mean / rstd.
  *   backward:      g = dy * (relu ? y > 0 : 1);  gcl_bn_bwd_reduce -> sum_g[c], sum_gx[c] (xhat-weighted);
  *                  gcl_bn_bwd_apply -> dx, (dres = g).
+ *   y_amax / dx_amax (optional, ZERO-INITIALISED amax slots): the apply passes also publish gcl_amax of the tensor they
+ *                  write, so the fp16x3 convolution that consumes it needs no extra pass over it.
  * ---------------------------------------------------------------------------------------------- */
 int64_t gcl_bn_scratch_len(int64_t n, int32_t c);
 int gcl_bn_stats(const float* x, int64_t n, int32_t c, float eps, float momentum,
@@ -194,14 +203,14 @@ int gcl_bn_stats_from_tiles(const float* partial, int64_t n_tiles, int64_t n, in
                             void* stream);
 int gcl_bn_apply(const float* x, int64_t n, int32_t c, const float* mean, const float* rstd,
                  const float* weight, const float* bias, const float* residual, int32_t relu,
-                 float* y, void* stream);
+                 float* y, int32_t* y_amax, void* stream);
 int gcl_bn_bwd_reduce(const float* x, const float* dy, const float* y, int64_t n, int32_t c,
                       const float* mean, const float* rstd, int32_t relu, double* scratch,
                       float* sum_g, float* sum_gx, void* stream);
 int gcl_bn_bwd_apply(const float* x, const float* dy, const float* y, int64_t n, int32_t c,
                      const float* mean, const float* rstd, const float* weight,
                      const float* sum_g, const float* sum_gx, int32_t relu,
-                     float* dx, float* dres, void* stream);
+                     float* dx, float* dres, int32_t* dx_amax, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GCL loss (lib/colocation_trainer.py:430-535, square_loss path) and feature-space 1-NN.

@@ -637,3 +637,48 @@ def test_gpu_built_batch_trains():
     np.random.seed(0)
     loss, parts, n = tr.train_step(batch)
     assert torch.isfinite(loss).item() and n == len(batch["sinput_C"])
+
+
+def test_fused_amax_tags_equal_separate_pass():
+    """BatchNorm apply / backward-apply publish max|y| / max|dx| themselves and the weight group refreshes all kernels
+    in one launch: every tag must equal a separate gcl_amax pass, and in-place writes must void it."""
+    import gcl_amd.MinkowskiEngine as ME
+    from gcl_amd.MinkowskiEngine import ops
+    from gcl_amd import _lib
+    lib = _lib.load()
+    ME.set_conv_precision("fp16x3")
+
+    def amax_ref(t):
+        return t.detach().abs().max().view(1)
+
+    val = ops.amax_value
+
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(5000, 64, generator=g) * 3).to(DEV).requires_grad_(True)
+    res = torch.randn(5000, 64, generator=g).to(DEV)
+    bn = torch.nn.BatchNorm1d(64).to(DEV)
+    y = ops.batch_norm(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, True, 0.1, 1e-5, res, True)
+    assert ops.known_amax(y) is not None and torch.equal(val(ops.known_amax(y)), amax_ref(y))
+    seen = {}
+    def hook(gx):
+        tag = ops.known_amax(gx)
+        seen["tag"] = (None if tag is None else val(tag), amax_ref(gx))
+
+    x.register_hook(hook)
+    (y * torch.randn(5000, 64, generator=g).to(DEV)).sum().backward()
+    if seen["tag"][0] is not None:                       # the engine handed over the tagged tensor itself
+        assert torch.equal(*seen["tag"])
+    y2 = y.detach()
+    ops.tag_amax(y2, ops.known_amax(y))
+    y2.mul_(2.0)
+    assert ops.known_amax(y2) is None                    # version bump voids the tag
+    from gcl_amd.model import load_model
+    model = load_model("ResUNetBN2C")(1, 32, normalize_feature=True, conv1_kernel_size=5, D=3).to(DEV)
+    model._ensure_amax_group(model, None)
+    ws = model._amax_group.params
+    assert len(ws) == 22
+    for w in (ws[0], ws[7], ws[-1]):
+        assert torch.equal(val(ops.tensor_amax(lib, w)), amax_ref(w))
+    with torch.no_grad():
+        ws[7].mul_(3.0)
+    assert ops.known_amax(ws[7]) is None and torch.equal(val(ops.tensor_amax(lib, ws[7])), amax_ref(ws[7]))
