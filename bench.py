@@ -139,17 +139,21 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        loss, _, _ = trainer.train_step(dbatch)
+    import itertools
+    for loss, _, _ in trainer.train_steps(itertools.repeat(dbatch, args.warmup)):
+        pass
     sync()
     log("warmup done")
     t0 = time.perf_counter()
+    # the trainer's epoch loop: all K x 3 np.random draws happen inside the timed region (helper thread, one step
+    # ahead).  Per-launch events (roofline) are recorded during the LAST timed step only: recording ~300 events per
+    # step costs ~3 ms of host time, which would otherwise perturb every step of the timed region
+    steps = trainer.train_steps(itertools.repeat(dbatch, args.steps))
     for it in range(args.steps):
-        # per-launch events (roofline) are recorded during the LAST timed step only: recording ~300 events per
-        # step costs ~3 ms of host time, which would otherwise perturb every step of the timed region
         if it == args.steps - 1 and not args.no_kernel_events:
             ops.PROFILE = []
-        loss, parts, _ = trainer.train_step(dbatch)
+        loss, parts, _ = next(steps)
+    steps.close()
     t_enqueue = time.perf_counter() - t0
     sync()
     dt = time.perf_counter() - t0

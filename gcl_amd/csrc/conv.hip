@@ -820,30 +820,24 @@ static int bwd_weight_wgs(long long n_chunks) {
 __global__ void __launch_bounds__(256) k_stem_fwd(const float* __restrict__ x, const float* __restrict__ w,
                                                   const int* __restrict__ nbr, long long n_out, int K, int cin,
                                                   float* __restrict__ y) {
-  extern __shared__ __attribute__((aligned(16))) float wl[];   // [K*cin][32]
-  for (int e = threadIdx.x; e < K * cin * 32; e += blockDim.x) wl[e] = w[e];
-  __syncthreads();
+  // thread = output row; the weights W[k][ci][0..31] are wave-uniform and come through the scalar cache (s_load),
+  // so the inner product costs one v_fmac with an SGPR operand per (offset, channel) and no LDS traffic
   long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= n_out) return;
+  if (v >= n_out) v = n_out - 1;   // keep the wave uniform; the duplicate rows are not stored
   float acc[32];
 #pragma unroll
   for (int c = 0; c < 32; ++c) acc[c] = 0.f;
+#pragma unroll 5
   for (int k = 0; k < K; ++k) {
     int idx = nbr[(long long)k * n_out + v];
-    if (idx < 0) continue;
     for (int ci = 0; ci < cin; ++ci) {
-      float xv = x[(long long)idx * cin + ci];
-      const float4* wr = reinterpret_cast<const float4*>(wl + (k * cin + ci) * 32);
+      float xv = idx >= 0 ? x[(long long)idx * cin + ci] : 0.f;
+      const float* wr = w + (k * cin + ci) * 32;
 #pragma unroll
-      for (int c4 = 0; c4 < 8; ++c4) {
-        float4 wv = wr[c4];
-        acc[4 * c4 + 0] = fmaf(xv, wv.x, acc[4 * c4 + 0]);
-        acc[4 * c4 + 1] = fmaf(xv, wv.y, acc[4 * c4 + 1]);
-        acc[4 * c4 + 2] = fmaf(xv, wv.z, acc[4 * c4 + 2]);
-        acc[4 * c4 + 3] = fmaf(xv, wv.w, acc[4 * c4 + 3]);
-      }
+      for (int c = 0; c < 32; ++c) acc[c] = fmaf(xv, wr[c], acc[c]);
     }
   }
+  if ((long long)blockIdx.x * blockDim.x + threadIdx.x >= n_out) return;
   float4* yo = reinterpret_cast<float4*>(y + v * 32);
 #pragma unroll
   for (int c4 = 0; c4 < 8; ++c4) yo[c4] = make_float4(acc[4 * c4], acc[4 * c4 + 1], acc[4 * c4 + 2], acc[4 * c4 + 3]);
@@ -853,12 +847,15 @@ constexpr int STEM_ROWS_PER_WG = 1024;
 constexpr int STEM_KMAX = 125;
 
 // dW[k][ci][c] = sum_v x[nbr[k][v]][ci] * dY[v][c]  as an exact-f32 MFMA GEMM: M = K offsets (4 blocks of 32),
-// N = 32 channels, reduction over the output rows v.  A[i = offset][kk = row] is gathered through the neighbour
-// table, B[kk = row][j = channel] is a coalesced row of dY.  Per-workgroup slabs + ordered reduction (k_stem_reduce).
+// N = 32 channels, reduction over the output rows v.  Per tile of 128 rows the workgroup first resolves the gather
+// with coalesced reads of the k-major neighbour table (lanes along rows) into an LDS tile A[k][row]; the MFMA phase
+// then reads A[i = offset][kk = row] from LDS (row pitch 129: conflict-free) and B[kk = row][j = channel] as a
+// coalesced row of dY.  Per-workgroup slabs + ordered reduction (k_stem_reduce).
+constexpr int STEM_TILE = 128, STEM_LD = STEM_TILE + 1;
 __global__ void __launch_bounds__(256) k_stem_bwd_weight(const float* __restrict__ x, const float* __restrict__ dy,
                                                          const int* __restrict__ nbr, long long n_out, int K,
                                                          int cin, float* slabs) {
-  __shared__ float red[4][4 * 16 * 64];
+  __shared__ float As[128 * STEM_LD];          // 66 KB; reused as the cross-wave reduction buffer [4][4*16*64]
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = l & 31, h = l >> 5;
   const long long r_begin = (long long)blockIdx.x * STEM_ROWS_PER_WG;
@@ -870,32 +867,46 @@ __global__ void __launch_bounds__(256) k_stem_bwd_weight(const float* __restrict
     for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[kb][r] = 0.f;
-    for (long long r0 = r_begin + w * 32; r0 < r_end; r0 += 128) {
+    for (long long r0 = r_begin; r0 < r_end; r0 += STEM_TILE) {
+      __syncthreads();
+      {   // thread -> row r = t & 127, offsets k = (t >> 7) + 2 j; 16 table reads, then 16 gathers, in flight at a time
+        const int r = threadIdx.x & (STEM_TILE - 1), kq = threadIdx.x >> 7;
+        const long long row = r0 + r;
+        const bool rv = row < r_end;
+        for (int j0 = 0; j0 < 64; j0 += 16) {
+          int idx[16];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const int k = kq + 2 * (j0 + j);
+            idx[j] = (rv && k < K) ? nbr[(long long)k * n_out + row] : -1;
+          }
+          float a[16];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) a[j] = idx[j] >= 0 ? x[(long long)idx[j] * cin + ci] : 0.f;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) As[(kq + 2 * (j0 + j)) * STEM_LD + r] = a[j];
+        }
+      }
+      __syncthreads();
 #pragma unroll 4
       for (int s = 0; s < 16; ++s) {
-        const long long row = r0 + 2 * s + h;
-        const bool valid = row < r_end;
-        const float b = valid ? dy[row * 32 + i] : 0.f;
+        const int rl = w * 32 + 2 * s + h;
+        const long long row = r0 + rl;
+        const float b = (row < r_end) ? dy[row * 32 + i] : 0.f;
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-          const int k = kb * 32 + i;
-          float a = 0.f;
-          if (valid && k < K) {
-            int idx = nbr[(long long)k * n_out + row];
-            if (idx >= 0) a = x[(long long)idx * cin + ci];
-          }
-          acc[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[kb], 0, 0, 0);
-        }
+        for (int kb = 0; kb < 4; ++kb)
+          acc[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(kb * 32 + i) * STEM_LD + rl], b, acc[kb], 0, 0, 0);
       }
     }
     __syncthreads();
+    float* red = As;
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) red[w][(kb * 16 + r) * 64 + l] = acc[kb][r];
+      for (int r = 0; r < 16; ++r) red[w * 4096 + (kb * 16 + r) * 64 + l] = acc[kb][r];
     __syncthreads();
     for (int e = threadIdx.x; e < 4 * 16 * 64; e += 256) {
-      float v = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+      float v = red[e] + red[4096 + e] + red[8192 + e] + red[12288 + e];
       int ll = e & 63, r = (e >> 6) & 15, kb = e >> 10;
       int k = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ll >> 5);
       if (k < K) slabs[((long long)blockIdx.x * K * cin + (long long)k * cin + ci) * 32 + (ll & 31)] = v;
@@ -903,12 +914,27 @@ __global__ void __launch_bounds__(256) k_stem_bwd_weight(const float* __restrict
   }
 }
 
-__global__ void k_stem_reduce(const float* __restrict__ slabs, int n_slabs, long long mat, float* dw) {
-  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= mat) return;
-  float s = 0.f;
-  for (int b = 0; b < n_slabs; ++b) s += slabs[(long long)b * mat + e];
-  dw[e] = s;
+// ordered sum of the per-workgroup slabs: thread = (element e = t & 63, part = t >> 6) adds slabs part, part + 4, ...
+// (4 loads in flight), the four parts are then added in order
+__global__ void __launch_bounds__(256) k_stem_reduce(const float* __restrict__ slabs, int n_slabs, long long mat,
+                                                     float* dw) {
+  __shared__ float red[4][64];
+  const int el = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const long long e = (long long)blockIdx.x * 64 + el;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (e < mat) {
+    int b = part;
+    for (; b + 12 < n_slabs; b += 16) {
+      s0 += slabs[(long long)b * mat + e];
+      s1 += slabs[(long long)(b + 4) * mat + e];
+      s2 += slabs[(long long)(b + 8) * mat + e];
+      s3 += slabs[(long long)(b + 12) * mat + e];
+    }
+    for (; b < n_slabs; b += 4) s0 += slabs[(long long)b * mat + e];
+  }
+  red[part][el] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (part == 0 && e < mat) dw[e] = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
 }
 
 }  // namespace gcl
@@ -1082,8 +1108,7 @@ int gcl_stem_fwd(const float* x, const float* w, const int32_t* nbr, int64_t n_o
   GCL_CHECK_ARG(x && w && nbr && y, "gcl_stem_fwd: null pointer");
   GCL_CHECK_ARG(cin >= 1 && cin <= 4 && cout == 32 && K >= 1 && K <= STEM_KMAX && n_out > 0,
                 "gcl_stem_fwd: supports Cin <= 4, Cout == 32, K <= 125 (got %d, %d, %d)", cin, cout, K);
-  size_t shm = (size_t)K * cin * 32 * sizeof(float);
-  hipLaunchKernelGGL(k_stem_fwd, dim3((unsigned)cdiv(n_out, 256)), dim3(256), shm, (hipStream_t)stream, x, w, nbr,
+  hipLaunchKernelGGL(k_stem_fwd, dim3((unsigned)cdiv(n_out, 256)), dim3(256), 0, (hipStream_t)stream, x, w, nbr,
                      (long long)n_out, K, cin, y);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
@@ -1102,7 +1127,7 @@ int gcl_stem_bwd_weight(const float* x, const float* dy, const int32_t* nbr, int
   int nwg = (int)cdiv(n_out, STEM_ROWS_PER_WG);
   long long mat = (long long)K * cin * 32;
   hipLaunchKernelGGL(k_stem_bwd_weight, dim3(nwg), dim3(256), 0, st, x, dy, nbr, (long long)n_out, K, cin, scratch);
-  hipLaunchKernelGGL(k_stem_reduce, dim3((unsigned)cdiv(mat, 256)), dim3(256), 0, st, (const float*)scratch, nwg, mat,
+  hipLaunchKernelGGL(k_stem_reduce, dim3((unsigned)cdiv(mat, 64)), dim3(256), 0, st, (const float*)scratch, nwg, mat,
                      dw);
   GCL_CHECK_LAUNCH();
   return GCL_OK;

@@ -98,15 +98,15 @@ __global__ void __launch_bounds__(256) k_bn_reduce(const float* __restrict__ x, 
   }
 }
 
-// ordered (deterministic) sum of the per-workgroup partials of 16 channels by one 256-thread workgroup:
-// thread = (channel ch = t & 15, slice sl = t >> 4) sums partials sl, sl+16, ...; slices are then added in order.
-__device__ __forceinline__ void reduce_partials16(const double* __restrict__ partial, int nwg, int c, int ch,
-                                                  double& s, double& ss) {
-  __shared__ double red[2][16][17];
-  const int sl = threadIdx.x >> 4, cl = threadIdx.x & 15;
+// ordered (deterministic) sum of the per-workgroup partials of 4 channels by one 256-thread workgroup:
+// thread = (channel ch = t & 3, slice sl = t >> 2) sums partials sl, sl+64, ...; the 64 slices are then added in order.
+__device__ __forceinline__ void reduce_partials4(const double* __restrict__ partial, int nwg, int c, int ch,
+                                                 double& s, double& ss) {
+  __shared__ double red[2][64][5];
+  const int sl = threadIdx.x >> 2, cl = threadIdx.x & 3;
   double a = 0, b = 0;
   if (ch < c)
-    for (int w = sl; w < nwg; w += 16) {
+    for (int w = sl; w < nwg; w += 64) {
       a += partial[(long long)w * 2 * c + ch];
       b += partial[(long long)w * 2 * c + c + ch];
     }
@@ -116,7 +116,7 @@ __device__ __forceinline__ void reduce_partials16(const double* __restrict__ par
   s = 0;
   ss = 0;
   if (sl == 0)
-    for (int q = 0; q < 16; ++q) {
+    for (int q = 0; q < 64; ++q) {
       s += red[0][q][cl];
       ss += red[1][q][cl];
     }
@@ -125,10 +125,10 @@ __device__ __forceinline__ void reduce_partials16(const double* __restrict__ par
 __global__ void __launch_bounds__(256) k_bn_stats_final(const double* __restrict__ partial, int nwg, long long n,
                                                         int c, float eps, float momentum, float* running_mean,
                                                         float* running_var, float* mean, float* rstd) {
-  int ch = blockIdx.x * 16 + (threadIdx.x & 15);
+  int ch = blockIdx.x * 4 + (threadIdx.x & 3);
   double s, ss;
-  reduce_partials16(partial, nwg, c, ch, s, ss);
-  if ((threadIdx.x >> 4) != 0 || ch >= c) return;
+  reduce_partials4(partial, nwg, c, ch, s, ss);
+  if ((threadIdx.x >> 2) != 0 || ch >= c) return;
   double m = s / (double)n;
   double var = ss / (double)n - m * m;
   if (var < 0) var = 0;
@@ -160,10 +160,10 @@ __global__ void __launch_bounds__(256) k_bn_tiles_reduce(const float* __restrict
 
 __global__ void __launch_bounds__(256) k_bn_bwd_final(const double* __restrict__ partial, int nwg, int c,
                                                       float* sum_g, float* sum_gx) {
-  int ch = blockIdx.x * 16 + (threadIdx.x & 15);
+  int ch = blockIdx.x * 4 + (threadIdx.x & 3);
   double s, ss;
-  reduce_partials16(partial, nwg, c, ch, s, ss);
-  if ((threadIdx.x >> 4) != 0 || ch >= c) return;
+  reduce_partials4(partial, nwg, c, ch, s, ss);
+  if ((threadIdx.x >> 2) != 0 || ch >= c) return;
   sum_g[ch] = (float)s;
   sum_gx[ch] = (float)ss;
 }
@@ -270,7 +270,7 @@ int gcl_bn_stats(const float* x, int64_t n, int32_t c, float eps, float momentum
   hipLaunchKernelGGL(k_bn_reduce<false>, dim3(nwg), dim3(256), 0, st, x, (const float*)nullptr,
                      (const float*)nullptr, (long long)n, c, (const float*)nullptr, (const float*)nullptr, 0, rows,
                      scratch);
-  hipLaunchKernelGGL(k_bn_stats_final, dim3((unsigned)cdiv(c, 16)), dim3(256), 0, st, (const double*)scratch, nwg,
+  hipLaunchKernelGGL(k_bn_stats_final, dim3((unsigned)cdiv(c, 4)), dim3(256), 0, st, (const double*)scratch, nwg,
                      (long long)n, c, eps, momentum, running_mean, running_var, mean, rstd);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
@@ -286,7 +286,7 @@ int gcl_bn_stats_from_tiles(const float* partial, int64_t n_tiles, int64_t n, in
   hipStream_t st = (hipStream_t)stream;
   int nwg = (int)cdiv(n_tiles, BN_TILES_PER_WG);
   hipLaunchKernelGGL(k_bn_tiles_reduce, dim3(nwg), dim3(256), 0, st, partial, (long long)n_tiles, c, scratch);
-  hipLaunchKernelGGL(k_bn_stats_final, dim3((unsigned)cdiv(c, 16)), dim3(256), 0, st, (const double*)scratch, nwg,
+  hipLaunchKernelGGL(k_bn_stats_final, dim3((unsigned)cdiv(c, 4)), dim3(256), 0, st, (const double*)scratch, nwg,
                      (long long)n, c, eps, momentum, running_mean, running_var, mean, rstd);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
@@ -315,7 +315,7 @@ int gcl_bn_bwd_reduce(const float* x, const float* dy, const float* y, int64_t n
   int nwg = (int)cdiv(n, rows);
   hipLaunchKernelGGL(k_bn_reduce<true>, dim3(nwg), dim3(256), 0, st, x, dy, y, (long long)n, c, mean, rstd, relu,
                      rows, scratch);
-  hipLaunchKernelGGL(k_bn_bwd_final, dim3((unsigned)cdiv(c, 16)), dim3(256), 0, st, (const double*)scratch, nwg, c,
+  hipLaunchKernelGGL(k_bn_bwd_final, dim3((unsigned)cdiv(c, 4)), dim3(256), 0, st, (const double*)scratch, nwg, c,
                      sum_g, sum_gx);
   GCL_CHECK_LAUNCH();
   return GCL_OK;

@@ -182,14 +182,36 @@ class FinestContrastiveLossTrainer:
         loss = self.pos_weight * pos + self.finest_weight * fin + self.neg_weight * neg
         return loss, (pos, fin, neg), F_out
 
+    def _draw_for(self, input_dict):
+        cfg = self.config
+        return draw_selections(len(input_dict["group"]), len(input_dict["sinput_C"]),
+                               cfg.num_pos_per_batch * cfg.batch_size, cfg.num_hn_samples_per_batch * cfg.batch_size)
+
+    def train_steps(self, batches):
+        """The epoch loop (``_train_epoch`` :811-916): yields train_step(batch) for every batch.  The ``np.random``
+        draws of batch i+1 (two permutations of all N rows: several ms of host time) are made by a helper thread
+        while step i is being enqueued; every draw is still made after the previous batch's, so the random stream is
+        consumed in the same order as by a serial loop."""
+        from concurrent.futures import ThreadPoolExecutor
+        it = iter(batches)
+        cur = next(it, None)
+        if cur is None:
+            return
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            fut = pool.submit(self._draw_for, cur)
+            while cur is not None:
+                draws = fut.result()
+                nxt = next(it, None)
+                if nxt is not None:
+                    fut = pool.submit(self._draw_for, nxt)
+                yield self.train_step(cur, draws)
+                cur = nxt
+
     def train_step(self, input_dict, draws=None):
         """One optimizer step on one batch (iter_size == 1).  Returns device scalars (no host sync here)."""
         self.model.train()
         if draws is None:     # host RNG first: overlaps with the GPU work still queued from the previous step
-            cfg = self.config
-            draws = draw_selections(len(input_dict["group"]), len(input_dict["sinput_C"]),
-                                    cfg.num_pos_per_batch * cfg.batch_size,
-                                    cfg.num_hn_samples_per_batch * cfg.batch_size)
+            draws = self._draw_for(input_dict)
         if self.ddp is not None:
             self.ddp.flat_grad.zero_()                     # one memset; gradients stay seated in the flat buffer
         else:

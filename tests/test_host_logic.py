@@ -74,3 +74,22 @@ def test_eval_pair_contract_and_registry():
     assert sum(p.numel() for p in m.parameters()) == 8753408
     fat = load_model("ResUNetFatBN")(1, 32, bn_momentum=0.05, normalize_feature=True, conv1_kernel_size=5, D=3)
     assert fat.conv1_tr.kernel.shape == (32 + 128, 128)
+
+
+def test_prefetched_draws_follow_the_serial_random_stream():
+    """train_steps() draws batch i+1 on a helper thread; the draws must equal those of a serial loop."""
+    import types
+    import numpy as np
+    from gcl_amd.lib.colocation_trainer import FinestContrastiveLossTrainer, draw_selections, make_config
+    tr = object.__new__(FinestContrastiveLossTrainer)
+    tr.config = make_config(batch_size=2, num_pos_per_batch=8, num_hn_samples_per_batch=16)
+    seen = []
+    tr.train_step = types.MethodType(lambda self, b, draws=None: seen.append(draws) or len(seen), tr)
+    batches = [{"group": list(range(40 + i)), "sinput_C": list(range(500 + 7 * i))} for i in range(5)]
+    np.random.seed(3)
+    out = list(tr.train_steps(batches))
+    np.random.seed(3)
+    ref = [draw_selections(len(b["group"]), len(b["sinput_C"]), 16, 32) for b in batches]
+    assert out == [1, 2, 3, 4, 5]
+    for got, want in zip(seen, ref):
+        assert all(np.array_equal(g, w) for g, w in zip(got, want))
