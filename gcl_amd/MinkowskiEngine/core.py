@@ -105,8 +105,8 @@ class KernelMap:
                 seg.append(seg[-1] + (c + ch - 1) // ch * ch)
             total = seg[-1]
             dev = self.nbr.device
-            pair_in = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
-            pair_out = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+            both = torch.empty(2 * max(total, 1), dtype=torch.int32, device=dev)    # adjacent: one fill for both
+            pair_in, pair_out = both[:max(total, 1)], both[max(total, 1):]
             nb = (self.n_out + 1023) // 1024
             scratch = torch.empty(self.K * nb + self.K + 1, dtype=torch.int32, device=dev)
             seg_host = _lib.host_i64(seg)

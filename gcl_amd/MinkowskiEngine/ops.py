@@ -214,6 +214,7 @@ class _SparseConvFn(torch.autograd.Function):
                 if want_stats else (_conv_launch(lib, x, Wk, 0, tbl, n_out, cin, cout, b, ctx.pairs,
                                                  x_amax=ctx.x_amax, w_amax=ctx.w_amax), None)
         ctx.save_for_backward(x, Wk)
+        ctx.set_materialize_grads(False)       # no zero-filled gradient for the (non-differentiable) statistics output
         ctx.kmap, ctx.transpose, ctx.mgr, ctx.w_shape, ctx.has_bias = kmap, transpose, mgr, W.shape, bias is not None
         if stats is None:
             stats = y.new_empty(0)
@@ -224,6 +225,8 @@ class _SparseConvFn(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, dy, _dstats):
         lib = _lib.load()
+        if dy is None:
+            return (None,) * 8
         x, Wk = ctx.saved_tensors
         K, cin, cout = Wk.shape
         kmap, transpose = ctx.kmap, ctx.transpose
@@ -318,10 +321,12 @@ class _BatchNormFn(torch.autograd.Function):
         y = torch.empty_like(x)
         global _LAST_BN_AMAX
         _LAST_BN_AMAX = slot = amax_slot(dev) if PRECISION == "fp16x3" else None
+        # with relu the sign bits of y (1 bit / element) are kept for the backward pass instead of y itself
+        mask = torch.empty(lib.gcl_bn_mask_len(n, c), dtype=torch.int64, device=dev) if relu else None
         _lib.check(lib.gcl_bn_apply(_lib.ptr(x), n, c, _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(weight.detach()),
-                                    _lib.ptr(bias.detach()), _lib.ptr(res), int(relu), _lib.ptr(y), _lib.ptr(slot),
-                                    _lib.stream()), "gcl_bn_apply")
-        ctx.save_for_backward(x, y if relu else None, weight, mean, rstd)
+                                    _lib.ptr(bias.detach()), _lib.ptr(res), int(relu), _lib.ptr(y), _lib.ptr(mask),
+                                    _lib.ptr(slot), _lib.stream()), "gcl_bn_apply")
+        ctx.save_for_backward(x, mask, weight, mean, rstd)
         ctx.relu, ctx.training, ctx.has_res = bool(relu), bool(training), residual is not None
         return y
 
@@ -329,14 +334,14 @@ class _BatchNormFn(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, dy):
         lib = _lib.load()
-        x, y, weight, mean, rstd = ctx.saved_tensors
+        x, mask, weight, mean, rstd = ctx.saved_tensors
         n, c = x.shape
         dev = x.device
         dy = dy.contiguous()
         sum_g = torch.empty(c, dtype=torch.float32, device=dev)
         sum_gx = torch.empty(c, dtype=torch.float32, device=dev)
         scratch = torch.empty(lib.gcl_bn_scratch_len(n, c), dtype=torch.float64, device=dev)
-        _lib.check(lib.gcl_bn_bwd_reduce(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(y), n, c, _lib.ptr(mean), _lib.ptr(rstd),
+        _lib.check(lib.gcl_bn_bwd_reduce(_lib.ptr(x), _lib.ptr(dy), None, _lib.ptr(mask), n, c, _lib.ptr(mean), _lib.ptr(rstd),
                                          int(ctx.relu), _lib.ptr(scratch), _lib.ptr(sum_g), _lib.ptr(sum_gx),
                                          _lib.stream()), "gcl_bn_bwd_reduce")
         dx = torch.empty_like(x)
@@ -346,7 +351,7 @@ class _BatchNormFn(torch.autograd.Function):
             sg, sx = sum_g, sum_gx
         else:                       # running statistics are constants: no batch-statistics terms
             sg = sx = torch.zeros(c, dtype=torch.float32, device=dev)
-        _lib.check(lib.gcl_bn_bwd_apply(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(y), n, c, _lib.ptr(mean), _lib.ptr(rstd),
+        _lib.check(lib.gcl_bn_bwd_apply(_lib.ptr(x), _lib.ptr(dy), None, _lib.ptr(mask), n, c, _lib.ptr(mean), _lib.ptr(rstd),
                                         _lib.ptr(weight.detach()), _lib.ptr(sg), _lib.ptr(sx), int(ctx.relu),
                                         _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(slot), _lib.stream()),
                    "gcl_bn_bwd_apply")
@@ -362,3 +367,38 @@ def batch_norm(x, weight, bias, running_mean, running_var, training, momentum, e
     if _LAST_BN_AMAX is not None:
         tag_amax(y, _LAST_BN_AMAX)
     return y
+
+
+class _RowNormalizeFn(torch.autograd.Function):
+    """y = x / ||x||_2 per row (model/resunet.py:226-230) in one pass; backward in one pass."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.require_gpu()
+        x = x.contiguous()
+        n, c = x.shape
+        y = torch.empty_like(x)
+        norm = torch.empty(n, dtype=torch.float32, device=x.device)
+        _lib.check(lib.gcl_row_normalize_fwd(_lib.ptr(x, torch.float32), n, c, _lib.ptr(y), _lib.ptr(norm),
+                                             _lib.stream()), "gcl_row_normalize_fwd")
+        ctx.save_for_backward(y, norm)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        lib = _lib.load()
+        y, norm = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(y)
+        _lib.check(lib.gcl_row_normalize_bwd(_lib.ptr(y), _lib.ptr(dy, torch.float32), _lib.ptr(norm), y.shape[0],
+                                             y.shape[1], _lib.ptr(dx), _lib.stream()), "gcl_row_normalize_bwd")
+        return dx
+
+
+def l2_normalize_rows(x):
+    """``x / torch.norm(x, p=2, dim=1, keepdim=True)``; widths the kernel does not cover use that expression."""
+    c = x.shape[1]
+    if x.dim() == 2 and x.shape[0] > 0 and 4 <= c <= 256 and (c & (c - 1)) == 0 and x.dtype == torch.float32:
+        return _RowNormalizeFn.apply(x)
+    return x / torch.norm(x, p=2, dim=1, keepdim=True)

@@ -671,8 +671,12 @@ int gcl_kernel_map_pairs(const int32_t* nbr, int32_t K, int64_t n_out, const int
   }
   int nb = (int)cdiv(n_out, PAIR_B);
   if (seg.off[K] > 0) {
-    GCL_CHECK_HIP(hipMemsetAsync(pair_in, 0xFF, (size_t)seg.off[K] * sizeof(int32_t), st));
-    GCL_CHECK_HIP(hipMemsetAsync(pair_out, 0xFF, (size_t)seg.off[K] * sizeof(int32_t), st));
+    if (pair_out == pair_in + seg.off[K]) {   // adjacent lists: one fill
+      GCL_CHECK_HIP(hipMemsetAsync(pair_in, 0xFF, (size_t)seg.off[K] * 2 * sizeof(int32_t), st));
+    } else {
+      GCL_CHECK_HIP(hipMemsetAsync(pair_in, 0xFF, (size_t)seg.off[K] * sizeof(int32_t), st));
+      GCL_CHECK_HIP(hipMemsetAsync(pair_out, 0xFF, (size_t)seg.off[K] * sizeof(int32_t), st));
+    }
   }
   hipLaunchKernelGGL(k_pairs_count, dim3(nb, K), dim3(256), 0, st, nbr, (long long)n_out, nb, scratch);
   hipLaunchKernelGGL(k_pairs_scan, dim3(K), dim3(256), 0, st, scratch, nb);

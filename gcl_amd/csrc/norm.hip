@@ -17,12 +17,23 @@ static inline int bn_rows_per_wg(long long n, int c) {
   return rows;
 }
 
+// ReLU sign bits of the forward output: element quad e (float4 granularity) -> bit (e & 63) of the four words
+// mask[(e >> 6) * 4 + component] (written by k_bn_apply with one ballot per component; every kernel below maps quad e
+// to lane e & 63, so a wave reads four wave-uniform words instead of 1 KB of y).  Returned as a float4 of 1 / 0.
+__device__ __forceinline__ float4 mask_as_y(const unsigned long long* __restrict__ mask, long long e) {
+  const unsigned long long* m = mask + (e >> 6) * 4;
+  const int b = (int)(e & 63);
+  return make_float4((float)((m[0] >> b) & 1), (float)((m[1] >> b) & 1), (float)((m[2] >> b) & 1),
+                     (float)((m[3] >> b) & 1));
+}
+
 // thread t -> channel quad cq = t % (c/4), row lane rl = t / (c/4)
 template <bool BWD>
 __global__ void __launch_bounds__(256) k_bn_reduce(const float* __restrict__ x, const float* __restrict__ dy,
                                                    const float* __restrict__ y, long long n, int c,
                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                   int relu, int rows_per_wg, double* partial) {
+                                                   int relu, const unsigned long long* __restrict__ mask,
+                                                   int rows_per_wg, double* partial) {
   __shared__ double red[2][256][4];
   const int cq_n = c >> 2;
   const int cq = threadIdx.x % cq_n, rl = threadIdx.x / cq_n, rstep = 256 / cq_n;
@@ -60,8 +71,13 @@ __global__ void __launch_bounds__(256) k_bn_reduce(const float* __restrict__ x, 
       ga = reinterpret_cast<const float4*>(dy + r * c)[cq];
       gb = reinterpret_cast<const float4*>(dy + q * c)[cq];
       if (relu) {
-        ya = reinterpret_cast<const float4*>(y + r * c)[cq];
-        yb = reinterpret_cast<const float4*>(y + q * c)[cq];
+        if (mask) {
+          ya = mask_as_y(mask, r * cq_n + cq);
+          yb = mask_as_y(mask, q * cq_n + cq);
+        } else {
+          ya = reinterpret_cast<const float4*>(y + r * c)[cq];
+          yb = reinterpret_cast<const float4*>(y + q * c)[cq];
+        }
       }
     }
     BN_ACC(xa, ga, ya)
@@ -72,7 +88,7 @@ __global__ void __launch_bounds__(256) k_bn_reduce(const float* __restrict__ x, 
     float4 ga = z4, ya = z4;
     if (BWD) {
       ga = reinterpret_cast<const float4*>(dy + r * c)[cq];
-      if (relu) ya = reinterpret_cast<const float4*>(y + r * c)[cq];
+      if (relu) ya = mask ? mask_as_y(mask, r * cq_n + cq) : reinterpret_cast<const float4*>(y + r * c)[cq];
     }
     BN_ACC(xa, ga, ya)
   }
@@ -187,7 +203,8 @@ __global__ void __launch_bounds__(256) k_bn_apply(const float* __restrict__ x, l
                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
                                                   const float* __restrict__ weight, const float* __restrict__ bias,
                                                   const float* __restrict__ residual, int relu,
-                                                  float* __restrict__ y, int* amax_bits) {
+                                                  float* __restrict__ y, unsigned long long* __restrict__ mask,
+                                                  int* amax_bits) {
   const int cq_n = c >> 2;
   float am = 0.f;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total4;
@@ -210,6 +227,14 @@ __global__ void __launch_bounds__(256) k_bn_apply(const float* __restrict__ x, l
     }
     reinterpret_cast<float4*>(y)[e] = o;
     am = amax4(am, o);
+    if (mask) {   // e - lane is a multiple of 64 (grid stride and block size are): one ballot per component
+      unsigned long long b0 = __ballot(o.x > 0.f), b1 = __ballot(o.y > 0.f), b2 = __ballot(o.z > 0.f),
+                         b3 = __ballot(o.w > 0.f);
+      if ((threadIdx.x & 63) == 0) {
+        unsigned long long* m = mask + (e >> 6) * 4;
+        m[0] = b0; m[1] = b1; m[2] = b2; m[3] = b3;
+      }
+    }
   }
   if (amax_bits) publish_amax(am, amax_bits);
 }
@@ -221,6 +246,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const float* __restrict__ 
                                                       const float* __restrict__ weight,
                                                       const float* __restrict__ sum_g,
                                                       const float* __restrict__ sum_gx, int relu,
+                                                      const unsigned long long* __restrict__ mask,
                                                       float* __restrict__ dx, float* __restrict__ dres,
                                                       int* amax_bits) {
   const int cq_n = c >> 2;
@@ -234,7 +260,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const float* __restrict__ 
     float4 xv = reinterpret_cast<const float4*>(x)[e];
     float4 g = reinterpret_cast<const float4*>(dy)[e];
     if (relu) {
-      float4 yv = reinterpret_cast<const float4*>(y)[e];
+      float4 yv = mask ? mask_as_y(mask, e) : reinterpret_cast<const float4*>(y)[e];
       g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
       g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
     }
@@ -248,6 +274,37 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const float* __restrict__ 
     if (dres) reinterpret_cast<float4*>(dres)[e] = g;
   }
   if (amax_bits) publish_amax(am, amax_bits);
+}
+
+// ---- row-wise L2 normalisation  y = x / ||x||_2  (model/resunet.py:226-230) -------------------------------------
+// c/4 lanes per row (power of two <= 64), float4 per lane.  No epsilon, like the reference: an all-zero row gives NaN.
+// backward: dx = (dy - y (y . dy)) / ||x||
+template <bool BWD>
+__global__ void __launch_bounds__(256) k_row_normalize(const float* __restrict__ a, const float* __restrict__ dy,
+                                                       const float* __restrict__ norm_in, long long n, int c,
+                                                       float* __restrict__ out, float* __restrict__ norm_out) {
+  const int lpr = c >> 2;
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long row = e / lpr;
+  const bool ok = row < n;
+  float4 v = make_float4(0, 0, 0, 0), g = make_float4(0, 0, 0, 0);
+  if (ok) {
+    v = reinterpret_cast<const float4*>(a)[e];
+    if (BWD) g = reinterpret_cast<const float4*>(dy)[e];
+  }
+  float s = BWD ? (v.x * g.x + v.y * g.y + v.z * g.z + v.w * g.w) : (v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
+  for (int o = 1; o < lpr; o <<= 1) s += __shfl_xor(s, o);
+  if (!ok) return;
+  float4 o4;
+  if (!BWD) {
+    const float nr = sqrtf(s);
+    o4 = make_float4(v.x / nr, v.y / nr, v.z / nr, v.w / nr);
+    if ((e % lpr) == 0) norm_out[row] = nr;
+  } else {
+    const float nr = norm_in[row];
+    o4 = make_float4((g.x - v.x * s) / nr, (g.y - v.y * s) / nr, (g.z - v.z * s) / nr, (g.w - v.w * s) / nr);
+  }
+  reinterpret_cast<float4*>(out)[e] = o4;
 }
 
 static bool bn_c_ok(int c) { return c >= 4 && c % 4 == 0 && (256 % (c / 4)) == 0; }
@@ -268,8 +325,8 @@ int gcl_bn_stats(const float* x, int64_t n, int32_t c, float eps, float momentum
   const int rows = bn_rows_per_wg(n, c);
   int nwg = (int)cdiv(n, rows);
   hipLaunchKernelGGL(k_bn_reduce<false>, dim3(nwg), dim3(256), 0, st, x, (const float*)nullptr,
-                     (const float*)nullptr, (long long)n, c, (const float*)nullptr, (const float*)nullptr, 0, rows,
-                     scratch);
+                     (const float*)nullptr, (long long)n, c, (const float*)nullptr, (const float*)nullptr, 0,
+                     (const unsigned long long*)nullptr, rows, scratch);
   hipLaunchKernelGGL(k_bn_stats_final, dim3((unsigned)cdiv(c, 4)), dim3(256), 0, st, (const double*)scratch, nwg,
                      (long long)n, c, eps, momentum, running_mean, running_var, mean, rstd);
   GCL_CHECK_LAUNCH();
@@ -293,45 +350,73 @@ int gcl_bn_stats_from_tiles(const float* partial, int64_t n_tiles, int64_t n, in
 }
 
 int gcl_bn_apply(const float* x, int64_t n, int32_t c, const float* mean, const float* rstd, const float* weight,
-                 const float* bias, const float* residual, int32_t relu, float* y, int32_t* y_amax, void* stream) {
+                 const float* bias, const float* residual, int32_t relu, float* y, uint64_t* relu_mask,
+                 int32_t* y_amax, void* stream) {
   GCL_CHECK_ARG(x && mean && rstd && weight && bias && y, "gcl_bn_apply: null pointer");
   GCL_CHECK_ARG(n > 0 && c >= 4 && c % 4 == 0, "gcl_bn_apply: unsupported shape");
   long long total4 = n * (c / 4);
   long long g = cdiv(total4, 256);
   if (g > 4096) g = 4096;
   hipLaunchKernelGGL(k_bn_apply, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, total4, c, mean, rstd,
-                     weight, bias, residual, relu, y, y_amax);
+                     weight, bias, residual, relu, y, (unsigned long long*)(relu ? relu_mask : nullptr), y_amax);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }
 
-int gcl_bn_bwd_reduce(const float* x, const float* dy, const float* y, int64_t n, int32_t c, const float* mean,
-                      const float* rstd, int32_t relu, double* scratch, float* sum_g, float* sum_gx, void* stream) {
+int64_t gcl_bn_mask_len(int64_t n, int32_t c) { return cdiv(n * (c / 4), 64) * 4; }
+
+int gcl_bn_bwd_reduce(const float* x, const float* dy, const float* y, const uint64_t* relu_mask, int64_t n,
+                      int32_t c, const float* mean, const float* rstd, int32_t relu, double* scratch, float* sum_g,
+                      float* sum_gx, void* stream) {
   GCL_CHECK_ARG(x && dy && mean && rstd && scratch && sum_g && sum_gx, "gcl_bn_bwd_reduce: null pointer");
-  GCL_CHECK_ARG(!relu || y, "gcl_bn_bwd_reduce: y is required when relu is set");
+  GCL_CHECK_ARG(!relu || y || relu_mask, "gcl_bn_bwd_reduce: y or relu_mask is required when relu is set");
   GCL_CHECK_ARG(n > 0 && bn_c_ok(c), "gcl_bn_bwd_reduce: unsupported shape n=%lld c=%d", (long long)n, c);
   hipStream_t st = (hipStream_t)stream;
   const int rows = bn_rows_per_wg(n, c);
   int nwg = (int)cdiv(n, rows);
   hipLaunchKernelGGL(k_bn_reduce<true>, dim3(nwg), dim3(256), 0, st, x, dy, y, (long long)n, c, mean, rstd, relu,
-                     rows, scratch);
+                     (const unsigned long long*)relu_mask, rows, scratch);
   hipLaunchKernelGGL(k_bn_bwd_final, dim3((unsigned)cdiv(c, 4)), dim3(256), 0, st, (const double*)scratch, nwg, c,
                      sum_g, sum_gx);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }
 
-int gcl_bn_bwd_apply(const float* x, const float* dy, const float* y, int64_t n, int32_t c, const float* mean,
-                     const float* rstd, const float* weight, const float* sum_g, const float* sum_gx, int32_t relu,
-                     float* dx, float* dres, int32_t* dx_amax, void* stream) {
+int gcl_bn_bwd_apply(const float* x, const float* dy, const float* y, const uint64_t* relu_mask, int64_t n, int32_t c,
+                     const float* mean, const float* rstd, const float* weight, const float* sum_g,
+                     const float* sum_gx, int32_t relu, float* dx, float* dres, int32_t* dx_amax, void* stream) {
   GCL_CHECK_ARG(x && dy && mean && rstd && weight && sum_g && sum_gx && dx, "gcl_bn_bwd_apply: null pointer");
-  GCL_CHECK_ARG(!relu || y, "gcl_bn_bwd_apply: y is required when relu is set");
+  GCL_CHECK_ARG(!relu || y || relu_mask, "gcl_bn_bwd_apply: y or relu_mask is required when relu is set");
   GCL_CHECK_ARG(n > 0 && c >= 4 && c % 4 == 0, "gcl_bn_bwd_apply: unsupported shape");
   long long total4 = n * (c / 4);
   long long g = cdiv(total4, 256);
   if (g > 4096) g = 4096;
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, dy, y, total4, c,
-                     1.0f / (float)n, mean, rstd, weight, sum_g, sum_gx, relu, dx, dres, dx_amax);
+                     1.0f / (float)n, mean, rstd, weight, sum_g, sum_gx, relu, (const unsigned long long*)relu_mask, dx, dres,
+                     dx_amax);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+static bool rownorm_c_ok(int c) { return c >= 4 && c <= 256 && (c & (c - 1)) == 0; }
+
+int gcl_row_normalize_fwd(const float* x, int64_t n, int32_t c, float* y, float* norm, void* stream) {
+  GCL_CHECK_ARG(x && y && norm, "gcl_row_normalize_fwd: null pointer");
+  GCL_CHECK_ARG(n > 0 && rownorm_c_ok(c), "gcl_row_normalize_fwd: c must be a power of two in [4, 256] (got %d)", c);
+  long long total = n * (c / 4);
+  hipLaunchKernelGGL(k_row_normalize<false>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     (const float*)nullptr, (const float*)nullptr, (long long)n, c, y, norm);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int gcl_row_normalize_bwd(const float* y, const float* dy, const float* norm, int64_t n, int32_t c, float* dx,
+                          void* stream) {
+  GCL_CHECK_ARG(y && dy && norm && dx, "gcl_row_normalize_bwd: null pointer");
+  GCL_CHECK_ARG(n > 0 && rownorm_c_ok(c), "gcl_row_normalize_bwd: c must be a power of two in [4, 256] (got %d)", c);
+  long long total = n * (c / 4);
+  hipLaunchKernelGGL(k_row_normalize<true>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, y, dy,
+                     norm, (long long)n, c, dx, (float*)nullptr);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }

@@ -74,7 +74,7 @@ class ResUNet2(ME.MinkowskiNetwork):
             out = ME.cat(out, skips[l - 1])
         out = self.final(MEF.relu(self.conv1_tr(out)))
         if self.normalize_feature:
-            return ME.SparseTensor(out.F / torch.norm(out.F, p=2, dim=1, keepdim=True),
+            return ME.SparseTensor(ME.ops.l2_normalize_rows(out.F),        # = out.F / torch.norm(out.F, 2, 1, True)
                                    coordinate_map_key=out.coordinate_map_key,
                                    coordinate_manager=out.coordinate_manager)
         return out

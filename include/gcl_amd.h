@@ -15,6 +15,7 @@
  *           gcl_stem_fwd / gcl_stem_bwd_weight       (Cin <= 4 first layer, model/resunet.py:38-45)
  *   ME.MinkowskiBatchNorm + MEF.relu + `out += residual`   model/common.py:4-6, model/residual_block.py:37-53
  *        -> gcl_bn_stats, gcl_bn_apply, gcl_bn_bwd_reduce, gcl_bn_bwd_apply
+ *   out.F / torch.norm(out.F, p=2, dim=1, keepdim=True)   model/resunet.py:226-230  -> gcl_row_normalize_fwd/bwd
  *   finest_contrastive_loss                          lib/colocation_trainer.py:430-535
  *        -> gcl_group_loss_fwd/bwd, gcl_nn_rowmin (pdist + min, lib/metrics.py:22-25),
  *           gcl_neg_mask, gcl_neg_loss_fwd/bwd
@@ -190,6 +191,9 @@ int gcl_stem_bwd_weight(const float* x, const float* dy, const int32_t* nbr, int
  *                  In eval mode the host passes running stats as mean / rstd.
  *   backward:      g = dy * (relu ? y > 0 : 1);  gcl_bn_bwd_reduce -> sum_g[c], sum_gx[c] (xhat-weighted);
  *                  gcl_bn_bwd_apply -> dx, (dres = g).
+ *   relu_mask (optional, uint64[gcl_bn_mask_len(n, c)]): with relu, gcl_bn_apply also writes the sign bits of y
+ *                  (1 bit per element); the backward passes then take the mask instead of re-reading y (pass
+ *                  y = NULL), which removes a third of their HBM traffic.
  *   y_amax / dx_amax (optional, ZERO-INITIALISED amax slots): the apply passes also publish gcl_amax of the tensor they
  *                  write, so the fp16x3 convolution that consumes it needs no extra pass over it.
  * ---------------------------------------------------------------------------------------------- */
@@ -203,14 +207,21 @@ int gcl_bn_stats_from_tiles(const float* partial, int64_t n_tiles, int64_t n, in
                             void* stream);
 int gcl_bn_apply(const float* x, int64_t n, int32_t c, const float* mean, const float* rstd,
                  const float* weight, const float* bias, const float* residual, int32_t relu,
-                 float* y, int32_t* y_amax, void* stream);
-int gcl_bn_bwd_reduce(const float* x, const float* dy, const float* y, int64_t n, int32_t c,
-                      const float* mean, const float* rstd, int32_t relu, double* scratch,
+                 float* y, uint64_t* relu_mask, int32_t* y_amax, void* stream);
+int64_t gcl_bn_mask_len(int64_t n, int32_t c);                  /* uint64 words */
+int gcl_bn_bwd_reduce(const float* x, const float* dy, const float* y, const uint64_t* relu_mask, int64_t n,
+                      int32_t c, const float* mean, const float* rstd, int32_t relu, double* scratch,
                       float* sum_g, float* sum_gx, void* stream);
-int gcl_bn_bwd_apply(const float* x, const float* dy, const float* y, int64_t n, int32_t c,
+int gcl_bn_bwd_apply(const float* x, const float* dy, const float* y, const uint64_t* relu_mask, int64_t n, int32_t c,
                      const float* mean, const float* rstd, const float* weight,
                      const float* sum_g, const float* sum_gx, int32_t relu,
                      float* dx, float* dres, int32_t* dx_amax, void* stream);
+
+/* Row-wise L2 normalisation of the output features, y = x / ||x||_2 (model/resunet.py:226-230; no epsilon, as there).
+ * norm[n] keeps the row norms for the backward pass: dx = (dy - y (y . dy)) / norm.  c: power of two in [4, 256]. */
+int gcl_row_normalize_fwd(const float* x, int64_t n, int32_t c, float* y, float* norm, void* stream);
+int gcl_row_normalize_bwd(const float* y, const float* dy, const float* norm, int64_t n, int32_t c, float* dx,
+                          void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GCL loss (lib/colocation_trainer.py:430-535, square_loss path) and feature-space 1-NN.

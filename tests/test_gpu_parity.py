@@ -682,3 +682,21 @@ def test_fused_amax_tags_equal_separate_pass():
     with torch.no_grad():
         ws[7].mul_(3.0)
     assert ops.known_amax(ws[7]) is None and torch.equal(val(ops.tensor_amax(lib, ws[7])), amax_ref(ws[7]))
+
+
+@pytest.mark.parametrize("n,c", [(5000, 32), (777, 64), (33, 16)])
+def test_row_normalize_matches_torch_expression(n, c):
+    """gcl_row_normalize_fwd/bwd == out.F / torch.norm(out.F, p=2, dim=1, keepdim=True) (model/resunet.py:226-230);
+    tolerance 2e-6 rel-L2 (fp32 summation order differs)."""
+    from gcl_amd.MinkowskiEngine import ops
+    g = torch.Generator().manual_seed(n + c)
+    x = torch.randn(n, c, generator=g).to(DEV).requires_grad_(True)
+    w = torch.randn(n, c, generator=g).to(DEV)
+    y = ops.l2_normalize_rows(x)
+    (y * w).sum().backward()
+    gx, x.grad = x.grad.clone(), None
+    xr = x.detach().double().requires_grad_(True)
+    yr = xr / torch.norm(xr, p=2, dim=1, keepdim=True)
+    (yr * w.double()).sum().backward()
+    assert rel_l2(y.detach().cpu().numpy(), yr.detach().cpu().numpy()) < 2e-6
+    assert rel_l2(gx.cpu().numpy(), xr.grad.cpu().numpy()) < 2e-6
