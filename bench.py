@@ -181,8 +181,12 @@ def main():
     roofline = None
     if prof:
         agg = {}
+        log("per-launch timings of the last timed step (events on the launch stream):")
         for name, e0, e1, pairs, cin, cout in prof:
             ms = e0.elapsed_time(e1)
+            log(f"  {name:36s} pairs={pairs:9d} {cin:3d}->{cout:3d}  {ms * 1e3:7.1f} us  "
+                f"{2.0 * pairs * cin * cout / (ms * 1e-3) / 1e12:6.1f} TFLOP/s  "
+                f"{(pairs * (cin + cout) * 4.0 + pairs * 8.0) / (ms * 1e-3) / 1e9:7.0f} GB/s")
             a = agg.setdefault(name, [0.0, 0.0, 0.0, 0])
             a[0] += ms
             a[1] += pairs * (cin + cout) * 4.0 + pairs * 8.0          # algorithmic bytes of a launch

@@ -166,10 +166,10 @@ def _conv_launch(lib, x, Wk, mode, table, n_out, cin, cout, bias, pairs=0, want_
     stats = None
     if want_stats and prec != 0:
         stats = torch.empty(((n_out + 31) // 32, 2, cout), dtype=torch.float32, device=x.device)
-    nb = 4 if cout % 128 == 0 else (2 if cout % 64 == 0 else 1)
-    if prec == 3:
-        nb = min(nb, 2)
-    name = f"k_conv_fwd<{nb}>" if prec == 0 else f"k_conv_fwd_split<{nb},{prec}>"
+    name = None
+    if PROFILE is not None:
+        nb = lib.gcl_conv_fwd_nb(n_out, cout, prec)
+        name = f"k_conv_fwd<{nb}>" if prec == 0 else f"k_conv_fwd_split<{nb},{prec}>"
     with _Timed(name, pairs, cin, cout):
         _lib.check(lib.gcl_conv_fwd(_lib.ptr(x, torch.float32), _lib.ptr(wp), prec, _lib.ptr(x_amax),
                                     _lib.ptr(w_amax), _lib.ptr(tbl), _lib.ptr(order), _lib.ptr(tile_mask), n_out, K,

@@ -388,10 +388,22 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
   __shared__ unsigned wmask[4];
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   const int i = l & 31, h = l >> 5;
-  const long long tile = (long long)xcd_tile(blockIdx.x, gridDim.x, swizzle) * 4 + w;
+  // swizzle 2 (1-D grid): the cout / (32 NB) column blocks that gather the SAME 128 rows get consecutive slots of one
+  // XCD (workgroups are dealt round-robin over the 8 XCDs) and share its L2
+  unsigned bxx = blockIdx.x, byy = blockIdx.y;
+  if (swizzle == 2) {
+    const unsigned ncb = (unsigned)(cout / (32 * NB)), nrw = (unsigned)((n_out + CONV_ROWS - 1) / CONV_ROWS);
+    const unsigned xcd = bxx & 7u, slot = bxx >> 3;
+    byy = slot % ncb;
+    bxx = (slot / ncb) * 8u + xcd;
+    if (bxx >= nrw) return;   // whole workgroup, before any barrier
+  } else {
+    bxx = xcd_tile(bxx, gridDim.x, swizzle);
+  }
+  const long long tile = (long long)bxx * 4 + w;
   const long long row0 = tile * 32;
   const bool active = row0 < n_out;
-  const int nb0 = blockIdx.y * NB;
+  const int nb0 = byy * NB;
   const int TNB = cout >> 5, CC = cin >> 5;
   const int p = l & 7, rsub = l >> 3;
 
@@ -682,7 +694,7 @@ __global__ void __launch_bounds__(256) k_conv_bwd_weight_split(const float* __re
                                                                const int* __restrict__ pair_b, SegOffW seg, int K,
                                                                int ca, int cb, long long n_chunks, int per,
                                                                float* slabs, const int* __restrict__ a_amax,
-                                                               const int* __restrict__ b_amax) {
+                                                               const int* __restrict__ b_amax, int n_wg_x, int n_tiles) {
   constexpr int NBI = TCA / 32, NBJ = TCB / 32;
   constexpr int PA = TCA / 4, PB = TCB / 4;         // 16-byte pieces per row
   constexpr int RA = 64 / PA, RB = 64 / PB;          // rows per load pass
@@ -694,9 +706,21 @@ __global__ void __launch_bounds__(256) k_conv_bwd_weight_split(const float* __re
   float (*Bs)[32][TCB] = reinterpret_cast<float (*)[32][TCB]>(lds_all + 4 * 32 * TCA);
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = l & 31, h = l >> 5;
+  // XCD-aware launch order (1-D grid): workgroups are dealt round-robin to the 8 XCDs, so the n_tiles channel tiles
+  // that re-read the SAME pair range are given consecutive slots of ONE XCD and share its L2
+  int bx, by;
+  if (n_tiles > 0) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    by = slot % n_tiles;
+    bx = (slot / n_tiles) * 8 + xcd;
+    if (bx >= n_wg_x) return;
+  } else {
+    bx = blockIdx.x;
+    by = blockIdx.y;
+  }
   const int tiles_b = cb / TCB;
-  const int ca0 = (blockIdx.y / tiles_b) * TCA, cb0 = (blockIdx.y % tiles_b) * TCB;
-  const long long c0 = (long long)blockIdx.x * per;
+  const int ca0 = (by / tiles_b) * TCA, cb0 = (by % tiles_b) * TCB;
+  const long long c0 = (long long)bx * per;
   const long long c1 = (c0 + per < n_chunks) ? c0 + per : n_chunks;
   if (c0 >= c1) return;   // uniform over the workgroup
 
@@ -717,7 +741,7 @@ __global__ void __launch_bounds__(256) k_conv_bwd_weight_split(const float* __re
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[a][b][r] *= out_scale;
     }
-    bwd_weight_flush<TCA, TCB>(acc, lds_all, slabs + (long long)(blockIdx.x + k) * ((long long)ca * cb), ca0, cb0, cb);
+    bwd_weight_flush<TCA, TCB>(acc, lds_all, slabs + (long long)(bx + k) * ((long long)ca * cb), ca0, cb0, cb);
   };
   auto load_pairs = [&](long long c, int& ia, int& ib) {
     ia = -1;
@@ -802,9 +826,31 @@ __global__ void __launch_bounds__(256) k_bwd_weight_reduce(const float* __restri
   if (seg.off[k + 1] > seg.off[k]) {
     long long first = seg.off[k] / GCL_PAIR_CHUNK, last = seg.off[k + 1] / GCL_PAIR_CHUNK - 1;
     long long lo = first / per, hi = last / per;
-    for (long long bx = lo; bx <= hi; ++bx) s += slabs[(bx + k) * mat + e];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;     // four slab loads in flight; fixed summation order
+    long long bx = lo;
+    for (; bx + 3 <= hi; bx += 4) {
+      s0 += slabs[(bx + k) * mat + e];
+      s1 += slabs[(bx + 1 + k) * mat + e];
+      s2 += slabs[(bx + 2 + k) * mat + e];
+      s3 += slabs[(bx + 3 + k) * mat + e];
+    }
+    for (; bx <= hi; ++bx) s0 += slabs[(bx + k) * mat + e];
+    s = (s0 + s1) + (s2 + s3);
   }
   dw[(long long)k * mat + e] = s;
+}
+
+// columns per wave (32 NB) of a forward launch: 128 when Cout allows, but 64 when the 128-wide launch would have
+// 513..1024 workgroups -- a second, poorly filled round on 256 CUs x 2 resident workgroups -- where twice as many
+// half-width workgroups (3 resident per CU) finish earlier (measured -7 % on the 128->128 / 256->256 layers of the
+// KITTI batch).  GCL_NB_POLICY=0 disables the rule.
+static int conv_fwd_nb(long long n_out, int cout, int prec) {
+  int nb = (cout % 128 == 0) ? 4 : ((cout % 64 == 0) ? 2 : 1);
+  static const int pol = [] { const char* s = getenv("GCL_NB_POLICY"); return s ? atoi(s) : 1; }();
+  if (prec == 3 && nb == 4) nb = 2;   // three planes: the double-buffered weight block of NB = 4 would not fit twice
+  long long wgs = cdiv(n_out, 128) * (cout / (32 * nb));
+  if (prec != 0 && pol == 1 && nb == 4 && wgs > 512 && wgs <= 1024) nb = 2;
+  return nb;
 }
 
 static int bwd_weight_wgs(long long n_chunks) {
@@ -1005,6 +1051,11 @@ int gcl_pack_weights(const float* w, int32_t K, int32_t cin, int32_t cout, int32
   return GCL_OK;
 }
 
+int32_t gcl_conv_fwd_nb(int64_t n_out, int32_t cout, int32_t prec) {
+  if (n_out <= 0 || cout <= 0 || cout % 32) return 0;
+  return conv_fwd_nb(n_out, cout, prec);
+}
+
 int gcl_conv_fwd(const float* x, const void* wp, int32_t prec, const int32_t* x_amax, const int32_t* w_amax,
                  const int32_t* tbl, const int32_t* order, const int32_t* tile_mask, int64_t n_out, int32_t K,
                  int32_t cin, int32_t cout, const float* bias, float* y, float* stats, void* stream) {
@@ -1023,14 +1074,18 @@ int gcl_conv_fwd(const float* x, const void* wp, int32_t prec, const int32_t* x_
     return e ? atoi(e) : 0;
   }();
   unsigned gx = (unsigned)cdiv(n_out, CONV_ROWS);
-  const int nb = (cout % 128 == 0) ? 4 : ((cout % 64 == 0) ? 2 : 1);
+  const int nb = conv_fwd_nb(n_out, cout, prec);
   dim3 grid(gx, cout / (32 * nb));
+  static const int colgroup = [] { const char* e = getenv("GCL_FWD_COLGROUP"); return e ? atoi(e) : 1; }();
+  const bool cg = colgroup && grid.y > 1 && !swz;
+  dim3 sgrid = cg ? dim3((unsigned)(cdiv(gx, 8) * 8 * grid.y)) : grid;
+  const int sswz = cg ? 2 : swz;
 #define LAUNCH_F32(NBV)                                                                                          \
   hipLaunchKernelGGL(k_conv_fwd<NBV>, grid, dim3(256), 0, st, x, (const float4*)wp, tbl, order, tile_mask,       \
                      (long long)n_out, K, cin, cout, bias, y, swz)
 #define LAUNCH_SPLIT(NBV, PLV)                                                                                   \
-  hipLaunchKernelGGL((k_conv_fwd_split<NBV, PLV>), grid, dim3(256), 0, st, x, (const u32x4*)wp, tbl, order,      \
-                     tile_mask, (long long)n_out, K, cin, cout, bias, y, swz, stats, x_amax, w_amax)
+  hipLaunchKernelGGL((k_conv_fwd_split<NBV, PLV>), sgrid, dim3(256), 0, st, x, (const u32x4*)wp, tbl, order,     \
+                     tile_mask, (long long)n_out, K, cin, cout, bias, y, sswz, stats, x_amax, w_amax)
 #define LAUNCH_SPLIT_NB(PLV)                                                             \
   {                                                                                      \
     if (nb == 4) LAUNCH_SPLIT(4, PLV); else if (nb == 2) LAUNCH_SPLIT(2, PLV); else LAUNCH_SPLIT(1, PLV); \
@@ -1078,9 +1133,12 @@ int gcl_conv_bwd_weight(const float* a, const float* b, const int32_t* pair_a, c
   if (nc > 0) {
     int tca = (ca % 64 == 0) ? 64 : 32, tcb = (cb % 64 == 0) ? 64 : 32;
     dim3 grid(W, (ca / tca) * (cb / tcb));
+    static const int dwswz = [] { const char* s = getenv("GCL_DW_SWIZZLE"); return s ? atoi(s) : 1; }();
+    const int stiles = (dwswz && grid.y > 1) ? (int)grid.y : 0;
+    dim3 sgrid = stiles ? dim3((unsigned)(cdiv(W, 8) * 8 * stiles)) : grid;
 #define LAUNCH_BWS(TA, TB, PLV)                                                                                     \
-  hipLaunchKernelGGL((k_conv_bwd_weight_split<TA, TB, PLV>), grid, dim3(256), 0, st, a, b, pair_a, pair_b, seg, K, \
-                     ca, cb, nc, per, scratch, a_amax, b_amax)
+  hipLaunchKernelGGL((k_conv_bwd_weight_split<TA, TB, PLV>), sgrid, dim3(256), 0, st, a, b, pair_a, pair_b, seg, K, \
+                     ca, cb, nc, per, scratch, a_amax, b_amax, W, stiles)
 #define LAUNCH_BW(TA, TB)                                                                                          \
   {                                                                                                                \
     if (prec == 0)                                                                                                 \

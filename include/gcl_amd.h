@@ -162,6 +162,9 @@ int gcl_amax_multi(const float* const* ptrs, const int64_t* sizes, int32_t n_ten
                    void* stream);
 int gcl_pack_weights(const float* w, int32_t K, int32_t cin, int32_t cout, int32_t mode, int32_t prec,
                      const int32_t* w_amax, void* wp, void* stream);
+/* NB of the kernel instance gcl_conv_fwd will launch for this shape (a wave covers 32 NB output columns): 4, 2 or 1;
+ * diagnostic (profile labels). */
+int32_t gcl_conv_fwd_nb(int64_t n_out, int32_t cout, int32_t prec);
 int gcl_conv_fwd(const float* x, const void* wp, int32_t prec, const int32_t* x_amax, const int32_t* w_amax,
                  const int32_t* tbl, const int32_t* order, const int32_t* tile_mask, int64_t n_out, int32_t K,
                  int32_t cin, int32_t cout, const float* bias, float* y, float* stats, void* stream);
