@@ -21,11 +21,12 @@ for _ in range(3):
 torch.cuda.synchronize()
 pr = cProfile.Profile()
 pr.enable()
-for _ in range(10):
-    tr.train_step(dbatch)
+import itertools
+for _ in tr.train_steps(itertools.repeat(dbatch, 10)):
+    pass
 pr.disable()
 torch.cuda.synchronize()
 for key in ("tottime", "cumulative"):
     s = io.StringIO()
-    pstats.Stats(pr, stream=s).sort_stats(key).print_stats(30)
-    print(s.getvalue()[:6000])
+    pstats.Stats(pr, stream=s).sort_stats(key).print_stats(45)
+    print(s.getvalue()[:9000])
