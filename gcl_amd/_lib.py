@@ -58,8 +58,8 @@ SIGNATURES = {
     "gcl_bn_bwd_apply": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "gcl_row_normalize_fwd": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
     "gcl_row_normalize_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
-    "gcl_group_loss_fwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp]),
-    "gcl_group_loss_bwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),
+    "gcl_group_loss_fwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _vp]),
+    "gcl_group_loss_bwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "gcl_nn_rowmin": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "gcl_neg_mask": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp]),
     "gcl_neg_loss_fwd": (_i32, [_vp, _vp, _i32, _f32, _vp, _vp]),

@@ -13,19 +13,70 @@
 namespace gcl {
 
 // ---- positive / finest loss: one wave per selected group, lane = channel ------------------------------
-__device__ __forceinline__ void group_stats(const float* __restrict__ f, int c, const long long* __restrict__ index,
-                                            const unsigned char* __restrict__ flag, long long b, long long e,
-                                            int lane, float& mean, float& ft, long long& tpos) {
-  float s = 0.f;
-  tpos = -1;
+// flags (config switches of finest_contrastive_loss, lib/colocation_trainer.py:463-488 / location_contrastive_loss
+// :768-776):  GL_SQRT   square_loss == False        distances enter as sqrt(d2 + 1e-7)
+//             GL_BLOCK  block_finest_gradient        mean of the NON-finest members vs the detached finest member
+//                                                    (always the sqrt form, :480-481)
+//             GL_PAIR   use_pair_group_positive_loss two drawn members instead of the spread about the mean
+//             GL_NOFIN  location_contrastive_loss    no finest term
+constexpr int GL_SQRT = 1, GL_BLOCK = 2, GL_PAIR = 4, GL_NOFIN = 8;
+
+struct GroupStats {
+  float mean, mean_b, ft;     // lane's channel of: mean of all members, mean of the non-finest members, finest member
+  long long tpos;             // position (in index) of the first finest member
+  float inv_n, inv_nb;
+};
+
+__device__ __forceinline__ GroupStats group_stats(const float* __restrict__ f, int c,
+                                                  const long long* __restrict__ index,
+                                                  const unsigned char* __restrict__ flag, long long b, long long e,
+                                                  int lane) {
+  GroupStats g;
+  float s = 0.f, sb = 0.f;
+  int nb = 0;
+  g.tpos = -1;
   for (long long j = b; j < e; ++j) {
-    long long row = index[j];
-    if (lane < c) s += f[row * c + lane];
-    if (tpos < 0 && flag[j]) tpos = j;
+    const float v = (lane < c) ? f[index[j] * c + lane] : 0.f;
+    s += v;
+    if (flag[j]) {
+      if (g.tpos < 0) g.tpos = j;
+    } else {
+      sb += v;
+      ++nb;
+    }
   }
-  mean = s / (float)(e - b);
-  if (tpos < 0) tpos = b;   // malformed input (no flag): fall back to the first member
-  ft = (lane < c) ? f[index[tpos] * c + lane] : 0.f;
+  g.inv_n = 1.f / (float)(e - b);
+  g.inv_nb = 1.f / (float)nb;          // nb == 0: inf, and mean_b = 0 * inf = NaN like torch.mean of an empty set
+  g.mean = s * g.inv_n;
+  g.mean_b = sb * g.inv_nb;
+  if (g.tpos < 0) g.tpos = b;          // malformed input (no flag): fall back to the first member
+  g.ft = (lane < c) ? f[index[g.tpos] * c + lane] : 0.f;
+  return g;
+}
+
+__device__ __forceinline__ float relu_keep_nan(float v) { return v != v ? v : fmaxf(v, 0.f); }
+
+// the two scalar terms (before the threshold) of one group; pp = the two drawn member positions (GL_PAIR)
+__device__ __forceinline__ void group_terms(const float* __restrict__ f, int c, const long long* __restrict__ index,
+                                            long long b, long long e, int lane, const GroupStats& g, int flags,
+                                            const int* __restrict__ pp, float& posv, float& finv) {
+  if (flags & GL_PAIR) {
+    const float fa = (lane < c) ? f[index[b + pp[0]] * c + lane] : 0.f;
+    const float fb = (lane < c) ? f[index[b + pp[1]] * c + lane] : 0.f;
+    const float d2 = wave_sum((fa - fb) * (fa - fb));
+    posv = (flags & GL_SQRT) ? sqrtf(d2 + 1e-7f) : d2;
+  } else {
+    float acc = 0.f;
+    for (long long j = b; j < e; ++j) {
+      const float d = (lane < c) ? g.mean - f[index[j] * c + lane] : 0.f;
+      if (flags & GL_SQRT) acc += sqrtf(wave_sum(d * d) + 1e-7f);
+      else acc += d * d;
+    }
+    posv = ((flags & GL_SQRT) ? acc : wave_sum(acc)) * g.inv_n;
+  }
+  const float dt = (lane < c) ? ((flags & GL_BLOCK) ? g.mean_b : g.mean) - g.ft : 0.f;
+  const float d2 = wave_sum(dt * dt);
+  finv = (flags & (GL_SQRT | GL_BLOCK)) ? sqrtf(d2 + 1e-7f) : d2;
 }
 
 __global__ void __launch_bounds__(64) k_group_loss_fwd(const float* __restrict__ f, int c,
@@ -33,24 +84,17 @@ __global__ void __launch_bounds__(64) k_group_loss_fwd(const float* __restrict__
                                                        const long long* __restrict__ goff,
                                                        const unsigned char* __restrict__ flag,
                                                        const long long* __restrict__ sel, float pos_thresh,
-                                                       float finest_thresh, float* pos, float* fin) {
+                                                       float finest_thresh, int flags, const int* __restrict__ pairpos,
+                                                       float* pos, float* fin) {
   const int lane = threadIdx.x;
-  const long long g = sel[blockIdx.x];
-  const long long b = goff[g], e = goff[g + 1];
-  float mean, ft;
-  long long tpos;
-  group_stats(f, c, index, flag, b, e, lane, mean, ft, tpos);
-  float acc = 0.f;
-  for (long long j = b; j < e; ++j) {
-    float d = (lane < c) ? mean - f[index[j] * c + lane] : 0.f;
-    acc += d * d;
-  }
-  float var = wave_sum(acc) / (float)(e - b);
-  float dt = (lane < c) ? mean - ft : 0.f;
-  float dfin = wave_sum(dt * dt);
+  const long long gi = sel[blockIdx.x];
+  const long long b = goff[gi], e = goff[gi + 1];
+  const GroupStats g = group_stats(f, c, index, flag, b, e, lane);
+  float posv, finv;
+  group_terms(f, c, index, b, e, lane, g, flags, pairpos ? pairpos + 2 * blockIdx.x : nullptr, posv, finv);
   if (lane == 0) {
-    pos[blockIdx.x] = fmaxf(var - pos_thresh, 0.f);
-    fin[blockIdx.x] = fmaxf(dfin - finest_thresh, 0.f);
+    pos[blockIdx.x] = relu_keep_nan(posv - pos_thresh);
+    fin[blockIdx.x] = (flags & GL_NOFIN) ? 0.f : relu_keep_nan(finv - finest_thresh);
   }
 }
 
@@ -59,33 +103,64 @@ __global__ void __launch_bounds__(64) k_group_loss_bwd(const float* __restrict__
                                                        const long long* __restrict__ goff,
                                                        const unsigned char* __restrict__ flag,
                                                        const long long* __restrict__ sel, float pos_thresh,
-                                                       float finest_thresh, const float* __restrict__ gpos,
+                                                       float finest_thresh, int flags, const int* __restrict__ pairpos,
+                                                       const float* __restrict__ gpos,
                                                        const float* __restrict__ gfin, float* df) {
   const int lane = threadIdx.x;
-  const long long g = sel[blockIdx.x];
-  const long long b = goff[g], e = goff[g + 1];
-  const float inv_n = 1.f / (float)(e - b);
-  float mean, ft;
-  long long tpos;
-  group_stats(f, c, index, flag, b, e, lane, mean, ft, tpos);
-  float acc = 0.f;
-  for (long long j = b; j < e; ++j) {
-    float d = (lane < c) ? mean - f[index[j] * c + lane] : 0.f;
-    acc += d * d;
+  const long long gi = sel[blockIdx.x];
+  const long long b = goff[gi], e = goff[gi + 1];
+  const GroupStats g = group_stats(f, c, index, flag, b, e, lane);
+  const int* pp = pairpos ? pairpos + 2 * blockIdx.x : nullptr;
+  float posv, finv;
+  group_terms(f, c, index, b, e, lane, g, flags, pp, posv, finv);
+  const float gp = (posv - pos_thresh > 0.f) ? gpos[blockIdx.x] : 0.f;
+  const float gf = (!(flags & GL_NOFIN) && finv - finest_thresh > 0.f) ? gfin[blockIdx.x] : 0.f;
+  if (gp == 0.f && gf == 0.f) return;            // wave-uniform
+  const bool sq = !(flags & GL_SQRT);
+
+  // finest term: d/df_j of |mu - f_t|^2 (or its sqrt), mu = mean over all / over the non-finest members
+  const float mu = (flags & GL_BLOCK) ? g.mean_b : g.mean;
+  const float dt = (lane < c) ? mu - g.ft : 0.f;
+  const float fin_scale = gf * ((flags & (GL_SQRT | GL_BLOCK)) ? 1.f / finv : 2.f);    // dL/d(d2) * 2, times dt below
+  const float fin_all = fin_scale * ((flags & GL_BLOCK) ? g.inv_nb : g.inv_n) * dt;    // via the mean
+
+  // positive term, non-pair sqrt form: u = (1/n) sum_j (m - f_j) / s_j
+  float u = 0.f;
+  if (!(flags & GL_PAIR) && !sq && gp != 0.f) {
+    for (long long j = b; j < e; ++j) {
+      const float d = (lane < c) ? g.mean - f[index[j] * c + lane] : 0.f;
+      u += d / sqrtf(wave_sum(d * d) + 1e-7f);
+    }
+    u *= g.inv_n;
   }
-  float var = wave_sum(acc) * inv_n;
-  float dt = (lane < c) ? mean - ft : 0.f;
-  float dfin = wave_sum(dt * dt);
-  const float gp = (var - pos_thresh > 0.f) ? gpos[blockIdx.x] : 0.f;
-  const float gf = (dfin - finest_thresh > 0.f) ? gfin[blockIdx.x] : 0.f;
-  if (lane >= c || (gp == 0.f && gf == 0.f)) return;
-  // d/df_j mean_i |m - f_i|^2 = (2/n)(f_j - m);   d/df_j |m - f_t|^2 = (2/n)(m - f_t) - [j == t] 2 (m - f_t)
   for (long long j = b; j < e; ++j) {
-    long long row = index[j];
-    float fj = f[row * c + lane];
-    float gr = gp * 2.f * inv_n * (fj - mean) + gf * 2.f * inv_n * dt;
-    if (j == tpos) gr -= gf * 2.f * dt;
-    atomicAdd(&df[row * c + lane], gr);
+    const long long row = index[j];
+    const float fj = (lane < c) ? f[row * c + lane] : 0.f;
+    float gr = 0.f;
+    if (!(flags & GL_PAIR) && gp != 0.f) {
+      if (sq) gr += gp * 2.f * g.inv_n * (fj - g.mean);
+      else {
+        const float d = (lane < c) ? g.mean - fj : 0.f;
+        const float sj = sqrtf(wave_sum(d * d) + 1e-7f);      // all lanes take part in the reduction
+        gr += gp * g.inv_n * (u - d / sj);
+      }
+    }
+    if (gf != 0.f) {
+      if (flags & GL_BLOCK) {
+        if (!flag[j]) gr += fin_all;                          // the finest member is detached (:480-481)
+      } else {
+        gr += fin_all;
+        if (j == g.tpos) gr -= fin_scale * dt;
+      }
+    }
+    if (lane < c && gr != 0.f) atomicAdd(&df[row * c + lane], gr);
+  }
+  if ((flags & GL_PAIR) && gp != 0.f && lane < c) {
+    const long long ra = index[b + pp[0]], rb = index[b + pp[1]];
+    const float diff = f[ra * c + lane] - f[rb * c + lane];
+    const float coef = gp * (sq ? 2.f : 1.f / posv);
+    atomicAdd(&df[ra * c + lane], coef * diff);
+    atomicAdd(&df[rb * c + lane], -coef * diff);
   }
 }
 
@@ -263,25 +338,32 @@ extern "C" {
 
 int gcl_group_loss_fwd(const float* f, int32_t c, const int64_t* index, const int64_t* goff,
                        const uint8_t* finest_flag, const int64_t* sel, int32_t n_sel, float pos_thresh,
-                       float finest_thresh, float* pos, float* fin, void* stream) {
+                       float finest_thresh, int32_t flags, const int32_t* pairpos, float* pos, float* fin,
+                       void* stream) {
   GCL_CHECK_ARG(f && index && goff && finest_flag && sel && pos && fin, "gcl_group_loss_fwd: null pointer");
+  GCL_CHECK_ARG(flags >= 0 && flags < 16 && (!(flags & GL_PAIR) || pairpos),
+                "gcl_group_loss_fwd: bad flags / pair positions missing");
   GCL_CHECK_ARG(c >= 1 && c <= 64, "gcl_group_loss_fwd: feature width must be <= 64 (got %d)", c);
   if (n_sel <= 0) return GCL_OK;
   hipLaunchKernelGGL(k_group_loss_fwd, dim3(n_sel), dim3(64), 0, (hipStream_t)stream, f, c, (const long long*)index,
-                     (const long long*)goff, finest_flag, (const long long*)sel, pos_thresh, finest_thresh, pos, fin);
+                     (const long long*)goff, finest_flag, (const long long*)sel, pos_thresh, finest_thresh, flags,
+                     (flags & GL_PAIR) ? pairpos : nullptr, pos, fin);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }
 
 int gcl_group_loss_bwd(const float* f, int32_t c, const int64_t* index, const int64_t* goff,
                        const uint8_t* finest_flag, const int64_t* sel, int32_t n_sel, float pos_thresh,
-                       float finest_thresh, const float* gpos, const float* gfin, float* df, void* stream) {
+                       float finest_thresh, int32_t flags, const int32_t* pairpos, const float* gpos,
+                       const float* gfin, float* df, void* stream) {
   GCL_CHECK_ARG(f && index && goff && finest_flag && sel && gpos && gfin && df, "gcl_group_loss_bwd: null pointer");
+  GCL_CHECK_ARG(flags >= 0 && flags < 16 && (!(flags & GL_PAIR) || pairpos),
+                "gcl_group_loss_bwd: bad flags / pair positions missing");
   GCL_CHECK_ARG(c >= 1 && c <= 64, "gcl_group_loss_bwd: feature width must be <= 64 (got %d)", c);
   if (n_sel <= 0) return GCL_OK;
   hipLaunchKernelGGL(k_group_loss_bwd, dim3(n_sel), dim3(64), 0, (hipStream_t)stream, f, c, (const long long*)index,
-                     (const long long*)goff, finest_flag, (const long long*)sel, pos_thresh, finest_thresh, gpos, gfin,
-                     df);
+                     (const long long*)goff, finest_flag, (const long long*)sel, pos_thresh, finest_thresh, flags,
+                     (flags & GL_PAIR) ? pairpos : nullptr, gpos, gfin, df);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }

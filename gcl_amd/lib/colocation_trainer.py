@@ -44,7 +44,8 @@ class _GCLLossFn(torch.autograd.Function):
     """(pos[s], fin[s], neg) of finest_contrastive_loss for fixed selections; one gradient buffer for all terms."""
 
     @staticmethod
-    def forward(ctx, F, index, goff, flag, sel, sel1, sel2, pos_thresh, fin_thresh, neg_thresh):
+    def forward(ctx, F, index, goff, flag, sel, sel1, sel2, pos_thresh, fin_thresh, neg_thresh, flags=0,
+                pairpos=None):
         lib = _lib.require_gpu()
         F = F.contiguous()
         n, c = F.shape
@@ -55,10 +56,11 @@ class _GCLLossFn(torch.autograd.Function):
         st = _lib.stream()
         _lib.check(lib.gcl_group_loss_fwd(_lib.ptr(F, torch.float32), c, _lib.ptr(index, torch.int64),
                                           _lib.ptr(goff, torch.int64), _lib.ptr(flag, torch.uint8),
-                                          _lib.ptr(sel, torch.int64), n_sel, pos_thresh, fin_thresh, _lib.ptr(pos),
-                                          _lib.ptr(fin), st), "gcl_group_loss_fwd")
+                                          _lib.ptr(sel, torch.int64), n_sel, pos_thresh, fin_thresh, int(flags),
+                                          _lib.ptr(pairpos, torch.int32), _lib.ptr(pos), _lib.ptr(fin), st),
+                   "gcl_group_loss_fwd")
         dmin = torch.empty(m, dtype=torch.float32, device=dev)
-        arg = torch.empty(m, dtype=torch.int32, device=dev)
+        arg = torch.empty(m, dtype=torch.int32, device=dev)     # hardest negative: fused pdist + row minimum (:510-512)
         _lib.check(lib.gcl_nn_rowmin(_lib.ptr(F), _lib.ptr(sel1, torch.int64), m, _lib.ptr(F),
                                      _lib.ptr(sel2, torch.int64), m, c, 1, _lib.ptr(dmin), _lib.ptr(arg), st),
                    "gcl_nn_rowmin")
@@ -73,31 +75,35 @@ class _GCLLossFn(torch.autograd.Function):
         out = torch.empty(2, dtype=torch.float32, device=dev)
         _lib.check(lib.gcl_neg_loss_fwd(_lib.ptr(dmin), _lib.ptr(keep), m, neg_thresh, _lib.ptr(out), st),
                    "gcl_neg_loss_fwd")
-        ctx.save_for_backward(F, index, goff, flag, sel, sel1, sel2, dmin, arg, keep, out)
-        ctx.th = (pos_thresh, fin_thresh, neg_thresh)
+        ctx.save_for_backward(F, index, goff, flag, sel, sel1, sel2, dmin, arg, keep, out, pairpos)
+        ctx.th = (pos_thresh, fin_thresh, neg_thresh, int(flags))
         return pos, fin, out[0]
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gpos, gfin, gneg):
         lib = _lib.load()
-        F, index, goff, flag, sel, sel1, sel2, dmin, arg, keep, out = ctx.saved_tensors
-        pos_thresh, fin_thresh, neg_thresh = ctx.th
+        F, index, goff, flag, sel, sel1, sel2, dmin, arg, keep, out, pairpos = ctx.saved_tensors
+        pos_thresh, fin_thresh, neg_thresh, flags = ctx.th
         n, c = F.shape
         st = _lib.stream()
         dF = torch.zeros_like(F)
         _lib.check(lib.gcl_group_loss_bwd(_lib.ptr(F), c, _lib.ptr(index), _lib.ptr(goff), _lib.ptr(flag),
-                                          _lib.ptr(sel), sel.shape[0], pos_thresh, fin_thresh,
-                                          _lib.ptr(gpos.contiguous()), _lib.ptr(gfin.contiguous()), _lib.ptr(dF), st),
+                                          _lib.ptr(sel), sel.shape[0], pos_thresh, fin_thresh, flags,
+                                          _lib.ptr(pairpos), _lib.ptr(gpos.contiguous()),
+                                          _lib.ptr(gfin.contiguous()), _lib.ptr(dF), st),
                    "gcl_group_loss_bwd")
         g = gneg.reshape(1).contiguous()
         _lib.check(lib.gcl_neg_loss_bwd(_lib.ptr(F), c, _lib.ptr(sel1), _lib.ptr(sel2), _lib.ptr(arg), _lib.ptr(dmin),
                                         _lib.ptr(keep), sel1.shape[0], neg_thresh, _lib.ptr(out), _lib.ptr(g),
                                         _lib.ptr(dF), st), "gcl_neg_loss_bwd")
-        return (dF,) + (None,) * 9
+        return (dF,) + (None,) * 11
 
 
-def draw_selections(n_groups, n_out, max_pos_cluster, max_hn_samples):
+LOSS_SQRT, LOSS_BLOCK, LOSS_PAIR, LOSS_NOFIN = 1, 2, 4, 8      # GCL_LOSS_* of include/gcl_amd.h
+
+
+def draw_selections(n_groups, n_out, max_pos_cluster, max_hn_samples, group_sizes=None, pair_positive=False):
     """The three host-side ``np.random.choice`` draws of finest_contrastive_loss, in the reference's order
     (lib/colocation_trainer.py:457, :506-507): selected positive groups, then the two negative row subsets.
     ``np.random.choice(n, k, replace=False)`` permutes all n rows (~4 ms at n = 0.5 M): the trainer therefore draws at
@@ -106,36 +112,70 @@ def draw_selections(n_groups, n_out, max_pos_cluster, max_hn_samples):
         pos_sel = np.random.choice(n_groups, max_pos_cluster, replace=False)
     else:
         pos_sel = np.arange(n_groups)
+    pair_pos = None
+    if pair_positive:        # two members per selected group, drawn inside the group loop (:467)
+        sizes = np.asarray(group_sizes)
+        pair_pos = np.stack([np.random.choice(int(sizes[i]), 2, replace=False) for i in pos_sel]).astype(np.int32)
     sel_hn1 = np.random.choice(n_out, min(n_out, max_hn_samples), replace=False)
     sel_hn2 = np.random.choice(n_out, min(n_out, max_hn_samples), replace=False)
-    return pos_sel, sel_hn1, sel_hn2
+    return pos_sel, sel_hn1, sel_hn2, pair_pos
 
 
 def finest_contrastive_loss(F_out, group, index, index_hash, finest_flag, max_pos_cluster=256, max_hn_samples=2048,
                             points=None, batch_lengths=None, pos_thresh=0.1, neg_thresh=1.4, finest_thresh=0.2,
-                            draws=None):
-    """(pos_loss, finest_loss, neg_loss) of lib/colocation_trainer.py:430-535 (square_loss, hard negatives).
+                            draws=None, square_loss=True, block_finest_gradient=False,
+                            use_pair_group_positive_loss=False, use_hard_negative=True, finest_term=True):
+    """(pos_loss, finest_loss, neg_loss) of lib/colocation_trainer.py:430-535 with its four config switches
+    (defaults = scripts/train_gcl_kitti.sh:96-105).  ``finest_term=False`` gives ``location_contrastive_loss``
+    (:734-809) when combined with ``square_loss=False``.
 
-    ``draws=(pos_sel, sel_hn1, sel_hn2)`` replays recorded selections; otherwise they are drawn from ``np.random``
-    in the reference's order.  ``index_hash``, ``points`` and ``batch_lengths`` are unused (see module docstring).
+    ``draws=(pos_sel, sel_hn1, sel_hn2[, pair_pos])`` replays recorded selections; otherwise they are drawn from
+    ``np.random`` in the reference's order.  ``use_hard_negative=False`` is rejected: the reference indexes the
+    distance matrix with an [M, 1] tensor there (:514-515), which broadcasts to an [M, M] average -- an accidental
+    semantics of a debug switch that no script sets.  ``index_hash``, ``points`` and ``batch_lengths`` are unused
+    (see module docstring).
     """
     dev = F_out.device
     n_out = F_out.shape[0]
     group = torch.as_tensor(group)
     n_groups = int(group.shape[0])
+    if not use_hard_negative:
+        raise NotImplementedError("use_hard_negative=False is not built (see the docstring)")
     if draws is None:
-        draws = draw_selections(n_groups, n_out, max_pos_cluster, max_hn_samples)
-    pos_sel, sel_hn1, sel_hn2 = draws
+        draws = draw_selections(n_groups, n_out, max_pos_cluster, max_hn_samples,
+                                group.cpu().numpy() if use_pair_group_positive_loss else None,
+                                use_pair_group_positive_loss)
+    pos_sel, sel_hn1, sel_hn2 = draws[:3]
+    pair_pos = draws[3] if len(draws) > 3 else None
+    if use_pair_group_positive_loss and pair_pos is None:
+        raise ValueError("use_pair_group_positive_loss needs the drawn member positions (draws[3])")
     if len(pos_sel) == 0:
         raise ZeroDivisionError("no positive group in the batch")
+    flags = (0 if square_loss else LOSS_SQRT) | (LOSS_BLOCK if block_finest_gradient else 0) | \
+            (LOSS_PAIR if use_pair_group_positive_loss else 0) | (0 if finest_term else LOSS_NOFIN)
     goff = torch.zeros(n_groups + 1, dtype=torch.int64, device=dev)       # no host sync when group is on the GPU
     goff[1:] = torch.cumsum(group.to(dev, torch.int64, non_blocking=True), 0)
     index = torch.as_tensor(index).to(dev, torch.int64, non_blocking=True).contiguous()
     flag = torch.as_tensor(finest_flag).to(dev, non_blocking=True).to(torch.uint8).contiguous()
     to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64)).to(dev, non_blocking=True)
+    to_dev32 = lambda a: None if a is None else \
+        torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev, non_blocking=True)
     pos, fin, neg = _GCLLossFn.apply(F_out, index, goff, flag, to_dev(pos_sel), to_dev(sel_hn1), to_dev(sel_hn2),
-                                     float(pos_thresh), float(finest_thresh), float(neg_thresh))
+                                     float(pos_thresh), float(finest_thresh), float(neg_thresh), flags,
+                                     to_dev32(pair_pos) if use_pair_group_positive_loss else None)
     return pos.sum() / len(pos_sel), fin.sum() / len(pos_sel), neg
+
+
+def location_contrastive_loss(F_out, group, index, index_hash, finest_flag, max_pos_cluster=256, max_hn_samples=2048,
+                              points=None, batch_lengths=None, pos_thresh=0.1, neg_thresh=1.4, draws=None,
+                              use_pair_group_positive_loss=False, use_hard_negative=True):
+    """lib/colocation_trainer.py:734-809 (the trainer's loss when finest_weight == 0): non-squared positive term, no
+    finest term (returned as 0), the same negative term."""
+    return finest_contrastive_loss(F_out, group, index, index_hash, finest_flag, max_pos_cluster, max_hn_samples,
+                                   points, batch_lengths, pos_thresh, neg_thresh, 0.0, draws, square_loss=False,
+                                   block_finest_gradient=False,
+                                   use_pair_group_positive_loss=use_pair_group_positive_loss,
+                                   use_hard_negative=use_hard_negative, finest_term=False)
 
 
 class FinestContrastiveLossTrainer:
@@ -145,10 +185,10 @@ class FinestContrastiveLossTrainer:
         self.config = config or make_config()
         cfg = self.config
         self.device = torch.device(device if device is not None else "cuda:0")
-        if cfg.use_group_circle_loss or not cfg.square_loss or cfg.block_finest_gradient \
-                or cfg.use_pair_group_positive_loss or not cfg.use_hard_negative or cfg.finest_weight == 0:
-            raise NotImplementedError("only the script-selected finest_contrastive_loss configuration is built "
-                                      "(scripts/train_gcl_kitti.sh:96-105)")
+        if cfg.use_group_circle_loss or not cfg.use_hard_negative:
+            raise NotImplementedError("location_circle_loss (lib/colocation_trainer.py:538-681) and "
+                                      "use_hard_negative=False are not built; the contrastive losses with their "
+                                      "other switches are")
         if model is None:
             Model = load_model(cfg.model)
             model = Model(1, cfg.model_n_out, bn_momentum=cfg.bn_momentum, normalize_feature=cfg.normalize_feature,
@@ -166,8 +206,14 @@ class FinestContrastiveLossTrainer:
     def location_loss(self, F_out, group, index, index_hash, finest_flag, max_pos_cluster, max_hn_samples,
                       points=None, batch_lengths=None, draws=None):
         cfg = self.config
+        if cfg.finest_weight == 0:            # lib/colocation_trainer.py:425-428
+            return location_contrastive_loss(F_out, group, index, index_hash, finest_flag, max_pos_cluster,
+                                             max_hn_samples, points, batch_lengths, cfg.pos_thresh, cfg.neg_thresh,
+                                             draws, cfg.use_pair_group_positive_loss, cfg.use_hard_negative)
         return finest_contrastive_loss(F_out, group, index, index_hash, finest_flag, max_pos_cluster, max_hn_samples,
-                                       points, batch_lengths, cfg.pos_thresh, cfg.neg_thresh, cfg.finest_thresh, draws)
+                                       points, batch_lengths, cfg.pos_thresh, cfg.neg_thresh, cfg.finest_thresh, draws,
+                                       cfg.square_loss, cfg.block_finest_gradient, cfg.use_pair_group_positive_loss,
+                                       cfg.use_hard_negative)
 
     def forward_loss(self, input_dict, draws=None):
         cfg = self.config
@@ -184,8 +230,12 @@ class FinestContrastiveLossTrainer:
 
     def _draw_for(self, input_dict):
         cfg = self.config
+        sizes = None
+        if cfg.use_pair_group_positive_loss:
+            sizes = torch.as_tensor(input_dict["group"]).cpu().numpy()
         return draw_selections(len(input_dict["group"]), len(input_dict["sinput_C"]),
-                               cfg.num_pos_per_batch * cfg.batch_size, cfg.num_hn_samples_per_batch * cfg.batch_size)
+                               cfg.num_pos_per_batch * cfg.batch_size, cfg.num_hn_samples_per_batch * cfg.batch_size,
+                               sizes, cfg.use_pair_group_positive_loss)
 
     def train_steps(self, batches):
         """The epoch loop (``_train_epoch`` :811-916): yields train_step(batch) for every batch.  The ``np.random``

@@ -227,20 +227,31 @@ int gcl_row_normalize_bwd(const float* y, const float* dy, const float* norm, in
                           void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * GCL loss (lib/colocation_trainer.py:430-535, square_loss path) and feature-space 1-NN.
+ * GCL loss (lib/colocation_trainer.py:430-535) and feature-space 1-NN.
  *   group g = rows index[goff[g] .. goff[g+1]) of F [n, c] (c <= 64); sel[s] = selected group ids.
- *   pos[s]    = relu(mean_j |mean - f_j|^2 - pos_thresh)          (:474)
- *   fin[s]    = relu(|mean - f_finest|^2 - finest_thresh)         (:484-485)
+ *   flags == 0 (the configuration of scripts/train_gcl_kitti.sh):
+ *     pos[s]  = relu(mean_j |mean - f_j|^2 - pos_thresh)          (:474)
+ *     fin[s]  = relu(|mean - f_finest|^2 - finest_thresh)         (:484-485)
+ *   flags (the other config switches of the same function, and location_contrastive_loss :768-776):
+ *     GCL_LOSS_SQRT   square_loss == False: distances enter as sqrt(d2 + 1e-7)                      (:470,:476,:487)
+ *     GCL_LOSS_BLOCK  block_finest_gradient: mean of the NON-finest members vs the detached finest (:479-481)
+ *     GCL_LOSS_PAIR   use_pair_group_positive_loss: pairpos[2 s], pairpos[2 s + 1] = the two drawn member
+ *                     positions inside group sel[s]                                                  (:466-470)
+ *     GCL_LOSS_NOFIN  no finest term (location_contrastive_loss)
  *   backward adds  gpos * dpos[s]/dF + gfin * dfin[s]/dF  into dF with float atomics (dF pre-zeroed by caller).
  * ---------------------------------------------------------------------------------------------- */
+#define GCL_LOSS_SQRT 1
+#define GCL_LOSS_BLOCK 2
+#define GCL_LOSS_PAIR 4
+#define GCL_LOSS_NOFIN 8
 int gcl_group_loss_fwd(const float* f, int32_t c, const int64_t* index, const int64_t* goff,
                        const uint8_t* finest_flag, const int64_t* sel, int32_t n_sel,
-                       float pos_thresh, float finest_thresh, float* pos, float* fin, void* stream);
+                       float pos_thresh, float finest_thresh, int32_t flags, const int32_t* pairpos,
+                       float* pos, float* fin, void* stream);
 int gcl_group_loss_bwd(const float* f, int32_t c, const int64_t* index, const int64_t* goff,
                        const uint8_t* finest_flag, const int64_t* sel, int32_t n_sel,
-                       float pos_thresh, float finest_thresh, const float* gpos, const float* gfin,
-                       float* df, void* stream);
-
+                       float pos_thresh, float finest_thresh, int32_t flags, const int32_t* pairpos,
+                       const float* gpos, const float* gfin, float* df, void* stream);
 /* Row-wise nearest neighbour: for every row i of A[rows_a[i]] (rows_a may be NULL = identity) the column j
  * minimising sum_c (a - b)^2 over B[rows_b[j]]; ties -> lowest j.  dmin = that squared distance, or
  * sqrt(d2 + 1e-7) when l2 != 0 (lib/metrics.py:24-25). */

@@ -77,9 +77,12 @@ def positional_hash(arr, M):
 
 def finest_contrastive_loss(F_out, group, index, index_hash, finest_flag, max_pos_cluster=256,
                             max_hn_samples=2048, pos_thresh=0.1, neg_thresh=1.4, finest_thresh=0.2,
-                            draws=None):
-    """lib/colocation_trainer.py:430-535.  ``draws`` = (pos_sel, sel_hn1, sel_hn2) replays recorded RNG
-    draws; when None they are drawn from ``np.random`` in the reference's order (:457, :506-507)."""
+                            draws=None, square_loss=True, block_finest_gradient=False,
+                            use_pair_group_positive_loss=False, finest_term=True):
+    """lib/colocation_trainer.py:430-535 with its config switches (:466-488; use_hard_negative is always True, see
+    tests/golden/make_golden.py); ``finest_term=False`` with ``square_loss=False`` is location_contrastive_loss
+    (:734-809).  ``draws`` = (pos_sel, sel_hn1, sel_hn2[, pair_pos]) replays recorded RNG draws; when None they are
+    drawn from ``np.random`` in the reference's order (:457, :467, :506-507)."""
     N_out = len(F_out)
     group = [int(g) for g in np.asarray(group)]
     index = torch.as_tensor(np.asarray(index), dtype=torch.long)
@@ -87,20 +90,38 @@ def finest_contrastive_loss(F_out, group, index, index_hash, finest_flag, max_po
     n_groups = len(group)
     index_split = torch.split(index, tuple(group))
     finest_split = torch.split(finest_flag, tuple(group))
+    pair_pos = None
     if draws is not None:
-        pos_sel, sel_hn1, sel_hn2 = (np.asarray(d) for d in draws)
+        pos_sel, sel_hn1, sel_hn2 = (np.asarray(d) for d in draws[:3])
+        pair_pos = draws[3] if len(draws) > 3 else None
     else:
         if n_groups > max_pos_cluster:
             pos_sel = np.random.choice(n_groups, max_pos_cluster, replace=False)
         else:
             pos_sel = np.arange(n_groups)
         sel_hn1 = sel_hn2 = None
-    pos_loss, finest_loss = 0, 0
-    for i in pos_sel:
+
+    def dist(d2):
+        return d2 if square_loss else torch.sqrt(d2 + 1e-7)
+
+    pos_loss, finest_loss = 0, torch.zeros(())
+    for s, i in enumerate(pos_sel):
         fs = F_out[index_split[i]]
+        fl = finest_split[i]
         mean = torch.mean(fs, dim=0)
-        pos_loss = pos_loss + torch.relu(torch.mean((mean - fs).pow(2).sum(-1)) - pos_thresh)        # :474
-        finest_loss = finest_loss + torch.relu((mean - fs[finest_split[i]][0]).pow(2).sum() - finest_thresh)  # :484-485
+        if use_pair_group_positive_loss:                                                              # :466-470
+            a, b = (np.random.choice(len(fs), 2, replace=False) if pair_pos is None else pair_pos[s])
+            pos_loss = pos_loss + torch.relu(dist((fs[a] - fs[b]).pow(2).sum(-1)) - pos_thresh)
+        else:                                                                                         # :472-476
+            pos_loss = pos_loss + torch.relu(torch.mean(dist((mean - fs).pow(2).sum(-1))) - pos_thresh)
+        if not finest_term:
+            continue
+        if block_finest_gradient:                                                                     # :478-481
+            blocked = fs[torch.bitwise_not(fl)]
+            finest_loss = finest_loss + torch.relu(torch.sqrt(
+                (torch.mean(blocked, dim=0) - fs[fl][0].detach()).pow(2).sum() + 1e-7) - finest_thresh)
+        else:                                                                                         # :483-488
+            finest_loss = finest_loss + torch.relu(dist((mean - fs[fl][0]).pow(2).sum()) - finest_thresh)
     pos_loss, finest_loss = pos_loss / len(pos_sel), finest_loss / len(pos_sel)                      # :500
     if sel_hn1 is None:
         sel_hn1 = np.random.choice(N_out, min(N_out, max_hn_samples), replace=False)

@@ -106,6 +106,20 @@ def main():
         "g16_s2": dict(seed=2, N=3000, n_groups=50, sizes=[16], max_pos=256, max_hn=4096),   # no subsampling
         "var_s3": dict(seed=3, N=5000, n_groups=400, sizes=[2, 4, 9, 16, 30], max_pos=1024, max_hn=1024),
     }
+    # the other config switches of the same function (config.py:38-43 defaults differ from the training script's:
+    # block_finest_gradient defaults to True) and location_contrastive_loss (finest_weight == 0)
+    base = dict(N=3000, n_groups=150, sizes=[2, 3, 5, 8, 16, 35], max_pos=64, max_hn=384)
+    cases.update({
+        "sqrt_s4": dict(base, seed=4, square_loss=False),
+        "block_s5": dict(base, seed=5, block_finest_gradient=True),
+        "pair_s6": dict(base, seed=6, use_pair_group_positive_loss=True),
+        # use_hard_negative=False is not captured: the reference indexes D_fs with an [M, 1] index tensor (:514-515),
+        # which broadcasts to an [M, M] average over (row, drawn column) pairs -- an accidental semantics of a debug
+        # switch no script sets; the build rejects it
+        "all_s8": dict(base, seed=8, square_loss=False, block_finest_gradient=True,
+                       use_pair_group_positive_loss=True),
+        "loc_s9": dict(base, seed=9, fn="location_contrastive_loss", square_loss=False),   # always the sqrt form
+    })
     for name, c in cases.items():
         rng = np.random.RandomState(c["seed"])
         gt = torch.Generator().manual_seed(c["seed"])
@@ -127,19 +141,25 @@ def main():
         tr = Trainer.__new__(Trainer)
         tr.device = torch.device("cpu")
         tr.pos_thresh, tr.neg_thresh, tr.finest_thresh = 0.1, 1.4, 0.2
-        tr.square_loss, tr.block_finest_gradient = True, False
-        tr.use_hard_negative, tr.use_pair_group_positive_loss = True, False
+        tr.square_loss = c.get("square_loss", True)
+        tr.block_finest_gradient = c.get("block_finest_gradient", False)
+        tr.use_hard_negative = c.get("use_hard_negative", True)
+        tr.use_pair_group_positive_loss = c.get("use_pair_group_positive_loss", False)
+        fn = getattr(tr, c.get("fn", "finest_contrastive_loss"))
 
         np.random.seed(c["seed"] + 100)
-        pos, fin, neg = tr.finest_contrastive_loss(
+        pos, fin, neg = fn(
             Fo, torch.from_numpy(group), torch.from_numpy(index), index_hash, torch.from_numpy(finest),
             max_pos_cluster=c["max_pos"], max_hn_samples=c["max_hn"])
         loss = pos + fin + neg
         loss.backward()
-        # re-draw in the same order to record the RNG draws (lib/colocation_trainer.py:457,506-507)
+        # re-draw in the same order to record the RNG draws (lib/colocation_trainer.py:457,467,506-507)
         np.random.seed(c["seed"] + 100)
         G = len(group)
         pos_sel = np.random.choice(G, c["max_pos"], replace=False) if G > c["max_pos"] else np.arange(G)
+        extra = {}
+        if tr.use_pair_group_positive_loss:
+            extra["pair_pos"] = np.stack([np.random.choice(int(group[i]), 2, replace=False) for i in pos_sel])
         sel1 = np.random.choice(N, min(N, c["max_hn"]), replace=False)
         sel2 = np.random.choice(N, min(N, c["max_hn"]), replace=False)
         np.savez_compressed(os.path.join(HERE, f"finest_loss_{name}.npz"),
@@ -147,7 +167,10 @@ def main():
                             index_hash=index_hash, np_seed=c["seed"] + 100,
                             max_pos_cluster=c["max_pos"], max_hn_samples=c["max_hn"],
                             pos_sel=pos_sel, sel_hn1=sel1, sel_hn2=sel2,
-                            pos=pos.item(), finest=fin.item(), neg=neg.item(), grad=Fo.grad.numpy())
+                            square_loss=tr.square_loss, block_finest_gradient=tr.block_finest_gradient,
+                            use_pair_group_positive_loss=tr.use_pair_group_positive_loss,
+                            finest_term=c.get("fn", "") != "location_contrastive_loss",
+                            pos=pos.item(), finest=fin.item(), neg=neg.item(), grad=Fo.grad.numpy(), **extra)
         print(name, pos.item(), fin.item(), neg.item(), float(Fo.grad.abs().sum()))
 
 

@@ -314,15 +314,26 @@ def test_resunet_forward_backward_vs_oracle(kind, precision):
 # ---------------------------------------------------------------------------------------------------------------
 # loss / kNN against the golden vectors captured from the reference's own code
 # ---------------------------------------------------------------------------------------------------------------
+def _loss_case(z):
+    """(draws, switches) recorded in a finest_loss_*.npz fixture (tests/golden/make_golden.py)."""
+    sw = {k: bool(z[k]) for k in ("square_loss", "block_finest_gradient", "use_pair_group_positive_loss",
+                                  "finest_term") if k in z.files}
+    draws = (z["pos_sel"], z["sel_hn1"], z["sel_hn2"], z["pair_pos"] if "pair_pos" in z.files else None)
+    return draws, sw
+
+
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "finest_loss_*.npz"))))
 def test_finest_contrastive_loss_golden(path):
+    """The reference's own outputs (all config switches of finest_contrastive_loss, and location_contrastive_loss):
+    loss triple within 2e-6 abs, dL/dF within 1e-5 rel-L2."""
     from gcl_amd.lib.colocation_trainer import finest_contrastive_loss
     z = np.load(path)
+    draws, sw = _loss_case(z)
     F = torch.from_numpy(z["F_out"]).to(DEV).requires_grad_(True)
-    kw = dict(max_pos_cluster=int(z["max_pos_cluster"]), max_hn_samples=int(z["max_hn_samples"]))
+    kw = dict(max_pos_cluster=int(z["max_pos_cluster"]), max_hn_samples=int(z["max_hn_samples"]), **sw)
     pos, fin, neg = finest_contrastive_loss(F, torch.from_numpy(z["group"]), torch.from_numpy(z["index"]),
                                             z["index_hash"], torch.from_numpy(z["finest_flag"]),
-                                            draws=(z["pos_sel"], z["sel_hn1"], z["sel_hn2"]), **kw)
+                                            draws=draws, **kw)
     assert abs(pos.item() - float(z["pos"])) < 2e-6 and abs(fin.item() - float(z["finest"])) < 2e-6
     if np.isnan(float(z["neg"])):
         assert np.isnan(neg.item())          # all hardest negatives were self matches: mean of empty
@@ -702,3 +713,23 @@ def test_row_normalize_matches_torch_expression(n, c):
     (yr * w.double()).sum().backward()
     assert rel_l2(y.detach().cpu().numpy(), yr.detach().cpu().numpy()) < 2e-6
     assert rel_l2(gx.cpu().numpy(), xr.grad.cpu().numpy()) < 2e-6
+
+
+@pytest.mark.parametrize("overrides", [dict(block_finest_gradient=True), dict(square_loss=False),
+                                       dict(use_pair_group_positive_loss=True), dict(finest_weight=0)])
+def test_trainer_accepts_the_other_loss_switches(overrides):
+    """config.py:38-43 / :158 switches other than the training script's selection run through the trainer (the
+    switch-by-switch values are pinned by the golden tests above); the two unbuilt ones are rejected loudly."""
+    from gcl_amd import synthetic
+    from gcl_amd.lib.colocation_trainer import FinestContrastiveLossTrainer, make_config
+    batch = synthetic.make_train_batch(77, batch_size=1, num_neighborhood=2, n_boxes=12)
+    tr = FinestContrastiveLossTrainer(make_config(batch_size=1, num_pos_per_batch=64, num_hn_samples_per_batch=128,
+                                                  **overrides), device=DEV)
+    np.random.seed(1)
+    loss, (pos, fin, neg), _ = tr.train_step(batch)
+    assert torch.isfinite(loss).item() and pos.item() >= 0
+    if overrides.get("finest_weight", 1) == 0:
+        assert fin.item() == 0.0
+    for bad in (dict(use_group_circle_loss=True), dict(use_hard_negative=False)):
+        with pytest.raises(NotImplementedError):
+            FinestContrastiveLossTrainer(make_config(**bad), device=DEV)

@@ -45,15 +45,24 @@ def test_hash_golden():
     assert np.array_equal(z["neg"], lo * M + hi)
 
 
+def _loss_case(z):
+    """(draws, switches) recorded in a finest_loss_*.npz fixture (tests/golden/make_golden.py)."""
+    sw = {k: bool(z[k]) for k in ("square_loss", "block_finest_gradient", "use_pair_group_positive_loss",
+                                  "finest_term") if k in z.files}
+    draws = (z["pos_sel"], z["sel_hn1"], z["sel_hn2"], z["pair_pos"] if "pair_pos" in z.files else None)
+    return draws, sw
+
+
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "finest_loss_*.npz"))))
 def test_finest_contrastive_loss_golden(path):
     z = np.load(path)
+    draws, sw = _loss_case(z)
     F = torch.from_numpy(z["F_out"]).requires_grad_(True)
     # (a) replaying the recorded draws
     pos, fin, neg = L.finest_contrastive_loss(
         F, z["group"], z["index"], z["index_hash"], z["finest_flag"],
         max_pos_cluster=int(z["max_pos_cluster"]), max_hn_samples=int(z["max_hn_samples"]),
-        draws=(z["pos_sel"], z["sel_hn1"], z["sel_hn2"]))
+        draws=draws, **sw)
     assert abs(pos.item() - float(z["pos"])) <= 1e-6 * max(1, abs(float(z["pos"])))
     assert abs(fin.item() - float(z["finest"])) <= 1e-6 * max(1, abs(float(z["finest"])))
     if np.isnan(float(z["neg"])):
@@ -67,5 +76,7 @@ def test_finest_contrastive_loss_golden(path):
     np.random.seed(int(z["np_seed"]))
     p2, f2, n2 = L.finest_contrastive_loss(
         F.detach(), z["group"], z["index"], z["index_hash"], z["finest_flag"],
-        max_pos_cluster=int(z["max_pos_cluster"]), max_hn_samples=int(z["max_hn_samples"]))
+        max_pos_cluster=int(z["max_pos_cluster"]), max_hn_samples=int(z["max_hn_samples"]), **sw)
     assert abs(p2.item() - float(z["pos"])) <= 1e-6 and abs(f2.item() - float(z["finest"])) <= 1e-6
+    if not np.isnan(float(z["neg"])):
+        assert abs(n2.item() - float(z["neg"])) <= 1e-6
