@@ -164,11 +164,29 @@ class MinkowskiBatchNorm(nn.Module):
 
 
 class MinkowskiInstanceNorm(nn.Module):
-    """Declared for import parity (model/common.py:7-8); the *IN* model variants are out of scope."""
+    """``ME.MinkowskiInstanceNorm(num_features)`` (model/common.py:7-8 passes ``dimension=D`` too): every cloud of the
+    batch is normalised on its own -- per channel (x - mean) / sqrt(var + 1e-8) with the biased variance over the
+    cloud's voxels, no running statistics (train == eval) -- followed by a shared affine map with parameters
+    ``weight`` / ``bias`` of shape [1, C] (ME 0.5).  ``forward(x, residual=None, relu=False)`` exposes the same fused
+    residual-add / ReLU as MinkowskiBatchNorm."""
+
+    EPS = 1e-8
 
     def __init__(self, num_features, dimension=-1):
         super().__init__()
-        raise NotImplementedError("MinkowskiInstanceNorm is out of scope for the GCL hot path (BN variants only)")
+        self.num_features = num_features
+        self.weight = nn.Parameter(torch.ones(1, num_features))
+        self.bias = nn.Parameter(torch.zeros(1, num_features))
+
+    def forward(self, x, residual=None, relu=False):
+        if residual is not None and residual.coordinate_map_key != x.coordinate_map_key:
+            raise ValueError("residual lives on a different coordinate map")
+        seg = x.coordinate_manager.batch_segments(x.coordinate_map_key.tensor_stride)
+        F = ops.instance_norm(x.F, self.weight, self.bias, seg, self.EPS,
+                              residual.F if residual is not None else None, relu)
+        out = SparseTensor(F, coordinate_map_key=x.coordinate_map_key, coordinate_manager=x.coordinate_manager)
+        out._nonneg = bool(relu)
+        return out
 
 
 def _selfcheck():

@@ -122,6 +122,7 @@ class CoordinateManager:
     so the two convs of a residual block and matching encoder/decoder levels share one map."""
 
     def __init__(self, coordinates):
+        self._segments = {}
         lib = _lib.require_gpu()
         if coordinates.dim() != 2 or coordinates.shape[1] != 4:
             raise ValueError("coordinates must be [N, 4] = (batch, x, y, z)")
@@ -164,6 +165,23 @@ class CoordinateManager:
 
     def num_rows(self, t):
         return self.get_coords(t).shape[0]
+
+    def batch_segments(self, t):
+        """[(first row, rows)] of every cloud at tensor stride ``t`` (InstanceNorm normalises per cloud).  Rows of one
+        cloud must be contiguous, which holds for collated input and for every strided map derived from it (first-
+        occurrence order); anything else is rejected.  One host read per level, cached."""
+        if t not in self._segments:
+            b = self.get_coords(t)[:, 0]
+            vals, counts = torch.unique_consecutive(b, return_counts=True)
+            vals, counts = vals.tolist(), counts.tolist()
+            if len(set(vals)) != len(vals):
+                raise NotImplementedError("MinkowskiInstanceNorm needs the rows of each cloud to be contiguous")
+            seg, start = [], 0
+            for c in counts:
+                seg.append((start, c))
+                start += c
+            self._segments[t] = seg
+        return self._segments[t]
 
     def _build_stride_maps(self, t):
         """Builds every missing power-of-two level up to max(t, 8) in ONE chain of launches: level 2s is built from

@@ -402,3 +402,79 @@ def l2_normalize_rows(x):
     if x.dim() == 2 and x.shape[0] > 0 and 4 <= c <= 256 and (c & (c - 1)) == 0 and x.dtype == torch.float32:
         return _RowNormalizeFn.apply(x)
     return x / torch.norm(x, p=2, dim=1, keepdim=True)
+
+
+class _InstanceNormFn(torch.autograd.Function):
+    """ME.MinkowskiInstanceNorm: per cloud (row segment) and channel, (x - mean) / sqrt(var + eps) with the biased
+    variance, then the shared affine map; (+ residual)(relu) fused like BatchNorm.  Every segment runs the BatchNorm
+    kernels on its row range."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, segments, eps, residual, relu):
+        lib = _lib.require_gpu()
+        x = x.contiguous()
+        n, c = x.shape
+        dev = x.device
+        ns = len(segments)
+        mean = torch.empty((ns, c), dtype=torch.float32, device=dev)
+        rstd = torch.empty((ns, c), dtype=torch.float32, device=dev)
+        res = residual.contiguous() if residual is not None else None
+        y = torch.empty_like(x)
+        w, b = weight.detach().contiguous().view(-1), bias.detach().contiguous().view(-1)
+        global _LAST_BN_AMAX
+        _LAST_BN_AMAX = slot = amax_slot(dev) if PRECISION == "fp16x3" else None
+        masks = []
+        st = _lib.stream()
+        for s, (r0, rows) in enumerate(segments):
+            xs = x[r0:r0 + rows]
+            scratch = torch.empty(lib.gcl_bn_scratch_len(rows, c), dtype=torch.float64, device=dev)
+            _lib.check(lib.gcl_bn_stats(_lib.ptr(xs, torch.float32), rows, c, float(eps), 0.0, None, None,
+                                        _lib.ptr(scratch), _lib.ptr(mean[s]), _lib.ptr(rstd[s]), st), "gcl_bn_stats")
+            mask = torch.empty(lib.gcl_bn_mask_len(rows, c), dtype=torch.int64, device=dev) if relu else None
+            masks.append(mask)
+            _lib.check(lib.gcl_bn_apply(_lib.ptr(xs), rows, c, _lib.ptr(mean[s]), _lib.ptr(rstd[s]), _lib.ptr(w),
+                                        _lib.ptr(b), _lib.ptr(res[r0:r0 + rows]) if res is not None else None,
+                                        int(relu), _lib.ptr(y[r0:r0 + rows]), _lib.ptr(mask), _lib.ptr(slot), st),
+                       "gcl_bn_apply")
+        ctx.save_for_backward(x, weight, mean, rstd, *[m for m in masks if m is not None])
+        ctx.segments, ctx.relu, ctx.has_res = segments, bool(relu), residual is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, weight, mean, rstd, *masks = ctx.saved_tensors
+        n, c = x.shape
+        dev = x.device
+        dy = dy.contiguous()
+        ns = len(ctx.segments)
+        sum_g = torch.empty((ns, c), dtype=torch.float32, device=dev)
+        sum_gx = torch.empty((ns, c), dtype=torch.float32, device=dev)
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if ctx.has_res else None
+        w = weight.detach().contiguous().view(-1)
+        slot = amax_slot(dev) if PRECISION == "fp16x3" else None
+        st = _lib.stream()
+        for s, (r0, rows) in enumerate(ctx.segments):
+            xs, gs = x[r0:r0 + rows], dy[r0:r0 + rows]
+            mask = masks[s] if ctx.relu else None
+            scratch = torch.empty(lib.gcl_bn_scratch_len(rows, c), dtype=torch.float64, device=dev)
+            _lib.check(lib.gcl_bn_bwd_reduce(_lib.ptr(xs), _lib.ptr(gs), None, _lib.ptr(mask), rows, c,
+                                             _lib.ptr(mean[s]), _lib.ptr(rstd[s]), int(ctx.relu), _lib.ptr(scratch),
+                                             _lib.ptr(sum_g[s]), _lib.ptr(sum_gx[s]), st), "gcl_bn_bwd_reduce")
+            _lib.check(lib.gcl_bn_bwd_apply(_lib.ptr(xs), _lib.ptr(gs), None, _lib.ptr(mask), rows, c,
+                                            _lib.ptr(mean[s]), _lib.ptr(rstd[s]), _lib.ptr(w), _lib.ptr(sum_g[s]),
+                                            _lib.ptr(sum_gx[s]), int(ctx.relu), _lib.ptr(dx[r0:r0 + rows]),
+                                            _lib.ptr(dres[r0:r0 + rows]) if dres is not None else None,
+                                            _lib.ptr(slot), st), "gcl_bn_bwd_apply")
+        if slot is not None:
+            tag_amax(dx, slot)
+        return dx, sum_gx.sum(0).view_as(weight), sum_g.sum(0).view_as(weight), None, None, dres, None
+
+
+def instance_norm(x, weight, bias, segments, eps=1e-8, residual=None, relu=False):
+    y = _InstanceNormFn.apply(x, weight, bias, segments, eps, residual, relu)
+    if _LAST_BN_AMAX is not None:
+        tag_amax(y, _LAST_BN_AMAX)
+    return y

@@ -3,7 +3,8 @@
 Interface and parameter names follow model/resunet.py (constructor :24-30, forward :173-232, widths :235-266), so a
 ``state_dict`` is interchangeable with the reference's.  Layers are generated from the width tables instead of being
 spelled out; BN + ReLU (+ residual) sites use the fused kernels of gcl_amd.MinkowskiEngine.MinkowskiBatchNorm.
-The ``KERNEL_SIZES[0]`` "extra" branch (:48-57, :141-151) and the IN variants are not built (unused by GCL's scripts).
+The IN variants (:269-291: BatchNorm after the level convolutions, InstanceNorm inside the residual blocks) are built
+too; the ``KERNEL_SIZES[0]`` "extra" branch (:48-57, :141-151) is not (unused by GCL's scripts).
 """
 import torch
 
@@ -94,3 +95,14 @@ ResUNetBN2D = _variant("ResUNetBN2D", [None, 64, 64, 128, 128], doc="model/resun
 ResUNetBN2E = _variant("ResUNetBN2E", [None, 64, 128, 128, 128], [None, 128, 128, 128, 256],
                        doc="model/resunet.py:257-260")
 ResUNetFatBN = _variant("ResUNetFatBN", [None, 128, 128, 128, 256], doc="model/resunet.py:263-266 (script default)")
+
+
+def _in_variant(name, base, doc):
+    return type(name, (base,), {"NORM_TYPE": "BN", "BLOCK_NORM_TYPE": "IN", "__doc__": doc})
+
+
+ResUNetIN2 = _in_variant("ResUNetIN2", ResUNetBN2, "model/resunet.py:269-271")
+ResUNetIN2B = _in_variant("ResUNetIN2B", ResUNetBN2B, "model/resunet.py:274-276")
+ResUNetIN2C = _in_variant("ResUNetIN2C", ResUNetBN2C, "model/resunet.py:279-281")
+ResUNetIN2D = _in_variant("ResUNetIN2D", ResUNetBN2D, "model/resunet.py:284-286")
+ResUNetIN2E = _in_variant("ResUNetIN2E", ResUNetBN2E, "model/resunet.py:289-291")

@@ -733,3 +733,61 @@ def test_trainer_accepts_the_other_loss_switches(overrides):
     for bad in (dict(use_group_circle_loss=True), dict(use_hard_negative=False)):
         with pytest.raises(NotImplementedError):
             FinestContrastiveLossTrainer(make_config(**bad), device=DEV)
+
+
+def test_instance_norm_matches_per_cloud_formula():
+    """ME.MinkowskiInstanceNorm semantics (per cloud and channel: biased variance, eps 1e-8, shared affine [1, C]) vs a
+    fp64 torch restatement, forward and backward, with the fused residual + ReLU; tolerance 2e-6 rel-L2."""
+    import gcl_amd.MinkowskiEngine as ME
+    g = torch.Generator().manual_seed(11)
+    sizes = [700, 33, 1500, 1]
+    C = torch.cat([torch.cat([torch.full((n, 1), b, dtype=torch.int32),
+                              torch.stack([torch.arange(n, dtype=torch.int32), torch.zeros(n, dtype=torch.int32),
+                                           torch.full((n,), b, dtype=torch.int32)], 1)], 1)
+                   for b, n in enumerate(sizes)]).to(DEV)
+    n, c = C.shape[0], 64
+    x = (torch.randn(n, c, generator=g) * 2 + 0.5).to(DEV).requires_grad_(True)
+    r = torch.randn(n, c, generator=g).to(DEV).requires_grad_(True)
+    wgt = torch.randn(n, c, generator=g).to(DEV)
+    norm = ME.MinkowskiInstanceNorm(c, dimension=3).to(DEV)
+    with torch.no_grad():
+        norm.weight.copy_(torch.rand(1, c, generator=g) + 0.5)
+        norm.bias.copy_(torch.randn(1, c, generator=g) * 0.1)
+    xs = ME.SparseTensor(x, coordinates=C)
+    rs = ME.SparseTensor(r, coordinate_map_key=xs.coordinate_map_key, coordinate_manager=xs.coordinate_manager)
+    y = norm(xs, residual=rs, relu=True).F
+    (y * wgt).sum().backward()
+    xd, rd = x.detach().double().requires_grad_(True), r.detach().double().requires_grad_(True)
+    wd, bd = norm.weight.detach().double().requires_grad_(True), norm.bias.detach().double().requires_grad_(True)
+    outs, start = [], 0
+    for m in sizes:
+        seg = xd[start:start + m]
+        mu = seg.mean(0, keepdim=True)
+        var = ((seg - mu) ** 2).mean(0, keepdim=True)
+        outs.append((seg - mu) / torch.sqrt(var + 1e-8) * wd + bd)
+        start += m
+    yr = torch.relu(torch.cat(outs) + rd)
+    (yr * wgt.double()).sum().backward()
+    assert rel_l2(y.detach().cpu(), yr.detach().cpu()) < 2e-6
+    # a 1-voxel cloud has variance 0: its gradient is scaled by 1 / sqrt(1e-8) -- compare the rest tightly
+    keep = torch.ones(n, dtype=torch.bool)
+    keep[-1] = False
+    assert rel_l2(x.grad.cpu()[keep], xd.grad.cpu()[keep]) < 1e-5
+    assert rel_l2(r.grad.cpu(), rd.grad.cpu()) < 2e-6
+    assert rel_l2(norm.weight.grad.cpu(), wd.grad.cpu()) < 1e-5 and rel_l2(norm.bias.grad.cpu(), bd.grad.cpu()) < 1e-5
+
+
+def test_in_model_variant_trains():
+    """ResUNetIN2C (model/resunet.py:279-281): BatchNorm after the level convolutions, InstanceNorm in the blocks."""
+    from gcl_amd import synthetic
+    from gcl_amd.lib.colocation_trainer import FinestContrastiveLossTrainer, make_config
+    batch = synthetic.make_train_batch(78, batch_size=1, num_neighborhood=2, n_boxes=12)
+    tr = FinestContrastiveLossTrainer(make_config(model="ResUNetIN2C", batch_size=1, num_pos_per_batch=64,
+                                                  num_hn_samples_per_batch=128), device=DEV)
+    keys = tr.model.state_dict().keys()
+    assert "block1.norm1.weight" in keys and "norm1.bn.weight" in keys and "block1.norm1.bn.weight" not in keys
+    np.random.seed(2)
+    l0 = tr.train_step(batch)[0].item()
+    for _ in range(3):
+        l1 = tr.train_step(batch)[0].item()
+    assert np.isfinite(l0) and np.isfinite(l1)
