@@ -10,7 +10,9 @@ draws, outputs, gradients).  What is captured, and from where:
 * ``util.misc._hash / _neg_hash / _exhaustive_hash``       util/misc.py:29-55
 * ``FinestContrastiveLossTrainer.finest_contrastive_loss`` lib/colocation_trainer.py:430-535
   (instance built with ``__new__`` + the attributes the method reads; np.random seeded, and the
-  three ``np.random.choice`` draws re-drawn in the same order to record them)
+  three ``np.random.choice`` draws re-drawn in the same order to record them); every config switch of the method and
+  ``location_contrastive_loss`` (:734-809)
+* ``HardestContrastiveLossTrainer.contrastive_hardest_negative_loss``  lib/trainer.py:410-462  (FCGF baseline)
 
 Third-party modules the reference imports but that are absent here (MinkowskiEngine, open3d,
 tensorboardX, easydict) are replaced by EMPTY stub modules -- none of their code is on this path.
@@ -43,6 +45,10 @@ def _import_reference():
     from lib.eval import find_nn_gpu
     from util.misc import _hash, _neg_hash, _exhaustive_hash
     from lib.colocation_trainer import FinestContrastiveLossTrainer
+    global HardestTrainer
+    sys.modules["model"] = types.ModuleType("model")          # lib/trainer.py:17 (the ME-based model package)
+    sys.modules["model"].load_model = None
+    from lib.trainer import HardestContrastiveLossTrainer as HardestTrainer
     return pdist, find_nn_gpu, _hash, _neg_hash, _exhaustive_hash, FinestContrastiveLossTrainer
 
 
@@ -174,5 +180,34 @@ def main():
         print(name, pos.item(), fin.item(), neg.item(), float(Fo.grad.abs().sum()))
 
 
+def hardest_golden():
+    """FCGF contrastive_hardest_negative_loss (lib/trainer.py:410-462)."""
+    for seed, (N0, N1, P, num_pos, num_hn) in {0: (3000, 2800, 900, 256, 512), 1: (2000, 2500, 300, 1024, 4096)}.items():
+        gt = torch.Generator().manual_seed(50 + seed)
+        rng = np.random.RandomState(50 + seed)
+        F0, F1 = _unit_rows(gt, N0, 32), _unit_rows(gt, N1, 32)
+        pairs = np.stack([rng.choice(N0, P, replace=False), rng.choice(N1, P, replace=False)], 1).astype(np.int64)
+        F1[pairs[:, 1]] = F0[pairs[:, 0]] + 0.3 * torch.randn(P, 32, generator=gt)
+        F1[rng.choice(N1, 200)] = F0[rng.choice(N0, 200)] + 0.05 * torch.randn(200, 32, generator=gt)   # hard negatives
+        F1 = F1 / F1.norm(dim=1, keepdim=True)
+        F0, F1 = F0.clone().requires_grad_(True), F1.clone().requires_grad_(True)
+        tr = HardestTrainer.__new__(HardestTrainer)
+        tr.pos_thresh, tr.neg_thresh = 0.1, 1.4
+        np.random.seed(seed + 200)
+        pos, neg = tr.contrastive_hardest_negative_loss(F0, F1, torch.from_numpy(pairs), num_pos=num_pos,
+                                                        num_hn_samples=num_hn)
+        (pos + neg).backward()
+        np.random.seed(seed + 200)
+        sel0 = np.random.choice(N0, min(N0, num_hn), replace=False)
+        sel1 = np.random.choice(N1, min(N1, num_hn), replace=False)
+        pos_sel = np.random.choice(P, num_pos, replace=False) if P > num_pos else np.zeros(0, np.int64)
+        np.savez_compressed(os.path.join(HERE, f"hardest_loss_s{seed}.npz"), F0=F0.detach().numpy(),
+                            F1=F1.detach().numpy(), pairs=pairs, num_pos=num_pos, num_hn=num_hn, np_seed=seed + 200,
+                            sel0=sel0, sel1=sel1, pos_sel=pos_sel, subsampled=P > num_pos, pos=pos.item(),
+                            neg=neg.item(), grad0=F0.grad.numpy(), grad1=F1.grad.numpy())
+        print("hardest", seed, pos.item(), neg.item())
+
+
 if __name__ == "__main__":
     main()
+    hardest_golden()

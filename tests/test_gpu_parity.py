@@ -791,3 +791,22 @@ def test_in_model_variant_trains():
     for _ in range(3):
         l1 = tr.train_step(batch)[0].item()
     assert np.isfinite(l0) and np.isfinite(l1)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "hardest_loss_*.npz"))))
+def test_fcgf_hardest_contrastive_loss_golden(path):
+    """lib/trainer.py:410-462 through gcl_nn_rowmin: (pos, neg) within 2e-6 abs of the reference's own output, gradients
+    within 1e-5 rel-L2; host draws from a seeded np.random reproduce the reference's selections."""
+    from gcl_amd.lib.trainer import contrastive_hardest_negative_loss
+    z = np.load(path)
+    F0 = torch.from_numpy(z["F0"]).to(DEV).requires_grad_(True)
+    F1 = torch.from_numpy(z["F1"]).to(DEV).requires_grad_(True)
+    kw = dict(num_pos=int(z["num_pos"]), num_hn_samples=int(z["num_hn"]))
+    draws = (z["sel0"], z["sel1"], z["pos_sel"] if bool(z["subsampled"]) else None)
+    pos, neg = contrastive_hardest_negative_loss(F0, F1, z["pairs"], draws=draws, **kw)
+    assert abs(pos.item() - float(z["pos"])) < 2e-6 and abs(neg.item() - float(z["neg"])) < 2e-6
+    (pos + neg).backward()
+    assert rel_l2(F0.grad.cpu(), z["grad0"]) < 1e-5 and rel_l2(F1.grad.cpu(), z["grad1"]) < 1e-5
+    np.random.seed(int(z["np_seed"]))
+    p2, n2 = contrastive_hardest_negative_loss(F0.detach(), F1.detach(), z["pairs"], **kw)
+    assert abs(p2.item() - float(z["pos"])) < 2e-6 and abs(n2.item() - float(z["neg"])) < 2e-6
