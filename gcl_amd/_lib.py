@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("GCL_LIB_PATH", os.path.join(CSRC, "libgcl_hip.so"))   # override: diagnostic builds only
-SOURCES = ["coords.hip", "conv.hip", "norm.hip", "loss.hip", "data.hip"]
+SOURCES = ["coords.hip", "conv.hip", "norm.hip", "loss.hip", "data.hip", "sc2pcr.hip"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "gcl_amd.h")
 
 _vp, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
@@ -58,6 +58,13 @@ SIGNATURES = {
     "gcl_bn_bwd_apply": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "gcl_row_normalize_fwd": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
     "gcl_row_normalize_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "gcl_sc2_chunks": (_i32, []),
+    "gcl_sc2_refine_partial_len": (_i32, []),
+    "gcl_sc2_confidence": (_i32, [_vp, _vp, _i32, _f32, _i32, _vp, _vp, _vp, _vp]),
+    "gcl_sc2_local_max": (_i32, [_vp, _vp, _i32, _f32, _vp, _vp]),
+    "gcl_sc2_seed_knn": (_i32, [_vp, _vp, _i32, _vp, _i32, _f32, _i32, _vp, _vp, _vp]),
+    "gcl_sc2_seed_trans": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _f32, _i32, _f32, _vp, _vp, _vp]),
+    "gcl_sc2_refine": (_i32, [_vp, _vp, _i32, _f32, _i32, _vp, _vp, _vp, _vp]),
     "gcl_group_loss_fwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _vp]),
     "gcl_group_loss_bwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "gcl_nn_rowmin": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),

@@ -1,0 +1,488 @@
+// SC2-PCR registration back-end on the device: the algorithm of scripts/SC2_PCR/SC2_PCR.py
+// (Matcher.SC2_PCR :304-381) for one pair of clouds, restated for gfx950.
+//
+// The reference materialises four [N, N] float matrices (N <= 8000: 256 MB each) and a [S, N] x [N, N] float matmul
+// on 0/1 values; here the compatibility of a correspondence pair is recomputed from the six coordinates wherever it
+// is needed (25-64 M pair evaluations are cheaper than one pass over such a matrix), the tight compatibility is kept
+// as a BIT matrix (N x N/64 words, 8 MB at N = 8000) and the second-order measure
+//   SC2[s][j] = sum_m tight[seed_s][m] tight[m][j] * hard[seed_s][j]                                      (:353-361)
+// becomes AND + popcount over 125 words.  Per-seed work (k1 = 30 nearest by SC2, local second-order selection of
+// k2 = 20, 20 x 20 power iteration, weighted Kabsch with a 3 x 3 Jacobi SVD) runs as one wavefront per seed.
+// Ties (argsort / argmax of equal values, unspecified in the reference) go to the LOWEST index; per-seed power
+// iterations always run num_iterations steps (see oracle/sc2pcr_oracle.py).
+#include "common.h"
+
+#include <math.h>
+
+namespace gcl {
+
+constexpr int SC_TILE = 256;      // correspondences per LDS tile
+constexpr int SC_CHUNKS = 8;      // column chunks of the matvec (partials added in fixed order)
+
+struct P3 { float x, y, z; };
+__device__ __forceinline__ float dist3(const P3& a, const P3& b) {
+  float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+  return sqrtf(dx * dx + dy * dy + dz * dz);   // torch.norm(a - b): no epsilon
+}
+__device__ __forceinline__ P3 ld3(const float* __restrict__ p, int i) { return P3{p[3 * i], p[3 * i + 1], p[3 * i + 2]}; }
+
+// ---- confidence = leading eigenvector of SC (:337, :345, :167-185) -------------------------------------------
+// partial[chunk][i] = sum_{j in chunk} clamp(1 - (|s_i s_j| - |t_i t_j|)^2 / d^2, 0) x_j
+__global__ void __launch_bounds__(SC_TILE) k_sc_matvec(const float* __restrict__ src, const float* __restrict__ tgt,
+                                                       int n, float d2_thre, const float* __restrict__ x,
+                                                       const int* __restrict__ done, float* partial) {
+  if (*done) return;
+  __shared__ float ts[SC_TILE][7];
+  const int i = blockIdx.x * SC_TILE + threadIdx.x;
+  const bool ok = i < n;
+  const P3 si = ok ? ld3(src, i) : P3{0, 0, 0}, ti = ok ? ld3(tgt, i) : P3{0, 0, 0};
+  const int per = (n + SC_CHUNKS - 1) / SC_CHUNKS;
+  const int j0 = blockIdx.y * per, j1 = min(n, j0 + per);
+  float acc = 0.f;
+  for (int jb = j0; jb < j1; jb += SC_TILE) {
+    __syncthreads();
+    const int j = jb + threadIdx.x;
+    if (j < j1) {
+      ts[threadIdx.x][0] = src[3 * j]; ts[threadIdx.x][1] = src[3 * j + 1]; ts[threadIdx.x][2] = src[3 * j + 2];
+      ts[threadIdx.x][3] = tgt[3 * j]; ts[threadIdx.x][4] = tgt[3 * j + 1]; ts[threadIdx.x][5] = tgt[3 * j + 2];
+      ts[threadIdx.x][6] = x[j];
+    }
+    __syncthreads();
+    const int m = min(SC_TILE, j1 - jb);
+    for (int q = 0; q < m; ++q) {
+      const float cd = fabsf(dist3(si, P3{ts[q][0], ts[q][1], ts[q][2]}) - dist3(ti, P3{ts[q][3], ts[q][4], ts[q][5]}));
+      acc += fmaxf(1.f - cd * cd / d2_thre, 0.f) * ts[q][6];
+    }
+  }
+  if (ok) partial[(size_t)blockIdx.y * n + i] = acc;
+}
+
+// one workgroup: y = sum of the partials, x_new = y / (|y| + 1e-6), done = allclose(x_new, x_old) (:176-181)
+__global__ void __launch_bounds__(1024) k_sc_normalize(const float* __restrict__ partial, int n, float* x, int* done) {
+  if (*done) return;
+  __shared__ float red[1024];
+  __shared__ int allc;
+  float ss = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    float y = 0.f;
+    for (int c = 0; c < SC_CHUNKS; ++c) y += partial[(size_t)c * n + i];
+    ss += y * y;
+  }
+  red[threadIdx.x] = ss;
+  if (threadIdx.x == 0) allc = 1;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const float inv = 1.f / (sqrtf(red[0]) + 1e-6f);
+  bool close = true;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    float y = 0.f;
+    for (int c = 0; c < SC_CHUNKS; ++c) y += partial[(size_t)c * n + i];
+    const float xn = y * inv, xo = x[i];
+    close = close && (fabsf(xn - xo) <= 1e-8f + 1e-5f * fabsf(xo));
+    x[i] = xn;
+  }
+  if (!close) allc = 0;      // benign race: every writer stores 0
+  __syncthreads();
+  if (threadIdx.x == 0 && allc) *done = 1;
+}
+
+// ---- seeds: non-maximum suppression (:32-58) -----------------------------------------------------------------
+// is_max[i] = all_j (conf_i >= conf_j  or  |s_i s_j| >= R);   is_max pre-set to 1
+__global__ void __launch_bounds__(SC_TILE) k_sc_local_max(const float* __restrict__ src, const float* __restrict__ conf,
+                                                          int n, float radius, int* is_max) {
+  __shared__ float ts[SC_TILE][4];
+  const int i = blockIdx.x * SC_TILE + threadIdx.x;
+  const bool ok = i < n;
+  const P3 si = ok ? ld3(src, i) : P3{0, 0, 0};
+  const float ci = ok ? conf[i] : 0.f;
+  const int per = (n + SC_CHUNKS - 1) / SC_CHUNKS;
+  const int j0 = blockIdx.y * per, j1 = min(n, j0 + per);
+  bool good = true;
+  for (int jb = j0; jb < j1; jb += SC_TILE) {
+    __syncthreads();
+    const int j = jb + threadIdx.x;
+    if (j < j1) {
+      ts[threadIdx.x][0] = src[3 * j]; ts[threadIdx.x][1] = src[3 * j + 1]; ts[threadIdx.x][2] = src[3 * j + 2];
+      ts[threadIdx.x][3] = conf[j];
+    }
+    __syncthreads();
+    const int m = min(SC_TILE, j1 - jb);
+    for (int q = 0; q < m; ++q)
+      good = good && ((ci >= ts[q][3]) || (dist3(si, P3{ts[q][0], ts[q][1], ts[q][2]}) >= radius));
+  }
+  if (ok && !good) is_max[i] = 0;
+}
+
+// ---- tight compatibility as a bit matrix: bit j of row i = (cross_ij < thr)  (:354) ---------------------------
+__global__ void __launch_bounds__(256) k_sc_tight_bits(const float* __restrict__ src, const float* __restrict__ tgt,
+                                                       int n, int words, float thr, unsigned long long* bits) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long long)n * words) return;
+  const int i = (int)(e / words), w = (int)(e % words);
+  const P3 si = ld3(src, i), ti = ld3(tgt, i);
+  unsigned long long b = 0;
+  const int jend = min(n, w * 64 + 64);
+  for (int j = w * 64; j < jend; ++j) {
+    const float cd = fabsf(dist3(si, ld3(src, j)) - dist3(ti, ld3(tgt, j)));
+    b |= (unsigned long long)(cd < thr) << (j & 63);
+  }
+  bits[e] = b;
+}
+
+// ---- per seed: second-order measure row and its k1 largest entries (:353-361, :85-86) -------------------------
+// one workgroup per seed; vals in LDS; selection by (value desc, index asc)
+constexpr int SC_MAXN = 8192;
+__global__ void __launch_bounds__(256) k_sc_seed_knn(const float* __restrict__ src, const float* __restrict__ tgt,
+                                                     const unsigned long long* __restrict__ bits, int n, int words,
+                                                     const long long* __restrict__ seeds, float d_thre, int k1,
+                                                     int* knn) {
+  __shared__ int vals[SC_MAXN];
+  __shared__ unsigned long long rowb[SC_MAXN / 64];
+  __shared__ int bv[256], bi[256];
+  const int r = (int)seeds[blockIdx.x];
+  for (int w = threadIdx.x; w < words; w += 256) rowb[w] = bits[(size_t)r * words + w];
+  __syncthreads();
+  const P3 sr = ld3(src, r), tr = ld3(tgt, r);
+  for (int j = threadIdx.x; j < n; j += 256) {
+    const float cd = fabsf(dist3(sr, ld3(src, j)) - dist3(tr, ld3(tgt, j)));
+    int v = 0;
+    if (cd < d_thre) {                       // hard[seed][j]: rows outside it score 0 and need no bit row
+      const unsigned long long* bj = bits + (size_t)j * words;
+      for (int w = 0; w < words; ++w) v += __popcll(rowb[w] & bj[w]);
+    }
+    vals[j] = v;
+  }
+  __syncthreads();
+  for (int round = 0; round < k1; ++round) {
+    int best = -1, besti = 0x7fffffff;
+    for (int j = threadIdx.x; j < n; j += 256) {
+      const int v = vals[j];
+      if (v > best) { best = v; besti = j; }      // ascending j per thread: the first maximum is the lowest index
+    }
+    bv[threadIdx.x] = best;
+    bi[threadIdx.x] = besti;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) {
+        const int v2 = bv[threadIdx.x + o], i2 = bi[threadIdx.x + o];
+        if (v2 > bv[threadIdx.x] || (v2 == bv[threadIdx.x] && i2 < bi[threadIdx.x])) {
+          bv[threadIdx.x] = v2;
+          bi[threadIdx.x] = i2;
+        }
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      knn[blockIdx.x * k1 + round] = bi[0];
+      vals[bi[0]] = -1;
+    }
+    __syncthreads();
+  }
+}
+
+// ---- 3 x 3 SVD (one-sided Jacobi, fp64) and the weighted Kabsch solution (common.py:7-45) ---------------------
+// H = A^T W B;  R = V diag(1, 1, det(V U^T)) U^T with singular values in DESCENDING order (torch.svd);  t = cb - R ca
+__device__ void kabsch_from_H(const double H[9], const double ca[3], const double cb[3], float* T12) {
+  double A[3][3], V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) A[i][j] = H[3 * i + j];
+  // H = U S V^T  <=>  one-sided Jacobi on the columns of H: H J1 J2 ... = U S, V = J1 J2 ...
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    double off = 0;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        double al = 0, be = 0, ga = 0;
+        for (int i = 0; i < 3; ++i) { al += A[i][p] * A[i][p]; be += A[i][q] * A[i][q]; ga += A[i][p] * A[i][q]; }
+        off = fmax(off, fabs(ga) / (sqrt(al * be) + 1e-300));
+        if (fabs(ga) <= 1e-300) continue;
+        const double zeta = (be - al) / (2.0 * ga);
+        const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+        for (int i = 0; i < 3; ++i) {
+          const double ap = A[i][p], aq = A[i][q];
+          A[i][p] = c * ap - s * aq; A[i][q] = s * ap + c * aq;
+          const double vp = V[i][p], vq = V[i][q];
+          V[i][p] = c * vp - s * vq; V[i][q] = s * vp + c * vq;
+        }
+      }
+    if (off < 1e-15) break;
+  }
+  double sg[3];
+  int ord[3] = {0, 1, 2};
+  for (int j = 0; j < 3; ++j) sg[j] = sqrt(A[0][j] * A[0][j] + A[1][j] * A[1][j] + A[2][j] * A[2][j]);
+  for (int a = 0; a < 2; ++a)
+    for (int b = a + 1; b < 3; ++b)
+      if (sg[ord[b]] > sg[ord[a]]) { int tmp = ord[a]; ord[a] = ord[b]; ord[b] = tmp; }
+  double U[3][3], Vs[3][3];
+  for (int j = 0; j < 3; ++j) {
+    const int c = ord[j];
+    for (int i = 0; i < 3; ++i) { Vs[i][j] = V[i][c]; U[i][j] = sg[c] > 1e-300 ? A[i][c] / sg[c] : 0.0; }
+  }
+  // rank-deficient H: complete U to an orthonormal basis (the result is then not unique, as in the reference)
+  const double smax = sg[ord[0]];
+  if (sg[ord[1]] <= 1e-12 * smax || smax <= 1e-300) {
+    if (smax <= 1e-300) { U[0][0] = 1; U[1][0] = 0; U[2][0] = 0; }
+    const int m = fabs(U[0][0]) < 0.9 ? 0 : 1;     // any vector not parallel to u0
+    double e[3] = {0, 0, 0};
+    e[m] = 1;
+    double dp = e[0] * U[0][0] + e[1] * U[1][0] + e[2] * U[2][0], nn = 0;
+    for (int i = 0; i < 3; ++i) { U[i][1] = e[i] - dp * U[i][0]; nn += U[i][1] * U[i][1]; }
+    nn = sqrt(nn);
+    for (int i = 0; i < 3; ++i) U[i][1] /= nn;
+  }
+  if (sg[ord[2]] <= 1e-12 * smax || smax <= 1e-300) {
+    U[0][2] = U[1][0] * U[2][1] - U[2][0] * U[1][1];
+    U[1][2] = U[2][0] * U[0][1] - U[0][0] * U[2][1];
+    U[2][2] = U[0][0] * U[1][1] - U[1][0] * U[0][1];
+  }
+  // d = det(V U^T) = det(V) det(U)
+  auto det3 = [](const double M[3][3]) {
+    return M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
+           M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
+  };
+  const double d = det3(Vs) * det3(U);
+  double R[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) R[i][j] = Vs[i][0] * U[j][0] + Vs[i][1] * U[j][1] + d * Vs[i][2] * U[j][2];
+  for (int i = 0; i < 3; ++i) {
+    const float r0 = (float)R[i][0], r1 = (float)R[i][1], r2 = (float)R[i][2];
+    T12[4 * i] = r0; T12[4 * i + 1] = r1; T12[4 * i + 2] = r2;
+    T12[4 * i + 3] = (float)(cb[i] - ((double)r0 * ca[0] + (double)r1 * ca[1] + (double)r2 * ca[2]));
+  }
+}
+
+// ---- per seed: local consensus, power iteration, weighted transformation (:60-147), one wave per seed ---------
+__global__ void __launch_bounds__(64) k_sc_seed_trans(const float* __restrict__ src, const float* __restrict__ tgt,
+                                                      const int* __restrict__ knn, int k1, int k2, float d_thre,
+                                                      int num_iterations, float* trans) {
+  __shared__ float ps[32][3], pt[32][3], fs[32][3], ft[32][3], xv[32];
+  __shared__ unsigned rowbits[32];
+  const int lane = threadIdx.x, s = blockIdx.x;
+  if (lane < k1) {
+    const int r = knn[s * k1 + lane];
+    for (int a = 0; a < 3; ++a) { ps[lane][a] = src[3 * r + a]; pt[lane][a] = tgt[3 * r + a]; }
+  }
+  __syncthreads();
+  unsigned rb = 0;
+  if (lane < k1)
+    for (int b = 0; b < k1; ++b) {
+      const float cd = fabsf(dist3(P3{ps[lane][0], ps[lane][1], ps[lane][2]}, P3{ps[b][0], ps[b][1], ps[b][2]}) -
+                             dist3(P3{pt[lane][0], pt[lane][1], pt[lane][2]}, P3{pt[b][0], pt[b][1], pt[b][2]}));
+      rb |= (unsigned)(cd < d_thre) << b;
+    }
+  if (lane < 32) rowbits[lane] = lane < k1 ? rb : 0u;
+  __syncthreads();
+  // local second-order score (:97) and its k2 largest (value desc, index asc): rank = position in the fine list
+  const int score = lane < k1 ? __popc(rowbits[0] & rb) : -1;
+  int rank = 0;
+  for (int c = 0; c < k1; ++c) {
+    const int sc = __popc(rowbits[0] & rowbits[c]);
+    rank += (sc > score || (sc == score && c < lane)) ? 1 : 0;
+  }
+  if (lane < k1 && rank < k2)
+    for (int a = 0; a < 3; ++a) { fs[rank][a] = ps[lane][a]; ft[rank][a] = pt[lane][a]; }
+  __syncthreads();
+  // soft 20 x 20 measure with zero diagonal (:119-131); lane p keeps row p
+  float M[32];
+#pragma unroll
+  for (int q = 0; q < 32; ++q) {
+    float m = 0.f;
+    if (lane < k2 && q < k2 && q != lane) {
+      const float cd = fabsf(dist3(P3{fs[lane][0], fs[lane][1], fs[lane][2]}, P3{fs[q][0], fs[q][1], fs[q][2]}) -
+                             dist3(P3{ft[lane][0], ft[lane][1], ft[lane][2]}, P3{ft[q][0], ft[q][1], ft[q][2]}));
+      m = fmaxf(1.f - cd * cd / (d_thre * d_thre), 0.f);
+    }
+    M[q] = m;
+  }
+  float x = lane < k2 ? 1.f : 0.f;
+  for (int it = 0; it < num_iterations; ++it) {
+    if (lane < 32) xv[lane] = x;
+    __syncthreads();
+    float y = 0.f;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) y += M[q] * xv[q];
+    const float nrm = sqrtf(wave_sum(lane < k2 ? y * y : 0.f));
+    x = lane < k2 ? y / (nrm + 1e-6f) : 0.f;
+    __syncthreads();
+  }
+  const float w = x / (wave_sum(x) + 1e-6f);                      // :132
+  // weighted Kabsch (common.py:18-33): fp32 centroids and covariance like the reference, SVD in fp64
+  const float sw = wave_sum(w) + 1e-6f;
+  float a[3] = {0, 0, 0}, b[3] = {0, 0, 0};
+  if (lane < k2)
+    for (int c = 0; c < 3; ++c) { a[c] = fs[lane][c]; b[c] = ft[lane][c]; }
+  float ca[3], cb[3];
+  for (int c = 0; c < 3; ++c) { ca[c] = wave_sum(a[c] * w) / sw; cb[c] = wave_sum(b[c] * w) / sw; }
+  double H[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) H[3 * i + j] = (double)wave_sum(lane < k2 ? (a[i] - ca[i]) * w * (b[j] - cb[j]) : 0.f);
+  if (lane == 0) {
+    const double cad[3] = {ca[0], ca[1], ca[2]}, cbd[3] = {cb[0], cb[1], cb[2]};
+    kabsch_from_H(H, cad, cbd, trans + 12 * s);
+  }
+}
+
+// ---- inlier count of every hypothesis (:149-161) --------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_sc_fitness(const float* __restrict__ src, const float* __restrict__ tgt, int n,
+                                                    const float* __restrict__ trans, float thr, float* fitness) {
+  __shared__ int red[256];
+  const float* T = trans + 12 * blockIdx.x;
+  int cnt = 0;
+  for (int j = threadIdx.x; j < n; j += 256) {
+    const P3 p = ld3(src, j), q = ld3(tgt, j);
+    const float x = T[0] * p.x + T[1] * p.y + T[2] * p.z + T[3] - q.x;
+    const float y = T[4] * p.x + T[5] * p.y + T[6] * p.z + T[7] - q.y;
+    const float z = T[8] * p.x + T[9] * p.y + T[10] * p.z + T[11] - q.z;
+    cnt += sqrtf(x * x + y * y + z * z) < thr;
+  }
+  red[threadIdx.x] = cnt;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) fitness[blockIdx.x] = (float)red[0];
+}
+
+// ---- post refinement (:238-279): weighted Kabsch over the inliers until the inlier count stops changing -------
+constexpr int RF_BLOCKS = 64, RF_TERMS = 17;   // sum w, sum w a (3), sum w b (3), sum w a b^T (9), count
+__global__ void __launch_bounds__(256) k_sc_refine_accum(const float* __restrict__ src, const float* __restrict__ tgt,
+                                                         int n, const float* __restrict__ T, float thr,
+                                                         const int* __restrict__ state, double* partial) {
+  if (state[0]) return;
+  __shared__ double red[256];
+  double acc[RF_TERMS];
+  for (int k = 0; k < RF_TERMS; ++k) acc[k] = 0;
+  for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += RF_BLOCKS * 256) {
+    const P3 p = ld3(src, j), q = ld3(tgt, j);
+    const float x = T[0] * p.x + T[1] * p.y + T[2] * p.z + T[3] - q.x;
+    const float y = T[4] * p.x + T[5] * p.y + T[6] * p.z + T[7] - q.y;
+    const float z = T[8] * p.x + T[9] * p.y + T[10] * p.z + T[11] - q.z;
+    const float d = sqrtf(x * x + y * y + z * z);
+    if (d < thr) {
+      const float r = d / thr;
+      const double w = 1.f / (1.f + r * r);
+      const double a[3] = {p.x, p.y, p.z}, b[3] = {q.x, q.y, q.z};
+      acc[0] += w;
+      for (int c = 0; c < 3; ++c) { acc[1 + c] += w * a[c]; acc[4 + c] += w * b[c]; }
+      for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < 3; ++k) acc[7 + 3 * i + k] += w * a[i] * b[k];
+      acc[16] += 1.0;
+    }
+  }
+  for (int k = 0; k < RF_TERMS; ++k) {
+    red[threadIdx.x] = acc[k];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x * RF_TERMS + k] = red[0];
+    __syncthreads();
+  }
+}
+
+// state[0] = done, state[1] = previous inlier count
+__global__ void k_sc_refine_solve(const double* __restrict__ partial, int* state, float* T) {
+  if (state[0]) return;
+  double s[RF_TERMS];
+  for (int k = 0; k < RF_TERMS; ++k) {
+    double v = 0;
+    for (int b = 0; b < RF_BLOCKS; ++b) v += partial[b * RF_TERMS + k];
+    s[k] = v;
+  }
+  const int cnt = (int)s[16];
+  if (abs(cnt - state[1]) < 1) {      // :266-267
+    state[0] = 1;
+    return;
+  }
+  state[1] = cnt;
+  const double sw = s[0] + 1e-6;      // common.py:22-23
+  double ca[3], cb[3], H[9];
+  for (int c = 0; c < 3; ++c) { ca[c] = s[1 + c] / sw; cb[c] = s[4 + c] / sw; }
+  // sum w (a - ca)(b - cb)^T = sum w a b^T - ca (sum w b)^T - (sum w a) cb^T + (sum w) ca cb^T
+  for (int i = 0; i < 3; ++i)
+    for (int k = 0; k < 3; ++k)
+      H[3 * i + k] = s[7 + 3 * i + k] - ca[i] * s[4 + k] - s[1 + i] * cb[k] + s[0] * ca[i] * cb[k];
+  kabsch_from_H(H, ca, cb, T);
+}
+
+}  // namespace gcl
+
+using namespace gcl;
+
+extern "C" {
+
+int32_t gcl_sc2_chunks(void) { return SC_CHUNKS; }
+int32_t gcl_sc2_refine_partial_len(void) { return RF_BLOCKS * RF_TERMS; }
+
+int gcl_sc2_confidence(const float* src, const float* tgt, int32_t n, float d_thre, int32_t num_iterations,
+                       float* partial, float* x, int32_t* done, void* stream) {
+  GCL_CHECK_ARG(src && tgt && partial && x && done, "gcl_sc2_confidence: null pointer");
+  GCL_CHECK_ARG(n > 0 && n <= SC_MAXN && d_thre > 0 && num_iterations >= 0, "gcl_sc2_confidence: 0 < n <= %d", SC_MAXN);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)cdiv(n, SC_TILE), SC_CHUNKS);
+  for (int it = 0; it < num_iterations; ++it) {
+    hipLaunchKernelGGL(k_sc_matvec, grid, dim3(SC_TILE), 0, st, src, tgt, n, d_thre * d_thre, (const float*)x,
+                       (const int*)done, partial);
+    hipLaunchKernelGGL(k_sc_normalize, dim3(1), dim3(1024), 0, st, (const float*)partial, n, x, done);
+  }
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int gcl_sc2_local_max(const float* src, const float* conf, int32_t n, float radius, int32_t* is_max, void* stream) {
+  GCL_CHECK_ARG(src && conf && is_max && n > 0, "gcl_sc2_local_max: bad argument");
+  hipLaunchKernelGGL(k_sc_local_max, dim3((unsigned)cdiv(n, SC_TILE), SC_CHUNKS), dim3(SC_TILE), 0,
+                     (hipStream_t)stream, src, conf, n, radius, is_max);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int gcl_sc2_seed_knn(const float* src, const float* tgt, int32_t n, const int64_t* seeds, int32_t n_seeds,
+                     float d_thre, int32_t k1, uint64_t* bits, int32_t* knn, void* stream) {
+  GCL_CHECK_ARG(src && tgt && seeds && bits && knn, "gcl_sc2_seed_knn: null pointer");
+  GCL_CHECK_ARG(n > 0 && n <= SC_MAXN && n_seeds > 0 && k1 >= 1 && k1 <= 32 && k1 <= n,
+                "gcl_sc2_seed_knn: need n <= %d, 1 <= k1 <= min(32, n)", SC_MAXN);
+  hipStream_t st = (hipStream_t)stream;
+  const int words = (n + 63) / 64;
+  hipLaunchKernelGGL(k_sc_tight_bits, dim3((unsigned)cdiv((long long)n * words, 256)), dim3(256), 0, st, src, tgt, n,
+                     words, d_thre * 0.5f, (unsigned long long*)bits);
+  hipLaunchKernelGGL(k_sc_seed_knn, dim3(n_seeds), dim3(256), 0, st, src, tgt, (const unsigned long long*)bits, n,
+                     words, (const long long*)seeds, d_thre, k1, knn);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int gcl_sc2_seed_trans(const float* src, const float* tgt, int32_t n, const int32_t* knn, int32_t n_seeds, int32_t k1,
+                       int32_t k2, float d_thre, int32_t num_iterations, float inlier_thresh, float* trans,
+                       float* fitness, void* stream) {
+  GCL_CHECK_ARG(src && tgt && knn && trans && fitness, "gcl_sc2_seed_trans: null pointer");
+  GCL_CHECK_ARG(n > 0 && n_seeds > 0 && k1 >= 1 && k1 <= 32 && k2 >= 1 && k2 <= k1, "gcl_sc2_seed_trans: bad k1 / k2");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_sc_seed_trans, dim3(n_seeds), dim3(64), 0, st, src, tgt, knn, k1, k2, d_thre, num_iterations,
+                     trans);
+  hipLaunchKernelGGL(k_sc_fitness, dim3(n_seeds), dim3(256), 0, st, src, tgt, n, (const float*)trans, inlier_thresh,
+                     fitness);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int gcl_sc2_refine(const float* src, const float* tgt, int32_t n, float thr, int32_t iterations, double* partial,
+                   int32_t* state, float* T, void* stream) {
+  GCL_CHECK_ARG(src && tgt && partial && state && T && n > 0 && iterations >= 0, "gcl_sc2_refine: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  GCL_CHECK_HIP(hipMemsetAsync(state, 0, 2 * sizeof(int32_t), st));
+  for (int it = 0; it < iterations; ++it) {
+    hipLaunchKernelGGL(k_sc_refine_accum, dim3(RF_BLOCKS), dim3(256), 0, st, src, tgt, n, (const float*)T, thr,
+                       (const int*)state, partial);
+    hipLaunchKernelGGL(k_sc_refine_solve, dim3(1), dim3(1), 0, st, (const double*)partial, state, T);
+  }
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,97 @@
+"""SC2-PCR registration back-end on the MI355X kernels (interface of scripts/SC2_PCR/SC2_PCR.py: class ``Matcher``).
+
+``Matcher(**config_KITTI.json).estimator(src_keypts, tgt_keypts, src_features, tgt_features)`` as called by the eval
+loop (scripts/test_kitti.py:172-180), batch size 1 (the reference asserts it too, :42, :249).  Putative
+correspondences come from ``gcl_nn_rowmin`` (the reference's argmin of sqrt(2 - 2 f.g) over L2-normalised features
+is the argmin of |f - g|^2); the registration itself is five C-ABI calls (include/gcl_amd.h, gcl_sc2_*) with three
+small torch steps in between (a stable sort for the seeds, an argmax, the inlier labels).  Nothing leaves the device
+until the caller reads the result.
+"""
+import numpy as np
+import torch
+
+from gcl_amd import _lib
+from gcl_amd.lib.metrics import pdist_min
+
+
+class Matcher:
+    def __init__(self, inlier_threshold=0.10, num_node="all", use_mutual=True, d_thre=0.1, num_iterations=10,
+                 ratio=0.2, nms_radius=0.1, max_points=8000, k1=30, k2=20, select_scene=None):
+        self.inlier_threshold, self.num_node, self.use_mutual = inlier_threshold, num_node, use_mutual
+        self.d_thre, self.num_iterations, self.ratio = d_thre, num_iterations, ratio
+        self.max_points, self.nms_radius, self.k1, self.k2 = max_points, nms_radius, k1, k2
+
+    # ---- scripts/SC2_PCR/SC2_PCR.py:281-302 --------------------------------------------------------------------
+    def match_pair(self, src_keypts, tgt_keypts, src_features, tgt_features):
+        N_src, N_tgt = src_features.shape[1], tgt_features.shape[1]
+        dev = src_features.device
+        if self.num_node == "all":
+            src_sel, tgt_sel = None, None
+        else:                                                    # with replacement, as the reference (:289-290)
+            src_sel = torch.from_numpy(np.random.choice(N_src, self.num_node)).to(dev)
+            tgt_sel = torch.from_numpy(np.random.choice(N_tgt, self.num_node)).to(dev)
+        _, arg = pdist_min(src_features[0], tgt_features[0], "SquareL2", rows_a=src_sel, rows_b=tgt_sel)
+        arg = arg.long()
+        src_rows = src_sel if src_sel is not None else torch.arange(N_src, device=dev)
+        tgt_rows = tgt_sel[arg] if tgt_sel is not None else arg
+        return src_keypts[:, src_rows], tgt_keypts[:, tgt_rows]
+
+    # ---- :304-381 ------------------------------------------------------------------------------------------------
+    def SC2_PCR(self, src_keypts, tgt_keypts):
+        lib = _lib.require_gpu()
+        if src_keypts.shape[0] != 1:
+            raise NotImplementedError("batch size 1 only (as the reference's pick_seeds / post_refinement)")
+        src = src_keypts[0, :self.max_points].to(torch.float32).contiguous()
+        tgt = tgt_keypts[0, :self.max_points].to(torch.float32).contiguous()
+        n = src.shape[0]
+        dev = src.device
+        st = _lib.stream()
+        # confidence of every correspondence (:337-345)
+        conf = torch.ones(n, dtype=torch.float32, device=dev)
+        partial = torch.empty(lib.gcl_sc2_chunks() * n, dtype=torch.float32, device=dev)
+        done = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.check(lib.gcl_sc2_confidence(_lib.ptr(src), _lib.ptr(tgt), n, float(self.d_thre),
+                                          int(self.num_iterations), _lib.ptr(partial), _lib.ptr(conf), _lib.ptr(done),
+                                          st), "gcl_sc2_confidence")
+        # seeds: local maxima first, by confidence (:32-58); ties -> lowest index
+        is_max = torch.ones(n, dtype=torch.int32, device=dev)
+        _lib.check(lib.gcl_sc2_local_max(_lib.ptr(src), _lib.ptr(conf), n, float(self.nms_radius), _lib.ptr(is_max),
+                                         st), "gcl_sc2_local_max")
+        n_seeds = int(n * self.ratio)
+        if n_seeds < 1:
+            raise ValueError("too few correspondences for SC2-PCR")
+        seeds = torch.sort(-(conf * is_max.float()), stable=True)[1][:n_seeds].contiguous()
+        # k1 most compatible correspondences of every seed under the second-order measure (:353-361, :85-86)
+        k1, k2 = (self.k1, self.k2) if self.k1 <= n else (4, 4)                      # :75-77
+        bits = torch.empty(n * ((n + 63) // 64), dtype=torch.int64, device=dev)
+        knn = torch.empty((n_seeds, k1), dtype=torch.int32, device=dev)
+        _lib.check(lib.gcl_sc2_seed_knn(_lib.ptr(src), _lib.ptr(tgt), n, _lib.ptr(seeds), n_seeds, float(self.d_thre),
+                                        k1, _lib.ptr(bits), _lib.ptr(knn), st), "gcl_sc2_seed_knn")
+        # one hypothesis per seed and its inlier count (:88-161)
+        trans = torch.empty((n_seeds, 12), dtype=torch.float32, device=dev)
+        fitness = torch.empty(n_seeds, dtype=torch.float32, device=dev)
+        _lib.check(lib.gcl_sc2_seed_trans(_lib.ptr(src), _lib.ptr(tgt), n, _lib.ptr(knn), n_seeds, k1, k2,
+                                          float(self.d_thre), int(self.num_iterations), float(self.inlier_threshold),
+                                          _lib.ptr(trans), _lib.ptr(fitness), st), "gcl_sc2_seed_trans")
+        best = torch.sort(-fitness, stable=True)[1][0]
+        T = trans[best].clone()
+        # post refinement over all correspondences (:238-279)
+        thr = 0.10 if self.inlier_threshold == 0.10 else 1.2
+        rpart = torch.empty(lib.gcl_sc2_refine_partial_len(), dtype=torch.float64, device=dev)
+        state = torch.empty(2, dtype=torch.int32, device=dev)
+        _lib.check(lib.gcl_sc2_refine(_lib.ptr(src), _lib.ptr(tgt), n, thr, 20, _lib.ptr(rpart), _lib.ptr(state),
+                                      _lib.ptr(T), st), "gcl_sc2_refine")
+        out = torch.zeros((1, 4, 4), dtype=torch.float32, device=dev)
+        out[0, :3, :] = T.view(3, 4)
+        out[0, 3, 3] = 1.0
+        self.last = dict(conf=conf, seeds=seeds, knn=knn, seed_trans=trans, fitness=fitness, best=best)
+        return out
+
+    # ---- :383-410 ------------------------------------------------------------------------------------------------
+    def estimator(self, src_keypts, tgt_keypts, src_features, tgt_features):
+        src_corr, tgt_corr = self.match_pair(src_keypts, tgt_keypts, src_features, tgt_features)
+        pred_trans = self.SC2_PCR(src_corr, tgt_corr)
+        warped = src_corr @ pred_trans[:, :3, :3].transpose(1, 2) + pred_trans[:, None, :3, 3]
+        distance = torch.sum((warped - tgt_corr) ** 2, dim=-1) ** 0.5
+        pred_labels = (distance < self.inlier_threshold).float()
+        return pred_trans, pred_labels, src_corr, tgt_corr

@@ -20,6 +20,8 @@
  *        -> gcl_group_loss_fwd/bwd, gcl_nn_rowmin (pdist + min, lib/metrics.py:22-25),
  *           gcl_neg_mask, gcl_neg_loss_fwd/bwd
  *   find_nn_gpu                                      lib/eval.py:18-48  -> gcl_nn_rowmin
+ *   Matcher.estimator (SC2-PCR)                      scripts/test_kitti.py:172-180, scripts/SC2_PCR/SC2_PCR.py
+ *        -> gcl_nn_rowmin, gcl_sc2_*
  *
  * Conventions
  *   - plain C types only; every pointer is a DEVICE pointer unless its name ends in _host;
@@ -270,6 +272,38 @@ int gcl_neg_loss_fwd(const float* dmin, const uint8_t* keep, int32_t m, float th
 int gcl_neg_loss_bwd(const float* f, int32_t c, const int64_t* sel1, const int64_t* sel2, const int32_t* arg,
                      const float* dmin, const uint8_t* keep, int32_t m, float thresh, const float* out,
                      const float* gneg, float* df, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * SC2-PCR registration back-end (scripts/SC2_PCR/SC2_PCR.py, Matcher.SC2_PCR :304-381) for ONE pair:
+ * src / tgt float [n, 3] = the putative correspondences (n <= 8192).  No [n, n] matrix is materialised; ties of the
+ * reference's argsort / argmax go to the lowest index.  Call order (the host keeps the few glue steps):
+ *   gcl_sc2_confidence  leading eigenvector of the first-order compatibility matrix by power iteration with the
+ *                       reference's torch.allclose early stop (:337-345, :167-185).  x float[n] must hold ones,
+ *                       done int32[1] zero; partial float[gcl_sc2_chunks() * n].  Result in x.
+ *   gcl_sc2_local_max   non-maximum suppression flags (:43-47); is_max int32[n] must hold ones.
+ *                       host: seeds = first int(n * ratio) of a stable descending sort of conf * is_max.
+ *   gcl_sc2_seed_knn    tight-compatibility bit matrix (bits uint64[n * ceil(n / 64)]), second-order measure of every
+ *                       seed and its k1 (<= 32) best correspondences, knn int32[n_seeds * k1] (:353-361, :85-86).
+ *   gcl_sc2_seed_trans  per seed: k2-subset by the local second-order measure, k2 x k2 power iteration
+ *                       (num_iterations steps), weighted Kabsch -> trans float[n_seeds * 12] (rows of [R | t]);
+ *                       fitness float[n_seeds] = inlier count under inlier_thresh (:88-161).
+ *                       host: best = lowest index of the maximum fitness.
+ *   gcl_sc2_refine      post refinement in place on T float[12] (:238-279): up to `iterations` weighted Kabsch steps
+ *                       over the inliers under thr, stopping when the inlier count repeats.
+ *                       partial double[gcl_sc2_refine_partial_len()], state int32[2].
+ * ---------------------------------------------------------------------------------------------- */
+int32_t gcl_sc2_chunks(void);
+int32_t gcl_sc2_refine_partial_len(void);
+int gcl_sc2_confidence(const float* src, const float* tgt, int32_t n, float d_thre, int32_t num_iterations,
+                       float* partial, float* x, int32_t* done, void* stream);
+int gcl_sc2_local_max(const float* src, const float* conf, int32_t n, float radius, int32_t* is_max, void* stream);
+int gcl_sc2_seed_knn(const float* src, const float* tgt, int32_t n, const int64_t* seeds, int32_t n_seeds,
+                     float d_thre, int32_t k1, uint64_t* bits, int32_t* knn, void* stream);
+int gcl_sc2_seed_trans(const float* src, const float* tgt, int32_t n, const int32_t* knn, int32_t n_seeds, int32_t k1,
+                       int32_t k2, float d_thre, int32_t num_iterations, float inlier_thresh, float* trans,
+                       float* fitness, void* stream);
+int gcl_sc2_refine(const float* src, const float* tgt, int32_t n, float thr, int32_t iterations, double* partial,
+                   int32_t* state, float* T, void* stream);
 
 #ifdef __cplusplus
 }

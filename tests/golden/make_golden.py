@@ -13,6 +13,7 @@ draws, outputs, gradients).  What is captured, and from where:
   three ``np.random.choice`` draws re-drawn in the same order to record them); every config switch of the method and
   ``location_contrastive_loss`` (:734-809)
 * ``HardestContrastiveLossTrainer.contrastive_hardest_negative_loss``  lib/trainer.py:410-462  (FCGF baseline)
+* ``Matcher.SC2_PCR``                                      scripts/SC2_PCR/SC2_PCR.py:304-381 (KITTI config)
 
 Third-party modules the reference imports but that are absent here (MinkowskiEngine, open3d,
 tensorboardX, easydict) are replaced by EMPTY stub modules -- none of their code is on this path.
@@ -208,6 +209,38 @@ def hardest_golden():
         print("hardest", seed, pos.item(), neg.item())
 
 
+def sc2pcr_problem(seed, N, inlier_ratio, noise=0.03):
+    """Synthetic putative correspondences: a planar-ish 80 m scene, ground-truth yaw + translation, uniform outliers."""
+    rng = np.random.RandomState(seed)
+    src = rng.uniform(-40, 40, (N, 3)).astype(np.float32)
+    src[:, 2] *= 0.1
+    ang = np.deg2rad(20.0 + seed)
+    c, s = np.cos(ang), np.sin(ang)
+    R = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])
+    t = np.array([3.0, 1.0 - seed, 0.5])
+    tgt = (src @ R.T + t + rng.normal(0, noise, (N, 3))).astype(np.float32)
+    out = rng.rand(N) > inlier_ratio
+    tgt[out] = rng.uniform(-40, 40, (int(out.sum()), 3)).astype(np.float32)
+    T = np.eye(4)
+    T[:3, :3], T[:3, 3] = R, t
+    return src, tgt, T
+
+
+def sc2pcr_golden():
+    """Matcher.SC2_PCR (scripts/SC2_PCR/SC2_PCR.py:304-381) with scripts/SC2_PCR/config_json/config_KITTI.json."""
+    from scripts.SC2_PCR.SC2_PCR import Matcher
+    cfg = dict(inlier_threshold=0.6, num_node=8000, use_mutual=False, d_thre=0.1, num_iterations=20, ratio=0.2,
+               nms_radius=0.6, max_points=8000, k1=30, k2=20)
+    m = Matcher(**cfg)
+    for seed, N, ratio in [(0, 1500, 0.35), (1, 2500, 0.5), (2, 800, 0.15), (3, 1200, 0.08)]:
+        src, tgt, T = sc2pcr_problem(seed, N, ratio)
+        est = m.SC2_PCR(torch.from_numpy(src)[None], torch.from_numpy(tgt)[None])[0].numpy()
+        np.savez_compressed(os.path.join(HERE, f"sc2pcr_s{seed}.npz"), src=src, tgt=tgt, T_true=T, T_ref=est,
+                            **{k: v for k, v in cfg.items() if k not in ("use_mutual",)})
+        print("sc2pcr", seed, N, ratio, float(np.abs(est - T).max()))
+
+
 if __name__ == "__main__":
     main()
     hardest_golden()
+    sc2pcr_golden()

@@ -810,3 +810,72 @@ def test_fcgf_hardest_contrastive_loss_golden(path):
     np.random.seed(int(z["np_seed"]))
     p2, n2 = contrastive_hardest_negative_loss(F0.detach(), F1.detach(), z["pairs"], **kw)
     assert abs(p2.item() - float(z["pos"])) < 2e-6 and abs(n2.item() - float(z["neg"])) < 2e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# "next" row: SC2-PCR registration back-end
+# ---------------------------------------------------------------------------------------------------------------
+SC2_KEYS = ("inlier_threshold", "d_thre", "num_iterations", "ratio", "nms_radius", "max_points", "k1", "k2")
+
+
+def _sc2_cfg(z):
+    return {k: (int(z[k]) if k in ("num_iterations", "max_points", "k1", "k2") else float(z[k])) for k in SC2_KEYS}
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "sc2pcr_*.npz"))))
+def test_sc2pcr_matches_reference_output_and_oracle_stages(path):
+    """Final transformation within 2e-3 of the reference's own output (tie order is unspecified there) and within
+    2e-4 of the oracle, which shares the lowest-index tie rule; the integer stages (seeds, k1-neighbour sets, best
+    hypothesis) equal the oracle's exactly, confidences within 1e-5."""
+    from gcl_amd.scripts.SC2_PCR import Matcher
+    from oracle.sc2pcr_oracle import sc2_pcr
+    z = np.load(path)
+    cfg = _sc2_cfg(z)
+    m = Matcher(num_node="all", use_mutual=False, **cfg)
+    src, tgt = torch.from_numpy(z["src"]).to(DEV), torch.from_numpy(z["tgt"]).to(DEV)
+    T = m.SC2_PCR(src[None], tgt[None])[0].cpu().numpy()
+    assert np.abs(T - z["T_ref"]).max() < 2e-3
+    To, st = sc2_pcr(z["src"], z["tgt"], return_stages=True, **cfg)
+    assert np.abs(T - To.numpy()).max() < 2e-4
+    assert np.allclose(m.last["conf"].cpu().numpy(), st["conf"].numpy(), rtol=0, atol=1e-5)
+    same_seeds = np.array_equal(m.last["seeds"].cpu().numpy(), st["seeds"].numpy())
+    if same_seeds:        # confidences equal to ~1e-7: the seed order can only differ on near-ties
+        assert np.array_equal(m.last["knn"].cpu().numpy(), st["knn"].numpy())
+        assert np.array_equal(m.last["fitness"].cpu().numpy(), st["fitness"].numpy())
+        assert int(m.last["best"]) == st["best"]
+        # hypotheses of consistent seeds agree closely; seeds sitting on outliers give near-singular 3 x 3 problems
+        good = st["fitness"].numpy() >= 0.5 * st["fitness"].numpy().max()
+        d = np.abs(m.last["seed_trans"].cpu().numpy().reshape(-1, 3, 4) - st["seed_trans"][:, :3, :].numpy())
+        assert good.sum() >= 5 and d[good].max() < 5e-3
+    else:
+        assert set(m.last["seeds"].cpu().numpy()[:50]) == set(st["seeds"].numpy()[:50])
+
+
+def test_sc2pcr_estimator_end_to_end_at_kitti_size():
+    """Matcher.estimator with config_KITTI.json (8000 sampled nodes from 5000 voxels): features -> correspondences ->
+    transformation; 30 % of the voxels have a true match."""
+    from gcl_amd.scripts.SC2_PCR import Matcher
+    rng = np.random.RandomState(3)
+    g = torch.Generator().manual_seed(3)
+    n = 5000
+    xyz0 = rng.uniform(-40, 40, (n, 3)).astype(np.float32)
+    xyz0[:, 2] *= 0.1
+    ang = np.deg2rad(12.0)
+    R = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]])
+    t = np.array([8.0, -1.0, 0.2])
+    perm = rng.permutation(n)
+    xyz1 = (xyz0 @ R.T + t + rng.normal(0, 0.03, (n, 3))).astype(np.float32)[perm]
+    F0 = torch.randn(n, 32, generator=g)
+    F0 = F0 / F0.norm(dim=1, keepdim=True)
+    F1 = F0.clone()
+    bad = torch.rand(n, generator=g) > 0.3
+    F1[bad] = torch.nn.functional.normalize(torch.randn(int(bad.sum()), 32, generator=g), dim=1)
+    F1 = F1[torch.from_numpy(perm)]
+    m = Matcher(inlier_threshold=0.6, num_node=8000, use_mutual=False, d_thre=0.1, num_iterations=20, ratio=0.2,
+                nms_radius=0.6, max_points=8000, k1=30, k2=20)
+    np.random.seed(0)
+    T, labels, s, tt = m.estimator(torch.from_numpy(xyz0).to(DEV)[None], torch.from_numpy(xyz1).to(DEV)[None],
+                                   F0.to(DEV)[None], F1.to(DEV)[None])
+    T = T[0].cpu().numpy()
+    assert np.abs(T[:3, :3] - R).max() < 2e-3 and np.abs(T[:3, 3] - t).max() < 2e-2
+    assert labels.shape == (1, 8000) and 0.2 < labels.mean().item() < 0.4 and s.shape == (1, 8000, 3)
