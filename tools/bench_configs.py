@@ -3,7 +3,9 @@
 configs[1]: KITTI-shaped pair, voxel 0.3 m, ResUNetBN2C-32 forward-only feature extraction (eval mode, batch 1 each,
             as scripts/test_kitti.py:141-152) -> active voxels/s.
 configs[4]: LoKITTI-shaped eval: 2 x forward + find_corr (5000 x 5000 feature 1-NN, scripts/test_kitti.py:154) ->
-            pairs/s and voxels/s (registration excluded: open3d RANSAC / SC2-PCR are out of scope).
+            pairs/s and voxels/s, without registration and with the SC2-PCR back-end (gcl_amd.scripts.SC2_PCR,
+            config_KITTI.json: 5000 sampled voxels per cloud, 8000 nodes) -- the README's "7 FPS on an RTX 3090"
+            configuration (README.md:193).  The SC2-PCR stage alone is also timed on the CPU oracle.
 Writes one JSON object to stdout.  Usage: python tools/bench_configs.py [--pairs 3] [--iters 10]
 """
 import argparse
@@ -59,8 +61,57 @@ def main():
                 find_corr(xyz0, xyz1, F0, F1, subsample_size=5000)          # includes the D2H of 5000 indices
         torch.cuda.synchronize()
         t_eval = time.perf_counter() - t0
+        # scripts/test_kitti.py:158-180 with use_RANSAC false: random 5000 voxels per cloud -> Matcher.estimator
+        from gcl_amd.scripts.SC2_PCR import Matcher
+        matcher = Matcher(inlier_threshold=0.6, num_node=8000, use_mutual=False, d_thre=0.1, num_iterations=20,
+                          ratio=0.2, nms_radius=0.6, max_points=8000, k1=30, k2=20)
+
+        def register(dp, F0, F1):
+            x0, x1 = dp["xyz0_dev"], dp["xyz1_dev"]
+            s0 = torch.from_numpy(np.random.choice(len(F0), min(5000, len(F0)), replace=False)).to(dev)
+            s1 = torch.from_numpy(np.random.choice(len(F1), min(5000, len(F1)), replace=False)).to(dev)
+            return matcher.estimator(x0[s0][None], x1[s1][None], F0[s0][None], F1[s1][None])[0][0]
+
+        for dp in dpairs:
+            dp["xyz0_dev"], dp["xyz1_dev"] = dp["pcd0"][0].to(dev), dp["pcd1"][0].to(dev)
+            T = register(dp, forward(dp, 0), forward(dp, 1))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        errs = []
+        for _ in range(args.iters):
+            for p, dp in zip(pairs, dpairs):
+                F0, F1 = forward(dp, 0), forward(dp, 1)
+                find_corr(p["pcd0"][0].numpy(), p["pcd1"][0].numpy(), F0, F1, subsample_size=5000)
+                T = register(dp, F0, F1).cpu()                               # the eval loop reads T on the host
+        torch.cuda.synchronize()
+        t_reg = time.perf_counter() - t0
+        # the registration stage alone, device vs the CPU oracle on the same correspondences
+        dp = dpairs[0]
+        F0, F1 = forward(dp, 0), forward(dp, 1)
+        np.random.seed(1)
+        s0 = torch.from_numpy(np.random.choice(len(F0), min(5000, len(F0)), replace=False)).to(dev)
+        s1 = torch.from_numpy(np.random.choice(len(F1), min(5000, len(F1)), replace=False)).to(dev)
+        sc, tc = matcher.match_pair(dp["xyz0_dev"][s0][None], dp["xyz1_dev"][s1][None], F0[s0][None], F1[s1][None])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            Tg = matcher.SC2_PCR(sc, tc)
+        torch.cuda.synchronize()
+        t_sc2_gpu = (time.perf_counter() - t0) / 10
+        sys.path.insert(0, ROOT)
+        from oracle.sc2pcr_oracle import sc2_pcr
+        torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+        t0 = time.perf_counter()
+        To = sc2_pcr(sc[0].cpu().numpy(), tc[0].cpu().numpy())
+        t_sc2_cpu = time.perf_counter() - t0
+        sc2_diff = float((Tg[0].cpu() - To).abs().max())
     n_pairs = args.iters * len(pairs)
     print(json.dumps({
+        "configs[4] eval incl. SC2-PCR registration (8000 nodes)": {
+            "pairs_per_s": round(n_pairs / t_reg, 2), "ms_per_pair": round(t_reg / n_pairs * 1e3, 3)},
+        "SC2-PCR stage alone (8000 correspondences)": {
+            "gpu_ms": round(t_sc2_gpu * 1e3, 3), "cpu_oracle_ms": round(t_sc2_cpu * 1e3, 1),
+            "cpu_threads": torch.get_num_threads(), "max_abs_diff_T": sc2_diff},
         "configs[1] forward-only": {"voxels_per_s": round(nvox / t_fwd, 1), "ms_per_cloud": round(t_fwd / (2 * n_pairs) * 1e3, 3),
                                     "avg_voxels_per_cloud": round(nvox / (2 * n_pairs), 1)},
         "configs[4] eval (2x fwd + 5000x5000 feature 1-NN, no registration)": {
