@@ -444,13 +444,56 @@ __global__ void __launch_bounds__(64) k_radix_hist(const unsigned* __restrict__ 
   for (int d = lane; d < 256; d += 64) hist[(long long)d * nblk + blockIdx.x] = cnt[d];
 }
 
+// one workgroup per digit d: within[d][b] = sum_{b' < b} hist[d][b'], total[d] = sum_b hist[d][b]  (the digit bases,
+// a 256-entry prefix sum of the totals, are formed by every scatter block itself: one launch instead of a 3-kernel
+// scan over the whole 256 x nblk histogram)
+__global__ void __launch_bounds__(256) k_radix_digit_scan(const int* __restrict__ hist, int nblk, int* within,
+                                                          int* total) {
+  __shared__ int part[256];
+  const int d = blockIdx.x, t = threadIdx.x;
+  const int per = (nblk + 255) / 256;
+  const int b0 = t * per, b1 = min(nblk, b0 + per);
+  const int* h = hist + (long long)d * nblk;
+  int s = 0;
+  for (int b = b0; b < b1; ++b) s += h[b];
+  part[t] = s;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {      // inclusive Hillis-Steele scan of the 256 chunk sums
+    int v = (t >= o) ? part[t - o] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - s;
+  int* w = within + (long long)d * nblk;
+  for (int b = b0; b < b1; ++b) {
+    w[b] = run;
+    run += h[b];
+  }
+  if (t == 255) total[d] = part[255];
+}
+
 __global__ void __launch_bounds__(64) k_radix_scatter(const unsigned* __restrict__ keys, const int* __restrict__ vals,
                                                       long long n, int shift, int nblk,
-                                                      const int* __restrict__ offs, unsigned* keys_out,
-                                                      int* vals_out) {
+                                                      const int* __restrict__ within, const int* __restrict__ total,
+                                                      unsigned* keys_out, int* vals_out) {
   __shared__ int base_[256];
   const int lane = threadIdx.x;
-  for (int d = lane; d < 256; d += 64) base_[d] = offs[(long long)d * nblk + blockIdx.x];
+  {   // digit bases = exclusive prefix sum of total[0..255]: lane l owns digits 4l .. 4l+3
+    const int t0 = total[4 * lane], t1 = total[4 * lane + 1], t2 = total[4 * lane + 2], t3 = total[4 * lane + 3];
+    const int mine = t0 + t1 + t2 + t3;
+    int inc = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+      int v = __shfl_up(inc, o);
+      if (lane >= o) inc += v;
+    }
+    const int ex = inc - mine;
+    const long long bb = blockIdx.x;
+    base_[4 * lane] = ex + within[(long long)(4 * lane) * nblk + bb];
+    base_[4 * lane + 1] = ex + t0 + within[(long long)(4 * lane + 1) * nblk + bb];
+    base_[4 * lane + 2] = ex + t0 + t1 + within[(long long)(4 * lane + 2) * nblk + bb];
+    base_[4 * lane + 3] = ex + t0 + t1 + t2 + within[(long long)(4 * lane + 3) * nblk + bb];
+  }
   __syncthreads();
   const long long base = (long long)blockIdx.x * RS_BLOCK;
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -689,7 +732,7 @@ int gcl_kernel_map_pairs(const int32_t* nbr, int32_t K, int64_t n_out, const int
 int64_t gcl_table_sort_scratch_len(int64_t n) {
   long long nblk = cdiv(n, RS_BLOCK);
   long long hist = 256 * nblk;
-  return 4 * n + 2 * hist + cdiv(hist, SCAN_B) + 64;
+  return 4 * n + 2 * hist + cdiv(hist, SCAN_B) + 64 + 256;   // keys/vals ping-pong, hist, within, digit totals
 }
 
 int gcl_table_sort(const int32_t* tbl, int32_t K, int64_t n, int32_t window, int32_t* scratch, int32_t* order,
@@ -729,11 +772,10 @@ int gcl_table_sort(const int32_t* tbl, int32_t K, int64_t n, int32_t window, int
     for (int p = 0; p < passes; ++p) {
       hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(64), 0, st, (const unsigned*)ka, (long long)n, base + 8 * p, nblk, hist);
       GCL_CHECK_LAUNCH();
-      int rc = device_scan(hist, hist_len, offs, bs, st);
-      if (rc) return rc;
+      hipLaunchKernelGGL(k_radix_digit_scan, dim3(256), dim3(256), 0, st, (const int*)hist, nblk, offs, bs);
       int* vout = (p == passes - 1) ? order : vb;
       hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(64), 0, st, (const unsigned*)ka, (const int*)va, (long long)n,
-                         base + 8 * p, nblk, (const int*)offs, kb, vout);
+                         base + 8 * p, nblk, (const int*)offs, (const int*)bs, kb, vout);
       unsigned* tk = ka; ka = kb; kb = tk;
       if (p != passes - 1) { int* tv = va; va = vb; vb = tv; }
     }
