@@ -111,13 +111,21 @@ def tensor_amax(lib, t):
 
 
 class WeightAmaxGroup:
-    """gcl_amax of all convolution kernels of a network in ONE launch per optimizer step (gcl_amax_multi)."""
+    """All convolution kernels of a network, refreshed together once per optimizer step: gcl_amax of every tensor in
+    ONE launch (gcl_amax_multi) and the MFMA-order weight packs of a direction in ONE launch each
+    (gcl_pack_weights_multi) -- forward packs with the refresh, input-gradient packs at the first backward request."""
 
     def __init__(self, params):
         self.params = [p for p in params]
-        for p in self.params:
+        for i, p in enumerate(self.params):
             p._gcl_amax_group = self
+            p._gcl_group_index = i
         self.ptrs = None
+        self.packs = {}          # direction ("fwd" / "bwd") -> (tag, [packed views])
+        self.bwd_modes = {}      # param index -> 1 | 2, recorded by the convolutions during the forward pass
+
+    def _shape3(self, p):
+        return tuple(p.shape) if p.dim() == 3 else (1,) + tuple(p.shape)
 
     def refresh(self, lib, want):
         ps = self.params
@@ -129,6 +137,7 @@ class WeightAmaxGroup:
             self.ptrs = ptrs
             self.table = torch.tensor(ptrs + [p.numel() for p in ps], dtype=torch.int64).to(dev)
             self.out = torch.empty((len(ps), AMAX_WORDS), dtype=torch.int32, device=dev)
+            self.desc = {}
         else:
             self.out = torch.empty_like(self.out)       # earlier slots may still be referenced by saved contexts
         n = len(ps)
@@ -140,7 +149,44 @@ class WeightAmaxGroup:
             tag_amax(p, slot)
             if p is want:
                 found = slot
+        self.packs = {}
         return found
+
+    def _tag(self):
+        return (tuple(p._version for p in self.params), _AMAX_EPOCH, PRECISION, self.out.data_ptr())
+
+    def packed(self, lib, p, mode):
+        """Packed weights of parameter ``p`` for ``mode`` (0 forward; 1 / 2 input gradient) from the group launch of
+        this step, or None when the group cannot serve it (f32 arithmetic, mode not recorded, stale amax)."""
+        prec = _PREC_CODES[PRECISION]
+        if prec != 4 or known_amax(p) is None:        # the group launches serve the default arithmetic only
+            return None
+        key = "fwd" if mode == 0 else "bwd"
+        i = p._gcl_group_index
+        if key == "bwd" and self.bwd_modes.get(i) != mode:
+            return None
+        tag = self._tag()
+        entry = self.packs.get(key)
+        if entry is None or entry[0] != tag:
+            idx = list(range(len(self.params))) if key == "fwd" else sorted(self.bwd_modes)
+            modes = [0] * len(idx) if key == "fwd" else [self.bwd_modes[j] for j in idx]
+            dkey = (key, tuple(idx), tuple(modes), prec)
+            if dkey not in self.desc:
+                rows, off, wg = [], 0, 0
+                for j, m in zip(idx, modes):
+                    K, ci, co = self._shape3(self.params[j])
+                    rows.append([self.ptrs[j], K, ci, co, m, j, off, wg])
+                    off += (lib.gcl_pack_weights_bytes(K, ci, co, prec) + 255) // 256 * 256
+                    wg += (K * ci * co + 255) // 256
+                offs = [r[6] for r in rows] + [off]
+                self.desc[dkey] = (torch.tensor(rows, dtype=torch.int64).to(self.params[0].device), offs, wg)
+            desc, offs, wgs = self.desc[dkey]
+            buf = torch.empty(offs[-1], dtype=torch.uint8, device=self.params[0].device)
+            _lib.check(lib.gcl_pack_weights_multi(_lib.ptr(desc), len(idx), wgs, prec, _lib.ptr(self.out),
+                                                  _lib.ptr(buf), _lib.stream()), "gcl_pack_weights_multi")
+            views = {j: buf[offs[q]:offs[q + 1]] for q, j in enumerate(idx)}
+            entry = self.packs[key] = (tag, views)
+        return entry[1].get(i)
 
 
 def ctypes_offset(t, elem):
@@ -148,7 +194,7 @@ def ctypes_offset(t, elem):
 
 
 def _conv_launch(lib, x, Wk, mode, table, n_out, cin, cout, bias, pairs=0, want_stats=False, x_amax=None,
-                 w_amax=None):
+                 w_amax=None, wp=None):
     """One output-stationary convolution launch.  ``Wk`` [K, *, *] is packed for ``mode`` (0 forward, 1 transposed,
     2 transposed + mirrored offsets) in the current precision; ``table`` = (tbl, order, tile_mask) from
     KernelMap.sorted_table(), or None for a kernel_size-1 conv; (cin, cout) are the EFFECTIVE widths of the launch.
@@ -158,9 +204,10 @@ def _conv_launch(lib, x, Wk, mode, table, n_out, cin, cout, bias, pairs=0, want_
     if prec == 4:
         x_amax = x_amax if x_amax is not None else tensor_amax(lib, x)
         w_amax = w_amax if w_amax is not None else tensor_amax(lib, Wk)
-    wp = torch.empty(lib.gcl_pack_weights_bytes(K, wc_in, wc_out, prec), dtype=torch.uint8, device=Wk.device)
-    _lib.check(lib.gcl_pack_weights(_lib.ptr(Wk, torch.float32), K, wc_in, wc_out, mode, prec, _lib.ptr(w_amax),
-                                    _lib.ptr(wp), _lib.stream()), "gcl_pack_weights")
+    if wp is None:      # not served by a WeightAmaxGroup launch: pack this tensor now
+        wp = torch.empty(lib.gcl_pack_weights_bytes(K, wc_in, wc_out, prec), dtype=torch.uint8, device=Wk.device)
+        _lib.check(lib.gcl_pack_weights(_lib.ptr(Wk, torch.float32), K, wc_in, wc_out, mode, prec, _lib.ptr(w_amax),
+                                        _lib.ptr(wp), _lib.stream()), "gcl_pack_weights")
     tbl, order, tile_mask = table if table is not None else (None, None, None)
     y = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
     stats = None
@@ -209,10 +256,16 @@ class _SparseConvFn(torch.autograd.Function):
             if fp16x3:
                 ctx.x_amax = x_known if x_known is not None else tensor_amax(lib, x)
                 ctx.w_amax = w_known if w_known is not None else tensor_amax(lib, Wk)
+            group = getattr(W, "_gcl_amax_group", None) if w_known is not None else None
+            wp = None
+            if group is not None:     # packed with all other kernels of the network; remember the backward layout
+                group.bwd_modes[W._gcl_group_index] = 2 if (kmap is not None and not transpose and kmap.same_map) else 1
+                wp = group.packed(lib, W, 0)
+            ctx.group, ctx.param = group, (W if group is not None else None)
             y, stats = _conv_launch(lib, x, Wk, 0, tbl, n_out, cin, cout, b, ctx.pairs, want_stats=True,
-                                    x_amax=ctx.x_amax, w_amax=ctx.w_amax) \
+                                    x_amax=ctx.x_amax, w_amax=ctx.w_amax, wp=wp) \
                 if want_stats else (_conv_launch(lib, x, Wk, 0, tbl, n_out, cin, cout, b, ctx.pairs,
-                                                 x_amax=ctx.x_amax, w_amax=ctx.w_amax), None)
+                                                 x_amax=ctx.x_amax, w_amax=ctx.w_amax, wp=wp), None)
         ctx.save_for_backward(x, Wk)
         ctx.set_materialize_grads(False)       # no zero-filled gradient for the (non-differentiable) statistics output
         ctx.kmap, ctx.transpose, ctx.mgr, ctx.w_shape, ctx.has_bias = kmap, transpose, mgr, W.shape, bias is not None
@@ -251,8 +304,10 @@ class _SparseConvFn(torch.autograd.Function):
                 mode, tbl = 2, kmap.sorted_table(transposed=False)
             else:
                 mode, tbl = 1, kmap.sorted_table(transposed=True)
+            group = getattr(ctx, "group", None)
+            wp = group.packed(lib, ctx.param, mode) if group is not None else None
             dx = _conv_launch(lib, dy, Wk, mode, tbl, x.shape[0], cout, cin, None, ctx.pairs, x_amax=dy_amax,
-                              w_amax=w_amax)
+                              w_amax=w_amax, wp=wp)
         if ctx.needs_input_grad[1]:
             dW = torch.empty_like(Wk)
             if ctx.stem:

@@ -37,6 +37,7 @@ SIGNATURES = {
     "gcl_pack_weights_bytes": (_i64, [_i32, _i32, _i32, _i32]),
     "gcl_amax": (_i32, [_vp, _i64, _vp, _i32, _vp]),
     "gcl_amax_multi": (_i32, [_vp, _vp, _i32, _vp, _vp]),
+    "gcl_pack_weights_multi": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _vp]),
     "gcl_conv_fwd_nb": (_i32, [_i64, _i32, _i32]),
     "gcl_pack_weights": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "gcl_table_sort_scratch_len": (_i64, [_i64]),
@@ -109,10 +110,17 @@ def load():
     return lib
 
 
+_gpu_ok = False
+
+
 def require_gpu():
-    if not torch.cuda.is_available():
-        raise RuntimeError("gcl_amd needs an AMD GPU (gfx950); torch.cuda.is_available() is False and there is no CPU path")
-    return load()
+    global _gpu_ok
+    if not _gpu_ok:
+        if not torch.cuda.is_available():
+            raise RuntimeError("gcl_amd needs an AMD GPU (gfx950); torch.cuda.is_available() is False and there is "
+                               "no CPU path")
+        _gpu_ok = True
+    return _lib if _lib is not None else load()
 
 
 def check(rc, what=""):
@@ -135,7 +143,9 @@ def ptr(t, dtype=None):
 
 
 def stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """Raw handle of torch's current HIP stream on the current device (the fast C accessors: this is called once per
+    launch, ~700 times per training step)."""
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def host_i64(values):

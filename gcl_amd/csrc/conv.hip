@@ -325,12 +325,9 @@ __global__ void __launch_bounds__(256) k_amax_multi(const float* const* __restri
 // wp16 (8 x 16-bit units): [(((k*CC + cc)*TNB + nb)*2 + m)*planes + pl][lane = h*32 + j][jj]
 //                         = plane pl of W_eff[k][cc*32 + 16m + 8h + jj][32 nb + j]   (fp16 mode: of W_eff * scale)
 template <int PL>
-__global__ void k_pack_weights_split(const float* __restrict__ w, int K, int cin, int cout, int mode,
-                                     const int* __restrict__ w_amax, unsigned short* wp) {
+__device__ __forceinline__ void pack_split_one(const float* __restrict__ w, int K, int cin, int cout, int mode,
+                                               const int* __restrict__ w_amax, unsigned short* wp, long long o) {
   constexpr int NPL = Prec<PL>::planes;
-  long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  long long total = (long long)K * cin * cout;
-  if (o >= total) return;
   int cin_e = mode == 0 ? cin : cout;
   int cout_e = mode == 0 ? cout : cin;
   int CC = cin_e / 32, TNB = cout_e / 32;
@@ -367,6 +364,33 @@ __global__ void k_pack_weights_split(const float* __restrict__ w, int K, int cin
     wp[((blk + 1) * 64 + l) * 8 + jj] = __builtin_bit_cast(unsigned short, mid);
     if (PL == 3) wp[((blk + 2) * 64 + l) * 8 + jj] = __builtin_bit_cast(unsigned short, (__bf16)(r - (float)mid));
   }
+}
+
+template <int PL>
+__global__ void k_pack_weights_split(const float* __restrict__ w, int K, int cin, int cout, int mode,
+                                     const int* __restrict__ w_amax, unsigned short* wp) {
+  long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= (long long)K * cin * cout) return;
+  pack_split_one<PL>(w, K, cin, cout, mode, w_amax, wp, o);
+}
+
+// all convolution kernels of a network in one launch.  desc[t] = {w pointer, K, cin, cout, mode, amax slot index,
+// byte offset of the packed tensor in `out`, first workgroup}; a workgroup finds its tensor by binary search
+struct PackDesc { long long w, K, cin, cout, mode, amax_index, out_off, first_wg; };
+template <int PL>
+__global__ void __launch_bounds__(256) k_pack_weights_multi(const PackDesc* __restrict__ desc, int n_tensors,
+                                                            const int* __restrict__ amax_slots,
+                                                            unsigned char* __restrict__ out) {
+  int lo = 0, hi = n_tensors - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (desc[mid].first_wg <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const PackDesc d = desc[lo];
+  const long long o = ((long long)blockIdx.x - d.first_wg) * 256 + threadIdx.x;
+  if (o >= d.K * d.cin * d.cout) return;
+  pack_split_one<PL>(reinterpret_cast<const float*>(d.w), (int)d.K, (int)d.cin, (int)d.cout, (int)d.mode,
+                     amax_slots + d.amax_index * AMAX_WORDS, reinterpret_cast<unsigned short*>(out + d.out_off), o);
 }
 
 template <int NB, int PL>
@@ -1047,6 +1071,26 @@ int gcl_pack_weights(const float* w, int32_t K, int32_t cin, int32_t cout, int32
   else if (prec == 2) hipLaunchKernelGGL(k_pack_weights_split<2>, grid, dim3(256), 0, st, w, K, cin, cout, mode, w_amax, (unsigned short*)wp);
   else if (prec == 3) hipLaunchKernelGGL(k_pack_weights_split<3>, grid, dim3(256), 0, st, w, K, cin, cout, mode, w_amax, (unsigned short*)wp);
   else hipLaunchKernelGGL(k_pack_weights_split<4>, grid, dim3(256), 0, st, w, K, cin, cout, mode, w_amax, (unsigned short*)wp);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int gcl_pack_weights_multi(const int64_t* desc, int32_t n_tensors, int64_t total_wgs, int32_t prec,
+                           const int32_t* amax_slots, void* out, void* stream) {
+  GCL_CHECK_ARG(desc && out && n_tensors > 0 && total_wgs > 0, "gcl_pack_weights_multi: bad argument");
+  GCL_CHECK_ARG(prec == 2 || prec == 3 || prec == 4, "gcl_pack_weights_multi: split precisions only (2, 3, 4)");
+  GCL_CHECK_ARG(prec != 4 || amax_slots, "gcl_pack_weights_multi: fp16x3 needs the amax slots");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)total_wgs);
+  if (prec == 2)
+    hipLaunchKernelGGL(k_pack_weights_multi<2>, grid, dim3(256), 0, st, (const PackDesc*)desc, n_tensors, amax_slots,
+                       (unsigned char*)out);
+  else if (prec == 3)
+    hipLaunchKernelGGL(k_pack_weights_multi<3>, grid, dim3(256), 0, st, (const PackDesc*)desc, n_tensors, amax_slots,
+                       (unsigned char*)out);
+  else
+    hipLaunchKernelGGL(k_pack_weights_multi<4>, grid, dim3(256), 0, st, (const PackDesc*)desc, n_tensors, amax_slots,
+                       (unsigned char*)out);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }

@@ -164,6 +164,12 @@ int gcl_amax_multi(const float* const* ptrs, const int64_t* sizes, int32_t n_ten
                    void* stream);
 int gcl_pack_weights(const float* w, int32_t K, int32_t cin, int32_t cout, int32_t mode, int32_t prec,
                      const int32_t* w_amax, void* wp, void* stream);
+/* gcl_pack_weights for a list of tensors in ONE launch (all convolution kernels of a network, once per optimizer step
+ * and direction).  desc: DEVICE int64[n_tensors][8] = {w pointer, K, cin, cout, mode, amax slot index, byte offset of
+ * the packed tensor inside `out`, first workgroup}, first workgroup = running sum of ceil(K*cin*cout / 256);
+ * total_wgs = that sum over all tensors; amax_slots: the slots written by gcl_amax_multi (prec 4).  prec 2, 3 or 4. */
+int gcl_pack_weights_multi(const int64_t* desc, int32_t n_tensors, int64_t total_wgs, int32_t prec,
+                           const int32_t* amax_slots, void* out, void* stream);
 /* NB of the kernel instance gcl_conv_fwd will launch for this shape (a wave covers 32 NB output columns): 4, 2 or 1;
  * diagnostic (profile labels). */
 int32_t gcl_conv_fwd_nb(int64_t n_out, int32_t cout, int32_t prec);
