@@ -38,11 +38,17 @@ def shard_indices(n_items, rank, world):
 class FlatDDP:
     """Flat-buffer gradient all-reduce for a module (no autograd hooks, no per-parameter collectives)."""
 
-    def __init__(self, process_group=None):
+    def __init__(self, process_group=None, overlap=True, n_buckets=2):
+        """``overlap``: split the flat gradient into ``n_buckets`` contiguous ranges and start the all-reduce of a
+        range as soon as the backward pass has produced all of its gradients (later-registered layers first), so the
+        collective of the decoder half runs under the encoder half of the backward pass.  Needs exactly one
+        ``backward()`` per ``all_reduce_gradients()``; use ``overlap=False`` when accumulating several."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.flat_param = self.flat_grad = None
         self.params = []
+        self.overlap, self.n_buckets = bool(overlap), max(1, int(n_buckets))
+        self._bounds, self._bucket_of, self._count, self._pending, self._works = [], {}, [], [], {}
 
     def attach(self, module):
         params = [p for p in module.parameters() if p.requires_grad]
@@ -61,6 +67,25 @@ class FlatDDP:
                 p.grad = self.flat_grad[off:off + n].view_as(p)
                 off += n
         self.params = params
+        # buckets = contiguous ranges of (almost) equal size, cut at parameter boundaries
+        cuts, acc, nb = [0], 0, self.n_buckets
+        for i, p in enumerate(params):
+            acc += p.numel()
+            if len(cuts) < nb and acc >= total * len(cuts) / nb and i + 1 < len(params):
+                cuts.append(i + 1)
+        cuts.append(len(params))
+        offs = [0]
+        for p in params:
+            offs.append(offs[-1] + p.numel())
+        self._bounds = [(offs[a], offs[b]) for a, b in zip(cuts[:-1], cuts[1:])]
+        self._count = [b - a for a, b in zip(cuts[:-1], cuts[1:])]
+        for bi, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+            for p in params[a:b]:
+                self._bucket_of[id(p)] = bi
+        self._pending, self._works = list(self._count), {}
+        if self.overlap and self.world > 1:
+            for p in params:
+                p.register_post_accumulate_grad_hook(self._on_grad)
         from .MinkowskiEngine import ops
         ops.invalidate_amax()                    # parameter storage moved (and is about to be broadcast into)
         if self.world > 1:
@@ -68,6 +93,19 @@ class FlatDDP:
             for b in module.buffers():
                 dist.broadcast(b, src=0, group=self.group)
         return self
+
+    def _launch(self, b):
+        lo, hi = self._bounds[b]
+        self._works[b] = dist.all_reduce(self.flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _on_grad(self, p):
+        b = self._bucket_of[id(p)]
+        if b in self._works:
+            raise RuntimeError("FlatDDP(overlap=True) saw a second backward pass before all_reduce_gradients(); "
+                               "use FlatDDP(overlap=False) when accumulating gradients over several passes")
+        self._pending[b] -= 1
+        if self._pending[b] == 0:
+            self._launch(b)
 
     def all_reduce_gradients(self):
         """Average gradients over ranks: ONE collective on the flat buffer (optimizer.zero_grad(set_to_none=False)
@@ -77,5 +115,13 @@ class FlatDDP:
                     p.grad.data_ptr() >= self.flat_grad.data_ptr() + self.flat_grad.numel() * self.flat_grad.element_size():
                 raise RuntimeError("parameter gradient left the flat buffer: call optimizer.zero_grad(set_to_none=False)")
         if self.world > 1:
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            if self.overlap:
+                for b in range(len(self._bounds)):       # ranges whose parameters got no gradient in this pass
+                    if b not in self._works:
+                        self._launch(b)
+                for b in sorted(self._works):
+                    self._works[b].wait()
+                self._pending, self._works = list(self._count), {}
+            else:
+                dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
             self.flat_grad.div_(self.world)

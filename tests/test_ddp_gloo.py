@@ -15,7 +15,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, overlap=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     from gcl_amd import ddp
@@ -23,7 +23,7 @@ def _worker(rank, world, port, out):
     assert (r, w) == (rank, world)
     torch.manual_seed(100 + rank)                      # different init per rank: broadcast must fix it
     model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.BatchNorm1d(16), torch.nn.Linear(16, 4))
-    d = ddp.FlatDDP().attach(model)
+    d = ddp.FlatDDP(overlap=overlap).attach(model)
     opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.8, weight_decay=1e-4)
     torch.manual_seed(7)
     X, Y = torch.randn(8, 6, 8), torch.randn(8, 6, 4)   # 8 "samples"
@@ -41,10 +41,11 @@ def _worker(rank, world, port, out):
 
 def test_flat_ddp_two_ranks_gloo():
     mgr = mp.Manager()
-    out = mgr.dict()
-    port = _free_port()
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    out, out_plain = mgr.dict(), mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)               # bucketed, overlapped
+    mp.spawn(_worker, args=(2, _free_port(), out_plain, False), nprocs=2, join=True)  # one collective per step
     (p0, g0, m0), (p1, g1, m1) = out[0], out[1]
+    assert torch.equal(p0, out_plain[0][0]) and torch.equal(g0, out_plain[0][1]), "bucketing changes nothing"
     assert sorted(m0 + m1) == list(range(8)) and not set(m0) & set(m1)
     assert torch.equal(p0, p1), "ranks hold identical parameters after averaged-gradient steps"
     assert torch.equal(g0, g1) and g0.abs().sum() > 0
