@@ -60,7 +60,7 @@ def pack_keys(C):
     C = np.asarray(C, dtype=np.int64)
     off = 1 << 15
     assert C[:, 0].min(initial=0) >= 0 and C[:, 0].max(initial=0) < (1 << 15)
-    assert np.abs(C[:, 1:]).max(initial=0) < off
+    assert C[:, 1:].min(initial=0) >= -off and C[:, 1:].max(initial=0) < off
     return (C[:, 0] << 48) | ((C[:, 1] + off) << 32) | ((C[:, 2] + off) << 16) | (C[:, 3] + off)
 
 
@@ -89,7 +89,8 @@ def kernel_map_np(C_in, C_out, ks, t_in, dilation=1):
     for k, o in enumerate(offs):
         Q = C_out.copy()
         Q[:, 1:] += o
-        ok = np.abs(Q[:, 1:]).max(axis=1, initial=0) < (1 << 15) if len(Q) else np.zeros(0, bool)
+        ok = ((Q[:, 1:].min(axis=1, initial=0) >= -(1 << 15)) & (Q[:, 1:].max(axis=1, initial=0) < (1 << 15))) \
+            if len(Q) else np.zeros(0, bool)     # the packable range is [-32768, 32767]
         q = pack_keys(np.where(ok[:, None], Q, 0)) if len(Q) else np.zeros(0, np.int64)
         pos = np.searchsorted(skeys, q)
         pos = np.minimum(pos, len(skeys) - 1) if len(skeys) else pos

@@ -101,6 +101,40 @@ def test_coordinate_errors():
         ME.SparseTensor(torch.ones(len(C), 1), coordinates=torch.from_numpy(C))
 
 
+def test_extreme_coordinates_and_dense_block_maps_bit_exact():
+    """Edge cases of the coordinate hash: the corners of the packable range (|x| = 32767, batch 32767), a FULL 20^3 block
+    (every one of the 27 / 125 neighbours present: longest probe chains, no bitmap rejections) and its stride maps."""
+    g = np.arange(-10, 10, dtype=np.int32)
+    cube = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    np.random.RandomState(0).shuffle(cube)
+    corners = np.array([[32767, 32767, 32767], [-32767, -32767, -32767], [32767, -32767, 0], [32766, 32767, 32767]],
+                       dtype=np.int32)
+    C = np.concatenate([np.concatenate([np.zeros((len(cube), 1), np.int32), cube], 1),
+                        np.concatenate([np.full((len(corners), 1), 32767, np.int32), corners], 1)]).astype(np.int32)
+    mgr, omgr = make_mgr(C), O.CoordinateManager(C)
+    for t in (2, 4, 8):
+        assert np.array_equal(mgr.get_coords(t).cpu().numpy(), omgr.get_coords(t))
+    for key in [(1, 3, 1), (1, 5, 1), (1, 3, 2), (2, 3, 1)]:
+        got, ref = O.canonical(mgr.kernel_map_triples(*key)), O.canonical(omgr.get_kernel_map(*key))
+        assert got.shape == ref.shape and np.array_equal(got, ref), key
+    assert mgr.get_kernel_map(1, 3, 1).n_pairs > 26 * 18 ** 3          # interior voxels have all 27 neighbours
+
+
+def test_empty_and_single_voxel_inputs():
+    """No rows: a clean error, not a launch with an empty grid.  One voxel: every level has one row and the whole
+    network still runs (eval statistics), matching the oracle."""
+    import gcl_amd.MinkowskiEngine as ME
+    with pytest.raises((ValueError, RuntimeError)):
+        ME.SparseTensor(torch.ones(0, 1, device=DEV), coordinates=torch.zeros((0, 4), dtype=torch.int32, device=DEV))
+    m, st = _model_and_state(3, 5)
+    m.eval()
+    C = torch.tensor([[0, 3, -2, 1]], dtype=torch.int32)
+    with torch.no_grad():
+        y = m(ME.SparseTensor(torch.ones(1, 1, device=DEV), coordinates=C.to(DEV))).F
+    ref = O.resunet_forward(st, C.numpy(), torch.ones(1, 1, dtype=torch.float64), 5, True, False, 0.05)
+    assert y.shape == (1, 32) and rel_l2(y.cpu(), ref.detach()) < 1e-4
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # convolution forward / input gradient / weight gradient
 # ---------------------------------------------------------------------------------------------------------------
