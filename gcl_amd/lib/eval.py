@@ -29,3 +29,18 @@ def find_corr(xyz0, xyz1, F0, F1, subsample_size=-1, nn_max_n=500):
     if subsample_size > 0 and subsample:
         return xyz0[inds0], xyz1[inds1[nn_inds.numpy()]]
     return xyz0, xyz1[nn_inds]
+
+
+def forward_pair(model, F0, C0, F1, C1):
+    """Features of the two clouds of an evaluation pair from ONE forward pass (scripts/test_kitti.py:141-152 runs the
+    model twice).  In eval mode the network treats the clouds of a batch independently (running BatchNorm statistics,
+    per-cloud coordinate maps), and every output row is accumulated in a fixed offset order whatever its tile mates
+    are, so the result equals the two separate passes bit for bit -- at half the launches of this launch-bound case.
+    ``C0`` / ``C1`` int32 [N, 4] with batch column 0."""
+    import gcl_amd.MinkowskiEngine as ME
+    if model.training:
+        raise RuntimeError("forward_pair needs model.eval(): batch statistics would mix the two clouds")
+    C1b = C1.clone()
+    C1b[:, 0] = 1
+    out = model(ME.SparseTensor(torch.cat([F0, F1]), coordinates=torch.cat([C0, C1b]))).F
+    return out[:len(F0)], out[len(F0):]

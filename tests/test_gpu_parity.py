@@ -913,3 +913,18 @@ def test_sc2pcr_estimator_end_to_end_at_kitti_size():
     T = T[0].cpu().numpy()
     assert np.abs(T[:3, :3] - R).max() < 2e-3 and np.abs(T[:3, 3] - t).max() < 2e-2
     assert labels.shape == (1, 8000) and 0.2 < labels.mean().item() < 0.4 and s.shape == (1, 8000, 3)
+
+
+def test_forward_pair_equals_two_forward_passes_bitwise():
+    import gcl_amd.MinkowskiEngine as ME
+    from gcl_amd import synthetic
+    from gcl_amd.lib.eval import forward_pair
+    m, _ = _model_and_state(4, 5)
+    m.eval()
+    p = synthetic.make_eval_pair(5, baseline=15.0, n_boxes=15)
+    F0, C0, F1, C1 = (p[k].to(DEV) for k in ("sinput0_F", "sinput0_C", "sinput1_F", "sinput1_C"))
+    with torch.no_grad():
+        a0 = m(ME.SparseTensor(F0, coordinates=C0)).F
+        a1 = m(ME.SparseTensor(F1, coordinates=C1)).F
+        b0, b1 = forward_pair(m, F0, C0, F1, C1)
+    assert torch.equal(a0, b0) and torch.equal(a1, b1)
