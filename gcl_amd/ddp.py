@@ -3,9 +3,11 @@
 The reference is single-GPU; this is the new capability BASELINE.json asks for.  The path shards
 naturally: every rank takes its own samples, builds its own coordinate maps, mines negatives inside its own batch
 (the reference's bs=4 semantics per rank) and keeps its own BatchNorm statistics (the reference has no SyncBN).
-The only exchange is the gradient: all parameters are re-seated as views of ONE flat fp32 buffer, so a step issues
-a single 35 MB all-reduce (xGMI rings are per-link bound: one large collective beats many small buckets) followed
-by a scale by 1/world_size.  Parameters and BN buffers are broadcast from rank 0 once.
+The only exchange is the gradient: all parameters are re-seated as views of ONE flat fp32 buffer (35 MB), all-reduced
+in two large contiguous buckets (xGMI rings are per-link bound: few large collectives beat many small ones) -- the
+bucket of the decoder layers starts from a post-accumulate hook as soon as the backward pass has filled it and overlaps
+with the encoder half of backward -- followed by a scale by 1/world_size.  Parameters and BN buffers are broadcast
+from rank 0 once.
 Works with any torch.distributed backend (gloo on CPU in tests/test_ddp_gloo.py).
 """
 import os
