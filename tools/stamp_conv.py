@@ -12,10 +12,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "gcl_amd", "csrc")
-LIB = os.path.join(ROOT, "gpurun_out", "libgcl_hip_stamps.so")
+LIB = os.path.join("/tmp", "libgcl_hip_stamps.so")
 os.makedirs(os.path.dirname(LIB), exist_ok=True)
 subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DGCL_STAMPS", "-o", LIB] +
-               [os.path.join(CSRC, f) for f in ("coords.hip", "conv.hip", "norm.hip", "loss.hip")], check=True)
+               [os.path.join(CSRC, f) for f in ("coords.hip", "conv.hip", "norm.hip", "loss.hip", "data.hip", "sc2pcr.hip")], check=True)
 os.environ["GCL_LIB_PATH"] = LIB
 
 import torch  # noqa: E402
