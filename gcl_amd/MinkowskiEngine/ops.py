@@ -218,7 +218,7 @@ def _conv_launch(lib, x, Wk, mode, table, n_out, cin, cout, bias, pairs=0, want_
         nb = lib.gcl_conv_fwd_nb(n_out, cout, prec)
         name = f"k_conv_fwd<{nb}>" if prec == 0 else f"k_conv_fwd_split<{nb},{prec}>"
     with _Timed(name, pairs, cin, cout):
-        _lib.check(lib.gcl_conv_fwd(_lib.ptr(x, torch.float32), _lib.ptr(wp), prec, _lib.ptr(x_amax),
+        _lib.check(lib.gcl_conv_fwd(_lib.ptr(x, torch.float32), x.shape[0], _lib.ptr(wp), prec, _lib.ptr(x_amax),
                                     _lib.ptr(w_amax), _lib.ptr(tbl), _lib.ptr(order), _lib.ptr(tile_mask), n_out, K,
                                     cin, cout, _lib.ptr(bias), _lib.ptr(y), _lib.ptr(stats), _lib.stream()),
                    "gcl_conv_fwd")

@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
                                                         int cin, int cout, const float* __restrict__ bias,
                                                         float* __restrict__ Y, int swizzle,
                                                         float* __restrict__ stats, const int* __restrict__ x_amax,
-                                                        const int* __restrict__ w_amax) {
+                                                        const int* __restrict__ w_amax, unsigned x_bytes) {
   constexpr int NPL = Prec<PL>::planes;
   constexpr int BLK = NB * 2 * NPL * 64;                // uint4 per (k, cc) weight block of this workgroup
   constexpr int BREG = (BLK + 255) / 256;
@@ -408,7 +408,9 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
   const float out_scale = (PL == 4) ? 1.f / (a_scale * amax_scale(w_amax)) : 1.f;   // exact: powers of two
   __shared__ __attribute__((aligned(16))) float Asm[4][32][LDS_STRIDE];   // wave-private A tiles
   __shared__ __attribute__((aligned(16))) u32x4 Bsm[2][BLK];              // weight block, double-buffered
-  __shared__ int Ism[4][27][32];                        // neighbour rows of the wave's tile: [wave][k][row] (K <= 27)
+  // neighbour rows of the wave's tile, [wave][k][(row & 7) * 4 + (row >> 3)] (K <= 27): the four rows a lane gathers
+  // (row, row + 8, row + 16, row + 24) are one 16-byte read
+  __shared__ __attribute__((aligned(16))) int Ism[4][27][32];
   __shared__ unsigned wmask[4];
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   const int i = l & 31, h = l >> 5;
@@ -446,7 +448,7 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
     int k = e >> 5, r = e & 31;
     int v = -1;
     if (active && row0 + r < n_out) v = tbl ? tbl[(long long)k * n_out + row0 + r] : (int)(row0 + r);
-    Ism[w][k][r] = v;
+    Ism[w][k][(r & 7) * 4 + (r >> 3)] = v;
   }
   __syncthreads();
   const unsigned wgmask = wmask[0] | wmask[1] | wmask[2] | wmask[3];
@@ -455,13 +457,18 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
   //   loads of step s+2 are issued at the end of step s and land in registers during step s+1,
   //   they are written to LDS at the end of step s+1 (A: wave-private tile; B: the buffer not being read),
   //   the barrier closing step s+1 publishes B(s+2).
+  // Gather through a buffer resource: a missing neighbour (row -1) wraps to a byte offset beyond the tensor and the
+  // hardware returns zeros -- no compare / branch / 64-bit address arithmetic per row (the loop is issue-bound)
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)x_bytes, 0x00020000);
+  const unsigned row_bytes = (unsigned)cin * 4u;
 #define GCL_GATHER_A(KK, CCV)                                                                                  \
   {                                                                                                            \
-    _Pragma("unroll") for (int ps = 0; ps < 4; ++ps) {                                                         \
-      int ridx = Ism[w][(KK)][rsub + 8 * ps];                                                                  \
-      st[ps] = make_float4(0.f, 0.f, 0.f, 0.f);                                                                \
-      if (ridx >= 0) st[ps] = *reinterpret_cast<const float4*>(X + (long long)ridx * cin + (CCV)*32 + p * 4);  \
-    }                                                                                                          \
+    const int4 ri_ = *reinterpret_cast<const int4*>(&Ism[w][(KK)][rsub * 4]);                                  \
+    const unsigned co_ = (unsigned)(CCV)*128u + (unsigned)p * 16u;                                             \
+    st[0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)((unsigned)ri_.x * row_bytes + co_), 0, 0)); \
+    st[1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)((unsigned)ri_.y * row_bytes + co_), 0, 0)); \
+    st[2] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)((unsigned)ri_.z * row_bytes + co_), 0, 0)); \
+    st[3] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)((unsigned)ri_.w * row_bytes + co_), 0, 0)); \
   }
 #define GCL_LOAD_B(KK, CCV)                                                                      \
   {                                                                                              \
@@ -1100,10 +1107,14 @@ int32_t gcl_conv_fwd_nb(int64_t n_out, int32_t cout, int32_t prec) {
   return conv_fwd_nb(n_out, cout, prec);
 }
 
-int gcl_conv_fwd(const float* x, const void* wp, int32_t prec, const int32_t* x_amax, const int32_t* w_amax,
-                 const int32_t* tbl, const int32_t* order, const int32_t* tile_mask, int64_t n_out, int32_t K,
-                 int32_t cin, int32_t cout, const float* bias, float* y, float* stats, void* stream) {
+int gcl_conv_fwd(const float* x, int64_t n_in, const void* wp, int32_t prec, const int32_t* x_amax,
+                 const int32_t* w_amax, const int32_t* tbl, const int32_t* order, const int32_t* tile_mask,
+                 int64_t n_out, int32_t K, int32_t cin, int32_t cout, const float* bias, float* y, float* stats,
+                 void* stream) {
   GCL_CHECK_ARG(x && wp && y, "gcl_conv_fwd: null pointer");
+  GCL_CHECK_ARG(n_in > 0 && (long long)n_in * cin * 4 < (1ll << 32) - (1ll << 20),
+                "gcl_conv_fwd: the input tensor must be non-empty and smaller than 4 GiB (buffer addressing)");
+  const unsigned x_bytes = (unsigned)((long long)n_in * cin * 4);
   GCL_CHECK_ARG(n_out > 0 && K >= 1 && K <= 27, "gcl_conv_fwd: n_out must be positive and 1 <= K <= 27");
   GCL_CHECK_ARG(tbl || K == 1, "gcl_conv_fwd: a neighbour table is required when K > 1");
   GCL_CHECK_ARG((order == nullptr) == (tile_mask == nullptr), "gcl_conv_fwd: order and tile_mask go together");
@@ -1129,7 +1140,7 @@ int gcl_conv_fwd(const float* x, const void* wp, int32_t prec, const int32_t* x_
                      (long long)n_out, K, cin, cout, bias, y, swz)
 #define LAUNCH_SPLIT(NBV, PLV)                                                                                   \
   hipLaunchKernelGGL((k_conv_fwd_split<NBV, PLV>), sgrid, dim3(256), 0, st, x, (const u32x4*)wp, tbl, order,     \
-                     tile_mask, (long long)n_out, K, cin, cout, bias, y, sswz, stats, x_amax, w_amax)
+                     tile_mask, (long long)n_out, K, cin, cout, bias, y, sswz, stats, x_amax, w_amax, x_bytes)
 #define LAUNCH_SPLIT_NB(PLV)                                                             \
   {                                                                                      \
     if (nb == 4) LAUNCH_SPLIT(4, PLV); else if (nb == 2) LAUNCH_SPLIT(2, PLV); else LAUNCH_SPLIT(1, PLV); \

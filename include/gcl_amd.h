@@ -144,6 +144,7 @@ int gcl_table_sort(const int32_t* tbl, int32_t K, int64_t n, int32_t window, int
  *           MFMA work of bf16x6); x_amax / w_amax are required in this mode only;
  *           wp = gcl_pack_weights_bytes(...) bytes of bf16 planes.  Cin, Cout multiples of 32.
  * gcl_conv_fwd: Y[row(j)] = sum_k X[tbl[k*n_out+j]] . Wp_k (+ bias); tbl == NULL means K == 1, identity.
+ *   X has n_in rows (n_in * Cin * 4 < 4 GiB: rows are gathered through a buffer resource, absent neighbours read 0).
  *   With (order, tile_mask) from gcl_table_sort, `tbl` is the PERMUTED table, row(j) = order[j] and each 32-row
  *   wave tile visits only the offsets of tile_mask; with NULLs, row(j) = j and every offset is visited.
  *   Output-stationary (no atomics, deterministic).  The same entry computes the input gradient when given
@@ -173,8 +174,9 @@ int gcl_pack_weights_multi(const int64_t* desc, int32_t n_tensors, int64_t total
 /* NB of the kernel instance gcl_conv_fwd will launch for this shape (a wave covers 32 NB output columns): 4, 2 or 1;
  * diagnostic (profile labels). */
 int32_t gcl_conv_fwd_nb(int64_t n_out, int32_t cout, int32_t prec);
-int gcl_conv_fwd(const float* x, const void* wp, int32_t prec, const int32_t* x_amax, const int32_t* w_amax,
-                 const int32_t* tbl, const int32_t* order, const int32_t* tile_mask, int64_t n_out, int32_t K,
+int gcl_conv_fwd(const float* x, int64_t n_in, const void* wp, int32_t prec, const int32_t* x_amax,
+                 const int32_t* w_amax, const int32_t* tbl, const int32_t* order, const int32_t* tile_mask,
+                 int64_t n_out, int32_t K,
                  int32_t cin, int32_t cout, const float* bias, float* y, float* stats, void* stream);
 
 /* dW[k] = sum over pairs of offset k of  A[pair_a]^T . B[pair_b]   (A: [*, ca], B: [*, cb]) -> dw [K, ca, cb].
