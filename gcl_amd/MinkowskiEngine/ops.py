@@ -328,7 +328,8 @@ class _SparseConvFn(torch.autograd.Function):
                 tile = f"{64 if cin % 64 == 0 else 32},{64 if cout % 64 == 0 else 32}"
                 name = f"k_conv_bwd_weight<{tile}>" if prec == 0 else f"k_conv_bwd_weight_split<{tile},{prec}>"
                 with _Timed(name, ctx.pairs, cin, cout):
-                    _lib.check(lib.gcl_conv_bwd_weight(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(pa), _lib.ptr(pb), seg_host,
+                    _lib.check(lib.gcl_conv_bwd_weight(_lib.ptr(x), x.shape[0], _lib.ptr(dy), dy.shape[0], _lib.ptr(pa),
+                                                       _lib.ptr(pb), seg_host,
                                                        K, cin, cout, prec, _lib.ptr(x_amax), _lib.ptr(dy_amax),
                                                        _lib.ptr(scratch), _lib.ptr(dW), _lib.stream()),
                                "gcl_conv_bwd_weight")

@@ -725,7 +725,8 @@ __global__ void __launch_bounds__(256) k_conv_bwd_weight_split(const float* __re
                                                                const int* __restrict__ pair_b, SegOffW seg, int K,
                                                                int ca, int cb, long long n_chunks, int per,
                                                                float* slabs, const int* __restrict__ a_amax,
-                                                               const int* __restrict__ b_amax, int n_wg_x, int n_tiles) {
+                                                               const int* __restrict__ b_amax, int n_wg_x, int n_tiles,
+                                                               unsigned a_bytes, unsigned b_bytes) {
   constexpr int NBI = TCA / 32, NBJ = TCB / 32;
   constexpr int PA = TCA / 4, PB = TCB / 4;         // 16-byte pieces per row
   constexpr int RA = 64 / PA, RB = 64 / PB;          // rows per load pass
@@ -785,17 +786,21 @@ __global__ void __launch_bounds__(256) k_conv_bwd_weight_split(const float* __re
   };
 
   float4 ga[NPA], gb[NPB];
+  // rows through buffer resources: a padding pair (row -1) wraps beyond the tensor and reads zeros (no branch, no
+  // 64-bit address arithmetic per row)
+  const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)b_bytes, 0x00020000);
+  const unsigned a_row = (unsigned)ca * 4u, b_row = (unsigned)cb * 4u;
+  const unsigned a_col = (unsigned)(ca0 + (l % PA) * 4) * 4u, b_col = (unsigned)(cb0 + (l % PB) * 4) * 4u;
 #define GCL_GATHER(IA, IB)                                                                              \
   {                                                                                                     \
     _Pragma("unroll") for (int ps = 0; ps < NPA; ++ps) {                                                \
-      int ridx = __shfl(IA, l / PA + RA * ps);                                                          \
-      ga[ps] = make_float4(0.f, 0.f, 0.f, 0.f);                                                         \
-      if (ridx >= 0) ga[ps] = *reinterpret_cast<const float4*>(A + (long long)ridx * ca + ca0 + (l % PA) * 4); \
+      unsigned ridx = (unsigned)__shfl(IA, l / PA + RA * ps);                                           \
+      ga[ps] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, (int)(ridx * a_row + a_col), 0, 0)); \
     }                                                                                                   \
     _Pragma("unroll") for (int ps = 0; ps < NPB; ++ps) {                                                \
-      int ridx = __shfl(IB, l / PB + RB * ps);                                                          \
-      gb[ps] = make_float4(0.f, 0.f, 0.f, 0.f);                                                         \
-      if (ridx >= 0) gb[ps] = *reinterpret_cast<const float4*>(B + (long long)ridx * cb + cb0 + (l % PB) * 4); \
+      unsigned ridx = (unsigned)__shfl(IB, l / PB + RB * ps);                                           \
+      gb[ps] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(brsrc, (int)(ridx * b_row + b_col), 0, 0)); \
     }                                                                                                   \
   }
 
@@ -1169,8 +1174,9 @@ int64_t gcl_conv_bwd_weight_scratch_len(int32_t K, int32_t ca, int32_t cb, int64
   return (long long)(bwd_weight_wgs(nc) + K) * ca * cb;
 }
 
-int gcl_conv_bwd_weight(const float* a, const float* b, const int32_t* pair_a, const int32_t* pair_b,
-                        const int64_t* seg_off_host, int32_t K, int32_t ca, int32_t cb, int32_t prec,
+int gcl_conv_bwd_weight(const float* a, int64_t n_a, const float* b, int64_t n_b, const int32_t* pair_a,
+                        const int32_t* pair_b, const int64_t* seg_off_host, int32_t K, int32_t ca, int32_t cb,
+                        int32_t prec,
                         const int32_t* a_amax, const int32_t* b_amax, float* scratch, float* dw, void* stream) {
   GCL_CHECK_ARG(a && b && pair_a && pair_b && seg_off_host && scratch && dw, "gcl_conv_bwd_weight: null pointer");
   GCL_CHECK_ARG(K >= 1 && K <= 125, "gcl_conv_bwd_weight: bad K");
@@ -1178,6 +1184,10 @@ int gcl_conv_bwd_weight(const float* a, const float* b, const int32_t* pair_a, c
                 "gcl_conv_bwd_weight: channel counts (%d, %d) must be positive multiples of 32", ca, cb);
   GCL_CHECK_ARG(prec_ok(prec), "gcl_conv_bwd_weight: prec must be 0, 2, 3 or 4");
   GCL_CHECK_ARG(prec != 4 || (a_amax && b_amax), "gcl_conv_bwd_weight: fp16x3 needs gcl_amax of both operands");
+  GCL_CHECK_ARG(n_a > 0 && n_b > 0 && (long long)n_a * ca * 4 < (1ll << 32) - (1ll << 20) &&
+                    (long long)n_b * cb * 4 < (1ll << 32) - (1ll << 20),
+                "gcl_conv_bwd_weight: operands must be non-empty and smaller than 4 GiB (buffer addressing)");
+  const unsigned a_bytes = (unsigned)((long long)n_a * ca * 4), b_bytes = (unsigned)((long long)n_b * cb * 4);
   hipStream_t st = (hipStream_t)stream;
   SegOffW seg;
   for (int k = 0; k <= K; ++k) seg.off[k] = seg_off_host[k];
@@ -1193,7 +1203,7 @@ int gcl_conv_bwd_weight(const float* a, const float* b, const int32_t* pair_a, c
     dim3 sgrid = stiles ? dim3((unsigned)(cdiv(W, 8) * 8 * stiles)) : grid;
 #define LAUNCH_BWS(TA, TB, PLV)                                                                                     \
   hipLaunchKernelGGL((k_conv_bwd_weight_split<TA, TB, PLV>), sgrid, dim3(256), 0, st, a, b, pair_a, pair_b, seg, K, \
-                     ca, cb, nc, per, scratch, a_amax, b_amax, W, stiles)
+                     ca, cb, nc, per, scratch, a_amax, b_amax, W, stiles, a_bytes, b_bytes)
 #define LAUNCH_BW(TA, TB)                                                                                          \
   {                                                                                                                \
     if (prec == 0)                                                                                                 \

@@ -183,11 +183,13 @@ int gcl_conv_fwd(const float* x, int64_t n_in, const void* wp, int32_t prec, con
  * Forward conv: A = X, pair_a = pair_in, B = dY, pair_b = pair_out.  Transposed conv: roles swapped.
  * Deterministic: per-wave partial slabs + ordered reduction.  prec as in gcl_conv_fwd (both operands are split
  * on the fly for prec 2 / 3).
+ * A has n_a rows, B n_b rows (each tensor < 4 GiB: rows are gathered through buffer resources, padding pairs read 0).
  * scratch: float[gcl_conv_bwd_weight_scratch_len(...)]. */
 int64_t gcl_conv_bwd_weight_scratch_len(int32_t K, int32_t ca, int32_t cb, int64_t n_pairs_padded);
-int gcl_conv_bwd_weight(const float* a, const float* b, const int32_t* pair_a, const int32_t* pair_b,
-                        const int64_t* seg_off_host, int32_t K, int32_t ca, int32_t cb, int32_t prec,
-                        const int32_t* a_amax, const int32_t* b_amax, float* scratch, float* dw, void* stream);
+int gcl_conv_bwd_weight(const float* a, int64_t n_a, const float* b, int64_t n_b, const int32_t* pair_a,
+                        const int32_t* pair_b, const int64_t* seg_off_host, int32_t K, int32_t ca, int32_t cb,
+                        int32_t prec, const int32_t* a_amax, const int32_t* b_amax, float* scratch, float* dw,
+                        void* stream);
 
 /* First layer (Cin <= 4, Cout == 32, any ks): VALU kernels over the nbr table. */
 int gcl_stem_fwd(const float* x, const float* w, const int32_t* nbr, int64_t n_out, int32_t K,
