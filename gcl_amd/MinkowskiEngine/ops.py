@@ -110,6 +110,27 @@ def tensor_amax(lib, t):
     return out
 
 
+PRESPLIT_MIN_C = int(os.environ.get("GCL_PRESPLIT_MIN_C", "128"))     # operands at least this wide are pre-split
+
+
+def planes_of(lib, t, amax):
+    """fp16x3 operand image of activation tensor ``t`` (gcl_split_planes), made once per tensor version and reused by
+    every launch that consumes it (forward + weight gradient, or input gradient + weight gradient)."""
+    tag = getattr(t, "_gcl_planes", None)
+    if tag is not None and tag[1] == t._version and tag[2] == _AMAX_EPOCH and tag[3] is amax:
+        return tag[0]
+    n, c = t.shape
+    planes = torch.empty((n, c), dtype=torch.int32, device=t.device)         # 4 bytes per element: hi | lo
+    _lib.check(lib.gcl_split_planes(_lib.ptr(t, torch.float32), n, c, _lib.ptr(amax), _lib.ptr(planes),
+                                    _lib.stream()), "gcl_split_planes")
+    t._gcl_planes = (planes, t._version, _AMAX_EPOCH, amax)
+    return planes
+
+
+def _want_planes(c):
+    return PRECISION == "fp16x3" and c >= PRESPLIT_MIN_C and c % 32 == 0
+
+
 class WeightAmaxGroup:
     """All convolution kernels of a network, refreshed together once per optimizer step: gcl_amax of every tensor in
     ONE launch (gcl_amax_multi) and the MFMA-order weight packs of a direction in ONE launch each
@@ -194,7 +215,7 @@ def ctypes_offset(t, elem):
 
 
 def _conv_launch(lib, x, Wk, mode, table, n_out, cin, cout, bias, pairs=0, want_stats=False, x_amax=None,
-                 w_amax=None, wp=None):
+                 w_amax=None, wp=None, x_planes=None):
     """One output-stationary convolution launch.  ``Wk`` [K, *, *] is packed for ``mode`` (0 forward, 1 transposed,
     2 transposed + mirrored offsets) in the current precision; ``table`` = (tbl, order, tile_mask) from
     KernelMap.sorted_table(), or None for a kernel_size-1 conv; (cin, cout) are the EFFECTIVE widths of the launch.
@@ -218,7 +239,8 @@ def _conv_launch(lib, x, Wk, mode, table, n_out, cin, cout, bias, pairs=0, want_
         nb = lib.gcl_conv_fwd_nb(n_out, cout, prec)
         name = f"k_conv_fwd<{nb}>" if prec == 0 else f"k_conv_fwd_split<{nb},{prec}>"
     with _Timed(name, pairs, cin, cout):
-        _lib.check(lib.gcl_conv_fwd(_lib.ptr(x, torch.float32), x.shape[0], _lib.ptr(wp), prec, _lib.ptr(x_amax),
+        xin, is_planes = (x_planes, 1) if x_planes is not None else (x, 0)
+        _lib.check(lib.gcl_conv_fwd(_lib.ptr(xin), x.shape[0], is_planes, _lib.ptr(wp), prec, _lib.ptr(x_amax),
                                     _lib.ptr(w_amax), _lib.ptr(tbl), _lib.ptr(order), _lib.ptr(tile_mask), n_out, K,
                                     cin, cout, _lib.ptr(bias), _lib.ptr(y), _lib.ptr(stats), _lib.stream()),
                    "gcl_conv_fwd")
@@ -262,10 +284,11 @@ class _SparseConvFn(torch.autograd.Function):
                 group.bwd_modes[W._gcl_group_index] = 2 if (kmap is not None and not transpose and kmap.same_map) else 1
                 wp = group.packed(lib, W, 0)
             ctx.group, ctx.param = group, (W if group is not None else None)
+            xp = planes_of(lib, x, ctx.x_amax) if (fp16x3 and _want_planes(cin)) else None
             y, stats = _conv_launch(lib, x, Wk, 0, tbl, n_out, cin, cout, b, ctx.pairs, want_stats=True,
-                                    x_amax=ctx.x_amax, w_amax=ctx.w_amax, wp=wp) \
+                                    x_amax=ctx.x_amax, w_amax=ctx.w_amax, wp=wp, x_planes=xp) \
                 if want_stats else (_conv_launch(lib, x, Wk, 0, tbl, n_out, cin, cout, b, ctx.pairs,
-                                                 x_amax=ctx.x_amax, w_amax=ctx.w_amax, wp=wp), None)
+                                                 x_amax=ctx.x_amax, w_amax=ctx.w_amax, wp=wp, x_planes=xp), None)
         ctx.save_for_backward(x, Wk)
         ctx.set_materialize_grads(False)       # no zero-filled gradient for the (non-differentiable) statistics output
         ctx.kmap, ctx.transpose, ctx.mgr, ctx.w_shape, ctx.has_bias = kmap, transpose, mgr, W.shape, bias is not None
@@ -306,8 +329,9 @@ class _SparseConvFn(torch.autograd.Function):
                 mode, tbl = 1, kmap.sorted_table(transposed=True)
             group = getattr(ctx, "group", None)
             wp = group.packed(lib, ctx.param, mode) if group is not None else None
+            dyp = planes_of(lib, dy, dy_amax) if (prec == 4 and _want_planes(cout)) else None
             dx = _conv_launch(lib, dy, Wk, mode, tbl, x.shape[0], cout, cin, None, ctx.pairs, x_amax=dy_amax,
-                              w_amax=w_amax, wp=wp)
+                              w_amax=w_amax, wp=wp, x_planes=dyp)
         if ctx.needs_input_grad[1]:
             dW = torch.empty_like(Wk)
             if ctx.stem:
@@ -328,8 +352,11 @@ class _SparseConvFn(torch.autograd.Function):
                 tile = f"{64 if cin % 64 == 0 else 32},{64 if cout % 64 == 0 else 32}"
                 name = f"k_conv_bwd_weight<{tile}>" if prec == 0 else f"k_conv_bwd_weight_split<{tile},{prec}>"
                 with _Timed(name, ctx.pairs, cin, cout):
-                    _lib.check(lib.gcl_conv_bwd_weight(_lib.ptr(x), x.shape[0], _lib.ptr(dy), dy.shape[0], _lib.ptr(pa),
-                                                       _lib.ptr(pb), seg_host,
+                    use_pl = prec == 4 and _want_planes(cin) and _want_planes(cout)
+                    xa = planes_of(lib, x, x_amax) if use_pl else x
+                    ya = planes_of(lib, dy, dy_amax) if use_pl else dy
+                    _lib.check(lib.gcl_conv_bwd_weight(_lib.ptr(xa), x.shape[0], _lib.ptr(ya), dy.shape[0], int(use_pl),
+                                                       _lib.ptr(pa), _lib.ptr(pb), seg_host,
                                                        K, cin, cout, prec, _lib.ptr(x_amax), _lib.ptr(dy_amax),
                                                        _lib.ptr(scratch), _lib.ptr(dW), _lib.stream()),
                                "gcl_conv_bwd_weight")

@@ -322,6 +322,31 @@ __global__ void __launch_bounds__(256) k_amax_multi(const float* const* __restri
                       __float_as_int(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))), blockIdx.x);
 }
 
+// fp32 [n, c] -> fp16 plane image [n][c / 32][2][32]: hi = fp16(x s), lo = fp16(x s - hi), s from the tensor's amax
+// slot.  One thread per 4 channels (16-byte read, two 8-byte writes).
+__global__ void __launch_bounds__(256) k_split_planes(const float4* __restrict__ x, long long total4, int c,
+                                                      const int* __restrict__ amax, unsigned short* __restrict__ planes) {
+  const float s = amax_scale(amax);
+  const int q_per_row = c >> 2;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total4;
+       e += (long long)gridDim.x * blockDim.x) {
+    const float4 v = x[e];
+    const long long row = e / q_per_row;
+    const int col = (int)(e % q_per_row) * 4;            // first channel of this quad
+    typedef _Float16 f16x4_ __attribute__((ext_vector_type(4)));
+    const float sv[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
+    f16x4_ h, lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      h[j] = (_Float16)sv[j];
+      lo[j] = (_Float16)(sv[j] - (float)h[j]);
+    }
+    unsigned short* base = planes + (row * c + (long long)(col >> 5) * 32) * 2 + (col & 31);   // hi of this slice
+    *reinterpret_cast<f16x4_*>(base) = h;
+    *reinterpret_cast<f16x4_*>(base + 32) = lo;
+  }
+}
+
 // wp16 (8 x 16-bit units): [(((k*CC + cc)*TNB + nb)*2 + m)*planes + pl][lane = h*32 + j][jj]
 //                         = plane pl of W_eff[k][cc*32 + 16m + 8h + jj][32 nb + j]   (fp16 mode: of W_eff * scale)
 template <int PL>
@@ -393,7 +418,11 @@ __global__ void __launch_bounds__(256) k_pack_weights_multi(const PackDesc* __re
                      amax_slots + d.amax_index * AMAX_WORDS, reinterpret_cast<unsigned short*>(out + d.out_off), o);
 }
 
-template <int NB, int PL>
+// PRE: X is not the fp32 tensor but its fp16 plane image made by gcl_split_planes -- per row and 32-channel slice
+// 64 bytes of hi followed by 64 bytes of lo, i.e. the same 128 bytes per (row, slice) and the same addressing as the
+// fp32 rows.  The main loop then has no split at all (the kernels are instruction-issue-bound: the split was 48 of ~120
+// instructions per step), a fragment is two 16-byte LDS reads.
+template <int NB, int PL, bool PRE = false>
 __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict__ X, const u32x4* __restrict__ Wp,
                                                         const int* __restrict__ tbl, const int* __restrict__ order,
                                                         const int* __restrict__ tile_mask, long long n_out, int K,
@@ -529,10 +558,15 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
         WAVE_FENCE();
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-          float4 f0 = *reinterpret_cast<const float4*>(&Asm[w][i][16 * m + 8 * h]);
-          float4 f1 = *reinterpret_cast<const float4*>(&Asm[w][i][16 * m + 8 * h + 4]);
           u32x4 ap[3];
-          split8<PL>(f0, f1, a_scale, ap);
+          if (PRE) {   // row image: dwords [0,16) = hi of channels 0..31, [16,32) = lo
+            ap[0] = *reinterpret_cast<const u32x4*>(&Asm[w][i][8 * m + 4 * h]);
+            ap[1] = *reinterpret_cast<const u32x4*>(&Asm[w][i][16 + 8 * m + 4 * h]);
+          } else {
+            float4 f0 = *reinterpret_cast<const float4*>(&Asm[w][i][16 * m + 8 * h]);
+            float4 f1 = *reinterpret_cast<const float4*>(&Asm[w][i][16 * m + 8 * h + 4]);
+            split8<PL>(f0, f1, a_scale, ap);
+          }
 #pragma unroll
           for (int b = 0; b < NB; ++b) {
             const u32x4* bb = &Bsm[buf][((b * 2 + m) * NPL) * 64 + l];
@@ -716,10 +750,64 @@ __global__ void __launch_bounds__(256) k_conv_bwd_weight(const float* __restrict
   flush(kcur);
 }
 
+// ---- weight gradient on PRE-SPLIT operands (fp16 plane images from gcl_split_planes) -----------------------------
+// dW = A^T B wants K-major fragments (8 consecutive PAIRS of one channel per lane) while rows are channel-major.  With
+// fp32 rows that is 8 scalar LDS reads + a split per fragment; with plane images the gathered 16-byte pieces are copied
+// into LDS unchanged and a fragment is two hardware-transposed 8-byte reads per plane (gfx950 ds_read_b64_tr_b16):
+// no VALU work at all between the gather and the MFMA.  LDS row image = the row's TC * 4 bytes, 32-byte blocks
+// [slice][plane][16-channel half] XOR-swizzled with the row so that the 4 rows x 2 column halves a 32-lane half reads
+// hit 64 different banks.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+template <int IMM>
+__device__ __forceinline__ u32x2 lds_read_tr16(unsigned base) {      // one base VGPR, compile-time byte offset
+  u32x2 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(base), "n"(IMM) : "memory");
+  return r;
+}
+template <int TC>
+__device__ __forceinline__ int tr_swz(int row) { return (TC == 64) ? ((row & 3) << 1) : (((row >> 1) & 1) << 1); }
+// both planes of the fragment of 32-channel slice (base addresses precomputed per lane) for the 16-pair half HALF
+template <int TC, int HALF>
+__device__ __forceinline__ void tr_fragment(unsigned base_hi, unsigned base_lo, u32x4* f) {
+  constexpr int ROWB = TC * 4;
+  u32x2 h0 = lds_read_tr16<(16 * HALF) * ROWB>(base_hi), h1 = lds_read_tr16<(16 * HALF + 4) * ROWB>(base_hi);
+  u32x2 l0 = lds_read_tr16<(16 * HALF) * ROWB>(base_lo), l1 = lds_read_tr16<(16 * HALF + 4) * ROWB>(base_lo);
+  f[0] = u32x4{h0.x, h0.y, h1.x, h1.y};
+  f[1] = u32x4{l0.x, l0.y, l1.x, l1.y};
+}
+template <int TCA, int TCB, int HALF>
+__device__ __forceinline__ void tr_mma_half(const unsigned (*baseA)[2], const unsigned (*baseB)[2],
+                                            f32x16 (&acc)[TCA / 32][TCB / 32]) {
+  constexpr int NBI = TCA / 32, NBJ = TCB / 32;
+  u32x4 fa[NBI][2], fb[NBJ][2];
+#pragma unroll
+  for (int a = 0; a < NBI; ++a) tr_fragment<TCA, HALF>(baseA[a][0], baseA[a][1], fa[a]);
+#pragma unroll
+  for (int b = 0; b < NBJ; ++b) tr_fragment<TCB, HALF>(baseB[b][0], baseB[b][1], fb[b]);
+  // the asm reads complete asynchronously and the compiler does not know: wait, then pin every fragment behind the
+  // wait with an empty asm (volatile asms keep their order) so that no MFMA is scheduled above it
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int a = 0; a < NBI; ++a) {
+    asm volatile("" : "+v"(fa[a][0]));
+    asm volatile("" : "+v"(fa[a][1]));
+  }
+#pragma unroll
+  for (int b = 0; b < NBJ; ++b) {
+    asm volatile("" : "+v"(fb[b][0]));
+    asm volatile("" : "+v"(fb[b][1]));
+  }
+#pragma unroll
+  for (int b = 0; b < NBJ; ++b)
+#pragma unroll
+    for (int a = 0; a < NBI; ++a) mfma_terms<4>(fa[a], fb[b], acc[a][b]);
+}
+
 // split-precision weight gradient: both operands are gathered activations, split on the fly into PL bf16 planes.
 // Same decomposition as k_conv_bwd_weight (wave-private LDS tiles, per-wave slabs, no workgroup barrier), plus a
 // two-deep software pipeline: pair indices are fetched two chunks ahead and rows one chunk ahead of their use.
-template <int TCA, int TCB, int PL>
+// PRE (PL == 4 only): A and B point at plane images; see above.
+template <int TCA, int TCB, int PL, bool PRE = false>
 __global__ void __launch_bounds__(256) k_conv_bwd_weight_split(const float* __restrict__ A, const float* __restrict__ B,
                                                                const int* __restrict__ pair_a,
                                                                const int* __restrict__ pair_b, SegOffW seg, int K,
@@ -738,6 +826,26 @@ __global__ void __launch_bounds__(256) k_conv_bwd_weight_split(const float* __re
   float (*Bs)[32][TCB] = reinterpret_cast<float (*)[32][TCB]>(lds_all + 4 * 32 * TCA);
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = l & 31, h = l >> 5;
+  // PRE: wave-private row images (same bytes as the fp32 tiles); lane 16 g + 4 q + p of a transposed read supplies
+  // row q (+ 8 in the upper half of the wave), 16-channel half g & 1, 8-byte piece p
+  unsigned char* const imgA = reinterpret_cast<unsigned char*>(&As[w][0][0]);
+  unsigned char* const imgB = reinterpret_cast<unsigned char*>(&Bs[w][0][0]);
+  unsigned trA[NBI][2], trB[NBJ][2];
+  if (PRE) {
+    const unsigned ldsA = (unsigned)(unsigned long long)((__attribute__((address_space(3))) unsigned char*)imgA);
+    const unsigned ldsB = (unsigned)(unsigned long long)((__attribute__((address_space(3))) unsigned char*)imgB);
+    const int q = (l & 15) >> 2, pp = l & 3, c16 = (l >> 4) & 1, trow = 8 * (l >> 5) + q;
+#pragma unroll
+    for (int a = 0; a < NBI; ++a)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+        trA[a][pl] = ldsA + trow * (TCA * 4) + (((a * 4 + pl * 2 + c16) ^ tr_swz<TCA>(q)) * 32) + pp * 8;
+#pragma unroll
+    for (int b = 0; b < NBJ; ++b)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+        trB[b][pl] = ldsB + trow * (TCB * 4) + (((b * 4 + pl * 2 + c16) ^ tr_swz<TCB>(q)) * 32) + pp * 8;
+  }
   // XCD-aware launch order (1-D grid): workgroups are dealt round-robin to the 8 XCDs, so the n_tiles channel tiles
   // that re-read the SAME pair range are given consecutive slots of ONE XCD and share its L2
   int bx, by;
@@ -817,16 +925,34 @@ __global__ void __launch_bounds__(256) k_conv_bwd_weight_split(const float* __re
       while (seg.off[kcur + 1] <= pbase) ++kcur;
     }
     WAVE_FENCE();
+    if (PRE) {   // 16-byte pieces go to LDS unchanged, 32-byte blocks swizzled with the row
 #pragma unroll
-    for (int ps = 0; ps < NPA; ++ps) *reinterpret_cast<float4*>(&As[w][l / PA + RA * ps][(l % PA) * 4]) = ga[ps];
+      for (int ps = 0; ps < NPA; ++ps) {
+        const int row = l / PA + RA * ps, pc = l % PA;
+        *reinterpret_cast<float4*>(imgA + row * (TCA * 4) + (((pc >> 1) ^ tr_swz<TCA>(row)) * 32) + (pc & 1) * 16) = ga[ps];
+      }
 #pragma unroll
-    for (int ps = 0; ps < NPB; ++ps) *reinterpret_cast<float4*>(&Bs[w][l / PB + RB * ps][(l % PB) * 4]) = gb[ps];
+      for (int ps = 0; ps < NPB; ++ps) {
+        const int row = l / PB + RB * ps, pc = l % PB;
+        *reinterpret_cast<float4*>(imgB + row * (TCB * 4) + (((pc >> 1) ^ tr_swz<TCB>(row)) * 32) + (pc & 1) * 16) = gb[ps];
+      }
+    } else {
+#pragma unroll
+      for (int ps = 0; ps < NPA; ++ps) *reinterpret_cast<float4*>(&As[w][l / PA + RA * ps][(l % PA) * 4]) = ga[ps];
+#pragma unroll
+      for (int ps = 0; ps < NPB; ++ps) *reinterpret_cast<float4*>(&Bs[w][l / PB + RB * ps][(l % PB) * 4]) = gb[ps];
+    }
     // rows of chunk c+1 (indices arrived a chunk ago), indices of chunk c+2
     ia1 = ia2;
     ib1 = ib2;
     if (c + 1 < c1) GCL_GATHER(ia1, ib1);
     load_pairs(c + 2, ia2, ib2);
     WAVE_FENCE();
+    if (PRE) {
+      tr_mma_half<TCA, TCB, 0>(trA, trB, acc);
+      tr_mma_half<TCA, TCB, 1>(trA, trB, acc);
+      continue;
+    }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       u32x4 pa[NBI][3];
@@ -1068,6 +1194,18 @@ int gcl_amax_multi(const float* const* ptrs, const int64_t* sizes, int32_t n_ten
   return GCL_OK;
 }
 
+int gcl_split_planes(const float* x, int64_t n, int32_t c, const int32_t* amax, void* planes, void* stream) {
+  GCL_CHECK_ARG(x && amax && planes, "gcl_split_planes: null pointer");
+  GCL_CHECK_ARG(n > 0 && c > 0 && c % 32 == 0, "gcl_split_planes: c must be a positive multiple of 32");
+  long long total4 = n * (c / 4);
+  long long g = cdiv(total4, 256);
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(k_split_planes, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const float4*)x, total4, c,
+                     amax, (unsigned short*)planes);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
 int gcl_pack_weights(const float* w, int32_t K, int32_t cin, int32_t cout, int32_t mode, int32_t prec,
                      const int32_t* w_amax, void* wp, void* stream) {
   GCL_CHECK_ARG(w && wp, "gcl_pack_weights: null pointer");
@@ -1112,7 +1250,7 @@ int32_t gcl_conv_fwd_nb(int64_t n_out, int32_t cout, int32_t prec) {
   return conv_fwd_nb(n_out, cout, prec);
 }
 
-int gcl_conv_fwd(const float* x, int64_t n_in, const void* wp, int32_t prec, const int32_t* x_amax,
+int gcl_conv_fwd(const float* x, int64_t n_in, int32_t x_is_planes, const void* wp, int32_t prec, const int32_t* x_amax,
                  const int32_t* w_amax, const int32_t* tbl, const int32_t* order, const int32_t* tile_mask,
                  int64_t n_out, int32_t K, int32_t cin, int32_t cout, const float* bias, float* y, float* stats,
                  void* stream) {
@@ -1128,6 +1266,7 @@ int gcl_conv_fwd(const float* x, int64_t n_in, const void* wp, int32_t prec, con
   GCL_CHECK_ARG(prec_ok(prec), "gcl_conv_fwd: prec must be 0 (f32), 2 (bf16x3), 3 (bf16x6) or 4 (fp16x3)");
   GCL_CHECK_ARG(!stats || prec != 0, "gcl_conv_fwd: fused BN statistics need a split-precision mode");
   GCL_CHECK_ARG(prec != 4 || (x_amax && w_amax), "gcl_conv_fwd: fp16x3 needs gcl_amax of x and of the weights");
+  GCL_CHECK_ARG(!x_is_planes || prec == 4, "gcl_conv_fwd: plane images are the fp16x3 operand format");
   hipStream_t st = (hipStream_t)stream;
   static const int swz = [] {   // tuning knob, default off (measured: -5 % with the global sort, +7 % with the windowed sort)
     const char* e = getenv("GCL_XCD_SWIZZLE");
@@ -1144,8 +1283,16 @@ int gcl_conv_fwd(const float* x, int64_t n_in, const void* wp, int32_t prec, con
   hipLaunchKernelGGL(k_conv_fwd<NBV>, grid, dim3(256), 0, st, x, (const float4*)wp, tbl, order, tile_mask,       \
                      (long long)n_out, K, cin, cout, bias, y, swz)
 #define LAUNCH_SPLIT(NBV, PLV)                                                                                   \
-  hipLaunchKernelGGL((k_conv_fwd_split<NBV, PLV>), sgrid, dim3(256), 0, st, x, (const u32x4*)wp, tbl, order,     \
-                     tile_mask, (long long)n_out, K, cin, cout, bias, y, sswz, stats, x_amax, w_amax, x_bytes)
+  do {                                                                                                           \
+    if (PLV == 4 && x_is_planes)                                                                                 \
+      hipLaunchKernelGGL((k_conv_fwd_split<NBV, 4, true>), sgrid, dim3(256), 0, st, x, (const u32x4*)wp, tbl,    \
+                         order, tile_mask, (long long)n_out, K, cin, cout, bias, y, sswz, stats, x_amax, w_amax, \
+                         x_bytes);                                                                               \
+    else                                                                                                         \
+      hipLaunchKernelGGL((k_conv_fwd_split<NBV, PLV>), sgrid, dim3(256), 0, st, x, (const u32x4*)wp, tbl, order, \
+                         tile_mask, (long long)n_out, K, cin, cout, bias, y, sswz, stats, x_amax, w_amax,        \
+                         x_bytes);                                                                               \
+  } while (0)
 #define LAUNCH_SPLIT_NB(PLV)                                                             \
   {                                                                                      \
     if (nb == 4) LAUNCH_SPLIT(4, PLV); else if (nb == 2) LAUNCH_SPLIT(2, PLV); else LAUNCH_SPLIT(1, PLV); \
@@ -1174,9 +1321,9 @@ int64_t gcl_conv_bwd_weight_scratch_len(int32_t K, int32_t ca, int32_t cb, int64
   return (long long)(bwd_weight_wgs(nc) + K) * ca * cb;
 }
 
-int gcl_conv_bwd_weight(const float* a, int64_t n_a, const float* b, int64_t n_b, const int32_t* pair_a,
-                        const int32_t* pair_b, const int64_t* seg_off_host, int32_t K, int32_t ca, int32_t cb,
-                        int32_t prec,
+int gcl_conv_bwd_weight(const float* a, int64_t n_a, const float* b, int64_t n_b, int32_t planes,
+                        const int32_t* pair_a, const int32_t* pair_b, const int64_t* seg_off_host, int32_t K,
+                        int32_t ca, int32_t cb, int32_t prec,
                         const int32_t* a_amax, const int32_t* b_amax, float* scratch, float* dw, void* stream) {
   GCL_CHECK_ARG(a && b && pair_a && pair_b && seg_off_host && scratch && dw, "gcl_conv_bwd_weight: null pointer");
   GCL_CHECK_ARG(K >= 1 && K <= 125, "gcl_conv_bwd_weight: bad K");
@@ -1184,6 +1331,7 @@ int gcl_conv_bwd_weight(const float* a, int64_t n_a, const float* b, int64_t n_b
                 "gcl_conv_bwd_weight: channel counts (%d, %d) must be positive multiples of 32", ca, cb);
   GCL_CHECK_ARG(prec_ok(prec), "gcl_conv_bwd_weight: prec must be 0, 2, 3 or 4");
   GCL_CHECK_ARG(prec != 4 || (a_amax && b_amax), "gcl_conv_bwd_weight: fp16x3 needs gcl_amax of both operands");
+  GCL_CHECK_ARG(!planes || prec == 4, "gcl_conv_bwd_weight: plane images are the fp16x3 operand format");
   GCL_CHECK_ARG(n_a > 0 && n_b > 0 && (long long)n_a * ca * 4 < (1ll << 32) - (1ll << 20) &&
                     (long long)n_b * cb * 4 < (1ll << 32) - (1ll << 20),
                 "gcl_conv_bwd_weight: operands must be non-empty and smaller than 4 GiB (buffer addressing)");
@@ -1211,6 +1359,9 @@ int gcl_conv_bwd_weight(const float* a, int64_t n_a, const float* b, int64_t n_b
                          nc, per, scratch);                                                                        \
     else if (prec == 2) LAUNCH_BWS(TA, TB, 2);                                                                     \
     else if (prec == 3) LAUNCH_BWS(TA, TB, 3);                                                                     \
+    else if (planes)                                                                                               \
+      hipLaunchKernelGGL((k_conv_bwd_weight_split<TA, TB, 4, true>), sgrid, dim3(256), 0, st, a, b, pair_a, pair_b, \
+                         seg, K, ca, cb, nc, per, scratch, a_amax, b_amax, W, stiles, a_bytes, b_bytes);           \
     else LAUNCH_BWS(TA, TB, 4);                                                                                    \
   }
     if (tca == 64 && tcb == 64) LAUNCH_BW(64, 64)

@@ -144,6 +144,7 @@ int gcl_table_sort(const int32_t* tbl, int32_t K, int64_t n, int32_t window, int
  *           MFMA work of bf16x6); x_amax / w_amax are required in this mode only;
  *           wp = gcl_pack_weights_bytes(...) bytes of bf16 planes.  Cin, Cout multiples of 32.
  * gcl_conv_fwd: Y[row(j)] = sum_k X[tbl[k*n_out+j]] . Wp_k (+ bias); tbl == NULL means K == 1, identity.
+ *   x_is_planes != 0 (prec 4 only): x points at the gcl_split_planes image of X instead of X (no split in the kernel).
  *   X has n_in rows (n_in * Cin * 4 < 4 GiB: rows are gathered through a buffer resource, absent neighbours read 0).
  *   With (order, tile_mask) from gcl_table_sort, `tbl` is the PERMUTED table, row(j) = order[j] and each 32-row
  *   wave tile visits only the offsets of tile_mask; with NULLs, row(j) = j and every offset is visited.
@@ -174,7 +175,11 @@ int gcl_pack_weights_multi(const int64_t* desc, int32_t n_tensors, int64_t total
 /* NB of the kernel instance gcl_conv_fwd will launch for this shape (a wave covers 32 NB output columns): 4, 2 or 1;
  * diagnostic (profile labels). */
 int32_t gcl_conv_fwd_nb(int64_t n_out, int32_t cout, int32_t prec);
-int gcl_conv_fwd(const float* x, int64_t n_in, const void* wp, int32_t prec, const int32_t* x_amax,
+/* fp16x3 operand image of an activation tensor: planes = uint16 [n][c / 32][2][32] -- per row and 32-channel slice the
+ * fp16 hi values (64 bytes) then the fp16 lo values (64 bytes) of x * scale(amax), i.e. 4 bytes per element like x.
+ * A tensor that several launches consume (forward, weight gradient; input gradient, weight gradient) is split once. */
+int gcl_split_planes(const float* x, int64_t n, int32_t c, const int32_t* amax, void* planes, void* stream);
+int gcl_conv_fwd(const float* x, int64_t n_in, int32_t x_is_planes, const void* wp, int32_t prec, const int32_t* x_amax,
                  const int32_t* w_amax, const int32_t* tbl, const int32_t* order, const int32_t* tile_mask,
                  int64_t n_out, int32_t K,
                  int32_t cin, int32_t cout, const float* bias, float* y, float* stats, void* stream);
@@ -183,12 +188,13 @@ int gcl_conv_fwd(const float* x, int64_t n_in, const void* wp, int32_t prec, con
  * Forward conv: A = X, pair_a = pair_in, B = dY, pair_b = pair_out.  Transposed conv: roles swapped.
  * Deterministic: per-wave partial slabs + ordered reduction.  prec as in gcl_conv_fwd (both operands are split
  * on the fly for prec 2 / 3).
+ * planes != 0 (prec 4 only): a AND b point at gcl_split_planes images (no split, hardware-transposed LDS reads).
  * A has n_a rows, B n_b rows (each tensor < 4 GiB: rows are gathered through buffer resources, padding pairs read 0).
  * scratch: float[gcl_conv_bwd_weight_scratch_len(...)]. */
 int64_t gcl_conv_bwd_weight_scratch_len(int32_t K, int32_t ca, int32_t cb, int64_t n_pairs_padded);
-int gcl_conv_bwd_weight(const float* a, int64_t n_a, const float* b, int64_t n_b, const int32_t* pair_a,
-                        const int32_t* pair_b, const int64_t* seg_off_host, int32_t K, int32_t ca, int32_t cb,
-                        int32_t prec, const int32_t* a_amax, const int32_t* b_amax, float* scratch, float* dw,
+int gcl_conv_bwd_weight(const float* a, int64_t n_a, const float* b, int64_t n_b, int32_t planes,
+                        const int32_t* pair_a, const int32_t* pair_b, const int64_t* seg_off_host, int32_t K,
+                        int32_t ca, int32_t cb, int32_t prec, const int32_t* a_amax, const int32_t* b_amax, float* scratch, float* dw,
                         void* stream);
 
 /* First layer (Cin <= 4, Cout == 32, any ks): VALU kernels over the nbr table. */
