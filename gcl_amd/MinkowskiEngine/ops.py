@@ -237,7 +237,8 @@ def _conv_launch(lib, x, Wk, mode, table, n_out, cin, cout, bias, pairs=0, want_
     name = None
     if PROFILE is not None:
         nb = lib.gcl_conv_fwd_nb(n_out, cout, prec)
-        name = f"k_conv_fwd<{nb}>" if prec == 0 else f"k_conv_fwd_split<{nb},{prec}>"
+        pre = "true" if x_planes is not None else "false"
+        name = f"k_conv_fwd<{nb}>" if prec == 0 else f"k_conv_fwd_split<{nb},{prec},{pre}>"
     with _Timed(name, pairs, cin, cout):
         xin, is_planes = (x_planes, 1) if x_planes is not None else (x, 0)
         _lib.check(lib.gcl_conv_fwd(_lib.ptr(xin), x.shape[0], is_planes, _lib.ptr(wp), prec, _lib.ptr(x_amax),
@@ -350,9 +351,10 @@ class _SparseConvFn(torch.autograd.Function):
                 scratch = torch.empty(lib.gcl_conv_bwd_weight_scratch_len(K, cin, cout, seg[-1]), dtype=torch.float32,
                                       device=x.device)
                 tile = f"{64 if cin % 64 == 0 else 32},{64 if cout % 64 == 0 else 32}"
-                name = f"k_conv_bwd_weight<{tile}>" if prec == 0 else f"k_conv_bwd_weight_split<{tile},{prec}>"
+                use_pl = prec == 4 and _want_planes(cin) and _want_planes(cout)
+                name = f"k_conv_bwd_weight<{tile}>" if prec == 0 else \
+                    f"k_conv_bwd_weight_split<{tile},{prec},{'true' if use_pl else 'false'}>"
                 with _Timed(name, ctx.pairs, cin, cout):
-                    use_pl = prec == 4 and _want_planes(cin) and _want_planes(cout)
                     xa = planes_of(lib, x, x_amax) if use_pl else x
                     ya = planes_of(lib, dy, dy_amax) if use_pl else dy
                     _lib.check(lib.gcl_conv_bwd_weight(_lib.ptr(xa), x.shape[0], _lib.ptr(ya), dy.shape[0], int(use_pl),
