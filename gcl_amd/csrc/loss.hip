@@ -164,6 +164,151 @@ __global__ void __launch_bounds__(64) k_group_loss_bwd(const float* __restrict__
   }
 }
 
+// ---- location_circle_loss (lib/colocation_trainer.py:538-681): per-group terms, one wave per selected group ----
+//   term(v) = softplus(logsumexp_i(S v_i max(v_i, 0).detach())) / S,  S = log_scale = 16
+//   pos:    v_i = dist(mean, f_i) - pos_thresh / 2 over all members                       (:607-618)
+//           (GL_PAIR: softplus(dist(f_a, f_b) - pos_thresh), :597-605)
+//   finest: v_i = dist(f_i, f_t) - finest_thresh over all members, or over the non-finest members with f_t detached
+//           (GL_BLOCK)                                                                     (:620-640)
+//   dist = squared distance, or sqrt(. + 1e-7) with GL_SQRT.  Also writes the group's mean feature (:585) for the
+//   negative term, which the host forms on the [M, M] matrices of group means.
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }   // torch threshold 20
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+
+// v of member j for the positive (WHICH = 0) or finest (WHICH = 1) term; `use` = whether the member takes part
+__device__ __forceinline__ float circle_v(int which, const float* __restrict__ f, int c, long long row, int lane,
+                                          const GroupStats& g, int flags, float thresh, bool is_finest, bool& use) {
+  const float fj = (lane < c) ? f[row * c + lane] : 0.f;
+  const float d = (lane < c) ? (which == 0 ? g.mean - fj : fj - g.ft) : 0.f;
+  const float d2 = wave_sum(d * d);
+  use = which == 0 || !((flags & GL_BLOCK) && is_finest);
+  return ((flags & GL_SQRT) ? sqrtf(d2 + 1e-7f) : d2) - thresh;
+}
+
+// logsumexp over the members of S v max(v, 0) (empty set: -inf, like torch)
+__device__ __forceinline__ float circle_lse(int which, const float* __restrict__ f, int c,
+                                            const long long* __restrict__ index,
+                                            const unsigned char* __restrict__ flag, long long b, long long e, int lane,
+                                            const GroupStats& g, int flags, float thresh, float S) {
+  float mx = -INFINITY;
+  for (long long j = b; j < e; ++j) {
+    bool use;
+    const float v = circle_v(which, f, c, index[j], lane, g, flags, thresh, flag[j] != 0, use);
+    if (use) mx = fmaxf(mx, S * v * fmaxf(v, 0.f));
+  }
+  if (mx == -INFINITY) return -INFINITY;
+  float s = 0.f;
+  for (long long j = b; j < e; ++j) {
+    bool use;
+    const float v = circle_v(which, f, c, index[j], lane, g, flags, thresh, flag[j] != 0, use);
+    if (use) s += expf(S * v * fmaxf(v, 0.f) - mx);
+  }
+  return mx + logf(s);
+}
+
+__global__ void __launch_bounds__(64) k_circle_group_fwd(const float* __restrict__ f, int c,
+                                                         const long long* __restrict__ index,
+                                                         const long long* __restrict__ goff,
+                                                         const unsigned char* __restrict__ flag,
+                                                         const long long* __restrict__ sel, float pos_thresh,
+                                                         float finest_thresh, float S, int flags,
+                                                         const int* __restrict__ pairpos, float* pos, float* fin,
+                                                         float* mean_out) {
+  const int lane = threadIdx.x;
+  const long long gi = sel[blockIdx.x];
+  const long long b = goff[gi], e = goff[gi + 1];
+  const GroupStats g = group_stats(f, c, index, flag, b, e, lane);
+  if (lane < c) mean_out[(long long)blockIdx.x * c + lane] = g.mean;
+  float pv;
+  if (flags & GL_PAIR) {
+    const int* pp = pairpos + 2 * blockIdx.x;
+    const float fa = (lane < c) ? f[index[b + pp[0]] * c + lane] : 0.f;
+    const float fb = (lane < c) ? f[index[b + pp[1]] * c + lane] : 0.f;
+    const float d2 = wave_sum((fa - fb) * (fa - fb));
+    pv = softplus_f(((flags & GL_SQRT) ? sqrtf(d2 + 1e-7f) : d2) - pos_thresh);
+  } else {
+    pv = softplus_f(circle_lse(0, f, c, index, flag, b, e, lane, g, flags, 0.5f * pos_thresh, S)) / S;
+  }
+  const float fv = softplus_f(circle_lse(1, f, c, index, flag, b, e, lane, g, flags, finest_thresh, S)) / S;
+  if (lane == 0) {
+    pos[blockIdx.x] = pv;
+    fin[blockIdx.x] = fv;
+  }
+}
+
+// dF += gpos dpos/dF + gfin dfin/dF + (1/n) gmean (gradient arriving at the group's mean feature), float atomics
+__global__ void __launch_bounds__(64) k_circle_group_bwd(const float* __restrict__ f, int c,
+                                                         const long long* __restrict__ index,
+                                                         const long long* __restrict__ goff,
+                                                         const unsigned char* __restrict__ flag,
+                                                         const long long* __restrict__ sel, float pos_thresh,
+                                                         float finest_thresh, float S, int flags,
+                                                         const int* __restrict__ pairpos,
+                                                         const float* __restrict__ gpos, const float* __restrict__ gfin,
+                                                         const float* __restrict__ gmean, float* df) {
+  const int lane = threadIdx.x;
+  const long long gi = sel[blockIdx.x];
+  const long long b = goff[gi], e = goff[gi + 1];
+  const GroupStats g = group_stats(f, c, index, flag, b, e, lane);
+  const float gp = gpos[blockIdx.x], gf = gfin[blockIdx.x];
+  const float gm = (gmean && lane < c) ? gmean[(long long)blockIdx.x * c + lane] * g.inv_n : 0.f;
+  const bool sq = !(flags & GL_SQRT);
+  // positive term: d/dv_i = sigmoid(lse) softmax_i max(v_i, 0); dv_i/df_j = k_i (m - f_i)(1/n - [i == j]),
+  // k_i = 2 (squared) or 1 / (v_i + thresh) (sqrt)
+  float lse_p = 0.f, sig_p = 0.f, u = 0.f;
+  if (!(flags & GL_PAIR) && gp != 0.f) {
+    lse_p = circle_lse(0, f, c, index, flag, b, e, lane, g, flags, 0.5f * pos_thresh, S);
+    sig_p = sigmoid_f(lse_p);
+    for (long long j = b; j < e; ++j) {
+      bool use;
+      const float v = circle_v(0, f, c, index[j], lane, g, flags, 0.5f * pos_thresh, false, use);
+      const float wgt = sig_p * expf(S * v * fmaxf(v, 0.f) - lse_p) * fmaxf(v, 0.f);
+      const float kk = sq ? 2.f : 1.f / (v + 0.5f * pos_thresh);
+      const float d = (lane < c) ? g.mean - f[index[j] * c + lane] : 0.f;
+      u += wgt * kk * d;
+    }
+    u *= g.inv_n;
+  }
+  const float lse_f = (gf != 0.f) ? circle_lse(1, f, c, index, flag, b, e, lane, g, flags, finest_thresh, S) : 0.f;
+  const float sig_f = sigmoid_f(lse_f);
+  float gt = 0.f;                                        // gradient collected for the finest member
+  for (long long j = b; j < e; ++j) {
+    const long long row = index[j];
+    const float fj = (lane < c) ? f[row * c + lane] : 0.f;
+    float gr = gm;
+    if (!(flags & GL_PAIR) && gp != 0.f) {
+      bool use;
+      const float v = circle_v(0, f, c, row, lane, g, flags, 0.5f * pos_thresh, false, use);
+      const float wgt = sig_p * expf(S * v * fmaxf(v, 0.f) - lse_p) * fmaxf(v, 0.f);
+      const float kk = sq ? 2.f : 1.f / (v + 0.5f * pos_thresh);
+      gr += gp * (u - wgt * kk * (g.mean - fj));
+    }
+    if (gf != 0.f && lse_f != -INFINITY) {
+      bool use;
+      const float v = circle_v(1, f, c, row, lane, g, flags, finest_thresh, flag[j] != 0, use);
+      if (use) {
+        const float wgt = sig_f * expf(S * v * fmaxf(v, 0.f) - lse_f) * fmaxf(v, 0.f);
+        const float kk = sq ? 2.f : 1.f / (v + finest_thresh);
+        const float dfi = gf * wgt * kk * (fj - g.ft);
+        gr += dfi;
+        if (!(flags & GL_BLOCK)) gt -= dfi;
+      }
+    }
+    if (lane < c && gr != 0.f) atomicAdd(&df[row * c + lane], gr);
+  }
+  if (lane < c && gt != 0.f) atomicAdd(&df[index[g.tpos] * c + lane], gt);
+  if ((flags & GL_PAIR) && gp != 0.f && lane < c) {
+    const int* pp = pairpos + 2 * blockIdx.x;
+    const long long ra = index[b + pp[0]], rb = index[b + pp[1]];
+    const float diff = f[ra * c + lane] - f[rb * c + lane];
+    const float d2 = wave_sum(diff * diff);
+    const float dist = sq ? d2 : sqrtf(d2 + 1e-7f);
+    const float coef = gp * sigmoid_f(dist - pos_thresh) * (sq ? 2.f : 1.f / dist);
+    atomicAdd(&df[ra * c + lane], coef * diff);
+    atomicAdd(&df[rb * c + lane], -coef * diff);
+  }
+}
+
 // ---- pairwise squared distance + row minimum ----------------------------------------------------------
 constexpr int NN_TA = 64;    // A rows per workgroup
 constexpr int NN_TB = 128;   // B rows per LDS tile
@@ -364,6 +509,38 @@ int gcl_group_loss_bwd(const float* f, int32_t c, const int64_t* index, const in
   hipLaunchKernelGGL(k_group_loss_bwd, dim3(n_sel), dim3(64), 0, (hipStream_t)stream, f, c, (const long long*)index,
                      (const long long*)goff, finest_flag, (const long long*)sel, pos_thresh, finest_thresh, flags,
                      (flags & GL_PAIR) ? pairpos : nullptr, gpos, gfin, df);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int gcl_circle_group_fwd(const float* f, int32_t c, const int64_t* index, const int64_t* goff,
+                         const uint8_t* finest_flag, const int64_t* sel, int32_t n_sel, float pos_thresh,
+                         float finest_thresh, float log_scale, int32_t flags, const int32_t* pairpos, float* pos,
+                         float* fin, float* mean_out, void* stream) {
+  GCL_CHECK_ARG(f && index && goff && finest_flag && sel && pos && fin && mean_out, "gcl_circle_group_fwd: null pointer");
+  GCL_CHECK_ARG(c >= 1 && c <= 64, "gcl_circle_group_fwd: feature width must be <= 64 (got %d)", c);
+  GCL_CHECK_ARG(flags >= 0 && flags < 8 && (!(flags & GL_PAIR) || pairpos) && log_scale > 0,
+                "gcl_circle_group_fwd: bad flags / pair positions missing / log_scale");
+  if (n_sel <= 0) return GCL_OK;
+  hipLaunchKernelGGL(k_circle_group_fwd, dim3(n_sel), dim3(64), 0, (hipStream_t)stream, f, c, (const long long*)index,
+                     (const long long*)goff, finest_flag, (const long long*)sel, pos_thresh, finest_thresh, log_scale,
+                     flags, pairpos, pos, fin, mean_out);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int gcl_circle_group_bwd(const float* f, int32_t c, const int64_t* index, const int64_t* goff,
+                         const uint8_t* finest_flag, const int64_t* sel, int32_t n_sel, float pos_thresh,
+                         float finest_thresh, float log_scale, int32_t flags, const int32_t* pairpos,
+                         const float* gpos, const float* gfin, const float* gmean, float* df, void* stream) {
+  GCL_CHECK_ARG(f && index && goff && finest_flag && sel && gpos && gfin && df, "gcl_circle_group_bwd: null pointer");
+  GCL_CHECK_ARG(c >= 1 && c <= 64, "gcl_circle_group_bwd: feature width must be <= 64 (got %d)", c);
+  GCL_CHECK_ARG(flags >= 0 && flags < 8 && (!(flags & GL_PAIR) || pairpos) && log_scale > 0,
+                "gcl_circle_group_bwd: bad flags / pair positions missing / log_scale");
+  if (n_sel <= 0) return GCL_OK;
+  hipLaunchKernelGGL(k_circle_group_bwd, dim3(n_sel), dim3(64), 0, (hipStream_t)stream, f, c, (const long long*)index,
+                     (const long long*)goff, finest_flag, (const long long*)sel, pos_thresh, finest_thresh, log_scale,
+                     flags, pairpos, gpos, gfin, gmean, df);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }

@@ -30,7 +30,7 @@ DEFAULT_CONFIG = dict(
     batch_size=4, num_pos_per_batch=256, num_hn_samples_per_batch=256, iter_size=1,
     pos_thresh=0.1, neg_thresh=1.4, finest_thresh=0.2, pos_weight=1.0, neg_weight=1.0, finest_weight=1.0,
     square_loss=True, block_finest_gradient=False, use_hard_negative=True, use_pair_group_positive_loss=False,
-    use_group_circle_loss=False, voxel_size=0.3,
+    use_group_circle_loss=False, safe_radius=0.75, voxel_size=0.3,
 )
 
 
@@ -178,6 +178,104 @@ def location_contrastive_loss(F_out, group, index, index_hash, finest_flag, max_
                                    use_hard_negative=use_hard_negative, finest_term=False)
 
 
+class _CircleGroupFn(torch.autograd.Function):
+    """Per-group terms of location_circle_loss and the groups' mean features (gcl_circle_group_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, F, index, goff, flag, sel, pos_thresh, fin_thresh, log_scale, flags, pairpos):
+        lib = _lib.require_gpu()
+        F = F.contiguous()
+        n, c = F.shape
+        n_sel = sel.shape[0]
+        dev = F.device
+        pos = torch.empty(n_sel, dtype=torch.float32, device=dev)
+        fin = torch.empty(n_sel, dtype=torch.float32, device=dev)
+        mean = torch.empty((n_sel, c), dtype=torch.float32, device=dev)
+        _lib.check(lib.gcl_circle_group_fwd(_lib.ptr(F, torch.float32), c, _lib.ptr(index, torch.int64),
+                                            _lib.ptr(goff, torch.int64), _lib.ptr(flag, torch.uint8),
+                                            _lib.ptr(sel, torch.int64), n_sel, pos_thresh, fin_thresh, log_scale,
+                                            int(flags), _lib.ptr(pairpos, torch.int32), _lib.ptr(pos), _lib.ptr(fin),
+                                            _lib.ptr(mean), _lib.stream()), "gcl_circle_group_fwd")
+        ctx.save_for_backward(F, index, goff, flag, sel, pairpos)
+        ctx.cfg = (pos_thresh, fin_thresh, log_scale, int(flags))
+        return pos, fin, mean
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gpos, gfin, gmean):
+        lib = _lib.load()
+        F, index, goff, flag, sel, pairpos = ctx.saved_tensors
+        pos_thresh, fin_thresh, log_scale, flags = ctx.cfg
+        dF = torch.zeros_like(F)
+        _lib.check(lib.gcl_circle_group_bwd(_lib.ptr(F), F.shape[1], _lib.ptr(index), _lib.ptr(goff), _lib.ptr(flag),
+                                            _lib.ptr(sel), sel.shape[0], pos_thresh, fin_thresh, log_scale, flags,
+                                            _lib.ptr(pairpos), _lib.ptr(gpos.contiguous()),
+                                            _lib.ptr(gfin.contiguous()), _lib.ptr(gmean.contiguous()), _lib.ptr(dF),
+                                            _lib.stream()), "gcl_circle_group_bwd")
+        return (dF,) + (None,) * 9
+
+
+def draw_circle_selections(n_groups, max_pos_cluster, group_sizes=None, pair_positive=False):
+    """np.random draws of location_circle_loss in the reference's order (:561-564 sorted selection, :599 pairs)."""
+    if n_groups > max_pos_cluster:
+        pos_sel = np.sort(np.random.choice(n_groups, max_pos_cluster, replace=False))
+    else:
+        pos_sel = np.arange(n_groups)
+    pair_pos = None
+    if pair_positive:
+        sizes = np.asarray(group_sizes)
+        pair_pos = np.stack([np.random.choice(int(sizes[i]), 2, replace=False) for i in pos_sel]).astype(np.int32)
+    return pos_sel, pair_pos
+
+
+def location_circle_loss(F_out, group, index, index_hash, finest_flag, max_pos_cluster=256, max_hn_samples=None,
+                         points=None, batch_lengths=None, pos_thresh=0.1, neg_thresh=1.4, finest_thresh=0.2,
+                         safe_radius=0.75, log_scale=16, draws=None, square_loss=True, block_finest_gradient=True,
+                         use_pair_group_positive_loss=False):
+    """(pos_loss, finest_loss, neg_loss) of lib/colocation_trainer.py:538-681.  ``points`` [N, 3] (the trainer passes
+    the voxel coordinates ``sinput_C[:, 1:]``, :858) and ``batch_lengths`` (rows per sample) are required here.
+    The per-group terms and the group means come from one HIP kernel pair; the negative term is a handful of torch
+    operations on the [M, M] matrices of the M <= max_pos_cluster selected groups (:642-676)."""
+    dev = F_out.device
+    group_t = torch.as_tensor(group)
+    n_groups = int(group_t.shape[0])
+    if draws is None:
+        draws = draw_circle_selections(n_groups, max_pos_cluster,
+                                       group_t.cpu().numpy() if use_pair_group_positive_loss else None,
+                                       use_pair_group_positive_loss)
+    pos_sel, pair_pos = draws[0], (draws[1] if len(draws) > 1 else None)
+    if len(pos_sel) == 0:
+        raise ZeroDivisionError("no positive group in the batch")
+    if use_pair_group_positive_loss and pair_pos is None:
+        raise ValueError("use_pair_group_positive_loss needs the drawn member positions (draws[1])")
+    flags = (0 if square_loss else LOSS_SQRT) | (LOSS_BLOCK if block_finest_gradient else 0) | \
+            (LOSS_PAIR if use_pair_group_positive_loss else 0)
+    goff = torch.zeros(n_groups + 1, dtype=torch.int64, device=dev)
+    goff[1:] = torch.cumsum(group_t.to(dev, torch.int64), 0)
+    index_d = torch.as_tensor(index).to(dev, torch.int64).contiguous()
+    flag = torch.as_tensor(finest_flag).to(dev).to(torch.uint8).contiguous()
+    sel = torch.from_numpy(np.ascontiguousarray(pos_sel, dtype=np.int64)).to(dev)
+    pp = None if pair_pos is None else torch.from_numpy(np.ascontiguousarray(pair_pos, dtype=np.int32)).to(dev)
+    pos, fin, feats_sel = _CircleGroupFn.apply(F_out, index_d, goff, flag, sel, float(pos_thresh), float(finest_thresh),
+                                               float(log_scale), flags, pp)
+    pos_loss, finest_loss = pos.sum() / len(pos_sel), fin.sum() / len(pos_sel)
+    # anchors: first member of every selected group (:583) and the sample it belongs to (:589-591)
+    pivot = index_d[goff[sel]]
+    coords_sel = torch.as_tensor(points).to(dev)[pivot].float()
+    acc = torch.cumsum(torch.as_tensor(np.asarray(batch_lengths, dtype=np.float64)), 0).to(dev)
+    item = torch.sum(pivot[:, None].double() > acc[None, :], dim=1)          # np.sum(pivot > accumulated)
+    batch_mask = item[:, None] == item[None, :]
+    d2 = -2 * coords_sel @ coords_sel.T + (coords_sel ** 2).sum(-1)[:, None] + (coords_sel ** 2).sum(-1)[None, :]
+    coords_dist = torch.sqrt(torch.clamp(d2, min=1e-12))                     # util/misc.py:7-26
+    feats_dist = torch.sqrt(torch.clamp(2 - 2 * feats_sel @ feats_sel.T, min=1e-12))     # normalised=True (:657-659)
+    neg_mask = (coords_dist > safe_radius) & batch_mask
+    has_neg = neg_mask.sum(-1) > 0
+    neg_weight = torch.clamp(neg_thresh - (feats_dist + 1e5 * (~neg_mask).float()), min=0).detach()
+    lse = torch.logsumexp(log_scale * (neg_thresh - feats_dist) * neg_weight, dim=-1)
+    neg_loss = (torch.nn.functional.softplus(lse) / log_scale)[has_neg].mean()
+    return pos_loss, finest_loss, neg_loss
+
+
 class FinestContrastiveLossTrainer:
     """The GCL trainer's hot loop body (``_train_epoch`` :811-916) without the dataset / logging / checkpoint shell."""
 
@@ -185,10 +283,8 @@ class FinestContrastiveLossTrainer:
         self.config = config or make_config()
         cfg = self.config
         self.device = torch.device(device if device is not None else "cuda:0")
-        if cfg.use_group_circle_loss or not cfg.use_hard_negative:
-            raise NotImplementedError("location_circle_loss (lib/colocation_trainer.py:538-681) and "
-                                      "use_hard_negative=False are not built; the contrastive losses with their "
-                                      "other switches are")
+        if not cfg.use_hard_negative:
+            raise NotImplementedError("use_hard_negative=False is not built (see finest_contrastive_loss)")
         if model is None:
             Model = load_model(cfg.model)
             model = Model(1, cfg.model_n_out, bn_momentum=cfg.bn_momentum, normalize_feature=cfg.normalize_feature,
@@ -206,6 +302,11 @@ class FinestContrastiveLossTrainer:
     def location_loss(self, F_out, group, index, index_hash, finest_flag, max_pos_cluster, max_hn_samples,
                       points=None, batch_lengths=None, draws=None):
         cfg = self.config
+        if cfg.use_group_circle_loss:         # lib/colocation_trainer.py:423-424
+            return location_circle_loss(F_out, group, index, index_hash, finest_flag, max_pos_cluster, max_hn_samples,
+                                        points, batch_lengths, cfg.pos_thresh, cfg.neg_thresh, cfg.finest_thresh,
+                                        cfg.safe_radius, 16, draws, cfg.square_loss, cfg.block_finest_gradient,
+                                        cfg.use_pair_group_positive_loss)
         if cfg.finest_weight == 0:            # lib/colocation_trainer.py:425-428
             return location_contrastive_loss(F_out, group, index, index_hash, finest_flag, max_pos_cluster,
                                              max_hn_samples, points, batch_lengths, cfg.pos_thresh, cfg.neg_thresh,
@@ -224,12 +325,17 @@ class FinestContrastiveLossTrainer:
             F_out, input_dict["group"], input_dict["index"], input_dict.get("index_hash"), input_dict["finest_flag"],
             max_pos_cluster=cfg.num_pos_per_batch * cfg.batch_size,
             max_hn_samples=cfg.num_hn_samples_per_batch * cfg.batch_size,
-            points=None, batch_lengths=input_dict.get("batch_lengths"), draws=draws)
+            points=input_dict["sinput_C"][:, 1:] if cfg.use_group_circle_loss else None,
+            batch_lengths=input_dict.get("batch_lengths"), draws=draws)
         loss = self.pos_weight * pos + self.finest_weight * fin + self.neg_weight * neg
         return loss, (pos, fin, neg), F_out
 
     def _draw_for(self, input_dict):
         cfg = self.config
+        if cfg.use_group_circle_loss:
+            sizes = torch.as_tensor(input_dict["group"]).cpu().numpy() if cfg.use_pair_group_positive_loss else None
+            return draw_circle_selections(len(input_dict["group"]), cfg.num_pos_per_batch * cfg.batch_size, sizes,
+                                          cfg.use_pair_group_positive_loss)
         sizes = None
         if cfg.use_pair_group_positive_loss:
             sizes = torch.as_tensor(input_dict["group"]).cpu().numpy()

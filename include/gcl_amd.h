@@ -270,6 +270,24 @@ int gcl_group_loss_bwd(const float* f, int32_t c, const int64_t* index, const in
                        const uint8_t* finest_flag, const int64_t* sel, int32_t n_sel,
                        float pos_thresh, float finest_thresh, int32_t flags, const int32_t* pairpos,
                        const float* gpos, const float* gfin, float* df, void* stream);
+/* location_circle_loss (lib/colocation_trainer.py:538-681), per-group part: with S = log_scale (16 in the reference)
+ *   pos[s] = softplus(logsumexp_i(S v_i max(v_i, 0))) / S,  v_i = dist(mean, f_i) - pos_thresh / 2      (:607-618)
+ *            (GCL_LOSS_PAIR: softplus(dist(f_a, f_b) - pos_thresh), :597-605)
+ *   fin[s] = the same form over v_i = dist(f_i, f_finest) - finest_thresh (GCL_LOSS_BLOCK: non-finest members only,
+ *            finest detached)                                                                          (:620-640)
+ *   mean_out[s][c] = the group's mean feature (:585); the negative term (:642-676) is formed by the host on the
+ *   [n_sel, n_sel] matrices of these means.  max(v, 0) is a constant in the backward pass, as in the reference.
+ *   backward: dF += gpos dpos/dF + gfin dfin/dF + gmean[s] / n_s (gmean may be NULL), float atomics.
+ *   flags: GCL_LOSS_SQRT | GCL_LOSS_BLOCK | GCL_LOSS_PAIR. */
+int gcl_circle_group_fwd(const float* f, int32_t c, const int64_t* index, const int64_t* goff,
+                         const uint8_t* finest_flag, const int64_t* sel, int32_t n_sel, float pos_thresh,
+                         float finest_thresh, float log_scale, int32_t flags, const int32_t* pairpos, float* pos,
+                         float* fin, float* mean_out, void* stream);
+int gcl_circle_group_bwd(const float* f, int32_t c, const int64_t* index, const int64_t* goff,
+                         const uint8_t* finest_flag, const int64_t* sel, int32_t n_sel, float pos_thresh,
+                         float finest_thresh, float log_scale, int32_t flags, const int32_t* pairpos,
+                         const float* gpos, const float* gfin, const float* gmean, float* df, void* stream);
+
 /* Row-wise nearest neighbour: for every row i of A[rows_a[i]] (rows_a may be NULL = identity) the column j
  * minimising sum_c (a - b)^2 over B[rows_b[j]]; ties -> lowest j.  dmin = that squared distance, or
  * sqrt(d2 + 1e-7) when l2 != 0 (lib/metrics.py:24-25). */

@@ -136,3 +136,76 @@ def finest_contrastive_loss(F_out, group, index, index_hash, finest_flag, max_po
     keep = torch.from_numpy(mask & mask_self)
     neg = torch.relu(neg_thresh - Dmin[keep]).pow(2)                                                   # :530
     return pos_loss, finest_loss, neg.mean()
+
+
+def square_distance(src, dst, normalised=False):
+    """util/misc.py:7-26 for [N, C] / [M, C] inputs."""
+    dist = -2 * src @ dst.T
+    if normalised:
+        dist = dist + 2
+    else:
+        dist = dist + (src ** 2).sum(-1)[:, None] + (dst ** 2).sum(-1)[None, :]
+    return torch.clamp(dist, min=1e-12)
+
+
+def location_circle_loss(F_out, group, index, finest_flag, points, batch_lengths, max_pos_cluster=256, pos_thresh=0.1,
+                         neg_thresh=1.4, finest_thresh=0.2, safe_radius=0.75, log_scale=16, draws=None,
+                         square_loss=True, block_finest_gradient=True, use_pair_group_positive_loss=False):
+    """lib/colocation_trainer.py:538-681.  ``draws`` = (pos_sel (sorted), pair_pos or None)."""
+    import torch.nn.functional as Fn
+    group = [int(g) for g in np.asarray(group)]
+    index = torch.as_tensor(np.asarray(index), dtype=torch.long)
+    finest_flag = torch.as_tensor(np.asarray(finest_flag), dtype=torch.bool)
+    points = torch.as_tensor(np.asarray(points))
+    index_split = torch.split(index, tuple(group))
+    finest_split = torch.split(finest_flag, tuple(group))
+    n_groups = len(group)
+    pair_pos = None
+    if draws is not None:
+        pos_sel = np.asarray(draws[0])
+        pair_pos = draws[1] if len(draws) > 1 else None
+    elif n_groups > max_pos_cluster:
+        pos_sel = np.sort(np.random.choice(n_groups, max_pos_cluster, replace=False))            # :561-562
+    else:
+        pos_sel = np.arange(n_groups)
+    M = len(pos_sel)
+    coords_sel = torch.zeros((M, 3))
+    feats_rows = []
+    acc = np.cumsum(np.asarray(batch_lengths, dtype=np.float64))                                  # :574-579
+    item = np.zeros(M, dtype=np.int64)
+
+    def dist(d2):
+        return d2 if square_loss else torch.sqrt(d2 + 1e-7)
+
+    def circle(v):                                                                                # :613-618
+        return Fn.softplus(torch.logsumexp(log_scale * v * torch.clamp(v, min=0).detach(), dim=-1)) / log_scale
+
+    pos_loss, finest_loss = 0, 0
+    for s, i in enumerate(pos_sel):
+        idx, fl = index_split[i], finest_split[i]
+        coords_sel[s] = points[idx[0]].float()                                                    # :583
+        fs = F_out[idx]
+        mean = torch.mean(fs, dim=0)
+        feats_rows.append(mean)                                                                   # :585
+        item[s] = int(np.sum(int(idx[0]) > acc))                                                  # :589-591
+        if use_pair_group_positive_loss:                                                          # :597-605
+            a, b = (np.random.choice(len(fs), 2, replace=False) if pair_pos is None else pair_pos[s])
+            pos_loss = pos_loss + Fn.softplus(dist((fs[a] - fs[b]).pow(2).sum(-1)) - pos_thresh)
+        else:                                                                                     # :607-618
+            pos_loss = pos_loss + circle(dist((mean - fs).pow(2).sum(-1)) - pos_thresh / 2)
+        if block_finest_gradient:                                                                 # :621-628
+            fd = dist((fs[~fl] - fs[fl][0].detach()).pow(2).sum(-1)) - finest_thresh
+        else:                                                                                     # :629-635
+            fd = dist((fs - fs[fl][0]).pow(2).sum(-1)) - finest_thresh
+        finest_loss = finest_loss + circle(fd)
+    pos_loss, finest_loss = pos_loss / M, finest_loss / M
+    feats_sel = torch.stack(feats_rows)
+    batch_mask = torch.from_numpy(item[:, None] == item[None, :])                                 # :645-650 (sorted selection)
+    coords_dist = torch.sqrt(square_distance(coords_sel, coords_sel))
+    feats_dist = torch.sqrt(square_distance(feats_sel, feats_sel, normalised=True))
+    neg_mask = (coords_dist > safe_radius) & batch_mask                                           # :665
+    sel = neg_mask.sum(-1) > 0
+    neg_weight = feats_dist + 1e5 * (~neg_mask).float()
+    neg_weight = torch.clamp(neg_thresh - neg_weight, min=0).detach()
+    lse = torch.logsumexp(log_scale * (neg_thresh - feats_dist) * neg_weight, dim=-1)
+    return pos_loss, finest_loss, (Fn.softplus(lse) / log_scale)[sel].mean()

@@ -14,6 +14,7 @@ draws, outputs, gradients).  What is captured, and from where:
   ``location_contrastive_loss`` (:734-809)
 * ``HardestContrastiveLossTrainer.contrastive_hardest_negative_loss``  lib/trainer.py:410-462  (FCGF baseline)
 * ``Matcher.SC2_PCR``                                      scripts/SC2_PCR/SC2_PCR.py:304-381 (KITTI config)
+* ``FinestContrastiveLossTrainer.location_circle_loss``    lib/colocation_trainer.py:538-681 (all switches)
 
 Third-party modules the reference imports but that are absent here (MinkowskiEngine, open3d,
 tensorboardX, easydict) are replaced by EMPTY stub modules -- none of their code is on this path.
@@ -72,6 +73,8 @@ def make_groups(rng, N, n_groups, sizes):
 
 def main():
     pdist, find_nn_gpu, _hash, _neg_hash, _exhaustive_hash, Trainer = _import_reference()
+    global _TRAINER_AND_HASH
+    _TRAINER_AND_HASH = (Trainer, _exhaustive_hash)
     torch.set_num_threads(4)
 
     # ---- pdist ---------------------------------------------------------------------------------
@@ -209,6 +212,62 @@ def hardest_golden():
         print("hardest", seed, pos.item(), neg.item())
 
 
+def circle_golden(Trainer, _exhaustive_hash):
+    """location_circle_loss (lib/colocation_trainer.py:538-681) with its switches."""
+    cases = {"c0": dict(seed=20), "c1": dict(seed=21, square_loss=False), "c2": dict(seed=22, block_finest_gradient=False),
+             "c3": dict(seed=23, use_pair_group_positive_loss=True)}
+    for name, c in cases.items():
+        rng = np.random.RandomState(c["seed"])
+        gt = torch.Generator().manual_seed(c["seed"])
+        N, n_groups, max_pos = 3000, 160, 96
+        batch_lengths = [1100, 900, 1000]
+        Fo = _unit_rows(gt, N, 32)
+        # groups stay inside one sample and are ordered by sample, as the collate function produces them
+        group, index, finest = [], [], []
+        starts = np.concatenate([[0], np.cumsum(batch_lengths)])
+        for s in range(3):
+            for _ in range(n_groups // 3 + (1 if s == 0 else 0)):
+                g = int(rng.choice([2, 3, 5, 8, 16, 35]))
+                rows = starts[s] + rng.choice(batch_lengths[s], g, replace=False)
+                fl = np.zeros(g, dtype=bool)
+                fl[rng.randint(0, g)] = True
+                group.append(g); index.append(rows); finest.append(fl)
+        group = np.asarray(group, dtype=np.int32)
+        index = np.concatenate(index).astype(np.int64)
+        finest = np.concatenate(finest)
+        p = 0
+        for gsz in group:
+            rows = index[p:p + gsz]
+            Fo[rows] = Fo[rows[0]] + 0.25 * torch.randn(int(gsz), 32, generator=gt)
+            p += gsz
+        Fo = (Fo / Fo.norm(dim=1, keepdim=True)).clone().requires_grad_(True)
+        points = torch.from_numpy(rng.randint(-40, 40, (N, 3)).astype(np.int32))
+        tr = Trainer.__new__(Trainer)
+        tr.device = torch.device("cpu")
+        tr.pos_thresh, tr.neg_thresh, tr.finest_thresh, tr.safe_radius, tr.log_scale = 0.1, 1.4, 0.2, 0.75, 16
+        tr.square_loss = c.get("square_loss", True)
+        tr.block_finest_gradient = c.get("block_finest_gradient", True)
+        tr.use_pair_group_positive_loss = c.get("use_pair_group_positive_loss", False)
+        np.random.seed(c["seed"] + 100)
+        pos, fin, neg = tr.location_circle_loss(Fo, torch.from_numpy(group), torch.from_numpy(index), None,
+                                                torch.from_numpy(finest), max_pos_cluster=max_pos, points=points,
+                                                batch_lengths=batch_lengths)
+        (pos + fin + neg).backward()
+        np.random.seed(c["seed"] + 100)
+        G = len(group)
+        pos_sel = np.sort(np.random.choice(G, max_pos, replace=False)) if G > max_pos else np.arange(G)
+        extra = {}
+        if tr.use_pair_group_positive_loss:
+            extra["pair_pos"] = np.stack([np.random.choice(int(group[i]), 2, replace=False) for i in pos_sel])
+        np.savez_compressed(os.path.join(HERE, f"circle_loss_{name}.npz"), F_out=Fo.detach().numpy(), group=group,
+                            index=index, finest_flag=finest, points=points.numpy(),
+                            batch_lengths=np.asarray(batch_lengths), max_pos_cluster=max_pos, np_seed=c["seed"] + 100,
+                            pos_sel=pos_sel, square_loss=tr.square_loss, block_finest_gradient=tr.block_finest_gradient,
+                            use_pair_group_positive_loss=tr.use_pair_group_positive_loss, pos=pos.item(),
+                            finest=fin.item(), neg=neg.item(), grad=Fo.grad.numpy(), **extra)
+        print("circle", name, pos.item(), fin.item(), neg.item(), float(Fo.grad.abs().sum()))
+
+
 def sc2pcr_problem(seed, N, inlier_ratio, noise=0.03):
     """Synthetic putative correspondences: a planar-ish 80 m scene, ground-truth yaw + translation, uniform outliers."""
     rng = np.random.RandomState(seed)
@@ -244,3 +303,4 @@ if __name__ == "__main__":
     main()
     hardest_golden()
     sc2pcr_golden()
+    circle_golden(*_TRAINER_AND_HASH)

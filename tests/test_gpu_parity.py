@@ -750,7 +750,8 @@ def test_row_normalize_matches_torch_expression(n, c):
 
 
 @pytest.mark.parametrize("overrides", [dict(block_finest_gradient=True), dict(square_loss=False),
-                                       dict(use_pair_group_positive_loss=True), dict(finest_weight=0)])
+                                       dict(use_pair_group_positive_loss=True), dict(finest_weight=0),
+                                       dict(use_group_circle_loss=True, block_finest_gradient=True)])
 def test_trainer_accepts_the_other_loss_switches(overrides):
     """config.py:38-43 / :158 switches other than the training script's selection run through the trainer (the
     switch-by-switch values are pinned by the golden tests above); the two unbuilt ones are rejected loudly."""
@@ -764,9 +765,8 @@ def test_trainer_accepts_the_other_loss_switches(overrides):
     assert torch.isfinite(loss).item() and pos.item() >= 0
     if overrides.get("finest_weight", 1) == 0:
         assert fin.item() == 0.0
-    for bad in (dict(use_group_circle_loss=True), dict(use_hard_negative=False)):
-        with pytest.raises(NotImplementedError):
-            FinestContrastiveLossTrainer(make_config(**bad), device=DEV)
+    with pytest.raises(NotImplementedError):
+        FinestContrastiveLossTrainer(make_config(use_hard_negative=False), device=DEV)
 
 
 def test_instance_norm_matches_per_cloud_formula():
@@ -928,3 +928,26 @@ def test_forward_pair_equals_two_forward_passes_bitwise():
         a1 = m(ME.SparseTensor(F1, coordinates=C1)).F
         b0, b1 = forward_pair(m, F0, C0, F1, C1)
     assert torch.equal(a0, b0) and torch.equal(a1, b1)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "circle_loss_*.npz"))))
+def test_location_circle_loss_golden(path):
+    """lib/colocation_trainer.py:538-681 on the device vs the reference's own outputs: loss triple within 1e-5 rel,
+    dL/dF within 1e-4 rel-L2 (exp / log chains in fp32); host draws reproduce the reference's selections."""
+    from gcl_amd.lib.colocation_trainer import location_circle_loss
+    z = np.load(path)
+    sw = {k: bool(z[k]) for k in ("square_loss", "block_finest_gradient", "use_pair_group_positive_loss")}
+    F = torch.from_numpy(z["F_out"]).to(DEV).requires_grad_(True)
+    draws = (z["pos_sel"], z["pair_pos"] if "pair_pos" in z.files else None)
+    kw = dict(max_pos_cluster=int(z["max_pos_cluster"]), points=torch.from_numpy(z["points"]),
+              batch_lengths=z["batch_lengths"].tolist(), **sw)
+    args = (torch.from_numpy(z["group"]), torch.from_numpy(z["index"]), None, torch.from_numpy(z["finest_flag"]))
+    pos, fin, neg = location_circle_loss(F, *args, draws=draws, **kw)
+    for got, key in ((pos, "pos"), (fin, "finest"), (neg, "neg")):
+        assert abs(got.item() - float(z[key])) <= 1e-5 * max(1, abs(float(z[key]))), key
+    (pos + fin + neg).backward()
+    assert rel_l2(F.grad.cpu(), z["grad"]) < 1e-4
+    np.random.seed(int(z["np_seed"]))
+    p2, f2, n2 = location_circle_loss(F.detach(), *args, **kw)
+    assert abs(p2.item() - float(z["pos"])) <= 1e-5 * max(1, abs(float(z["pos"])))
+    assert abs(n2.item() - float(z["neg"])) <= 1e-5

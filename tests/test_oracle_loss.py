@@ -80,3 +80,21 @@ def test_finest_contrastive_loss_golden(path):
     assert abs(p2.item() - float(z["pos"])) <= 1e-6 and abs(f2.item() - float(z["finest"])) <= 1e-6
     if not np.isnan(float(z["neg"])):
         assert abs(n2.item() - float(z["neg"])) <= 1e-6
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "circle_loss_*.npz"))))
+def test_location_circle_loss_golden(path):
+    """oracle/loss_oracle.location_circle_loss vs the reference's own output (all switches), incl. the RNG stream."""
+    z = np.load(path)
+    sw = {k: bool(z[k]) for k in ("square_loss", "block_finest_gradient", "use_pair_group_positive_loss")}
+    F = torch.from_numpy(z["F_out"]).requires_grad_(True)
+    draws = (z["pos_sel"], z["pair_pos"] if "pair_pos" in z.files else None)
+    args = (z["group"], z["index"], z["finest_flag"], z["points"], z["batch_lengths"])
+    pos, fin, neg = L.location_circle_loss(F, *args, max_pos_cluster=int(z["max_pos_cluster"]), draws=draws, **sw)
+    for got, key in ((pos, "pos"), (fin, "finest"), (neg, "neg")):
+        assert abs(got.item() - float(z[key])) <= 2e-6 * max(1, abs(float(z[key])))
+    (pos + fin + neg).backward()
+    assert np.allclose(F.grad.numpy(), z["grad"], rtol=1e-4, atol=1e-6)
+    np.random.seed(int(z["np_seed"]))
+    p2, f2, n2 = L.location_circle_loss(F.detach(), *args, max_pos_cluster=int(z["max_pos_cluster"]), **sw)
+    assert abs(p2.item() - float(z["pos"])) <= 2e-6 * max(1, abs(float(z["pos"])))
