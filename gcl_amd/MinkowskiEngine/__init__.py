@@ -82,6 +82,16 @@ class _ConvBase(nn.Module):
                 self.bias.uniform_(-stdv, stdv)
 
     def forward(self, x):
+        mgr, t_out, kmap, n_out = self._maps(x)
+        # in training mode the epilogue also emits per-tile column sums, which a following MinkowskiBatchNorm consumes
+        F, stats = sparse_conv(x.F, self.kernel, kmap, n_out, self.TRANSPOSE, self.bias, mgr,
+                               want_stats=FUSED_BN_STATS and self.training and self.bias is None
+                               and self.in_channels > 4)
+        out = SparseTensor(F, coordinate_map_key=CoordinateMapKey(t_out), coordinate_manager=mgr)
+        out._bn_stats = stats
+        return out
+
+    def _maps(self, x):
         if not isinstance(x, SparseTensor):
             raise TypeError("input must be a SparseTensor")
         mgr = x.coordinate_manager
@@ -103,13 +113,7 @@ class _ConvBase(nn.Module):
         else:
             kmap = mgr.get_kernel_map(t_in, self.kernel_size, self.stride)
             n_out = mgr.num_rows(t_out)
-        # in training mode the epilogue also emits per-tile column sums, which a following MinkowskiBatchNorm consumes
-        F, stats = sparse_conv(x.F, self.kernel, kmap, n_out, self.TRANSPOSE, self.bias, mgr,
-                               want_stats=FUSED_BN_STATS and self.training and self.bias is None
-                               and self.in_channels > 4)
-        out = SparseTensor(F, coordinate_map_key=CoordinateMapKey(t_out), coordinate_manager=mgr)
-        out._bn_stats = stats
-        return out
+        return mgr, t_out, kmap, n_out
 
     def extra_repr(self):
         return (f"in={self.in_channels}, out={self.out_channels}, kernel_size={self.kernel_size}, "
@@ -149,6 +153,19 @@ class MinkowskiBatchNorm(nn.Module):
         self._pending_batches = 0
         return super()._load_from_state_dict(*args, **kwargs)
 
+    def eval_affine(self):
+        """(scale, shift) of the eval-mode BatchNorm y = x * scale + shift, cached until a parameter or buffer changes."""
+        bn = self.bn
+        key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
+               bn.weight.data_ptr(), bn.running_mean.data_ptr())
+        cached = getattr(self, "_affine", None)
+        if cached is None or cached[0] != key:
+            with torch.no_grad():
+                scale = (bn.weight * torch.rsqrt(bn.running_var + bn.eps)).float().contiguous()
+                shift = (bn.bias - bn.running_mean * scale).float().contiguous()
+            self._affine = cached = (key, scale, shift)
+        return cached[1], cached[2]
+
     def forward(self, x, residual=None, relu=False):
         bn = self.bn
         res = residual.F if residual is not None else None
@@ -161,6 +178,26 @@ class MinkowskiBatchNorm(nn.Module):
         out = SparseTensor(F, coordinate_map_key=x.coordinate_map_key, coordinate_manager=x.coordinate_manager)
         out._nonneg = bool(relu)
         return out
+
+
+def conv_bn(conv, norm, x, residual=None, relu=False):
+    """``norm(conv(x))`` with the fused residual add / ReLU of MinkowskiBatchNorm.forward.  In inference (module in eval
+    mode, autograd off, BatchNorm, default arithmetic) convolution + BatchNorm + residual + ReLU are ONE launch
+    (gcl_conv_fwd_fused); otherwise the two modules run one after the other."""
+    fused = (not conv.training and not norm.training and not torch.is_grad_enabled()
+             and isinstance(norm, MinkowskiBatchNorm) and conv.bias is None and conv.in_channels > 4
+             and ops.PRECISION == "fp16x3")
+    if not fused:
+        return norm(conv(x), residual=residual, relu=relu)
+    mgr, t_out, kmap, n_out = conv._maps(x)
+    if residual is not None and residual.coordinate_map_key.tensor_stride != t_out:
+        raise ValueError("residual lives on a different coordinate map")
+    scale, shift = norm.eval_affine()
+    F = ops.conv_bn_eval(x.F, conv.kernel, kmap, n_out, conv.TRANSPOSE, scale, shift,
+                         residual.F if residual is not None else None, relu)
+    out = SparseTensor(F, coordinate_map_key=CoordinateMapKey(t_out), coordinate_manager=mgr)
+    out._nonneg = bool(relu)
+    return out
 
 
 class MinkowskiInstanceNorm(nn.Module):

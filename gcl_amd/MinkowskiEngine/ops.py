@@ -563,3 +563,34 @@ def instance_norm(x, weight, bias, segments, eps=1e-8, residual=None, relu=False
     if _LAST_BN_AMAX is not None:
         tag_amax(y, _LAST_BN_AMAX)
     return y
+
+
+def conv_bn_eval(x, W, kmap, n_out, transpose, scale, shift, residual=None, relu=False):
+    """Inference: convolution + BatchNorm (running statistics, as per-column ``scale`` / ``shift``) + residual add + ReLU
+    in one launch (gcl_conv_fwd_fused).  No autograd graph: callers use it under torch.no_grad() only."""
+    lib = _lib.require_gpu()
+    if PRECISION != "fp16x3":
+        raise RuntimeError("conv_bn_eval is built for the default fp16x3 arithmetic")
+    x = x.contiguous()
+    Wk = (W if W.dim() == 3 else W.unsqueeze(0)).contiguous()
+    K, cin, cout = Wk.shape
+    x_amax = tensor_amax(lib, x)
+    w_amax = tensor_amax(lib, W if W.is_contiguous() else Wk)
+    group = getattr(W, "_gcl_amax_group", None)
+    wp = group.packed(lib, W, 0) if group is not None else None
+    prec = 4
+    if wp is None:
+        wp = torch.empty(lib.gcl_pack_weights_bytes(K, cin, cout, prec), dtype=torch.uint8, device=x.device)
+        _lib.check(lib.gcl_pack_weights(_lib.ptr(Wk, torch.float32), K, cin, cout, 0, prec, _lib.ptr(w_amax),
+                                        _lib.ptr(wp), _lib.stream()), "gcl_pack_weights")
+    tbl, order, tile_mask = kmap.sorted_table(transposed=transpose) if kmap is not None else (None, None, None)
+    y = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
+    slot = amax_slot(x.device)
+    res = residual.contiguous() if residual is not None else None
+    _lib.check(lib.gcl_conv_fwd_fused(_lib.ptr(x, torch.float32), x.shape[0], 0, _lib.ptr(wp), prec, _lib.ptr(x_amax),
+                                      _lib.ptr(w_amax), _lib.ptr(tbl), _lib.ptr(order), _lib.ptr(tile_mask), n_out, K,
+                                      cin, cout, _lib.ptr(shift, torch.float32), _lib.ptr(scale, torch.float32),
+                                      _lib.ptr(res), int(relu), _lib.ptr(slot), _lib.ptr(y), None, _lib.stream()),
+               "gcl_conv_fwd_fused")
+    tag_amax(y, slot)
+    return y

@@ -418,6 +418,14 @@ __global__ void __launch_bounds__(256) k_pack_weights_multi(const PackDesc* __re
                      amax_slots + d.amax_index * AMAX_WORDS, reinterpret_cast<unsigned short*>(out + d.out_off), o);
 }
 
+// optional fused epilogue of the inference path: y = relu?(acc * col_scale + bias (+ residual)), amax(y) published
+struct ConvEpi {
+  const float* col_scale;   // per output column (BatchNorm in eval mode: gamma * rsqrt(var + eps)), NULL = 1
+  const float* residual;    // [n_out, cout] added before the ReLU, NULL = none
+  int relu;
+  int* y_amax;              // zero-initialised amax slot of y, NULL = not wanted
+};
+
 // PRE: X is not the fp32 tensor but its fp16 plane image made by gcl_split_planes -- per row and 32-channel slice
 // 64 bytes of hi followed by 64 bytes of lo, i.e. the same 128 bytes per (row, slice) and the same addressing as the
 // fp32 rows.  The main loop then has no split at all (the kernels are instruction-issue-bound: the split was 48 of ~120
@@ -429,7 +437,7 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
                                                         int cin, int cout, const float* __restrict__ bias,
                                                         float* __restrict__ Y, int swizzle,
                                                         float* __restrict__ stats, const int* __restrict__ x_amax,
-                                                        const int* __restrict__ w_amax, unsigned x_bytes) {
+                                                        const int* __restrict__ w_amax, unsigned x_bytes, ConvEpi epi) {
   constexpr int NPL = Prec<PL>::planes;
   constexpr int BLK = NB * 2 * NPL * 64;                // uint4 per (k, cc) weight block of this workgroup
   constexpr int BREG = (BLK + 255) / 256;
@@ -607,21 +615,27 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
   if (!active) return;
   int orow_l = -1;
   if ((l < 32) && (row0 + l < n_out)) orow_l = order ? order[row0 + l] : (int)(row0 + l);
+  float ymax = 0.f;
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     const int col = (nb0 + b) * 32 + i;
     float bvv = bias ? bias[col] : 0.f;
-    // consume the (conditional) bias load HERE: otherwise every store below waits for all earlier stores (vmcnt(0))
+    float csc = epi.col_scale ? epi.col_scale[col] * out_scale : out_scale;
+    // consume the (conditional) loads HERE: otherwise every store below waits for all earlier stores (vmcnt(0))
     asm volatile("v_mov_b32 %0, %1" : "=v"(bvv) : "v"(bvv));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(csc) : "v"(csc));
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       int orow = __shfl(orow_l, (r & 3) + 8 * (r >> 2) + 4 * h);
       if (orow >= 0) {
-        float v = acc[b][r] * out_scale + bvv;
+        float v = acc[b][r] * csc + bvv;
+        if (epi.residual) v += epi.residual[(long long)orow * cout + col];
+        if (epi.relu) v = fmaxf(v, 0.f);
         Y[(long long)orow * cout + col] = v;
         s1 += v;
         s2 += v * v;
+        ymax = fmaxf(ymax, fabsf(v));
       }
     }
     if (stats) {   // per-tile column sums for the BatchNorm that follows (saves its statistics pass over Y)
@@ -632,6 +646,11 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
         stats[(tile * 2 + 1) * cout + col] = s2;
       }
     }
+  }
+  if (epi.y_amax) {   // one publish per wave (launches of this path are small: inference on single clouds)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o));
+    if (l == 0) amax_slot_publish(epi.y_amax, __float_as_int(ymax), (unsigned)tile);
   }
 }
 
@@ -1250,10 +1269,28 @@ int32_t gcl_conv_fwd_nb(int64_t n_out, int32_t cout, int32_t prec) {
   return conv_fwd_nb(n_out, cout, prec);
 }
 
+int gcl_conv_fwd_fused(const float* x, int64_t n_in, int32_t x_is_planes, const void* wp, int32_t prec,
+                       const int32_t* x_amax, const int32_t* w_amax, const int32_t* tbl, const int32_t* order,
+                       const int32_t* tile_mask, int64_t n_out, int32_t K, int32_t cin, int32_t cout, const float* bias,
+                       const float* col_scale, const float* residual, int32_t relu, int32_t* y_amax, float* y,
+                       float* stats, void* stream);
+
 int gcl_conv_fwd(const float* x, int64_t n_in, int32_t x_is_planes, const void* wp, int32_t prec, const int32_t* x_amax,
                  const int32_t* w_amax, const int32_t* tbl, const int32_t* order, const int32_t* tile_mask,
                  int64_t n_out, int32_t K, int32_t cin, int32_t cout, const float* bias, float* y, float* stats,
                  void* stream) {
+  return gcl_conv_fwd_fused(x, n_in, x_is_planes, wp, prec, x_amax, w_amax, tbl, order, tile_mask, n_out, K, cin, cout,
+                            bias, nullptr, nullptr, 0, nullptr, y, stats, stream);
+}
+
+int gcl_conv_fwd_fused(const float* x, int64_t n_in, int32_t x_is_planes, const void* wp, int32_t prec,
+                       const int32_t* x_amax, const int32_t* w_amax, const int32_t* tbl, const int32_t* order,
+                       const int32_t* tile_mask, int64_t n_out, int32_t K, int32_t cin, int32_t cout, const float* bias,
+                       const float* col_scale, const float* residual, int32_t relu, int32_t* y_amax, float* y,
+                       float* stats, void* stream) {
+  const ConvEpi epi{col_scale, residual, relu, y_amax};
+  GCL_CHECK_ARG(prec != 0 || (!col_scale && !residual && !relu && !y_amax),
+                "gcl_conv_fwd_fused: the fused epilogue needs a split-precision mode");
   GCL_CHECK_ARG(x && wp && y, "gcl_conv_fwd: null pointer");
   GCL_CHECK_ARG(n_in > 0 && (long long)n_in * cin * 4 < (1ll << 32) - (1ll << 20),
                 "gcl_conv_fwd: the input tensor must be non-empty and smaller than 4 GiB (buffer addressing)");
@@ -1287,11 +1324,11 @@ int gcl_conv_fwd(const float* x, int64_t n_in, int32_t x_is_planes, const void* 
     if (PLV == 4 && x_is_planes)                                                                                 \
       hipLaunchKernelGGL((k_conv_fwd_split<NBV, 4, true>), sgrid, dim3(256), 0, st, x, (const u32x4*)wp, tbl,    \
                          order, tile_mask, (long long)n_out, K, cin, cout, bias, y, sswz, stats, x_amax, w_amax, \
-                         x_bytes);                                                                               \
+                         x_bytes, epi);                                                                               \
     else                                                                                                         \
       hipLaunchKernelGGL((k_conv_fwd_split<NBV, PLV>), sgrid, dim3(256), 0, st, x, (const u32x4*)wp, tbl, order, \
                          tile_mask, (long long)n_out, K, cin, cout, bias, y, sswz, stats, x_amax, w_amax,        \
-                         x_bytes);                                                                               \
+                         x_bytes, epi);                                                                               \
   } while (0)
 #define LAUNCH_SPLIT_NB(PLV)                                                             \
   {                                                                                      \

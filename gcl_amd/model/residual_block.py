@@ -24,8 +24,8 @@ class BasicBlockBase(nn.Module):
 
     def forward(self, x):
         shortcut = x if self.downsample is None else self.downsample(x)
-        y = self.norm1(self.conv1(x), relu=True)
-        return self.norm2(self.conv2(y), residual=shortcut, relu=True)
+        y = ME.conv_bn(self.conv1, self.norm1, x, relu=True)
+        return ME.conv_bn(self.conv2, self.norm2, y, residual=shortcut, relu=True)
 
 
 class BasicBlockBN(BasicBlockBase):

@@ -65,12 +65,12 @@ class ResUNet2(ME.MinkowskiNetwork):
         skips = {}
         out = x
         for l in (1, 2, 3, 4):
-            out = getattr(self, f"norm{l}")(getattr(self, f"conv{l}")(out))
+            out = ME.conv_bn(getattr(self, f"conv{l}"), getattr(self, f"norm{l}"), out)
             out = getattr(self, f"block{l}")(out)          # ends in a fused relu
             skips[l] = out
             out = MEF.relu(out)
         for l in (4, 3, 2):
-            out = getattr(self, f"norm{l}_tr")(getattr(self, f"conv{l}_tr")(out))
+            out = ME.conv_bn(getattr(self, f"conv{l}_tr"), getattr(self, f"norm{l}_tr"), out)
             out = MEF.relu(getattr(self, f"block{l}_tr")(out))
             out = ME.cat(out, skips[l - 1])
         out = self.final(MEF.relu(self.conv1_tr(out)))

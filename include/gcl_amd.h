@@ -184,6 +184,16 @@ int gcl_conv_fwd(const float* x, int64_t n_in, int32_t x_is_planes, const void* 
                  int64_t n_out, int32_t K,
                  int32_t cin, int32_t cout, const float* bias, float* y, float* stats, void* stream);
 
+/* gcl_conv_fwd with a fused inference epilogue: y = relu?(conv * col_scale + bias (+ residual)), i.e. convolution +
+ * BatchNorm in eval mode (col_scale = gamma * rsqrt(var + eps), bias = beta - mean * col_scale) + BasicBlock's residual
+ * add + ReLU in ONE launch (model/residual_block.py:37-53 with running statistics); y_amax (optional, zero-initialised
+ * amax slot) receives max|y| for the next fp16x3 convolution.  Split-precision modes only. */
+int gcl_conv_fwd_fused(const float* x, int64_t n_in, int32_t x_is_planes, const void* wp, int32_t prec,
+                       const int32_t* x_amax, const int32_t* w_amax, const int32_t* tbl, const int32_t* order,
+                       const int32_t* tile_mask, int64_t n_out, int32_t K, int32_t cin, int32_t cout, const float* bias,
+                       const float* col_scale, const float* residual, int32_t relu, int32_t* y_amax, float* y,
+                       float* stats, void* stream);
+
 /* dW[k] = sum over pairs of offset k of  A[pair_a]^T . B[pair_b]   (A: [*, ca], B: [*, cb]) -> dw [K, ca, cb].
  * Forward conv: A = X, pair_a = pair_in, B = dY, pair_b = pair_out.  Transposed conv: roles swapped.
  * Deterministic: per-wave partial slabs + ordered reduction.  prec as in gcl_conv_fwd (both operands are split
