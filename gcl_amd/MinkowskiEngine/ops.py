@@ -238,7 +238,7 @@ def _conv_launch(lib, x, Wk, mode, table, n_out, cin, cout, bias, pairs=0, want_
     if PROFILE is not None:
         nb = lib.gcl_conv_fwd_nb(n_out, cout, prec)
         pre = "true" if x_planes is not None else "false"
-        name = f"k_conv_fwd<{nb}>" if prec == 0 else f"k_conv_fwd_split<{nb},{prec},{pre}>"
+        name = f"k_conv_fwd<{nb}>" if prec == 0 else f"k_conv_fwd_split<{nb},{prec},{pre},false>"
     with _Timed(name, pairs, cin, cout):
         xin, is_planes = (x_planes, 1) if x_planes is not None else (x, 0)
         _lib.check(lib.gcl_conv_fwd(_lib.ptr(xin), x.shape[0], is_planes, _lib.ptr(wp), prec, _lib.ptr(x_amax),

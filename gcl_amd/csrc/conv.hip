@@ -430,7 +430,7 @@ struct ConvEpi {
 // 64 bytes of hi followed by 64 bytes of lo, i.e. the same 128 bytes per (row, slice) and the same addressing as the
 // fp32 rows.  The main loop then has no split at all (the kernels are instruction-issue-bound: the split was 48 of ~120
 // instructions per step), a fragment is two 16-byte LDS reads.
-template <int NB, int PL, bool PRE = false>
+template <int NB, int PL, bool PRE = false, bool EPI = false>
 __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict__ X, const u32x4* __restrict__ Wp,
                                                         const int* __restrict__ tbl, const int* __restrict__ order,
                                                         const int* __restrict__ tile_mask, long long n_out, int K,
@@ -620,7 +620,7 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
   for (int b = 0; b < NB; ++b) {
     const int col = (nb0 + b) * 32 + i;
     float bvv = bias ? bias[col] : 0.f;
-    float csc = epi.col_scale ? epi.col_scale[col] * out_scale : out_scale;
+    float csc = (EPI && epi.col_scale) ? epi.col_scale[col] * out_scale : out_scale;
     // consume the (conditional) loads HERE: otherwise every store below waits for all earlier stores (vmcnt(0))
     asm volatile("v_mov_b32 %0, %1" : "=v"(bvv) : "v"(bvv));
     asm volatile("v_mov_b32 %0, %1" : "=v"(csc) : "v"(csc));
@@ -630,12 +630,12 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
       int orow = __shfl(orow_l, (r & 3) + 8 * (r >> 2) + 4 * h);
       if (orow >= 0) {
         float v = acc[b][r] * csc + bvv;
-        if (epi.residual) v += epi.residual[(long long)orow * cout + col];
-        if (epi.relu) v = fmaxf(v, 0.f);
+        if (EPI && epi.residual) v += epi.residual[(long long)orow * cout + col];
+        if (EPI && epi.relu) v = fmaxf(v, 0.f);
         Y[(long long)orow * cout + col] = v;
         s1 += v;
         s2 += v * v;
-        ymax = fmaxf(ymax, fabsf(v));
+        if (EPI) ymax = fmaxf(ymax, fabsf(v));
       }
     }
     if (stats) {   // per-tile column sums for the BatchNorm that follows (saves its statistics pass over Y)
@@ -647,7 +647,7 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
       }
     }
   }
-  if (epi.y_amax) {   // one publish per wave (launches of this path are small: inference on single clouds)
+  if (EPI && epi.y_amax) {   // one publish per wave (launches of this path are small: inference on single clouds)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o));
     if (l == 0) amax_slot_publish(epi.y_amax, __float_as_int(ymax), (unsigned)tile);
@@ -1289,6 +1289,7 @@ int gcl_conv_fwd_fused(const float* x, int64_t n_in, int32_t x_is_planes, const 
                        const float* col_scale, const float* residual, int32_t relu, int32_t* y_amax, float* y,
                        float* stats, void* stream) {
   const ConvEpi epi{col_scale, residual, relu, y_amax};
+  const bool use_epi = col_scale || residual || relu || y_amax;
   GCL_CHECK_ARG(prec != 0 || (!col_scale && !residual && !relu && !y_amax),
                 "gcl_conv_fwd_fused: the fused epilogue needs a split-precision mode");
   GCL_CHECK_ARG(x && wp && y, "gcl_conv_fwd: null pointer");
@@ -1319,16 +1320,17 @@ int gcl_conv_fwd_fused(const float* x, int64_t n_in, int32_t x_is_planes, const 
 #define LAUNCH_F32(NBV)                                                                                          \
   hipLaunchKernelGGL(k_conv_fwd<NBV>, grid, dim3(256), 0, st, x, (const float4*)wp, tbl, order, tile_mask,       \
                      (long long)n_out, K, cin, cout, bias, y, swz)
+#define LAUNCH_SPLIT_I(NBV, PLV, PREV, EPIV)                                                                     \
+  hipLaunchKernelGGL((k_conv_fwd_split<NBV, PLV, PREV, EPIV>), sgrid, dim3(256), 0, st, x, (const u32x4*)wp, tbl, \
+                     order, tile_mask, (long long)n_out, K, cin, cout, bias, y, sswz, stats, x_amax, w_amax,     \
+                     x_bytes, epi)
 #define LAUNCH_SPLIT(NBV, PLV)                                                                                   \
   do {                                                                                                           \
-    if (PLV == 4 && x_is_planes)                                                                                 \
-      hipLaunchKernelGGL((k_conv_fwd_split<NBV, 4, true>), sgrid, dim3(256), 0, st, x, (const u32x4*)wp, tbl,    \
-                         order, tile_mask, (long long)n_out, K, cin, cout, bias, y, sswz, stats, x_amax, w_amax, \
-                         x_bytes, epi);                                                                               \
-    else                                                                                                         \
-      hipLaunchKernelGGL((k_conv_fwd_split<NBV, PLV>), sgrid, dim3(256), 0, st, x, (const u32x4*)wp, tbl, order, \
-                         tile_mask, (long long)n_out, K, cin, cout, bias, y, sswz, stats, x_amax, w_amax,        \
-                         x_bytes, epi);                                                                               \
+    if (PLV == 4 && x_is_planes) {                                                                               \
+      if (use_epi) LAUNCH_SPLIT_I(NBV, 4, true, true); else LAUNCH_SPLIT_I(NBV, 4, true, false);                 \
+    } else {                                                                                                     \
+      if (use_epi) LAUNCH_SPLIT_I(NBV, PLV, false, true); else LAUNCH_SPLIT_I(NBV, PLV, false, false);           \
+    }                                                                                                            \
   } while (0)
 #define LAUNCH_SPLIT_NB(PLV)                                                             \
   {                                                                                      \
@@ -1347,6 +1349,7 @@ int gcl_conv_fwd_fused(const float* x, int64_t n_in, int32_t x_is_planes, const 
   } else LAUNCH_SPLIT_NB(4)
 #undef LAUNCH_F32
 #undef LAUNCH_SPLIT
+#undef LAUNCH_SPLIT_I
 #undef LAUNCH_SPLIT_NB
 #undef LAUNCH_SPLIT_NB2
   GCL_CHECK_LAUNCH();
