@@ -117,19 +117,20 @@ __global__ void __launch_bounds__(SC_TILE) k_sc_local_max(const float* __restric
 }
 
 // ---- tight compatibility as a bit matrix: bit j of row i = (cross_ij < thr)  (:354) ---------------------------
+// one wavefront per row i: lanes = 64 consecutive columns j (coalesced point reads), one ballot per word
 __global__ void __launch_bounds__(256) k_sc_tight_bits(const float* __restrict__ src, const float* __restrict__ tgt,
                                                        int n, int words, float thr, unsigned long long* bits) {
-  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= (long long)n * words) return;
-  const int i = (int)(e / words), w = (int)(e % words);
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;                                   // whole wave
   const P3 si = ld3(src, i), ti = ld3(tgt, i);
-  unsigned long long b = 0;
-  const int jend = min(n, w * 64 + 64);
-  for (int j = w * 64; j < jend; ++j) {
-    const float cd = fabsf(dist3(si, ld3(src, j)) - dist3(ti, ld3(tgt, j)));
-    b |= (unsigned long long)(cd < thr) << (j & 63);
+  for (int w = 0; w < words; ++w) {
+    const int j = w * 64 + lane;
+    bool ok = false;
+    if (j < n) ok = fabsf(dist3(si, ld3(src, j)) - dist3(ti, ld3(tgt, j))) < thr;
+    const unsigned long long b = __ballot(ok);
+    if (lane == 0) bits[(size_t)i * words + w] = b;
   }
-  bits[e] = b;
 }
 
 // ---- per seed: second-order measure row and its k1 largest entries (:353-361, :85-86) -------------------------
@@ -449,8 +450,8 @@ int gcl_sc2_seed_knn(const float* src, const float* tgt, int32_t n, const int64_
                 "gcl_sc2_seed_knn: need n <= %d, 1 <= k1 <= min(32, n)", SC_MAXN);
   hipStream_t st = (hipStream_t)stream;
   const int words = (n + 63) / 64;
-  hipLaunchKernelGGL(k_sc_tight_bits, dim3((unsigned)cdiv((long long)n * words, 256)), dim3(256), 0, st, src, tgt, n,
-                     words, d_thre * 0.5f, (unsigned long long*)bits);
+  hipLaunchKernelGGL(k_sc_tight_bits, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, st, src, tgt, n, words, d_thre * 0.5f,
+                     (unsigned long long*)bits);
   hipLaunchKernelGGL(k_sc_seed_knn, dim3(n_seeds), dim3(256), 0, st, src, tgt, (const unsigned long long*)bits, n,
                      words, (const long long*)seeds, d_thre, k1, knn);
   GCL_CHECK_LAUNCH();
