@@ -22,11 +22,11 @@ from . import utils
 from . import MinkowskiFunctional  # noqa: F401  (import MinkowskiEngine.MinkowskiFunctional as MEF)
 from .core import CoordinateManager, CoordinateMapKey, SparseTensor, cat
 from . import ops
-from .ops import batch_norm, set_conv_precision, sparse_conv
+from .ops import batch_norm, invalidate_amax, set_conv_precision, sparse_conv
 
 __all__ = ["SparseTensor", "CoordinateManager", "CoordinateMapKey", "MinkowskiConvolution",
            "MinkowskiConvolutionTranspose", "MinkowskiBatchNorm", "MinkowskiInstanceNorm", "MinkowskiNetwork",
-           "MinkowskiFunctional", "cat", "utils", "set_conv_precision"]
+           "MinkowskiFunctional", "cat", "utils", "set_conv_precision", "invalidate_amax"]
 
 
 # tuning knob: let convolutions emit the column sums a following BatchNorm needs (saves its statistics pass)
@@ -48,6 +48,11 @@ class MinkowskiNetwork(nn.Module):
         if self._amax_group is None:
             ws = [m.kernel for m in self.modules() if isinstance(m, _ConvBase) and m.in_channels > 4]
             self._amax_group = ops.WeightAmaxGroup(ws) if ws else False
+        elif self._amax_group and self.training:
+            # training forwards re-measure max|W| unconditionally (the launch happens once per optimizer step anyway):
+            # writes through ``p.data`` / raw aliases do not bump ``p._version`` and would leave a stale scale.  In eval
+            # mode the tags are keyed on ``_version``; after such a write call ME.invalidate_amax()
+            self._amax_group.void_tags()
 
 
 class _ConvBase(nn.Module):
@@ -141,6 +146,7 @@ class MinkowskiBatchNorm(nn.Module):
             raise NotImplementedError("affine=True, track_running_stats=True only")
         self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum, affine=True, track_running_stats=True)
         self._pending_batches = 0                # training forwards not yet added to bn.num_batches_tracked (device)
+        self._train_forwards = 0                 # monotonic: the running statistics change through raw pointers
         self.register_state_dict_pre_hook(MinkowskiBatchNorm._flush_batches)
 
     @staticmethod
@@ -157,7 +163,7 @@ class MinkowskiBatchNorm(nn.Module):
         """(scale, shift) of the eval-mode BatchNorm y = x * scale + shift, cached until a parameter or buffer changes."""
         bn = self.bn
         key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
-               bn.weight.data_ptr(), bn.running_mean.data_ptr())
+               bn.weight.data_ptr(), bn.running_mean.data_ptr(), self._train_forwards, float(bn.eps))
         cached = getattr(self, "_affine", None)
         if cached is None or cached[0] != key:
             with torch.no_grad():
@@ -175,6 +181,7 @@ class MinkowskiBatchNorm(nn.Module):
                        bn.momentum, bn.eps, res, relu, getattr(x, "_bn_stats", None))
         if self.training:
             self._pending_batches += 1           # flushed into bn.num_batches_tracked when the state is read
+            self._train_forwards += 1            # voids the cached eval-mode (scale, shift)
         out = SparseTensor(F, coordinate_map_key=x.coordinate_map_key, coordinate_manager=x.coordinate_manager)
         out._nonneg = bool(relu)
         return out

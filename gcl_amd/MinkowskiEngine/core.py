@@ -352,6 +352,7 @@ class SparseTensor:
         self._same_map(other)
         self._F = self._F + other.F
         self._nonneg = False
+        self._bn_stats = None          # column sums published by a convolution describe the OLD features
         return self
 
     def __add__(self, other):

@@ -145,6 +145,10 @@ class WeightAmaxGroup:
         self.packs = {}          # direction ("fwd" / "bwd") -> (tag, [packed views])
         self.bwd_modes = {}      # param index -> 1 | 2, recorded by the convolutions during the forward pass
 
+    def void_tags(self):
+        for p in self.params:
+            p._gcl_amax = None
+
     def _shape3(self, p):
         return tuple(p.shape) if p.dim() == 3 else (1,) + tuple(p.shape)
 
@@ -215,14 +219,14 @@ def ctypes_offset(t, elem):
 
 
 def _conv_launch(lib, x, Wk, mode, table, n_out, cin, cout, bias, pairs=0, want_stats=False, x_amax=None,
-                 w_amax=None, wp=None, x_planes=None):
+                 w_amax=None, wp=None, x_planes=None, generic=False):
     """One output-stationary convolution launch.  ``Wk`` [K, *, *] is packed for ``mode`` (0 forward, 1 transposed,
     2 transposed + mirrored offsets) in the current precision; ``table`` = (tbl, order, tile_mask) from
     KernelMap.sorted_table(), or None for a kernel_size-1 conv; (cin, cout) are the EFFECTIVE widths of the launch.
     ``want_stats``: also return the per-tile column sums [ceil(n_out/32), 2, cout] for a following BatchNorm."""
     prec = _PREC_CODES[PRECISION]
     K, wc_in, wc_out = Wk.shape
-    if prec == 4:
+    if prec == 4 and not generic:
         x_amax = x_amax if x_amax is not None else tensor_amax(lib, x)
         w_amax = w_amax if w_amax is not None else tensor_amax(lib, Wk)
     if wp is None:      # not served by a WeightAmaxGroup launch: pack this tensor now
@@ -238,7 +242,8 @@ def _conv_launch(lib, x, Wk, mode, table, n_out, cin, cout, bias, pairs=0, want_
     if PROFILE is not None:
         nb = lib.gcl_conv_fwd_nb(n_out, cout, prec)
         pre = "true" if x_planes is not None else "false"
-        name = f"k_conv_fwd<{nb}>" if prec == 0 else f"k_conv_fwd_split<{nb},{prec},{pre},false>"
+        name = "k_conv_generic" if generic else \
+            (f"k_conv_fwd<{nb}>" if prec == 0 else f"k_conv_fwd_split<{nb},{prec},{pre},false>")
     with _Timed(name, pairs, cin, cout):
         xin, is_planes = (x_planes, 1) if x_planes is not None else (x, 0)
         _lib.check(lib.gcl_conv_fwd(_lib.ptr(xin), x.shape[0], is_planes, _lib.ptr(wp), prec, _lib.ptr(x_amax),
@@ -255,19 +260,21 @@ class _SparseConvFn(torch.autograd.Function):
     def forward(ctx, x, W, bias, kmap, n_out, transpose, mgr, want_stats):
         lib = _lib.require_gpu()
         stats = None
-        fp16x3 = _PREC_CODES[PRECISION] == 4
-        x_known = known_amax(x) if fp16x3 else None
-        w_known = tensor_amax(lib, W) if (fp16x3 and W.is_contiguous() and W.shape[-2] > 4) else None
         x = x.contiguous()
         Wk = (W if W.dim() == 3 else W.unsqueeze(0)).contiguous()
         K, cin, cout = Wk.shape
         if x.shape[1] != cin:
             raise ValueError(f"feature width {x.shape[1]} != in_channels {cin}")
-        ctx.stem = cin <= 4
+        # three kernel families behind the C ABI: the first-layer VALU kernels (Cin <= 4), the exact-fp32 VALU kernels
+        # for generic shapes (any Cin / Cout, K <= 125) and the MFMA kernels (Cin, Cout multiples of 32, K <= 27)
+        ctx.stem = cin <= 4 and cout % 32 == 0 and not transpose and kmap is not None and bias is None
+        ctx.generic = generic = (not ctx.stem) and (cin % 32 != 0 or cout % 32 != 0 or K > 27)
+        fp16x3 = _PREC_CODES[PRECISION] == 4 and not ctx.stem and not generic
+        x_known = known_amax(x) if fp16x3 else None
+        w_known = tensor_amax(lib, W) if (fp16x3 and W.is_contiguous()) else None
         ctx.x_amax = ctx.w_amax = None
+        ctx.group = ctx.param = None
         if ctx.stem:
-            if transpose or kmap is None or bias is not None:
-                raise NotImplementedError("Cin <= 4 is supported for the first (non-transposed, bias-free) conv only")
             y = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
             _lib.check(lib.gcl_stem_fwd(_lib.ptr(x, torch.float32), _lib.ptr(Wk), _lib.ptr(kmap.nbr), n_out, K, cin,
                                         cout, _lib.ptr(y), _lib.stream()), "gcl_stem_fwd")
@@ -279,17 +286,18 @@ class _SparseConvFn(torch.autograd.Function):
             if fp16x3:
                 ctx.x_amax = x_known if x_known is not None else tensor_amax(lib, x)
                 ctx.w_amax = w_known if w_known is not None else tensor_amax(lib, Wk)
-            group = getattr(W, "_gcl_amax_group", None) if w_known is not None else None
+            group = getattr(W, "_gcl_amax_group", None) if (w_known is not None or generic) else None
             wp = None
             if group is not None:     # packed with all other kernels of the network; remember the backward layout
                 group.bwd_modes[W._gcl_group_index] = 2 if (kmap is not None and not transpose and kmap.same_map) else 1
                 wp = group.packed(lib, W, 0)
             ctx.group, ctx.param = group, (W if group is not None else None)
             xp = planes_of(lib, x, ctx.x_amax) if (fp16x3 and _want_planes(cin)) else None
-            y, stats = _conv_launch(lib, x, Wk, 0, tbl, n_out, cin, cout, b, ctx.pairs, want_stats=True,
-                                    x_amax=ctx.x_amax, w_amax=ctx.w_amax, wp=wp, x_planes=xp) \
-                if want_stats else (_conv_launch(lib, x, Wk, 0, tbl, n_out, cin, cout, b, ctx.pairs,
-                                                 x_amax=ctx.x_amax, w_amax=ctx.w_amax, wp=wp, x_planes=xp), None)
+            want_stats = want_stats and not generic
+            y = _conv_launch(lib, x, Wk, 0, tbl, n_out, cin, cout, b, ctx.pairs, want_stats=want_stats,
+                             x_amax=ctx.x_amax, w_amax=ctx.w_amax, wp=wp, x_planes=xp, generic=generic)
+            if want_stats:
+                y, stats = y
         ctx.save_for_backward(x, Wk)
         ctx.set_materialize_grads(False)       # no zero-filled gradient for the (non-differentiable) statistics output
         ctx.kmap, ctx.transpose, ctx.mgr, ctx.w_shape, ctx.has_bias = kmap, transpose, mgr, W.shape, bias is not None
@@ -306,15 +314,16 @@ class _SparseConvFn(torch.autograd.Function):
             return (None,) * 8
         x, Wk = ctx.saved_tensors
         K, cin, cout = Wk.shape
-        kmap, transpose = ctx.kmap, ctx.transpose
+        kmap, transpose, generic = ctx.kmap, ctx.transpose, ctx.generic
         prec = _PREC_CODES[PRECISION]
-        dy_amax = known_amax(dy) if (prec == 4 and not ctx.stem) else None
+        fp16x3 = prec == 4 and not ctx.stem and not generic
+        dy_amax = known_amax(dy) if fp16x3 else None
         dy = dy.contiguous()
         dx = dW = dbias = None
-        if dy_amax is None and prec == 4 and not ctx.stem:
+        if dy_amax is None and fp16x3:
             dy_amax = tensor_amax(lib, dy)
-        x_amax = ctx.x_amax if (prec != 4 or ctx.x_amax is not None or ctx.stem) else tensor_amax(lib, x)
-        w_amax = ctx.w_amax if (prec != 4 or ctx.w_amax is not None or ctx.stem) else tensor_amax(lib, Wk)
+        x_amax = ctx.x_amax if (not fp16x3 or ctx.x_amax is not None) else tensor_amax(lib, x)
+        w_amax = ctx.w_amax if (not fp16x3 or ctx.w_amax is not None) else tensor_amax(lib, Wk)
         if not ctx.stem and PROFILE is not None:
             ctx.pairs = kmap.n_pairs if kmap is not None else x.shape[0]
         if ctx.needs_input_grad[0]:
@@ -328,11 +337,11 @@ class _SparseConvFn(torch.autograd.Function):
                 mode, tbl = 2, kmap.sorted_table(transposed=False)
             else:
                 mode, tbl = 1, kmap.sorted_table(transposed=True)
-            group = getattr(ctx, "group", None)
+            group = ctx.group
             wp = group.packed(lib, ctx.param, mode) if group is not None else None
-            dyp = planes_of(lib, dy, dy_amax) if (prec == 4 and _want_planes(cout)) else None
+            dyp = planes_of(lib, dy, dy_amax) if (fp16x3 and _want_planes(cout)) else None
             dx = _conv_launch(lib, dy, Wk, mode, tbl, x.shape[0], cout, cin, None, ctx.pairs, x_amax=dy_amax,
-                              w_amax=w_amax, wp=wp, x_planes=dyp)
+                              w_amax=w_amax, wp=wp, x_planes=dyp, generic=generic)
         if ctx.needs_input_grad[1]:
             dW = torch.empty_like(Wk)
             if ctx.stem:
@@ -351,9 +360,12 @@ class _SparseConvFn(torch.autograd.Function):
                 scratch = torch.empty(lib.gcl_conv_bwd_weight_scratch_len(K, cin, cout, seg[-1]), dtype=torch.float32,
                                       device=x.device)
                 tile = f"{64 if cin % 64 == 0 else 32},{64 if cout % 64 == 0 else 32}"
-                use_pl = prec == 4 and _want_planes(cin) and _want_planes(cout)
-                name = f"k_conv_bwd_weight<{tile}>" if prec == 0 else \
-                    f"k_conv_bwd_weight_split<{tile},{prec},{'true' if use_pl else 'false'}>"
+                use_pl = fp16x3 and _want_planes(cin) and _want_planes(cout)
+                name = "k_conv_bwd_weight_generic" if (cin % 32 or cout % 32) else \
+                    (f"k_conv_bwd_weight<{tile}>" if prec == 0 else
+                     f"k_conv_bwd_weight_split<{tile},{prec},{'true' if use_pl else 'false'}>")
+                if prec == 4 and not fp16x3 and not (cin % 32 or cout % 32):     # K > 27 with MFMA-shaped channels
+                    x_amax, dy_amax = tensor_amax(lib, x), tensor_amax(lib, dy)
                 with _Timed(name, ctx.pairs, cin, cout):
                     xa = planes_of(lib, x, x_amax) if use_pl else x
                     ya = planes_of(lib, dy, dy_amax) if use_pl else dy

@@ -88,10 +88,25 @@ _lib = None
 def build(force=False, verbose=False):
     """Compile csrc/*.hip for gfx950 into csrc/libgcl_hip.so (in-tree, so it travels to the GPU box)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "common.h"), HEADER]
+    hdrs = [os.path.join(CSRC, "common.h"), HEADER]
+    deps = srcs + hdrs
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH] + srcs
+    # one object per translation unit, stale ones compiled concurrently, then one link
+    hdr_time = max(os.path.getmtime(h) for h in hdrs)
+    objs, jobs = [], []
+    for s in srcs:
+        o = s[:-4] + ".o"
+        objs.append(o)
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_time):
+            cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in jobs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = ["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
@@ -141,6 +156,12 @@ def ptr(t, dtype=None):
         return None
     if not t.is_cuda:
         raise RuntimeError("gcl_amd operators take GPU tensors only (no CPU path)")
+    if t.device.index != torch._C._cuda_getDevice():
+        # kernels are launched on the CURRENT device's stream: a tensor that lives elsewhere would be read / written by
+        # the wrong GPU, unordered against torch's own work on its device
+        raise RuntimeError(f"gcl_amd: tensor on cuda:{t.device.index} but the current device is "
+                           f"cuda:{torch._C._cuda_getDevice()}; call torch.cuda.set_device({t.device.index}) (one "
+                           "process per GPU) or wrap the call in `with torch.cuda.device(t.device):`")
     if not t.is_contiguous():
         raise RuntimeError("gcl_amd: tensor must be contiguous")
     if dtype is not None and t.dtype != dtype:

@@ -414,6 +414,16 @@ __global__ void __launch_bounds__(256) k_pack_weights_multi(const PackDesc* __re
   const PackDesc d = desc[lo];
   const long long o = ((long long)blockIdx.x - d.first_wg) * 256 + threadIdx.x;
   if (o >= d.K * d.cin * d.cout) return;
+  if ((d.cin & 31) || (d.cout & 31) || d.K > 27) {      // generic shape: fp32 W_eff[k][c][n] (k_pack_weights_generic)
+    const int cin = (int)d.cin, cout = (int)d.cout, K = (int)d.K, mode = (int)d.mode;
+    const float* w = reinterpret_cast<const float*>(d.w);
+    const int cin_e = mode == 0 ? cin : cout, cout_e = mode == 0 ? cout : cin;
+    const int n = (int)(o % cout_e), c = (int)((o / cout_e) % cin_e), k = (int)(o / ((long long)cin_e * cout_e));
+    reinterpret_cast<float*>(out + d.out_off)[o] =
+        (mode == 0) ? w[((long long)k * cin + c) * cout + n]
+                    : w[((long long)((mode == 2) ? (K - 1 - k) : k) * cin + n) * cout + c];
+    return;
+  }
   pack_split_one<PL>(reinterpret_cast<const float*>(d.w), (int)d.K, (int)d.cin, (int)d.cout, (int)d.mode,
                      amax_slots + d.amax_index * AMAX_WORDS, reinterpret_cast<unsigned short*>(out + d.out_off), o);
 }
@@ -1046,7 +1056,7 @@ static int bwd_weight_wgs(long long n_chunks) {
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_stem_fwd(const float* __restrict__ x, const float* __restrict__ w,
                                                   const int* __restrict__ nbr, long long n_out, int K, int cin,
-                                                  float* __restrict__ y) {
+                                                  int cout, float* __restrict__ y) {
   // thread = output row; the weights W[k][ci][0..31] are wave-uniform and come through the scalar cache (s_load),
   // so the inner product costs one v_fmac with an SGPR operand per (offset, channel) and no LDS traffic
   long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1059,13 +1069,13 @@ __global__ void __launch_bounds__(256) k_stem_fwd(const float* __restrict__ x, c
     int idx = nbr[(long long)k * n_out + v];
     for (int ci = 0; ci < cin; ++ci) {
       float xv = idx >= 0 ? x[(long long)idx * cin + ci] : 0.f;
-      const float* wr = w + (k * cin + ci) * 32;
+      const float* wr = w + (long long)(k * cin + ci) * cout + blockIdx.y * 32;     // blockIdx.y = 32-column block
 #pragma unroll
       for (int c = 0; c < 32; ++c) acc[c] = fmaf(xv, wr[c], acc[c]);
     }
   }
   if ((long long)blockIdx.x * blockDim.x + threadIdx.x >= n_out) return;
-  float4* yo = reinterpret_cast<float4*>(y + v * 32);
+  float4* yo = reinterpret_cast<float4*>(y + v * cout + blockIdx.y * 32);
 #pragma unroll
   for (int c4 = 0; c4 < 8; ++c4) yo[c4] = make_float4(acc[4 * c4], acc[4 * c4 + 1], acc[4 * c4 + 2], acc[4 * c4 + 3]);
 }
@@ -1081,8 +1091,9 @@ constexpr int STEM_KMAX = 125;
 constexpr int STEM_TILE = 128, STEM_LD = STEM_TILE + 1;
 __global__ void __launch_bounds__(256) k_stem_bwd_weight(const float* __restrict__ x, const float* __restrict__ dy,
                                                          const int* __restrict__ nbr, long long n_out, int K,
-                                                         int cin, float* slabs) {
-  __shared__ float As[128 * STEM_LD];          // 66 KB; reused as the cross-wave reduction buffer [4][4*16*64]
+                                                         int cin, int cout, float* slabs) {
+  __shared__ float As[128 * STEM_LD];
+  const int cb0 = blockIdx.y * 32;             // 32-column block of dY / dW          // 66 KB; reused as the cross-wave reduction buffer [4][4*16*64]
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = l & 31, h = l >> 5;
   const long long r_begin = (long long)blockIdx.x * STEM_ROWS_PER_WG;
@@ -1119,7 +1130,7 @@ __global__ void __launch_bounds__(256) k_stem_bwd_weight(const float* __restrict
       for (int s = 0; s < 16; ++s) {
         const int rl = w * 32 + 2 * s + h;
         const long long row = r0 + rl;
-        const float b = (row < r_end) ? dy[row * 32 + i] : 0.f;
+        const float b = (row < r_end) ? dy[row * cout + cb0 + i] : 0.f;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
           acc[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(kb * 32 + i) * STEM_LD + rl], b, acc[kb], 0, 0, 0);
@@ -1136,7 +1147,7 @@ __global__ void __launch_bounds__(256) k_stem_bwd_weight(const float* __restrict
       float v = red[e] + red[4096 + e] + red[8192 + e] + red[12288 + e];
       int ll = e & 63, r = (e >> 6) & 15, kb = e >> 10;
       int k = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ll >> 5);
-      if (k < K) slabs[((long long)blockIdx.x * K * cin + (long long)k * cin + ci) * 32 + (ll & 31)] = v;
+      if (k < K) slabs[((long long)blockIdx.x * K * cin + (long long)k * cin + ci) * cout + cb0 + (ll & 31)] = v;
     }
   }
 }
@@ -1164,6 +1175,133 @@ __global__ void __launch_bounds__(256) k_stem_reduce(const float* __restrict__ s
   if (part == 0 && e < mat) dw[e] = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// generic shapes (any Cin / Cout, K up to 125): exact-fp32 VALU kernels.  The MFMA kernels above need channel
+// counts that are multiples of 32 and K <= 27; everything else -- demo.py:29's 16-dim head (`final` 64 -> 16), a
+// 5^3 convolution on wide features -- runs here, so that the C ABI takes every shape the reference's models can have.
+// These layers are small: a thread owns one output row x TC output columns, the weights W_eff[k][c][n0 .. n0+TC) are
+// wave-uniform and come through the scalar cache (as in k_stem_fwd), rows are read 16 bytes at a time when aligned.
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_pack_weights_generic(const float* __restrict__ w, int K, int cin, int cout, int mode, float* wp) {
+  long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= (long long)K * cin * cout) return;
+  const int cin_e = mode == 0 ? cin : cout, cout_e = mode == 0 ? cout : cin;
+  const int n = (int)(o % cout_e), c = (int)((o / cout_e) % cin_e), k = (int)(o / ((long long)cin_e * cout_e));
+  float v;
+  if (mode == 0) v = w[((long long)k * cin + c) * cout + n];
+  else v = w[((long long)((mode == 2) ? (K - 1 - k) : k) * cin + n) * cout + c];
+  wp[o] = v;
+}
+
+template <int TC>
+__global__ void __launch_bounds__(256) k_conv_generic(const float* __restrict__ X, const float* __restrict__ W,
+                                                      const int* __restrict__ tbl, const int* __restrict__ order,
+                                                      long long n_out, int K, int cin, int cout,
+                                                      const float* __restrict__ bias, float* __restrict__ Y,
+                                                      ConvEpi epi) {
+  long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = r < n_out;
+  if (!live) r = n_out - 1;             // keep the wave uniform; the duplicates are not stored
+  const int n0 = blockIdx.y * TC;
+  const int ncol = (cout - n0 < TC) ? cout - n0 : TC;
+  float acc[TC];
+#pragma unroll
+  for (int j = 0; j < TC; ++j) acc[j] = 0.f;
+  const bool vec = (cin & 3) == 0;
+  for (int k = 0; k < K; ++k) {
+    const int idx = tbl ? tbl[(long long)k * n_out + r] : (int)r;
+    if (idx < 0) continue;
+    const float* xr = X + (long long)idx * cin;
+    const float* wk = W + (long long)k * cin * cout + n0;
+    if (vec) {
+      for (int c = 0; c < cin; c += 4) {
+        const float4 xv = *reinterpret_cast<const float4*>(xr + c);
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float* wr = wk + (long long)(c + q) * cout;
+#pragma unroll
+          for (int j = 0; j < TC; ++j) acc[j] = fmaf(xs[q], wr[j < ncol ? j : 0], acc[j]);
+        }
+      }
+    } else {
+      for (int c = 0; c < cin; ++c) {
+        const float xv = xr[c];
+        const float* wr = wk + (long long)c * cout;
+#pragma unroll
+        for (int j = 0; j < TC; ++j) acc[j] = fmaf(xv, wr[j < ncol ? j : 0], acc[j]);
+      }
+    }
+  }
+  float ymax = 0.f;
+  if (live) {
+    const long long orow = order ? order[r] : r;
+#pragma unroll
+    for (int j = 0; j < TC; ++j) {
+      if (j < ncol) {
+        const int col = n0 + j;
+        float v = acc[j] * (epi.col_scale ? epi.col_scale[col] : 1.f) + (bias ? bias[col] : 0.f);
+        if (epi.residual) v += epi.residual[orow * cout + col];
+        if (epi.relu) v = fmaxf(v, 0.f);
+        Y[orow * cout + col] = v;
+        ymax = fmaxf(ymax, fabsf(v));
+      }
+    }
+  }
+  if (epi.y_amax) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o));
+    if ((threadIdx.x & 63) == 0) amax_slot_publish(epi.y_amax, __float_as_int(ymax), blockIdx.x * 4 + (threadIdx.x >> 6));
+  }
+}
+
+// weight gradient for generic shapes: workgroup = (range of 128-pair chunks, 16 x 16 tile of dW); thread (i, j) keeps
+// one element.  Per chunk the 128 x 16 pieces of both operands are staged in LDS.  Same slab / ordered-reduction scheme
+// as the MFMA kernels (k_bwd_weight_reduce), so the result is deterministic.
+__global__ void __launch_bounds__(256) k_conv_bwd_weight_generic(const float* __restrict__ A, const float* __restrict__ B,
+                                                                 const int* __restrict__ pair_a,
+                                                                 const int* __restrict__ pair_b, SegOffW seg, int K,
+                                                                 int ca, int cb, long long n_chunks, int per,
+                                                                 float* slabs) {
+  __shared__ float As[GCL_PAIR_CHUNK][17], Bs[GCL_PAIR_CHUNK][17];
+  const int t = threadIdx.x, i = t >> 4, j = t & 15;
+  const int tiles_b = (cb + 15) / 16;
+  const int ca0 = (blockIdx.y / tiles_b) * 16, cb0 = (blockIdx.y % tiles_b) * 16;
+  const long long c0 = (long long)blockIdx.x * per;
+  const long long c1 = (c0 + per < n_chunks) ? c0 + per : n_chunks;
+  if (c0 >= c1) return;
+  const long long mat = (long long)ca * cb;
+  float acc = 0.f;
+  int kcur = 0;
+  while (seg.off[kcur + 1] <= c0 * GCL_PAIR_CHUNK) ++kcur;
+  auto flush = [&](int k) {
+    if (ca0 + i < ca && cb0 + j < cb) slabs[(long long)(blockIdx.x + k) * mat + (long long)(ca0 + i) * cb + cb0 + j] = acc;
+    acc = 0.f;
+  };
+  for (long long c = c0; c < c1; ++c) {
+    const long long pbase = c * GCL_PAIR_CHUNK;
+    if (pbase >= seg.off[kcur + 1]) {
+      flush(kcur);
+      while (seg.off[kcur + 1] <= pbase) ++kcur;
+    }
+    __syncthreads();
+    for (int e = t; e < GCL_PAIR_CHUNK * 16; e += 256) {
+      const int p = e >> 4, ch = e & 15;
+      const int ia = pair_a[pbase + p], ib = pair_b[pbase + p];
+      As[p][ch] = (ia >= 0 && ca0 + ch < ca) ? A[(long long)ia * ca + ca0 + ch] : 0.f;
+      Bs[p][ch] = (ib >= 0 && cb0 + ch < cb) ? B[(long long)ib * cb + cb0 + ch] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int p = 0; p < GCL_PAIR_CHUNK; ++p) acc = fmaf(As[p][i], Bs[p][j], acc);
+  }
+  flush(kcur);
+}
+
+// shapes the MFMA kernels do not take
+static bool generic_shape(int K, int cin, int cout) { return (cin % 32) != 0 || (cout % 32) != 0 || K > 27; }
+
 }  // namespace gcl
 
 using namespace gcl;
@@ -1183,6 +1321,7 @@ int gcl_debug_stamps(unsigned long long* out_host, int reset) {
 
 int64_t gcl_pack_weights_bytes(int32_t K, int32_t cin, int32_t cout, int32_t prec) {
   long long n = (long long)K * cin * cout;
+  if (generic_shape(K, cin, cout)) return n * 4;      // fp32 W_eff[k][c][n] for the generic kernels
   return prec == 0 ? n * 4 : n * 2 * (prec == 3 ? 3 : 2);
 }
 
@@ -1228,14 +1367,18 @@ int gcl_split_planes(const float* x, int64_t n, int32_t c, const int32_t* amax, 
 int gcl_pack_weights(const float* w, int32_t K, int32_t cin, int32_t cout, int32_t mode, int32_t prec,
                      const int32_t* w_amax, void* wp, void* stream) {
   GCL_CHECK_ARG(w && wp, "gcl_pack_weights: null pointer");
-  GCL_CHECK_ARG(K >= 1 && cin % 32 == 0 && cout % 32 == 0 && cin > 0 && cout > 0,
-                "gcl_pack_weights: Cin (%d) and Cout (%d) must be positive multiples of 32", cin, cout);
+  GCL_CHECK_ARG(K >= 1 && K <= 125 && cin > 0 && cout > 0, "gcl_pack_weights: bad shape (K %d, Cin %d, Cout %d)", K, cin, cout);
   GCL_CHECK_ARG(mode >= 0 && mode <= 2, "gcl_pack_weights: mode must be 0, 1 or 2");
   GCL_CHECK_ARG(prec_ok(prec), "gcl_pack_weights: prec must be 0 (f32), 2 (bf16x3), 3 (bf16x6) or 4 (fp16x3)");
-  GCL_CHECK_ARG(prec != 4 || w_amax, "gcl_pack_weights: fp16x3 needs the weight tensor's gcl_amax");
   long long total = (long long)K * cin * cout;
   dim3 grid((unsigned)cdiv(total, 256));
   hipStream_t st = (hipStream_t)stream;
+  if (generic_shape(K, cin, cout)) {
+    hipLaunchKernelGGL(k_pack_weights_generic, grid, dim3(256), 0, st, w, K, cin, cout, mode, (float*)wp);
+    GCL_CHECK_LAUNCH();
+    return GCL_OK;
+  }
+  GCL_CHECK_ARG(prec != 4 || w_amax, "gcl_pack_weights: fp16x3 needs the weight tensor's gcl_amax");
   if (prec == 0) hipLaunchKernelGGL(k_pack_weights, grid, dim3(256), 0, st, w, K, cin, cout, mode, (float*)wp);
   else if (prec == 2) hipLaunchKernelGGL(k_pack_weights_split<2>, grid, dim3(256), 0, st, w, K, cin, cout, mode, w_amax, (unsigned short*)wp);
   else if (prec == 3) hipLaunchKernelGGL(k_pack_weights_split<3>, grid, dim3(256), 0, st, w, K, cin, cout, mode, w_amax, (unsigned short*)wp);
@@ -1290,9 +1433,25 @@ int gcl_conv_fwd_fused(const float* x, int64_t n_in, int32_t x_is_planes, const 
                        float* stats, void* stream) {
   const ConvEpi epi{col_scale, residual, relu, y_amax};
   const bool use_epi = col_scale || residual || relu || y_amax;
-  GCL_CHECK_ARG(prec != 0 || (!col_scale && !residual && !relu && !y_amax),
+  GCL_CHECK_ARG(prec != 0 || generic_shape(K, cin, cout) || (!col_scale && !residual && !relu && !y_amax),
                 "gcl_conv_fwd_fused: the fused epilogue needs a split-precision mode");
   GCL_CHECK_ARG(x && wp && y, "gcl_conv_fwd: null pointer");
+  if (generic_shape(K, cin, cout)) {     // any Cin / Cout, K <= 125: exact-fp32 VALU kernel (wp = fp32 W_eff, see gcl_pack_weights)
+    GCL_CHECK_ARG(n_in > 0 && n_out > 0 && K >= 1 && K <= 125 && cin > 0 && cout > 0, "gcl_conv_fwd: bad shape");
+    GCL_CHECK_ARG(tbl || K == 1, "gcl_conv_fwd: a neighbour table is required when K > 1");
+    GCL_CHECK_ARG(!stats, "gcl_conv_fwd: fused BN statistics need Cin, Cout multiples of 32 and K <= 27");
+    GCL_CHECK_ARG(!x_is_planes, "gcl_conv_fwd: plane images need Cin, Cout multiples of 32 and K <= 27");
+    hipStream_t gst = (hipStream_t)stream;
+    if (cout > 8) {
+      hipLaunchKernelGGL(k_conv_generic<16>, dim3((unsigned)cdiv(n_out, 256), (unsigned)cdiv(cout, 16)), dim3(256), 0, gst,
+                         x, (const float*)wp, tbl, order, (long long)n_out, K, cin, cout, bias, y, epi);
+    } else {
+      hipLaunchKernelGGL(k_conv_generic<8>, dim3((unsigned)cdiv(n_out, 256), (unsigned)cdiv(cout, 8)), dim3(256), 0, gst,
+                         x, (const float*)wp, tbl, order, (long long)n_out, K, cin, cout, bias, y, epi);
+    }
+    GCL_CHECK_LAUNCH();
+    return GCL_OK;
+  }
   GCL_CHECK_ARG(n_in > 0 && (long long)n_in * cin * 4 < (1ll << 32) - (1ll << 20),
                 "gcl_conv_fwd: the input tensor must be non-empty and smaller than 4 GiB (buffer addressing)");
   const unsigned x_bytes = (unsigned)((long long)n_in * cin * 4);
@@ -1367,9 +1526,24 @@ int gcl_conv_bwd_weight(const float* a, int64_t n_a, const float* b, int64_t n_b
                         const int32_t* a_amax, const int32_t* b_amax, float* scratch, float* dw, void* stream) {
   GCL_CHECK_ARG(a && b && pair_a && pair_b && seg_off_host && scratch && dw, "gcl_conv_bwd_weight: null pointer");
   GCL_CHECK_ARG(K >= 1 && K <= 125, "gcl_conv_bwd_weight: bad K");
-  GCL_CHECK_ARG(ca % 32 == 0 && cb % 32 == 0 && ca > 0 && cb > 0,
-                "gcl_conv_bwd_weight: channel counts (%d, %d) must be positive multiples of 32", ca, cb);
+  GCL_CHECK_ARG(ca > 0 && cb > 0, "gcl_conv_bwd_weight: channel counts (%d, %d) must be positive", ca, cb);
   GCL_CHECK_ARG(prec_ok(prec), "gcl_conv_bwd_weight: prec must be 0, 2, 3 or 4");
+  if ((ca % 32) != 0 || (cb % 32) != 0) {     // generic shapes: exact-fp32 VALU kernel, same slabs + ordered reduction
+    GCL_CHECK_ARG(!planes, "gcl_conv_bwd_weight: plane images need channel counts that are multiples of 32");
+    GCL_CHECK_ARG(n_a > 0 && n_b > 0, "gcl_conv_bwd_weight: empty operand");
+    hipStream_t gst = (hipStream_t)stream;
+    SegOffW gseg;
+    for (int k = 0; k <= K; ++k) gseg.off[k] = seg_off_host[k];
+    const long long gnc = gseg.off[K] / GCL_PAIR_CHUNK, gmat = (long long)ca * cb;
+    const int gW = bwd_weight_wgs(gnc), gper = (int)cdiv(gnc > 0 ? gnc : 1, gW);
+    if (gnc > 0)
+      hipLaunchKernelGGL(k_conv_bwd_weight_generic, dim3(gW, (unsigned)(cdiv(ca, 16) * cdiv(cb, 16))), dim3(256), 0, gst, a, b,
+                         pair_a, pair_b, gseg, K, ca, cb, gnc, gper, scratch);
+    hipLaunchKernelGGL(k_bwd_weight_reduce, dim3((unsigned)cdiv(gmat, 256), K), dim3(256), 0, gst, (const float*)scratch,
+                       gseg, gper, gmat, dw);
+    GCL_CHECK_LAUNCH();
+    return GCL_OK;
+  }
   GCL_CHECK_ARG(prec != 4 || (a_amax && b_amax), "gcl_conv_bwd_weight: fp16x3 needs gcl_amax of both operands");
   GCL_CHECK_ARG(!planes || prec == 4, "gcl_conv_bwd_weight: plane images are the fp16x3 operand format");
   GCL_CHECK_ARG(n_a > 0 && n_b > 0 && (long long)n_a * ca * 4 < (1ll << 32) - (1ll << 20) &&
@@ -1420,10 +1594,10 @@ int gcl_conv_bwd_weight(const float* a, int64_t n_a, const float* b, int64_t n_b
 int gcl_stem_fwd(const float* x, const float* w, const int32_t* nbr, int64_t n_out, int32_t K, int32_t cin,
                  int32_t cout, float* y, void* stream) {
   GCL_CHECK_ARG(x && w && nbr && y, "gcl_stem_fwd: null pointer");
-  GCL_CHECK_ARG(cin >= 1 && cin <= 4 && cout == 32 && K >= 1 && K <= STEM_KMAX && n_out > 0,
-                "gcl_stem_fwd: supports Cin <= 4, Cout == 32, K <= 125 (got %d, %d, %d)", cin, cout, K);
-  hipLaunchKernelGGL(k_stem_fwd, dim3((unsigned)cdiv(n_out, 256)), dim3(256), 0, (hipStream_t)stream, x, w, nbr,
-                     (long long)n_out, K, cin, y);
+  GCL_CHECK_ARG(cin >= 1 && cin <= 4 && cout > 0 && cout % 32 == 0 && K >= 1 && K <= STEM_KMAX && n_out > 0,
+                "gcl_stem_fwd: supports Cin <= 4, Cout a multiple of 32, K <= 125 (got %d, %d, %d)", cin, cout, K);
+  hipLaunchKernelGGL(k_stem_fwd, dim3((unsigned)cdiv(n_out, 256), (unsigned)(cout / 32)), dim3(256), 0, (hipStream_t)stream,
+                     x, w, nbr, (long long)n_out, K, cin, cout, y);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }
@@ -1435,12 +1609,13 @@ int64_t gcl_stem_bwd_weight_scratch_len(int32_t K, int32_t cin, int32_t cout, in
 int gcl_stem_bwd_weight(const float* x, const float* dy, const int32_t* nbr, int64_t n_out, int32_t K, int32_t cin,
                         int32_t cout, float* scratch, float* dw, void* stream) {
   GCL_CHECK_ARG(x && dy && nbr && scratch && dw, "gcl_stem_bwd_weight: null pointer");
-  GCL_CHECK_ARG(cin >= 1 && cin <= 4 && cout == 32 && K >= 1 && K <= STEM_KMAX && n_out > 0,
-                "gcl_stem_bwd_weight: supports Cin <= 4, Cout == 32, K <= 125 (got %d, %d, %d)", cin, cout, K);
+  GCL_CHECK_ARG(cin >= 1 && cin <= 4 && cout > 0 && cout % 32 == 0 && K >= 1 && K <= STEM_KMAX && n_out > 0,
+                "gcl_stem_bwd_weight: supports Cin <= 4, Cout a multiple of 32, K <= 125 (got %d, %d, %d)", cin, cout, K);
   hipStream_t st = (hipStream_t)stream;
   int nwg = (int)cdiv(n_out, STEM_ROWS_PER_WG);
-  long long mat = (long long)K * cin * 32;
-  hipLaunchKernelGGL(k_stem_bwd_weight, dim3(nwg), dim3(256), 0, st, x, dy, nbr, (long long)n_out, K, cin, scratch);
+  long long mat = (long long)K * cin * cout;
+  hipLaunchKernelGGL(k_stem_bwd_weight, dim3(nwg, (unsigned)(cout / 32)), dim3(256), 0, st, x, dy, nbr, (long long)n_out, K,
+                     cin, cout, scratch);
   hipLaunchKernelGGL(k_stem_reduce, dim3((unsigned)cdiv(mat, 64)), dim3(256), 0, st, (const float*)scratch, nwg, mat,
                      dw);
   GCL_CHECK_LAUNCH();

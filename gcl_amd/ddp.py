@@ -21,13 +21,13 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available() and torch.cuda.device_count() > local:
+        torch.cuda.set_device(local)     # every backend: the HIP kernels launch on the current device
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
@@ -51,6 +51,7 @@ class FlatDDP:
         self.params = []
         self.overlap, self.n_buckets = bool(overlap), max(1, int(n_buckets))
         self._bounds, self._bucket_of, self._count, self._pending, self._works = [], {}, [], [], {}
+        self._sync = True
 
     def attach(self, module):
         params = [p for p in module.parameters() if p.requires_grad]
@@ -100,11 +101,18 @@ class FlatDDP:
         lo, hi = self._bounds[b]
         self._works[b] = dist.all_reduce(self.flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
+    def set_last_microstep(self, last):
+        """Gradient accumulation: call with False before every backward pass except the last one of an optimizer step
+        (the hooks then leave the buckets alone) and with True before the last (buckets start as they complete)."""
+        self._sync = bool(last)
+
     def _on_grad(self, p):
+        if not self._sync:
+            return
         b = self._bucket_of[id(p)]
         if b in self._works:
             raise RuntimeError("FlatDDP(overlap=True) saw a second backward pass before all_reduce_gradients(); "
-                               "use FlatDDP(overlap=False) when accumulating gradients over several passes")
+                               "call set_last_microstep(False) before the earlier passes of an accumulated step")
         self._pending[b] -= 1
         if self._pending[b] == 0:
             self._launch(b)
@@ -124,6 +132,7 @@ class FlatDDP:
                 for b in sorted(self._works):
                     self._works[b].wait()
                 self._pending, self._works = list(self._count), {}
+                self._sync = True
             else:
                 dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
             self.flat_grad.div_(self.world)

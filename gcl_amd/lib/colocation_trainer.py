@@ -344,37 +344,72 @@ class FinestContrastiveLossTrainer:
                                sizes, cfg.use_pair_group_positive_loss)
 
     def train_steps(self, batches):
-        """The epoch loop (``_train_epoch`` :811-916): yields train_step(batch) for every batch.  The ``np.random``
-        draws of batch i+1 (two permutations of all N rows: several ms of host time) are made by a helper thread
-        while step i is being enqueued; every draw is still made after the previous batch's, so the random stream is
-        consumed in the same order as by a serial loop."""
+        """The epoch loop (``_train_epoch`` :811-916): yields train_step(...) for every optimizer step, i.e. for every
+        ``config.iter_size`` consecutive batches (:838, a trailing incomplete group is dropped like ``len // iter_size``).
+        The ``np.random`` draws of step i+1 (two permutations of all N rows per batch: several ms of host time) are made
+        by a helper thread while step i is being enqueued; every draw is still made after the previous batch's, so the
+        random stream is consumed in the same order as by a serial loop."""
         from concurrent.futures import ThreadPoolExecutor
         it = iter(batches)
-        cur = next(it, None)
+        k = max(1, int(getattr(self.config, "iter_size", 1)))
+
+        def take():
+            grp = []
+            for b in it:
+                grp.append(b)
+                if len(grp) == k:
+                    return grp
+            return None
+
+        def draw(grp):
+            return [self._draw_for(b) for b in grp]
+
+        cur = take()
         if cur is None:
             return
         with ThreadPoolExecutor(max_workers=1) as pool:
-            fut = pool.submit(self._draw_for, cur)
+            fut = pool.submit(draw, cur)
             while cur is not None:
                 draws = fut.result()
-                nxt = next(it, None)
+                nxt = take()
                 if nxt is not None:
-                    fut = pool.submit(self._draw_for, nxt)
-                yield self.train_step(cur, draws)
+                    fut = pool.submit(draw, nxt)
+                yield self.train_step(cur if k > 1 else cur[0], draws if k > 1 else draws[0])
                 cur = nxt
 
     def train_step(self, input_dict, draws=None):
-        """One optimizer step on one batch (iter_size == 1).  Returns device scalars (no host sync here)."""
+        """One optimizer step.  ``input_dict``: one batch, or a list of ``iter_size`` batches whose gradients are
+        accumulated with every loss term divided by ``iter_size`` (lib/colocation_trainer.py:838-887); ``draws`` then is
+        a list too.  Returns device scalars (summed over the micro-batches like ``batch_loss`` :880-883; no host sync)."""
+        with torch.cuda.device(self.device):      # the HIP kernels launch on the current device's stream
+            return self._train_step(input_dict, draws)
+
+    def _train_step(self, input_dict, draws=None):
         self.model.train()
+        micro = list(input_dict) if isinstance(input_dict, (list, tuple)) else [input_dict]
+        n_micro = len(micro)
         if draws is None:     # host RNG first: overlaps with the GPU work still queued from the previous step
-            draws = self._draw_for(input_dict)
+            mdraws = [self._draw_for(b) for b in micro]
+        else:
+            mdraws = list(draws) if isinstance(input_dict, (list, tuple)) else [draws]
         if self.ddp is not None:
             self.ddp.flat_grad.zero_()                     # one memset; gradients stay seated in the flat buffer
         else:
             self.optimizer.zero_grad(set_to_none=os.environ.get("GCL_ZERO_NONE", "1") == "1")   # assign, not 66 adds + fills
-        loss, parts, F_out = self.forward_loss(input_dict, draws)
-        loss.backward()
+        tot_loss, tot_parts, n_rows = None, None, 0
+        for i, (b, d) in enumerate(zip(micro, mdraws)):
+            if self.ddp is not None:
+                self.ddp.set_last_microstep(i == n_micro - 1)     # bucket all-reduces start in the LAST backward only
+            loss, parts, F_out = self.forward_loss(b, d)
+            if n_micro > 1:
+                parts = tuple(p / n_micro for p in parts)         # :875-877
+                loss = self.pos_weight * parts[0] + self.finest_weight * parts[1] + self.neg_weight * parts[2]
+            loss.backward()
+            n_rows += F_out.shape[0]
+            dl, dp = loss.detach(), tuple(p.detach() for p in parts)
+            tot_loss = dl if tot_loss is None else tot_loss + dl
+            tot_parts = dp if tot_parts is None else tuple(a + b_ for a, b_ in zip(tot_parts, dp))
         if self.ddp is not None:
             self.ddp.all_reduce_gradients()
         self.optimizer.step()
-        return loss.detach(), tuple(p.detach() for p in parts), F_out.shape[0]
+        return tot_loss, tot_parts, n_rows

@@ -1,0 +1,143 @@
+"""Evaluation loop body of the reference's registration benchmark (interface of scripts/test_kitti.py:29-227).
+
+``eval_pairs(model, pairs, matcher)`` composes, per pair and in the reference's order:
+  2 x feature extraction (``:141-152``)  ->  ``find_corr`` on <= 5000 random rows per cloud + nearest-neighbour
+  distances under the ground truth (``:154-155``)  ->  ``random_sample`` to exactly 5000 voxels (``:160-161``)  ->
+  registration with the SC2-PCR ``Matcher.estimator`` (``:178-180``, the ``use_RANSAC false`` branch; open3d's RANSAC
+  is a third-party CPU back-end and is not built)  ->  RTE / RRE / success meters (``:189-217``).
+
+What differs by design: the clouds of ``batch_pairs`` pairs go through ONE forward pass (``forward_clouds``): in eval
+mode the network treats the clouds of a batch independently (running BatchNorm statistics, per-cloud coordinate maps)
+and every output row is accumulated in a fixed offset order, so the features equal the separate passes bit for bit at
+a fraction of the launches of this launch-bound case.  All host random draws are made per pair in the reference's
+order, so a seeded run selects the same rows whatever ``batch_pairs`` is.
+"""
+import time
+
+import numpy as np
+import torch
+
+import gcl_amd.MinkowskiEngine as ME
+from gcl_amd.lib.eval import find_corr
+
+
+class AverageMeter:
+    """lib/timer.py:6-26."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.val, self.avg, self.sum, self.sq_sum, self.count, self.var = 0, 0, 0.0, 0.0, 0, 0.0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+        self.sq_sum += val ** 2 * n
+        self.var = self.sq_sum / self.count - self.avg ** 2
+
+
+def apply_transform(pts, trans):
+    """scripts/test_kitti.py:45-48."""
+    return pts @ trans[:3, :3].t() + trans[:3, 3]
+
+
+def evaluate_nn_dist(xyz0, xyz1, T_gth):
+    """scripts/test_kitti.py:50-53."""
+    xyz0 = apply_transform(xyz0, T_gth)
+    return np.sqrt(((xyz0 - xyz1) ** 2).sum(1) + 1e-6).tolist()
+
+
+def random_sample(pcd, feats, N):
+    """Exactly N rows (scripts/test_kitti.py:55-75): a permutation prefix when there are more, draws WITH replacement
+    when there are fewer.  ``feats`` may live on the GPU; the index is drawn on the host like the reference's."""
+    n1 = pcd.shape[0]
+    if n1 == N:
+        return pcd, feats
+    choice = np.random.permutation(n1)[:N] if n1 > N else np.random.choice(n1, N)
+    sel = torch.from_numpy(choice).to(feats.device) if isinstance(feats, torch.Tensor) else choice
+    return pcd[choice], feats[sel]
+
+
+def forward_clouds(model, clouds):
+    """Features of several clouds from ONE forward pass.  ``clouds``: list of (F [N_i, C], coords int32 [N_i, 4] with any
+    batch column); returns the list of per-cloud feature tensors.  Eval mode only (batch statistics would mix clouds)."""
+    if model.training:
+        raise RuntimeError("forward_clouds needs model.eval(): batch statistics would mix the clouds")
+    if len(clouds) == 1:
+        return [model(ME.SparseTensor(clouds[0][0], coordinates=clouds[0][1])).F]
+    Cs = []
+    for b, (_, C) in enumerate(clouds):
+        Cb = C.clone()
+        Cb[:, 0] = b
+        Cs.append(Cb)
+    out = model(ME.SparseTensor(torch.cat([f for f, _ in clouds]), coordinates=torch.cat(Cs))).F
+    return list(torch.split(out, [len(f) for f, _ in clouds]))
+
+
+def rotation_translation_error(T_est, T_gth):
+    """(rte, rre in radians) with the reference's clamp of the trace diagonal (scripts/test_kitti.py:189-192)."""
+    T_est, T_gth = torch.as_tensor(T_est).float().cpu(), torch.as_tensor(T_gth).float().cpu()
+    rte = float(np.linalg.norm((T_est[:3, 3] - T_gth[:3, 3]).numpy()))
+    m = T_est[:3, :3].t() @ T_gth[:3, :3]
+    d = torch.min(torch.ones(3), torch.diagonal(m))
+    with np.errstate(invalid="ignore"):
+        rre = float(np.arccos((float(d.sum()) - 1) / 2))
+    return rte, rre
+
+
+def eval_pairs(model, pairs, matcher, device=None, batch_pairs=1, subsample_size=5000, n_points=5000,
+               rte_thresh=2.0, rre_thresh=5.0, collect=False):
+    """The loop of scripts/test_kitti.py:129-227 over ``pairs`` (dicts with the keys of ``collate_debug_pair_fn``:
+    pcd0 / pcd1, sinput{0,1}_C, sinput{0,1}_F, T_gt).  Returns a dict with the three meters' summary, the per-pair
+    lists (T_est, rte, rre, success, nn distances when ``collect``) and the stage times in seconds."""
+    if matcher is None:
+        raise NotImplementedError("only the SC2-PCR branch (use_RANSAC false) is built: open3d RANSAC is a CPU third party")
+    dev = torch.device(device) if device is not None else next(model.parameters()).device
+    model.eval()
+    success_meter, rte_meter, rre_meter = AverageMeter(), AverageMeter(), AverageMeter()
+    out = dict(T_est=[], rte=[], rre=[], success=[], dists_nn=[], n_voxels=0)
+    t_feat = t_reg = 0.0
+    pairs = list(pairs)
+    with torch.cuda.device(dev), torch.no_grad():
+        for b0 in range(0, len(pairs), max(1, batch_pairs)):
+            chunk = pairs[b0:b0 + max(1, batch_pairs)]
+            t0 = time.perf_counter()
+            clouds = []
+            for d in chunk:
+                for k in (0, 1):
+                    clouds.append((d[f"sinput{k}_F"].to(dev, non_blocking=True),
+                                   d[f"sinput{k}_C"].to(dev, non_blocking=True)))
+            feats = forward_clouds(model, clouds)
+            t_feat += time.perf_counter() - t0
+            for j, d in enumerate(chunk):
+                F0, F1 = feats[2 * j].detach(), feats[2 * j + 1].detach()
+                out["n_voxels"] += len(F0) + len(F1)
+                xyz0, xyz1, T_gth = d["pcd0"][0], d["pcd1"][0], d["T_gt"]
+                xyz0np, xyz1np = xyz0.numpy(), xyz1.numpy()
+                xyz0_corr, xyz1_corr = find_corr(xyz0, xyz1, F0, F1, subsample_size=subsample_size)
+                if collect:
+                    out["dists_nn"].append(evaluate_nn_dist(xyz0_corr, xyz1_corr, T_gth))
+                xyz0s, F0s = random_sample(xyz0np, F0, n_points)
+                xyz1s, F1s = random_sample(xyz1np, F1, n_points)
+                t0 = time.perf_counter()
+                x0, x1 = torch.from_numpy(xyz0s).to(dev), torch.from_numpy(xyz1s).to(dev)
+                T_est, _, _, _ = matcher.estimator(x0[None], x1[None], F0s[None], F1s[None])
+                T_est = T_est[0].to("cpu")                      # the reference reads T on the host here (:180)
+                t_reg += time.perf_counter() - t0
+                rte, rre = rotation_translation_error(T_est, T_gth)
+                if rte < rte_thresh:
+                    rte_meter.update(rte)
+                if not np.isnan(rre) and rre < np.pi / 180 * rre_thresh:
+                    rre_meter.update(rre * 180 / np.pi)
+                ok = rte < rte_thresh and not np.isnan(rre) and rre < np.pi / 180 * rre_thresh
+                success_meter.update(1 if ok else 0)
+                out["T_est"].append(T_est)
+                out["rte"].append(rte)
+                out["rre"].append(rre)
+                out["success"].append(bool(ok))
+    out.update(rte_avg=rte_meter.avg, rte_var=rte_meter.var, rre_avg=rre_meter.avg, rre_var=rre_meter.var,
+               success_rate=success_meter.avg, n_pairs=success_meter.count, feat_time=t_feat, reg_time=t_reg)
+    return out

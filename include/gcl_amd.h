@@ -142,7 +142,11 @@ int gcl_table_sort(const int32_t* tbl, int32_t K, int64_t n, int32_t window, int
  *   prec 4: 2 fp16 planes of the operands scaled by a per-tensor power of two (gcl_amax), 3 fp16-MFMA terms
  *           ("fp16x3": 11+11 significand bits with round-to-nearest = 24 bits, i.e. native-fp32 accuracy at half the
  *           MFMA work of bf16x6); x_amax / w_amax are required in this mode only;
- *           wp = gcl_pack_weights_bytes(...) bytes of bf16 planes.  Cin, Cout multiples of 32.
+ *           wp = gcl_pack_weights_bytes(...) bytes of bf16 planes.
+ *   Shapes: the MFMA kernels take Cin, Cout multiples of 32 and K <= 27.  EVERY OTHER shape (any Cin, Cout > 0, K <= 125;
+ *   e.g. the 16-dim head of demo.py:29, `final` 64 -> 16) is a "generic shape": gcl_pack_weights then writes plain fp32
+ *   W_eff[k][Cin_eff][Cout_eff] (prec ignored), gcl_conv_fwd / gcl_conv_fwd_fused / gcl_conv_bwd_weight run exact-fp32
+ *   VALU kernels (amax pointers, plane images and `stats` are not used / not accepted there).
  * gcl_conv_fwd: Y[row(j)] = sum_k X[tbl[k*n_out+j]] . Wp_k (+ bias); tbl == NULL means K == 1, identity.
  *   x_is_planes != 0 (prec 4 only): x points at the gcl_split_planes image of X instead of X (no split in the kernel).
  *   X has n_in rows (n_in * Cin * 4 < 4 GiB: rows are gathered through a buffer resource, absent neighbours read 0).
@@ -207,7 +211,8 @@ int gcl_conv_bwd_weight(const float* a, int64_t n_a, const float* b, int64_t n_b
                         int32_t ca, int32_t cb, int32_t prec, const int32_t* a_amax, const int32_t* b_amax, float* scratch, float* dw,
                         void* stream);
 
-/* First layer (Cin <= 4, Cout == 32, any ks): VALU kernels over the nbr table. */
+/* First layer (Cin <= 4, Cout a multiple of 32, any ks <= 5): VALU kernels over the nbr table (one 32-column block per
+ * workgroup column).  Other first-layer widths go through gcl_conv_fwd / gcl_conv_bwd_weight (generic shapes). */
 int gcl_stem_fwd(const float* x, const float* w, const int32_t* nbr, int64_t n_out, int32_t K,
                  int32_t cin, int32_t cout, float* y, void* stream);
 int64_t gcl_stem_bwd_weight_scratch_len(int32_t K, int32_t cin, int32_t cout, int64_t n_out);

@@ -1,0 +1,377 @@
+"""GPU tests of the drop-in boundary (round 2): the UN-FUSED operator surface the reference's own model files would
+use, generic channel counts (demo.py:29's 16-dim model), the wide-stem variants, the eval loop as a product function,
+gradient accumulation, and the cache / tag invalidation rules of the host shim."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import loss_oracle as LO          # noqa: E402
+from oracle import me_oracle as O             # noqa: E402
+
+DEV = "cuda:0"
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))        # tests/ref_shaped_model.py
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def _randomise_bn(m):
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if name.endswith("bn.weight"):
+                p.uniform_(0.5, 1.5)
+            elif name.endswith("bn.bias"):
+                p.uniform_(-0.1, 0.1)
+
+
+def _state64(m):
+    return {k: v.detach().cpu().double().clone() for k, v in m.state_dict().items() if "num_batches" not in k}
+
+
+def _lidar_cloud(seed, stride=3, n_boxes=20):
+    import gcl_amd.MinkowskiEngine as ME
+    from gcl_amd import synthetic
+    xyz = synthetic.raycast(synthetic.make_scene(seed, n_boxes=n_boxes), np.zeros(3), seed + 7)[::stride]
+    coords, _ = ME.utils.sparse_quantize(xyz / 0.3, return_index=True)
+    return ME.utils.batched_coordinates([coords])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# 1a. un-fused, reference-shaped forward: conv -> norm -> MEF.relu, `out += residual`, ME.cat, final SparseTensor
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("k1", [5, 3])
+def test_unfused_reference_shaped_model_matches_fused_model_and_oracle(k1):
+    import gcl_amd.MinkowskiEngine as ME
+    import gcl_amd.MinkowskiEngine.MinkowskiFunctional as MEF
+    from gcl_amd.model import load_model
+    from ref_shaped_model import build
+    torch.manual_seed(0)
+    fused = load_model("ResUNetBN2C")(1, 32, bn_momentum=0.05, normalize_feature=True, conv1_kernel_size=k1, D=3).to(DEV)
+    _randomise_bn(fused)
+    plain = build(ME, MEF, 1, 32, bn_momentum=0.05, normalize_feature=True, conv1_kernel_size=k1).to(DEV)
+    missing = plain.load_state_dict(fused.state_dict(), strict=True)          # same names, same shapes
+    assert not missing.missing_keys and not missing.unexpected_keys
+    st = _state64(fused)
+    C = _lidar_cloud(1)
+    feats = torch.ones(len(C), 1)
+    g = torch.Generator().manual_seed(1)
+    gy = torch.randn(len(C), 32, generator=g, dtype=torch.float64)
+    outs = {}
+    for name, m in (("fused", fused), ("plain", plain)):
+        m.train()
+        out = m(ME.SparseTensor(feats.to(DEV), coordinates=C.to(DEV)))
+        assert np.array_equal(out.C.cpu().numpy(), C.numpy())
+        out.F.backward(gy.float().to(DEV))
+        outs[name] = (out.F.detach().cpu(), {n: p.grad.cpu().clone() for n, p in m.named_parameters()},
+                      {n: b.cpu().clone() for n, b in m.named_buffers() if "running" in n})
+    so = {k: v.clone().requires_grad_("running" not in k) for k, v in st.items()}
+    Fo = O.resunet_forward(so, C.numpy(), feats.double(), k1, True, True, 0.05)
+    Fo.backward(gy)
+    # the two host paths drive the same kernels: features agree to fp32 rounding of the (differently fused) BN passes
+    assert rel_l2(outs["plain"][0], outs["fused"][0]) < 2e-6
+    assert rel_l2(outs["plain"][0], Fo.detach()) < 1e-4 and rel_l2(outs["fused"][0], Fo.detach()) < 1e-4
+    for n in outs["plain"][1]:
+        assert rel_l2(outs["plain"][1][n], so[n].grad) < 2e-3, n
+        assert rel_l2(outs["plain"][1][n], outs["fused"][1][n]) < 1e-3, n
+    for n in outs["plain"][2]:
+        assert rel_l2(outs["plain"][2][n], so[n]) < 1e-4, n
+    # eval mode (running statistics): un-fused BatchNorm reads the buffers, the fused model uses conv+BN in one launch
+    with torch.no_grad():
+        fused.eval(), plain.eval()
+        Fe_f = fused(ME.SparseTensor(feats.to(DEV), coordinates=C.to(DEV))).F.cpu()
+        Fe_p = plain(ME.SparseTensor(feats.to(DEV), coordinates=C.to(DEV))).F.cpu()
+    Feo = O.resunet_forward({k: v.detach() for k, v in so.items()}, C.numpy(), feats.double(), k1, True, False, 0.05)
+    assert rel_l2(Fe_p, Feo) < 1e-4 and rel_l2(Fe_f, Feo) < 1e-4 and rel_l2(Fe_p, Fe_f) < 2e-6
+
+
+def test_unfused_surface_pieces():
+    """MEF.relu on a tensor that is NOT known to be non-negative, SparseTensor.__iadd__ dropping stale BN column sums,
+    MinkowskiBatchNorm.forward(x) without residual, ME.cat order."""
+    import gcl_amd.MinkowskiEngine as ME
+    import gcl_amd.MinkowskiEngine.MinkowskiFunctional as MEF
+    C = _lidar_cloud(2, stride=6)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(len(C), 32, generator=g)
+    s = ME.SparseTensor(x.to(DEV), coordinates=C.to(DEV))
+    r = MEF.relu(s)
+    assert torch.equal(r.F.cpu(), torch.relu(x)) and r.coordinate_manager is s.coordinate_manager
+    conv = ME.MinkowskiConvolution(32, 32, kernel_size=3, stride=1, dimension=3).to(DEV)
+    bn = ME.MinkowskiBatchNorm(32, momentum=0.05).to(DEV)
+    conv.train(), bn.train()
+    y = conv(s)
+    assert getattr(y, "_bn_stats", None) is not None          # the conv epilogue published column sums of y
+    y += s                                                    # ... which no longer describe y's features
+    assert y._bn_stats is None
+    z = bn(y)
+    ref = torch.nn.functional.batch_norm(y.F.detach().cpu().double(), None, None, bn.bn.weight.detach().cpu().double(),
+                                         bn.bn.bias.detach().cpu().double(), True, 0.05, 1e-5)
+    assert rel_l2(z.F.detach().cpu(), ref) < 2e-6
+    c = ME.cat(r, s)
+    assert torch.equal(c.F[:, :32], r.F) and torch.equal(c.F[:, 32:], s.F)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# 1b. demo.py:29 -- ResUNetBN2C(1, 16, normalize_feature=True, conv1_kernel_size=3): Cout = 16 head
+# ---------------------------------------------------------------------------------------------------------------
+def test_demo_model_16dim_vs_oracle():
+    import gcl_amd.MinkowskiEngine as ME
+    from gcl_amd import synthetic
+    from gcl_amd.model import load_model
+    torch.manual_seed(0)
+    m = load_model("ResUNetBN2C")(1, 16, normalize_feature=True, conv1_kernel_size=3, D=3).to(DEV)     # demo.py:29
+    _randomise_bn(m)
+    st = _state64(m)
+    assert st["final.kernel"].shape == (64, 16)
+    xyz = synthetic.make_box_cloud(0, 5000)
+    for voxel in (0.3, 0.025):                       # configs[0] and demo.py:66-70's default voxel size
+        coords, _ = ME.utils.sparse_quantize(xyz / voxel, return_index=True)
+        C = ME.utils.batched_coordinates([coords])
+        feats = torch.ones(len(C), 1)
+        m.train()
+        F = m(ME.SparseTensor(feats.to(DEV), coordinates=C.to(DEV))).F
+        so = {k: v.clone().requires_grad_("running" not in k) for k, v in st.items()}
+        Fo = O.resunet_forward(so, C.numpy(), feats.double(), 3, True, True, 0.1)
+        assert F.shape == (len(C), 16) and rel_l2(F.detach().cpu(), Fo.detach()) < 1e-4
+        gy = torch.randn(Fo.shape, generator=torch.Generator().manual_seed(2), dtype=torch.float64)
+        Fo.backward(gy)
+        m.zero_grad()
+        F.backward(gy.float().to(DEV))
+        for n, p in m.named_parameters():
+            assert rel_l2(p.grad.cpu(), so[n].grad) < 2e-3, n
+        m.eval()
+        with torch.no_grad():
+            Fe = m(ME.SparseTensor(feats.to(DEV), coordinates=C.to(DEV))).F
+        Feo = O.resunet_forward({k: v.detach() for k, v in so.items()}, C.numpy(), feats.double(), 3, True, False, 0.1)
+        assert rel_l2(Fe.cpu(), Feo) < 1e-4
+        st = _state64(m)            # running statistics moved
+
+
+@pytest.mark.parametrize("name", ["ResUNetBN2E", "ResUNetBN2B", "ResUNetBN2D"])
+def test_other_width_variants_vs_oracle(name):
+    """ResUNetBN2E has CHANNELS[1] = 128: the first-layer kernels take any Cout that is a multiple of 32."""
+    import gcl_amd.MinkowskiEngine as ME
+    from gcl_amd.model import load_model
+    torch.manual_seed(1)
+    m = load_model(name)(1, 32, bn_momentum=0.05, normalize_feature=True, conv1_kernel_size=5, D=3).to(DEV)
+    _randomise_bn(m)
+    st = _state64(m)
+    C = _lidar_cloud(3, stride=5)
+    feats = torch.ones(len(C), 1)
+    m.train()
+    F = m(ME.SparseTensor(feats.to(DEV), coordinates=C.to(DEV))).F
+    so = {k: v.clone().requires_grad_("running" not in k) for k, v in st.items()}
+    Fo = O.resunet_forward(so, C.numpy(), feats.double(), 5, True, True, 0.05)
+    assert rel_l2(F.detach().cpu(), Fo.detach()) < 1e-4
+    gy = torch.randn(Fo.shape, generator=torch.Generator().manual_seed(2), dtype=torch.float64)
+    Fo.backward(gy)
+    F.backward(gy.float().to(DEV))
+    for n, p in m.named_parameters():
+        assert rel_l2(p.grad.cpu(), so[n].grad) < 2e-3, n
+
+
+def test_in_variant_with_wide_stem_runs():
+    import gcl_amd.MinkowskiEngine as ME
+    from gcl_amd.model import load_model
+    m = load_model("ResUNetIN2E")(3, 32, bn_momentum=0.05, normalize_feature=True, conv1_kernel_size=3, D=3).to(DEV)
+    C = _lidar_cloud(4, stride=6)
+    F = m(ME.SparseTensor(torch.rand(len(C), 3).to(DEV), coordinates=C.to(DEV))).F
+    F.sum().backward()
+    assert torch.isfinite(F).all() and all(torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# ADVICE: caches and tags
+# ---------------------------------------------------------------------------------------------------------------
+def test_eval_affine_cache_follows_running_statistics():
+    """eval -> train forward WITHOUT optimizer step -> eval: the fused conv+BN inference launch must see the new running
+    statistics (they are updated through raw pointers, which does not bump tensor versions)."""
+    import gcl_amd.MinkowskiEngine as ME
+    C = _lidar_cloud(5, stride=6)
+    x = torch.randn(len(C), 32, generator=torch.Generator().manual_seed(0)) * 3 + 1
+    conv = ME.MinkowskiConvolution(32, 32, kernel_size=3, stride=1, dimension=3).to(DEV)
+    bn = ME.MinkowskiBatchNorm(32, momentum=0.5).to(DEV)
+
+    def both():
+        conv.eval(), bn.eval()
+        with torch.no_grad():
+            s = ME.SparseTensor(x.to(DEV), coordinates=C.to(DEV))
+            return ME.conv_bn(conv, bn, s, relu=True).F.cpu(), torch.relu(bn(conv(s)).F).cpu()
+
+    f0, u0 = both()
+    assert rel_l2(f0, u0) < 2e-6
+    conv.train(), bn.train()
+    bn(conv(ME.SparseTensor(x.to(DEV), coordinates=C.to(DEV))))       # moves running_mean / running_var
+    f1, u1 = both()
+    assert rel_l2(u1, u0) > 1e-2, "the running statistics did change"
+    assert rel_l2(f1, u1) < 2e-6, "fused inference path used stale statistics"
+
+
+def test_weight_writes_through_data_keep_the_fp16x3_scale_right():
+    """p.data.mul_(...) does not bump p._version: a training-mode forward re-measures max|W| anyway; in eval mode
+    ME.invalidate_amax() is the documented way."""
+    import gcl_amd.MinkowskiEngine as ME
+    from gcl_amd.model import load_model
+    torch.manual_seed(2)
+    m = load_model("ResUNetBN2C")(1, 32, bn_momentum=0.05, normalize_feature=True, conv1_kernel_size=3, D=3).to(DEV)
+    C = _lidar_cloud(6, stride=6)
+    feats = torch.ones(len(C), 1)
+    run = lambda: m(ME.SparseTensor(feats.to(DEV), coordinates=C.to(DEV))).F.detach().cpu()
+    m.train()
+    run()
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() >= 2:
+                p.data.mul_(300.0)         # far outside the fp16 range of the old scale
+    F = run()
+    Fo = O.resunet_forward(_state64_train(m), C.numpy(), feats.double(), 3, True, True, 0.05)
+    assert torch.isfinite(F).all() and rel_l2(F, Fo.detach()) < 1e-4
+    m.eval()
+    with torch.no_grad():
+        run()
+        for p in m.parameters():
+            if p.dim() >= 2:
+                p.data.mul_(1.0 / 300.0)
+        ME.invalidate_amax()
+        Fe = run()
+    Feo = O.resunet_forward(_state64(m), C.numpy(), feats.double(), 3, True, False, 0.05)
+    assert rel_l2(Fe, Feo) < 1e-4
+
+
+def _state64_train(m):
+    """State BEFORE the forward that is being checked is not available any more; training-mode features do not depend
+    on the running statistics, so the current buffers do."""
+    return _state64(m)
+
+
+def test_tensor_on_another_device_is_rejected():
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import gcl_amd.MinkowskiEngine as ME
+    C = _lidar_cloud(7, stride=8)
+    with torch.cuda.device(0):
+        with pytest.raises(RuntimeError, match="current device"):
+            ME.SparseTensor(torch.ones(len(C), 1, device="cuda:1"), coordinates=C.to("cuda:1"))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# a10: gradient accumulation (iter_size), a17: the eval loop
+# ---------------------------------------------------------------------------------------------------------------
+def test_iter_size_two_accumulates_like_the_reference():
+    """iter_size = 2 (lib/colocation_trainer.py:838, :875-879, :887): each micro-batch's loss terms divided by 2, two
+    backward passes, one SGD step -- against the oracle's gradients of the same two batches."""
+    from gcl_amd import ddp, synthetic
+    from gcl_amd.lib.colocation_trainer import FinestContrastiveLossTrainer, make_config
+    batches = [synthetic.collate_train([synthetic.make_train_sample(s, num_neighborhood=2, n_boxes=10)]) for s in (21, 22)]
+    rng = np.random.RandomState(0)
+    draws = []
+    for b in batches:
+        N, Gn = len(b["sinput_C"]), len(b["group"])
+        draws.append((rng.choice(Gn, min(Gn, 64), replace=False), rng.choice(N, 256, replace=False),
+                      rng.choice(N, 256, replace=False)))
+    cfg = make_config(batch_size=1, num_pos_per_batch=64, num_hn_samples_per_batch=256, iter_size=2)
+    results = []
+    for use_ddp in (False, True):
+        torch.manual_seed(11)
+        tr = FinestContrastiveLossTrainer(cfg, device=DEV, ddp=ddp.FlatDDP() if use_ddp else None)
+        st0 = _state64(tr.model)
+        p0 = {n: p.detach().cpu().double().clone() for n, p in tr.model.named_parameters()}
+        loss, parts, n = tr.train_step(batches, draws=draws)
+        grads = {n: p.grad.detach().cpu().clone() for n, p in tr.model.named_parameters()}
+        results.append((loss.item(), [p.item() for p in parts], grads,
+                        {n: p.detach().cpu().clone() for n, p in tr.model.named_parameters()}))
+    assert n == sum(len(b["sinput_C"]) for b in batches)
+    so = {k: v.clone().requires_grad_("running" not in k) for k, v in st0.items()}
+    total = 0.0
+    ref_parts = np.zeros(3)
+    for b, d in zip(batches, draws):
+        Fo = O.resunet_forward(so, b["sinput_C"].numpy(), b["sinput_F"].double(), 5, True, True, 0.05)
+        terms = LO.finest_contrastive_loss(Fo, b["group"].numpy(), b["index"].numpy(), b["index_hash"],
+                                           b["finest_flag"].numpy(), draws=d)
+        l = sum(t / 2 for t in terms)
+        l.backward()
+        total += l.item()
+        ref_parts += np.array([t.item() / 2 for t in terms])
+    for loss_v, parts_v, grads, params in results:
+        assert abs(loss_v - total) < 2e-4 * max(1.0, abs(total)) and np.allclose(parts_v, ref_parts, rtol=2e-4, atol=2e-5)
+        for name, gr in grads.items():
+            assert rel_l2(gr, so[name].grad) < 5e-3, name
+    # one SGD step (first step: momentum buffer = gradient): p1 = p0 - lr * (g + wd * p0)
+    name = "block2_tr.conv2.kernel"
+    want = p0[name] - 0.1 * (so[name].grad + 1e-4 * p0[name])
+    assert rel_l2(results[0][3][name], want) < 1e-5
+
+
+def _twin_pair(seed, shift_voxels=(8, 0, 0), voxel=0.3):
+    """An eval pair whose second cloud is the first one moved by a multiple of 8 voxels (every U-Net level stays aligned):
+    well-conditioned for an UNTRAINED network -- twin voxels get equal features, everything else is an outlier.  Input
+    features carry a small per-voxel jitter so that no two voxels have tied features."""
+    from gcl_amd import synthetic
+    p = synthetic.make_eval_pair(seed, voxel_size=voxel, baseline=6.0, n_boxes=25)
+    keep = torch.arange(0, len(p["sinput0_C"]), 3)                      # ~1/3 of the voxels: a few thousand rows
+    C0 = p["sinput0_C"][keep].clone()
+    xyz0 = p["pcd0"][0][keep].clone()
+    sh = torch.tensor(shift_voxels, dtype=torch.int32)
+    C1 = C0.clone()
+    C1[:, 1:] += sh
+    xyz1 = xyz0 + sh.float() * voxel
+    F = 1.0 + 0.05 * torch.randn(len(C0), 1, generator=torch.Generator().manual_seed(seed))
+    T = torch.eye(4)
+    T[:3, 3] = sh.float() * voxel
+    return {"pcd0": (xyz0,), "pcd1": (xyz1,), "sinput0_C": C0, "sinput1_C": C1, "sinput0_F": F, "sinput1_F": F.clone(),
+            "T_gt": T}
+
+
+def test_eval_pairs_matches_the_oracle_chain_and_batching_is_bitwise_neutral():
+    """scripts/test_kitti.py:129-227 as gcl_amd.scripts.test_kitti.eval_pairs: composed T of every pair against the CPU
+    chain me_oracle.resunet_forward -> loss_oracle.find_nn -> sc2pcr_oracle.sc2_pcr on the same seeded draws (same
+    np.random call order as the reference's loop), RTE / RRE / success meters, and the B-pairs-per-forward mode
+    returning the same transformations bit for bit."""
+    from gcl_amd.model import load_model
+    from gcl_amd.scripts.SC2_PCR import Matcher
+    from gcl_amd.scripts.test_kitti import eval_pairs
+    from oracle.sc2pcr_oracle import sc2_pcr
+    torch.manual_seed(5)
+    m = load_model("ResUNetBN2C")(1, 32, bn_momentum=0.05, normalize_feature=True, conv1_kernel_size=5, D=3).to(DEV)
+    _randomise_bn(m)
+    m.eval()
+    st = _state64(m)
+    pairs = [_twin_pair(60, (8, 0, 0)), _twin_pair(61, (-8, 16, 0)), _twin_pair(62, (16, 8, 8))]
+    cfgm = dict(inlier_threshold=0.6, num_node=1500, use_mutual=False, d_thre=0.1, num_iterations=20, ratio=0.2,
+                nms_radius=0.6, max_points=8000, k1=30, k2=20)
+    NPTS = 1500
+    assert all(len(p["sinput0_C"]) > NPTS for p in pairs)
+    np.random.seed(9)
+    r1 = eval_pairs(m, pairs, Matcher(**cfgm), device=DEV, batch_pairs=1, subsample_size=NPTS, n_points=NPTS, collect=True)
+    np.random.seed(9)
+    r3 = eval_pairs(m, pairs, Matcher(**cfgm), device=DEV, batch_pairs=3, subsample_size=NPTS, n_points=NPTS)
+    assert r1["n_pairs"] == 3 and len(r1["T_est"]) == 3 and len(r1["dists_nn"][0]) == NPTS
+    for a, b in zip(r1["T_est"], r3["T_est"]):
+        assert torch.equal(a, b), "batched forward must not change a single bit"
+    assert r1["rte"] == r3["rte"] and r1["success"] == r3["success"]
+    # the oracle chain with the same draws
+    np.random.seed(9)
+    for i, d in enumerate(pairs):
+        Fs = [O.resunet_forward(st, d[f"sinput{k}_C"].numpy(), d[f"sinput{k}_F"].double(), 5, True, False, 0.05).float()
+              for k in (0, 1)]
+        xyz = [d["pcd0"][0].numpy(), d["pcd1"][0].numpy()]
+        for k in (0, 1):                                  # find_corr's two draws (:33-34)
+            np.random.choice(len(Fs[k]), min(len(Fs[k]), NPTS), replace=False)
+        sel = [np.random.permutation(len(xyz[k]))[:NPTS] for k in (0, 1)]     # random_sample (:160-161), n1 > N
+        x0, x1, F0, F1 = xyz[0][sel[0]], xyz[1][sel[1]], Fs[0][sel[0]], Fs[1][sel[1]]
+        s_sel = np.random.choice(NPTS, cfgm["num_node"])                    # Matcher.match_pair (:289-290)
+        t_sel = np.random.choice(NPTS, cfgm["num_node"])
+        nn = LO.find_nn(F0[s_sel], F1[t_sel], nn_max_n=-1).numpy()
+        T_o = sc2_pcr(x0[s_sel], x1[t_sel[nn]], inlier_threshold=0.6, d_thre=0.1, num_iterations=20, ratio=0.2,
+                      nms_radius=0.6, max_points=8000, k1=30, k2=20)
+        T_o = torch.as_tensor(T_o).float().reshape(4, 4)
+        assert (r1["T_est"][i] - T_o).abs().max().item() < 2e-3, (i, r1["T_est"][i], T_o)
+        assert (T_o - d["T_gt"]).abs().max().item() < 5e-2            # and both found the true motion
+    assert r1["success_rate"] == 1.0 and r1["rte_avg"] < 0.05 and r1["rre_avg"] < 0.5
+    assert r1["success"] == [True, True, True] and r1["n_voxels"] == sum(2 * len(p["sinput0_C"]) for p in pairs)

@@ -179,6 +179,10 @@ CONV_CASES = [
     (128, 128, 3, 1, False), (128, 256, 3, 2, False), (256, 256, 3, 1, False),
     (256, 128, 3, 2, True), (256, 64, 3, 2, True), (128, 64, 3, 2, True),
     (96, 64, 1, 1, False), (64, 32, 1, 1, False),
+    # generic shapes (exact-fp32 VALU kernels behind the same C-ABI entry points): demo.py:29's 16-dim head, channel
+    # counts that are no multiple of 32 / 16 / 4, a 5^3 kernel on wide features, a transposed generic conv
+    (64, 16, 1, 1, False), (48, 80, 3, 1, False), (16, 16, 3, 2, False), (30, 7, 3, 1, False), (32, 32, 5, 1, False),
+    (80, 48, 3, 2, True),
 ]
 
 
@@ -199,7 +203,7 @@ def precision(request):
 
 @pytest.mark.parametrize("cin,cout,ks,stride,transpose", CONV_CASES)
 def test_conv_fwd_bwd_vs_oracle(cin, cout, ks, stride, transpose, precision):
-    r = _conv_case(cin, cout, ks, stride, transpose, bias=(cout == 32 and ks == 1))
+    r = _conv_case(cin, cout, ks, stride, transpose, bias=(cout in (16, 32) and ks == 1))
     tol = PREC_TOL[precision]
     assert rel_l2(*r["y"]) < tol, rel_l2(*r["y"])
     assert rel_l2(*r["dx"]) < tol, rel_l2(*r["dx"])
@@ -664,6 +668,14 @@ def test_colocation_groups_gpu_bit_exact(seed, nn):
     assert np.array_equal(idx.cpu().numpy(), np.asarray(index, dtype=np.int64))
     assert np.array_equal(fl.cpu().numpy(), np.asarray(finest, dtype=bool))
     assert len(group) > 100
+    # ... and the per-point restatement of the reference's loop under oracle/ (brute-force radius searches), on the same
+    # float32 centre-frame points the device builder receives
+    from oracle.colocation_oracle import colocation_groups as oracle_groups
+    og, oi, of = oracle_groups(xyz_th, xyz_cmpl_th, list_M, radius, K=5,
+                               nghb_cf=[synthetic._apply(list_M[j], x) for j, x in enumerate(xyz_cmpl_th)])
+    assert np.array_equal(g.cpu().numpy(), np.asarray(og, dtype=np.int32))
+    assert np.array_equal(idx.cpu().numpy(), np.asarray(oi, dtype=np.int64))
+    assert np.array_equal(fl.cpu().numpy(), np.asarray(of, dtype=bool))
 
 
 def test_gpu_built_batch_trains():

@@ -93,3 +93,36 @@ def test_prefetched_draws_follow_the_serial_random_stream():
     assert out == [1, 2, 3, 4, 5]
     for got, want in zip(seen, ref):
         assert all(np.array_equal(g, w) for g, w in zip(got, want))
+
+
+def test_train_steps_groups_iter_size_batches_and_keeps_the_random_stream():
+    """config.iter_size = 2: one optimizer step per two consecutive batches (lib/colocation_trainer.py:838), the draws of
+    every batch still made in batch order; a trailing odd batch is dropped like ``len(loader) // iter_size``."""
+    import types
+    from gcl_amd.lib.colocation_trainer import FinestContrastiveLossTrainer, draw_selections, make_config
+    tr = object.__new__(FinestContrastiveLossTrainer)
+    tr.config = make_config(batch_size=2, num_pos_per_batch=8, num_hn_samples_per_batch=16, iter_size=2)
+    seen = []
+    tr.train_step = types.MethodType(lambda self, b, draws=None: seen.append((b, draws)) or len(seen), tr)
+    batches = [{"group": list(range(40 + i)), "sinput_C": list(range(500 + 7 * i))} for i in range(5)]
+    np.random.seed(3)
+    assert list(tr.train_steps(batches)) == [1, 2]
+    np.random.seed(3)
+    ref = [draw_selections(len(b["group"]), len(b["sinput_C"]), 16, 32) for b in batches[:4]]
+    flat = [d for _, ds in seen for d in ds]
+    assert [len(b) for b, _ in seen] == [2, 2] and seen[1][0][0] is batches[2]
+    for got, want in zip(flat, ref):
+        assert all(np.array_equal(g, w) for g, w in zip(got, want))
+
+
+def test_generator_groups_equal_the_oracle_restatement():
+    """The synthetic generator's vectorised group builder (cKDTree) against oracle/colocation_oracle.py, the per-point
+    restatement of get_matching_indices_colocation (util/pointcloud.py:69-132) -- with the reference's float64
+    transform of the neighbour clouds and with the float32 centre-frame points the device builder receives."""
+    from oracle.colocation_oracle import colocation_groups
+    xyz, cmpl, _, _, group, index, finest, list_M = synthetic.make_train_sample(13, 0.3, num_neighborhood=2, n_boxes=8)
+    r = synthetic.sample_search_radius(13, 0.3, 2)
+    for cf in (None, [synthetic._apply(list_M[j], x) for j, x in enumerate(cmpl)]):
+        og, oi, of = colocation_groups(xyz, cmpl, list_M, r, K=5, nghb_cf=cf)
+        assert og == list(group) and oi == list(index) and of == list(finest)
+    assert len(group) > 100
