@@ -29,18 +29,18 @@ def set_conv_precision(name):
 
 
 # bench.py sets this to a list to time individual launches with events on the launch stream:
-# entries are (kernel name, start event, end event, pairs, cin, cout)
+# entries are (kernel name, start event, end event, pairs, cin, cout, n_in, n_out, K)
 PROFILE = None
 
 
 class _Timed:
     """Brackets one launch with events on torch's current stream (the stream the kernel is launched on)."""
 
-    def __init__(self, name, pairs, cin, cout):
+    def __init__(self, name, pairs, cin, cout, n_in=0, n_out=0, K=1):
         self.rec = None
         if PROFILE is not None:
             self.rec = (name, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
-                        int(pairs), cin, cout)
+                        int(pairs), cin, cout, int(n_in), int(n_out), int(K))
 
     def __enter__(self):
         if self.rec is not None:
@@ -244,7 +244,7 @@ def _conv_launch(lib, x, Wk, mode, table, n_out, cin, cout, bias, pairs=0, want_
         pre = "true" if x_planes is not None else "false"
         name = "k_conv_generic" if generic else \
             (f"k_conv_fwd<{nb}>" if prec == 0 else f"k_conv_fwd_split<{nb},{prec},{pre},false>")
-    with _Timed(name, pairs, cin, cout):
+    with _Timed(name, pairs, cin, cout, x.shape[0], n_out, K):
         xin, is_planes = (x_planes, 1) if x_planes is not None else (x, 0)
         _lib.check(lib.gcl_conv_fwd(_lib.ptr(xin), x.shape[0], is_planes, _lib.ptr(wp), prec, _lib.ptr(x_amax),
                                     _lib.ptr(w_amax), _lib.ptr(tbl), _lib.ptr(order), _lib.ptr(tile_mask), n_out, K,
@@ -366,7 +366,7 @@ class _SparseConvFn(torch.autograd.Function):
                      f"k_conv_bwd_weight_split<{tile},{prec},{'true' if use_pl else 'false'}>")
                 if prec == 4 and not fp16x3 and not (cin % 32 or cout % 32):     # K > 27 with MFMA-shaped channels
                     x_amax, dy_amax = tensor_amax(lib, x), tensor_amax(lib, dy)
-                with _Timed(name, ctx.pairs, cin, cout):
+                with _Timed(name, ctx.pairs, cin, cout, x.shape[0], dy.shape[0], K):
                     xa = planes_of(lib, x, x_amax) if use_pl else x
                     ya = planes_of(lib, dy, dy_amax) if use_pl else dy
                     _lib.check(lib.gcl_conv_bwd_weight(_lib.ptr(xa), x.shape[0], _lib.ptr(ya), dy.shape[0], int(use_pl),

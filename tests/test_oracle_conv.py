@@ -79,3 +79,56 @@ def test_resunet_forward_runs_and_is_normalised():
     assert torch.allclose(out.norm(dim=1), torch.ones(len(C), dtype=torch.float64), atol=1e-12)
     n_params = sum(int(np.prod(v.shape)) for k, v in st.items() if "running" not in k)
     assert n_params == 8753408
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the C / OpenMP restatement of ME's CPU path (oracle/me_cpu.c; bench.py's cpu_baseline) against the torch oracle
+# ---------------------------------------------------------------------------------------------------------------
+def test_c_restatement_maps_bit_exact():
+    from oracle import me_cpu
+    C = _cloud(3, n=1500, extent=14, batch=2)
+    mo, mc = O.CoordinateManager(C), me_cpu.CoordinateManager(C)
+    for t in (2, 4, 8):
+        assert np.array_equal(mo.get_coords(t), mc.get_coords(t))
+    for key in [(1, 3, 1), (1, 5, 1), (1, 3, 2), (2, 3, 1), (2, 3, 2), (4, 3, 2), (8, 3, 1)]:
+        a, b = O.canonical(mo.get_kernel_map(*key)), O.canonical(mc.get_kernel_map(*key).triples())
+        assert a.shape == b.shape and np.array_equal(a, b), key
+    with pytest.raises(ValueError, match="duplicate"):
+        me_cpu.CoordinateManager(np.concatenate([C, C[:2]]))
+
+
+@pytest.mark.parametrize("cin,cout,ks,stride,transpose", [(32, 64, 3, 2, False), (64, 64, 3, 1, False),
+                                                          (128, 64, 3, 2, True), (1, 32, 5, 1, False),
+                                                          (48, 20, 3, 1, False)])
+def test_c_restatement_conv_fwd_bwd(cin, cout, ks, stride, transpose):
+    from oracle import me_cpu
+    C = _cloud(4, n=1200, extent=10, batch=2)
+    mo, mc = O.CoordinateManager(C), me_cpu.CoordinateManager(C)
+    g = torch.Generator().manual_seed(1)
+    t_in = 2 if transpose else 1
+    key = (t_in // stride, ks, stride) if transpose else (t_in, ks, stride)
+    n_in = len(mo.get_coords(t_in))
+    n_out = len(mo.get_coords(t_in // stride if transpose else t_in * stride))
+    x = torch.randn(n_in, cin, generator=g, dtype=torch.float64)
+    W = torch.randn(ks ** 3, cin, cout, generator=g, dtype=torch.float64) / 8
+    b = torch.randn(1, cout, generator=g, dtype=torch.float64)
+    xo, Wo = x.clone().requires_grad_(True), W.clone().requires_grad_(True)
+    yo = O.sparse_conv(xo, Wo, mo.get_kernel_map(*key), n_out, transpose=transpose, bias=b)
+    xc, Wc = x.float().requires_grad_(True), W.float().requires_grad_(True)
+    yc = O.sparse_conv(xc, Wc, mc.get_kernel_map(*key), n_out, transpose=transpose, bias=b.float())
+    gy = torch.randn(yo.shape, generator=g, dtype=torch.float64)
+    yo.backward(gy)
+    yc.backward(gy.float())
+    rel = lambda a, r: float((a.double() - r).norm() / r.norm())
+    assert rel(yc.detach(), yo.detach()) < 2e-6 and rel(xc.grad, xo.grad) < 2e-6 and rel(Wc.grad, Wo.grad) < 2e-6
+
+
+def test_c_restatement_whole_network_equals_torch_oracle():
+    from oracle import me_cpu
+    C = _cloud(5, n=900, extent=10, batch=2)
+    st = O.random_state(0, dtype=torch.float32)
+    feats = torch.ones(len(C), 1)
+    a = O.resunet_forward({k: v.clone() for k, v in st.items()}, C, feats, 5, True, True, 0.05)
+    b = O.resunet_forward({k: v.clone() for k, v in st.items()}, C, feats, 5, True, True, 0.05,
+                          mgr=me_cpu.CoordinateManager(C))
+    assert float((a - b).norm() / a.norm()) < 1e-5
