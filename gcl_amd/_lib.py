@@ -30,6 +30,7 @@ SIGNATURES = {
     "gcl_colocation_hits": (_i32, [_vp, _vp, _i64, _i32, ctypes.POINTER(ctypes.c_double), _vp, _i64, _f32,
                                     ctypes.c_double, _i32, _vp, _vp, _vp, _vp]),
     "gcl_colocation_emit": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gcl_host_legacy_choice": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "gcl_kernel_map_bitmap_len": (_i64, []),
     "gcl_kernel_map_scratch_len": (_i64, [_i32, _i64]),
     "gcl_kernel_map": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),

@@ -209,4 +209,80 @@ int gcl_colocation_emit(const int32_t* hits, const int32_t* cnt, const double* f
   return GCL_OK;
 }
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * HOST function (no GPU): numpy's legacy ``np.random.choice(n, k, replace=False)`` -- i.e. ``permutation(n)[:k]``, the
+ * call the reference makes three times per training step (lib/colocation_trainer.py:457, :506-507) -- reproduced bit for
+ * bit from the RandomState's MT19937 state, outside the Python interpreter lock.  At n = 0.5 M rows numpy needs 8 ms per
+ * call and holds the interpreter lock while it shuffles, which stalls the thread that enqueues the GPU work.
+ *   key[624], *pos: the generator state as returned by np.random.get_state() (updated in place: the caller hands it back
+ *   with np.random.set_state, so the random stream continues exactly where numpy's own call would have left it);
+ *   out[k] = the first k entries of the shuffled arange(n); work: int64[n] scratch.
+ * Algorithm = numpy/random/mtrand.pyx (_shuffle_raw: for i = n-1 .. 1: j = random_interval(i); swap) with
+ * distributions.c random_interval (smallest mask >= max, rejection on next_uint32 / next_uint64). */
+namespace {
+struct MT {
+  uint32_t* key;
+  int pos;
+};
+inline void mt_gen(uint32_t* mt) {
+  const int N = 624, M = 397;
+  const uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MAT = 0x9908b0dfu;
+  int i;
+  uint32_t y;
+  for (i = 0; i < N - M; i++) {
+    y = (mt[i] & UPPER) | (mt[i + 1] & LOWER);
+    mt[i] = mt[i + M] ^ (y >> 1) ^ (-(int32_t)(y & 1) & MAT);
+  }
+  for (; i < N - 1; i++) {
+    y = (mt[i] & UPPER) | (mt[i + 1] & LOWER);
+    mt[i] = mt[i + (M - N)] ^ (y >> 1) ^ (-(int32_t)(y & 1) & MAT);
+  }
+  y = (mt[N - 1] & UPPER) | (mt[0] & LOWER);
+  mt[N - 1] = mt[M - 1] ^ (y >> 1) ^ (-(int32_t)(y & 1) & MAT);
+}
+inline uint32_t mt_next32(MT& s) {
+  if (s.pos == 624) {
+    mt_gen(s.key);
+    s.pos = 0;
+  }
+  uint32_t y = s.key[s.pos++];
+  y ^= (y >> 11);
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= (y >> 18);
+  return y;
+}
+inline uint64_t mt_interval(MT& s, uint64_t max) {
+  if (max == 0) return 0;
+  uint64_t mask = max, value;
+  mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16; mask |= mask >> 32;
+  if (max <= 0xffffffffull) {
+    while ((value = (mt_next32(s) & mask)) > max) {}
+  } else {
+    while (true) {
+      uint64_t hi = mt_next32(s), lo = mt_next32(s);
+      value = ((hi << 32) | lo) & mask;
+      if (value <= max) break;
+    }
+  }
+  return value;
+}
+}  // namespace
+
+int gcl_host_legacy_choice(uint32_t* key, int32_t* pos, int64_t n, int64_t k, int64_t* work, int64_t* out) {
+  GCL_CHECK_ARG(key && pos && work && out, "gcl_host_legacy_choice: null pointer");
+  GCL_CHECK_ARG(n >= 1 && k >= 0 && k <= n && *pos >= 0 && *pos <= 624, "gcl_host_legacy_choice: bad n / k / state");
+  MT s{key, *pos};
+  for (int64_t i = 0; i < n; ++i) work[i] = i;
+  for (int64_t i = n - 1; i >= 1; --i) {
+    const int64_t j = (int64_t)mt_interval(s, (uint64_t)i);
+    const int64_t t = work[j];
+    work[j] = work[i];
+    work[i] = t;
+  }
+  for (int64_t i = 0; i < k; ++i) out[i] = work[i];
+  *pos = s.pos;
+  return GCL_OK;
+}
+
 }  // extern "C"

@@ -37,6 +37,44 @@ def shard_indices(n_items, rank, world):
     return list(range(rank, n_items, world))
 
 
+def balance_global_batch(sizes, world):
+    """Splits one global batch (``len(sizes)`` = world * per-rank batch size samples with voxel counts ``sizes``) into
+    ``world`` groups of EQUAL sample count whose voxel sums are as even as a greedy assignment gets them (largest sample
+    first, to the lightest rank that still has room).  Per-rank work is proportional to the voxel count and every step
+    ends in an all-reduce, so the heaviest rank sets the step time (+-30 % per-rank spread with a plain
+    DistributedSampler).  Deterministic (ties -> lowest rank), so every rank computes the same plan."""
+    n = len(sizes)
+    if n % world:
+        raise ValueError(f"{n} samples do not split evenly over {world} ranks")
+    per = n // world
+    order = sorted(range(n), key=lambda i: (-int(sizes[i]), i))
+    groups, load = [[] for _ in range(world)], [0] * world
+    for i in order:
+        r = min((r for r in range(world) if len(groups[r]) < per), key=lambda r: (load[r], r))
+        groups[r].append(i)
+        load[r] += int(sizes[i])
+    return [sorted(g) for g in groups]
+
+
+def epoch_plan(sizes, world, batch_size, seed=0, balance=True):
+    """Per-rank batches of one epoch: samples are shuffled (seeded: identical on every rank), cut into global batches of
+    world * batch_size samples (a trailing partial one is dropped, like DistributedSampler(drop_last=True)), and every
+    global batch is dealt to the ranks by ``balance_global_batch`` (or strided when ``balance`` is False).
+    Returns plan[rank] = list of batches, each a list of ``batch_size`` sample ids."""
+    import random
+    ids = list(range(len(sizes)))
+    random.Random(seed).shuffle(ids)
+    gb = world * batch_size
+    plan = [[] for _ in range(world)]
+    for b0 in range(0, len(ids) - gb + 1, gb):
+        chunk = ids[b0:b0 + gb]
+        groups = balance_global_batch([sizes[i] for i in chunk], world) if balance else \
+            [list(range(r, gb, world)) for r in range(world)]
+        for r in range(world):
+            plan[r].append([chunk[j] for j in groups[r]])
+    return plan
+
+
 class FlatDDP:
     """Flat-buffer gradient all-reduce for a module (no autograd hooks, no per-parameter collectives)."""
 

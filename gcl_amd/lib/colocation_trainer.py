@@ -103,21 +103,42 @@ class _GCLLossFn(torch.autograd.Function):
 LOSS_SQRT, LOSS_BLOCK, LOSS_PAIR, LOSS_NOFIN = 1, 2, 4, 8      # GCL_LOSS_* of include/gcl_amd.h
 
 
+def legacy_choice(n, k):
+    """``np.random.choice(n, k, replace=False)`` on numpy's global RandomState -- same values, same stream position
+    afterwards -- computed by the native host routine gcl_host_legacy_choice outside the interpreter lock (numpy: 8 ms per
+    call at n = 0.5 M, holding the lock, which stalls the thread that enqueues the GPU work).  Small n go to numpy."""
+    if n < 4096 or k > n:
+        return np.random.choice(n, k, replace=False)
+    import ctypes
+    lib = _lib.load()
+    st = np.random.get_state()
+    if st[0] != "MT19937":
+        return np.random.choice(n, k, replace=False)
+    key = np.array(st[1], dtype=np.uint32, copy=True)
+    pos = ctypes.c_int32(int(st[2]))
+    work, out = np.empty(n, np.int64), np.empty(k, np.int64)
+    _lib.check(lib.gcl_host_legacy_choice(ctypes.c_void_p(key.ctypes.data), ctypes.byref(pos), n, k,
+                                          ctypes.c_void_p(work.ctypes.data), ctypes.c_void_p(out.ctypes.data)),
+               "gcl_host_legacy_choice")
+    np.random.set_state((st[0], key, int(pos.value), st[3], st[4]))
+    return out
+
+
 def draw_selections(n_groups, n_out, max_pos_cluster, max_hn_samples, group_sizes=None, pair_positive=False):
     """The three host-side ``np.random.choice`` draws of finest_contrastive_loss, in the reference's order
     (lib/colocation_trainer.py:457, :506-507): selected positive groups, then the two negative row subsets.
     ``np.random.choice(n, k, replace=False)`` permutes all n rows (~4 ms at n = 0.5 M): the trainer therefore draws at
     the START of a step, while the GPU is still busy with the previous step's backward pass."""
     if n_groups > max_pos_cluster:
-        pos_sel = np.random.choice(n_groups, max_pos_cluster, replace=False)
+        pos_sel = legacy_choice(n_groups, max_pos_cluster)
     else:
         pos_sel = np.arange(n_groups)
     pair_pos = None
     if pair_positive:        # two members per selected group, drawn inside the group loop (:467)
         sizes = np.asarray(group_sizes)
         pair_pos = np.stack([np.random.choice(int(sizes[i]), 2, replace=False) for i in pos_sel]).astype(np.int32)
-    sel_hn1 = np.random.choice(n_out, min(n_out, max_hn_samples), replace=False)
-    sel_hn2 = np.random.choice(n_out, min(n_out, max_hn_samples), replace=False)
+    sel_hn1 = legacy_choice(n_out, min(n_out, max_hn_samples))
+    sel_hn2 = legacy_choice(n_out, min(n_out, max_hn_samples))
     return pos_sel, sel_hn1, sel_hn2, pair_pos
 
 
@@ -400,6 +421,7 @@ class FinestContrastiveLossTrainer:
         for i, (b, d) in enumerate(zip(micro, mdraws)):
             if self.ddp is not None:
                 self.ddp.set_last_microstep(i == n_micro - 1)     # bucket all-reduces start in the LAST backward only
+            wait_for_batch(b)
             loss, parts, F_out = self.forward_loss(b, d)
             if n_micro > 1:
                 parts = tuple(p / n_micro for p in parts)         # :875-877
@@ -418,9 +440,10 @@ class FinestContrastiveLossTrainer:
 def prefetch_to_device(batches, device, keys=("sinput_C", "sinput_F", "group", "index", "finest_flag")):
     """What the reference's step does first -- ``input_dict[...].to(self.device)`` (lib/colocation_trainer.py:843-845) --
     as a loader-side prefetch: the tensors of batch i+1 are copied host -> device (pinned memory, non-blocking) on a
-    COPY stream while the kernels of batch i run on the compute stream; the compute stream waits for the copy event
-    before it first touches the batch.  Yields dicts whose ``keys`` are device tensors (everything else passes through).
-    ``train_steps`` pulls one batch ahead of the step it enqueues, which is what gives the copy its head start."""
+    COPY stream while the kernels of batch i run on the compute stream.  Yields dicts whose ``keys`` are device tensors
+    (everything else passes through) plus ``"_h2d_event"``: ``train_step`` makes the compute stream wait for it when it
+    first touches the batch (NOT when the batch is pulled: ``train_steps`` pulls one batch ahead of the step it
+    enqueues, which is what gives the copy its head start)."""
     dev = torch.device(device)
     copy_stream = torch.cuda.Stream(device=dev)
     for b in batches:
@@ -434,10 +457,16 @@ def prefetch_to_device(batches, device, keys=("sinput_C", "sinput_F", "group", "
                     out[k] = v.to(dev, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(copy_stream)
-        cur = torch.cuda.current_stream(dev)
+        out["_h2d_event"] = ev
+        yield out
+
+
+def wait_for_batch(batch):
+    """Orders the current stream behind the host -> device copy of a prefetched batch (no-op for ordinary batches)."""
+    ev = batch.get("_h2d_event") if isinstance(batch, dict) else None
+    if ev is not None:
+        cur = torch.cuda.current_stream()
         cur.wait_event(ev)
-        for k in keys:
-            v = out.get(k)
+        for v in batch.values():
             if isinstance(v, torch.Tensor) and v.is_cuda:
                 v.record_stream(cur)          # allocated on the copy stream, consumed on the compute stream
-        yield out

@@ -99,6 +99,13 @@ int gcl_colocation_emit(const int32_t* hits, const int32_t* cnt, const double* f
                         int32_t n_clouds, int32_t K, int32_t* scratch, int32_t* group, int64_t* index, uint8_t* finest,
                         int32_t* totals, void* stream);
 
+/* HOST function (no GPU, every pointer is a HOST pointer): numpy's legacy np.random.choice(n, k, replace=False) =
+ * permutation(n)[:k] -- the three draws of every training step (lib/colocation_trainer.py:457, :506-507) -- reproduced
+ * bit for bit from the RandomState's MT19937 state (key[624], *pos as in np.random.get_state(); both updated in place so
+ * that np.random.set_state continues the stream), outside the interpreter lock: numpy needs 8 ms per call at 0.5 M rows and
+ * holds the lock meanwhile, which stalls the thread that enqueues the GPU work.  work: int64[n] scratch, out: int64[k]. */
+int gcl_host_legacy_choice(uint32_t* key, int32_t* pos, int64_t n, int64_t k, int64_t* work, int64_t* out);
+
 /* Kernel map for kernel size ks^3 (x fastest in k), offsets scaled by `step` (= input tensor stride x dilation),
  * region centred on the OUTPUT coordinate:  nbr[k * n_out + v] = input row at c_out[v] + o_k * step, or -1.
  * same_map != 0: coords_out IS the input map (stride-1 conv): only offsets k <= K/2 are looked up, the mirror

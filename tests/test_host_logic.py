@@ -126,3 +126,24 @@ def test_generator_groups_equal_the_oracle_restatement():
         og, oi, of = colocation_groups(xyz, cmpl, list_M, r, K=5, nghb_cf=cf)
         assert og == list(group) and oi == list(index) and of == list(finest)
     assert len(group) > 100
+
+
+def test_native_legacy_choice_is_numpy_bit_for_bit():
+    """gcl_host_legacy_choice (host code of the C-ABI library, no GPU): np.random.choice(n, k, replace=False) of the global
+    RandomState -- same indices AND the same stream position afterwards -- so that a seeded training run still draws
+    what the reference draws (lib/colocation_trainer.py:457, :506-507)."""
+    from gcl_amd.lib.colocation_trainer import draw_selections, legacy_choice
+    for seed, n, k in [(0, 530321, 1024), (1, 5000, 5000), (2, 19699, 1024), (3, 4096, 1), (4, 100000, 0), (5, 70001, 77)]:
+        np.random.seed(seed)
+        np.random.rand(seed * 5)                 # an arbitrary position inside the 624-word state block
+        a, ra = np.random.choice(n, k, replace=False), np.random.rand(3)
+        np.random.seed(seed)
+        np.random.rand(seed * 5)
+        b, rb = legacy_choice(n, k), np.random.rand(3)
+        assert np.array_equal(a, b) and np.array_equal(ra, rb), (seed, n, k)
+    np.random.seed(11)
+    got = draw_selections(20000, 530000, 1024, 1024)
+    np.random.seed(11)
+    want = (np.random.choice(20000, 1024, replace=False), np.random.choice(530000, 1024, replace=False),
+            np.random.choice(530000, 1024, replace=False))
+    assert all(np.array_equal(g, w) for g, w in zip(got[:3], want))
