@@ -1,5 +1,6 @@
 """SparseTensor + coordinate manager (host side of the coordinate/kernel-map kernels in csrc/coords.hip)."""
 import os
+import weakref
 
 import torch
 
@@ -8,6 +9,15 @@ from .. import _lib
 
 # rows are mask-sorted inside windows of this many consecutive rows (0 = one global sort); tuning knob
 SORT_WINDOW = int(os.environ.get("GCL_SORT_WINDOW", "0"))
+# TUNING KNOB, default off (0).  Levels whose tensor stride is <= SPATIAL_MAX_STRIDE mask-sort their tables inside
+# windows of SPATIAL_WINDOW rows of a SPATIAL pre-order (cloud, Morton cell; gcl_spatial_order) and run with one
+# contiguous tile range per XCD, so that the rows in flight on an XCD are spatial neighbours and find each other's
+# gathered input rows in L2.  Measured (profiles/r02_spatial_micro.txt): much better than windows of the loader order
+# (64->64 @s1: 274 vs 339 us) but no better than the global mask sort (247 us) -- the extra (offset, slice) steps of
+# the less uniform tiles cost what the L2 hits save: the kernels are bound by the latency of a step, not by bytes.
+SPATIAL_MAX_STRIDE = int(os.environ.get("GCL_SPATIAL_MAX_STRIDE", "0"))
+SPATIAL_WINDOW = int(os.environ.get("GCL_SPATIAL_WINDOW", "4096"))
+SPATIAL_MIN_ROWS = int(os.environ.get("GCL_SPATIAL_MIN_ROWS", "32768"))     # single clouds stay on the global sort
 
 
 def _pow2_cap(n):
@@ -48,8 +58,10 @@ class KernelMap:
     each offset segment padded with -1 to a multiple of GCL_PAIR_CHUNK.
     """
 
-    def __init__(self, nbr, nbr_t, counts_dev, n_in, n_out, K):
+    def __init__(self, nbr, nbr_t, counts_dev, n_in, n_out, K, mgr=None, t_in=1, t_out=1):
         self.nbr, self.nbr_t = nbr, nbr_t
+        self._mgr = weakref.ref(mgr) if mgr is not None else (lambda: None)   # no manager <-> map reference cycle
+        self._t_in, self._t_out = t_in, t_out
         self.n_in, self.n_out, self.K = n_in, n_out, K
         self.same_map = nbr_t is None
         self._pairs = None
@@ -90,9 +102,14 @@ class KernelMap:
                 order = torch.empty(n, dtype=torch.int32, device=dev)
                 tbl_sorted = torch.empty_like(tbl)
                 tile_mask = torch.empty((n + 31) // 32, dtype=torch.int32, device=dev)
-                _lib.check(lib.gcl_table_sort(_lib.ptr(tbl), self.K, n, SORT_WINDOW, _lib.ptr(scratch), _lib.ptr(order),
-                                              _lib.ptr(tbl_sorted), _lib.ptr(tile_mask), _lib.stream()),
-                           "gcl_table_sort")
+                t_rows = self._t_in if transposed else self._t_out          # the level whose rows this table lists
+                mgr = self._mgr()
+                spatial = mgr is not None and 0 < t_rows <= SPATIAL_MAX_STRIDE and n >= SPATIAL_MIN_ROWS
+                pre = mgr.spatial_order(t_rows) if spatial else None
+                _lib.check(lib.gcl_table_sort_pre(_lib.ptr(tbl), self.K, n, SPATIAL_WINDOW if spatial else SORT_WINDOW,
+                                                  _lib.ptr(pre), _lib.ptr(scratch), _lib.ptr(order), _lib.ptr(tbl_sorted),
+                                                  _lib.ptr(tile_mask), _lib.stream()), "gcl_table_sort")
+                tbl_sorted._gcl_flags = 1 if spatial else 0                # GCL_CONV_XCD_RANGES
                 self._sorted[key] = (tbl_sorted, order, tile_mask)
         return self._sorted[key]
 
@@ -141,6 +158,7 @@ class CoordinateManager:
         self._checked = set()
         self._kmaps = {}
         self._identity = {}
+        self._spatial = {}
         self._bitmap = None
 
     # -- coordinate maps -----------------------------------------------------------------------------------
@@ -165,6 +183,19 @@ class CoordinateManager:
 
     def num_rows(self, t):
         return self.get_coords(t).shape[0]
+
+    def spatial_order(self, t):
+        """Rows of the level at tensor stride ``t`` in (cloud, Morton cell) order (gcl_spatial_order); cached."""
+        if t not in self._spatial:
+            lib = _lib.load()
+            C = self.get_coords(t)
+            n = C.shape[0]
+            scratch = torch.empty(lib.gcl_table_sort_scratch_len(n), dtype=torch.int32, device=self.device)
+            order = torch.empty(n, dtype=torch.int32, device=self.device)
+            _lib.check(lib.gcl_spatial_order(_lib.ptr(C), n, t, _lib.ptr(scratch), _lib.ptr(order), _lib.stream()),
+                       "gcl_spatial_order")
+            self._spatial[t] = order
+        return self._spatial[t]
 
     def batch_segments(self, t):
         """[(first row, rows)] of every cloud at tensor stride ``t`` (InstanceNorm normalises per cloud).  Rows of one
@@ -250,7 +281,7 @@ class CoordinateManager:
         _lib.check(lib.gcl_kernel_map(_lib.ptr(C_out), n_out, _lib.ptr(table_in), cap_in, kernel_size, t_in,
                                       int(same), _lib.ptr(self._bitmap), _lib.ptr(scratch), _lib.ptr(nbr),
                                       _lib.ptr(nbr_t), n_in, _lib.ptr(counts), _lib.stream()), "gcl_kernel_map")
-        km = KernelMap(nbr, nbr_t, counts, n_in, n_out, K)
+        km = KernelMap(nbr, nbr_t, counts, n_in, n_out, K, self, t_in, t_out)
         self._kmaps[key] = km
         return km
 

@@ -248,7 +248,8 @@ def _conv_launch(lib, x, Wk, mode, table, n_out, cin, cout, bias, pairs=0, want_
         xin, is_planes = (x_planes, 1) if x_planes is not None else (x, 0)
         _lib.check(lib.gcl_conv_fwd(_lib.ptr(xin), x.shape[0], is_planes, _lib.ptr(wp), prec, _lib.ptr(x_amax),
                                     _lib.ptr(w_amax), _lib.ptr(tbl), _lib.ptr(order), _lib.ptr(tile_mask), n_out, K,
-                                    cin, cout, _lib.ptr(bias), _lib.ptr(y), _lib.ptr(stats), _lib.stream()),
+                                    cin, cout, _lib.ptr(bias), _lib.ptr(y), _lib.ptr(stats),
+                                    getattr(tbl, "_gcl_flags", 0), _lib.stream()),
                    "gcl_conv_fwd")
     return (y, stats) if want_stats else y
 
@@ -602,7 +603,8 @@ def conv_bn_eval(x, W, kmap, n_out, transpose, scale, shift, residual=None, relu
     _lib.check(lib.gcl_conv_fwd_fused(_lib.ptr(x, torch.float32), x.shape[0], 0, _lib.ptr(wp), prec, _lib.ptr(x_amax),
                                       _lib.ptr(w_amax), _lib.ptr(tbl), _lib.ptr(order), _lib.ptr(tile_mask), n_out, K,
                                       cin, cout, _lib.ptr(shift, torch.float32), _lib.ptr(scale, torch.float32),
-                                      _lib.ptr(res), int(relu), _lib.ptr(slot), _lib.ptr(y), None, _lib.stream()),
+                                      _lib.ptr(res), int(relu), _lib.ptr(slot), _lib.ptr(y), None,
+                                      getattr(tbl, "_gcl_flags", 0), _lib.stream()),
                "gcl_conv_fwd_fused")
     tag_amax(y, slot)
     return y

@@ -464,12 +464,18 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
   // swizzle 2 (1-D grid): the cout / (32 NB) column blocks that gather the SAME 128 rows get consecutive slots of one
   // XCD (workgroups are dealt round-robin over the 8 XCDs) and share its L2
   unsigned bxx = blockIdx.x, byy = blockIdx.y;
-  if (swizzle == 2) {
+  if (swizzle >= 2) {
     const unsigned ncb = (unsigned)(cout / (32 * NB)), nrw = (unsigned)((n_out + CONV_ROWS - 1) / CONV_ROWS);
     const unsigned xcd = bxx & 7u, slot = bxx >> 3;
     byy = slot % ncb;
-    bxx = (slot / ncb) * 8u + xcd;
-    if (bxx >= nrw) return;   // whole workgroup, before any barrier
+    if (swizzle == 2) {
+      bxx = (slot / ncb) * 8u + xcd;
+      if (bxx >= nrw) return;   // whole workgroup, before any barrier
+    } else {                    // 3: every XCD owns a CONTIGUOUS range of row tiles (spatially ordered tables)
+      const unsigned q = nrw >> 3, r = nrw & 7u, mine = q + (xcd < r ? 1u : 0u), j = slot / ncb;
+      if (j >= mine) return;
+      bxx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
   } else {
     bxx = xcd_tile(bxx, gridDim.x, swizzle);
   }
@@ -1416,21 +1422,21 @@ int gcl_conv_fwd_fused(const float* x, int64_t n_in, int32_t x_is_planes, const 
                        const int32_t* x_amax, const int32_t* w_amax, const int32_t* tbl, const int32_t* order,
                        const int32_t* tile_mask, int64_t n_out, int32_t K, int32_t cin, int32_t cout, const float* bias,
                        const float* col_scale, const float* residual, int32_t relu, int32_t* y_amax, float* y,
-                       float* stats, void* stream);
+                       float* stats, int32_t flags, void* stream);
 
 int gcl_conv_fwd(const float* x, int64_t n_in, int32_t x_is_planes, const void* wp, int32_t prec, const int32_t* x_amax,
                  const int32_t* w_amax, const int32_t* tbl, const int32_t* order, const int32_t* tile_mask,
                  int64_t n_out, int32_t K, int32_t cin, int32_t cout, const float* bias, float* y, float* stats,
-                 void* stream) {
+                 int32_t flags, void* stream) {
   return gcl_conv_fwd_fused(x, n_in, x_is_planes, wp, prec, x_amax, w_amax, tbl, order, tile_mask, n_out, K, cin, cout,
-                            bias, nullptr, nullptr, 0, nullptr, y, stats, stream);
+                            bias, nullptr, nullptr, 0, nullptr, y, stats, flags, stream);
 }
 
 int gcl_conv_fwd_fused(const float* x, int64_t n_in, int32_t x_is_planes, const void* wp, int32_t prec,
                        const int32_t* x_amax, const int32_t* w_amax, const int32_t* tbl, const int32_t* order,
                        const int32_t* tile_mask, int64_t n_out, int32_t K, int32_t cin, int32_t cout, const float* bias,
                        const float* col_scale, const float* residual, int32_t relu, int32_t* y_amax, float* y,
-                       float* stats, void* stream) {
+                       float* stats, int32_t flags, void* stream) {
   const ConvEpi epi{col_scale, residual, relu, y_amax};
   const bool use_epi = col_scale || residual || relu || y_amax;
   GCL_CHECK_ARG(prec != 0 || generic_shape(K, cin, cout) || (!col_scale && !residual && !relu && !y_amax),
@@ -1475,7 +1481,8 @@ int gcl_conv_fwd_fused(const float* x, int64_t n_in, int32_t x_is_planes, const 
   static const int colgroup = [] { const char* e = getenv("GCL_FWD_COLGROUP"); return e ? atoi(e) : 1; }();
   const bool cg = colgroup && grid.y > 1 && !swz;
   dim3 sgrid = cg ? dim3((unsigned)(cdiv(gx, 8) * 8 * grid.y)) : grid;
-  const int sswz = cg ? 2 : swz;
+  const bool ranges = (flags & GCL_CONV_XCD_RANGES) != 0;     // spatially ordered table: contiguous tile range per XCD
+  const int sswz = cg ? (ranges ? 3 : 2) : (ranges ? 1 : swz);
 #define LAUNCH_F32(NBV)                                                                                          \
   hipLaunchKernelGGL(k_conv_fwd<NBV>, grid, dim3(256), 0, st, x, (const float4*)wp, tbl, order, tile_mask,       \
                      (long long)n_out, K, cin, cout, bias, y, swz)

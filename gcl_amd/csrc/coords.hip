@@ -528,15 +528,16 @@ __global__ void __launch_bounds__(64) k_radix_scatter(const unsigned* __restrict
 // pairs: unique keys, so the result equals a stable sort); no global passes.
 template <int WIN>
 __global__ void __launch_bounds__(256) k_window_sort(const int* __restrict__ tbl, int K, long long n, int* order,
-                                                     unsigned* keys_sorted) {
+                                                     unsigned* keys_sorted, const int* __restrict__ pre) {
   __shared__ unsigned long long kv[WIN];
   const long long base = (long long)blockIdx.x * WIN;
   for (int e = threadIdx.x; e < WIN; e += 256) {
     long long v = base + e;
     unsigned long long key = ~0ull;            // padding sorts last
     if (v < n) {
+      const long long row = pre ? pre[v] : v;  // windows of a spatial pre-order (gcl_spatial_order) or of the row order
       unsigned m = 0;
-      for (int k = 0; k < K; ++k) m |= (tbl[(long long)k * n + v] >= 0 ? 1u : 0u) << k;
+      for (int k = 0; k < K; ++k) m |= (tbl[(long long)k * n + row] >= 0 ? 1u : 0u) << k;
       key = ((unsigned long long)m << 32) | (unsigned)e;
     }
     kv[e] = key;
@@ -561,10 +562,32 @@ __global__ void __launch_bounds__(256) k_window_sort(const int* __restrict__ tbl
     long long j = base + e;
     if (j < n) {
       unsigned long long key = kv[e];
-      order[j] = (int)(base + (unsigned)(key & 0xffffffffu));
+      const long long v = base + (unsigned)(key & 0xffffffffu);
+      order[j] = pre ? pre[v] : (int)v;
       keys_sorted[j] = (unsigned)(key >> 32);
     }
   }
+}
+
+// 16-bit spatial key of a row: cloud id (5 bits, wraps) above an 11-bit Morton code of its cell -- 16 x 16 voxels in x / y
+// (4 bits each: 256 voxels before the code wraps), 4 voxels in z (3 bits) -- so that rows close in space get close keys.
+// A LOCALITY heuristic only (which rows run together on a CU / XCD and re-use each other's gathered neighbours in L2):
+// results never depend on it.
+__global__ void k_spatial_keys(const int4* __restrict__ coords, long long n, int tstride, unsigned* keys, int* vals) {
+  long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n) return;
+  const int4 c = coords[v];
+  const unsigned cx = (unsigned)((c.y / tstride + 4096) >> 4), cy = (unsigned)((c.z / tstride + 4096) >> 4),
+                 cz = (unsigned)((c.w / tstride + 4096) >> 2);
+  unsigned m = 0;
+#pragma unroll
+  for (int b = 3; b >= 0; --b) {       // interleaved from the most significant bit: coarse cells first
+    m = (m << 1) | ((cx >> b) & 1u);
+    m = (m << 1) | ((cy >> b) & 1u);
+    if (b < 3) m = (m << 1) | ((cz >> b) & 1u);
+  }
+  keys[v] = (((unsigned)c.x & 31u) << 11) | (m & 2047u);
+  vals[v] = (int)v;
 }
 
 __global__ void k_permute_table(const int* __restrict__ tbl, const int* __restrict__ order, long long n,
@@ -735,9 +758,44 @@ int64_t gcl_table_sort_scratch_len(int64_t n) {
   return 4 * n + 2 * hist + cdiv(hist, SCAN_B) + 64 + 256;   // keys/vals ping-pong, hist, within, digit totals
 }
 
+int gcl_spatial_order(const int32_t* coords, int64_t n, int32_t tensor_stride, int32_t* scratch, int32_t* order,
+                      void* stream) {
+  GCL_CHECK_ARG(coords && scratch && order, "gcl_spatial_order: null pointer");
+  GCL_CHECK_ARG(n > 0 && tensor_stride >= 1, "gcl_spatial_order: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = (int)cdiv(n, RS_BLOCK);
+  const long long hist_len = 256ll * nblk;
+  unsigned* ka = (unsigned*)scratch;
+  unsigned* kb = ka + n;
+  int* va = scratch + 2 * n;
+  int* vb = scratch + 3 * n;
+  int* hist = scratch + 4 * n;
+  int* offs = hist + hist_len;
+  int* bs = offs + hist_len;
+  hipLaunchKernelGGL(k_spatial_keys, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, (const int4*)coords, (long long)n,
+                     tensor_stride, ka, va);
+  for (int p = 0; p < 2; ++p) {      // 16-bit keys: two stable 8-bit passes
+    hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(64), 0, st, (const unsigned*)ka, (long long)n, 8 * p, nblk, hist);
+    hipLaunchKernelGGL(k_radix_digit_scan, dim3(256), dim3(256), 0, st, (const int*)hist, nblk, offs, bs);
+    int* vout = (p == 1) ? order : vb;
+    hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(64), 0, st, (const unsigned*)ka, (const int*)va, (long long)n,
+                       8 * p, nblk, (const int*)offs, (const int*)bs, kb, vout);
+    unsigned* tk = ka; ka = kb; kb = tk;
+    int* tv = va; va = vb; vb = tv;
+  }
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
 int gcl_table_sort(const int32_t* tbl, int32_t K, int64_t n, int32_t window, int32_t* scratch, int32_t* order,
                    int32_t* tbl_sorted, int32_t* tile_mask, void* stream) {
+  return gcl_table_sort_pre(tbl, K, n, window, nullptr, scratch, order, tbl_sorted, tile_mask, stream);
+}
+
+int gcl_table_sort_pre(const int32_t* tbl, int32_t K, int64_t n, int32_t window, const int32_t* pre, int32_t* scratch,
+                       int32_t* order, int32_t* tbl_sorted, int32_t* tile_mask, void* stream) {
   GCL_CHECK_ARG(tbl && scratch && order && tbl_sorted && tile_mask, "gcl_table_sort: null pointer");
+  GCL_CHECK_ARG(!pre || window, "gcl_table_sort_pre: a pre-order needs window = 2048 or 4096");
   GCL_CHECK_ARG(K >= 1 && K <= 27 && n > 0, "gcl_table_sort: K must be <= 27 (3^3 kernels), n > 0");
   GCL_CHECK_ARG(window == 0 || window == 2048 || window == 4096, "gcl_table_sort: window must be 0, 2048 or 4096");
   hipStream_t st = (hipStream_t)stream;
@@ -745,10 +803,10 @@ int gcl_table_sort(const int32_t* tbl, int32_t K, int64_t n, int32_t window, int
   if (window) {
     if (window == 2048)
       hipLaunchKernelGGL(k_window_sort<2048>, dim3((unsigned)cdiv(n, 2048)), dim3(256), 0, st, tbl, K, (long long)n,
-                         order, ka);
+                         order, ka, pre);
     else
       hipLaunchKernelGGL(k_window_sort<4096>, dim3((unsigned)cdiv(n, 4096)), dim3(256), 0, st, tbl, K, (long long)n,
-                         order, ka);
+                         order, ka, pre);
   } else {
     int nblk = (int)cdiv(n, RS_BLOCK);
     long long hist_len = 256ll * nblk;

@@ -136,6 +136,16 @@ int gcl_kernel_map_pairs(const int32_t* nbr, int32_t K, int64_t n_out, const int
 int64_t gcl_table_sort_scratch_len(int64_t n);
 int gcl_table_sort(const int32_t* tbl, int32_t K, int64_t n, int32_t window, int32_t* scratch, int32_t* order,
                    int32_t* tbl_sorted, int32_t* tile_mask, void* stream);
+/* Spatial pre-order of the rows of a coordinate map at tensor stride `tensor_stride`: order[j] = row at position j when
+ * rows are sorted by (cloud id, Morton code of the 4^3-voxel cell); stable, deterministic.  gcl_table_sort_pre with
+ * window = 2048 | 4096 then mask-sorts inside windows of THAT order: the rows a workgroup (and, with
+ * GCL_CONV_XCD_RANGES, an XCD) processes together are spatial neighbours and re-use each other's gathered input rows in
+ * L2 instead of fetching every row from the Infinity Cache once per kernel offset.  A locality heuristic only: results
+ * do not depend on it.  scratch: int32[gcl_table_sort_scratch_len(n)]. */
+int gcl_spatial_order(const int32_t* coords, int64_t n, int32_t tensor_stride, int32_t* scratch, int32_t* order,
+                      void* stream);
+int gcl_table_sort_pre(const int32_t* tbl, int32_t K, int64_t n, int32_t window, const int32_t* pre, int32_t* scratch,
+                       int32_t* order, int32_t* tbl_sorted, int32_t* tile_mask, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Sparse convolution (fp32, exact-f32 MFMA).
@@ -190,10 +200,14 @@ int32_t gcl_conv_fwd_nb(int64_t n_out, int32_t cout, int32_t prec);
  * fp16 hi values (64 bytes) then the fp16 lo values (64 bytes) of x * scale(amax), i.e. 4 bytes per element like x.
  * A tensor that several launches consume (forward, weight gradient; input gradient, weight gradient) is split once. */
 int gcl_split_planes(const float* x, int64_t n, int32_t c, const int32_t* amax, void* planes, void* stream);
+/* flags: GCL_CONV_XCD_RANGES -- the table comes from gcl_table_sort_pre on a spatial pre-order: give every XCD (L2) a
+ * CONTIGUOUS range of row tiles, so that the input rows a tile gathers are mostly the ones its neighbours on the same XCD
+ * just gathered.  Launch-order hint only. */
+#define GCL_CONV_XCD_RANGES 1
 int gcl_conv_fwd(const float* x, int64_t n_in, int32_t x_is_planes, const void* wp, int32_t prec, const int32_t* x_amax,
                  const int32_t* w_amax, const int32_t* tbl, const int32_t* order, const int32_t* tile_mask,
                  int64_t n_out, int32_t K,
-                 int32_t cin, int32_t cout, const float* bias, float* y, float* stats, void* stream);
+                 int32_t cin, int32_t cout, const float* bias, float* y, float* stats, int32_t flags, void* stream);
 
 /* gcl_conv_fwd with a fused inference epilogue: y = relu?(conv * col_scale + bias (+ residual)), i.e. convolution +
  * BatchNorm in eval mode (col_scale = gamma * rsqrt(var + eps), bias = beta - mean * col_scale) + BasicBlock's residual
@@ -203,7 +217,7 @@ int gcl_conv_fwd_fused(const float* x, int64_t n_in, int32_t x_is_planes, const 
                        const int32_t* x_amax, const int32_t* w_amax, const int32_t* tbl, const int32_t* order,
                        const int32_t* tile_mask, int64_t n_out, int32_t K, int32_t cin, int32_t cout, const float* bias,
                        const float* col_scale, const float* residual, int32_t relu, int32_t* y_amax, float* y,
-                       float* stats, void* stream);
+                       float* stats, int32_t flags, void* stream);
 
 /* dW[k] = sum over pairs of offset k of  A[pair_a]^T . B[pair_b]   (A: [*, ca], B: [*, cb]) -> dw [K, ca, cb].
  * Forward conv: A = X, pair_a = pair_in, B = dY, pair_b = pair_out.  Transposed conv: roles swapped.

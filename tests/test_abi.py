@@ -46,26 +46,26 @@ def test_version_and_error_string_without_gpu():
     rc = lib.gcl_pack_weights(None, 27, 32, 32, 0, 0, None, None, None)
     assert rc == -1 and b"null" in lib.gcl_last_error()
     p8 = ctypes.c_void_p(8)
-    rc = lib.gcl_conv_fwd(p8, 10, 0, p8, 0, None, None, None, None, None, 10, 27, 32, 32, None, p8, None, None)
+    rc = lib.gcl_conv_fwd(p8, 10, 0, p8, 0, None, None, None, None, None, 10, 27, 32, 32, None, p8, None, 0, None)
     assert rc == -1 and b"neighbour table" in lib.gcl_last_error()
     # generic shapes (Cin / Cout no multiple of 32, K > 27) are accepted by the same entries; what they cannot take
     # (fused BN statistics, plane images) is rejected before any launch
-    rc = lib.gcl_conv_fwd(p8, 10, 0, p8, 3, None, None, p8, None, None, 10, 27, 48, 32, None, p8, p8, None)
+    rc = lib.gcl_conv_fwd(p8, 10, 0, p8, 3, None, None, p8, None, None, 10, 27, 48, 32, None, p8, p8, 0, None)
     assert rc == -1 and b"multiples of 32" in lib.gcl_last_error()
-    rc = lib.gcl_conv_fwd(p8, 10, 1, p8, 4, None, None, p8, None, None, 10, 27, 64, 16, None, p8, None, None)
+    rc = lib.gcl_conv_fwd(p8, 10, 1, p8, 4, None, None, p8, None, None, 10, 27, 64, 16, None, p8, None, 0, None)
     assert rc == -1 and b"plane images" in lib.gcl_last_error()
     assert lib.gcl_pack_weights_bytes(1, 64, 16, 4) == 64 * 16 * 4          # fp32 W_eff for the generic kernels
     assert lib.gcl_pack_weights_bytes(125, 32, 32, 4) == 125 * 32 * 32 * 4
     rc = lib.gcl_stem_fwd(p8, p8, p8, 10, 27, 1, 48, p8, None)
     assert rc == -1 and b"multiple of 32" in lib.gcl_last_error()
-    rc = lib.gcl_conv_fwd(p8, 10, 0, p8, 3, None, None, p8, p8, None, 10, 27, 32, 32, None, p8, None, None)
+    rc = lib.gcl_conv_fwd(p8, 10, 0, p8, 3, None, None, p8, p8, None, 10, 27, 32, 32, None, p8, None, 0, None)
     assert rc == -1 and b"go together" in lib.gcl_last_error()
-    rc = lib.gcl_conv_fwd(p8, 10, 0, p8, 1, None, None, p8, None, None, 10, 27, 32, 32, None, p8, None, None)
+    rc = lib.gcl_conv_fwd(p8, 10, 0, p8, 1, None, None, p8, None, None, 10, 27, 32, 32, None, p8, None, 0, None)
     assert rc == -1 and b"prec" in lib.gcl_last_error()
     assert lib.gcl_pack_weights_bytes(27, 64, 64, 0) == 27 * 64 * 64 * 4
     assert lib.gcl_pack_weights_bytes(27, 64, 64, 3) == 27 * 64 * 64 * 6
     assert lib.gcl_pack_weights_bytes(27, 64, 64, 4) == 27 * 64 * 64 * 4
-    rc = lib.gcl_conv_fwd(p8, 10, 0, p8, 4, None, None, p8, None, None, 10, 27, 32, 32, None, p8, None, None)
+    rc = lib.gcl_conv_fwd(p8, 10, 0, p8, 4, None, None, p8, None, None, 10, 27, 32, 32, None, p8, None, 0, None)
     assert rc == -1 and b"gcl_amax" in lib.gcl_last_error()
 
 

@@ -164,7 +164,7 @@ def test_other_width_variants_vs_oracle(name):
     m = load_model(name)(1, 32, bn_momentum=0.05, normalize_feature=True, conv1_kernel_size=5, D=3).to(DEV)
     _randomise_bn(m)
     st = _state64(m)
-    C = _lidar_cloud(3, stride=5)
+    C = _lidar_cloud(3, stride=2)          # enough rows at tensor stride 8 for well-conditioned 256-channel BatchNorms
     feats = torch.ones(len(C), 1)
     m.train()
     F = m(ME.SparseTensor(feats.to(DEV), coordinates=C.to(DEV))).F
