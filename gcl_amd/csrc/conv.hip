@@ -200,6 +200,12 @@ __device__ unsigned long long g_stamps[8];
 #define STAMP(V)
 #endif
 
+#ifndef GCL_FWD_MIN_WAVES
+#define GCL_FWD_MIN_WAVES(NB, PL) (((NB) <= 2 && (PL) != 3) ? 4 : 2)
+#endif
+// swizzle of the 16-byte pieces of an un-padded 128-byte LDS row: conflict-free ds_read_b128 of one piece of 32 rows
+__device__ __forceinline__ int a_swz(int row) { return (row >> 1) & 7; }
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -441,7 +447,7 @@ struct ConvEpi {
 // fp32 rows.  The main loop then has no split at all (the kernels are instruction-issue-bound: the split was 48 of ~120
 // instructions per step), a fragment is two 16-byte LDS reads.
 template <int NB, int PL, bool PRE = false, bool EPI = false>
-__global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict__ X, const u32x4* __restrict__ Wp,
+__global__ void __launch_bounds__(256, GCL_FWD_MIN_WAVES(NB, PL)) k_conv_fwd_split(const float* __restrict__ X, const u32x4* __restrict__ Wp,
                                                         const int* __restrict__ tbl, const int* __restrict__ order,
                                                         const int* __restrict__ tile_mask, long long n_out, int K,
                                                         int cin, int cout, const float* __restrict__ bias,
@@ -453,11 +459,15 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
   constexpr int BREG = (BLK + 255) / 256;
   const float a_scale = (PL == 4) ? amax_scale(x_amax) : 1.f;
   const float out_scale = (PL == 4) ? 1.f / (a_scale * amax_scale(w_amax)) : 1.f;   // exact: powers of two
-  __shared__ __attribute__((aligned(16))) float Asm[4][32][LDS_STRIDE];   // wave-private A tiles
+  __shared__ __attribute__((aligned(16))) float Asm[4][32][32];   // wave-private A tiles: un-padded 128-byte rows, 16-byte pieces XOR-swizzled with the row
   __shared__ __attribute__((aligned(16))) u32x4 Bsm[2][BLK];              // weight block, double-buffered
   // neighbour rows of the wave's tile, [wave][k][(row & 7) * 4 + (row >> 3)] (K <= 27): the four rows a lane gathers
-  // (row, row + 8, row + 16, row + 24) are one 16-byte read
-  __shared__ __attribute__((aligned(16))) int Ism[4][27][32];
+  // (row, row + 8, row + 16, row + 24) are one 16-byte read.  The table holds HALF of the offsets at a time (k < 15, later
+  // k >= 15: the loop visits offsets in ascending order; the second half waits in registers and is written when the first
+  // unit with k >= 15 is issued) -- 7.5 KB instead of 14 KB per workgroup, which is what lets a fourth workgroup of the
+  // NB = 2 instances share a CU's 160 KB LDS (occupancy is what hides the gather latency here)
+  constexpr int ISM_H = 15;
+  __shared__ __attribute__((aligned(16))) int Ism[4][ISM_H][32];
   __shared__ unsigned wmask[4];
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   const int i = l & 31, h = l >> 5;
@@ -497,12 +507,21 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
   mymask = __builtin_amdgcn_readfirstlane(mymask);
   if (l == 0) wmask[w] = mymask;
   // all neighbour indices of the tile go to LDS once: no index load (and no index -> gather dependency) in the loop
-  for (int e = l; e < K * 32; e += 64) {
-    int k = e >> 5, r = e & 31;
+  for (int e = l; e < (K < ISM_H ? K : ISM_H) * 32; e += 64) {
+    const int k = e >> 5, r = e & 31;
     int v = -1;
     if (active && row0 + r < n_out) v = tbl ? tbl[(long long)k * n_out + row0 + r] : (int)(row0 + r);
     Ism[w][k][(r & 7) * 4 + (r >> 3)] = v;
   }
+  int ib[6];                       // entries e = 32 ISM_H + l + 64 j (offsets k = e / 32 >= 15, rows e % 32), j = 0 .. 5
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int e = 32 * ISM_H + l + 64 * j, k = e >> 5, r = e & 31;
+    int v = -1;
+    if (k < K && active && row0 + r < n_out) v = tbl[(long long)k * n_out + row0 + r];
+    ib[j] = v;
+  }
+  bool second_half = false;
   __syncthreads();
   const unsigned wgmask = wmask[0] | wmask[1] | wmask[2] | wmask[3];
 
@@ -516,7 +535,16 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
   const unsigned row_bytes = (unsigned)cin * 4u;
 #define GCL_GATHER_A(KK, CCV)                                                                                  \
   {                                                                                                            \
-    const int4 ri_ = *reinterpret_cast<const int4*>(&Ism[w][(KK)][rsub * 4]);                                  \
+    if ((KK) >= ISM_H && !second_half) {   /* every gather of an offset < 14 has been issued: switch the table */ \
+      second_half = true;                                                                                      \
+      WAVE_FENCE();                                                                                            \
+      _Pragma("unroll") for (int j_ = 0; j_ < 6; ++j_) {                                                       \
+        const int e_ = 32 * ISM_H + l + 64 * j_;                                                               \
+        if ((e_ >> 5) < K) Ism[w][(e_ >> 5) - ISM_H][((e_ & 31) & 7) * 4 + ((e_ & 31) >> 3)] = ib[j_];         \
+      }                                                                                                        \
+      WAVE_FENCE();                                                                                            \
+    }                                                                                                          \
+    const int4 ri_ = *reinterpret_cast<const int4*>(&Ism[w][(KK) >= ISM_H ? (KK) - ISM_H : (KK)][rsub * 4]);    \
     const unsigned co_ = (unsigned)(CCV)*128u + (unsigned)p * 16u;                                             \
     st[0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)((unsigned)ri_.x * row_bytes + co_), 0, 0)); \
     st[1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)((unsigned)ri_.y * row_bytes + co_), 0, 0)); \
@@ -534,7 +562,7 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
   {                                                                                                          \
     if (MINE) {                                                                                              \
       _Pragma("unroll") for (int ps = 0; ps < 4; ++ps)                                                       \
-          *reinterpret_cast<float4*>(&Asm[w][rsub + 8 * ps][p * 4]) = st[ps];                                \
+          *reinterpret_cast<float4*>(&Asm[w][rsub + 8 * ps][(p ^ a_swz(rsub + 8 * ps)) << 2]) = st[ps];      \
     }                                                                                                        \
     _Pragma("unroll") for (int e = 0; e < BREG; ++e) {                                                       \
       if ((BLK % 256 == 0) || (e * 256 + t < BLK)) Bsm[BUF][e * 256 + t] = br[e];                           \
@@ -584,11 +612,11 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
         for (int m = 0; m < 2; ++m) {
           u32x4 ap[3];
           if (PRE) {   // row image: dwords [0,16) = hi of channels 0..31, [16,32) = lo
-            ap[0] = *reinterpret_cast<const u32x4*>(&Asm[w][i][8 * m + 4 * h]);
-            ap[1] = *reinterpret_cast<const u32x4*>(&Asm[w][i][16 + 8 * m + 4 * h]);
+            ap[0] = *reinterpret_cast<const u32x4*>(&Asm[w][i][((2 * m + h) ^ a_swz(i)) << 2]);
+            ap[1] = *reinterpret_cast<const u32x4*>(&Asm[w][i][((4 + 2 * m + h) ^ a_swz(i)) << 2]);
           } else {
-            float4 f0 = *reinterpret_cast<const float4*>(&Asm[w][i][16 * m + 8 * h]);
-            float4 f1 = *reinterpret_cast<const float4*>(&Asm[w][i][16 * m + 8 * h + 4]);
+            float4 f0 = *reinterpret_cast<const float4*>(&Asm[w][i][((4 * m + 2 * h) ^ a_swz(i)) << 2]);
+            float4 f1 = *reinterpret_cast<const float4*>(&Asm[w][i][((4 * m + 2 * h + 1) ^ a_swz(i)) << 2]);
             split8<PL>(f0, f1, a_scale, ap);
           }
 #pragma unroll
@@ -664,6 +692,242 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split(const float* __restrict_
     }
   }
   if (EPI && epi.y_amax) {   // one publish per wave (launches of this path are small: inference on single clouds)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o));
+    if (l == 0) amax_slot_publish(epi.y_amax, __float_as_int(ymax), (unsigned)tile);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// TWO (offset, slice) units per workgroup barrier.  k_conv_fwd_split issues the loads of a step just before the barrier
+// that closes the previous one and needs them when that step's 12 MFMAs per wave are done: the window a gather has to
+// arrive in is ONE short compute phase, far less than the latency of random 128-byte rows from the Infinity Cache under
+// load, so every step ends up waiting for the slowest row of its tile.  Here a step carries two units -- twice the
+// bytes in flight per wave, twice the MFMA work to hide them behind, half the barriers and half the loop overhead --
+// with the same per-unit arithmetic in the same order (bitwise-identical results).  The wave-private A tiles are
+// un-padded 128-byte rows whose 16-byte pieces are XOR-swizzled with the row (conflict-free ds_read_b128 like the
+// padded layout, 32 KB instead of 37 KB: two workgroups of NB = 2 fit a CU's 160 KB LDS).
+// ---------------------------------------------------------------------------------------------------
+template <int NB, int PL, bool PRE = false, bool EPI = false>
+__global__ void __launch_bounds__(256) k_conv_fwd_split2(const float* __restrict__ X, const u32x4* __restrict__ Wp,
+                                                         const int* __restrict__ tbl, const int* __restrict__ order,
+                                                         const int* __restrict__ tile_mask, long long n_out, int K,
+                                                         int cin, int cout, const float* __restrict__ bias,
+                                                         float* __restrict__ Y, int swizzle,
+                                                         float* __restrict__ stats, const int* __restrict__ x_amax,
+                                                         const int* __restrict__ w_amax, unsigned x_bytes, ConvEpi epi) {
+  constexpr int U = 2;
+  constexpr int NPL = Prec<PL>::planes;
+  constexpr int BLK = NB * 2 * NPL * 64;                // uint4 per unit weight block of this workgroup
+  constexpr int BREG = (BLK + 255) / 256;
+  const float a_scale = (PL == 4) ? amax_scale(x_amax) : 1.f;
+  const float out_scale = (PL == 4) ? 1.f / (a_scale * amax_scale(w_amax)) : 1.f;   // exact: powers of two
+  __shared__ __attribute__((aligned(16))) float Asm[4][U][32][32];        // wave-private A tiles, swizzled pieces
+  __shared__ __attribute__((aligned(16))) u32x4 Bsm[2][U][BLK];           // weight blocks, double-buffered
+  __shared__ __attribute__((aligned(16))) int Ism[4][27][32];
+  __shared__ unsigned wmask[4];
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  const int i = l & 31, h = l >> 5;
+  unsigned bxx = blockIdx.x, byy = blockIdx.y;
+  if (swizzle >= 2) {
+    const unsigned ncb = (unsigned)(cout / (32 * NB)), nrw = (unsigned)((n_out + CONV_ROWS - 1) / CONV_ROWS);
+    const unsigned xcd = bxx & 7u, slot = bxx >> 3;
+    byy = slot % ncb;
+    if (swizzle == 2) {
+      bxx = (slot / ncb) * 8u + xcd;
+      if (bxx >= nrw) return;
+    } else {
+      const unsigned q = nrw >> 3, r = nrw & 7u, mine = q + (xcd < r ? 1u : 0u), j = slot / ncb;
+      if (j >= mine) return;
+      bxx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+  } else {
+    bxx = xcd_tile(bxx, gridDim.x, swizzle);
+  }
+  const long long tile = (long long)bxx * 4 + w;
+  const long long row0 = tile * 32;
+  const bool active = row0 < n_out;
+  const int nb0 = byy * NB;
+  const int TNB = cout >> 5, CC = cin >> 5;
+  const int p = l & 7, rsub = l >> 3;
+
+  f32x16 acc[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+
+  unsigned mymask = 0u;
+  if (active) mymask = tile_mask ? (unsigned)tile_mask[tile] : ((K >= 32) ? ~0u : ((1u << K) - 1u));
+  mymask = __builtin_amdgcn_readfirstlane(mymask);
+  if (l == 0) wmask[w] = mymask;
+  for (int e = l; e < K * 32; e += 64) {
+    int k = e >> 5, r = e & 31;
+    int v = -1;
+    if (active && row0 + r < n_out) v = tbl ? tbl[(long long)k * n_out + row0 + r] : (int)(row0 + r);
+    Ism[w][k][(r & 7) * 4 + (r >> 3)] = v;
+  }
+  __syncthreads();
+  const unsigned wgmask = wmask[0] | wmask[1] | wmask[2] | wmask[3];
+
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)x_bytes, 0x00020000);
+  const unsigned row_bytes = (unsigned)cin * 4u;
+  // swizzled LDS float offsets of this lane's four gathered rows (write side) and of its fragment row (read side)
+  int wr_off[4];
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) wr_off[ps] = (rsub + 8 * ps) * 32 + ((p ^ a_swz(rsub + 8 * ps)) << 2);
+  const int rd_swz = a_swz(i);
+
+  if (wgmask != 0u) {
+    // cursor over the unit sequence: offsets of the workgroup mask in ascending order x the CC channel slices
+    unsigned m_rest = wgmask & (wgmask - 1);
+    int kc = __builtin_ctz(wgmask), cc = 0;
+    bool more = true;                                   // the cursor points at an existing unit
+    float4 st[U][4];
+    u32x4 br[U][BREG];
+    int kn[U], cn[U];
+    bool hn[U], mn[U];                                   // staged step: unit exists / this wave has rows for it
+    bool hc[U], mc[U];                                   // current step (in LDS)
+    auto advance = [&]() {
+      cc += 1;
+      if (cc == CC) {
+        cc = 0;
+        if (m_rest) {
+          kc = __builtin_ctz(m_rest);
+          m_rest &= m_rest - 1;
+        } else {
+          more = false;
+        }
+      }
+    };
+#define GCL2_LOAD_STEP()                                                                                          \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                                 \
+    hn[u] = more;                                                                                                 \
+    mn[u] = false;                                                                                                \
+    kn[u] = kc;                                                                                                   \
+    cn[u] = cc;                                                                                                   \
+    if (more) {                                                                                                   \
+      mn[u] = (mymask >> kc) & 1u;                                                                                \
+      if (mn[u]) {                                                                                                \
+        const int4 ri_ = *reinterpret_cast<const int4*>(&Ism[w][kc][rsub * 4]);                                  \
+        const unsigned co_ = (unsigned)cc * 128u + (unsigned)p * 16u;                                             \
+        st[u][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)((unsigned)ri_.x * row_bytes + co_), 0, 0)); \
+        st[u][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)((unsigned)ri_.y * row_bytes + co_), 0, 0)); \
+        st[u][2] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)((unsigned)ri_.z * row_bytes + co_), 0, 0)); \
+        st[u][3] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)((unsigned)ri_.w * row_bytes + co_), 0, 0)); \
+      }                                                                                                           \
+      const u32x4* src_ = Wp + (((long long)kc * CC + cc) * TNB + nb0) * (2 * NPL * 64);                          \
+      _Pragma("unroll") for (int e = 0; e < BREG; ++e) {                                                          \
+        if ((BLK % 256 == 0) || (e * 256 + t < BLK)) br[u][e] = src_[e * 256 + t];                               \
+      }                                                                                                           \
+      advance();                                                                                                  \
+    }                                                                                                             \
+  }
+#define GCL2_STORE_STEP(BUF)                                                                                      \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                                 \
+    if (hn[u]) {                                                                                                  \
+      if (mn[u]) {                                                                                                \
+        float* at_ = &Asm[w][u][0][0];                                                                            \
+        _Pragma("unroll") for (int ps = 0; ps < 4; ++ps) *reinterpret_cast<float4*>(at_ + wr_off[ps]) = st[u][ps]; \
+      }                                                                                                           \
+      _Pragma("unroll") for (int e = 0; e < BREG; ++e) {                                                          \
+        if ((BLK % 256 == 0) || (e * 256 + t < BLK)) Bsm[BUF][u][e * 256 + t] = br[u][e];                         \
+      }                                                                                                           \
+    }                                                                                                             \
+  }
+    // step 0 -> LDS, step 1 -> registers
+    GCL2_LOAD_STEP();
+    GCL2_STORE_STEP(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      hc[u] = hn[u];
+      mc[u] = mn[u];
+    }
+    GCL2_LOAD_STEP();
+    __syncthreads();
+    int buf = 0;
+    while (true) {
+      // ---- compute the current step: its units from Asm[w][u] (own tiles) and Bsm[buf][u]
+      WAVE_FENCE();
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (hc[u] && mc[u]) {
+          const float* ar = &Asm[w][u][i][0];
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            u32x4 ap[3];
+            if (PRE) {   // row image: pieces 0..3 = hi of channels 0..31, 4..7 = lo
+              ap[0] = *reinterpret_cast<const u32x4*>(ar + (((2 * m + h) ^ rd_swz) << 2));
+              ap[1] = *reinterpret_cast<const u32x4*>(ar + (((4 + 2 * m + h) ^ rd_swz) << 2));
+            } else {
+              float4 f0 = *reinterpret_cast<const float4*>(ar + (((4 * m + 2 * h) ^ rd_swz) << 2));
+              float4 f1 = *reinterpret_cast<const float4*>(ar + (((4 * m + 2 * h + 1) ^ rd_swz) << 2));
+              split8<PL>(f0, f1, a_scale, ap);
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+              const u32x4* bb = &Bsm[buf][u][((b * 2 + m) * NPL) * 64 + l];
+              u32x4 bp[3];
+              bp[0] = bb[0];
+              bp[1] = bb[64];
+              if (NPL == 3) bp[2] = bb[128];
+              mfma_terms<PL>(ap, bp, acc[b]);
+            }
+          }
+        }
+      }
+      if (!hn[0]) break;   // nothing staged in registers: done
+      // ---- staged step: registers -> LDS (A: own tiles, after this wave's reads; B: the buffer nobody reads)
+      WAVE_FENCE();
+      GCL2_STORE_STEP(buf ^ 1);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        hc[u] = hn[u];
+        mc[u] = mn[u];
+      }
+      // ---- the step after: issue its loads (in flight across the barrier and the next compute phase)
+      GCL2_LOAD_STEP();
+      __syncthreads();   // publishes the weight blocks just written; their buffer was last read two steps ago
+      buf ^= 1;
+    }
+#undef GCL2_LOAD_STEP
+#undef GCL2_STORE_STEP
+  }
+  if (!active) return;
+  int orow_l = -1;
+  if ((l < 32) && (row0 + l < n_out)) orow_l = order ? order[row0 + l] : (int)(row0 + l);
+  float ymax = 0.f;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int col = (nb0 + b) * 32 + i;
+    float bvv = bias ? bias[col] : 0.f;
+    float csc = (EPI && epi.col_scale) ? epi.col_scale[col] * out_scale : out_scale;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(bvv) : "v"(bvv));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(csc) : "v"(csc));
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int orow = __shfl(orow_l, (r & 3) + 8 * (r >> 2) + 4 * h);
+      if (orow >= 0) {
+        float v = acc[b][r] * csc + bvv;
+        if (EPI && epi.residual) v += epi.residual[(long long)orow * cout + col];
+        if (EPI && epi.relu) v = fmaxf(v, 0.f);
+        Y[(long long)orow * cout + col] = v;
+        s1 += v;
+        s2 += v * v;
+        if (EPI) ymax = fmaxf(ymax, fabsf(v));
+      }
+    }
+    if (stats) {
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (h == 0) {
+        stats[(tile * 2 + 0) * cout + col] = s1;
+        stats[(tile * 2 + 1) * cout + col] = s2;
+      }
+    }
+  }
+  if (EPI && epi.y_amax) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o));
     if (l == 0) amax_slot_publish(epi.y_amax, __float_as_int(ymax), (unsigned)tile);
@@ -1044,6 +1308,8 @@ __global__ void __launch_bounds__(256) k_bwd_weight_reduce(const float* __restri
 static int conv_fwd_nb(long long n_out, int cout, int prec) {
   int nb = (cout % 128 == 0) ? 4 : ((cout % 64 == 0) ? 2 : 1);
   static const int pol = [] { const char* s = getenv("GCL_NB_POLICY"); return s ? atoi(s) : 1; }();
+  static const int force = [] { const char* s = getenv("GCL_FORCE_NB"); return s ? atoi(s) : 0; }();   // diagnostic
+  if (force == 1 || (force == 2 && nb > 2)) return force;
   if (prec == 3 && nb == 4) nb = 2;   // three planes: the double-buffered weight block of NB = 4 would not fit twice
   long long wgs = cdiv(n_out, 128) * (cout / (32 * nb));
   if (prec != 0 && pol == 1 && nb == 4 && wgs > 512 && wgs <= 1024) nb = 2;
@@ -1486,10 +1752,25 @@ int gcl_conv_fwd_fused(const float* x, int64_t n_in, int32_t x_is_planes, const 
 #define LAUNCH_F32(NBV)                                                                                          \
   hipLaunchKernelGGL(k_conv_fwd<NBV>, grid, dim3(256), 0, st, x, (const float4*)wp, tbl, order, tile_mask,       \
                      (long long)n_out, K, cin, cout, bias, y, swz)
+  // TUNING KNOB: GCL_CONV_UNITS=2 selects k_conv_fwd_split2 (two units per barrier) for the NB <= 2 instances of the
+  // two-plane arithmetics.  Measured on the KITTI batch (profiles/r02_conv_units.txt): bitwise-identical results, every
+  // layer 10-40 % SLOWER (80 KB of LDS per workgroup: 2 instead of 3-4 workgroups per CU) -- occupancy, not the
+  // prefetch distance, is what hides the gather latency here.  Default 1.
+  static const int units = [] { const char* e = getenv("GCL_CONV_UNITS"); return e ? atoi(e) : 1; }();
 #define LAUNCH_SPLIT_I(NBV, PLV, PREV, EPIV)                                                                     \
-  hipLaunchKernelGGL((k_conv_fwd_split<NBV, PLV, PREV, EPIV>), sgrid, dim3(256), 0, st, x, (const u32x4*)wp, tbl, \
-                     order, tile_mask, (long long)n_out, K, cin, cout, bias, y, sswz, stats, x_amax, w_amax,     \
-                     x_bytes, epi)
+  do {                                                                                                           \
+    if constexpr (NBV <= 2 && PLV != 3) {                                                                        \
+      if (units >= 2) {                                                                                          \
+        hipLaunchKernelGGL((k_conv_fwd_split2<NBV, PLV, PREV, EPIV>), sgrid, dim3(256), 0, st, x, (const u32x4*)wp, \
+                           tbl, order, tile_mask, (long long)n_out, K, cin, cout, bias, y, sswz, stats, x_amax,   \
+                           w_amax, x_bytes, epi);                                                                \
+        break;                                                                                                   \
+      }                                                                                                          \
+    }                                                                                                            \
+    hipLaunchKernelGGL((k_conv_fwd_split<NBV, PLV, PREV, EPIV>), sgrid, dim3(256), 0, st, x, (const u32x4*)wp, tbl, \
+                       order, tile_mask, (long long)n_out, K, cin, cout, bias, y, sswz, stats, x_amax, w_amax,   \
+                       x_bytes, epi);                                                                            \
+  } while (0)
 #define LAUNCH_SPLIT(NBV, PLV)                                                                                   \
   do {                                                                                                           \
     if (PLV == 4 && x_is_planes) {                                                                               \

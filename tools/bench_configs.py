@@ -116,8 +116,43 @@ def main():
         To = sc2_pcr(sc[0].cpu().numpy(), tc[0].cpu().numpy())
         t_sc2_cpu = time.perf_counter() - t0
         sc2_diff = float((Tg[0].cpu() - To).abs().max())
+        # ---- round 2: the packaged eval loop (gcl_amd.scripts.test_kitti.eval_pairs) with B pairs per forward pass
+        from gcl_amd.scripts.test_kitti import eval_pairs, forward_clouds
+        big = [synthetic.make_eval_pair(100 + s, baseline=15.0 + 5.0 * (s % 6)) for s in range(8)]
+        dbig = [{k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in p_.items()} for p_ in big]
+        batched = {}
+        for B in (1, 2, 4, 8):
+            clouds = [(dp_[f"sinput{k}_F"], dp_[f"sinput{k}_C"]) for dp_ in dbig[:B] for k in (0, 1)]
+            forward_clouds(model, clouds)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            nv = 0
+            for _ in range(args.iters):
+                for c0 in range(0, 8, B):
+                    cl = [(dp_[f"sinput{k}_F"], dp_[f"sinput{k}_C"]) for dp_ in dbig[c0:c0 + B] for k in (0, 1)]
+                    nv += sum(len(f) for f, _ in cl)
+                    forward_clouds(model, cl)
+            torch.cuda.synchronize()
+            dtb = time.perf_counter() - t0
+            batched[f"B={B} pairs ({2 * B} clouds) per forward"] = {
+                "voxels_per_s": round(nv / dtb, 1), "ms_per_cloud": round(dtb / (args.iters * 16) * 1e3, 3)}
+        np.random.seed(0)
+        eval_pairs(model, big, matcher, device=dev, batch_pairs=8)                   # warm-up
+        loop = {}
+        for B in (1, 8):
+            np.random.seed(0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(max(1, args.iters // 3)):
+                r = eval_pairs(model, big, matcher, device=dev, batch_pairs=B)
+            torch.cuda.synchronize()
+            dtl = (time.perf_counter() - t0) / max(1, args.iters // 3)
+            loop[f"batch_pairs={B}"] = {"pairs_per_s": round(len(big) / dtl, 2), "ms_per_pair": round(dtl / len(big) * 1e3, 3),
+                                        "voxels_per_s": round(r["n_voxels"] / dtl, 1)}
     n_pairs = args.iters * len(pairs)
     print(json.dumps({
+        "configs[1] forward-only, B pairs per forward pass (forward_clouds: bitwise-equal features)": batched,
+        "configs[4] packaged eval loop eval_pairs (2 x fwd + find_corr + random_sample + SC2-PCR + RTE/RRE meters)": loop,
         "configs[4] eval incl. SC2-PCR registration (8000 nodes)": {
             "pairs_per_s": round(n_pairs / t_reg, 2), "ms_per_pair": round(t_reg / n_pairs * 1e3, 3)},
         "configs[4] eval incl. SC2-PCR, both clouds in one forward pass (forward_pair)": {
