@@ -276,10 +276,14 @@ class CoordinateManager:
         nbr_t = None if same else torch.empty((K, n_in), dtype=torch.int32, device=self.device)
         counts = torch.empty(K, dtype=torch.int32, device=self.device)
         if self._bitmap is None:
-            self._bitmap = torch.empty(lib.gcl_kernel_map_bitmap_len(), dtype=torch.int32, device=self.device)
+            self._bitmap = {}
+        bitmap_valid = t_in in self._bitmap            # one presence bitmap per coordinate table, filled once
+        if not bitmap_valid:
+            self._bitmap[t_in] = torch.empty(lib.gcl_kernel_map_bitmap_len(), dtype=torch.int32, device=self.device)
         scratch = torch.empty(lib.gcl_kernel_map_scratch_len(kernel_size, n_out), dtype=torch.int32, device=self.device)
         _lib.check(lib.gcl_kernel_map(_lib.ptr(C_out), n_out, _lib.ptr(table_in), cap_in, kernel_size, t_in,
-                                      int(same), _lib.ptr(self._bitmap), _lib.ptr(scratch), _lib.ptr(nbr),
+                                      int(same) | (2 if bitmap_valid else 0), _lib.ptr(self._bitmap[t_in]),
+                                      _lib.ptr(scratch), _lib.ptr(nbr),
                                       _lib.ptr(nbr_t), n_in, _lib.ptr(counts), _lib.stream()), "gcl_kernel_map")
         km = KernelMap(nbr, nbr_t, counts, n_in, n_out, K, self, t_in, t_out)
         self._kmaps[key] = km

@@ -697,11 +697,13 @@ int gcl_kernel_map(const int32_t* coords_out, int64_t n_out, const int64_t* tabl
   GCL_CHECK_ARG(coords_out && table_in && nbr && counts && scratch, "gcl_kernel_map: null pointer");
   GCL_CHECK_ARG(ks >= 1 && (ks & 1) && ks <= 5, "gcl_kernel_map: kernel size must be 1, 3 or 5");
   GCL_CHECK_ARG(n_out > 0 && step >= 1 && is_pow2(cap_in), "gcl_kernel_map: bad sizes");
+  const bool bitmap_valid = (same_map & 2) != 0;      // bit 1: `bitmap` already describes table_in (built by an earlier call)
+  same_map &= 1;
   GCL_CHECK_ARG(!same_map || (nbr_t == nullptr && n_in == n_out), "gcl_kernel_map: same_map excludes nbr_t");
   hipStream_t st = (hipStream_t)stream;
   int K = ks * ks * ks;
   int nblk = (int)cdiv(n_out, 256);
-  if (bitmap) {
+  if (bitmap && !bitmap_valid) {
     GCL_CHECK_HIP(hipMemsetAsync(bitmap, 0, BITMAP_WORDS * sizeof(int32_t), st));
     hipLaunchKernelGGL(k_bitmap_fill, dim3((unsigned)cdiv(cap_in, 256)), dim3(256), 0, st, (const Slot*)table_in,
                        (long long)cap_in, (unsigned*)bitmap);

@@ -111,6 +111,8 @@ int gcl_host_legacy_choice(uint32_t* key, int32_t* pos, int64_t n, int64_t k, in
  * same_map != 0: coords_out IS the input map (stride-1 conv): only offsets k <= K/2 are looked up, the mirror
  *   entries nbr[(K-1-k) * n + u] = v are written from the hits; nbr_t must be NULL.
  * same_map == 0 and nbr_t != NULL (n_in rows): nbr_t[k * n_in + u] = v for every pair (filled with -1 first).
+ * same_map bit 1 (value 2): `bitmap` was already filled for THIS table_in by an earlier call (the three kernel maps that
+ *   read the stride-1 table of a step share one fill); bit 0 is the same-map flag described above.
  * bitmap: optional int32[gcl_kernel_map_bitmap_len()] scratch: a presence bit per hashed key lets most absent
  *   neighbours return without probing the table.  scratch: int32[gcl_kernel_map_scratch_len(ks, n_out)] (per-block
  *   pair counts, summed in order -- no contended atomics).  counts[k] (int32[K], device) = #pairs of offset k. */
