@@ -289,6 +289,37 @@ class CoordinateManager:
         self._kmaps[key] = km
         return km
 
+    # -- loader-side prefetch -----------------------------------------------------------------------------------
+    def prefetch(self, specs):
+        """Builds, on the CURRENT stream, everything a network will ask this manager for: ``specs`` = iterable of
+        (t_in, kernel_size, stride, tables, pairs) with ``tables`` a tuple of ``transposed`` flags for
+        KernelMap.sorted_table and ``pairs`` whether the weight gradient's pair lists are needed.  A trainer calls this
+        for batch i+1 on a side stream while batch i trains (the maps depend on the coordinates only), which takes the
+        ~150 small integer launches and the level-size read-back off the training stream's critical path."""
+        for t_in, ks, stride, tables, pairs in specs:
+            km = self.get_kernel_map(t_in, ks, stride)
+            for tr in tables:
+                km.sorted_table(transposed=bool(tr))
+            if pairs:
+                km.pairs()
+        return self
+
+    def device_tensors(self):
+        """Every device tensor this manager holds (for ``record_stream`` when it was built on another stream)."""
+        out = []
+        for C, table, _ in self._maps.values():
+            out += [C, table]
+        out += list(self._status.values()) + list((self._bitmap or {}).values()) + list(self._spatial.values())
+        for km in self._kmaps.values():
+            out += [t for t in (km.nbr, km.nbr_t, km._counts_dev) if t is not None]
+            for tup in km._sorted.values():
+                out += [t for t in tup if t is not None]
+            if km._pairs is not None:
+                out += [km._pairs[0], km._pairs[1]]
+        for p in self._identity.values():
+            out.append(p[0])
+        return [t for t in out if isinstance(t, torch.Tensor) and t.is_cuda]
+
     def identity_pairs(self, n):
         """Pair lists of a kernel_size-1 convolution (row i <-> row i), padded to GCL_PAIR_CHUNK."""
         if n not in self._identity:
@@ -336,7 +367,10 @@ class SparseTensor:
                                    "(ME.SparseTensor(feats.to(device), coordinates=coords.to(device)))")
             if features.shape[0] != coordinates.shape[0]:
                 raise ValueError("features and coordinates differ in length")
-            coordinate_manager = CoordinateManager(coordinates)
+            if coordinate_manager is None:
+                coordinate_manager = CoordinateManager(coordinates)
+            elif coordinate_manager.num_rows(tensor_stride) != coordinates.shape[0]:     # a manager prefetched for these rows
+                raise ValueError("coordinate_manager was built for a different coordinate set")
             coordinate_map_key = CoordinateMapKey(tensor_stride)
         elif coordinate_map_key is None or coordinate_manager is None:
             raise ValueError("either coordinates or (coordinate_map_key, coordinate_manager) is required")

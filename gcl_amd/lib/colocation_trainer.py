@@ -319,6 +319,8 @@ class FinestContrastiveLossTrainer:
                                          weight_decay=cfg.weight_decay)
         self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, cfg.exp_gamma)
         self.pos_weight, self.neg_weight, self.finest_weight = cfg.pos_weight, cfg.neg_weight, cfg.finest_weight
+        self.map_prefetch = os.environ.get("GCL_MAP_PREFETCH", "1") == "1"
+        self._side = None
 
     def location_loss(self, F_out, group, index, index_hash, finest_flag, max_pos_cluster, max_hn_samples,
                       points=None, batch_lengths=None, draws=None):
@@ -340,7 +342,8 @@ class FinestContrastiveLossTrainer:
     def forward_loss(self, input_dict, draws=None):
         cfg = self.config
         sinput = ME.SparseTensor(input_dict["sinput_F"].to(self.device, non_blocking=True),
-                                 coordinates=input_dict["sinput_C"].to(self.device, non_blocking=True))
+                                 coordinates=input_dict["sinput_C"].to(self.device, non_blocking=True),
+                                 coordinate_manager=input_dict.get("_coordinate_manager"))
         F_out = self.model(sinput).F
         pos, fin, neg = self.location_loss(
             F_out, input_dict["group"], input_dict["index"], input_dict.get("index_hash"), input_dict["finest_flag"],
@@ -364,6 +367,34 @@ class FinestContrastiveLossTrainer:
                                cfg.num_pos_per_batch * cfg.batch_size, cfg.num_hn_samples_per_batch * cfg.batch_size,
                                sizes, cfg.use_pair_group_positive_loss)
 
+    def _prepare(self, batch):
+        """Loader-side work for a coming batch, run by train_steps' helper thread while the previous step is being
+        enqueued: the host draws (native, outside the interpreter lock) and -- for batches that are already on the
+        device -- the coordinate manager with every kernel map, sorted table and pair list of the network, built on a
+        low-priority SIDE stream (CoordinateManager.prefetch).  The maps depend on the coordinates only; building them
+        ahead removes the level-size read-back (the one host sync of a step) and ~150 small launches from the training
+        stream, whose gaps they fill instead."""
+        draws = self._draw_for(batch)
+        C = batch.get("sinput_C") if isinstance(batch, dict) else None
+        if isinstance(batch, dict) and "_coordinate_manager" in batch:       # a stale manager of an earlier pass
+            batch = {k: v for k, v in batch.items() if k not in ("_coordinate_manager", "_maps_event")}
+        specs = getattr(getattr(self, "model", None), "map_specs", None)
+        if getattr(self, "map_prefetch", False) and specs is not None and isinstance(C, torch.Tensor) and C.is_cuda:
+            with torch.cuda.device(self.device):
+                if getattr(self, "_side", None) is None:
+                    lo, _hi = torch.cuda.Stream.priority_range()        # (lowest priority, highest priority)
+                    self._side = torch.cuda.Stream(device=self.device, priority=lo)
+                with torch.cuda.stream(self._side):
+                    ev = batch.get("_h2d_event")
+                    if ev is not None:
+                        self._side.wait_event(ev)
+                    mgr = ME.CoordinateManager(C).prefetch(specs())
+                    done = torch.cuda.Event()
+                    done.record(self._side)
+            batch = dict(batch)               # never mutate the caller's dict (it may be fed again)
+            batch["_coordinate_manager"], batch["_maps_event"] = mgr, done
+        return draws, batch
+
     def train_steps(self, batches):
         """The epoch loop (``_train_epoch`` :811-916): yields train_step(...) for every optimizer step, i.e. for every
         ``config.iter_size`` consecutive batches (:838, a trailing incomplete group is dropped like ``len // iter_size``).
@@ -383,7 +414,7 @@ class FinestContrastiveLossTrainer:
             return None
 
         def draw(grp):
-            return [self._draw_for(b) for b in grp]
+            return [self._prepare(b) for b in grp]
 
         cur = take()
         if cur is None:
@@ -391,7 +422,8 @@ class FinestContrastiveLossTrainer:
         with ThreadPoolExecutor(max_workers=1) as pool:
             fut = pool.submit(draw, cur)
             while cur is not None:
-                draws = fut.result()
+                prep = fut.result()                      # [(draws, batch with its prefetched maps)]
+                draws, cur = [p[0] for p in prep], [p[1] for p in prep]
                 nxt = take()
                 if nxt is not None:
                     fut = pool.submit(draw, nxt)
@@ -463,10 +495,18 @@ def prefetch_to_device(batches, device, keys=("sinput_C", "sinput_F", "group", "
 
 def wait_for_batch(batch):
     """Orders the current stream behind the host -> device copy of a prefetched batch (no-op for ordinary batches)."""
-    ev = batch.get("_h2d_event") if isinstance(batch, dict) else None
+    if not isinstance(batch, dict):
+        return
+    ev, mev = batch.get("_h2d_event"), batch.get("_maps_event")
+    if ev is None and mev is None:
+        return
+    cur = torch.cuda.current_stream()
     if ev is not None:
-        cur = torch.cuda.current_stream()
         cur.wait_event(ev)
         for v in batch.values():
             if isinstance(v, torch.Tensor) and v.is_cuda:
                 v.record_stream(cur)          # allocated on the copy stream, consumed on the compute stream
+    if mev is not None:                       # coordinate manager prefetched on the side stream
+        cur.wait_event(mev)
+        for t in batch["_coordinate_manager"].device_tensors():
+            t.record_stream(cur)

@@ -61,6 +61,20 @@ class ResUNet2(ME.MinkowskiNetwork):
         self.final = ME.MinkowskiConvolution(in_channels=tr[1], out_channels=out_channels, kernel_size=1, stride=1,
                                              dilation=1, bias=True, dimension=D)
 
+    def map_specs(self):
+        """(t_in, kernel_size, stride, tables, pairs) of every kernel map a training step of this network touches
+        (CoordinateManager.prefetch): the first layer reads its map directly (no sorted table, no pair lists), the
+        stride-1 levels need one table, the strided maps both (down-convolution forward / up-convolution input gradient
+        read ``nbr``, the other two directions ``nbr_t``)."""
+        specs = [(1, self.conv1.kernel_size, 1, () if self.conv1.in_channels <= 4 else (False,), self.conv1.in_channels > 4)]
+        t = 1
+        for l in (1, 2, 3, 4):
+            if l > 1:
+                specs.append((t // 2, self.KERNEL_SIZES[l - 1], 2, (False, True), True))
+            specs.append((t, 3, 1, (False,), True))
+            t *= 2
+        return specs
+
     def forward(self, x):
         skips = {}
         out = x

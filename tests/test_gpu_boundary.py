@@ -419,3 +419,27 @@ def test_full_size_batch_against_oracle_fixture():
     # running statistics after this one training-mode forward (momentum 0.05)
     assert rel_l2(m.norm1.bn.running_mean.cpu(), z["running_mean_norm1"]) < 1e-4
     assert rel_l2(m.block4.norm2.bn.running_var.cpu(), z["running_var_block4"]) < 1e-4
+
+
+def test_map_prefetch_on_side_stream_changes_nothing():
+    """train_steps builds the coordinate manager of batch i+1 (maps, sorted tables, pair lists) on a side stream while
+    batch i trains, from host batches copied by prefetch_to_device: losses and parameters equal the lazy path bit for
+    bit (except the loss backward's float atomics: allclose on the parameters)."""
+    from gcl_amd import synthetic
+    from gcl_amd.lib.colocation_trainer import FinestContrastiveLossTrainer, make_config, prefetch_to_device
+    batches = [synthetic.collate_train([synthetic.make_train_sample(s, num_neighborhood=2, n_boxes=10)]) for s in (31, 32, 33)]
+    keys = ("sinput_C", "sinput_F", "group", "index", "finest_flag")
+    host = [{k: v for k, v in b.items() if k in keys} for b in batches]
+    cfg = make_config(batch_size=1, num_pos_per_batch=64, num_hn_samples_per_batch=128)
+    runs = []
+    for prefetch in (False, True):
+        torch.manual_seed(3)
+        np.random.seed(3)
+        tr = FinestContrastiveLossTrainer(cfg, device=DEV)
+        tr.map_prefetch = prefetch
+        seq = [host[i % 3] for i in range(5)]
+        losses = [l.item() for l, _, _ in tr.train_steps(prefetch_to_device(seq, DEV, keys))]
+        torch.cuda.synchronize()
+        runs.append((losses, torch.cat([p.detach().reshape(-1) for p in tr.model.parameters()]).cpu()))
+    assert runs[0][0][0] == runs[1][0][0], "first step (identical parameters): identical loss"
+    assert np.allclose(runs[0][0], runs[1][0], rtol=1e-5) and torch.allclose(runs[0][1], runs[1][1], rtol=1e-4, atol=1e-6)
