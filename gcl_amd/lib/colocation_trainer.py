@@ -367,14 +367,12 @@ class FinestContrastiveLossTrainer:
                                cfg.num_pos_per_batch * cfg.batch_size, cfg.num_hn_samples_per_batch * cfg.batch_size,
                                sizes, cfg.use_pair_group_positive_loss)
 
-    def _prepare(self, batch):
-        """Loader-side work for a coming batch, run by train_steps' helper thread while the previous step is being
-        enqueued: the host draws (native, outside the interpreter lock) and -- for batches that are already on the
-        device -- the coordinate manager with every kernel map, sorted table and pair list of the network, built on a
-        low-priority SIDE stream (CoordinateManager.prefetch).  The maps depend on the coordinates only; building them
-        ahead removes the level-size read-back (the one host sync of a step) and ~150 small launches from the training
-        stream, whose gaps they fill instead."""
-        draws = self._draw_for(batch)
+    def _prefetch_maps(self, batch):
+        """Loader-side work for a coming batch that is already on the device: its coordinate manager with every kernel
+        map, sorted table and pair list of the network, built on a low-priority SIDE stream (CoordinateManager.prefetch)
+        by a helper thread while the previous step is being enqueued.  The maps depend on the coordinates only; building
+        them ahead removes the level-size read-back (the one host sync of a step) and ~150 small launches from the
+        training stream, whose gaps they fill instead.  Returns the batch (a copy carrying the manager) to train on."""
         C = batch.get("sinput_C") if isinstance(batch, dict) else None
         if isinstance(batch, dict) and "_coordinate_manager" in batch:       # a stale manager of an earlier pass
             batch = {k: v for k, v in batch.items() if k not in ("_coordinate_manager", "_maps_event")}
@@ -393,14 +391,15 @@ class FinestContrastiveLossTrainer:
                     done.record(self._side)
             batch = dict(batch)               # never mutate the caller's dict (it may be fed again)
             batch["_coordinate_manager"], batch["_maps_event"] = mgr, done
-        return draws, batch
+        return batch
 
     def train_steps(self, batches):
         """The epoch loop (``_train_epoch`` :811-916): yields train_step(...) for every optimizer step, i.e. for every
         ``config.iter_size`` consecutive batches (:838, a trailing incomplete group is dropped like ``len // iter_size``).
-        The ``np.random`` draws of step i+1 (two permutations of all N rows per batch: several ms of host time) are made
-        by a helper thread while step i is being enqueued; every draw is still made after the previous batch's, so the
-        random stream is consumed in the same order as by a serial loop."""
+        Two helper threads work one step ahead of the step being enqueued: one makes the ``np.random`` draws of the next
+        step (two permutations of all N rows per batch: ~12 ms of native code outside the interpreter lock; every draw
+        still after the previous batch's, so the random stream is consumed in the order of a serial loop), the other
+        builds the next batches' coordinate maps on a side stream (``_prefetch_maps``)."""
         from concurrent.futures import ThreadPoolExecutor
         it = iter(batches)
         k = max(1, int(getattr(self.config, "iter_size", 1)))
@@ -414,19 +413,21 @@ class FinestContrastiveLossTrainer:
             return None
 
         def draw(grp):
-            return [self._prepare(b) for b in grp]
+            return [self._draw_for(b) for b in grp]
+
+        def maps(grp):
+            return [self._prefetch_maps(b) for b in grp]
 
         cur = take()
         if cur is None:
             return
-        with ThreadPoolExecutor(max_workers=1) as pool:
-            fut = pool.submit(draw, cur)
+        with ThreadPoolExecutor(max_workers=1) as draw_pool, ThreadPoolExecutor(max_workers=1) as map_pool:
+            fd, fm = draw_pool.submit(draw, cur), map_pool.submit(maps, cur)
             while cur is not None:
-                prep = fut.result()                      # [(draws, batch with its prefetched maps)]
-                draws, cur = [p[0] for p in prep], [p[1] for p in prep]
+                draws, cur = fd.result(), fm.result()
                 nxt = take()
                 if nxt is not None:
-                    fut = pool.submit(draw, nxt)
+                    fd, fm = draw_pool.submit(draw, nxt), map_pool.submit(maps, nxt)
                 yield self.train_step(cur if k > 1 else cur[0], draws if k > 1 else draws[0])
                 cur = nxt
 

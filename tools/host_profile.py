@@ -12,17 +12,19 @@ import torch
 from gcl_amd import synthetic
 from gcl_amd.lib.colocation_trainer import FinestContrastiveLossTrainer, make_config
 
-batch = synthetic.make_train_batch(100, batch_size=4, group_mode="fixed16")
+from gcl_amd.lib.colocation_trainer import prefetch_to_device
+keys = ("sinput_C", "sinput_F", "group", "index", "finest_flag")
+batches = [synthetic.make_train_batch(100 + 1000 * j, batch_size=4, group_mode="fixed16") for j in range(2)]
 dev = torch.device("cuda:0")
-dbatch = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in batch.items() if k != "index_hash"}
+torch.cuda.set_device(dev)
+host = [{k: v.pin_memory() for k, v in b.items() if k in keys} for b in batches]
 tr = FinestContrastiveLossTrainer(make_config(), device=dev)
-for _ in range(3):
-    tr.train_step(dbatch)
+for _ in tr.train_steps(prefetch_to_device([host[i % 2] for i in range(4)], dev, keys)):
+    pass
 torch.cuda.synchronize()
 pr = cProfile.Profile()
 pr.enable()
-import itertools
-for _ in tr.train_steps(itertools.repeat(dbatch, 10)):
+for _ in tr.train_steps(prefetch_to_device([host[i % 2] for i in range(10)], dev, keys)):
     pass
 pr.disable()
 torch.cuda.synchronize()
