@@ -13,6 +13,7 @@ import shutil
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
+n_steps_arg = int(sys.argv[2]) if len(sys.argv) > 2 else 5          # steps + warm-up of the profiled command
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 
@@ -22,10 +23,10 @@ def short(name):
     return re.sub(r"^void ", "", n).replace("gcl::", "").replace(" ", "")
 
 
-ks = glob.glob(os.path.join(G, "prof_final", "*", "*_kernel_stats.csv"))[0]
+ks = (glob.glob(os.path.join(G, "prof_final", "*", "*_kernel_stats.csv")) + glob.glob(os.path.join(G, "prof_final", "*_kernel_stats.csv")))[0]
 shutil.copy(ks, os.path.join(P, f"{tag}_kernel_stats.csv"))
 rows = list(csv.DictReader(open(ks)))
-n_steps = 5          # bench.py --steps 4 --warmup 1
+n_steps = n_steps_arg
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 with open(os.path.join(P, f"{tag}_kernel_stats_summary.txt"), "w") as fh:
     fh.write("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-kernel-events\n")
@@ -37,7 +38,8 @@ with open(os.path.join(P, f"{tag}_kernel_stats_summary.txt"), "w") as fh:
 
 def load(path):
     d = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(glob.glob(path)[0])):
+    hits = glob.glob(path) + glob.glob(path.replace(os.sep + "*" + os.sep, os.sep))
+    for r in csv.DictReader(open(hits[0])):
         d[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return d
 
@@ -66,6 +68,11 @@ for n in fe:
         w = sum(wr[n]["WRITE_SIZE"]) / len(wr[n]["WRITE_SIZE"]) if n in wr else 0.0
         out[n] = {"launches": len(fe[n]["FETCH_SIZE"]), "fetch_size_kb_avg": round(f, 1), "write_size_kb_avg": round(w, 1),
                   "hbm_bytes_per_launch": round((2 * f + w) * 1024)}
+        avg_ns = {short(r["Name"]): float(r["AverageNs"]) for r in rows}.get(n)
+        if n in sq and avg_ns and sum(sq[n]["SQ_VALU_MFMA_BUSY_CYCLES"]) > 0:
+            # MFMA pipe busy share: busy cycles per dispatch and SIMD (1024 SIMDs) over the launch duration at 2.4 GHz
+            per = sum(sq[n]["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(sq[n]["SQ_VALU_MFMA_BUSY_CYCLES"]) / 1024.0
+            out[n]["mfma_busy"] = round(per / (avg_ns * 2.4), 4)
 json.dump(out, open(os.path.join(P, "pmc_summary.json"), "w"), indent=1)
 print(open(os.path.join(P, f"{tag}_kernel_stats_summary.txt")).read())
 print(open(os.path.join(P, f"{tag}_pmc_sq.txt")).read()[:2500])
