@@ -66,6 +66,7 @@ SIGNATURES = {
     "gcl_bn_bwd_apply": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "gcl_row_normalize_fwd": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
     "gcl_row_normalize_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "gcl_sgd_multi": (_i32, [_vp, _vp, _i32, _f32, _f32, _f32, _i32, _vp]),
     "gcl_sc2_chunks": (_i32, []),
     "gcl_sc2_refine_partial_len": (_i32, []),
     "gcl_sc2_confidence": (_i32, [_vp, _vp, _i32, _f32, _i32, _vp, _vp, _vp, _vp]),

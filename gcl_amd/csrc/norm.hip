@@ -307,6 +307,25 @@ __global__ void __launch_bounds__(256) k_row_normalize(const float* __restrict__
   reinterpret_cast<float4*>(out)[e] = o4;
 }
 
+// ---- SGD with momentum and weight decay over a LIST of tensors in one launch ---------------------------------------
+// torch.optim.SGD's update (lib/colocation_trainer.py:73-77: lr, momentum, weight_decay; dampening 0, no Nesterov):
+//   d = g + wd * p;   buf = first ? d : momentum * buf + d;   p -= lr * buf
+// table[t] = {p, g, buf} device pointers, sizes[t] elements; grid = (chunks, tensors).  Replaces the 7 multi-tensor
+// launches of torch's foreach implementation (and its ~0.6 ms of host time) per optimizer step.
+struct SgdPtrs { float* p; const float* g; float* buf; };
+__global__ void __launch_bounds__(256) k_sgd_multi(const SgdPtrs* __restrict__ table, const long long* __restrict__ sizes,
+                                                   float lr, float momentum, float wd, int first) {
+  const SgdPtrs t = table[blockIdx.y];
+  const long long n = sizes[blockIdx.y];
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+    const float p = t.p[e];
+    const float d = t.g[e] + wd * p;
+    const float b = first ? d : momentum * t.buf[e] + d;
+    t.buf[e] = b;
+    t.p[e] = p - lr * b;
+  }
+}
+
 static bool bn_c_ok(int c) { return c >= 4 && c % 4 == 0 && (256 % (c / 4)) == 0; }
 
 }  // namespace gcl
@@ -417,6 +436,15 @@ int gcl_row_normalize_bwd(const float* y, const float* dy, const float* norm, in
   long long total = n * (c / 4);
   hipLaunchKernelGGL(k_row_normalize<true>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, y, dy,
                      norm, (long long)n, c, dx, (float*)nullptr);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int gcl_sgd_multi(const void* table, const int64_t* sizes, int32_t n_tensors, float lr, float momentum,
+                  float weight_decay, int32_t first, void* stream) {
+  GCL_CHECK_ARG(table && sizes && n_tensors > 0 && n_tensors <= 65535, "gcl_sgd_multi: bad argument");
+  hipLaunchKernelGGL(k_sgd_multi, dim3(64, (unsigned)n_tensors), dim3(256), 0, (hipStream_t)stream,
+                     (const SgdPtrs*)table, (const long long*)sizes, lr, momentum, weight_decay, first);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }

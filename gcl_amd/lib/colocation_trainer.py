@@ -142,10 +142,22 @@ def draw_selections(n_groups, n_out, max_pos_cluster, max_hn_samples, group_size
     return pos_sel, sel_hn1, sel_hn2, pair_pos
 
 
+def prepare_loss_inputs(group, index, finest_flag, device):
+    """(goff, index, flag) on the device in the layouts the loss kernels read: exclusive group offsets int64 [G + 1],
+    member rows int64, finest flags uint8.  ``train_steps`` computes them for the next batch on the side stream."""
+    group = torch.as_tensor(group)
+    goff = torch.zeros(int(group.shape[0]) + 1, dtype=torch.int64, device=device)       # no host sync when group is on the GPU
+    goff[1:] = torch.cumsum(group.to(device, torch.int64, non_blocking=True), 0)
+    index = torch.as_tensor(index).to(device, torch.int64, non_blocking=True).contiguous()
+    flag = torch.as_tensor(finest_flag).to(device, non_blocking=True).to(torch.uint8).contiguous()
+    return goff, index, flag
+
+
 def finest_contrastive_loss(F_out, group, index, index_hash, finest_flag, max_pos_cluster=256, max_hn_samples=2048,
                             points=None, batch_lengths=None, pos_thresh=0.1, neg_thresh=1.4, finest_thresh=0.2,
                             draws=None, square_loss=True, block_finest_gradient=False,
-                            use_pair_group_positive_loss=False, use_hard_negative=True, finest_term=True):
+                            use_pair_group_positive_loss=False, use_hard_negative=True, finest_term=True,
+                            prepared=None):
     """(pos_loss, finest_loss, neg_loss) of lib/colocation_trainer.py:430-535 with its four config switches
     (defaults = scripts/train_gcl_kitti.sh:96-105).  ``finest_term=False`` gives ``location_contrastive_loss``
     (:734-809) when combined with ``square_loss=False``.
@@ -174,16 +186,15 @@ def finest_contrastive_loss(F_out, group, index, index_hash, finest_flag, max_po
         raise ZeroDivisionError("no positive group in the batch")
     flags = (0 if square_loss else LOSS_SQRT) | (LOSS_BLOCK if block_finest_gradient else 0) | \
             (LOSS_PAIR if use_pair_group_positive_loss else 0) | (0 if finest_term else LOSS_NOFIN)
-    goff = torch.zeros(n_groups + 1, dtype=torch.int64, device=dev)       # no host sync when group is on the GPU
-    goff[1:] = torch.cumsum(group.to(dev, torch.int64, non_blocking=True), 0)
-    index = torch.as_tensor(index).to(dev, torch.int64, non_blocking=True).contiguous()
-    flag = torch.as_tensor(finest_flag).to(dev, non_blocking=True).to(torch.uint8).contiguous()
-    to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64)).to(dev, non_blocking=True)
+    goff, index, flag = prepared if prepared is not None else prepare_loss_inputs(group, index, finest_flag, dev)
     to_dev32 = lambda a: None if a is None else \
         torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev, non_blocking=True)
-    pos, fin, neg = _GCLLossFn.apply(F_out, index, goff, flag, to_dev(pos_sel), to_dev(sel_hn1), to_dev(sel_hn2),
-                                     float(pos_thresh), float(finest_thresh), float(neg_thresh), flags,
-                                     to_dev32(pair_pos) if use_pair_group_positive_loss else None)
+    n_pos, n_hn = len(pos_sel), len(sel_hn1)                   # the three selections travel in ONE host -> device copy
+    sel_all = torch.from_numpy(np.concatenate([np.asarray(pos_sel, dtype=np.int64), np.asarray(sel_hn1, dtype=np.int64),
+                                               np.asarray(sel_hn2, dtype=np.int64)])).to(dev, non_blocking=True)
+    pos, fin, neg = _GCLLossFn.apply(F_out, index, goff, flag, sel_all[:n_pos], sel_all[n_pos:n_pos + n_hn],
+                                     sel_all[n_pos + n_hn:], float(pos_thresh), float(finest_thresh), float(neg_thresh),
+                                     flags, to_dev32(pair_pos) if use_pair_group_positive_loss else None)
     return pos.sum() / len(pos_sel), fin.sum() / len(pos_sel), neg
 
 
@@ -315,15 +326,20 @@ class FinestContrastiveLossTrainer:
         if ddp is not None:
             ddp.attach(self.model)          # flat parameter/gradient buffers + initial broadcast
         # lib/colocation_trainer.py:73-77: SGD(lr, momentum, weight_decay), dampening left at its default
-        self.optimizer = torch.optim.SGD(self.model.parameters(), lr=cfg.lr, momentum=cfg.momentum,
-                                         weight_decay=cfg.weight_decay)
+        if os.environ.get("GCL_FUSED_SGD", "1") == "1":          # same update, one launch (gcl_amd/lib/optim.py)
+            from gcl_amd.lib.optim import FusedSGD
+            self.optimizer = FusedSGD(self.model.parameters(), lr=cfg.lr, momentum=cfg.momentum,
+                                      weight_decay=cfg.weight_decay)
+        else:
+            self.optimizer = torch.optim.SGD(self.model.parameters(), lr=cfg.lr, momentum=cfg.momentum,
+                                             weight_decay=cfg.weight_decay)
         self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, cfg.exp_gamma)
         self.pos_weight, self.neg_weight, self.finest_weight = cfg.pos_weight, cfg.neg_weight, cfg.finest_weight
         self.map_prefetch = os.environ.get("GCL_MAP_PREFETCH", "1") == "1"
         self._side = None
 
     def location_loss(self, F_out, group, index, index_hash, finest_flag, max_pos_cluster, max_hn_samples,
-                      points=None, batch_lengths=None, draws=None):
+                      points=None, batch_lengths=None, draws=None, prepared=None):
         cfg = self.config
         if cfg.use_group_circle_loss:         # lib/colocation_trainer.py:423-424
             return location_circle_loss(F_out, group, index, index_hash, finest_flag, max_pos_cluster, max_hn_samples,
@@ -337,7 +353,7 @@ class FinestContrastiveLossTrainer:
         return finest_contrastive_loss(F_out, group, index, index_hash, finest_flag, max_pos_cluster, max_hn_samples,
                                        points, batch_lengths, cfg.pos_thresh, cfg.neg_thresh, cfg.finest_thresh, draws,
                                        cfg.square_loss, cfg.block_finest_gradient, cfg.use_pair_group_positive_loss,
-                                       cfg.use_hard_negative)
+                                       cfg.use_hard_negative, prepared=prepared)
 
     def forward_loss(self, input_dict, draws=None):
         cfg = self.config
@@ -350,7 +366,7 @@ class FinestContrastiveLossTrainer:
             max_pos_cluster=cfg.num_pos_per_batch * cfg.batch_size,
             max_hn_samples=cfg.num_hn_samples_per_batch * cfg.batch_size,
             points=input_dict["sinput_C"][:, 1:] if cfg.use_group_circle_loss else None,
-            batch_lengths=input_dict.get("batch_lengths"), draws=draws)
+            batch_lengths=input_dict.get("batch_lengths"), draws=draws, prepared=input_dict.get("_loss_inputs"))
         loss = self.pos_weight * pos + self.finest_weight * fin + self.neg_weight * neg
         return loss, (pos, fin, neg), F_out
 
@@ -375,7 +391,7 @@ class FinestContrastiveLossTrainer:
         training stream, whose gaps they fill instead.  Returns the batch (a copy carrying the manager) to train on."""
         C = batch.get("sinput_C") if isinstance(batch, dict) else None
         if isinstance(batch, dict) and "_coordinate_manager" in batch:       # a stale manager of an earlier pass
-            batch = {k: v for k, v in batch.items() if k not in ("_coordinate_manager", "_maps_event")}
+            batch = {k: v for k, v in batch.items() if k not in ("_coordinate_manager", "_maps_event", "_loss_inputs")}
         specs = getattr(getattr(self, "model", None), "map_specs", None)
         if getattr(self, "map_prefetch", False) and specs is not None and isinstance(C, torch.Tensor) and C.is_cuda:
             with torch.cuda.device(self.device):
@@ -387,10 +403,11 @@ class FinestContrastiveLossTrainer:
                     if ev is not None:
                         self._side.wait_event(ev)
                     mgr = ME.CoordinateManager(C).prefetch(specs())
+                    prep = prepare_loss_inputs(batch["group"], batch["index"], batch["finest_flag"], self.device)
                     done = torch.cuda.Event()
                     done.record(self._side)
             batch = dict(batch)               # never mutate the caller's dict (it may be fed again)
-            batch["_coordinate_manager"], batch["_maps_event"] = mgr, done
+            batch["_coordinate_manager"], batch["_maps_event"], batch["_loss_inputs"] = mgr, done, prep
         return batch
 
     def train_steps(self, batches):
@@ -509,5 +526,5 @@ def wait_for_batch(batch):
                 v.record_stream(cur)          # allocated on the copy stream, consumed on the compute stream
     if mev is not None:                       # coordinate manager prefetched on the side stream
         cur.wait_event(mev)
-        for t in batch["_coordinate_manager"].device_tensors():
+        for t in batch["_coordinate_manager"].device_tensors() + list(batch.get("_loss_inputs") or ()):
             t.record_stream(cur)

@@ -282,6 +282,12 @@ int gcl_row_normalize_fwd(const float* x, int64_t n, int32_t c, float* y, float*
 int gcl_row_normalize_bwd(const float* y, const float* dy, const float* norm, int64_t n, int32_t c, float* dx,
                           void* stream);
 
+/* torch.optim.SGD's step (lib/colocation_trainer.py:73-77, :887: lr, momentum, weight_decay; dampening 0, no Nesterov)
+ * for a list of tensors in ONE launch:  d = g + wd p;  buf = first ? d : momentum buf + d;  p -= lr buf.
+ * table: DEVICE array of n_tensors x {float* p, const float* g, float* buf}; sizes: DEVICE int64[n_tensors]. */
+int gcl_sgd_multi(const void* table, const int64_t* sizes, int32_t n_tensors, float lr, float momentum,
+                  float weight_decay, int32_t first, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * GCL loss (lib/colocation_trainer.py:430-535) and feature-space 1-NN.
  *   group g = rows index[goff[g] .. goff[g+1]) of F [n, c] (c <= 64); sel[s] = selected group ids.

@@ -445,3 +445,26 @@ def test_map_prefetch_on_side_stream_changes_nothing():
         runs.append((losses, torch.cat([p.detach().reshape(-1) for p in tr.model.parameters()]).cpu()))
     assert runs[0][0] == runs[1][0], "identical losses, step by step (steps 2.. run on maps built on the side stream)"
     assert torch.equal(runs[0][1], runs[1][1]) and len(set(runs[0][0])) >= 3
+
+
+def test_fused_sgd_equals_torch_sgd():
+    """gcl_amd.lib.optim.FusedSGD (one launch, gcl_sgd_multi) against torch.optim.SGD with the reference's settings
+    (lr 0.1, momentum 0.8, weight decay 1e-4; lib/colocation_trainer.py:73-77) over three steps with an ExponentialLR."""
+    from gcl_amd.lib.optim import FusedSGD
+    g = torch.Generator().manual_seed(0)
+    shapes = [(27, 64, 64), (64,), (1, 32), (125, 1, 32), (7,)]
+    init = [torch.randn(s, generator=g) for s in shapes]
+    res = []
+    for cls in (torch.optim.SGD, FusedSGD):
+        ps = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+        opt = cls(ps, lr=0.1, momentum=0.8, weight_decay=1e-4)
+        sch = torch.optim.lr_scheduler.ExponentialLR(opt, 0.99)
+        gg = torch.Generator().manual_seed(1)
+        for _ in range(3):
+            for p in ps:
+                p.grad = torch.randn(p.shape, generator=gg).to(DEV)
+            opt.step()
+            sch.step()
+        res.append(([p.detach().cpu() for p in ps], [opt.state[p]["momentum_buffer"].cpu() for p in ps]))
+    for a, b in zip(res[0][0] + res[0][1], res[1][0] + res[1][1]):
+        assert torch.allclose(a, b, rtol=2e-6, atol=1e-7)
