@@ -31,6 +31,8 @@ __all__ = ["SparseTensor", "CoordinateManager", "CoordinateMapKey", "MinkowskiCo
 
 # tuning knob: let convolutions emit the column sums a following BatchNorm needs (saves its statistics pass)
 FUSED_BN_STATS = os.environ.get("GCL_FUSED_BN_STATS", "1") == "1"
+# training: convolution + BatchNorm of ME.conv_bn as one autograd node (same launches, less host work per layer)
+FUSED_CONV_BN_NODE = os.environ.get("GCL_FUSED_CONV_BN_NODE", "1") == "1"
 
 
 class MinkowskiNetwork(nn.Module):
@@ -194,6 +196,21 @@ def conv_bn(conv, norm, x, residual=None, relu=False):
     fused = (not conv.training and not norm.training and not torch.is_grad_enabled()
              and isinstance(norm, MinkowskiBatchNorm) and conv.bias is None and conv.in_channels > 4
              and ops.PRECISION == "fp16x3")
+    if (not fused and FUSED_CONV_BN_NODE and conv.training and norm.training and isinstance(norm, MinkowskiBatchNorm)
+            and conv.bias is None and torch.is_grad_enabled()):
+        # training: the same launches as norm(conv(x)) behind ONE autograd node (ops._ConvBNFn)
+        mgr, t_out, kmap, n_out = conv._maps(x)
+        if residual is not None and residual.coordinate_map_key.tensor_stride != t_out:
+            raise ValueError("residual lives on a different coordinate map")
+        bn = norm.bn
+        F = ops.conv_bn_train(x.F, conv.kernel, kmap, n_out, conv.TRANSPOSE, mgr, bn.weight, bn.bias, bn.running_mean,
+                              bn.running_var, bn.momentum, bn.eps, residual.F if residual is not None else None,
+                              bool(relu), FUSED_BN_STATS and conv.in_channels > 4)
+        norm._pending_batches += 1
+        norm._train_forwards += 1
+        out = SparseTensor(F, coordinate_map_key=CoordinateMapKey(t_out), coordinate_manager=mgr)
+        out._nonneg = bool(relu)
+        return out
     if not fused:
         return norm(conv(x), residual=residual, relu=relu)
     mgr, t_out, kmap, n_out = conv._maps(x)

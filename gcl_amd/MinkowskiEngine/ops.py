@@ -398,8 +398,8 @@ class _BatchNormFn(torch.autograd.Function):
         n, c = x.shape
         dev = x.device
         if training:
-            mean = torch.empty(c, dtype=torch.float32, device=dev)
-            rstd = torch.empty(c, dtype=torch.float32, device=dev)
+            mr = torch.empty((2, c), dtype=torch.float32, device=dev)          # one allocation: mean | rstd
+            mean, rstd = mr[0], mr[1]
             if tile_stats is not None:      # column sums already produced by the convolution epilogue
                 nt = tile_stats.shape[0]
                 scratch = torch.empty(lib.gcl_bn_tiles_scratch_len(nt, c), dtype=torch.float64, device=dev)
@@ -436,8 +436,8 @@ class _BatchNormFn(torch.autograd.Function):
         n, c = x.shape
         dev = x.device
         dy = dy.contiguous()
-        sum_g = torch.empty(c, dtype=torch.float32, device=dev)
-        sum_gx = torch.empty(c, dtype=torch.float32, device=dev)
+        sums = torch.empty((2, c), dtype=torch.float32, device=dev)           # one allocation: sum_g | sum_gx
+        sum_g, sum_gx = sums[0], sums[1]
         scratch = torch.empty(lib.gcl_bn_scratch_len(n, c), dtype=torch.float64, device=dev)
         _lib.check(lib.gcl_bn_bwd_reduce(_lib.ptr(x), _lib.ptr(dy), None, _lib.ptr(mask), n, c, _lib.ptr(mean), _lib.ptr(rstd),
                                          int(ctx.relu), _lib.ptr(scratch), _lib.ptr(sum_g), _lib.ptr(sum_gx),
@@ -465,6 +465,57 @@ def batch_norm(x, weight, bias, running_mean, running_var, training, momentum, e
     if _LAST_BN_AMAX is not None:
         tag_amax(y, _LAST_BN_AMAX)
     return y
+
+
+class _SubCtx:
+    """Stand-in for an autograd ctx when one Function runs the forward / backward of another as a sub-step."""
+    needs_input_grad = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+    def set_materialize_grads(self, value):
+        pass
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+
+class _ConvBNFn(torch.autograd.Function):
+    """``norm(conv(x))`` (+ residual)(+ ReLU) of a bias-free convolution and a BatchNorm as ONE autograd node: the same
+    kernel launches as _SparseConvFn followed by _BatchNormFn (their forward / backward bodies are run as sub-steps),
+    half the autograd nodes and wrapper objects per layer -- the training step is bound by the host on slower hosts."""
+
+    @staticmethod
+    def forward(ctx, x, W, bn_w, bn_b, residual, running_mean, running_var, kmap, n_out, transpose, mgr, momentum, eps,
+                relu, want_stats):
+        c1, c2 = _SubCtx(), _SubCtx()
+        y, stats = _SparseConvFn.forward(c1, x, W, None, kmap, n_out, transpose, mgr, want_stats)
+        z = _BatchNormFn.forward(c2, y, bn_w, bn_b, running_mean, running_var, True, momentum, eps, residual, relu,
+                                 stats if stats.numel() else None)
+        ctx.c1, ctx.c2 = c1, c2
+        ctx.amax = _LAST_BN_AMAX
+        return z
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dz):
+        c1, c2 = ctx.c1, ctx.c2
+        g = _BatchNormFn.backward(c2, dz.contiguous())
+        dy, d_w, d_b, dres = g[0], g[1], g[2], g[8]
+        c1.needs_input_grad = (ctx.needs_input_grad[0], ctx.needs_input_grad[1], False)
+        dx, dW = _SparseConvFn.backward(c1, dy, None)[:2]
+        ctx.c1 = ctx.c2 = None
+        return dx, dW, d_w, d_b, dres, None, None, None, None, None, None, None, None, None, None
+
+
+def conv_bn_train(x, W, kmap, n_out, transpose, mgr, bn_w, bn_b, running_mean, running_var, momentum, eps, residual, relu,
+                  want_stats):
+    z = _ConvBNFn.apply(x, W, bn_w, bn_b, residual, running_mean, running_var, kmap, n_out, transpose, mgr, momentum, eps,
+                        relu, want_stats)
+    if _LAST_BN_AMAX is not None:
+        tag_amax(z, _LAST_BN_AMAX)
+    return z
 
 
 class _RowNormalizeFn(torch.autograd.Function):

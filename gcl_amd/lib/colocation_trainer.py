@@ -190,8 +190,10 @@ def finest_contrastive_loss(F_out, group, index, index_hash, finest_flag, max_po
     to_dev32 = lambda a: None if a is None else \
         torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev, non_blocking=True)
     n_pos, n_hn = len(pos_sel), len(sel_hn1)                   # the three selections travel in ONE host -> device copy
-    sel_all = torch.from_numpy(np.concatenate([np.asarray(pos_sel, dtype=np.int64), np.asarray(sel_hn1, dtype=np.int64),
-                                               np.asarray(sel_hn2, dtype=np.int64)])).to(dev, non_blocking=True)
+    sel_host = torch.empty(n_pos + 2 * n_hn, dtype=torch.int64, pin_memory=True)     # pinned: the copy is asynchronous
+    np.concatenate([np.asarray(pos_sel, dtype=np.int64), np.asarray(sel_hn1, dtype=np.int64),
+                    np.asarray(sel_hn2, dtype=np.int64)], out=sel_host.numpy())
+    sel_all = sel_host.to(dev, non_blocking=True)
     pos, fin, neg = _GCLLossFn.apply(F_out, index, goff, flag, sel_all[:n_pos], sel_all[n_pos:n_pos + n_hn],
                                      sel_all[n_pos + n_hn:], float(pos_thresh), float(finest_thresh), float(neg_thresh),
                                      flags, to_dev32(pair_pos) if use_pair_group_positive_loss else None)
@@ -335,6 +337,7 @@ class FinestContrastiveLossTrainer:
                                              weight_decay=cfg.weight_decay)
         self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, cfg.exp_gamma)
         self.pos_weight, self.neg_weight, self.finest_weight = cfg.pos_weight, cfg.neg_weight, cfg.finest_weight
+        self._params = [p for p in self.model.parameters()]
         self.map_prefetch = os.environ.get("GCL_MAP_PREFETCH", "1") == "1"
         self._side = None
 
@@ -466,7 +469,11 @@ class FinestContrastiveLossTrainer:
         if self.ddp is not None:
             self.ddp.flat_grad.zero_()                     # one memset; gradients stay seated in the flat buffer
         else:
-            self.optimizer.zero_grad(set_to_none=os.environ.get("GCL_ZERO_NONE", "1") == "1")   # assign, not 66 adds + fills
+            if os.environ.get("GCL_ZERO_NONE", "1") == "1":     # gradients are assigned, not accumulated into zeros
+                for p in self._params:
+                    p.grad = None
+            else:
+                self.optimizer.zero_grad(set_to_none=False)
         tot_loss, tot_parts, n_rows = None, None, 0
         for i, (b, d) in enumerate(zip(micro, mdraws)):
             if self.ddp is not None:
