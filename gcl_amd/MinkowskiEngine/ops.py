@@ -223,7 +223,7 @@ def _conv_launch(lib, x, Wk, mode, table, n_out, cin, cout, bias, pairs=0, want_
     """One output-stationary convolution launch.  ``Wk`` [K, *, *] is packed for ``mode`` (0 forward, 1 transposed,
     2 transposed + mirrored offsets) in the current precision; ``table`` = (tbl, order, tile_mask) from
     KernelMap.sorted_table(), or None for a kernel_size-1 conv; (cin, cout) are the EFFECTIVE widths of the launch.
-    ``want_stats``: also return the per-tile column sums [ceil(n_out/32), 2, cout] for a following BatchNorm."""
+    ``want_stats``: also return the per-workgroup column sums [ceil(n_out/128), 2, cout] for a following BatchNorm."""
     prec = _PREC_CODES[PRECISION]
     K, wc_in, wc_out = Wk.shape
     if prec == 4 and not generic:
@@ -237,7 +237,7 @@ def _conv_launch(lib, x, Wk, mode, table, n_out, cin, cout, bias, pairs=0, want_
     y = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
     stats = None
     if want_stats and prec != 0:
-        stats = torch.empty(((n_out + 31) // 32, 2, cout), dtype=torch.float32, device=x.device)
+        stats = torch.empty(((n_out + 127) // 128, 2, cout), dtype=torch.float32, device=x.device)
     name = None
     if PROFILE is not None:
         nb = lib.gcl_conv_fwd_nb(n_out, cout, prec)

@@ -656,10 +656,13 @@ __global__ void __launch_bounds__(256, GCL_FWD_MIN_WAVES(NB, PL)) k_conv_fwd_spl
 #undef GCL_LOAD_B
 #undef GCL_STORE_LDS
 #undef GCL_ADVANCE
-  if (!active) return;
+  if (!active && !stats) return;
   int orow_l = -1;
-  if ((l < 32) && (row0 + l < n_out)) orow_l = order ? order[row0 + l] : (int)(row0 + l);
+  if (active && (l < 32) && (row0 + l < n_out)) orow_l = order ? order[row0 + l] : (int)(row0 + l);
   float ymax = 0.f;
+  // column sums of this wave's 32 rows go to its own (now idle) A tile; wave 0 adds the four waves in order and writes
+  // ONE partial per workgroup (128 rows) for the BatchNorm that follows (saves its statistics pass over Y)
+  float* const ssc = &Asm[w][0][0];   // wave w's tile; tiles are 32 x 32 floats apart
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     const int col = (nb0 + b) * 32 + i;
@@ -682,14 +685,33 @@ __global__ void __launch_bounds__(256, GCL_FWD_MIN_WAVES(NB, PL)) k_conv_fwd_spl
         if (EPI) ymax = fmaxf(ymax, fabsf(v));
       }
     }
-    if (stats) {   // per-tile column sums for the BatchNorm that follows (saves its statistics pass over Y)
+    if (stats) {
       s1 += __shfl_xor(s1, 32);
       s2 += __shfl_xor(s2, 32);
       if (h == 0) {
-        stats[(tile * 2 + 0) * cout + col] = s1;
-        stats[(tile * 2 + 1) * cout + col] = s2;
+        ssc[b * 32 + i] = s1;
+        ssc[NB * 32 + b * 32 + i] = s2;
       }
     }
+  }
+  if (stats) {
+    __syncthreads();
+    if (w == 0 && h == 0) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int col = (nb0 + b) * 32 + i;
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {
+          const float* o = ssc + ww * (32 * 32);
+          t1 += o[b * 32 + i];
+          t2 += o[NB * 32 + b * 32 + i];
+        }
+        stats[((long long)bxx * 2 + 0) * cout + col] = t1;
+        stats[((long long)bxx * 2 + 1) * cout + col] = t2;
+      }
+    }
+    if (!active) return;
   }
   if (EPI && epi.y_amax) {   // one publish per wave (launches of this path are small: inference on single clouds)
 #pragma unroll
@@ -893,15 +915,19 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split2(const float* __restrict
 #undef GCL2_LOAD_STEP
 #undef GCL2_STORE_STEP
   }
-  if (!active) return;
+  if (!active && !stats) return;
   int orow_l = -1;
-  if ((l < 32) && (row0 + l < n_out)) orow_l = order ? order[row0 + l] : (int)(row0 + l);
+  if (active && (l < 32) && (row0 + l < n_out)) orow_l = order ? order[row0 + l] : (int)(row0 + l);
   float ymax = 0.f;
+  // column sums of this wave's 32 rows go to its own (now idle) A tile; wave 0 adds the four waves in order and writes
+  // ONE partial per workgroup (128 rows) for the BatchNorm that follows (saves its statistics pass over Y)
+  float* const ssc = &Asm[w][0][0][0];
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     const int col = (nb0 + b) * 32 + i;
     float bvv = bias ? bias[col] : 0.f;
     float csc = (EPI && epi.col_scale) ? epi.col_scale[col] * out_scale : out_scale;
+    // consume the (conditional) loads HERE: otherwise every store below waits for all earlier stores (vmcnt(0))
     asm volatile("v_mov_b32 %0, %1" : "=v"(bvv) : "v"(bvv));
     asm volatile("v_mov_b32 %0, %1" : "=v"(csc) : "v"(csc));
     float s1 = 0.f, s2 = 0.f;
@@ -922,10 +948,29 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split2(const float* __restrict
       s1 += __shfl_xor(s1, 32);
       s2 += __shfl_xor(s2, 32);
       if (h == 0) {
-        stats[(tile * 2 + 0) * cout + col] = s1;
-        stats[(tile * 2 + 1) * cout + col] = s2;
+        ssc[b * 32 + i] = s1;
+        ssc[NB * 32 + b * 32 + i] = s2;
       }
     }
+  }
+  if (stats) {
+    __syncthreads();
+    if (w == 0 && h == 0) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int col = (nb0 + b) * 32 + i;
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {
+          const float* o = ssc + ww * (2 * 32 * 32);
+          t1 += o[b * 32 + i];
+          t2 += o[NB * 32 + b * 32 + i];
+        }
+        stats[((long long)bxx * 2 + 0) * cout + col] = t1;
+        stats[((long long)bxx * 2 + 1) * cout + col] = t2;
+      }
+    }
+    if (!active) return;
   }
   if (EPI && epi.y_amax) {
 #pragma unroll

@@ -157,6 +157,44 @@ __global__ void __launch_bounds__(256) k_bn_stats_final(const double* __restrict
   }
 }
 
+// One-launch finalisation straight from the convolution epilogue's fp32 partials [n_part][2][c] (one per 128-row
+// workgroup): 1024 threads = (channel t & 3, slice t >> 2); slice s adds partials s, s + 256, ... in fp64, the 256 slices
+// are then added in order (deterministic).  Used when there are at most BN_DIRECT_MAX partials (a 0.5 M-voxel level has
+// ~4 k); beyond that the two-stage path below keeps the per-thread chains short.
+constexpr int BN_DIRECT_MAX = 16384;
+__global__ void __launch_bounds__(1024) k_bn_stats_direct(const float* __restrict__ partial, int n_part, long long n, int c,
+                                                          float eps, float momentum, float* running_mean,
+                                                          float* running_var, float* mean, float* rstd) {
+  __shared__ double red[2][256][5];
+  const int cl = threadIdx.x & 3, sl = threadIdx.x >> 2;
+  const int ch = blockIdx.x * 4 + cl;
+  double a = 0, b = 0;
+  if (ch < c)
+    for (int w = sl; w < n_part; w += 256) {
+      a += (double)partial[(long long)w * 2 * c + ch];
+      b += (double)partial[(long long)w * 2 * c + c + ch];
+    }
+  red[0][sl][cl] = a;
+  red[1][sl][cl] = b;
+  __syncthreads();
+  if (sl != 0 || ch >= c) return;
+  double s = 0, ss = 0;
+  for (int q = 0; q < 256; ++q) {
+    s += red[0][q][cl];
+    ss += red[1][q][cl];
+  }
+  double m = s / (double)n;
+  double var = ss / (double)n - m * m;
+  if (var < 0) var = 0;
+  mean[ch] = (float)m;
+  rstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    double unb = (n > 1) ? var * (double)n / (double)(n - 1) : var;
+    running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * m);
+    running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unb);
+  }
+}
+
 // statistics from the per-tile column sums written by the convolution epilogue: partial [n_tiles][2][c] (fp32 sums of
 // <= 32 rows each).  Stage 1 adds 32 tiles per workgroup in fp64 (coalesced: thread = column), stage 2 is the
 // ordinary ordered finalisation over the per-workgroup partials.
@@ -360,6 +398,12 @@ int gcl_bn_stats_from_tiles(const float* partial, int64_t n_tiles, int64_t n, in
   GCL_CHECK_ARG(partial && scratch && mean && rstd, "gcl_bn_stats_from_tiles: null pointer");
   GCL_CHECK_ARG(n > 0 && n_tiles > 0 && c > 0, "gcl_bn_stats_from_tiles: bad sizes");
   hipStream_t st = (hipStream_t)stream;
+  if (n_tiles <= BN_DIRECT_MAX) {
+    hipLaunchKernelGGL(k_bn_stats_direct, dim3((unsigned)cdiv(c, 4)), dim3(1024), 0, st, partial, (int)n_tiles,
+                       (long long)n, c, eps, momentum, running_mean, running_var, mean, rstd);
+    GCL_CHECK_LAUNCH();
+    return GCL_OK;
+  }
   int nwg = (int)cdiv(n_tiles, BN_TILES_PER_WG);
   hipLaunchKernelGGL(k_bn_tiles_reduce, dim3(nwg), dim3(256), 0, st, partial, (long long)n_tiles, c, scratch);
   hipLaunchKernelGGL(k_bn_stats_final, dim3((unsigned)cdiv(c, 4)), dim3(256), 0, st, (const double*)scratch, nwg,
