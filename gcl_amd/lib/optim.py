@@ -43,12 +43,15 @@ class FusedSGD(torch.optim.SGD):
             for i, (p, b) in enumerate(zip(ps, bufs)):
                 ptrs[i, 0], ptrs[i, 1], ptrs[i, 2] = p.data_ptr(), p.grad.data_ptr(), b.data_ptr()
             key = (len(ps), dev)
-            if self._key != key:          # pinned staging + device tables, sizes never change
+            if self._key != key:          # element counts never change
                 self._key = key
-                self._pin = torch.empty((len(ps), 3), dtype=torch.int64, pin_memory=True)
                 self._sizes = torch.tensor([p.numel() for p in ps], dtype=torch.int64).to(dev)
-            self._pin.numpy()[:] = ptrs
-            table = self._pin.to(dev, non_blocking=True)       # gradients are fresh tensors every step: new pointers
+            # gradients are fresh tensors every step: new pointers.  A FRESH pinned staging tensor per step -- the copy is
+            # asynchronous and the host runs up to a step ahead of the GPU, so a re-used buffer would be overwritten
+            # before the previous step's copy has executed (torch's pinned allocator recycles a block only after that)
+            pin = torch.empty((len(ps), 3), dtype=torch.int64, pin_memory=True)
+            pin.numpy()[:] = ptrs
+            table = pin.to(dev, non_blocking=True)
             _lib.check(lib.gcl_sgd_multi(_lib.ptr(table), _lib.ptr(self._sizes), len(ps), float(group["lr"]),
                                          float(group["momentum"]), float(group["weight_decay"]), int(first),
                                          _lib.stream()), "gcl_sgd_multi")
