@@ -216,14 +216,27 @@ int gcl_colocation_emit(const int32_t* hits, const int32_t* cnt, const double* f
  * call and holds the interpreter lock while it shuffles, which stalls the thread that enqueues the GPU work.
  *   key[624], *pos: the generator state as returned by np.random.get_state() (updated in place: the caller hands it back
  *   with np.random.set_state, so the random stream continues exactly where numpy's own call would have left it);
- *   out[k] = the first k entries of the shuffled arange(n); work: int64[n] scratch.
+ *   out[k] = the first k entries of the shuffled arange(n); work: int64[n + n / 32 + 64] scratch.
  * Algorithm = numpy/random/mtrand.pyx (_shuffle_raw: for i = n-1 .. 1: j = random_interval(i); swap) with
  * distributions.c random_interval (smallest mask >= max, rejection on next_uint32 / next_uint64). */
 namespace {
 struct MT {
   uint32_t* key;
   int pos;
+  uint32_t out[624];      // tempered outputs of the current state block (filled in bulk: the loop vectorises)
+  bool fresh = false;
 };
+inline void mt_temper_block(MT& s) {
+  for (int i = 0; i < 624; ++i) {
+    uint32_t y = s.key[i];
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    s.out[i] = y;
+  }
+  s.fresh = true;
+}
 inline void mt_gen(uint32_t* mt) {
   const int N = 624, M = 397;
   const uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MAT = 0x9908b0dfu;
@@ -244,13 +257,10 @@ inline uint32_t mt_next32(MT& s) {
   if (s.pos == 624) {
     mt_gen(s.key);
     s.pos = 0;
+    s.fresh = false;
   }
-  uint32_t y = s.key[s.pos++];
-  y ^= (y >> 11);
-  y ^= (y << 7) & 0x9d2c5680u;
-  y ^= (y << 15) & 0xefc60000u;
-  y ^= (y >> 18);
-  return y;
+  if (!s.fresh) mt_temper_block(s);
+  return s.out[s.pos++];
 }
 inline uint64_t mt_interval(MT& s, uint64_t max) {
   if (max == 0) return 0;
@@ -272,17 +282,89 @@ inline uint64_t mt_interval(MT& s, uint64_t max) {
 int gcl_host_legacy_choice(uint32_t* key, int32_t* pos, int64_t n, int64_t k, int64_t* work, int64_t* out) {
   GCL_CHECK_ARG(key && pos && work && out, "gcl_host_legacy_choice: null pointer");
   GCL_CHECK_ARG(n >= 1 && k >= 0 && k <= n && *pos >= 0 && *pos <= 624, "gcl_host_legacy_choice: bad n / k / state");
-  MT s{key, *pos};
-  for (int64_t i = 0; i < n; ++i) work[i] = i;
-  for (int64_t i = n - 1; i >= 1; --i) {
-    const int64_t j = (int64_t)mt_interval(s, (uint64_t)i);
-    const int64_t t = work[j];
-    work[j] = work[i];
-    work[i] = t;
+  MT s;
+  s.key = key;
+  s.pos = *pos;
+  if (k * 8 > n || n < 4096) {            // dense selection: shuffle the whole array as numpy does
+    for (int64_t i = 0; i < n; ++i) work[i] = i;
+    for (int64_t i = n - 1; i >= 1; --i) {
+      const int64_t j = (int64_t)mt_interval(s, (uint64_t)i);
+      const int64_t t = work[j];
+      work[j] = work[i];
+      work[i] = t;
+    }
+    for (int64_t i = 0; i < k; ++i) out[i] = work[i];
+    *pos = s.pos;
+    return GCL_OK;
   }
-  for (int64_t i = 0; i < k; ++i) out[i] = work[i];
+  // Sparse selection (k << n): only the first k entries of the shuffled arange(n) are wanted.  The swap partners
+  // j_i (i = n-1 .. 1) are drawn in numpy's order -- the random stream is consumed exactly as by the full shuffle -- and
+  // kept as 32-bit numbers; then the swaps are UNDONE from the last one (i = 1) back to the first (i = n-1) for k
+  // tokens that start at the final positions 0 .. k-1: a token sitting on i moves to j_i and vice versa, and after the
+  // last undo its position is its value in arange(n).  A presence bitmap (n / 8 bytes, cache resident) answers "is a
+  // token on i or on j_i?" -- no for all but a few thousand of the n steps -- instead of 16 random bytes per step.
+  uint32_t* js = reinterpret_cast<uint32_t*>(work);                      // n entries
+  if (n > 0xffffffffll) {
+    for (int64_t i = n - 1; i >= 1; --i) js[i] = (uint32_t)mt_interval(s, (uint64_t)i);
+  } else {
+    // random_interval(i) for i = n-1 .. 1 without an unpredictable branch per draw: all i that share a mask are served
+    // from the tempered block in one loop -- every output is masked and stored to js[i], and i steps down only when
+    // the value was accepted (<= i); the outputs are consumed one by one exactly as numpy's rejection loop does
+    int64_t i = n - 1;
+    while (i >= 1) {
+      uint64_t mask = (uint64_t)i;
+      mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+      const int64_t lo = (int64_t)(mask >> 1) + 1;          // the smallest i with this mask
+      const uint32_t m32 = (uint32_t)mask;
+      while (i >= lo) {
+        if (s.pos == 624) {
+          mt_gen(s.key);
+          s.pos = 0;
+          s.fresh = false;
+        }
+        if (!s.fresh) mt_temper_block(s);
+        const uint32_t* o = s.out + s.pos;
+        const int avail = 624 - s.pos;
+        int c = 0;
+        for (; c < avail && i >= lo; ++c) {
+          const uint32_t v = o[c] & m32;
+          js[i] = v;
+          i -= (v <= (uint32_t)i) ? 1 : 0;
+        }
+        s.pos += c;
+      }
+    }
+  }
   *pos = s.pos;
-  return GCL_OK;
+  int32_t* tok = reinterpret_cast<int32_t*>(work + (n + 1) / 2 + 1);     // token on a position (valid where its bit is set)
+  uint64_t* bits = reinterpret_cast<uint64_t*>(work + 2 * ((n + 1) / 2 + 1));
+  const int64_t nw = (n + 63) / 64;
+  for (int64_t w = 0; w < nw; ++w) bits[w] = 0;
+  int64_t* where = out;                                                  // where[t] = current position of token t
+  for (int64_t t = 0; t < k; ++t) {
+    where[t] = t;
+    tok[t] = (int32_t)t;
+    bits[t >> 6] |= 1ull << (t & 63);
+  }
+  for (int64_t i = 1; i < n; ++i) {
+    const int64_t j = js[i];
+    const bool hi = (bits[i >> 6] >> (i & 63)) & 1ull, hj = (bits[j >> 6] >> (j & 63)) & 1ull;
+    if (!(hi | hj) || i == j) continue;
+    const int32_t ti = hi ? tok[i] : -1, tj = hj ? tok[j] : -1;
+    if (ti >= 0) {
+      where[ti] = j;
+      tok[j] = ti;
+    }
+    if (tj >= 0) {
+      where[tj] = i;
+      tok[i] = tj;
+    }
+    if (hi != hj) {                       // exactly one token moved: update the bitmap
+      bits[i >> 6] ^= 1ull << (i & 63);
+      bits[j >> 6] ^= 1ull << (j & 63);
+    }
+  }
+  return GCL_OK;                          // out[t] = where[t] = permutation(n)[t]
 }
 
 }  // extern "C"

@@ -116,7 +116,7 @@ def legacy_choice(n, k):
         return np.random.choice(n, k, replace=False)
     key = np.array(st[1], dtype=np.uint32, copy=True)
     pos = ctypes.c_int32(int(st[2]))
-    work, out = np.empty(n, np.int64), np.empty(k, np.int64)
+    work, out = np.empty(n + n // 32 + 64, np.int64), np.empty(k, np.int64)
     _lib.check(lib.gcl_host_legacy_choice(ctypes.c_void_p(key.ctypes.data), ctypes.byref(pos), n, k,
                                           ctypes.c_void_p(work.ctypes.data), ctypes.c_void_p(out.ctypes.data)),
                "gcl_host_legacy_choice")

@@ -103,7 +103,8 @@ int gcl_colocation_emit(const int32_t* hits, const int32_t* cnt, const double* f
  * permutation(n)[:k] -- the three draws of every training step (lib/colocation_trainer.py:457, :506-507) -- reproduced
  * bit for bit from the RandomState's MT19937 state (key[624], *pos as in np.random.get_state(); both updated in place so
  * that np.random.set_state continues the stream), outside the interpreter lock: numpy needs 8 ms per call at 0.5 M rows and
- * holds the lock meanwhile, which stalls the thread that enqueues the GPU work.  work: int64[n] scratch, out: int64[k]. */
+ * holds the lock meanwhile, which stalls the thread that enqueues the GPU work.  work: int64[n + n / 32 + 64] scratch,
+ * out: int64[k]. */
 int gcl_host_legacy_choice(uint32_t* key, int32_t* pos, int64_t n, int64_t k, int64_t* work, int64_t* out);
 
 /* Kernel map for kernel size ks^3 (x fastest in k), offsets scaled by `step` (= input tensor stride x dilation),

@@ -133,7 +133,8 @@ def test_native_legacy_choice_is_numpy_bit_for_bit():
     RandomState -- same indices AND the same stream position afterwards -- so that a seeded training run still draws
     what the reference draws (lib/colocation_trainer.py:457, :506-507)."""
     from gcl_amd.lib.colocation_trainer import draw_selections, legacy_choice
-    for seed, n, k in [(0, 530321, 1024), (1, 5000, 5000), (2, 19699, 1024), (3, 4096, 1), (4, 100000, 0), (5, 70001, 77)]:
+    for seed, n, k in [(0, 530321, 1024), (1, 5000, 5000), (2, 19699, 1024), (3, 4096, 1), (4, 100000, 0), (5, 70001, 77),
+                       (6, 65536, 100), (7, 65537, 100), (8, 8192, 1024), (9, 8192, 1025), (10, 4099, 512), (11, 1 << 20, 3)]:
         np.random.seed(seed)
         np.random.rand(seed * 5)                 # an arbitrary position inside the 624-word state block
         a, ra = np.random.choice(n, k, replace=False), np.random.rand(3)
