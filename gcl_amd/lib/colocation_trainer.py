@@ -494,24 +494,41 @@ class FinestContrastiveLossTrainer:
         return tot_loss, tot_parts, n_rows
 
 
-def prefetch_to_device(batches, device, keys=("sinput_C", "sinput_F", "group", "index", "finest_flag")):
+def prefetch_to_device(batches, device, keys=("sinput_C", "sinput_F", "group", "index", "finest_flag"), ring=3):
     """What the reference's step does first -- ``input_dict[...].to(self.device)`` (lib/colocation_trainer.py:843-845) --
     as a loader-side prefetch: the tensors of batch i+1 are copied host -> device (pinned memory, non-blocking) on a
     COPY stream while the kernels of batch i run on the compute stream.  Yields dicts whose ``keys`` are device tensors
     (everything else passes through) plus ``"_h2d_event"``: ``train_step`` makes the compute stream wait for it when it
     first touches the batch (NOT when the batch is pulled: ``train_steps`` pulls one batch ahead of the step it
-    enqueues, which is what gives the copy its head start)."""
+    enqueues, which is what gives the copy its head start).
+    The device side is a ring of ``ring`` persistent staging buffers per key (grown on demand), not fresh allocations:
+    a block that another stream has just used is not reusable by the caching allocator until its events have passed,
+    so per-step allocations on the copy stream kept falling through to hipMalloc (~0.1 ms each on the enqueuing
+    thread).  Before slot s is overwritten the copy stream waits for an event recorded NOW on the compute stream: the
+    batch that last used the slot was pulled ``ring`` batches ago and its step has been enqueued by then."""
     dev = torch.device(device)
     copy_stream = torch.cuda.Stream(device=dev)
-    for b in batches:
+    slots = [dict() for _ in range(max(2, int(ring)))]
+    for i, b in enumerate(batches):
         out = dict(b)
+        slot = slots[i % len(slots)]
+        if i >= len(slots):
+            free = torch.cuda.Event()
+            free.record(torch.cuda.current_stream(dev))
+            copy_stream.wait_event(free)
         with torch.cuda.stream(copy_stream):
             for k in keys:
                 v = b.get(k)
                 if isinstance(v, torch.Tensor) and not v.is_cuda:
                     if not v.is_pinned():
                         v = v.pin_memory()
-                    out[k] = v.to(dev, non_blocking=True)
+                    n = v.numel()
+                    buf = slot.get(k)
+                    if buf is None or buf.dtype != v.dtype or buf.numel() < n:
+                        buf = slot[k] = torch.empty(int(n * 1.25) + 16, dtype=v.dtype, device=dev)
+                    dst = buf[:n].view(v.shape)
+                    dst.copy_(v, non_blocking=True)
+                    out[k] = dst
             ev = torch.cuda.Event()
             ev.record(copy_stream)
         out["_h2d_event"] = ev
