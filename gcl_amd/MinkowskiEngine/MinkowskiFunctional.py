@@ -8,7 +8,8 @@ def relu(x):
     from .core import SparseTensor
     if getattr(x, "_nonneg", False):
         return x
-    out = SparseTensor(torch.relu(x.F), coordinate_map_key=x.coordinate_map_key,
+    from . import ops
+    out = SparseTensor(ops.relu(x.F), coordinate_map_key=x.coordinate_map_key,
                        coordinate_manager=x.coordinate_manager)
     out._nonneg = True
     return out

@@ -440,7 +440,8 @@ def cat(*tensors):
     a = tensors[0]
     for b in tensors[1:]:
         a._same_map(b)
-    out = SparseTensor(torch.cat([t.F for t in tensors], dim=1), coordinate_map_key=a.coordinate_map_key,
+    from . import ops
+    out = SparseTensor(ops.cat_features([t.F for t in tensors]), coordinate_map_key=a.coordinate_map_key,
                        coordinate_manager=a.coordinate_manager)
     out._nonneg = all(t._nonneg for t in tensors)
     return out

@@ -384,6 +384,12 @@ class _SparseConvFn(torch.autograd.Function):
 def sparse_conv(x, W, kmap, n_out, transpose, bias, mgr, want_stats=False):
     """Returns (y, stats): ``stats`` = per-tile column sums for a following BatchNorm (None unless requested and
     available in the current precision)."""
+    if _TAPE is not None:
+        with torch.no_grad():
+            c1 = _SubCtx()
+            y, stats = _SparseConvFn.forward(c1, x, W, bias, kmap, n_out, transpose, mgr, want_stats)
+        _TAPE.add("conv", y, c1, x, (W, bias))
+        return y, (stats if stats.numel() else None)
     y, stats = _SparseConvFn.apply(x, W, bias, kmap, n_out, transpose, mgr, want_stats)
     return y, (stats if stats.numel() else None)
 
@@ -509,13 +515,155 @@ class _ConvBNFn(torch.autograd.Function):
         return dx, dW, d_w, d_b, dres, None, None, None, None, None, None, None, None, None, None
 
 
+class Tape:
+    """The layer calls of ONE training forward pass of a network, recorded so that the whole network becomes a single
+    autograd node (``with ops.tape() as t: ...; out = t.finish(out)``): while a tape is active, ``conv_bn_train``,
+    ``sparse_conv``, ``relu``, ``cat`` and ``l2_normalize_rows`` run their forward bodies without autograd and append
+    an entry; ``finish`` wraps the result in ``_TapeFn``, whose backward walks the entries in reverse with the same
+    backward bodies autograd would have called, in the same order.  Same launches, same arithmetic -- what disappears is
+    the per-node cost of ~50 autograd nodes per step (engine dispatch, the backward thread hand-over, wrapper objects),
+    which matters because the step is bound by the host's launch rate.  Only for graphs made of exactly these ops
+    (gcl_amd.model.ResUNet2 with BatchNorm); anything else keeps the ordinary autograd path."""
+
+    def __init__(self):
+        self.entries = []
+        self.made = set()          # id() of tensors produced inside the tape (their producers want an input gradient)
+
+    def add(self, kind, out, *payload):
+        self.entries.append((kind, out) + payload)
+        self.made.add(id(out))
+        return out
+
+    def params(self):
+        seen, out = set(), []
+        for e in self.entries:
+            for t in e[-1]:
+                if t is not None and id(t) not in seen:
+                    seen.add(id(t))
+                    out.append(t)
+        return out
+
+    def finish(self, out):
+        global _TAPE
+        _TAPE = None
+        ps = self.params()
+        return _TapeFn.apply(self, out, *ps)
+
+    def backward(self, dout, out):
+        grads, pgrads = {id(out): dout}, {}
+
+        def give(t, g):
+            if g is None or t is None or id(t) not in self.made:
+                return
+            k = id(t)
+            grads[k] = g if k not in grads else grads[k] + g
+
+        def pgive(p, g):
+            if p is not None and g is not None:
+                k = id(p)
+                pgrads[k] = g if k not in pgrads else pgrads[k] + g
+
+        for e in reversed(self.entries):
+            kind, y = e[0], e[1]
+            g = grads.pop(id(y), None)
+            if g is None:
+                continue
+            if kind == "convbn":
+                c1, c2, x, res, (W, bw, bb) = e[2], e[3], e[4], e[5], e[6]
+                r = _BatchNormFn.backward(c2, g.contiguous())
+                c1.needs_input_grad = (id(x) in self.made, True, False)
+                dx, dW = _SparseConvFn.backward(c1, r[0], None)[:2]
+                give(x, dx)
+                give(res, r[8])
+                pgive(W, dW)
+                pgive(bw, r[1])
+                pgive(bb, r[2])
+            elif kind == "conv":
+                c1, x, (W, b) = e[2], e[3], e[4]
+                c1.needs_input_grad = (id(x) in self.made, True, b is not None)
+                dx, dW, db = _SparseConvFn.backward(c1, g, None)[:3]
+                give(x, dx)
+                pgive(W, dW)
+                pgive(b, db)
+            elif kind == "relu":
+                give(e[2], torch.ops.aten.threshold_backward(g, y, 0))
+            elif kind == "cat":
+                off = 0
+                for t in e[2]:
+                    give(t, g[:, off:off + t.shape[1]])
+                    off += t.shape[1]
+            elif kind == "rownorm":
+                give(e[3], _RowNormalizeFn.backward(e[2], g))
+        self.entries = None
+        return pgrads
+
+
+_TAPE = None
+TAPE_ENABLED = os.environ.get("GCL_TAPE", "1") == "1"
+
+
+class tape:
+    """Context manager: ``with ops.tape() as t`` activates a Tape for the layer calls inside (training only)."""
+
+    def __enter__(self):
+        global _TAPE
+        _TAPE = Tape()
+        return _TAPE
+
+    def __exit__(self, *exc):
+        global _TAPE
+        _TAPE = None
+        return False
+
+
+class _TapeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tp, out, *params):
+        ctx.tp, ctx.out, ctx.n = tp, out, len(params)
+        ctx.pids = [id(p) for p in params]
+        return out.view_as(out)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        pg = ctx.tp.backward(dout, ctx.out)
+        ctx.tp = ctx.out = None
+        return (None, None) + tuple(pg.get(k) for k in ctx.pids)
+
+
 def conv_bn_train(x, W, kmap, n_out, transpose, mgr, bn_w, bn_b, running_mean, running_var, momentum, eps, residual, relu,
                   want_stats):
-    z = _ConvBNFn.apply(x, W, bn_w, bn_b, residual, running_mean, running_var, kmap, n_out, transpose, mgr, momentum, eps,
-                        relu, want_stats)
+    if _TAPE is not None:
+        with torch.no_grad():
+            c1, c2 = _SubCtx(), _SubCtx()
+            y, stats = _SparseConvFn.forward(c1, x, W, None, kmap, n_out, transpose, mgr, want_stats)
+            z = _BatchNormFn.forward(c2, y, bn_w, bn_b, running_mean, running_var, True, momentum, eps, residual, relu,
+                                     stats if stats.numel() else None)
+        _TAPE.add("convbn", z, c1, c2, x, residual, (W, bn_w, bn_b))
+    else:
+        z = _ConvBNFn.apply(x, W, bn_w, bn_b, residual, running_mean, running_var, kmap, n_out, transpose, mgr, momentum,
+                            eps, relu, want_stats)
     if _LAST_BN_AMAX is not None:
         tag_amax(z, _LAST_BN_AMAX)
     return z
+
+
+def relu(x):
+    """ReLU of a feature matrix (tape-aware; MEF.relu)."""
+    if _TAPE is not None and id(x) in _TAPE.made:
+        with torch.no_grad():
+            y = torch.relu(x)
+        return _TAPE.add("relu", y, x, ())
+    return torch.relu(x)
+
+
+def cat_features(tensors):
+    """Channel concatenation of feature matrices (tape-aware; ME.cat)."""
+    if _TAPE is not None and any(id(t) in _TAPE.made for t in tensors):
+        with torch.no_grad():
+            y = torch.cat(tensors, dim=1)
+        return _TAPE.add("cat", y, tuple(tensors), ())
+    return torch.cat(tensors, dim=1)
 
 
 class _RowNormalizeFn(torch.autograd.Function):
@@ -549,6 +697,11 @@ def l2_normalize_rows(x):
     """``x / torch.norm(x, p=2, dim=1, keepdim=True)``; widths the kernel does not cover use that expression."""
     c = x.shape[1]
     if x.dim() == 2 and x.shape[0] > 0 and 4 <= c <= 256 and (c & (c - 1)) == 0 and x.dtype == torch.float32:
+        if _TAPE is not None and id(x) in _TAPE.made:
+            with torch.no_grad():
+                cx = _SubCtx()
+                y = _RowNormalizeFn.forward(cx, x)
+            return _TAPE.add("rownorm", y, cx, x, ())
         return _RowNormalizeFn.apply(x)
     return x / torch.norm(x, p=2, dim=1, keepdim=True)
 

@@ -76,6 +76,17 @@ class ResUNet2(ME.MinkowskiNetwork):
         return specs
 
     def forward(self, x):
+        ops = ME.ops
+        use_tape = (ops.TAPE_ENABLED and self.training and torch.is_grad_enabled() and self.NORM_TYPE == "BN"
+                    and self.BLOCK_NORM_TYPE == "BN" and ME.FUSED_CONV_BN_NODE and not x.F.requires_grad)
+        if not use_tape:
+            return self._forward(x)
+        with ops.tape() as tp:          # the whole network as ONE autograd node (ops.Tape)
+            out = self._forward(x)
+            F = tp.finish(out.F)
+        return ME.SparseTensor(F, coordinate_map_key=out.coordinate_map_key, coordinate_manager=out.coordinate_manager)
+
+    def _forward(self, x):
         skips = {}
         out = x
         for l in (1, 2, 3, 4):
