@@ -399,8 +399,9 @@ class FinestContrastiveLossTrainer:
         if getattr(self, "map_prefetch", False) and specs is not None and isinstance(C, torch.Tensor) and C.is_cuda:
             with torch.cuda.device(self.device):
                 if getattr(self, "_side", None) is None:
-                    lo, _hi = torch.cuda.Stream.priority_range()        # (lowest priority, highest priority)
-                    self._side = torch.cuda.Stream(device=self.device, priority=lo)
+                    lo, hi = torch.cuda.Stream.priority_range()         # (lowest priority, highest priority)
+                    prio = {"low": lo, "high": hi}.get(os.environ.get("GCL_SIDE_PRIORITY", "high"), 0)
+                    self._side = torch.cuda.Stream(device=self.device, priority=prio)
                 with torch.cuda.stream(self._side):
                     ev = batch.get("_h2d_event")
                     if ev is not None:
@@ -432,11 +433,26 @@ class FinestContrastiveLossTrainer:
                     return grp
             return None
 
+        import time
+        trace = os.environ.get("GCL_TRACE_HELPERS") == "1"          # diagnostic: wall / CPU time of the helper threads
+        acc = self._helper_times = getattr(self, "_helper_times", {"draw": [0.0, 0.0, 0], "maps": [0.0, 0.0, 0]})
+
+        def timed(name, fn, grp):
+            if not trace:
+                return fn(grp)
+            w0, c0 = time.perf_counter(), time.thread_time()
+            out = fn(grp)
+            a = acc[name]
+            a[0] += time.perf_counter() - w0
+            a[1] += time.thread_time() - c0
+            a[2] += 1
+            return out
+
         def draw(grp):
-            return [self._draw_for(b) for b in grp]
+            return timed("draw", lambda g: [self._draw_for(b) for b in g], grp)
 
         def maps(grp):
-            return [self._prefetch_maps(b) for b in grp]
+            return timed("maps", lambda g: [self._prefetch_maps(b) for b in g], grp)
 
         cur = take()
         if cur is None:
