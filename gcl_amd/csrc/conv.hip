@@ -721,6 +721,285 @@ __global__ void __launch_bounds__(256, GCL_FWD_MIN_WAVES(NB, PL)) k_conv_fwd_spl
 }
 
 // ---------------------------------------------------------------------------------------------------
+// HALO-TILE forward kernel (stride-1 3^3 maps; tiles from gcl_table_sort_halo).  The (offset, slice) loop of
+// k_conv_fwd_split gathers every neighbour INSTANCE of a 128-row tile from memory (~8 per output row and slice on the
+// KITTI batch, served by the Infinity Cache at its gather rate -- that rate, not the MFMA pipe, bounds those kernels).
+// Here the tile is a compact blob of 128 rows in fine spatial order: its ~170 DISTINCT input rows (the halo) are
+// staged ONCE per 32-channel slice in LDS -- split into the fp16 / bf16 planes on the way, so the split is paid once per
+// halo row instead of once per gathered instance -- and the offset loop reads its A fragments from LDS through 16-bit
+// halo slots (slot table of the tile in LDS, slot HMAX = a row of zeros for absent neighbours).  Memory traffic of the A
+// operand drops ~5x; the weight blocks go through LDS as before (one workgroup barrier per unit, register sets loaded
+// DEPTH units ahead).  Loop order: slices outer, offsets inner (ascending), every product summed in a fixed order:
+// deterministic.  A tile whose halo exceeds HMAX rows is processed in passes over slot ranges (slots are ranked by row
+// id, so the pass split is deterministic).
+// STATUS: opt-in (GCL_HALO=1).  Measured on the KITTI batch it is 1.5 - 1.7x SLOWER than k_conv_fwd_split on the
+// mask-sorted table (profiles/r02_conv_experiments.txt): a spatial tile visits 13.7 - 18.6 units per wave where the
+// global mask sort visits 7.9 - 12.8, a workgroup pays ~6 serialized memory round trips outside its unit loop
+// (prologue, one staging per slice, epilogue) at 3 workgroups per CU, and removing the gather traffic did not shorten
+// the per-unit time -- the unit loop is bound by its latency chain, not by bytes.
+// ---------------------------------------------------------------------------------------------------
+constexpr int HALO_HMAX = 224;
+template <int NB, int PL, bool EPI, int DEPTH>
+__global__ void __launch_bounds__(256, (NB <= 2 ? 3 : 2)) k_conv_fwd_halo(const float* __restrict__ X, const u32x4* __restrict__ Wp,
+                                                          const int* __restrict__ hcount, const int* __restrict__ hrows,
+                                                          const unsigned short* __restrict__ hloc, int hcap,
+                                                          const int* __restrict__ order, const int* __restrict__ tile_mask,
+                                                          long long n_out, int K, int cin, int cout,
+                                                          const float* __restrict__ bias, float* __restrict__ Y,
+                                                          float* __restrict__ stats, const int* __restrict__ x_amax,
+                                                          const int* __restrict__ w_amax, unsigned x_bytes, ConvEpi epi) {
+  static_assert(PL != 3, "two-plane arithmetics only");
+  constexpr int NPL = 2;
+  constexpr int BLK = NB * 2 * NPL * 64;
+  constexpr int BREG = (BLK + 255) / 256;
+  const float a_scale = (PL == 4) ? amax_scale(x_amax) : 1.f;
+  const float out_scale = (PL == 4) ? 1.f / (a_scale * amax_scale(w_amax)) : 1.f;
+  __shared__ __attribute__((aligned(16))) float Hs[HALO_HMAX + 1][32];   // plane images of the halo rows' slice: 64 B hi | 64 B lo, 16-byte pieces XOR-swizzled
+  __shared__ __attribute__((aligned(16))) u32x4 Bsm[2][BLK];
+  __shared__ __attribute__((aligned(16))) unsigned short Lsm[27][128];   // halo slot of (offset, tile row)
+  __shared__ int Hrow[256];                                              // input rows of the pass's halo slots (-1 beyond)
+  __shared__ unsigned wmask[4];
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  const int i = l & 31, h = l >> 5;
+  // 1-D grid: the column blocks of one tile get consecutive slots of one XCD (they stage the same halo: L2 hits)
+  const unsigned ncb = (unsigned)(cout / (32 * NB)), nrw = (unsigned)((n_out + CONV_ROWS - 1) / CONV_ROWS);
+  unsigned bxx, byy;
+  {
+    const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    byy = slot % ncb;
+    const unsigned q = nrw >> 3, r = nrw & 7u, mine = q + (xcd < r ? 1u : 0u), j = slot / ncb;
+    if (j >= mine) return;   // whole workgroup, before any barrier
+    bxx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;     // contiguous tile range per XCD
+  }
+  const long long tile = (long long)bxx * 4 + w;
+  const long long row0 = tile * 32;
+  const bool active = row0 < n_out;
+  const int nb0 = byy * NB;
+  const int TNB = cout >> 5, CC = cin >> 5;
+
+  f32x16 acc[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+
+  unsigned mymask = 0u;
+  if (active) mymask = (unsigned)tile_mask[tile];
+  mymask = __builtin_amdgcn_readfirstlane(mymask);
+  if (l == 0) wmask[w] = mymask;
+  const int H = hcount[bxx];
+  const int npass = (H + HALO_HMAX - 1) / HALO_HMAX;
+  const int* const myhalo = hrows + (long long)bxx * hcap;
+  {   // slot table of the tile (K x 128 u16, contiguous) and the halo rows of the first pass
+    const u32x4* src = reinterpret_cast<const u32x4*>(hloc + (long long)bxx * K * 128);
+    u32x4* dst = reinterpret_cast<u32x4*>(&Lsm[0][0]);
+    for (int e = t; e < K * 16; e += 256) dst[e] = src[e];
+    Hrow[t] = (t < H && t < HALO_HMAX) ? myhalo[t] : -1;
+  }
+  if (t < 8) *reinterpret_cast<float4*>(&Hs[HALO_HMAX][t * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  const unsigned wgmask = wmask[0] | wmask[1] | wmask[2] | wmask[3];
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)x_bytes, 0x00020000);
+  const unsigned row_bytes = (unsigned)cin * 4u;
+
+#define GCL_LOAD_BH(SET, KK, CCV)                                                                \
+  {                                                                                              \
+    const u32x4* src_ = Wp + (((long long)(KK)*CC + (CCV)) * TNB + nb0) * (2 * NPL * 64);        \
+    _Pragma("unroll") for (int e = 0; e < BREG; ++e) {                                           \
+      if ((BLK % 256 == 0) || (e * 256 + t < BLK)) br[SET][e] = src_[e * 256 + t];               \
+    }                                                                                            \
+  }
+#define GCL_STORE_BH(SET, BUF)                                                                   \
+  {                                                                                              \
+    _Pragma("unroll") for (int e = 0; e < BREG; ++e) {                                           \
+      if ((BLK % 256 == 0) || (e * 256 + t < BLK)) Bsm[BUF][e * 256 + t] = br[SET][e];           \
+    }                                                                                            \
+  }
+  // unit iterator: offsets of the workgroup's mask ascending (inner), slices, passes (outer)
+#define GCL_UNIT_ADVANCE(KV, CV, PV, RESTV, HASV)  \
+  {                                                \
+    if (RESTV) {                                   \
+      KV = __builtin_ctz(RESTV);                   \
+      RESTV &= RESTV - 1;                          \
+    } else {                                       \
+      KV = k_first;                                \
+      RESTV = wgmask & (wgmask - 1);               \
+      CV += 1;                                     \
+      if (CV == CC) {                              \
+        CV = 0;                                    \
+        PV += 1;                                   \
+        if (PV == npass) HASV = false;             \
+      }                                            \
+    }                                              \
+  }
+
+  if (wgmask != 0u && npass > 0) {
+    u32x4 br[DEPTH][BREG];
+    const int k_first = __builtin_ctz(wgmask);
+    int bk = k_first, bc = 0, bp = 0;              // weight-block iterator, DEPTH units ahead of the compute loop
+    unsigned brest = wgmask & (wgmask - 1);
+    bool bhas = true;
+    int ck = k_first, cc = 0, cp = 0;              // compute iterator
+    unsigned crest = wgmask & (wgmask - 1);
+    bool chas = true;
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) {
+      if (bhas) {
+        GCL_LOAD_BH(u, bk, bc);
+        GCL_UNIT_ADVANCE(bk, bc, bp, brest, bhas);
+      }
+    }
+    GCL_STORE_BH(0, 0);                            // block of unit 0 (published by the staging barrier below)
+    if (bhas) {
+      GCL_LOAD_BH(0, bk, bc);                      // set 0 now carries unit DEPTH
+      GCL_UNIT_ADVANCE(bk, bc, bp, brest, bhas);
+    }
+    int buf = 0;
+    bool new_slice = true;
+    while (chas) {
+#pragma unroll
+      for (int u = 0; u < DEPTH; ++u) {
+        if (!chas) break;
+        const int hbase = cp * HALO_HMAX;
+        const int hn = (H - hbase < HALO_HMAX) ? (H - hbase) : HALO_HMAX;
+        if (new_slice) {
+          // ---- stage the halo rows' slice: thread (row j = t / 4 + 64 v, quarter q = t % 4) loads 8 channels of up to
+          // four rows (all loads issued before the first use), splits them and writes 16 bytes of the hi half and 16
+          // bytes of the lo half.  Every wave is past its last read of Hs (the barrier that closed the previous unit).
+          if (cc == 0 && cp > 0) {                 // halo rows of this pass
+            Hrow[t] = (hbase + t < H && t < HALO_HMAX) ? myhalo[hbase + t] : -1;
+            __syncthreads();
+          }
+          const int q = t & 3;
+          float4 f[4][2];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int j = (t >> 2) + 64 * v;
+            const unsigned off = (unsigned)Hrow[j] * row_bytes + (unsigned)cc * 128u + (unsigned)q * 32u;   // row -1: zeros
+            f[v][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 0, 0));
+            f[v][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(off + 16u), 0, 0));
+          }
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int j = (t >> 2) + 64 * v;
+            if (j < HALO_HMAX) {
+              u32x4 pl[2];
+              split8<PL>(f[v][0], f[v][1], a_scale, pl);
+              const int sw = a_swz(j);
+              *reinterpret_cast<u32x4*>(&Hs[j][(q ^ sw) << 2]) = pl[0];
+              *reinterpret_cast<u32x4*>(&Hs[j][((4 + q) ^ sw) << 2]) = pl[1];
+            }
+          }
+          __syncthreads();
+          new_slice = false;
+        }
+        if ((mymask >> ck) & 1u) {
+          unsigned slot = (unsigned)Lsm[ck][w * 32 + i] - (unsigned)hbase;
+          if (slot >= (unsigned)hn) slot = HALO_HMAX;      // absent neighbour, or a halo row of another pass: zeros
+          const float* rowp = &Hs[slot][0];
+          const int sw = a_swz((int)slot);
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            u32x4 ap[2];
+            ap[0] = *reinterpret_cast<const u32x4*>(&rowp[((2 * m + h) ^ sw) << 2]);
+            ap[1] = *reinterpret_cast<const u32x4*>(&rowp[((4 + 2 * m + h) ^ sw) << 2]);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+              const u32x4* bb = &Bsm[buf][((b * 2 + m) * NPL) * 64 + l];
+              u32x4 bp2[2];
+              bp2[0] = bb[0];
+              bp2[1] = bb[64];
+              mfma_terms<PL>(ap, bp2, acc[b]);
+            }
+          }
+        }
+        {
+          const int cc_before = cc, cp_before = cp;
+          GCL_UNIT_ADVANCE(ck, cc, cp, crest, chas);
+          new_slice = (cc != cc_before) || (cp != cp_before);
+        }
+        if (chas) {
+          // ---- weight block of the next unit (register set (u + 1) % DEPTH, loaded DEPTH units ago) -> the LDS buffer
+          // nobody reads; the set is then refilled with the block DEPTH units further on
+          constexpr int nu = 0;
+          (void)nu;
+          GCL_STORE_BH((u + 1) % DEPTH, buf ^ 1);
+          if (bhas) {
+            GCL_LOAD_BH((u + 1) % DEPTH, bk, bc);
+            GCL_UNIT_ADVANCE(bk, bc, bp, brest, bhas);
+          }
+        }
+        __syncthreads();
+        buf ^= 1;
+      }
+    }
+  }
+#undef GCL_LOAD_BH
+#undef GCL_STORE_BH
+#undef GCL_UNIT_ADVANCE
+  // (the loop's closing barrier, or the one after the prologue, has every wave past its last read of Bsm)
+  if (!active && !stats) return;
+  int orow_l = -1;
+  if (active && (l < 32) && (row0 + l < n_out)) orow_l = order[row0 + l];
+  float ymax = 0.f;
+  float* const ssc = reinterpret_cast<float*>(&Bsm[0][0]) + w * (NB * 64);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int col = (nb0 + b) * 32 + i;
+    float bvv = bias ? bias[col] : 0.f;
+    float csc = (EPI && epi.col_scale) ? epi.col_scale[col] * out_scale : out_scale;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(bvv) : "v"(bvv));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(csc) : "v"(csc));
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int orow = __shfl(orow_l, (r & 3) + 8 * (r >> 2) + 4 * h);
+      if (orow >= 0) {
+        float v = acc[b][r] * csc + bvv;
+        if (EPI && epi.residual) v += epi.residual[(long long)orow * cout + col];
+        if (EPI && epi.relu) v = fmaxf(v, 0.f);
+        Y[(long long)orow * cout + col] = v;
+        s1 += v;
+        s2 += v * v;
+        if (EPI) ymax = fmaxf(ymax, fabsf(v));
+      }
+    }
+    if (stats) {
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (h == 0) {
+        ssc[b * 32 + i] = s1;
+        ssc[NB * 32 + b * 32 + i] = s2;
+      }
+    }
+  }
+  if (stats) {
+    __syncthreads();
+    if (w == 0 && h == 0) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int col = (nb0 + b) * 32 + i;
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {
+          const float* o = ssc + ww * (NB * 64);
+          t1 += o[b * 32 + i];
+          t2 += o[NB * 32 + b * 32 + i];
+        }
+        stats[((long long)bxx * 2 + 0) * cout + col] = t1;
+        stats[((long long)bxx * 2 + 1) * cout + col] = t2;
+      }
+    }
+    if (!active) return;
+  }
+  if (EPI && epi.y_amax) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o));
+    if (l == 0) amax_slot_publish(epi.y_amax, __float_as_int(ymax), (unsigned)tile);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // TWO (offset, slice) units per workgroup barrier.  k_conv_fwd_split issues the loads of a step just before the barrier
 // that closes the previous one and needs them when that step's 12 MFMAs per wave are done: the window a gather has to
 // arrive in is ONE short compute phase, far less than the latency of random 128-byte rows from the Infinity Cache under
@@ -1844,6 +2123,47 @@ int gcl_conv_fwd_fused(const float* x, int64_t n_in, int32_t x_is_planes, const 
 #undef LAUNCH_SPLIT_I
 #undef LAUNCH_SPLIT_NB
 #undef LAUNCH_SPLIT_NB2
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int gcl_conv_fwd_halo(const float* x, int64_t n_in, const void* wp, int32_t prec, const int32_t* x_amax,
+                      const int32_t* w_amax, const int32_t* hcount, const int32_t* hrows, const uint16_t* hloc,
+                      const int32_t* order, const int32_t* tile_mask, int64_t n_out, int32_t K, int32_t cin,
+                      int32_t cout, const float* bias, const float* col_scale, const float* residual, int32_t relu,
+                      int32_t* y_amax, float* y, float* stats, void* stream) {
+  const ConvEpi epi{col_scale, residual, relu, y_amax};
+  const bool use_epi = col_scale || residual || relu || y_amax;
+  GCL_CHECK_ARG(x && wp && y && hcount && hrows && hloc && order && tile_mask, "gcl_conv_fwd_halo: null pointer");
+  GCL_CHECK_ARG(n_in > 0 && (long long)n_in * cin * 4 < (1ll << 32) - (1ll << 20),
+                "gcl_conv_fwd_halo: the input tensor must be non-empty and smaller than 4 GiB (buffer addressing)");
+  GCL_CHECK_ARG(n_out > 0 && K >= 1 && K <= 27, "gcl_conv_fwd_halo: n_out must be positive and 1 <= K <= 27");
+  GCL_CHECK_ARG(cin % 32 == 0 && cout % 32 == 0 && cin > 0 && cout > 0,
+                "gcl_conv_fwd_halo: Cin (%d) and Cout (%d) must be positive multiples of 32", cin, cout);
+  GCL_CHECK_ARG(prec == 2 || prec == 4, "gcl_conv_fwd_halo: prec must be 2 (bf16x3) or 4 (fp16x3)");
+  GCL_CHECK_ARG(prec != 4 || (x_amax && w_amax), "gcl_conv_fwd_halo: fp16x3 needs gcl_amax of x and of the weights");
+  const unsigned x_bytes = (unsigned)((long long)n_in * cin * 4);
+  hipStream_t st = (hipStream_t)stream;
+  static const int nb4 = [] { const char* e = getenv("GCL_HALO_NB4"); return e ? atoi(e) : 0; }();
+  const int nb = (nb4 && cout % 128 == 0) ? 4 : ((cout % 64 == 0) ? 2 : 1);
+  const unsigned gx = (unsigned)cdiv(n_out, CONV_ROWS);
+  const dim3 grid((unsigned)(cdiv(gx, 8) * 8 * (cout / (32 * nb))));
+  const int hcap = K * 128;
+#define LAUNCH_HALO(NBV, PLV, EPIV)                                                                               \
+  hipLaunchKernelGGL((k_conv_fwd_halo<NBV, PLV, EPIV, 2>), grid, dim3(256), 0, st, x, (const u32x4*)wp, hcount, hrows, \
+                     hloc, hcap, order, tile_mask, (long long)n_out, K, cin, cout, bias, y, stats, x_amax, w_amax, \
+                     x_bytes, epi)
+#define LAUNCH_HALO_P(NBV)                                                     \
+  {                                                                            \
+    if (prec == 4) {                                                           \
+      if (use_epi) LAUNCH_HALO(NBV, 4, true); else LAUNCH_HALO(NBV, 4, false); \
+    } else {                                                                   \
+      if (use_epi) LAUNCH_HALO(NBV, 2, true); else LAUNCH_HALO(NBV, 2, false); \
+    }                                                                          \
+  }
+  if (nb == 4) LAUNCH_HALO_P(4) else if (nb == 2) LAUNCH_HALO_P(2) else LAUNCH_HALO_P(1)
+#undef LAUNCH_HALO
+#undef LAUNCH_HALO_P
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }

@@ -417,7 +417,9 @@ class FinestContrastiveLossTrainer:
     def train_steps(self, batches):
         """The epoch loop (``_train_epoch`` :811-916): yields train_step(...) for every optimizer step, i.e. for every
         ``config.iter_size`` consecutive batches (:838, a trailing incomplete group is dropped like ``len // iter_size``).
-        Two helper threads work one step ahead of the step being enqueued: one makes the ``np.random`` draws of the next
+        Two helper threads work ``GCL_PREFETCH_DEPTH`` (default 2) steps ahead of the step being enqueued (the map
+        helper's latency is a full step when the GPU is saturated -- its side-stream kernels queue behind the training
+        stream's -- so one step of lead made the enqueuing thread wait ~3 ms per step for it): one makes the ``np.random`` draws of the next
         step (two permutations of all N rows per batch: ~12 ms of native code outside the interpreter lock; every draw
         still after the previous batch's, so the random stream is consumed in the order of a serial loop), the other
         builds the next batches' coordinate maps on a side stream (``_prefetch_maps``)."""
@@ -454,18 +456,29 @@ class FinestContrastiveLossTrainer:
         def maps(grp):
             return timed("maps", lambda g: [self._prefetch_maps(b) for b in g], grp)
 
-        cur = take()
-        if cur is None:
-            return
+        depth = max(1, int(os.environ.get("GCL_PREFETCH_DEPTH", "2")))      # steps the helpers work ahead
+        from collections import deque
         with ThreadPoolExecutor(max_workers=1) as draw_pool, ThreadPoolExecutor(max_workers=1) as map_pool:
-            fd, fm = draw_pool.submit(draw, cur), map_pool.submit(maps, cur)
-            while cur is not None:
+            pending = deque()
+
+            def refill():
+                while len(pending) < depth:
+                    grp = take()
+                    if grp is None:
+                        return
+                    pending.append((draw_pool.submit(draw, grp), map_pool.submit(maps, grp)))
+
+            refill()
+            while pending:
+                fd, fm = pending.popleft()
+                w0 = time.perf_counter()
                 draws, cur = fd.result(), fm.result()
-                nxt = take()
-                if nxt is not None:
-                    fd, fm = draw_pool.submit(draw, nxt), map_pool.submit(maps, nxt)
+                if trace:       # how long the enqueuing thread stood waiting for its helpers
+                    wt = acc.setdefault("wait", [0.0, 0.0, 0])
+                    wt[0] += time.perf_counter() - w0
+                    wt[2] += 1
+                refill()
                 yield self.train_step(cur if k > 1 else cur[0], draws if k > 1 else draws[0])
-                cur = nxt
 
     def train_step(self, input_dict, draws=None):
         """One optimizer step.  ``input_dict``: one batch, or a list of ``iter_size`` batches whose gradients are
@@ -500,6 +513,7 @@ class FinestContrastiveLossTrainer:
                 parts = tuple(p / n_micro for p in parts)         # :875-877
                 loss = self.pos_weight * parts[0] + self.finest_weight * parts[1] + self.neg_weight * parts[2]
             loss.backward()
+            release_batch(b)
             n_rows += F_out.shape[0]
             dl, dp = loss.detach(), tuple(p.detach() for p in parts)
             tot_loss = dl if tot_loss is None else tot_loss + dl
@@ -510,28 +524,37 @@ class FinestContrastiveLossTrainer:
         return tot_loss, tot_parts, n_rows
 
 
-def prefetch_to_device(batches, device, keys=("sinput_C", "sinput_F", "group", "index", "finest_flag"), ring=3):
+def prefetch_to_device(batches, device, keys=("sinput_C", "sinput_F", "group", "index", "finest_flag"), ring=4):
     """What the reference's step does first -- ``input_dict[...].to(self.device)`` (lib/colocation_trainer.py:843-845) --
     as a loader-side prefetch: the tensors of batch i+1 are copied host -> device (pinned memory, non-blocking) on a
     COPY stream while the kernels of batch i run on the compute stream.  Yields dicts whose ``keys`` are device tensors
     (everything else passes through) plus ``"_h2d_event"``: ``train_step`` makes the compute stream wait for it when it
     first touches the batch (NOT when the batch is pulled: ``train_steps`` pulls one batch ahead of the step it
     enqueues, which is what gives the copy its head start).
-    The device side is a ring of ``ring`` persistent staging buffers per key (grown on demand), not fresh allocations:
-    a block that another stream has just used is not reusable by the caching allocator until its events have passed,
-    so per-step allocations on the copy stream kept falling through to hipMalloc (~0.1 ms each on the enqueuing
-    thread).  Before slot s is overwritten the copy stream waits for an event recorded NOW on the compute stream: the
-    batch that last used the slot was pulled ``ring`` batches ago and its step has been enqueued by then."""
+    The device side is a pool of persistent staging slots (``ring`` to start with, grown on demand), not fresh
+    allocations: a block that another stream has just used is not reusable by the caching allocator until its events
+    have passed, so per-step allocations on the copy stream kept falling through to hipMalloc (~0.1 ms each on the
+    enqueuing thread).  A slot is handed out again only after its consumer has called ``release_batch`` (the trainer
+    does, once the batch's forward / backward is enqueued): that records an event on the compute stream which the copy
+    stream waits for before overwriting the slot.  A consumer that never releases gets the old behaviour once the pool
+    has grown to ``4 * ring`` slots: the oldest slot is reused behind an event recorded on the compute stream NOW."""
     dev = torch.device(device)
     copy_stream = torch.cuda.Stream(device=dev)
-    slots = [dict() for _ in range(max(2, int(ring)))]
+    slots = [{"bufs": {}, "busy": False, "free": None, "age": -1} for _ in range(max(2, int(ring)))]
+    limit = 4 * len(slots)
     for i, b in enumerate(batches):
         out = dict(b)
-        slot = slots[i % len(slots)]
-        if i >= len(slots):
-            free = torch.cuda.Event()
-            free.record(torch.cuda.current_stream(dev))
-            copy_stream.wait_event(free)
+        slot = next((s_ for s_ in slots if not s_["busy"]), None)
+        if slot is None and len(slots) < limit:
+            slot = {"bufs": {}, "busy": False, "free": None, "age": -1}
+            slots.append(slot)
+        if slot is None:
+            slot = min(slots, key=lambda s_: s_["age"])
+            slot["free"] = torch.cuda.Event()
+            slot["free"].record(torch.cuda.current_stream(dev))
+        if slot["free"] is not None:
+            copy_stream.wait_event(slot["free"])
+        slot["busy"], slot["age"], slot["free"] = True, i, None
         with torch.cuda.stream(copy_stream):
             for k in keys:
                 v = b.get(k)
@@ -539,16 +562,29 @@ def prefetch_to_device(batches, device, keys=("sinput_C", "sinput_F", "group", "
                     if not v.is_pinned():
                         v = v.pin_memory()
                     n = v.numel()
-                    buf = slot.get(k)
+                    buf = slot["bufs"].get(k)
                     if buf is None or buf.dtype != v.dtype or buf.numel() < n:
-                        buf = slot[k] = torch.empty(int(n * 1.25) + 16, dtype=v.dtype, device=dev)
+                        buf = slot["bufs"][k] = torch.empty(int(n * 1.25) + 16, dtype=v.dtype, device=dev)
                     dst = buf[:n].view(v.shape)
                     dst.copy_(v, non_blocking=True)
                     out[k] = dst
             ev = torch.cuda.Event()
             ev.record(copy_stream)
-        out["_h2d_event"] = ev
+        out["_h2d_event"], out["_h2d_slot"] = ev, (slot, i)
         yield out
+
+
+def release_batch(batch):
+    """The consumer is done ENQUEUING work that reads a prefetched batch: its staging slot may be overwritten once the
+    current stream has passed this point (see ``prefetch_to_device``).  No-op for ordinary batches."""
+    st = batch.get("_h2d_slot") if isinstance(batch, dict) else None
+    if st is None:
+        return
+    slot, age = st
+    if slot["busy"] and slot["age"] == age:
+        slot["free"] = torch.cuda.Event()
+        slot["free"].record(torch.cuda.current_stream())
+        slot["busy"] = False
 
 
 def wait_for_batch(batch):

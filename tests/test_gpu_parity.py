@@ -510,6 +510,88 @@ def test_table_sort_is_a_stable_mask_sort(window):
         core.SORT_WINDOW = old
 
 
+@pytest.fixture
+def halo_tiles():
+    """Opt-in halo-tile path (gcl_table_sort_halo + gcl_conv_fwd_halo) switched on for every stride-1 3^3 map."""
+    from gcl_amd.MinkowskiEngine import core
+    old = core.HALO, core.HALO_MIN_ROWS
+    core.HALO, core.HALO_MIN_ROWS = True, 1
+    yield
+    core.HALO, core.HALO_MIN_ROWS = old
+
+
+@pytest.mark.parametrize("seed,n,t", [(9, 5000, 1), (10, 300, 1), (11, 20000, 2), (12, 1, 1)])
+def test_halo_tiles_are_consistent(halo_tiles, seed, n, t):
+    """gcl_table_sort_halo: order is a permutation, the permuted table and tile masks are consistent with it (so
+    gcl_conv_fwd can use them as they are), and per 128-row tile hrows lists exactly the distinct input rows of the
+    tile's entries in ascending order with hloc pointing every entry at its row (0xFFFF = no neighbour)."""
+    C = random_cloud(seed, n=n, batch=2)
+    mgr = make_mgr(C)
+    km = mgr.get_kernel_map(t, 3, 1)
+    tbl = km.nbr.cpu().numpy()
+    ts_t, order_t, tmask_t = km.sorted_table(False)
+    hcount, hrows, hloc = (x.cpu().numpy() for x in ts_t._gcl_halo)
+    ts, order, tmask = ts_t.cpu().numpy(), order_t.cpu().numpy(), tmask_t.cpu().numpy()
+    n_rows = tbl.shape[1]
+    assert np.array_equal(np.sort(order), np.arange(n_rows))
+    assert np.array_equal(ts, tbl[:, order])
+    mask = np.zeros(n_rows, dtype=np.int64)
+    for k in range(km.K):
+        mask |= (tbl[k] >= 0).astype(np.int64) << k
+    pad = (-n_rows) % 32
+    mt = np.concatenate([mask[order], np.zeros(pad, np.int64)]).reshape(-1, 32)
+    assert np.array_equal(tmask.astype(np.int64), np.bitwise_or.reduce(mt, axis=1))
+    hloc = hloc.view(np.uint16)
+    for tile in range((n_rows + 127) // 128):
+        ent = ts[:, tile * 128:(tile + 1) * 128]                       # [K, rows of the tile]
+        distinct = np.unique(ent[ent >= 0])
+        assert hcount[tile] == len(distinct)
+        assert np.array_equal(hrows[tile, :len(distinct)], distinct)
+        loc = hloc[tile, :, :ent.shape[1]]
+        assert np.array_equal(loc == 0xFFFF, ent < 0)
+        assert np.array_equal(hrows[tile][loc[ent >= 0]], ent[ent >= 0])
+        m = mask[order[tile * 128:(tile + 1) * 128]]
+        assert np.all(np.diff(m) >= 0)                                 # mask-sorted inside the tile
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 32), (64, 64), (128, 128), (256, 256), (32, 64), (96, 32)])
+def test_halo_conv_fwd_bwd_vs_oracle(halo_tiles, cin, cout, precision):
+    """The halo-tile kernel behind the same layer: forward, input gradient (the same kernel with mirrored weights) and
+    weight gradient against the fp64 oracle, at the tolerance of the production kernel."""
+    if precision in ("f32", "bf16x6"):
+        pytest.skip("halo tiles carry two planes (fp16x3 / bf16x3); the other arithmetics take the production kernel")
+    r = _conv_case(cin, cout, 3, 1, False, seed=3, n=6000)
+    tol = PREC_TOL[precision]
+    assert rel_l2(*r["y"]) < tol, rel_l2(*r["y"])
+    assert rel_l2(*r["dx"]) < tol, rel_l2(*r["dx"])
+    assert rel_l2(*r["dW"]) < tol, rel_l2(*r["dW"])
+
+
+def test_halo_multi_pass_tiles_and_determinism(halo_tiles):
+    """A dense block: every 128-row tile names far more than the 224 halo rows one LDS window holds, so tiles run in
+    several passes over slot ranges; result equals the production kernel to rounding and is bitwise reproducible."""
+    import gcl_amd.MinkowskiEngine as ME
+    from gcl_amd.MinkowskiEngine import core
+    g = np.stack(np.meshgrid(np.arange(14), np.arange(14), np.arange(14), indexing="ij"), -1).reshape(-1, 3)
+    rng = np.random.default_rng(0)
+    g = g[rng.permutation(len(g))]                 # loader order is not spatial
+    C = np.concatenate([np.zeros((len(g), 1), np.int64), g], 1).astype(np.int32)
+    torch.manual_seed(0)
+    conv = ME.MinkowskiConvolution(64, 64, kernel_size=3, stride=1, dimension=3).to(DEV)
+    x = torch.randn(len(g), 64, device=DEV)
+    outs = []
+    for halo in (True, True, False):
+        core.HALO = halo
+        mgr = make_mgr(C)
+        if halo:
+            hc = mgr.get_kernel_map(1, 3, 1).sorted_table(False)[0]._gcl_halo[0]
+            assert int(hc.max()) > 224
+        with torch.no_grad():
+            outs.append(conv(ME.SparseTensor(x, coordinate_map_key=ME.CoordinateMapKey(1), coordinate_manager=mgr)).F)
+    assert torch.equal(outs[0], outs[1])
+    assert rel_l2(outs[0].cpu().double(), outs[2].cpu().double()) < 2e-6
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # callers either side of the kernels: extract_features, find_corr / eval step, training step with DDP wrapper
 # ---------------------------------------------------------------------------------------------------------------
