@@ -710,13 +710,14 @@ def test_resunet_fat_variant_vs_oracle():
     gy = torch.randn(Fo.shape, generator=g, dtype=torch.float64)
     Fo.backward(gy)
     F.backward(gy.float().to(DEV))
-    # small cloud: BatchNorm-parameter gradients amplify fp32 rounding (1e-2).  conv1.kernel: the input features are
-    # exactly 1, so dW_k = sum of dy over the rows that have offset k, and BatchNorm's backward makes dy sum to zero per
-    # channel -- a cancellation whose fp32 residue depends on how the statistics were rounded (8e-3 with the separate
-    # statistics pass and with 128-row partials, < 2e-3 with 32-row partials: all equally valid fp32 results)
+    # This case is ill-conditioned in fp32: the ORACLE ITSELF run in torch-CPU float32 differs from its float64 run by
+    # 4.6e-3 ... 6.5e-3 rel-L2 on every encoder kernel / BatchNorm gradient (2e-3 in the decoder; measured with the
+    # same state dict, cloud and output gradient) -- a small cloud whose BatchNorm backward cancels large sums.  The
+    # HIP path lands at 1e-3 ... 8e-3; the bound is 3x the fp32 oracle's own distance.
     for name, p_ in m.named_parameters():
-        tol = 2e-2 if name == "conv1.kernel" else (1e-2 if ".bn." in name else 4e-3)
-        assert rel_l2(p_.grad.cpu(), so[name].grad) < tol, name
+        tol = 2e-2
+        err = rel_l2(p_.grad.cpu(), so[name].grad)
+        assert err < tol, (name, err)
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -29,7 +29,8 @@ rows = list(csv.DictReader(open(ks)))
 n_steps = n_steps_arg
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 with open(os.path.join(P, f"{tag}_kernel_stats_summary.txt"), "w") as fh:
-    fh.write("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-kernel-events\n")
+    fh.write("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-kernel-events "
+             "(tools/collect_profiles.sh)\n")
     fh.write(f"GPU busy per training step: {tot / 1e6 / n_steps:.2f} ms ({n_steps} steps incl. warm-up)\n\n")
     for r in rows[:40]:
         fh.write(f"{short(r['Name'])[:60]:60s} calls/step={int(r['Calls']) / n_steps:7.1f} ms/step={float(r['TotalDurationNs']) / 1e6 / n_steps:7.3f} "
@@ -47,7 +48,7 @@ def load(path):
 sq = load(os.path.join(G, "pmc_final1", "*", "*_counter_collection.csv"))
 with open(os.path.join(P, f"{tag}_pmc_sq.txt"), "w") as fh:
     fh.write("rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU "
-             "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT -- python3 bench.py --steps 4 --warmup 1 (sums over all dispatches;\n"
+             "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT -- python3 bench.py --steps 8 --warmup 2 (sums over all dispatches;\n"
              "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* in quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES in cycles)\n\n")
     for n, c in sorted(sq.items(), key=lambda kv: -sum(kv[1]["SQ_WAVE_CYCLES"])):
         wc = sum(c["SQ_WAVE_CYCLES"])
@@ -59,7 +60,7 @@ with open(os.path.join(P, f"{tag}_pmc_sq.txt"), "w") as fh:
                  f"lds_bank_conflict={sum(c['SQ_LDS_BANK_CONFLICT']):.3e}\n")
 fe = load(os.path.join(G, "pmc_final2", "*", "*_counter_collection.csv"))
 wr = load(os.path.join(G, "pmc_final3", "*", "*_counter_collection.csv"))
-out = {"_source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) on `bench.py --steps 4 --warmup 1`; "
+out = {"_source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) on `bench.py --steps 8 --warmup 2` (tools/collect_profiles.sh); "
                   "hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 averaged over launches (gfx950: FETCH_SIZE "
                   "counts half of a 16-B/lane stream -- MI355X_MICROARCH.md 'HBM'; Infinity-Cache hits are included)"}
 for n in fe:

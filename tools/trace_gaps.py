@@ -1,46 +1,32 @@
-"""DIAGNOSTIC: per-step GPU busy time, idle gaps and top kernels from a rocprofv3 --kernel-trace sqlite DB.
-usage: python tools/trace_gaps.py gpurun_out/prof_final/r_results.db [n_steps]"""
-import collections
-import re
-import sqlite3
+"""GPU idle time between consecutive kernels, from a rocprofv3 --kernel-trace CSV (per queue and overall).
+usage: python tools/trace_gaps.py <..._kernel_trace.csv> [skip_fraction]"""
+import csv
 import sys
+from collections import defaultdict
 
-db = sqlite3.connect(sys.argv[1])
-N = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-cur = db.cursor()
-tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
-kd = [t for t in tabs if "kernel_dispatch" in t][0]
-ks = [t for t in tabs if "kernel_symbol" in t][0]
-rows = cur.execute(f"select s.kernel_name, d.start, d.end from {kd} d join {ks} s on d.kernel_id = s.id order by d.start").fetchall()
-
-
-def short(n):
-    n = re.sub(r"^void ", "", n.split("(")[0]).replace("gcl::", "")
-    m = re.match(r"_ZN3gcl\d+([a-z_0-9]+?)(I[^E]*E)?E", n)
-    return (m.group(1) + (m.group(2) or "")) if m else n[:50]
-
-
-# the last step = from the last k_coords_insert to the end
-starts = [i for i, r in enumerate(rows) if "k_coords_insert" in r[0]]
-lo, hi = starts[-2], starts[-1]
-step = rows[lo:hi]
-wall = step[-1][2] - step[0][1]
-busy = sum(e - s for _, s, e in step)
-print(f"last full step: {len(step)} kernels, wall {wall / 1e6:.2f} ms, busy {busy / 1e6:.2f} ms, idle {(wall - busy) / 1e6:.2f} ms")
-gaps = []
-for a, b in zip(step[:-1], step[1:]):
-    g = b[1] - a[2]
-    if g > 0:
-        gaps.append((g, short(a[0]), short(b[0])))
-gaps.sort(reverse=True)
-print("largest gaps (us): ", [(round(g / 1e3, 1), a, b) for g, a, b in gaps[:12]])
-hist = collections.Counter()
-for g, _, _ in gaps:
-    hist["<2us" if g < 2e3 else "<5us" if g < 5e3 else "<10us" if g < 1e4 else "<50us" if g < 5e4 else ">=50us"] += g
-print("idle by gap size (ms):", {k: round(v / 1e6, 2) for k, v in hist.items()})
-tot = collections.defaultdict(lambda: [0, 0])
-for n, s, e in step:
-    tot[short(n)][0] += 1
-    tot[short(n)][1] += e - s
-for n, v in sorted(tot.items(), key=lambda kv: -kv[1][1])[:40]:
-    print(f"{n:50s} calls={v[0]:4d} ms={v[1] / 1e6:7.3f} avg_us={v[1] / v[0] / 1e3:8.1f}")
+rows = list(csv.DictReader(open(sys.argv[1])))
+skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.3
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+rows = rows[int(len(rows) * skip):]                      # steady state only
+t0, t1 = int(rows[0]["Start_Timestamp"]), max(int(r["End_Timestamp"]) for r in rows)
+span = t1 - t0
+by_q = defaultdict(list)
+for r in rows:
+    by_q[r.get("Queue_Id", "0")].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+print(f"{len(rows)} dispatches over {span / 1e6:.2f} ms")
+for q, iv in sorted(by_q.items(), key=lambda kv: -len(kv[1])):
+    busy = sum(e - s for s, e in iv)
+    gaps = [iv[i + 1][0] - iv[i][1] for i in range(len(iv) - 1)]
+    pos = [g for g in gaps if g > 0]
+    small = [g for g in pos if g < 50_000]
+    print(f"queue {q}: {len(iv)} dispatches, busy {busy / 1e6:.2f} ms ({busy / span * 100:.1f} % of the span), "
+          f"gaps < 50 us: {len(small)} totalling {sum(small) / 1e6:.2f} ms (median {sorted(small)[len(small) // 2] / 1e3 if small else 0:.1f} us), "
+          f"gaps >= 50 us: {len(pos) - len(small)} totalling {(sum(pos) - sum(small)) / 1e6:.2f} ms")
+# union over all queues: time during which NO kernel runs
+ev = sorted((s, e) for iv in by_q.values() for s, e in iv)
+idle, cur = 0, ev[0][1]
+for s, e in ev[1:]:
+    if s > cur:
+        idle += s - cur
+    cur = max(cur, e)
+print(f"no kernel running on any queue: {idle / 1e6:.2f} ms = {idle / span * 100:.1f} % of the span")
