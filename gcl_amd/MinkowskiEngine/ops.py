@@ -219,11 +219,13 @@ def ctypes_offset(t, elem):
 
 
 def _conv_launch(lib, x, Wk, mode, table, n_out, cin, cout, bias, pairs=0, want_stats=False, x_amax=None,
-                 w_amax=None, wp=None, x_planes=None, generic=False):
+                 w_amax=None, wp=None, x_planes=None, generic=False, add=None):
     """One output-stationary convolution launch.  ``Wk`` [K, *, *] is packed for ``mode`` (0 forward, 1 transposed,
     2 transposed + mirrored offsets) in the current precision; ``table`` = (tbl, order, tile_mask) from
     KernelMap.sorted_table(), or None for a kernel_size-1 conv; (cin, cout) are the EFFECTIVE widths of the launch.
-    ``want_stats``: also return the per-workgroup column sums [ceil(n_out/128), 2, cout] for a following BatchNorm."""
+    ``want_stats``: also return the per-workgroup column sums [ceil(n_out/128), 2, cout] for a following BatchNorm.
+    ``add`` [n_out, cout] (split-precision MFMA kernels only): added to the result in the epilogue (a gradient that
+    already reached the same tensor through another path: saves the separate accumulation pass)."""
     prec = _PREC_CODES[PRECISION]
     K, wc_in, wc_out = Wk.shape
     if prec == 4 and not generic:
@@ -253,10 +255,17 @@ def _conv_launch(lib, x, Wk, mode, table, n_out, cin, cout, bias, pairs=0, want_
             _lib.check(lib.gcl_conv_fwd_halo(_lib.ptr(x, torch.float32), x.shape[0], _lib.ptr(wp), prec, _lib.ptr(x_amax),
                                              _lib.ptr(w_amax), _lib.ptr(halo[0]), _lib.ptr(halo[1]), _lib.ptr(halo[2]),
                                              _lib.ptr(order), _lib.ptr(tile_mask), n_out, K, cin, cout, _lib.ptr(bias),
-                                             None, None, 0, None, _lib.ptr(y), _lib.ptr(stats), _lib.stream()),
+                                             None, _lib.ptr(add), 0, None, _lib.ptr(y), _lib.ptr(stats), _lib.stream()),
                        "gcl_conv_fwd_halo")
             return (y, stats) if want_stats else y
         xin, is_planes = (x_planes, 1) if x_planes is not None else (x, 0)
+        if add is not None:
+            _lib.check(lib.gcl_conv_fwd_fused(_lib.ptr(xin), x.shape[0], is_planes, _lib.ptr(wp), prec, _lib.ptr(x_amax),
+                                              _lib.ptr(w_amax), _lib.ptr(tbl), _lib.ptr(order), _lib.ptr(tile_mask), n_out,
+                                              K, cin, cout, _lib.ptr(bias), None, _lib.ptr(add, torch.float32), 0, None,
+                                              _lib.ptr(y), _lib.ptr(stats), getattr(tbl, "_gcl_flags", 0), _lib.stream()),
+                       "gcl_conv_fwd_fused")
+            return (y, stats) if want_stats else y
         _lib.check(lib.gcl_conv_fwd(_lib.ptr(xin), x.shape[0], is_planes, _lib.ptr(wp), prec, _lib.ptr(x_amax),
                                     _lib.ptr(w_amax), _lib.ptr(tbl), _lib.ptr(order), _lib.ptr(tile_mask), n_out, K,
                                     cin, cout, _lib.ptr(bias), _lib.ptr(y), _lib.ptr(stats),
@@ -352,8 +361,13 @@ class _SparseConvFn(torch.autograd.Function):
             group = ctx.group
             wp = group.packed(lib, ctx.param, mode) if group is not None else None
             dyp = planes_of(lib, dy, dy_amax) if (fp16x3 and _want_planes(cout)) else None
+            acc = getattr(ctx, "dx_accumulate", None)       # Tape: a gradient that already reached x through another path
+            if acc is not None and (generic or prec == 0 or acc.shape != (x.shape[0], cin) or not acc.is_contiguous()
+                                    or acc.dtype != torch.float32):
+                acc = None
+            ctx.dx_accumulated = acc is not None
             dx = _conv_launch(lib, dy, Wk, mode, tbl, x.shape[0], cout, cin, None, ctx.pairs, x_amax=dy_amax,
-                              w_amax=w_amax, wp=wp, x_planes=dyp, generic=generic)
+                              w_amax=w_amax, wp=wp, x_planes=dyp, generic=generic, add=acc)
         if ctx.needs_input_grad[1]:
             dW = torch.empty_like(Wk)
             if ctx.stem:
@@ -583,8 +597,12 @@ class Tape:
                 c1, c2, x, res, (W, bw, bb) = e[2], e[3], e[4], e[5], e[6]
                 r = _BatchNormFn.backward(c2, g.contiguous())
                 c1.needs_input_grad = (id(x) in self.made, True, False)
+                c1.dx_accumulate = grads.get(id(x)) if FUSE_GRAD_ADD else None
                 dx, dW = _SparseConvFn.backward(c1, r[0], None)[:2]
-                give(x, dx)
+                if getattr(c1, "dx_accumulated", False):
+                    grads[id(x)] = dx                    # the launch's epilogue added the gradient that was waiting
+                else:
+                    give(x, dx)
                 give(res, r[8])
                 pgive(W, dW)
                 pgive(bw, r[1])
@@ -592,8 +610,12 @@ class Tape:
             elif kind == "conv":
                 c1, x, (W, b) = e[2], e[3], e[4]
                 c1.needs_input_grad = (id(x) in self.made, True, b is not None)
+                c1.dx_accumulate = grads.get(id(x)) if FUSE_GRAD_ADD else None
                 dx, dW, db = _SparseConvFn.backward(c1, g, None)[:3]
-                give(x, dx)
+                if getattr(c1, "dx_accumulated", False):
+                    grads[id(x)] = dx
+                else:
+                    give(x, dx)
                 pgive(W, dW)
                 pgive(b, db)
             elif kind == "relu":
@@ -611,6 +633,9 @@ class Tape:
 
 _TAPE = None
 TAPE_ENABLED = os.environ.get("GCL_TAPE", "1") == "1"
+# Tape backward: a convolution's input gradient lands on a tensor that already holds a gradient from another path (the
+# residual branch of a block, a skip connection) -> the waiting gradient is added in the launch's epilogue
+FUSE_GRAD_ADD = os.environ.get("GCL_FUSE_GRAD_ADD", "1") == "1"
 
 
 class tape:

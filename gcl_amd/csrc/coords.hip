@@ -976,7 +976,7 @@ int gcl_table_sort_pre(const int32_t* tbl, int32_t K, int64_t n, int32_t window,
     // at most three 8-bit passes: a 27-offset mask is ordered by its 24 most significant bits (offsets 3..26); the
     // three dropped bits only permute rows inside runs that already share 24 bits (measured: MFMA work unchanged,
     // one pass of ~45 us per table saved)
-    constexpr int max_passes = 3;
+    static const int max_passes = [] { const char* e = getenv("GCL_SORT_PASSES"); int v = e ? atoi(e) : 3; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
     int base = 0;
     if (passes > max_passes) {
       base = K - 8 * max_passes;
