@@ -28,6 +28,7 @@ DEFAULT_CONFIG = dict(
     model="ResUNetBN2C", model_n_out=32, conv1_kernel_size=5, normalize_feature=True, bn_momentum=0.05,
     optimizer="SGD", lr=0.1, momentum=0.8, weight_decay=1e-4, exp_gamma=0.99,
     batch_size=4, num_pos_per_batch=256, num_hn_samples_per_batch=256, iter_size=1,
+    hit_ratio_thresh=0.3, val_max_iter=400, nn_max_n=500,
     pos_thresh=0.1, neg_thresh=1.4, finest_thresh=0.2, pos_weight=1.0, neg_weight=1.0, finest_weight=1.0,
     square_loss=True, block_finest_gradient=False, use_hard_negative=True, use_pair_group_positive_loss=False,
     use_group_circle_loss=False, safe_radius=0.75, voxel_size=0.3,
@@ -479,6 +480,61 @@ class FinestContrastiveLossTrainer:
                     wt[2] += 1
                 refill()
                 yield self.train_step(cur if k > 1 else cur[0], draws if k > 1 else draws[0])
+
+    # ---- validation step (``_valid_epoch`` :306-379) -----------------------------------------------------------
+    @staticmethod
+    def apply_transform(pts, trans):
+        """lib/colocation_trainer.py:234-239."""
+        return pts @ trans[:3, :3].t() + trans[:3, 3]
+
+    def find_corr(self, xyz0, xyz1, F0, F1, subsample_size=-1):
+        """lib/colocation_trainer.py:381-395 (np.random.choice subsample of both clouds, then feature 1-NN)."""
+        from gcl_amd.lib.eval import find_corr
+        return find_corr(xyz0, xyz1, F0, F1, subsample_size=subsample_size, nn_max_n=getattr(self.config, "nn_max_n", 500))
+
+    def evaluate_hit_ratio(self, xyz0, xyz1, T_gth, thresh=0.1):
+        """lib/colocation_trainer.py:397-400."""
+        moved = self.apply_transform(xyz0, T_gth)
+        dist = torch.sqrt(((moved - xyz1) ** 2).sum(1) + 1e-6)
+        return (dist < thresh).float().mean().item()
+
+    def _valid_epoch(self, val_batches, val_max_iter=None):
+        """``_valid_epoch`` (lib/colocation_trainer.py:306-379) over ``val_batches`` (pair dicts of
+        ``collate_debug_pair_fn``: sinput{0,1}_C / _F, pcd0 / pcd1, T_gt): eval-mode features of both clouds (ONE
+        forward pass per pair: bitwise equal to the reference's two, ``scripts.test_kitti.forward_clouds``), feature
+        1-NN correspondences on 5000-row subsamples, ``est_quad_linear_robust``, and the five meters the reference
+        returns.  The dataset shell (``reset_seed``, timers, logging) stays with the caller."""
+        from gcl_amd.lib.metrics import corr_dist
+        from gcl_amd.scripts.test_kitti import AverageMeter, forward_clouds
+        from gcl_amd.util.transform_estimation import est_quad_linear_robust
+        self.model.eval()
+        limit = getattr(self.config, "val_max_iter", -1) if val_max_iter is None else val_max_iter
+        hit_ratio_meter, feat_match_ratio, loss_meter, rte_meter, rre_meter = (AverageMeter() for _ in range(5))
+        num_data = 0
+        with torch.no_grad(), torch.cuda.device(self.device):
+            for input_dict in val_batches:
+                if 0 < limit <= num_data:
+                    break
+                dev = self.device
+                F0, F1 = forward_clouds(self.model, [(input_dict["sinput0_F"].to(dev), input_dict["sinput0_C"].to(dev).int()),
+                                                     (input_dict["sinput1_F"].to(dev), input_dict["sinput1_C"].to(dev).int())])
+                xyz0, xyz1, T_gt = input_dict["pcd0"][0], input_dict["pcd1"][0], input_dict["T_gt"]
+                T_gt = torch.as_tensor(T_gt).float().reshape(4, 4)
+                xyz0_corr, xyz1_corr = self.find_corr(xyz0, xyz1, F0, F1, subsample_size=5000)
+                T_est = est_quad_linear_robust(xyz0_corr, xyz1_corr)
+                loss_meter.update(float(corr_dist(T_est, T_gt, xyz0, xyz1, weight=None)))
+                rte_meter.update(float(np.linalg.norm((T_est[:3, 3] - T_gt[:3, 3]).numpy())))
+                with np.errstate(invalid="ignore"):
+                    rre = float(np.arccos((float(torch.trace(T_est[:3, :3].t() @ T_gt[:3, :3])) - 1) / 2))
+                if not np.isnan(rre):
+                    rre_meter.update(rre)
+                hit_ratio = self.evaluate_hit_ratio(xyz0_corr, xyz1_corr, T_gt,
+                                                    thresh=getattr(self.config, "hit_ratio_thresh", 0.3))
+                hit_ratio_meter.update(hit_ratio)
+                feat_match_ratio.update(float(hit_ratio > 0.05))
+                num_data += 1
+        return {"loss": loss_meter.avg, "rre": rre_meter.avg, "rte": rte_meter.avg,
+                "feat_match_ratio": feat_match_ratio.avg, "hit_ratio": hit_ratio_meter.avg, "n": num_data}
 
     def train_step(self, input_dict, draws=None):
         """One optimizer step.  ``input_dict``: one batch, or a list of ``iter_size`` batches whose gradients are

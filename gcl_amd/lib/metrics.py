@@ -1,4 +1,4 @@
-"""Pairwise feature distances (interface of lib/metrics.py:22-29).
+"""Pairwise feature distances and the validation metric (interface of lib/metrics.py:13-29).
 
 ``pdist`` keeps the reference's signature and returns the full [M, M'] matrix (torch ops, compatibility only);
 the hot path never materialises it: ``pdist_min`` returns the row minimum and arg-minimum from one HIP kernel
@@ -7,6 +7,17 @@ the hot path never materialises it: ``pdist_min`` returns the row minimum and ar
 import torch
 
 from gcl_amd import _lib
+
+
+def corr_dist(est, gth, xyz0, xyz1, weight=None, max_dist=1):
+    """Mean (clamped) distance between the points moved by the estimated and by the true transformation
+    (lib/metrics.py:13-19; the validation step's "loss", lib/colocation_trainer.py:343).  ``xyz1`` is unused, as there."""
+    moved_est = xyz0 @ est[:3, :3].t() + est[:3, 3]
+    moved_gth = xyz0 @ gth[:3, :3].t() + gth[:3, 3]
+    dists = torch.clamp(torch.sqrt(((moved_est - moved_gth) ** 2).sum(1)), max=max_dist)
+    if weight is not None:
+        dists = weight * dists
+    return dists.mean()
 
 
 def pdist(A, B, dist_type="L2"):

@@ -47,7 +47,7 @@ def apply_transform(pts, trans):
 def evaluate_nn_dist(xyz0, xyz1, T_gth):
     """scripts/test_kitti.py:50-53."""
     xyz0 = apply_transform(xyz0, T_gth)
-    return np.sqrt(((xyz0 - xyz1) ** 2).sum(1) + 1e-6).tolist()
+    return torch.sqrt(((torch.as_tensor(xyz0) - torch.as_tensor(xyz1)) ** 2).sum(1) + 1e-6).tolist()
 
 
 def random_sample(pcd, feats, N):

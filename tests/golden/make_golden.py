@@ -15,6 +15,8 @@ draws, outputs, gradients).  What is captured, and from where:
 * ``HardestContrastiveLossTrainer.contrastive_hardest_negative_loss``  lib/trainer.py:410-462  (FCGF baseline)
 * ``Matcher.SC2_PCR``                                      scripts/SC2_PCR/SC2_PCR.py:304-381 (KITTI config)
 * ``FinestContrastiveLossTrainer.location_circle_loss``    lib/colocation_trainer.py:538-681 (all switches)
+* ``util.transform_estimation.est_quad_linear_robust``     util/transform_estimation.py:97-126, ``lib.metrics.corr_dist``
+  (lib/metrics.py:13-19), ``evaluate_hit_ratio`` (lib/colocation_trainer.py:397-400): the validation step's host half
 
 Third-party modules the reference imports but that are absent here (MinkowskiEngine, open3d,
 tensorboardX, easydict) are replaced by EMPTY stub modules -- none of their code is on this path.
@@ -299,8 +301,42 @@ def sc2pcr_golden():
         print("sc2pcr", seed, N, ratio, float(np.abs(est - T).max()))
 
 
+def validation_golden(Trainer):
+    """The validation step's host arithmetic (lib/colocation_trainer.py:306-400): util.transform_estimation.
+    est_quad_linear_robust (util/transform_estimation.py:97-126: 20 re-weighted Gauss-Newton steps on the small-angle
+    linearisation), lib.metrics.corr_dist (lib/metrics.py:13-19) and the trainer's evaluate_hit_ratio (:397-400), on
+    correspondence sets with outliers (the same generator as the SC2-PCR problems, smaller motions: the estimator is a
+    local one)."""
+    from util import transform_estimation as te
+    from lib.metrics import corr_dist
+    tr = Trainer.__new__(Trainer)
+    for seed, N, ratio, ang, noise in [(0, 1200, 0.2, 0.05, 0.02), (1, 3000, 0.45, -0.12, 0.05), (2, 400, 0.0, 0.2, 0.0)]:
+        rng = np.random.RandomState(100 + seed)
+        src = rng.uniform(-20, 20, (N, 3)).astype(np.float32)
+        c, s_ = np.cos(ang), np.sin(ang)
+        R = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]]) @ np.array([[1, 0, 0], [0, np.cos(ang / 2), -np.sin(ang / 2)],
+                                                                      [0, np.sin(ang / 2), np.cos(ang / 2)]])
+        t = np.array([0.8, -0.3 * seed, 0.1])
+        tgt = (src @ R.T + t + rng.normal(0, noise, (N, 3))).astype(np.float32)
+        out = rng.rand(N) < ratio
+        tgt[out] = (src[out] + rng.uniform(-6, 6, (int(out.sum()), 3))).astype(np.float32)
+        T = np.eye(4, dtype=np.float32)
+        T[:3, :3], T[:3, 3] = R, t
+        a, b, Tg = torch.from_numpy(src), torch.from_numpy(tgt), torch.from_numpy(T)
+        est = te.est_quad_linear_robust(a, b)
+        w = torch.from_numpy(rng.rand(N, 1).astype(np.float32))
+        est_w = te.est_quad_linear_robust(a, b, w)
+        loss = corr_dist(est, Tg, a, b, weight=None)
+        hit = tr.evaluate_hit_ratio(a, b, Tg, thresh=0.3)
+        np.savez_compressed(os.path.join(HERE, f"validation_s{seed}.npz"), src=src, tgt=tgt, T_gt=T, T_ref=est.numpy(),
+                            weight=w.numpy(), T_ref_weighted=est_w.numpy(), corr_dist=float(loss), hit_ratio=float(hit),
+                            hit_thresh=0.3)
+        print("validation", seed, N, ratio, float((est - Tg).abs().max()), float(loss), hit)
+
+
 if __name__ == "__main__":
     main()
     hardest_golden()
     sc2pcr_golden()
     circle_golden(*_TRAINER_AND_HASH)
+    validation_golden(_TRAINER_AND_HASH[0])

@@ -330,6 +330,61 @@ def _twin_pair(seed, shift_voxels=(8, 0, 0), voxel=0.3):
             "T_gt": T}
 
 
+def test_valid_epoch_matches_the_oracle_chain():
+    """``_valid_epoch`` (lib/colocation_trainer.py:306-379): meters of the packaged validation step against the CPU chain
+    me_oracle.resunet_forward -> loss_oracle.find_nn -> transform_oracle.est_quad_linear_robust on the same seeded
+    draws (find_corr's two np.random.choice calls per pair, :385-388)."""
+    from gcl_amd.lib.colocation_trainer import FinestContrastiveLossTrainer, make_config
+    from oracle import transform_oracle as TO
+    torch.manual_seed(5)
+    tr = FinestContrastiveLossTrainer(make_config(hit_ratio_thresh=0.3), device=DEV)
+    m = tr.model
+    m.eval()
+    st = {k: v.detach().cpu().double() for k, v in m.state_dict().items() if "num_batches" not in k}
+    # small motions (the estimator is a local one): twins shifted by 8 voxels = 2.4 m would be outside its basin, so the
+    # second cloud is the first one with the SAME voxel grid and the metric points moved by a small rigid motion
+    pairs = []
+    for seed, ang, t in [(70, 0.03, (0.25, -0.1, 0.05)), (71, -0.05, (-0.2, 0.15, 0.0))]:
+        d = _twin_pair(seed, (0, 0, 0))
+        c, s_ = np.cos(ang), np.sin(ang)
+        T = torch.eye(4)
+        T[:3, :3] = torch.tensor([[c, -s_, 0.0], [s_, c, 0.0], [0.0, 0.0, 1.0]])
+        T[:3, 3] = torch.tensor(t)
+        d["pcd1"] = (d["pcd0"][0] @ T[:3, :3].t() + T[:3, 3],)
+        d["T_gt"] = T
+        pairs.append(d)
+    np.random.seed(21)
+    out = tr._valid_epoch(pairs)
+    assert out["n"] == 2 and not m.training
+    np.random.seed(21)
+    loss, rte, rre, hit = [], [], [], []
+    for d in pairs:
+        Fs = [O.resunet_forward(st, d[f"sinput{k}_C"].numpy(), d[f"sinput{k}_F"].double(), 5, True, False, 0.05).float()
+              for k in (0, 1)]
+        xyz0, xyz1 = d["pcd0"][0].numpy(), d["pcd1"][0].numpy()
+        n0, n1 = len(Fs[0]), len(Fs[1])
+        if n0 > 5000:
+            i0 = np.random.choice(n0, min(n0, 5000), replace=False)
+            i1 = np.random.choice(n1, min(n1, 5000), replace=False)
+        else:
+            i0, i1 = np.arange(n0), np.arange(n1)
+        nn = LO.find_nn(Fs[0][i0], Fs[1][i1], nn_max_n=-1).numpy()
+        a, b = xyz0[i0], xyz1[i1[nn]]
+        T_o = TO.est_quad_linear_robust(a, b)
+        Tg = d["T_gt"].numpy()
+        loss.append(TO.corr_dist(T_o, Tg, xyz0))
+        rte.append(float(np.linalg.norm(T_o[:3, 3] - Tg[:3, 3])))
+        with np.errstate(invalid="ignore"):
+            r = float(np.arccos((np.trace(T_o[:3, :3].T @ Tg[:3, :3]) - 1) / 2))
+        if not np.isnan(r):                                   # the reference's meter skips NaN (:349-351)
+            rre.append(r)
+        hit.append(TO.hit_ratio(a, b, Tg, 0.3))
+    assert abs(out["loss"] - np.mean(loss)) < 2e-3 and abs(out["rte"] - np.mean(rte)) < 2e-3
+    assert abs(out["hit_ratio"] - np.mean(hit)) < 2e-3 and out["feat_match_ratio"] == 1.0
+    assert abs(out["rre"] - (np.mean(rre) if rre else 0.0)) < 4e-3
+    assert out["rte"] < 0.05 and out["hit_ratio"] > 0.9          # an untrained net on twin clouds: the motion is found
+
+
 def test_eval_pairs_matches_the_oracle_chain_and_batching_is_bitwise_neutral():
     """scripts/test_kitti.py:129-227 as gcl_amd.scripts.test_kitti.eval_pairs: composed T of every pair against the CPU
     chain me_oracle.resunet_forward -> loss_oracle.find_nn -> sc2pcr_oracle.sc2_pcr on the same seeded draws (same
