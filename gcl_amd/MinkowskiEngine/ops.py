@@ -247,9 +247,10 @@ def _conv_launch(lib, x, Wk, mode, table, n_out, cin, cout, bias, pairs=0, want_
         nb = lib.gcl_conv_fwd_nb(n_out, cout, prec)
         pre = "true" if x_planes is not None else "false"
         name = "k_conv_generic" if generic else \
-            (f"k_conv_fwd<{nb}>" if prec == 0 else f"k_conv_fwd_split<{nb},{prec},{pre},false>")
+            (f"k_conv_fwd<{nb}>" if prec == 0 else
+             f"k_conv_fwd_split<{nb},{prec},{pre},{'true' if add is not None else 'false'}>")
         if halo is not None:
-            name = f"k_conv_fwd_halo<{2 if cout % 64 == 0 else 1},{prec},false>"
+            name = f"k_conv_fwd_halo<{2 if cout % 64 == 0 else 1},{prec},{'true' if add is not None else 'false'}>"
     with _Timed(name, pairs, cin, cout, x.shape[0], n_out, K):
         if halo is not None:
             _lib.check(lib.gcl_conv_fwd_halo(_lib.ptr(x, torch.float32), x.shape[0], _lib.ptr(wp), prec, _lib.ptr(x_amax),
