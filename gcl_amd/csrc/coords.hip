@@ -429,6 +429,63 @@ __global__ void k_row_masks(const int* __restrict__ tbl, int K, long long n, uns
   vals[v] = (int)v;
 }
 
+// bit_count[k] (32 zero-initialised ints) += number of rows whose mask has offset k.  A small fixed grid walks the
+// masks, every thread counts in registers, the workgroup adds up in LDS and issues ONE integer atomic per offset
+// (64 x 27 atomics per table: same-address atomics serialise at ~10 ns each, one per wave cost 2 ms per table)
+__global__ void __launch_bounds__(256) k_mask_bit_count(const unsigned* __restrict__ keys, long long n, int K, int* bit_count) {
+  __shared__ int tot[32];
+  if (threadIdx.x < 32) tot[threadIdx.x] = 0;
+  __syncthreads();
+  int c[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) c[k] = 0;
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long long)gridDim.x * blockDim.x) {
+    const unsigned m = keys[v];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) c[k] += (int)((m >> k) & 1u);
+  }
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    int x = c[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    if ((threadIdx.x & 63) == 0 && x) atomicAdd(&tot[k], x);
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < K && tot[threadIdx.x]) atomicAdd(&bit_count[threadIdx.x], tot[threadIdx.x]);
+}
+
+// Sort key = the mask with its bits re-ordered by how often each offset occurs in THIS table: the rarest offset
+// becomes the most significant bit, the most frequent one the least significant (ties: lower offset index lower).
+// Rows that own a rare offset then sit together, so the unit that offset costs is shared by a whole tile, while the
+// trailing (frequent) bits are set in most rows anyway.  Measured on the KITTI batch against the offset-index order:
+// 7.75 vs 8.26 units per 32-row tile at tensor stride 1, 9.88 vs 10.99 at stride 4, 11.41 vs 13.11 at stride 8
+// (exact sparse work: 6.3 / 7.3 / 7.7).  pos[k] = key bit of offset k, written for k_tile_masks.
+__global__ void __launch_bounds__(256) k_mask_keys(unsigned* keys, long long n, int K, const int* __restrict__ bit_count,
+                                                   int* pos_out) {
+  __shared__ int pos[32];
+  if (threadIdx.x < 32) {
+    const int k = threadIdx.x;
+    int p = 0;
+    if (k < K) {
+      const int ck = bit_count[k];
+      for (int j = 0; j < K; ++j) {
+        const int cj = bit_count[j];
+        p += (cj > ck || (cj == ck && j < k)) ? 1 : 0;
+      }
+    }
+    pos[k] = p;
+    if (blockIdx.x == 0 && k < K) pos_out[k] = p;
+  }
+  __syncthreads();
+  long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n) return;
+  const unsigned m = keys[v];
+  unsigned key = 0;
+  for (int k = 0; k < K; ++k) key |= ((m >> k) & 1u) << pos[k];
+  keys[v] = key;
+}
+
 __global__ void __launch_bounds__(64) k_radix_hist(const unsigned* __restrict__ keys, long long n, int shift,
                                                    int nblk, int* hist) {
   __shared__ int cnt[256];
@@ -750,14 +807,20 @@ __global__ void k_permute_table(const int* __restrict__ tbl, const int* __restri
   if (j < n) tbl_sorted[(long long)k * n + j] = tbl[(long long)k * n + order[j]];
 }
 
+// pos (optional): the keys are masks with bit k moved to pos[k] (k_mask_keys); the tile mask is returned in offset order
 __global__ void k_tile_masks(const unsigned* __restrict__ keys_sorted, long long n, long long n_tiles,
-                             int* tile_mask) {
+                             int* tile_mask, const int* __restrict__ pos, int K) {
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_tiles) return;
   unsigned m = 0;
   for (int r = 0; r < 32; ++r) {
     long long j = t * 32 + r;
     if (j < n) m |= keys_sorted[j];
+  }
+  if (pos) {
+    unsigned u = 0;
+    for (int k = 0; k < K; ++k) u |= ((m >> pos[k]) & 1u) << k;
+    m = u;
   }
   tile_mask[t] = (int)m;
 }
@@ -910,7 +973,7 @@ int gcl_kernel_map_pairs(const int32_t* nbr, int32_t K, int64_t n_out, const int
 int64_t gcl_table_sort_scratch_len(int64_t n) {
   long long nblk = cdiv(n, RS_BLOCK);
   long long hist = 256 * nblk;
-  return 4 * n + 2 * hist + cdiv(hist, SCAN_B) + 64 + 256;   // keys/vals ping-pong, hist, within, digit totals
+  return 4 * n + 2 * hist + cdiv(hist, SCAN_B) + 64 + 256 + 64;   // keys/vals ping-pong, hist, within, digit totals, offset counts + key bit positions
 }
 
 int gcl_spatial_order(const int32_t* coords, int64_t n, int32_t tensor_stride, int32_t* scratch, int32_t* order,
@@ -955,6 +1018,8 @@ int gcl_table_sort_pre(const int32_t* tbl, int32_t K, int64_t n, int32_t window,
   GCL_CHECK_ARG(window == 0 || window == 2048 || window == 4096, "gcl_table_sort: window must be 0, 2048 or 4096");
   hipStream_t st = (hipStream_t)stream;
   unsigned* ka = (unsigned*)scratch;
+  int* bit_count = nullptr;
+  int* key_pos = nullptr;
   if (window) {
     if (window == 2048)
       hipLaunchKernelGGL(k_window_sort<2048>, dim3((unsigned)cdiv(n, 2048)), dim3(256), 0, st, tbl, K, (long long)n,
@@ -971,7 +1036,18 @@ int gcl_table_sort_pre(const int32_t* tbl, int32_t K, int64_t n, int32_t window,
     int* hist = scratch + 4 * n;
     int* offs = hist + hist_len;
     int* bs = offs + hist_len;
+    static const int freq_order = [] { const char* e = getenv("GCL_SORT_FREQ_ORDER"); return e ? atoi(e) : 1; }();
+    if (freq_order) {
+      bit_count = scratch + gcl_table_sort_scratch_len(n) - 64;
+      key_pos = bit_count + 32;
+      GCL_CHECK_HIP(hipMemsetAsync(bit_count, 0, 32 * sizeof(int32_t), st));
+    }
     hipLaunchKernelGGL(k_row_masks, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, tbl, K, (long long)n, ka, va);
+    if (freq_order) {
+      hipLaunchKernelGGL(k_mask_bit_count, dim3(64), dim3(256), 0, st, (const unsigned*)ka, (long long)n, K, bit_count);
+      hipLaunchKernelGGL(k_mask_keys, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, ka, (long long)n, K,
+                         (const int*)bit_count, key_pos);
+    }
     int passes = (K + 7) / 8;
     // at most three 8-bit passes: a 27-offset mask is ordered by its 24 most significant bits (offsets 3..26); the
     // three dropped bits only permute rows inside runs that already share 24 bits (measured: MFMA work unchanged,
@@ -995,7 +1071,7 @@ int gcl_table_sort_pre(const int32_t* tbl, int32_t K, int64_t n, int32_t window,
   }
   long long n_tiles = cdiv(n, 32);
   hipLaunchKernelGGL(k_tile_masks, dim3((unsigned)cdiv(n_tiles, 256)), dim3(256), 0, st, (const unsigned*)ka,
-                     (long long)n, n_tiles, tile_mask);
+                     (long long)n, n_tiles, tile_mask, (const int*)key_pos, K);
   hipLaunchKernelGGL(k_permute_table, dim3((unsigned)cdiv(n, 256), K), dim3(256), 0, st, tbl, (const int*)order,
                      (long long)n, tbl_sorted);
   GCL_CHECK_LAUNCH();
@@ -1014,7 +1090,7 @@ int gcl_table_sort_halo(const int32_t* tbl, int32_t K, int64_t n, const int32_t*
                      (const int4*)coords, tensor_stride, order, ka);
   long long n_tiles = cdiv(n, 32);
   hipLaunchKernelGGL(k_tile_masks, dim3((unsigned)cdiv(n_tiles, 256)), dim3(256), 0, st, (const unsigned*)ka,
-                     (long long)n, n_tiles, tile_mask);
+                     (long long)n, n_tiles, tile_mask, (const int*)nullptr, K);
   hipLaunchKernelGGL(k_permute_table, dim3((unsigned)cdiv(n, 256), K), dim3(256), 0, st, tbl, (const int*)order,
                      (long long)n, tbl_sorted);
   hipLaunchKernelGGL(k_halo_build, dim3((unsigned)cdiv(n, 128)), dim3(256), 0, st, (const int*)tbl_sorted, (long long)n, K,

@@ -498,8 +498,18 @@ def test_table_sort_is_a_stable_mask_sort(window):
                 for k in range(km.K):
                     mask |= (tbl[k] >= 0).astype(np.int64) << k
                 win = np.arange(n) // window if window else np.zeros(n, dtype=np.int64)
-                # the global radix sort runs at most three 8-bit passes: keys = the 24 most significant mask bits
-                key = mask if window else mask >> max(0, km.K - 24)
+                # the global sort's key: mask bits re-ordered by offset frequency in this table (rarest offset = most
+                # significant bit, ties: lower offset lower), at most three 8-bit radix passes = its 24 top bits
+                if window:
+                    key = mask
+                else:
+                    cnt = np.array([int(((mask >> k) & 1).sum()) for k in range(km.K)])
+                    pos = np.array([int(((cnt > cnt[k]) | ((cnt == cnt[k]) & (np.arange(km.K) < k))).sum())
+                                    for k in range(km.K)])
+                    key = np.zeros_like(mask)
+                    for k in range(km.K):
+                        key |= ((mask >> k) & 1) << pos[k]
+                    key = key >> max(0, km.K - 24)
                 ref_order = np.lexsort((np.arange(n), key, win))
                 assert np.array_equal(order, ref_order)
                 assert np.array_equal(ts, tbl[:, order])
