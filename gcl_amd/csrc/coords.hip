@@ -483,6 +483,8 @@ __global__ void __launch_bounds__(256) k_mask_keys(unsigned* keys, long long n, 
   const unsigned m = keys[v];
   unsigned key = 0;
   for (int k = 0; k < K; ++k) key |= ((m >> k) & 1u) << pos[k];
+  // (taking the key's rank in the reflected Gray-code sequence would save another 2 - 3 % of the units -- measured --
+  // but its pseudo-random low digits turn every radix scatter into 64 single-row writes per wave: +1 .. 2 ms per step)
   keys[v] = key;
 }
 
