@@ -431,7 +431,7 @@ __global__ void k_row_masks(const int* __restrict__ tbl, int K, long long n, uns
 
 // bit_count[k] (32 zero-initialised ints) += number of rows whose mask has offset k.  A small fixed grid walks the
 // masks, every thread counts in registers, the workgroup adds up in LDS and issues ONE integer atomic per offset
-// (64 x 27 atomics per table: same-address atomics serialise at ~10 ns each, one per wave cost 2 ms per table)
+// (512 x 27 atomics per table: same-address atomics serialise at ~10 ns each, one per wave cost 2 ms per table)
 __global__ void __launch_bounds__(256) k_mask_bit_count(const unsigned* __restrict__ keys, long long n, int K, int* bit_count) {
   __shared__ int tot[32];
   if (threadIdx.x < 32) tot[threadIdx.x] = 0;
@@ -1046,7 +1046,7 @@ int gcl_table_sort_pre(const int32_t* tbl, int32_t K, int64_t n, int32_t window,
     }
     hipLaunchKernelGGL(k_row_masks, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, tbl, K, (long long)n, ka, va);
     if (freq_order) {
-      hipLaunchKernelGGL(k_mask_bit_count, dim3(64), dim3(256), 0, st, (const unsigned*)ka, (long long)n, K, bit_count);
+      hipLaunchKernelGGL(k_mask_bit_count, dim3(512), dim3(256), 0, st, (const unsigned*)ka, (long long)n, K, bit_count);
       hipLaunchKernelGGL(k_mask_keys, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, ka, (long long)n, K,
                          (const int*)bit_count, key_pos);
     }
