@@ -921,8 +921,6 @@ __global__ void __launch_bounds__(256, (NB <= 2 ? 3 : 2)) k_conv_fwd_halo(const 
         if (chas) {
           // ---- weight block of the next unit (register set (u + 1) % DEPTH, loaded DEPTH units ago) -> the LDS buffer
           // nobody reads; the set is then refilled with the block DEPTH units further on
-          constexpr int nu = 0;
-          (void)nu;
           GCL_STORE_BH((u + 1) % DEPTH, buf ^ 1);
           if (bhas) {
             GCL_LOAD_BH((u + 1) % DEPTH, bk, bc);
