@@ -476,6 +476,31 @@ def test_full_size_batch_against_oracle_fixture():
     assert rel_l2(m.block4.norm2.bn.running_var.cpu(), z["running_var_block4"]) < 1e-4
 
 
+def test_prefetch_staging_slots_are_reused_only_after_release():
+    """prefetch_to_device: device staging slots are handed out again only after release_batch (an event on the compute
+    stream the copy stream waits for); a consumer that never releases makes the pool grow to 4 x ring and then falls
+    back to re-using the oldest slot behind an event.  Every yielded batch holds its source's values when consumed."""
+    from gcl_amd.lib.colocation_trainer import prefetch_to_device, release_batch, wait_for_batch
+    g = torch.Generator().manual_seed(0)
+    host = [{"sinput_C": torch.randint(0, 100, (1000 - 7 * i, 4), generator=g, dtype=torch.int32),     # never growing:
+             "sinput_F": torch.randn(1000 - 7 * i, 1, generator=g), "tag": i} for i in range(12)]      # slots keep their buffers
+    for release in (True, False):
+        ptrs = set()
+        with torch.cuda.device(DEV):
+            for i, b in enumerate(prefetch_to_device(iter(host), DEV, keys=("sinput_C", "sinput_F"), ring=2)):
+                wait_for_batch(b)
+                assert b["tag"] == i and b["sinput_C"].is_cuda
+                x = b["sinput_F"] * 2.0                      # work on the compute stream that reads the slot
+                assert torch.equal(b["sinput_C"].cpu(), host[i]["sinput_C"])
+                assert torch.equal(x.cpu(), host[i]["sinput_F"] * 2.0)
+                ptrs.add(b["sinput_F"].data_ptr())
+                if release:
+                    release_batch(b)
+        assert len(ptrs) <= (2 if release else 8), (release, len(ptrs))
+        if not release:
+            assert len(ptrs) == 8                            # grew to 4 x ring, then re-used the oldest slots
+
+
 def test_map_prefetch_on_side_stream_changes_nothing():
     """train_steps builds the coordinate manager of batch i+1 (maps, sorted tables, pair lists) on a side stream while
     batch i trains, from host batches copied by prefetch_to_device: losses and parameters equal the lazy path bit for
