@@ -507,10 +507,12 @@ __global__ void __launch_bounds__(256, GCL_FWD_MIN_WAVES(NB, PL)) k_conv_fwd_spl
   mymask = __builtin_amdgcn_readfirstlane(mymask);
   if (l == 0) wmask[w] = mymask;
   // all neighbour indices of the tile go to LDS once: no index load (and no index -> gather dependency) in the loop
+  // only the offsets of the wave's mask are ever looked up: the other table rows are not fetched (a wave tile visits
+  // ~8 of 27 offsets on the KITTI batch: the index table is as large as a C = 32 output tile)
   for (int e = l; e < (K < ISM_H ? K : ISM_H) * 32; e += 64) {
     const int k = e >> 5, r = e & 31;
     int v = -1;
-    if (active && row0 + r < n_out) v = tbl ? tbl[(long long)k * n_out + row0 + r] : (int)(row0 + r);
+    if (active && ((mymask >> k) & 1u) && row0 + r < n_out) v = tbl ? tbl[(long long)k * n_out + row0 + r] : (int)(row0 + r);
     Ism[w][k][(r & 7) * 4 + (r >> 3)] = v;
   }
   int ib[6];                       // entries e = 32 ISM_H + l + 64 j (offsets k = e / 32 >= 15, rows e % 32), j = 0 .. 5
@@ -518,7 +520,7 @@ __global__ void __launch_bounds__(256, GCL_FWD_MIN_WAVES(NB, PL)) k_conv_fwd_spl
   for (int j = 0; j < 6; ++j) {
     const int e = 32 * ISM_H + l + 64 * j, k = e >> 5, r = e & 31;
     int v = -1;
-    if (k < K && active && row0 + r < n_out) v = tbl[(long long)k * n_out + row0 + r];
+    if (k < K && active && ((mymask >> k) & 1u) && row0 + r < n_out) v = tbl[(long long)k * n_out + row0 + r];
     ib[j] = v;
   }
   bool second_half = false;
