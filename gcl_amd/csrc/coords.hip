@@ -802,11 +802,16 @@ __global__ void __launch_bounds__(256) k_halo_build(const int* __restrict__ tbl_
   if (t == 0) hcount[tile] = H;
 }
 
+// tile_mask (optional): an offset missing from a 32-row tile's mask is -1 for all of its rows by definition -- written
+// without the (scattered, 4-byte) read of the source table: ~19 of 27 offsets on the KITTI batch
 __global__ void k_permute_table(const int* __restrict__ tbl, const int* __restrict__ order, long long n,
-                                int* tbl_sorted) {
+                                int* tbl_sorted, const int* __restrict__ tile_mask) {
   long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   int k = blockIdx.y;
-  if (j < n) tbl_sorted[(long long)k * n + j] = tbl[(long long)k * n + order[j]];
+  if (j >= n) return;
+  int v = -1;
+  if (!tile_mask || ((tile_mask[j >> 5] >> k) & 1)) v = tbl[(long long)k * n + order[j]];
+  tbl_sorted[(long long)k * n + j] = v;
 }
 
 // pos (optional): the keys are masks with bit k moved to pos[k] (k_mask_keys); the tile mask is returned in offset order
@@ -1075,7 +1080,7 @@ int gcl_table_sort_pre(const int32_t* tbl, int32_t K, int64_t n, int32_t window,
   hipLaunchKernelGGL(k_tile_masks, dim3((unsigned)cdiv(n_tiles, 256)), dim3(256), 0, st, (const unsigned*)ka,
                      (long long)n, n_tiles, tile_mask, (const int*)key_pos, K);
   hipLaunchKernelGGL(k_permute_table, dim3((unsigned)cdiv(n, 256), K), dim3(256), 0, st, tbl, (const int*)order,
-                     (long long)n, tbl_sorted);
+                     (long long)n, tbl_sorted, (const int*)tile_mask);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }
@@ -1094,7 +1099,7 @@ int gcl_table_sort_halo(const int32_t* tbl, int32_t K, int64_t n, const int32_t*
   hipLaunchKernelGGL(k_tile_masks, dim3((unsigned)cdiv(n_tiles, 256)), dim3(256), 0, st, (const unsigned*)ka,
                      (long long)n, n_tiles, tile_mask, (const int*)nullptr, K);
   hipLaunchKernelGGL(k_permute_table, dim3((unsigned)cdiv(n, 256), K), dim3(256), 0, st, tbl, (const int*)order,
-                     (long long)n, tbl_sorted);
+                     (long long)n, tbl_sorted, (const int*)tile_mask);
   hipLaunchKernelGGL(k_halo_build, dim3((unsigned)cdiv(n, 128)), dim3(256), 0, st, (const int*)tbl_sorted, (long long)n, K,
                      K * 128, hcount, hrows, hloc);
   GCL_CHECK_LAUNCH();
