@@ -814,16 +814,17 @@ __global__ void k_permute_table(const int* __restrict__ tbl, const int* __restri
   tbl_sorted[(long long)k * n + j] = v;
 }
 
-// pos (optional): the keys are masks with bit k moved to pos[k] (k_mask_keys); the tile mask is returned in offset order
-__global__ void k_tile_masks(const unsigned* __restrict__ keys_sorted, long long n, long long n_tiles,
-                             int* tile_mask, const int* __restrict__ pos, int K) {
-  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+// pos (optional): the keys are masks with bit k moved to pos[k] (k_mask_keys); the tile mask is returned in offset order.
+// Lane = row (coalesced key reads), OR over the 32 lanes of a tile by butterfly shuffles.
+__global__ void __launch_bounds__(256) k_tile_masks(const unsigned* __restrict__ keys_sorted, long long n, long long n_tiles,
+                                                    int* tile_mask, const int* __restrict__ pos, int K) {
+  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned m = (j < n) ? keys_sorted[j] : 0u;
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) m |= __shfl_xor(m, o);
+  if ((threadIdx.x & 31) != 0) return;
+  const long long t = j >> 5;
   if (t >= n_tiles) return;
-  unsigned m = 0;
-  for (int r = 0; r < 32; ++r) {
-    long long j = t * 32 + r;
-    if (j < n) m |= keys_sorted[j];
-  }
   if (pos) {
     unsigned u = 0;
     for (int k = 0; k < K; ++k) u |= ((m >> pos[k]) & 1u) << k;
@@ -1077,7 +1078,7 @@ int gcl_table_sort_pre(const int32_t* tbl, int32_t K, int64_t n, int32_t window,
     }
   }
   long long n_tiles = cdiv(n, 32);
-  hipLaunchKernelGGL(k_tile_masks, dim3((unsigned)cdiv(n_tiles, 256)), dim3(256), 0, st, (const unsigned*)ka,
+  hipLaunchKernelGGL(k_tile_masks, dim3((unsigned)cdiv(n_tiles * 32, 256)), dim3(256), 0, st, (const unsigned*)ka,
                      (long long)n, n_tiles, tile_mask, (const int*)key_pos, K);
   hipLaunchKernelGGL(k_permute_table, dim3((unsigned)cdiv(n, 256), K), dim3(256), 0, st, tbl, (const int*)order,
                      (long long)n, tbl_sorted, (const int*)tile_mask);
@@ -1096,7 +1097,7 @@ int gcl_table_sort_halo(const int32_t* tbl, int32_t K, int64_t n, const int32_t*
   hipLaunchKernelGGL(k_halo_sort<4096>, dim3((unsigned)cdiv(n, 4096)), dim3(256), 0, st, tbl, K, (long long)n, pre,
                      (const int4*)coords, tensor_stride, order, ka);
   long long n_tiles = cdiv(n, 32);
-  hipLaunchKernelGGL(k_tile_masks, dim3((unsigned)cdiv(n_tiles, 256)), dim3(256), 0, st, (const unsigned*)ka,
+  hipLaunchKernelGGL(k_tile_masks, dim3((unsigned)cdiv(n_tiles * 32, 256)), dim3(256), 0, st, (const unsigned*)ka,
                      (long long)n, n_tiles, tile_mask, (const int*)nullptr, K);
   hipLaunchKernelGGL(k_permute_table, dim3((unsigned)cdiv(n, 256), K), dim3(256), 0, st, tbl, (const int*)order,
                      (long long)n, tbl_sorted, (const int*)tile_mask);
