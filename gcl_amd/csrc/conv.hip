@@ -474,8 +474,14 @@ __global__ void __launch_bounds__(256, GCL_FWD_MIN_WAVES(NB, PL)) k_conv_fwd_spl
   // swizzle 2 (1-D grid): the cout / (32 NB) column blocks that gather the SAME 128 rows get consecutive slots of one
   // XCD (workgroups are dealt round-robin over the 8 XCDs) and share its L2
   unsigned bxx = blockIdx.x, byy = blockIdx.y;
+  // bit 4 of `swizzle`: process the row tiles in DESCENDING order.  The mask sort puts the rows that own rare offsets
+  // last; their tiles visit 2 - 3x the average number of offsets (per-workgroup union: mean 8.9, p90 17, max 27 at
+  // stride 1), so in ascending order the longest workgroups start last and the launch ends on a thin, slow tail
+  const bool heavy_first = (swizzle & 16) != 0;
+  swizzle &= 15;
+  const unsigned nrw = (unsigned)((n_out + CONV_ROWS - 1) / CONV_ROWS);
   if (swizzle >= 2) {
-    const unsigned ncb = (unsigned)(cout / (32 * NB)), nrw = (unsigned)((n_out + CONV_ROWS - 1) / CONV_ROWS);
+    const unsigned ncb = (unsigned)(cout / (32 * NB));
     const unsigned xcd = bxx & 7u, slot = bxx >> 3;
     byy = slot % ncb;
     if (swizzle == 2) {
@@ -489,6 +495,7 @@ __global__ void __launch_bounds__(256, GCL_FWD_MIN_WAVES(NB, PL)) k_conv_fwd_spl
   } else {
     bxx = xcd_tile(bxx, gridDim.x, swizzle);
   }
+  if (heavy_first) bxx = nrw - 1u - bxx;
   const long long tile = (long long)bxx * 4 + w;
   const long long row0 = tile * 32;
   const bool active = row0 < n_out;
@@ -1029,6 +1036,7 @@ __global__ void __launch_bounds__(256) k_conv_fwd_split2(const float* __restrict
   __shared__ unsigned wmask[4];
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   const int i = l & 31, h = l >> 5;
+  swizzle &= 15;   // (bit 4, heavy tiles first, is a k_conv_fwd_split feature)
   unsigned bxx = blockIdx.x, byy = blockIdx.y;
   if (swizzle >= 2) {
     const unsigned ncb = (unsigned)(cout / (32 * NB)), nrw = (unsigned)((n_out + CONV_ROWS - 1) / CONV_ROWS);
@@ -2072,7 +2080,8 @@ int gcl_conv_fwd_fused(const float* x, int64_t n_in, int32_t x_is_planes, const 
   const bool cg = colgroup && grid.y > 1 && !swz;
   dim3 sgrid = cg ? dim3((unsigned)(cdiv(gx, 8) * 8 * grid.y)) : grid;
   const bool ranges = (flags & GCL_CONV_XCD_RANGES) != 0;     // spatially ordered table: contiguous tile range per XCD
-  const int sswz = cg ? (ranges ? 3 : 2) : (ranges ? 1 : swz);
+  static const int heavy_first = [] { const char* e = getenv("GCL_CONV_HEAVY_FIRST"); return e ? atoi(e) : 1; }();
+  const int sswz = (cg ? (ranges ? 3 : 2) : (ranges ? 1 : swz)) | ((heavy_first && tile_mask && !ranges) ? 16 : 0);
 #define LAUNCH_F32(NBV)                                                                                          \
   hipLaunchKernelGGL(k_conv_fwd<NBV>, grid, dim3(256), 0, st, x, (const float4*)wp, tbl, order, tile_mask,       \
                      (long long)n_out, K, cin, cout, bias, y, swz)
