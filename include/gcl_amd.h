@@ -131,8 +131,12 @@ int gcl_kernel_map_pairs(const int32_t* nbr, int32_t K, int64_t n_out, const int
                          int32_t* scratch, int32_t* pair_in, int32_t* pair_out, void* stream);
 
 /* Row ordering for the output-stationary convolution: sorts the rows of a [K][n] neighbour table (K <= 27) by
- * their K-bit presence mask (stable radix sort; global mode: by the 24 most significant mask bits, i.e. key =
- * mask >> max(0, K - 24), three 8-bit passes), so that the rows of a 32-row wave tile need nearly the same offsets.  order[j] = original row at sorted position j; tbl_sorted[k*n + j] = tbl[k*n + order[j]];
+ * their K-bit presence mask (stable radix sort), so that the rows of a 32-row wave tile need nearly the same offsets.
+ * Global mode: the sort key is the mask with its bits re-ordered by how often each offset occurs in THIS table -- the
+ * rarest offset is the most significant key bit, the most frequent the least significant, ties: lower offset lower --
+ * and the sort runs on the key's 24 most significant bits (key >> max(0, K - 24), three 8-bit passes).  Rows that own a
+ * rare offset then share its visit.  The convolution walks the tiles from the END of this order (the tiles with the
+ * most offsets first).  order[j] = original row at sorted position j; tbl_sorted[k*n + j] = tbl[k*n + order[j]];
  * tile_mask[t] = OR of the masks of sorted rows 32t .. 32t+31.  scratch: int32[gcl_table_sort_scratch_len(n)].
  * window = 0: one global sort.  window = 2048 | 4096: rows are sorted only inside windows of that many consecutive
  * rows (one LDS bitonic sort per window): keeps the loader's spatial coherence for the gathers. */
