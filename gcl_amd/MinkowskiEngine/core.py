@@ -440,6 +440,8 @@ class SparseTensor:
 
     def __iadd__(self, other):          # `out += residual` (model/residual_block.py:50)
         self._same_map(other)
+        from . import ops
+        ops.tape_guard("SparseTensor.__iadd__", self._F, other.F)
         self._F = self._F + other.F
         self._nonneg = False
         self._bn_stats = None          # column sums published by a convolution describe the OLD features
@@ -447,6 +449,8 @@ class SparseTensor:
 
     def __add__(self, other):
         self._same_map(other)
+        from . import ops
+        ops.tape_guard("SparseTensor.__add__", self._F, other.F)
         return SparseTensor(self._F + other.F, coordinate_map_key=self.coordinate_map_key,
                             coordinate_manager=self.coordinate_manager)
 

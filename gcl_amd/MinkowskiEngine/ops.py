@@ -490,8 +490,21 @@ class _BatchNormFn(torch.autograd.Function):
         return dx, sum_gx, sum_g, None, None, None, None, None, dres, None, None
 
 
+def tape_guard(what, *tensors):
+    """While a Tape is active only the tape-aware entry points may consume a tensor the tape produced: anything else
+    (a stand-alone BatchNorm after a frozen / biased convolution, ``a + b`` on SparseTensors, ...) would put an
+    ordinary autograd node behind a tensor that has no autograd history, and Tape.backward would silently drop the
+    gradient of everything upstream.  Fail loudly instead; ``GCL_TAPE=0`` (or eval-mode submodules, which
+    ResUNet2.forward detects itself) selects the per-layer autograd path."""
+    if _TAPE is not None and any(t is not None and id(t) in _TAPE.made for t in tensors):
+        raise RuntimeError(f"{what} consumed a tensor recorded by the whole-network Tape, which only knows conv_bn / "
+                           "sparse_conv / relu / cat / l2_normalize_rows; run this model with GCL_TAPE=0 "
+                           "(gcl_amd.MinkowskiEngine.ops.TAPE_ENABLED = False)")
+
+
 def batch_norm(x, weight, bias, running_mean, running_var, training, momentum, eps, residual=None, relu=False,
                tile_stats=None):
+    tape_guard("MinkowskiBatchNorm", x, residual)
     y = _BatchNormFn.apply(x, weight, bias, running_mean, running_var, training, momentum, eps, residual, relu,
                            tile_stats)
     if _LAST_BN_AMAX is not None:
@@ -813,6 +826,7 @@ class _InstanceNormFn(torch.autograd.Function):
 
 
 def instance_norm(x, weight, bias, segments, eps=1e-8, residual=None, relu=False):
+    tape_guard("MinkowskiInstanceNorm", x, residual)
     y = _InstanceNormFn.apply(x, weight, bias, segments, eps, residual, relu)
     if _LAST_BN_AMAX is not None:
         tag_amax(y, _LAST_BN_AMAX)

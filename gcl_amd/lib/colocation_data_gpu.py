@@ -25,17 +25,13 @@ def _cap(n):
     return cap
 
 
-def sparse_quantize_gpu(xyz, voxel_size, batch_id=0, return_table=False):
-    """``xyz`` float32 [P,3] on the GPU -> (coords int32 [N,4] with ``batch_id`` in column 0, index int64 [N]):
-    coords = floor(xyz / voxel_size), first occurrence per voxel, index ascending -- exactly
-    ``ME.utils.sparse_quantize(xyz / voxel_size, return_index=True)`` + the batch column."""
+def unique_coords_gpu(raw, return_table=False):
+    """First-occurrence unique rows of int32 [P,4] voxel coordinates on the GPU (gcl_unique_coords): (coords [N,4],
+    index int64 [N] ascending) -- the ``return_index=True`` half of ``ME.utils.sparse_quantize``."""
     lib = _lib.require_gpu()
-    xyz = xyz.contiguous()
-    P = xyz.shape[0]
-    dev = xyz.device
-    raw = torch.empty((P, 4), dtype=torch.int32, device=dev)
-    _lib.check(lib.gcl_voxel_coords(_lib.ptr(xyz, torch.float32), P, float(voxel_size), int(batch_id), _lib.ptr(raw),
-                                    _lib.stream()), "gcl_voxel_coords")
+    raw = raw.contiguous()
+    P = raw.shape[0]
+    dev = raw.device
     cap = _cap(P)
     table = torch.empty((cap, 2), dtype=torch.int64, device=dev)
     scratch = torch.empty(lib.gcl_scan_scratch_len(P), dtype=torch.int32, device=dev)
@@ -43,8 +39,9 @@ def sparse_quantize_gpu(xyz, voxel_size, batch_id=0, return_table=False):
     index = torch.empty(P, dtype=torch.int64, device=dev)
     meta = torch.empty(8, dtype=torch.int32, device=dev)
     off = lambda t, e: ctypes.c_void_p(t.data_ptr() + e * t.element_size())
-    _lib.check(lib.gcl_unique_coords(_lib.ptr(raw), P, _lib.ptr(table), cap, _lib.ptr(scratch), _lib.ptr(coords),
-                                     _lib.ptr(index), off(meta, 0), off(meta, 4), _lib.stream()), "gcl_unique_coords")
+    _lib.check(lib.gcl_unique_coords(_lib.ptr(raw, torch.int32), P, _lib.ptr(table), cap, _lib.ptr(scratch),
+                                     _lib.ptr(coords), _lib.ptr(index), off(meta, 0), off(meta, 4), _lib.stream()),
+               "gcl_unique_coords")
     m = meta.tolist()
     if m[4]:
         raise ValueError(f"{m[4]} points outside the packable voxel range")
@@ -52,6 +49,19 @@ def sparse_quantize_gpu(xyz, voxel_size, batch_id=0, return_table=False):
     if return_table:
         return coords[:n], index[:n], (table, cap)
     return coords[:n], index[:n]
+
+
+def sparse_quantize_gpu(xyz, voxel_size, batch_id=0, return_table=False):
+    """``xyz`` float32 [P,3] on the GPU -> (coords int32 [N,4] with ``batch_id`` in column 0, index int64 [N]):
+    coords = floor(xyz / voxel_size), first occurrence per voxel, index ascending -- exactly
+    ``ME.utils.sparse_quantize(xyz / voxel_size, return_index=True)`` + the batch column."""
+    lib = _lib.require_gpu()
+    xyz = xyz.contiguous()
+    P = xyz.shape[0]
+    raw = torch.empty((P, 4), dtype=torch.int32, device=xyz.device)
+    _lib.check(lib.gcl_voxel_coords(_lib.ptr(xyz, torch.float32), P, float(voxel_size), int(batch_id), _lib.ptr(raw),
+                                    _lib.stream()), "gcl_voxel_coords")
+    return unique_coords_gpu(raw, return_table)
 
 
 def colocation_groups_gpu(xyz_own, xyz_cf, coords, n_center, n_clouds, list_M, voxel_size, radius, K=5):

@@ -104,24 +104,34 @@ class _GCLLossFn(torch.autograd.Function):
 LOSS_SQRT, LOSS_BLOCK, LOSS_PAIR, LOSS_NOFIN = 1, 2, 4, 8      # GCL_LOSS_* of include/gcl_amd.h
 
 
+# Serialises every use of numpy's GLOBAL RandomState by the trainer's threads: legacy_choice holds it from get_state to
+# set_state (the native shuffle in between runs without the interpreter lock), and train_steps holds it while it pulls
+# the next batch from the caller's iterator (a num_workers=0 loader with np.random augmentation draws there).  Loader
+# code running on OTHER threads of the caller must not use the global np.random while train_steps runs.
+import threading
+NP_RANDOM_LOCK = threading.RLock()
+
+
 def legacy_choice(n, k):
     """``np.random.choice(n, k, replace=False)`` on numpy's global RandomState -- same values, same stream position
     afterwards -- computed by the native host routine gcl_host_legacy_choice outside the interpreter lock (numpy: 8 ms per
     call at n = 0.5 M, holding the lock, which stalls the thread that enqueues the GPU work).  Small n go to numpy."""
     if n < 4096 or k > n:
-        return np.random.choice(n, k, replace=False)
+        with NP_RANDOM_LOCK:
+            return np.random.choice(n, k, replace=False)
     import ctypes
     lib = _lib.load()
-    st = np.random.get_state()
-    if st[0] != "MT19937":
-        return np.random.choice(n, k, replace=False)
-    key = np.array(st[1], dtype=np.uint32, copy=True)
-    pos = ctypes.c_int32(int(st[2]))
-    work, out = np.empty(n + n // 32 + 64, np.int64), np.empty(k, np.int64)
-    _lib.check(lib.gcl_host_legacy_choice(ctypes.c_void_p(key.ctypes.data), ctypes.byref(pos), n, k,
-                                          ctypes.c_void_p(work.ctypes.data), ctypes.c_void_p(out.ctypes.data)),
-               "gcl_host_legacy_choice")
-    np.random.set_state((st[0], key, int(pos.value), st[3], st[4]))
+    with NP_RANDOM_LOCK:
+        st = np.random.get_state()
+        if st[0] != "MT19937":
+            return np.random.choice(n, k, replace=False)
+        key = np.array(st[1], dtype=np.uint32, copy=True)
+        pos = ctypes.c_int32(int(st[2]))
+        work, out = np.empty(n + n // 32 + 64, np.int64), np.empty(k, np.int64)
+        _lib.check(lib.gcl_host_legacy_choice(ctypes.c_void_p(key.ctypes.data), ctypes.byref(pos), n, k,
+                                              ctypes.c_void_p(work.ctypes.data), ctypes.c_void_p(out.ctypes.data)),
+                   "gcl_host_legacy_choice")
+        np.random.set_state((st[0], key, int(pos.value), st[3], st[4]))
     return out
 
 
@@ -430,10 +440,11 @@ class FinestContrastiveLossTrainer:
 
         def take():
             grp = []
-            for b in it:
-                grp.append(b)
-                if len(grp) == k:
-                    return grp
+            with NP_RANDOM_LOCK:          # a loader that draws from the global np.random must not interleave with a draw
+                for b in it:
+                    grp.append(b)
+                    if len(grp) == k:
+                        return grp
             return None
 
         import time
@@ -592,22 +603,18 @@ def prefetch_to_device(batches, device, keys=("sinput_C", "sinput_F", "group", "
     have passed, so per-step allocations on the copy stream kept falling through to hipMalloc (~0.1 ms each on the
     enqueuing thread).  A slot is handed out again only after its consumer has called ``release_batch`` (the trainer
     does, once the batch's forward / backward is enqueued): that records an event on the compute stream which the copy
-    stream waits for before overwriting the slot.  A consumer that never releases gets the old behaviour once the pool
-    has grown to ``4 * ring`` slots: the oldest slot is reused behind an event recorded on the compute stream NOW."""
+    stream waits for before overwriting the slot.  A slot that was handed out and not released is NEVER
+    recycled -- the pool grows instead (``train_steps`` legitimately holds ``(GCL_PREFETCH_DEPTH + 1) * iter_size``
+    unreleased batches; a consumer that never releases simply gets one slot per batch, i.e. per-batch allocations)."""
     dev = torch.device(device)
     copy_stream = torch.cuda.Stream(device=dev)
     slots = [{"bufs": {}, "busy": False, "free": None, "age": -1} for _ in range(max(2, int(ring)))]
-    limit = 4 * len(slots)
     for i, b in enumerate(batches):
         out = dict(b)
         slot = next((s_ for s_ in slots if not s_["busy"]), None)
-        if slot is None and len(slots) < limit:
+        if slot is None:          # every slot belongs to a batch that is still pending: grow, never overwrite
             slot = {"bufs": {}, "busy": False, "free": None, "age": -1}
             slots.append(slot)
-        if slot is None:
-            slot = min(slots, key=lambda s_: s_["age"])
-            slot["free"] = torch.cuda.Event()
-            slot["free"].record(torch.cuda.current_stream(dev))
         if slot["free"] is not None:
             copy_stream.wait_event(slot["free"])
         slot["busy"], slot["age"], slot["free"] = True, i, None

@@ -15,7 +15,7 @@ from gcl_amd import _lib
 class FusedSGD(torch.optim.SGD):
     def __init__(self, params, lr, momentum=0.0, weight_decay=0.0):
         super().__init__(params, lr=lr, momentum=momentum, dampening=0.0, weight_decay=weight_decay, nesterov=False)
-        self._key = None
+        self._sizes = {}          # per parameter list (identity of its tensors): device int64 element counts
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -42,17 +42,19 @@ class FusedSGD(torch.optim.SGD):
             ptrs = np.empty((len(ps), 3), dtype=np.int64)
             for i, (p, b) in enumerate(zip(ps, bufs)):
                 ptrs[i, 0], ptrs[i, 1], ptrs[i, 2] = p.data_ptr(), p.grad.data_ptr(), b.data_ptr()
-            key = (len(ps), dev)
-            if self._key != key:          # element counts never change
-                self._key = key
-                self._sizes = torch.tensor([p.numel() for p in ps], dtype=torch.int64).to(dev)
+            # element counts of THIS list of tensors (another param group, or a step in which a different subset has
+            # gradients, is another list: keyed on the tensors' identities, never on the list length)
+            key = (dev,) + tuple(id(p) for p in ps)
+            sizes = self._sizes.get(key)
+            if sizes is None:
+                sizes = self._sizes[key] = torch.tensor([p.numel() for p in ps], dtype=torch.int64).to(dev)
             # gradients are fresh tensors every step: new pointers.  A FRESH pinned staging tensor per step -- the copy is
             # asynchronous and the host runs up to a step ahead of the GPU, so a re-used buffer would be overwritten
             # before the previous step's copy has executed (torch's pinned allocator recycles a block only after that)
             pin = torch.empty((len(ps), 3), dtype=torch.int64, pin_memory=True)
             pin.numpy()[:] = ptrs
             table = pin.to(dev, non_blocking=True)
-            _lib.check(lib.gcl_sgd_multi(_lib.ptr(table), _lib.ptr(self._sizes), len(ps), float(group["lr"]),
+            _lib.check(lib.gcl_sgd_multi(_lib.ptr(table), _lib.ptr(sizes), len(ps), float(group["lr"]),
                                          float(group["momentum"]), float(group["weight_decay"]), int(first),
                                          _lib.stream()), "gcl_sgd_multi")
         return None

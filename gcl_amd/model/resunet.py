@@ -78,13 +78,19 @@ class ResUNet2(ME.MinkowskiNetwork):
     def forward(self, x):
         ops = ME.ops
         use_tape = (ops.TAPE_ENABLED and self.training and torch.is_grad_enabled() and self.NORM_TYPE == "BN"
-                    and self.BLOCK_NORM_TYPE == "BN" and ME.FUSED_CONV_BN_NODE and not x.F.requires_grad)
+                    and self.BLOCK_NORM_TYPE == "BN" and ME.FUSED_CONV_BN_NODE and not x.F.requires_grad
+                    and self._all_training())
         if not use_tape:
             return self._forward(x)
         with ops.tape() as tp:          # the whole network as ONE autograd node (ops.Tape)
             out = self._forward(x)
             F = tp.finish(out.F)
         return ME.SparseTensor(F, coordinate_map_key=out.coordinate_map_key, coordinate_manager=out.coordinate_manager)
+
+    def _all_training(self):
+        """The Tape records ``conv_bn`` calls only; a submodule in eval mode (frozen-BN fine-tuning) makes ME.conv_bn
+        fall back to ``norm(conv(x))``, which the Tape cannot follow -- such models take the per-layer autograd path."""
+        return all(m.training for m in self.modules())
 
     def _forward(self, x):
         skips = {}

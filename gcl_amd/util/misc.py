@@ -33,31 +33,50 @@ def _hash(arr, M):
     return h
 
 
+def _point_channels(n_points, rgb, normal, check):
+    """Input feature columns of ``extract_features`` as (array, offset, scale) triples: colours shifted to
+    [-0.5, 0.5], normals halved, or a single column of ones when the cloud carries neither (util/misc.py:58-130)."""
+    out = []
+    for name, arr, lim, off, scale in (("color", rgb, "[0, 1]", -0.5, 1.0), ("normal", normal, "[-1, 1]", 0.0, 0.5)):
+        if arr is None:
+            continue
+        arr = np.asarray(arr)
+        if check:
+            if arr.shape != (n_points, 3):
+                raise AssertionError(f"{name} must be [{n_points}, 3], got {arr.shape}")
+            if np.any(arr > 1):
+                raise ValueError(f"Invalid {name}. {name.capitalize()} must range from {lim}")
+        out.append((arr, off, scale))
+    return out
+
+
 def extract_features(model, xyz, rgb=None, normal=None, voxel_size=0.05, device=None, skip_check=False, is_eval=True):
-    """numpy cloud -> voxelise -> SparseTensor -> model -> (xyz[inds], F)   (util/misc.py:58-130)."""
+    """Features of one raw cloud: ``(xyz[kept], F)`` with one row per occupied voxel (interface of util/misc.py:58-130;
+    called by demo.py:35-40).  The voxelisation runs on the GPU (``sparse_quantize_gpu`` -- bit-identical to
+    ``ME.utils.sparse_quantize(np.floor(xyz / voxel_size), return_index=True)``: first point of every voxel, ascending)
+    and the per-voxel input features are gathered there too, so only the raw points cross PCIe.  float32 clouds are
+    divided on the device (correctly rounded fp32 quotient = numpy's); any other dtype keeps numpy's own quotient on
+    the host and only the voxel hash runs on the device.  There is no CPU path: ``device`` defaults to cuda:0."""
+    from gcl_amd.lib.colocation_data_gpu import sparse_quantize_gpu, unique_coords_gpu
+    dev = torch.device("cuda:0" if device is None else device)
     if is_eval:
         model.eval()
-    if not skip_check:
-        assert xyz.shape[1] == 3
-        if rgb is not None:
-            assert len(rgb) == len(xyz) and rgb.shape[1] == 3
-            if np.any(rgb > 1):
-                raise ValueError("Invalid color. Color must range from [0, 1]")
-        if normal is not None:
-            assert len(normal) == len(xyz) and normal.shape[1] == 3
-            if np.any(normal > 1):
-                raise ValueError("Invalid normal. Normal must range from [-1, 1]")
-    if device is None:
-        device = torch.device("cuda:0")
-    feats = []
-    if rgb is not None:
-        feats.append(rgb - 0.5)
-    if normal is not None:
-        feats.append(normal / 2)
-    if rgb is None and normal is None:
-        feats.append(np.ones((len(xyz), 1)))
-    feats = np.hstack(feats)
-    coords, inds = ME.utils.sparse_quantize(np.floor(xyz / voxel_size), return_index=True)
-    coords = ME.utils.batched_coordinates([coords])
-    stensor = ME.SparseTensor(torch.tensor(feats[inds], dtype=torch.float32), coordinates=coords, device=device)
-    return xyz[inds], model(stensor).F
+    pts = np.asarray(xyz)
+    if not skip_check and (pts.ndim != 2 or pts.shape[1] != 3):
+        raise AssertionError(f"xyz must be [N, 3], got {pts.shape}")
+    channels = _point_channels(len(pts), rgb, normal, check=not skip_check)
+    with torch.cuda.device(dev):
+        if pts.dtype == np.float32:
+            coords, kept = sparse_quantize_gpu(torch.from_numpy(np.ascontiguousarray(pts)).to(dev), voxel_size)
+        else:
+            cells = np.zeros((len(pts), 4), dtype=np.int32)            # column 0 = batch id 0
+            cells[:, 1:] = np.floor(pts / voxel_size)
+            coords, kept = unique_coords_gpu(torch.from_numpy(cells).to(dev))
+        if channels:
+            cols = [(torch.from_numpy(np.ascontiguousarray(a)).to(dev)[kept].double() + off) * scale
+                    for a, off, scale in channels]
+            feats = torch.cat(cols, dim=1).float()
+        else:
+            feats = torch.ones((len(kept), 1), dtype=torch.float32, device=dev)
+        out = model(ME.SparseTensor(feats, coordinates=coords))
+    return xyz[kept.cpu().numpy()], out.F

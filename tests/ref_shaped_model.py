@@ -57,77 +57,43 @@ def build(ME, MEF, in_channels=1, out_channels=32, bn_momentum=0.05, normalize_f
                                                                  stride=s, dilation=1, bias=False, dimension=3)
             up = lambda ci, co: ME.MinkowskiConvolutionTranspose(in_channels=ci, out_channels=co, kernel_size=3,
                                                                   stride=2, dilation=1, bias=False, dimension=3)
-            self.conv1 = conv(in_channels, ch[1], conv1_kernel_size, 1)
-            self.norm1 = make_norm(norm, ch[1])
-            self.block1 = Block(ch[1])
-            self.conv2 = conv(ch[1], ch[2], 3, 2)
-            self.norm2 = make_norm(norm, ch[2])
-            self.block2 = Block(ch[2])
-            self.conv3 = conv(ch[2], ch[3], 3, 2)
-            self.norm3 = make_norm(norm, ch[3])
-            self.block3 = Block(ch[3])
-            self.conv4 = conv(ch[3], ch[4], 3, 2)
-            self.norm4 = make_norm(norm, ch[4])
-            self.block4 = Block(ch[4])
-            self.conv4_tr = up(ch[4], tr[4])
-            self.norm4_tr = make_norm(norm, tr[4])
-            self.block4_tr = Block(tr[4])
-            self.conv3_tr = up(ch[3] + tr[4], tr[3])
-            self.norm3_tr = make_norm(norm, tr[3])
-            self.block3_tr = Block(tr[3])
-            self.conv2_tr = up(ch[2] + tr[3], tr[2])
-            self.norm2_tr = make_norm(norm, tr[2])
-            self.block2_tr = Block(tr[2])
+            # the reference's parameter names (state dicts interchange): conv{l} / norm{l} / block{l} going down,
+            # conv{l}_tr / norm{l}_tr / block{l}_tr coming back up, then the two 1x1x1 heads
+            down_in = {1: in_channels, 2: ch[1], 3: ch[2], 4: ch[3]}
+            for lvl in (1, 2, 3, 4):
+                first = conv(down_in[lvl], ch[lvl], conv1_kernel_size if lvl == 1 else 3, 1 if lvl == 1 else 2)
+                self.add_module(f"conv{lvl}", first)
+                self.add_module(f"norm{lvl}", make_norm(norm, ch[lvl]))
+                self.add_module(f"block{lvl}", Block(ch[lvl]))
+            up_in = {4: ch[4], 3: ch[3] + tr[4], 2: ch[2] + tr[3]}
+            for lvl in (4, 3, 2):
+                self.add_module(f"conv{lvl}_tr", up(up_in[lvl], tr[lvl]))
+                self.add_module(f"norm{lvl}_tr", make_norm(norm, tr[lvl]))
+                self.add_module(f"block{lvl}_tr", Block(tr[lvl]))
             self.conv1_tr = conv(ch[1] + tr[2], tr[1], 1, 1)
             self.final = ME.MinkowskiConvolution(in_channels=tr[1], out_channels=out_channels, kernel_size=1, stride=1,
                                                  dilation=1, bias=True, dimension=3)
 
+        def _stage(self, suffix, x):
+            """conv -> norm -> residual block as three separate module calls (the un-fused surface); the caller
+            applies MEF.relu itself."""
+            y = self._modules["conv" + suffix](x)
+            y = self._modules["norm" + suffix](y)
+            return self._modules["block" + suffix](y)
+
         def forward(self, x):
-            out_s1 = self.conv1(x)
-            out_s1 = self.norm1(out_s1)
-            out_s1 = self.block1(out_s1)
-            out = MEF.relu(out_s1)
-
-            out_s2 = self.conv2(out)
-            out_s2 = self.norm2(out_s2)
-            out_s2 = self.block2(out_s2)
-            out = MEF.relu(out_s2)
-
-            out_s4 = self.conv3(out)
-            out_s4 = self.norm3(out_s4)
-            out_s4 = self.block3(out_s4)
-            out = MEF.relu(out_s4)
-
-            out_s8 = self.conv4(out)
-            out_s8 = self.norm4(out_s8)
-            out_s8 = self.block4(out_s8)
-            out = MEF.relu(out_s8)
-
-            out = self.conv4_tr(out)
-            out = self.norm4_tr(out)
-            out = self.block4_tr(out)
-            out_s4_tr = MEF.relu(out)
-            out = ME.cat(out_s4_tr, out_s4)
-
-            out = self.conv3_tr(out)
-            out = self.norm3_tr(out)
-            out = self.block3_tr(out)
-            out_s2_tr = MEF.relu(out)
-            out = ME.cat(out_s2_tr, out_s2)
-
-            out = self.conv2_tr(out)
-            out = self.norm2_tr(out)
-            out = self.block2_tr(out)
-            out_s1_tr = MEF.relu(out)
-            out = ME.cat(out_s1_tr, out_s1)
-
-            out = self.conv1_tr(out)
-            out = MEF.relu(out)
-            out = self.final(out)
-            if self.normalize_feature:
-                return ME.SparseTensor(out.F / torch.norm(out.F, p=2, dim=1, keepdim=True),
-                                       coordinate_map_key=out.coordinate_map_key,
-                                       coordinate_manager=out.coordinate_manager)
-            return out
+            kept, cur = {}, x
+            for lvl in (1, 2, 3, 4):                      # encoder: keep the un-activated block output for the skip
+                kept[lvl] = self._stage(str(lvl), cur)
+                cur = MEF.relu(kept[lvl])
+            for lvl in (4, 3, 2):                         # decoder: up-convolve, activate, concatenate with the skip
+                cur = ME.cat(MEF.relu(self._stage(f"{lvl}_tr", cur)), kept[lvl - 1])
+            cur = self.final(MEF.relu(self.conv1_tr(cur)))
+            if not self.normalize_feature:
+                return cur
+            rows = cur.F
+            return ME.SparseTensor(rows / torch.norm(rows, p=2, dim=1, keepdim=True),
+                                   coordinate_map_key=cur.coordinate_map_key,
+                                   coordinate_manager=cur.coordinate_manager)
 
     return Net()

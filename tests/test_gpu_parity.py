@@ -698,6 +698,41 @@ def test_fp16x3_dynamic_range(kind):
     assert rel_l2(conv.kernel.grad.cpu(), W.grad) < 2e-6
 
 
+def test_fp16x3_small_rows_elementwise():
+    """The fp16x3 caveat as a number: the two fp16 planes of an operand are cut relative to
+    the TENSOR maximum, so rows whose magnitude is 2^-20 of it keep only the bits above 2^-25 of the scaled range (the
+    lo plane is subnormal there).  Every 16th input row is scaled by 2^-20 and only feeds outputs through its own
+    centre offset weights -- reported per output row: error relative to that row's own norm next to the tensor-wide
+    rel-L2.  Bounds asserted: tensor-wide 2e-6 (fp32 level); small rows 1.5e-2 of their own norm (what 2^-25-of-max
+    absolute resolution leaves of a 2^-20 value), i.e. ABSOLUTE error <= 2^-24 of the output maximum everywhere."""
+    import gcl_amd.MinkowskiEngine as ME
+    from gcl_amd.MinkowskiEngine import ops
+    assert ops.PRECISION == "fp16x3"
+    n = 4096
+    C = torch.zeros((n, 4), dtype=torch.int32)
+    C[:, 1] = torch.arange(n) * 4                # isolated voxels: every output row sees only its own input row
+    mgr, omgr = make_mgr(C), O.CoordinateManager(C)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, 64, generator=g, dtype=torch.float64)
+    small = torch.arange(n) % 16 == 0
+    x[small] *= 2.0 ** -20
+    conv = ME.MinkowskiConvolution(64, 64, kernel_size=3, stride=1, dimension=3).to(DEV)
+    with torch.no_grad():
+        y = conv(ME.SparseTensor(x.float().to(DEV), coordinate_map_key=ME.CoordinateMapKey(1),
+                                 coordinate_manager=mgr)).F.cpu().double()
+    yo = O.sparse_conv(x.float().double(), conv.kernel.detach().cpu().double(), omgr.get_kernel_map(1, 3, 1), n)
+    err = (y - yo).norm(dim=1)
+    row_rel = err / yo.norm(dim=1)
+    total = rel_l2(y, yo)
+    worst_small, worst_big = float(row_rel[small].max()), float(row_rel[~small].max())
+    abs_vs_max = float((y - yo).abs().max() / yo.abs().max())
+    print(f"fp16x3 element-wise: tensor rel-L2 {total:.2e}; rows at 2^-20 of the maximum: worst per-row relative error "
+          f"{worst_small:.2e}; full-scale rows: {worst_big:.2e}; max |error| / max |y| = {abs_vs_max:.2e}")
+    assert total < 2e-6 and worst_big < 2e-6
+    assert worst_small < 1.5e-2
+    assert abs_vs_max < 2.0 ** -23
+
+
 def test_resunet_fat_variant_vs_oracle():
     """ResUNetFatBN (the reference script's default model, scripts/train_gcl_kitti.sh:13; model/resunet.py:263-266)
     runs through the same kernels: wider decoder (TR_CHANNELS 128,128,128,256), concat widths 160 / 192 / 384."""
