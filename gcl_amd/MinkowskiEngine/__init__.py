@@ -205,7 +205,7 @@ def conv_bn(conv, norm, x, residual=None, relu=False):
         bn = norm.bn
         F = ops.conv_bn_train(x.F, conv.kernel, kmap, n_out, conv.TRANSPOSE, mgr, bn.weight, bn.bias, bn.running_mean,
                               bn.running_var, bn.momentum, bn.eps, residual.F if residual is not None else None,
-                              bool(relu), FUSED_BN_STATS and conv.in_channels > 4)
+                              bool(relu), FUSED_BN_STATS and conv.in_channels > 4, bn_module=norm)
         norm._pending_batches += 1
         norm._train_forwards += 1
         out = SparseTensor(F, coordinate_map_key=CoordinateMapKey(t_out), coordinate_manager=mgr)

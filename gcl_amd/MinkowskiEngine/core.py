@@ -158,6 +158,61 @@ class CoordinateManager:
     """Owns the coordinate maps (one per tensor stride) and caches kernel maps per (t_in, kernel_size, stride),
     so the two convs of a residual block and matching encoder/decoder levels share one map."""
 
+    native = None       # NativeMaps when the maps were built by ONE gcl_maps_build call (build_native)
+
+    @classmethod
+    def build_native(cls, coordinates, specs, n_levels=4, arena=None):
+        """A manager whose stride maps, kernel maps, mask-sorted tables and pair lists were all built by one native call
+        (``specs`` as in ``prefetch`` + (t, 1, 1, (), True) for kernel_size-1 identity pairs; native.NativeMaps).  The
+        whole-network plan reads the native descriptor directly; the Python accessors below (get_coords,
+        get_kernel_map, identity_pairs) hand out tensor VIEWS of the same arena on demand, so the per-operator path
+        runs on exactly the same maps."""
+        from .native import NativeMaps
+        nm = NativeMaps(coordinates, specs, n_levels, arena)
+        self = cls.__new__(cls)
+        self.native, self.device = nm, nm.device
+        self._segments, self._maps, self._status = {}, {}, {}
+        self._checked = set(1 << l for l in range(nm.n_levels))       # gcl_maps_build has validated the coordinates
+        self._kmaps, self._identity, self._spatial, self._bitmap = {}, {}, {}, None
+        return self
+
+    def _native_level(self, t):
+        nm = self.native
+        l = int(t).bit_length() - 1
+        if nm is None or (1 << l) != t or l >= nm.n_levels:
+            return False
+        d = nm.desc
+        n, cap = int(d.n_rows[l]), int(d.cap[l])
+        self._maps[t] = (nm.view(d.coords[l], (n, 4), torch.int32), nm.view(d.table[l], (cap, 2), torch.int64), cap)
+        return True
+
+    def _native_kernel_map(self, key):
+        nm = self.native
+        if nm is None or key not in nm.keys or key[1] == 1:
+            return None
+        m = nm.desc.maps[nm.keys.index(key)]
+        K, n_in, n_out = int(m.K), int(m.n_in), int(m.n_out)
+        i32 = torch.int32
+        km = KernelMap.__new__(KernelMap)
+        km.nbr, km.nbr_t = nm.view(m.nbr, (K, n_out), i32), nm.view(m.nbr_t, (K, n_in), i32)
+        km._mgr = weakref.ref(self)
+        km._t_in, km._t_out = key[0], key[0] * key[2]
+        km.n_in, km.n_out, km.K = n_in, n_out, K
+        km.same_map = km.nbr_t is None
+        km._counts_dev = nm.view(m.counts, (K,), i32)
+        km._counts = [int(m.counts_host[k]) for k in range(K)]
+        km._sorted, km._pairs = {}, None
+        for tag, (a, b, c), rows in (("n", (m.tbl_n, m.order_n, m.mask_n), n_out), ("t", (m.tbl_t, m.order_t, m.mask_t), n_in)):
+            if a:
+                tbl = nm.view(a, (K, rows), i32)
+                tbl._gcl_flags = 0
+                km._sorted[tag] = (tbl, nm.view(b, (rows,), i32), nm.view(c, ((rows + 31) // 32,), i32))
+        if m.pair_in:
+            seg = [int(m.seg_off[k]) for k in range(K + 1)]
+            total = max(seg[-1], 1)
+            km._pairs = (nm.view(m.pair_in, (total,), i32), nm.view(m.pair_out, (total,), i32), seg, _lib.host_i64(seg))
+        return km
+
     def __init__(self, coordinates):
         self._segments = {}
         lib = _lib.require_gpu()
@@ -197,7 +252,9 @@ class CoordinateManager:
                              "(use ME.utils.sparse_quantize)")
 
     def get_coords(self, t):
-        if t not in self._maps:
+        if t not in self._maps and not self._native_level(t):
+            if self.native is not None:
+                raise ValueError(f"tensor stride {t} was not part of the native map build")
             self._build_stride_maps(t)
         return self._maps[t][0]
 
@@ -280,6 +337,12 @@ class CoordinateManager:
         key = (t_in, kernel_size, stride)
         if key in self._kmaps:
             return self._kmaps[key]
+        if self.native is not None:
+            km = self._native_kernel_map(key)
+            if km is None:
+                raise ValueError(f"kernel map {key} was not part of the native map build (model.native_map_specs)")
+            self._kmaps[key] = km
+            return km
         lib = _lib.load()
         if 1 not in self._checked:
             # first map of this tensor: build the whole stride pyramid now, so that the validity check of the input
@@ -327,6 +390,8 @@ class CoordinateManager:
     def device_tensors(self):
         """Every device tensor this manager holds (for ``record_stream`` when it was built on another stream)."""
         out = []
+        if self.native is not None:      # one arena holds every map
+            return [self.native.arena, self.native.coords]
         for C, table, _ in self._maps.values():
             out += [C, table]
         out += list(self._status.values()) + list((self._bitmap or {}).values()) + list(self._spatial.values())
@@ -343,6 +408,15 @@ class CoordinateManager:
 
     def identity_pairs(self, n):
         """Pair lists of a kernel_size-1 convolution (row i <-> row i), padded to GCL_PAIR_CHUNK."""
+        if n not in self._identity and self.native is not None:
+            nm = self.native
+            for i, key in enumerate(nm.keys):
+                m = nm.desc.maps[i]
+                if key[1] == 1 and int(m.n_in) == n and m.pair_in:
+                    seg = [0, int(m.seg_off[1])]
+                    p = nm.view(m.pair_in, (seg[1],), torch.int32)
+                    self._identity[n] = (p, p, seg, _lib.host_i64(seg))
+                    break
         if n not in self._identity:
             ch = _lib.PAIR_CHUNK
             total = (n + ch - 1) // ch * ch

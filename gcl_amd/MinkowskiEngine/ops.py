@@ -403,8 +403,21 @@ class _SparseConvFn(torch.autograd.Function):
                                "gcl_conv_bwd_weight")
             dW = dW.view(ctx.w_shape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            dbias = dy.sum(0, keepdim=True)
+            dbias = _col_sum(lib, dy)
         return dx, dW, dbias, None, None, None, None, None
+
+
+def _col_sum(lib, dy):
+    """``dy.sum(0, keepdim=True)`` by gcl_col_sum (ordered fp64 partials: deterministic, and the same launch the
+    whole-network plan issues, so both paths stay bitwise equal); widths the kernel does not take use torch."""
+    n, c = dy.shape
+    if n == 0 or c < 4 or c % 4 or 256 % (c // 4) or dy.dtype != torch.float32:
+        return dy.sum(0, keepdim=True)
+    out = torch.empty((1, c), dtype=torch.float32, device=dy.device)
+    scratch = torch.empty(lib.gcl_bn_scratch_len(n, c), dtype=torch.float64, device=dy.device)
+    _lib.check(lib.gcl_col_sum(_lib.ptr(dy, torch.float32), n, c, _lib.ptr(scratch), _lib.ptr(out), _lib.stream()),
+               "gcl_col_sum")
+    return out
 
 
 def sparse_conv(x, W, kmap, n_out, transpose, bias, mgr, want_stats=False):
@@ -682,13 +695,14 @@ class _TapeFn(torch.autograd.Function):
 
 
 def conv_bn_train(x, W, kmap, n_out, transpose, mgr, bn_w, bn_b, running_mean, running_var, momentum, eps, residual, relu,
-                  want_stats):
+                  want_stats, bn_module=None):
     if _TAPE is not None:
         with torch.no_grad():
             c1, c2 = _SubCtx(), _SubCtx()
             y, stats = _SparseConvFn.forward(c1, x, W, None, kmap, n_out, transpose, mgr, want_stats)
             z = _BatchNormFn.forward(c2, y, bn_w, bn_b, running_mean, running_var, True, momentum, eps, residual, relu,
                                      stats if stats.numel() else None)
+        c2.bn_extra = (running_mean, running_var, momentum, eps, bn_module)     # what a NetworkPlan record needs
         _TAPE.add("convbn", z, c1, c2, x, residual, (W, bn_w, bn_b))
     else:
         z = _ConvBNFn.apply(x, W, bn_w, bn_b, residual, running_mean, running_var, kmap, n_out, transpose, mgr, momentum,

@@ -11,10 +11,42 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("GCL_LIB_PATH", os.path.join(CSRC, "libgcl_hip.so"))   # override: diagnostic builds only
-SOURCES = ["coords.hip", "conv.hip", "norm.hip", "loss.hip", "data.hip", "sc2pcr.hip"]
+SOURCES = ["coords.hip", "conv.hip", "norm.hip", "loss.hip", "data.hip", "sc2pcr.hip", "plan.hip"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "gcl_amd.h")
 
 _vp, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+
+MAX_LEVELS, MAX_MAPS = 8, 16          # GCL_MAX_LEVELS, GCL_MAX_MAPS
+MAPS_PINNED_BYTES = 512 * (MAX_MAPS + 1)
+ERR_ARENA = -4
+
+
+class MapSpec(ctypes.Structure):      # gcl_map_spec
+    _fields_ = [("t_in", _i32), ("kernel_size", _i32), ("stride", _i32), ("tables", _i32), ("pairs", _i32)]
+
+
+class MapDesc(ctypes.Structure):      # gcl_map_desc
+    _fields_ = [("t_in", _i32), ("kernel_size", _i32), ("stride", _i32), ("K", _i32), ("level_in", _i32),
+                ("level_out", _i32), ("n_in", _i64), ("n_out", _i64), ("n_pairs", _i64),
+                ("nbr", _vp), ("nbr_t", _vp), ("counts", _vp),
+                ("tbl_n", _vp), ("order_n", _vp), ("mask_n", _vp), ("tbl_t", _vp), ("order_t", _vp), ("mask_t", _vp),
+                ("pair_in", _vp), ("pair_out", _vp), ("seg_off", _i64 * 128), ("counts_host", _i32 * 128)]
+
+
+class MapsDesc(ctypes.Structure):     # gcl_maps_desc
+    _fields_ = [("n_levels", _i32), ("n_maps", _i32), ("n_rows", _i64 * MAX_LEVELS), ("coords", _vp * MAX_LEVELS),
+                ("table", _vp * MAX_LEVELS), ("cap", _i64 * MAX_LEVELS), ("status", _i32 * 4), ("arena_used", _i64),
+                ("maps", MapDesc * MAX_MAPS)]
+
+
+class PlanOp(ctypes.Structure):       # gcl_plan_op
+    _fields_ = [("kind", _i32), ("x", _i32), ("x2", _i32), ("y", _i32), ("level_in", _i32), ("level_out", _i32),
+                ("cin", _i32), ("cout", _i32), ("map", _i32), ("transpose", _i32), ("K", _i32), ("w", _i32),
+                ("bias", _i32), ("bn_w", _i32), ("bn_b", _i32), ("bn", _i32), ("relu", _i32), ("momentum", _f32),
+                ("eps", _f32)]
+
+
+OP_CONVBN, OP_CONV, OP_RELU, OP_CAT, OP_ROWNORM = 1, 2, 3, 4, 5
 
 # name -> (restype, argtypes); mirrors include/gcl_amd.h one to one (tests/test_abi.py checks both directions)
 SIGNATURES = {
@@ -70,6 +102,17 @@ SIGNATURES = {
     "gcl_row_normalize_fwd": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
     "gcl_row_normalize_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "gcl_sgd_multi": (_i32, [_vp, _vp, _i32, _f32, _f32, _f32, _i32, _vp]),
+    "gcl_col_sum": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
+    "gcl_maps_arena_bytes": (_i64, [_i64, _vp, _i32, _i32]),
+    "gcl_maps_build": (_i32, [_vp, _i64, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _vp]),
+    "gcl_plan_create": (_vp, [_vp, _i32, _i32, _i32, _vp, _i32, _i32]),
+    "gcl_plan_destroy": (None, [_vp]),
+    "gcl_plan_state_bytes": (_i64, [_vp]),
+    "gcl_plan_arena_bytes": (_i64, [_vp, _vp]),
+    "gcl_plan_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "gcl_plan_backward": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
+    "gcl_plan_profile": (_i32, [_vp, _i32]),
+    "gcl_plan_profile_read": (_i32, [_vp, _vp, _i32]),
     "gcl_sc2_chunks": (_i32, []),
     "gcl_sc2_refine_partial_len": (_i32, []),
     "gcl_sc2_confidence": (_i32, [_vp, _vp, _i32, _f32, _i32, _vp, _vp, _vp, _vp]),

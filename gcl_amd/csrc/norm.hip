@@ -366,6 +366,15 @@ __global__ void __launch_bounds__(256) k_sgd_multi(const SgdPtrs* __restrict__ t
 
 static bool bn_c_ok(int c) { return c >= 4 && c % 4 == 0 && (256 % (c / 4)) == 0; }
 
+// column sums of a matrix from k_bn_reduce<false>'s per-workgroup fp64 partials (ordered => deterministic)
+__global__ void __launch_bounds__(256) k_col_sum_final(const double* __restrict__ partial, int nwg, int c, float* out) {
+  int ch = blockIdx.x * 4 + (threadIdx.x & 3);
+  double s, ss;
+  reduce_partials4(partial, nwg, c, ch, s, ss);
+  if ((threadIdx.x >> 2) != 0 || ch >= c) return;
+  out[ch] = (float)s;
+}
+
 }  // namespace gcl
 
 using namespace gcl;
@@ -480,6 +489,20 @@ int gcl_row_normalize_bwd(const float* y, const float* dy, const float* norm, in
   long long total = n * (c / 4);
   hipLaunchKernelGGL(k_row_normalize<true>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, y, dy,
                      norm, (long long)n, c, dx, (float*)nullptr);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int gcl_col_sum(const float* x, int64_t n, int32_t c, double* scratch, float* out, void* stream) {
+  GCL_CHECK_ARG(x && scratch && out, "gcl_col_sum: null pointer");
+  GCL_CHECK_ARG(n > 0 && bn_c_ok(c), "gcl_col_sum: unsupported shape n=%lld c=%d (c/4 must divide 256)", (long long)n, c);
+  hipStream_t st = (hipStream_t)stream;
+  const int rows = bn_rows_per_wg(n, c);
+  int nwg = (int)cdiv(n, rows);
+  hipLaunchKernelGGL(k_bn_reduce<false>, dim3(nwg), dim3(256), 0, st, x, (const float*)nullptr,
+                     (const float*)nullptr, (long long)n, c, (const float*)nullptr, (const float*)nullptr, 0,
+                     (const unsigned long long*)nullptr, rows, scratch);
+  hipLaunchKernelGGL(k_col_sum_final, dim3((unsigned)cdiv(c, 4)), dim3(256), 0, st, (const double*)scratch, nwg, c, out);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }

@@ -1,0 +1,971 @@
+// Native step runtime: one C call enqueues a whole pass (include/gcl_amd.h, "Native step runtime").
+//
+//   gcl_maps_build     = what CoordinateManager.__init__ / _build_stride_maps / get_kernel_map / KernelMap.sorted_table /
+//                        KernelMap.pairs do from Python (gcl_amd/MinkowskiEngine/core.py), for all maps of a network;
+//   gcl_plan_forward / = what ops.Tape records and replays (gcl_amd/MinkowskiEngine/ops.py: _SparseConvFn, _BatchNormFn,
+//   gcl_plan_backward    Tape.backward) for a network given as operator records.
+//
+// Reference path: model/resunet.py:173-232 (ResUNet2.forward), model/residual_block.py:37-53, and the coordinate manager
+// ME builds behind lib/colocation_trainer.py:843-845.  Both families call the SAME extern "C" entries the per-operator
+// path calls, with the same arguments in the same order, so results are bitwise identical (tests/test_gpu_plan.py); what
+// disappears is ~560 Python -> ctypes round trips (~40 us each) per training step.
+// Memory: bump allocation from the caller's arena, nothing is freed inside a pass (288 GB of HBM: a 0.5 M-voxel step
+// uses a few GB); a dry run of the same code sizes the arena.
+#include "common.h"
+
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+namespace gcl {
+
+// ---------------------------------------------------------------------------------------------------
+// small elementwise kernels of the plan path
+// ---------------------------------------------------------------------------------------------------
+// MEF.relu: torch.relu semantics (NaN propagates)
+__global__ void __launch_bounds__(256) k_relu_fwd(const float4* __restrict__ x, long long n4, float4* __restrict__ y) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    float4 v = x[i];
+    v.x = v.x < 0.f ? 0.f : v.x;
+    v.y = v.y < 0.f ? 0.f : v.y;
+    v.z = v.z < 0.f ? 0.f : v.z;
+    v.w = v.w < 0.f ? 0.f : v.w;
+    y[i] = v;
+  }
+}
+// aten::threshold_backward(g, y, 0): g where y > 0, else 0
+__global__ void __launch_bounds__(256) k_relu_bwd(const float4* __restrict__ g, const float4* __restrict__ y, long long n4,
+                                                  float4* __restrict__ gx) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    float4 a = g[i];
+    const float4 b = y[i];
+    a.x = b.x > 0.f ? a.x : 0.f;
+    a.y = b.y > 0.f ? a.y : 0.f;
+    a.z = b.z > 0.f ? a.z : 0.f;
+    a.w = b.w > 0.f ? a.w : 0.f;
+    gx[i] = a;
+  }
+}
+// ME.cat(a, b): y[r] = a[r] | b[r]   (channel counts are multiples of 4)
+__global__ void __launch_bounds__(256) k_cat2(const float4* __restrict__ a, int ca4, const float4* __restrict__ b, int cb4,
+                                              long long n, float4* __restrict__ y) {
+  const int c4 = ca4 + cb4;
+  const long long total = n * c4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / c4;
+    const int q = (int)(i - r * c4);
+    y[i] = q < ca4 ? a[r * ca4 + q] : b[r * cb4 + (q - ca4)];
+  }
+}
+__global__ void __launch_bounds__(256) k_split2(const float4* __restrict__ g, int ca4, int cb4, long long n,
+                                                float4* __restrict__ ga, float4* __restrict__ gb) {
+  const int c4 = ca4 + cb4;
+  const long long total = n * c4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / c4;
+    const int q = (int)(i - r * c4);
+    const float4 v = g[i];
+    if (q < ca4) ga[r * ca4 + q] = v; else gb[r * cb4 + (q - ca4)] = v;
+  }
+}
+__global__ void __launch_bounds__(256) k_add2(const float4* __restrict__ a, const float4* __restrict__ b, long long n4,
+                                              float4* __restrict__ y) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 u = a[i], v = b[i];
+    y[i] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+  }
+}
+// identity pair list of a kernel_size-1 convolution: p[i] = i for i < n, -1 padding (CoordinateManager.identity_pairs)
+__global__ void __launch_bounds__(256) k_identity_pairs(int* __restrict__ p, long long n, long long total) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < total) p[i] = i < n ? (int)i : -1;
+}
+
+static inline unsigned grid_for(long long items, unsigned cap = 4096) {
+  long long g = cdiv(items > 0 ? items : 1, 256);
+  return (unsigned)(g > cap ? cap : g);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// arena
+// ---------------------------------------------------------------------------------------------------
+struct Arena {
+  char* base;
+  long long size, off;
+  bool dry;          // size the pass only: no launch, pointers are never dereferenced
+  void* take(long long bytes) {
+    off = (off + 255) & ~255ll;
+    char* p = base + off;
+    off += bytes > 0 ? bytes : 0;
+    return p;
+  }
+  template <typename T>
+  T* take_n(long long count) { return (T*)take(count * (long long)sizeof(T)); }
+  bool fits() const { return dry || off <= size; }
+};
+
+static char* const DRY_BASE = (char*)0x100000;    // dry runs hand out fake non-null addresses that are never dereferenced
+
+static long long pow2_cap(long long n) {
+  long long cap = 64;
+  while (cap < 2 * n) cap *= 2;
+  return cap;
+}
+
+#define PLAN_CALL(expr)          \
+  do {                           \
+    if (!A.dry) {                \
+      int rc_ = (expr);          \
+      if (rc_ != GCL_OK) return rc_; \
+    }                            \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------------
+// maps
+// ---------------------------------------------------------------------------------------------------
+static int level_of(int t) {
+  int l = 0;
+  while ((1 << l) < t) ++l;
+  return ((1 << l) == t) ? l : -1;
+}
+
+static int maps_build(const int32_t* coords, long long n, const gcl_map_spec* specs, int n_specs, int n_levels, Arena& A,
+                      int32_t* pinned, gcl_maps_desc* out, hipStream_t st) {
+  void* stream = (void*)st;
+  memset(out, 0, sizeof(*out));
+  out->n_levels = n_levels;
+  out->n_maps = n_specs;
+  // level 0: the input coordinates and their hash table (CoordinateManager.__init__)
+  const long long cap0 = pow2_cap(n);
+  out->coords[0] = (int32_t*)coords;
+  out->n_rows[0] = n;
+  out->cap[0] = cap0;
+  out->table[0] = A.take_n<int64_t>(cap0 * 2);
+  int32_t* status = A.take_n<int32_t>(4);
+  PLAN_CALL(gcl_coords_insert(coords, n, out->table[0], cap0, status, stream));
+  // levels 1 ..: one chain of launches, row counts stay on the device (CoordinateManager._build_stride_maps)
+  int32_t* meta = A.take_n<int32_t>(8 * (n_levels > 1 ? n_levels - 1 : 1));
+  if (!A.dry && n_levels > 1) GCL_CHECK_HIP(hipMemsetAsync(meta, 0, sizeof(int32_t) * 8 * (n_levels - 1), st));
+  const int32_t* cb = coords;
+  const int32_t* n_dev = nullptr;
+  for (int l = 1; l < n_levels; ++l) {
+    out->cap[l] = cap0;
+    out->table[l] = A.take_n<int64_t>(cap0 * 2);
+    int32_t* scratch = A.take_n<int32_t>(gcl_scan_scratch_len(n));
+    out->coords[l] = A.take_n<int32_t>(n * 4);
+    PLAN_CALL(gcl_stride_map(cb, n, n_dev, 1 << l, out->table[l], cap0, scratch, out->coords[l], meta + 8 * (l - 1),
+                             meta + 8 * (l - 1) + 4, stream));
+    cb = out->coords[l];
+    n_dev = meta + 8 * (l - 1);
+    out->n_rows[l] = n;        // upper bound until the read-back below
+  }
+  if (!A.dry) {     // the first of the two host syncs: input status + level sizes
+    GCL_CHECK_HIP(hipMemcpyAsync(pinned, status, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (n_levels > 1)
+      GCL_CHECK_HIP(hipMemcpyAsync(pinned + 4, meta, sizeof(int32_t) * 8 * (n_levels - 1), hipMemcpyDeviceToHost, st));
+    GCL_CHECK_HIP(hipStreamSynchronize(st));
+    for (int j = 0; j < 4; ++j) out->status[j] = pinned[j];
+    GCL_CHECK_ARG(pinned[0] == 0, "%d coordinates outside the packable range (batch < 65535, |x|,|y|,|z| < 32768)", pinned[0]);
+    GCL_CHECK_ARG(pinned[1] == 0, "%d duplicate coordinates: ME.SparseTensor expects unique rows (use ME.utils.sparse_quantize)",
+                  pinned[1]);
+    for (int l = 1; l < n_levels; ++l) {
+      GCL_CHECK_ARG(pinned[4 + 8 * (l - 1) + 4] == 0, "%d strided coordinates outside the packable range",
+                    pinned[4 + 8 * (l - 1) + 4]);
+      out->n_rows[l] = pinned[4 + 8 * (l - 1)];
+    }
+  }
+  // kernel maps (CoordinateManager.get_kernel_map), one presence bitmap per coordinate table
+  int32_t* bitmap[GCL_MAX_LEVELS] = {nullptr};
+  for (int s = 0; s < n_specs; ++s) {
+    const gcl_map_spec& sp = specs[s];
+    gcl_map_desc& d = out->maps[s];
+    d.t_in = sp.t_in;
+    d.kernel_size = sp.kernel_size;
+    d.stride = sp.stride;
+    d.K = sp.kernel_size * sp.kernel_size * sp.kernel_size;
+    d.level_in = level_of(sp.t_in);
+    d.level_out = level_of(sp.t_in * sp.stride);
+    GCL_CHECK_ARG(d.level_in >= 0 && d.level_out >= 0 && d.level_out < n_levels && (sp.stride == 1 || sp.stride == 2),
+                  "gcl_maps_build: map %d (t_in %d, stride %d) is outside the %d levels built", s, sp.t_in, sp.stride, n_levels);
+    GCL_CHECK_ARG(sp.kernel_size == 1 || sp.kernel_size == 3 || sp.kernel_size == 5, "gcl_maps_build: kernel size 1, 3 or 5");
+    d.n_in = out->n_rows[d.level_in];
+    d.n_out = out->n_rows[d.level_out];
+    if (sp.kernel_size == 1) {
+      GCL_CHECK_ARG(sp.stride == 1, "gcl_maps_build: kernel_size 1 with stride > 1");
+      continue;      // identity pairs only, after the counts are known (nothing to count here)
+    }
+    d.nbr = A.take_n<int32_t>((long long)d.K * d.n_out);
+    const bool same = sp.stride == 1;
+    d.nbr_t = same ? nullptr : A.take_n<int32_t>((long long)d.K * d.n_in);
+    d.counts = A.take_n<int32_t>(d.K);
+    const bool bitmap_valid = bitmap[d.level_in] != nullptr;
+    if (!bitmap_valid) bitmap[d.level_in] = A.take_n<int32_t>(gcl_kernel_map_bitmap_len());
+    int32_t* scratch = A.take_n<int32_t>(gcl_kernel_map_scratch_len(sp.kernel_size, d.n_out));
+    PLAN_CALL(gcl_kernel_map(out->coords[d.level_out], d.n_out, out->table[d.level_in], out->cap[d.level_in],
+                             sp.kernel_size, sp.t_in, (same ? 1 : 0) | (bitmap_valid ? 2 : 0), bitmap[d.level_in], scratch,
+                             d.nbr, d.nbr_t, d.n_in, d.counts, stream));
+    if (!A.dry)
+      GCL_CHECK_HIP(hipMemcpyAsync(pinned + 128 * (s + 1), d.counts, sizeof(int32_t) * d.K, hipMemcpyDeviceToHost, st));
+  }
+  // mask-sorted tables (KernelMap.sorted_table); K > 27 tables are used as they are
+  for (int s = 0; s < n_specs; ++s) {
+    const gcl_map_spec& sp = specs[s];
+    gcl_map_desc& d = out->maps[s];
+    if (sp.kernel_size == 1) continue;
+    for (int tr = 0; tr < 2; ++tr) {
+      if (!(sp.tables & (1 << tr))) continue;
+      const int32_t* tbl = tr ? d.nbr_t : d.nbr;
+      GCL_CHECK_ARG(tbl, "gcl_maps_build: map %d has no transposed table (stride 1)", s);
+      const long long rows = tr ? d.n_in : d.n_out;
+      GCL_CHECK_ARG(d.K <= 27, "gcl_maps_build: sorted tables need K <= 27");
+      int32_t* scratch = A.take_n<int32_t>(gcl_table_sort_scratch_len(rows));
+      int32_t* order = A.take_n<int32_t>(rows);
+      int32_t* sorted = A.take_n<int32_t>((long long)d.K * rows);
+      int32_t* mask = A.take_n<int32_t>(cdiv(rows, 32));
+      PLAN_CALL(gcl_table_sort_pre(tbl, d.K, rows, 0, nullptr, scratch, order, sorted, mask, stream));
+      if (tr) { d.tbl_t = sorted; d.order_t = order; d.mask_t = mask; }
+      else { d.tbl_n = sorted; d.order_n = order; d.mask_n = mask; }
+    }
+  }
+  // the second host sync: per-offset pair counts -> padded segment offsets -> pair lists (KernelMap.pairs)
+  if (!A.dry) GCL_CHECK_HIP(hipStreamSynchronize(st));
+  for (int s = 0; s < n_specs; ++s) {
+    const gcl_map_spec& sp = specs[s];
+    gcl_map_desc& d = out->maps[s];
+    if (sp.kernel_size == 1) {
+      if (!sp.pairs) continue;
+      const long long total = cdiv(d.n_in, GCL_PAIR_CHUNK) * GCL_PAIR_CHUNK;
+      d.pair_in = d.pair_out = A.take_n<int32_t>(total);
+      d.seg_off[0] = 0;
+      d.seg_off[1] = total;
+      d.n_pairs = d.n_in;
+      d.counts_host[0] = (int32_t)d.n_in;
+      if (!A.dry) {
+        hipLaunchKernelGGL(k_identity_pairs, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, d.pair_in, (long long)d.n_in,
+                           total);
+        GCL_CHECK_LAUNCH();
+      }
+      continue;
+    }
+    long long total = 0;
+    d.seg_off[0] = 0;
+    for (int k = 0; k < d.K; ++k) {
+      // dry run: every output row could own every offset
+      const long long c = A.dry ? d.n_out : (long long)pinned[128 * (s + 1) + k];
+      d.counts_host[k] = (int32_t)c;
+      d.n_pairs += c;
+      total += cdiv(c, GCL_PAIR_CHUNK) * GCL_PAIR_CHUNK;
+      d.seg_off[k + 1] = total;
+    }
+    if (!sp.pairs) continue;
+    const long long len = total > 0 ? total : 1;
+    int32_t* both = A.take_n<int32_t>(2 * len);
+    d.pair_in = both;
+    d.pair_out = both + len;
+    int32_t* scratch = A.take_n<int32_t>((long long)d.K * cdiv(d.n_out, 1024) + d.K + 1);
+    PLAN_CALL(gcl_kernel_map_pairs(d.nbr, d.K, d.n_out, d.seg_off, scratch, d.pair_in, d.pair_out, stream));
+  }
+  out->arena_used = A.off;
+  if (!A.fits()) {
+    set_error("gcl_maps_build: arena too small (%lld bytes needed, %lld given)", A.off, A.size);
+    return GCL_ERR_ARENA;
+  }
+  return GCL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// plan
+// ---------------------------------------------------------------------------------------------------
+struct TState {            // a tensor of the pass (forward value or gradient)
+  float* ptr = nullptr;
+  int32_t* amax = nullptr;   // amax slot that holds max|tensor|, or NULL = not measured yet
+  void* planes = nullptr;    // gcl_split_planes image, or NULL = not made yet
+};
+
+struct OpSaved {           // what the backward pass of a record needs from its forward pass
+  float* conv_out = nullptr;            // CONVBN: the convolution output (the BatchNorm input)
+  unsigned long long* mask = nullptr;   // CONVBN with relu: sign bits of the output
+  float *mean = nullptr, *rstd = nullptr;
+  int32_t* x_amax = nullptr;
+  float* norm = nullptr;                // ROWNORM
+};
+
+struct ProfRec {
+  hipEvent_t e0, e1;
+  double kind, pairs, cin, cout, n_in, n_out, K;
+};
+
+struct Plan {
+  std::vector<gcl_plan_op> ops;
+  int n_tensors = 0, n_params = 0, n_bn = 0, presplit = 128;
+  std::vector<int> worder;          // parameter ids of the MFMA-shaped kernels (amax slot / pack order)
+  std::vector<int> widx;            // parameter id -> position in worder, -1 otherwise
+  std::vector<int> wmode;           // per position: input-gradient pack mode (1 | 2), 0 = no input gradient needed
+  std::vector<long long> wK, wcin, wcout, off_fwd, off_bwd;
+  long long bytes_fwd = 0, bytes_bwd = 0, wgs_fwd = 0, wgs_bwd = 0;
+  int n_bwd = 0;
+  std::vector<char> made;           // tensor id -> produced by a record of the plan
+  // device tables (inside the caller's `state` buffer), re-uploaded when a parameter pointer changes
+  std::vector<long long> host_tables, uploaded;
+  // per pass
+  const gcl_maps_desc* maps = nullptr;
+  gcl_maps_desc maps_copy;
+  std::vector<TState> t, g;
+  std::vector<OpSaved> saved;
+  std::vector<void*> params;
+  Arena A{DRY_BASE, 0, 0, true};
+  int32_t* slot_pool = nullptr;
+  long long n_slots = 0, next_slot = 0;
+  bool slots_exhausted = false;
+  int32_t* w_amax = nullptr;        // [n_weights][GCL_AMAX_WORDS]
+  unsigned char *pack_fwd = nullptr, *pack_bwd = nullptr;
+  void* state = nullptr;
+  bool forward_done = false, bwd_packed = false;
+  // profiling
+  bool profile = false;
+  std::vector<ProfRec> prof;
+  size_t prof_used = 0;
+};
+
+static long long state_words(const Plan& P) { return (long long)P.worder.size() * (2 + 8 + 8); }
+
+static int32_t* new_slot(Plan& P) {      // slots are used once per pass (they start zeroed); the pool is sized for the worst case
+  if (P.next_slot >= P.n_slots) {
+    P.slots_exhausted = true;
+    return P.slot_pool;
+  }
+  return P.slot_pool + (P.next_slot++) * GCL_AMAX_WORDS;
+}
+
+static int ensure_amax(Plan& P, TState& ts, long long numel, hipStream_t st) {
+  Arena& A = P.A;
+  if (ts.amax) return GCL_OK;
+  ts.amax = new_slot(P);
+  PLAN_CALL(gcl_amax(ts.ptr, numel, ts.amax, 1, (void*)st));
+  return GCL_OK;
+}
+
+static int ensure_planes(Plan& P, TState& ts, long long n, int c, hipStream_t st) {
+  Arena& A = P.A;
+  if (ts.planes) return GCL_OK;
+  ts.planes = A.take(n * c * 4);
+  PLAN_CALL(gcl_split_planes(ts.ptr, n, c, ts.amax, ts.planes, (void*)st));
+  return GCL_OK;
+}
+
+struct ProfScope {      // brackets one launch with events when profiling is armed
+  Plan& P;
+  hipStream_t st;
+  ProfRec* r = nullptr;
+  ProfScope(Plan& P_, hipStream_t st_, int kind, double pairs, int cin, int cout, long long n_in, long long n_out, int K)
+      : P(P_), st(st_) {
+    if (!P.profile || P.A.dry) return;
+    if (P.prof_used == P.prof.size()) {
+      ProfRec nr{};
+      if (hipEventCreate(&nr.e0) != hipSuccess || hipEventCreate(&nr.e1) != hipSuccess) return;
+      P.prof.push_back(nr);
+    }
+    r = &P.prof[P.prof_used++];
+    r->kind = kind; r->pairs = pairs; r->cin = cin; r->cout = cout; r->n_in = (double)n_in; r->n_out = (double)n_out; r->K = K;
+    (void)hipEventRecord(r->e0, st);
+  }
+  ~ProfScope() { if (r) (void)hipEventRecord(r->e1, st); }
+};
+
+static bool is_stem(const gcl_plan_op& op, const gcl_map_desc& m) {
+  return op.cin <= 4 && (op.cout % 32) == 0 && !op.transpose && m.kernel_size > 1 && op.bias < 0;
+}
+
+// the convolution of a CONVBN / CONV record (ops._SparseConvFn.forward); returns its output in *y_out
+static int conv_forward(Plan& P, int i, float** y_out, float** stats_out, hipStream_t st) {
+  Arena& A = P.A;
+  const gcl_plan_op& op = P.ops[i];
+  const gcl_maps_desc& M = *P.maps;
+  const gcl_map_desc& m = M.maps[op.map];
+  const long long n_in = M.n_rows[op.level_in], n_out = M.n_rows[op.level_out];
+  TState& x = P.t[op.x];
+  float* y = A.take_n<float>(n_out * op.cout);
+  *y_out = y;
+  *stats_out = nullptr;
+  const float* W = (const float*)P.params[op.w];
+  if (is_stem(op, m)) {
+    PLAN_CALL(gcl_stem_fwd(x.ptr, W, m.nbr, n_out, op.K, op.cin, op.cout, y, (void*)st));
+    return GCL_OK;
+  }
+  const int wi = P.widx[op.w];
+  int rc = ensure_amax(P, x, n_in * op.cin, st);
+  if (rc) return rc;
+  P.saved[i].x_amax = x.amax;
+  const bool pl = op.cin >= P.presplit;
+  if (pl && (rc = ensure_planes(P, x, n_in, op.cin, st))) return rc;
+  float* stats = nullptr;
+  if (op.kind == GCL_OP_CONVBN) stats = A.take_n<float>(cdiv(n_out, 128) * 2 * op.cout);
+  *stats_out = stats;
+  const int32_t *tbl = nullptr, *order = nullptr, *mask = nullptr;
+  if (m.kernel_size > 1) {
+    tbl = op.transpose ? m.tbl_t : m.tbl_n;
+    order = op.transpose ? m.order_t : m.order_n;
+    mask = op.transpose ? m.mask_t : m.mask_n;
+    GCL_CHECK_ARG(A.dry || tbl, "gcl_plan_forward: record %d needs a sorted table the maps do not carry", i);
+  }
+  const float* bias = op.bias >= 0 ? (const float*)P.params[op.bias] : nullptr;
+  ProfScope ps(P, st, 0, (double)(m.kernel_size > 1 ? m.n_pairs : n_out), op.cin, op.cout, n_in, n_out, op.K);
+  PLAN_CALL(gcl_conv_fwd(pl ? (const float*)x.planes : x.ptr, n_in, pl ? 1 : 0, P.pack_fwd + P.off_fwd[wi], 4, x.amax,
+                         P.w_amax + (long long)wi * GCL_AMAX_WORDS, tbl, order, mask, n_out, op.K, op.cin, op.cout, bias,
+                         y, stats, 0, (void*)st));
+  return GCL_OK;
+}
+
+static int upload_tables(Plan& P, hipStream_t st) {
+  // [ptrs n | sizes n | fwd desc n x 8 | bwd desc n_bwd x 8]  (WeightAmaxGroup.refresh / .packed)
+  const size_t n = P.worder.size();
+  std::vector<long long>& h = P.host_tables;
+  h.assign((size_t)state_words(P), 0);
+  long long wg = 0;
+  for (size_t q = 0; q < n; ++q) {
+    h[q] = (long long)(uintptr_t)P.params[P.worder[q]];
+    h[n + q] = P.wK[q] * P.wcin[q] * P.wcout[q];
+    long long* d = &h[2 * n + 8 * q];
+    d[0] = h[q]; d[1] = P.wK[q]; d[2] = P.wcin[q]; d[3] = P.wcout[q]; d[4] = 0; d[5] = (long long)q; d[6] = P.off_fwd[q]; d[7] = wg;
+    wg += cdiv(h[n + q], 256);
+  }
+  P.wgs_fwd = wg;
+  wg = 0;
+  size_t row = 0;
+  for (size_t q = 0; q < n; ++q) {
+    if (!P.wmode[q]) continue;
+    long long* d = &h[2 * n + 8 * n + 8 * row++];
+    d[0] = h[q]; d[1] = P.wK[q]; d[2] = P.wcin[q]; d[3] = P.wcout[q]; d[4] = P.wmode[q]; d[5] = (long long)q; d[6] = P.off_bwd[q]; d[7] = wg;
+    wg += cdiv(h[n + q], 256);
+  }
+  P.wgs_bwd = wg;
+  if (h != P.uploaded) {      // parameters were (re-)seated: rare; the copy is finished before the vector can change
+    GCL_CHECK_HIP(hipMemcpyAsync(P.state, h.data(), h.size() * sizeof(long long), hipMemcpyHostToDevice, st));
+    GCL_CHECK_HIP(hipStreamSynchronize(st));
+    P.uploaded = h;
+  }
+  return GCL_OK;
+}
+
+static int plan_forward(Plan& P, const float* x_in, void* const* bn_stats, float** y_out, hipStream_t st) {
+  Arena& A = P.A;
+  const gcl_maps_desc& M = *P.maps;
+  const size_t nw = P.worder.size();
+  P.t.assign(P.n_tensors, TState());
+  P.g.assign(P.n_tensors, TState());
+  P.saved.assign(P.ops.size(), OpSaved());
+  if (P.profile && !A.dry) P.prof_used = 0;      // records of a profiled pass stay readable until the next profiled pass
+  // amax slots of the pass: one zero fill (ops.amax_slot hands out slots of a zero-filled pool)
+  P.n_slots = 4 * (long long)P.n_tensors + 2 * (long long)P.ops.size() + 16;
+  P.next_slot = 0;
+  P.slots_exhausted = false;
+  P.slot_pool = A.take_n<int32_t>(P.n_slots * GCL_AMAX_WORDS);
+  if (!A.dry) GCL_CHECK_HIP(hipMemsetAsync(P.slot_pool, 0, (size_t)P.n_slots * GCL_AMAX_WORDS * sizeof(int32_t), st));
+  // all convolution kernels: max|W| in one launch, forward packs in one launch (WeightAmaxGroup)
+  P.w_amax = A.take_n<int32_t>((long long)nw * GCL_AMAX_WORDS);
+  P.pack_fwd = (unsigned char*)A.take(P.bytes_fwd);
+  P.bwd_packed = false;
+  if (nw && !A.dry) {
+    int rc = upload_tables(P, st);
+    if (rc) return rc;
+    const long long* tab = (const long long*)P.state;
+    PLAN_CALL(gcl_amax_multi((const float* const*)tab, (const int64_t*)(tab + nw), (int32_t)nw, P.w_amax, (void*)st));
+    PLAN_CALL(gcl_pack_weights_multi((const int64_t*)(tab + 2 * nw), (int32_t)nw, P.wgs_fwd, 4, P.w_amax, P.pack_fwd, (void*)st));
+  }
+  P.t[0].ptr = (float*)x_in;
+  for (size_t i = 0; i < P.ops.size(); ++i) {
+    const gcl_plan_op& op = P.ops[i];
+    const long long n_out = M.n_rows[op.level_out];
+    TState& y = P.t[op.y];
+    int rc;
+    switch (op.kind) {
+      case GCL_OP_CONVBN: {
+        float *cy, *stats;
+        if ((rc = conv_forward(P, (int)i, &cy, &stats, st))) return rc;
+        OpSaved& sv = P.saved[i];
+        sv.conv_out = cy;
+        const int c = op.cout;
+        float* mr = A.take_n<float>(2 * c);
+        sv.mean = mr;
+        sv.rstd = mr + c;
+        float* rm = (float*)bn_stats[2 * op.bn];
+        float* rv = (float*)bn_stats[2 * op.bn + 1];
+        if (stats) {       // column sums from the convolution epilogue
+          const long long nt = cdiv(n_out, 128);
+          double* scratch = A.take_n<double>(gcl_bn_tiles_scratch_len(nt, c));
+          PLAN_CALL(gcl_bn_stats_from_tiles(stats, nt, n_out, c, op.eps, op.momentum, rm, rv, scratch, sv.mean, sv.rstd, (void*)st));
+        } else {
+          double* scratch = A.take_n<double>(gcl_bn_scratch_len(n_out, c));
+          PLAN_CALL(gcl_bn_stats(cy, n_out, c, op.eps, op.momentum, rm, rv, scratch, sv.mean, sv.rstd, (void*)st));
+        }
+        y.ptr = A.take_n<float>(n_out * c);
+        y.amax = new_slot(P);
+        if (op.relu) sv.mask = A.take_n<unsigned long long>(gcl_bn_mask_len(n_out, c));
+        const float* res = op.x2 >= 0 ? P.t[op.x2].ptr : nullptr;
+        PLAN_CALL(gcl_bn_apply(cy, n_out, c, sv.mean, sv.rstd, (const float*)P.params[op.bn_w], (const float*)P.params[op.bn_b],
+                               res, op.relu, y.ptr, (uint64_t*)sv.mask, y.amax, (void*)st));
+        break;
+      }
+      case GCL_OP_CONV: {
+        float *cy, *stats;
+        if ((rc = conv_forward(P, (int)i, &cy, &stats, st))) return rc;
+        y.ptr = cy;
+        break;
+      }
+      case GCL_OP_RELU: {
+        const long long n4 = n_out * op.cout / 4;
+        y.ptr = A.take_n<float>(n_out * op.cout);
+        if (!A.dry) {
+          hipLaunchKernelGGL(k_relu_fwd, dim3(grid_for(n4)), dim3(256), 0, st, (const float4*)P.t[op.x].ptr, n4, (float4*)y.ptr);
+          GCL_CHECK_LAUNCH();
+        }
+        break;
+      }
+      case GCL_OP_CAT: {
+        const int ca = op.cin, cb = op.cout - op.cin;
+        y.ptr = A.take_n<float>(n_out * op.cout);
+        if (!A.dry) {
+          hipLaunchKernelGGL(k_cat2, dim3(grid_for(n_out * op.cout / 4)), dim3(256), 0, st, (const float4*)P.t[op.x].ptr, ca / 4,
+                             (const float4*)P.t[op.x2].ptr, cb / 4, n_out, (float4*)y.ptr);
+          GCL_CHECK_LAUNCH();
+        }
+        break;
+      }
+      case GCL_OP_ROWNORM: {
+        y.ptr = A.take_n<float>(n_out * op.cout);
+        P.saved[i].norm = A.take_n<float>(n_out);
+        PLAN_CALL(gcl_row_normalize_fwd(P.t[op.x].ptr, n_out, op.cout, y.ptr, P.saved[i].norm, (void*)st));
+        break;
+      }
+      default:
+        set_error("gcl_plan_forward: unknown record kind %d", op.kind);
+        return GCL_ERR_ARG;
+    }
+  }
+  *y_out = P.t[P.ops.back().y].ptr;
+  return GCL_OK;
+}
+
+// Tape.backward's give(): the first gradient of a tensor is kept, later ones are added in arrival order
+static int give(Plan& P, int tensor, float* gptr, long long numel, hipStream_t st) {
+  Arena& A = P.A;
+  if (tensor < 0 || !P.made[tensor] || !gptr) return GCL_OK;
+  TState& g = P.g[tensor];
+  if (!g.ptr) {
+    g = TState();
+    g.ptr = gptr;
+    return GCL_OK;
+  }
+  float* sum = A.take_n<float>(numel);
+  if (!A.dry) {
+    hipLaunchKernelGGL(k_add2, dim3(grid_for(numel / 4)), dim3(256), 0, st, (const float4*)g.ptr, (const float4*)gptr, numel / 4,
+                       (float4*)sum);
+    GCL_CHECK_LAUNCH();
+  }
+  g = TState();
+  g.ptr = sum;
+  return GCL_OK;
+}
+
+// ops._SparseConvFn.backward for record i with output gradient dy (dy.amax set when a producer published it)
+static int conv_backward(Plan& P, int i, TState dy, void* const* grads, hipStream_t st) {
+  Arena& A = P.A;
+  const gcl_plan_op& op = P.ops[i];
+  const gcl_maps_desc& M = *P.maps;
+  const gcl_map_desc& m = M.maps[op.map];
+  const long long n_in = M.n_rows[op.level_in], n_out = M.n_rows[op.level_out];
+  TState& x = P.t[op.x];
+  float* dW = (float*)grads[op.w];
+  int rc;
+  if (is_stem(op, m)) {
+    float* scratch = A.take_n<float>(gcl_stem_bwd_weight_scratch_len(op.K, op.cin, op.cout, n_out));
+    ProfScope ps(P, st, 2, (double)m.n_pairs, op.cin, op.cout, n_in, n_out, op.K);
+    PLAN_CALL(gcl_stem_bwd_weight(x.ptr, dy.ptr, m.nbr, n_out, op.K, op.cin, op.cout, scratch, dW, (void*)st));
+    return GCL_OK;
+  }
+  const int wi = P.widx[op.w];
+  if ((rc = ensure_amax(P, dy, n_out * op.cout, st))) return rc;
+  const int32_t* w_amax = P.w_amax + (long long)wi * GCL_AMAX_WORDS;
+  const double pairs = (double)(m.kernel_size > 1 ? m.n_pairs : n_out);
+  if (P.made[op.x]) {      // input gradient: the same output-stationary kernel over the opposite table
+    int mode;
+    const int32_t *tbl = nullptr, *order = nullptr, *mask = nullptr;
+    if (m.kernel_size == 1) mode = 1;
+    else if (op.transpose) { mode = 1; tbl = m.tbl_n; order = m.order_n; mask = m.mask_n; }
+    else if (m.stride == 1) { mode = 2; tbl = m.tbl_n; order = m.order_n; mask = m.mask_n; }
+    else { mode = 1; tbl = m.tbl_t; order = m.order_t; mask = m.mask_t; }
+    GCL_CHECK_ARG(mode == P.wmode[wi], "gcl_plan_backward: record %d: input-gradient pack mode mismatch", i);
+    GCL_CHECK_ARG(A.dry || m.kernel_size == 1 || tbl, "gcl_plan_backward: record %d needs a sorted table the maps do not carry", i);
+    const bool pl = op.cout >= P.presplit;
+    if (pl && (rc = ensure_planes(P, dy, n_out, op.cout, st))) return rc;
+    float* acc = P.g[op.x].ptr;       // a gradient that already reached x through another path: added in the epilogue
+    float* dx = A.take_n<float>(n_in * op.cin);
+    {
+      ProfScope ps(P, st, acc ? 1 : 0, pairs, op.cout, op.cin, n_out, n_in, op.K);
+      if (acc)
+        PLAN_CALL(gcl_conv_fwd_fused(pl ? (const float*)dy.planes : dy.ptr, n_out, pl ? 1 : 0, P.pack_bwd + P.off_bwd[wi], 4,
+                                     dy.amax, w_amax, tbl, order, mask, n_in, op.K, op.cout, op.cin, nullptr, nullptr, acc, 0,
+                                     nullptr, dx, nullptr, 0, (void*)st));
+      else
+        PLAN_CALL(gcl_conv_fwd(pl ? (const float*)dy.planes : dy.ptr, n_out, pl ? 1 : 0, P.pack_bwd + P.off_bwd[wi], 4, dy.amax,
+                               w_amax, tbl, order, mask, n_in, op.K, op.cout, op.cin, nullptr, dx, nullptr, 0, (void*)st));
+    }
+    P.g[op.x] = TState();
+    P.g[op.x].ptr = dx;
+  }
+  {      // weight gradient over the compacted pair lists
+    const int32_t *pa = m.pair_in, *pb = m.pair_out;
+    if (op.transpose) { pa = m.pair_out; pb = m.pair_in; }
+    GCL_CHECK_ARG(A.dry || (pa && pb), "gcl_plan_backward: record %d needs pair lists the maps do not carry", i);
+    float* scratch = A.take_n<float>(gcl_conv_bwd_weight_scratch_len(op.K, op.cin, op.cout, m.seg_off[op.K]));
+    const bool pl = op.cin >= P.presplit && op.cout >= P.presplit;
+    if (pl) {
+      x.amax = P.saved[i].x_amax;
+      if ((rc = ensure_planes(P, x, n_in, op.cin, st))) return rc;
+      if ((rc = ensure_planes(P, dy, n_out, op.cout, st))) return rc;
+    }
+    ProfScope ps(P, st, 2, pairs, op.cin, op.cout, n_in, n_out, op.K);
+    PLAN_CALL(gcl_conv_bwd_weight(pl ? (const float*)x.planes : x.ptr, n_in, pl ? (const float*)dy.planes : dy.ptr, n_out,
+                                  pl ? 1 : 0, pa, pb, m.seg_off, op.K, op.cin, op.cout, 4, P.saved[i].x_amax, dy.amax, scratch,
+                                  dW, (void*)st));
+  }
+  if (op.bias >= 0) {
+    double* scratch = A.take_n<double>(gcl_bn_scratch_len(n_out, op.cout));
+    PLAN_CALL(gcl_col_sum(dy.ptr, n_out, op.cout, scratch, (float*)grads[op.bias], (void*)st));
+  }
+  return GCL_OK;
+}
+
+static int plan_backward(Plan& P, const float* dy, void* const* grads, int first, int last, hipStream_t st) {
+  Arena& A = P.A;
+  const gcl_maps_desc& M = *P.maps;
+  const size_t nw = P.worder.size();
+  if (last == (int)P.ops.size()) {
+    P.g[P.ops.back().y] = TState();
+    P.g[P.ops.back().y].ptr = (float*)dy;
+  }
+  if (!P.bwd_packed) {       // input-gradient packs of all kernels in one launch (WeightAmaxGroup.packed("bwd"))
+    P.pack_bwd = (unsigned char*)A.take(P.bytes_bwd);
+    if (P.n_bwd && !A.dry) {
+      const long long* tab = (const long long*)P.state;
+      PLAN_CALL(gcl_pack_weights_multi((const int64_t*)(tab + 2 * nw + 8 * nw), P.n_bwd, P.wgs_bwd, 4, P.w_amax, P.pack_bwd,
+                                       (void*)st));
+    }
+    P.bwd_packed = true;
+  }
+  for (int i = last - 1; i >= first; --i) {
+    const gcl_plan_op& op = P.ops[i];
+    const long long n_out = M.n_rows[op.level_out], n_in = M.n_rows[op.level_in];
+    TState g = P.g[op.y];
+    P.g[op.y] = TState();
+    if (!g.ptr) continue;
+    int rc;
+    switch (op.kind) {
+      case GCL_OP_CONVBN: {
+        const OpSaved& sv = P.saved[i];
+        const int c = op.cout;
+        float* sum_g = (float*)grads[op.bn_b];
+        float* sum_gx = (float*)grads[op.bn_w];
+        double* scratch = A.take_n<double>(gcl_bn_scratch_len(n_out, c));
+        PLAN_CALL(gcl_bn_bwd_reduce(sv.conv_out, g.ptr, nullptr, (const uint64_t*)sv.mask, n_out, c, sv.mean, sv.rstd, op.relu,
+                                    scratch, sum_g, sum_gx, (void*)st));
+        TState d;
+        d.ptr = A.take_n<float>(n_out * c);
+        d.amax = new_slot(P);
+        float* dres = op.x2 >= 0 ? A.take_n<float>(n_out * c) : nullptr;
+        PLAN_CALL(gcl_bn_bwd_apply(sv.conv_out, g.ptr, nullptr, (const uint64_t*)sv.mask, n_out, c, sv.mean, sv.rstd,
+                                   (const float*)P.params[op.bn_w], sum_g, sum_gx, op.relu, d.ptr, dres, d.amax, (void*)st));
+        if ((rc = conv_backward(P, i, d, grads, st))) return rc;
+        if ((rc = give(P, op.x2, dres, n_out * c, st))) return rc;
+        break;
+      }
+      case GCL_OP_CONV:
+        if ((rc = conv_backward(P, i, g, grads, st))) return rc;
+        break;
+      case GCL_OP_RELU: {
+        const long long numel = n_out * op.cout;
+        float* gx = A.take_n<float>(numel);
+        if (!A.dry) {
+          hipLaunchKernelGGL(k_relu_bwd, dim3(grid_for(numel / 4)), dim3(256), 0, st, (const float4*)g.ptr,
+                             (const float4*)P.t[op.y].ptr, numel / 4, (float4*)gx);
+          GCL_CHECK_LAUNCH();
+        }
+        if ((rc = give(P, op.x, gx, numel, st))) return rc;
+        break;
+      }
+      case GCL_OP_CAT: {
+        const int ca = op.cin, cb = op.cout - op.cin;
+        float* ga = A.take_n<float>(n_out * ca);
+        float* gb = A.take_n<float>(n_out * cb);
+        if (!A.dry) {
+          hipLaunchKernelGGL(k_split2, dim3(grid_for(n_out * op.cout / 4)), dim3(256), 0, st, (const float4*)g.ptr, ca / 4, cb / 4,
+                             n_out, (float4*)ga, (float4*)gb);
+          GCL_CHECK_LAUNCH();
+        }
+        if ((rc = give(P, op.x, ga, n_out * ca, st))) return rc;
+        if ((rc = give(P, op.x2, gb, n_out * cb, st))) return rc;
+        break;
+      }
+      case GCL_OP_ROWNORM: {
+        float* dx = A.take_n<float>(n_in * op.cin);
+        PLAN_CALL(gcl_row_normalize_bwd(P.t[op.y].ptr, g.ptr, P.saved[i].norm, n_out, op.cout, dx, (void*)st));
+        if ((rc = give(P, op.x, dx, n_in * op.cin, st))) return rc;
+        break;
+      }
+      default:
+        return GCL_ERR_ARG;
+    }
+  }
+  return GCL_OK;
+}
+
+static int check_maps(const Plan& P, const gcl_maps_desc* M) {
+  GCL_CHECK_ARG(M && M->n_levels >= 1 && M->n_levels <= GCL_MAX_LEVELS && M->n_maps >= 0 && M->n_maps <= GCL_MAX_MAPS,
+                "gcl_plan: bad maps descriptor");
+  for (size_t i = 0; i < P.ops.size(); ++i) {
+    const gcl_plan_op& op = P.ops[i];
+    GCL_CHECK_ARG(op.level_in < M->n_levels && op.level_out < M->n_levels, "gcl_plan: record %d uses a level the maps lack", (int)i);
+    if (op.kind == GCL_OP_CONVBN || op.kind == GCL_OP_CONV) {
+      GCL_CHECK_ARG(op.map >= 0 && op.map < M->n_maps, "gcl_plan: record %d names map %d of %d", (int)i, op.map, M->n_maps);
+      const gcl_map_desc& m = M->maps[op.map];
+      GCL_CHECK_ARG(m.K == op.K, "gcl_plan: record %d expects K = %d, map %d has %d", (int)i, op.K, op.map, m.K);
+      const int lin = op.transpose ? m.level_out : m.level_in, lout = op.transpose ? m.level_in : m.level_out;
+      GCL_CHECK_ARG(lin == op.level_in && lout == op.level_out, "gcl_plan: record %d and map %d disagree on the levels", (int)i, op.map);
+    }
+  }
+  return GCL_OK;
+}
+
+}  // namespace gcl
+
+using namespace gcl;
+
+extern "C" {
+
+int64_t gcl_maps_arena_bytes(int64_t n, const gcl_map_spec* specs_host, int32_t n_specs, int32_t n_levels) {
+  if (n <= 0 || !specs_host || n_specs < 0 || n_specs > GCL_MAX_MAPS || n_levels < 1 || n_levels > GCL_MAX_LEVELS) return -1;
+  Arena A{DRY_BASE, 0, 0, true};
+  gcl_maps_desc d;
+  if (maps_build(nullptr, n, specs_host, n_specs, n_levels, A, nullptr, &d, nullptr) != GCL_OK) return -1;
+  return A.off + 4096;
+}
+
+int gcl_maps_build(const int32_t* coords, int64_t n, const gcl_map_spec* specs_host, int32_t n_specs, int32_t n_levels,
+                   void* arena, int64_t arena_bytes, void* pinned_host, gcl_maps_desc* out_host, void* stream) {
+  GCL_CHECK_ARG(coords && specs_host && arena && pinned_host && out_host, "gcl_maps_build: null pointer");
+  GCL_CHECK_ARG(n > 0, "gcl_maps_build: empty SparseTensor");
+  GCL_CHECK_ARG(n_specs >= 0 && n_specs <= GCL_MAX_MAPS && n_levels >= 1 && n_levels <= GCL_MAX_LEVELS,
+                "gcl_maps_build: at most %d maps and %d levels", GCL_MAX_MAPS, GCL_MAX_LEVELS);
+  // read-back area (int32): row 0 = input status + per-level meta, row s + 1 = the pair counts of map s; 128 words per row
+  Arena A{(char*)arena, arena_bytes, 0, false};
+  return maps_build(coords, n, specs_host, n_specs, n_levels, A, (int32_t*)pinned_host, out_host, (hipStream_t)stream);
+}
+
+void* gcl_plan_create(const gcl_plan_op* ops_host, int32_t n_ops, int32_t n_tensors, int32_t n_params,
+                      const int32_t* weight_order_host, int32_t n_weights, int32_t presplit_min_c) {
+  if (!ops_host || n_ops <= 0 || n_tensors <= 1 || n_params <= 0 || n_weights < 0 || (n_weights && !weight_order_host)) {
+    set_error("gcl_plan_create: bad argument");
+    return nullptr;
+  }
+  Plan* P = new (std::nothrow) Plan();
+  if (!P) {
+    set_error("gcl_plan_create: out of host memory");
+    return nullptr;
+  }
+  P->ops.assign(ops_host, ops_host + n_ops);
+  P->n_tensors = n_tensors;
+  P->n_params = n_params;
+  P->presplit = presplit_min_c > 0 ? presplit_min_c : 128;
+  P->worder.assign(weight_order_host, weight_order_host + n_weights);
+  P->widx.assign(n_params, -1);
+  P->made.assign(n_tensors, 0);
+  const size_t nw = (size_t)n_weights;
+  P->wmode.assign(nw, 0);
+  P->wK.assign(nw, 0);
+  P->wcin.assign(nw, 0);
+  P->wcout.assign(nw, 0);
+  P->off_fwd.assign(nw, 0);
+  P->off_bwd.assign(nw, 0);
+  bool ok = true;
+  for (int q = 0; q < n_weights && ok; ++q) {
+    const int p = weight_order_host[q];
+    ok = p >= 0 && p < n_params && P->widx[p] < 0;
+    if (ok) P->widx[p] = q;
+  }
+  std::vector<char> seen_param(n_params, 0);
+  for (int i = 0; i < n_ops && ok; ++i) {
+    const gcl_plan_op& op = P->ops[i];
+    auto tensor_ok = [&](int t) { return t >= 0 && t < n_tensors; };
+    ok = tensor_ok(op.x) && tensor_ok(op.y) && op.y != 0 && !P->made[op.y] && (op.x == 0 || P->made[op.x]) &&
+         op.level_in >= 0 && op.level_in < GCL_MAX_LEVELS && op.level_out >= 0 && op.level_out < GCL_MAX_LEVELS &&
+         op.cin > 0 && op.cout > 0;
+    if (!ok) break;
+    if (op.x2 >= 0) ok = tensor_ok(op.x2) && P->made[op.x2];
+    if (!ok) break;
+    auto claim = [&](int p) {       // every parameter belongs to exactly one record (its gradient is written, not added)
+      if (p < 0 || p >= n_params || seen_param[p]) return false;
+      seen_param[p] = 1;
+      return true;
+    };
+    if (op.kind == GCL_OP_CONVBN || op.kind == GCL_OP_CONV) {
+      ok = claim(op.w) && op.map >= 0 && op.map < GCL_MAX_MAPS && op.K >= 1 && op.K <= 125;
+      if (ok && op.bias >= 0) ok = claim(op.bias) && op.kind == GCL_OP_CONV;
+      if (ok && op.kind == GCL_OP_CONVBN) ok = claim(op.bn_w) && claim(op.bn_b) && op.bn >= 0 && op.cout % 4 == 0;
+      if (ok && op.kind == GCL_OP_CONVBN) P->n_bn = op.bn + 1 > P->n_bn ? op.bn + 1 : P->n_bn;
+      if (!ok) break;
+      const bool stem_shape = op.cin <= 4 && (op.cout % 32) == 0 && !op.transpose && op.K > 1 && op.bias < 0;
+      if (!stem_shape) {
+        // MFMA-shaped kernels only (the generic VALU shapes stay on the per-operator path)
+        ok = (op.cin % 32) == 0 && (op.cout % 32) == 0 && op.K <= 27 && P->widx[op.w] >= 0;
+        if (!ok) break;
+        const int q = P->widx[op.w];
+        P->wK[q] = op.K; P->wcin[q] = op.cin; P->wcout[q] = op.cout;
+        // input-gradient layout recorded by the forward pass: mirrored offsets on a stride-1 map, plain transpose otherwise
+        // (the caller tells stride-1 3^3 / 5^3 maps apart through `transpose` and level_in == level_out)
+        if (op.x != 0) P->wmode[q] = (op.K > 1 && !op.transpose && op.level_in == op.level_out) ? 2 : 1;
+      } else {
+        ok = op.x == 0;      // the Cin <= 4 first layer has no input gradient
+      }
+    } else if (op.kind == GCL_OP_CAT) {
+      ok = op.x2 >= 0 && op.cin % 4 == 0 && (op.cout - op.cin) > 0 && (op.cout - op.cin) % 4 == 0 && op.level_in == op.level_out;
+    } else if (op.kind == GCL_OP_RELU || op.kind == GCL_OP_ROWNORM) {
+      ok = op.cin == op.cout && op.cout % 4 == 0 && op.level_in == op.level_out;
+    } else {
+      ok = false;
+    }
+    P->made[op.y] = 1;
+  }
+  if (!ok) {
+    set_error("gcl_plan_create: malformed or unsupported operator records");
+    delete P;
+    return nullptr;
+  }
+  for (size_t q = 0; q < nw; ++q) {
+    if (!P->wK[q]) {
+      set_error("gcl_plan_create: weight_order names a parameter no record uses");
+      delete P;
+      return nullptr;
+    }
+    const long long bytes = (gcl_pack_weights_bytes((int)P->wK[q], (int)P->wcin[q], (int)P->wcout[q], 4) + 255) / 256 * 256;
+    P->off_fwd[q] = P->bytes_fwd;
+    P->bytes_fwd += bytes;
+    if (P->wmode[q]) {
+      P->off_bwd[q] = P->bytes_bwd;
+      P->bytes_bwd += bytes;
+      ++P->n_bwd;
+    }
+  }
+  return P;
+}
+
+void gcl_plan_destroy(void* plan) {
+  Plan* P = (Plan*)plan;
+  if (!P) return;
+  for (ProfRec& r : P->prof) {
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  delete P;
+}
+
+int64_t gcl_plan_state_bytes(const void* plan) {
+  if (!plan) return -1;
+  return state_words(*(const Plan*)plan) * 8 + 256;
+}
+
+int64_t gcl_plan_arena_bytes(void* plan, const gcl_maps_desc* maps_host) {
+  Plan* P = (Plan*)plan;
+  if (!P || check_maps(*P, maps_host) != GCL_OK) return -1;
+  P->maps = maps_host;
+  P->A = Arena{DRY_BASE, 0, 0, true};
+  P->params.assign(P->n_params, nullptr);
+  std::vector<void*> nulls(2 * (P->n_bn > 0 ? P->n_bn : 1), nullptr), gn(P->n_params, nullptr);
+  float* y = nullptr;
+  const bool prof = P->profile;
+  P->profile = false;
+  int rc = plan_forward(*P, nullptr, nulls.data(), &y, nullptr);
+  if (rc == GCL_OK) rc = plan_backward(*P, (const float*)DRY_BASE, gn.data(), 0, (int)P->ops.size(), nullptr);
+  P->profile = prof;
+  P->forward_done = false;
+  return rc == GCL_OK ? P->A.off + 4096 : -1;
+}
+
+int gcl_plan_forward(void* plan, const gcl_maps_desc* maps_host, const float* x, void* const* params_host,
+                     void* const* bn_stats_host, void* state, void* arena, int64_t arena_bytes, float** y_out_host,
+                     void* stream) {
+  Plan* P = (Plan*)plan;
+  GCL_CHECK_ARG(P && maps_host && x && params_host && bn_stats_host && state && arena && y_out_host, "gcl_plan_forward: null pointer");
+  int rc = check_maps(*P, maps_host);
+  if (rc) return rc;
+  P->maps_copy = *maps_host;        // the backward pass runs after the caller may have released its descriptor
+  P->maps = &P->maps_copy;
+  P->params.assign(params_host, params_host + P->n_params);
+  P->state = state;
+  P->A = Arena{(char*)arena, arena_bytes, 0, false};
+  P->forward_done = false;
+  // size check first (cheap dry run of both passes): never launch into an arena that cannot hold the pass
+  {
+    Arena real = P->A;
+    P->A = Arena{DRY_BASE, 0, 0, true};
+    std::vector<void*> gn(P->n_params, nullptr);
+    float* yy = nullptr;
+    const bool prof = P->profile;
+    P->profile = false;
+    rc = plan_forward(*P, x, bn_stats_host, &yy, nullptr);
+    if (rc == GCL_OK) rc = plan_backward(*P, (const float*)DRY_BASE, gn.data(), 0, (int)P->ops.size(), nullptr);
+    P->profile = prof;
+    const long long need = P->A.off;
+    P->A = real;
+    if (rc) return rc;
+    if (need > arena_bytes) {
+      set_error("gcl_plan_forward: arena too small (%lld bytes needed, %lld given)", need, (long long)arena_bytes);
+      return GCL_ERR_ARENA;
+    }
+  }
+  rc = plan_forward(*P, x, bn_stats_host, y_out_host, (hipStream_t)stream);
+  P->forward_done = rc == GCL_OK;
+  return rc;
+}
+
+int gcl_plan_backward(void* plan, const float* dy, void* const* grads_host, int32_t first_op, int32_t last_op, void* stream) {
+  Plan* P = (Plan*)plan;
+  GCL_CHECK_ARG(P && grads_host, "gcl_plan_backward: null pointer");
+  GCL_CHECK_ARG(P->forward_done, "gcl_plan_backward: no forward pass to differentiate");
+  GCL_CHECK_ARG(first_op >= 0 && first_op < last_op && last_op <= (int)P->ops.size(), "gcl_plan_backward: bad record range");
+  GCL_CHECK_ARG(last_op != (int)P->ops.size() || dy, "gcl_plan_backward: the last segment needs dy");
+  int rc = plan_backward(*P, dy, grads_host, first_op, last_op, (hipStream_t)stream);
+  if (rc == GCL_OK && !P->A.fits()) {
+    set_error("gcl_plan_backward: arena overrun");
+    return GCL_ERR_ARENA;
+  }
+  if (rc == GCL_OK && P->slots_exhausted) {
+    set_error("gcl_plan_backward: amax slot pool exhausted");
+    return GCL_ERR_ARG;
+  }
+  if (first_op == 0) P->forward_done = false;
+  return rc;
+}
+
+int gcl_plan_profile(void* plan, int32_t enable) {
+  Plan* P = (Plan*)plan;
+  GCL_CHECK_ARG(P, "gcl_plan_profile: null plan");
+  P->profile = enable != 0;
+  return GCL_OK;
+}
+
+int gcl_plan_profile_read(void* plan, double* records_host, int32_t max_records) {
+  Plan* P = (Plan*)plan;
+  if (!P || !records_host) return GCL_ERR_ARG;
+  int n = 0;
+  for (size_t i = 0; i < P->prof_used && n < max_records; ++i) {
+    const ProfRec& r = P->prof[i];
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+    double* o = records_host + 8 * n++;
+    o[0] = r.kind; o[1] = ms; o[2] = r.pairs; o[3] = r.cin; o[4] = r.cout; o[5] = r.n_in; o[6] = r.n_out; o[7] = r.K;
+  }
+  return n;
+}
+
+}  // extern "C"

@@ -90,6 +90,7 @@ class FlatDDP:
         self.overlap, self.n_buckets = bool(overlap), max(1, int(n_buckets))
         self._bounds, self._bucket_of, self._count, self._pending, self._works = [], {}, [], [], {}
         self._sync = True
+        self.launch_order = []         # buckets started early by bucket_ready (diagnostic / tests)
 
     def attach(self, module):
         params = [p for p in module.parameters() if p.requires_grad]
@@ -144,6 +145,15 @@ class FlatDDP:
         (the hooks then leave the buckets alone) and with True before the last (buckets start as they complete)."""
         self._sync = bool(last)
 
+    def bucket_ready(self, b):
+        """Every gradient of bucket ``b`` has been written by work already enqueued on the current stream (the
+        whole-network plan calls this between its backward segments): start the bucket's all-reduce now, under the rest
+        of the backward pass.  No-op outside the last micro-step of an accumulated optimizer step."""
+        if not self._sync or self.world <= 1 or b in self._works:
+            return
+        self.launch_order.append(b)
+        self._launch(b)
+
     def _on_grad(self, p):
         if not self._sync:
             return
@@ -171,6 +181,7 @@ class FlatDDP:
                     self._works[b].wait()
                 self._pending, self._works = list(self._count), {}
                 self._sync = True
+                self.last_launch_order, self.launch_order = self.launch_order, []
             else:
                 dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
             self.flat_grad.div_(self.world)

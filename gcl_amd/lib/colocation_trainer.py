@@ -352,6 +352,57 @@ class FinestContrastiveLossTrainer:
         self.map_prefetch = os.environ.get("GCL_MAP_PREFETCH", "1") == "1"
         self._side = None
 
+    # ---- whole-network plan (gcl_amd/MinkowskiEngine/native.py) ------------------------------------------------
+    def _plan_for_step(self, micro):
+        """The NetworkPlan every micro-batch of this step will run through, or None (Tape / per-layer autograd path)."""
+        plan_for = getattr(self.model, "plan_for", None)
+        if plan_for is None or not self.model.training:
+            return None
+        plan = None
+        for b in micro:
+            mgr = b.get("_coordinate_manager") if isinstance(b, dict) else None
+            if mgr is None or mgr.native is None:
+                return None
+            probe = types.SimpleNamespace(coordinate_manager=mgr, coordinate_map_key=ME.CoordinateMapKey(1),
+                                          F=b["sinput_F"])
+            plan = plan_for(probe)
+            if plan is None:
+                return None
+        return plan
+
+    def _seat_gradients(self):
+        """``p.grad`` of every parameter = its view of ONE flat buffer (FlatDDP's when data-parallel)."""
+        if getattr(self, "_grad_views", None) is None:
+            ps = self._params
+            total = sum(p.numel() for p in ps)
+            if self.ddp is not None:
+                if [id(p) for p in self.ddp.params] != [id(p) for p in ps]:
+                    raise RuntimeError("FlatDDP and the trainer disagree on the parameter list")
+                self._flat_grad = self.ddp.flat_grad
+            else:
+                self._flat_grad = torch.zeros(total, dtype=torch.float32, device=self.device)
+            self._flat_grad2 = None
+            self._grad_views, off = [], 0
+            for p in ps:
+                self._grad_views.append(self._flat_grad[off:off + p.numel()].view_as(p))
+                off += p.numel()
+            self._grad_views2 = None
+        if self._grad_views2 is None and int(getattr(self.config, "iter_size", 1)) > 1:
+            self._flat_grad2 = torch.zeros_like(self._flat_grad)
+            self._grad_views2, off = [], 0
+            for p in self._params:
+                self._grad_views2.append(self._flat_grad2[off:off + p.numel()].view_as(p))
+                off += p.numel()
+        for p, v in zip(self._params, self._grad_views):
+            g = p.grad
+            if g is None or g.data_ptr() != v.data_ptr():
+                p.grad = v
+
+    def _plan_buckets(self):
+        if getattr(self, "_bucket_map", None) is None:
+            self._bucket_map = {i: self.ddp._bucket_of[id(p)] for i, p in enumerate(self._params)}
+        return self._bucket_map
+
     def location_loss(self, F_out, group, index, index_hash, finest_flag, max_pos_cluster, max_hn_samples,
                       points=None, batch_lengths=None, draws=None, prepared=None):
         cfg = self.config
@@ -405,7 +456,8 @@ class FinestContrastiveLossTrainer:
         training stream, whose gaps they fill instead.  Returns the batch (a copy carrying the manager) to train on."""
         C = batch.get("sinput_C") if isinstance(batch, dict) else None
         if isinstance(batch, dict) and "_coordinate_manager" in batch:       # a stale manager of an earlier pass
-            batch = {k: v for k, v in batch.items() if k not in ("_coordinate_manager", "_maps_event", "_loss_inputs")}
+            batch = {k: v for k, v in batch.items()
+                     if k not in ("_coordinate_manager", "_maps_event", "_loss_inputs", "_map_arena")}
         specs = getattr(getattr(self, "model", None), "map_specs", None)
         if getattr(self, "map_prefetch", False) and specs is not None and isinstance(C, torch.Tensor) and C.is_cuda:
             with torch.cuda.device(self.device):
@@ -413,17 +465,45 @@ class FinestContrastiveLossTrainer:
                     lo, hi = torch.cuda.Stream.priority_range()         # (lowest priority, highest priority)
                     prio = {"low": lo, "high": hi}.get(os.environ.get("GCL_SIDE_PRIORITY", "high"), 0)
                     self._side = torch.cuda.Stream(device=self.device, priority=prio)
+                from gcl_amd.MinkowskiEngine import native
+                nspecs = getattr(self.model, "native_map_specs", None)
+                use_native = native.PLAN_ENABLED and nspecs is not None
+                slot = None
                 with torch.cuda.stream(self._side):
                     ev = batch.get("_h2d_event")
                     if ev is not None:
                         self._side.wait_event(ev)
-                    mgr = ME.CoordinateManager(C).prefetch(specs())
+                    if use_native:
+                        # ONE native call (interpreter lock released, both host syncs inside) into a pooled arena
+                        slot = self._take_map_arena()
+                        if slot["free"] is not None:
+                            self._side.wait_event(slot["free"])
+                        mgr = ME.CoordinateManager.build_native(C, nspecs(), arena=slot["arena"])
+                        slot["arena"] = mgr.native.arena
+                    else:
+                        mgr = ME.CoordinateManager(C).prefetch(specs())
                     prep = prepare_loss_inputs(batch["group"], batch["index"], batch["finest_flag"], self.device)
                     done = torch.cuda.Event()
                     done.record(self._side)
             batch = dict(batch)               # never mutate the caller's dict (it may be fed again)
             batch["_coordinate_manager"], batch["_maps_event"], batch["_loss_inputs"] = mgr, done, prep
+            batch["_map_arena"] = slot
         return batch
+
+    def _take_map_arena(self):
+        """A free arena of the map pool (``{"arena", "free", "busy"}``): handed out by the map helper thread, released by
+        ``release_batch`` on the training thread once the batch's backward pass is enqueued (the event recorded there
+        is what the side stream waits for before the arena is overwritten).  Grows on demand; never recycles a busy one."""
+        import threading
+        if getattr(self, "_map_arenas", None) is None:
+            self._map_arenas, self._map_lock = [], threading.Lock()
+        with self._map_lock:
+            slot = next((a for a in self._map_arenas if not a["busy"]), None)
+            if slot is None:
+                slot = {"arena": None, "free": None, "busy": False, "lock": self._map_lock}
+                self._map_arenas.append(slot)
+            slot["busy"] = True
+        return slot
 
     def train_steps(self, batches):
         """The epoch loop (``_train_epoch`` :811-916): yields train_step(...) for every optimizer step, i.e. for every
@@ -562,7 +642,11 @@ class FinestContrastiveLossTrainer:
             mdraws = [self._draw_for(b) for b in micro]
         else:
             mdraws = list(draws) if isinstance(input_dict, (list, tuple)) else [draws]
-        if self.ddp is not None:
+        plan = self._plan_for_step(micro)
+        if plan is not None:
+            # whole-network plan: every gradient is WRITTEN into its seat in the flat buffer (no zero fill, no accumulate)
+            self._seat_gradients()
+        elif self.ddp is not None:
             self.ddp.flat_grad.zero_()                     # one memset; gradients stay seated in the flat buffer
         else:
             if os.environ.get("GCL_ZERO_NONE", "1") == "1":     # gradients are assigned, not accumulated into zeros
@@ -574,12 +658,24 @@ class FinestContrastiveLossTrainer:
         for i, (b, d) in enumerate(zip(micro, mdraws)):
             if self.ddp is not None:
                 self.ddp.set_last_microstep(i == n_micro - 1)     # bucket all-reduces start in the LAST backward only
+            if plan is not None:
+                # micro-batch 0 writes the seats; later ones write a second buffer that is added afterwards (:875-887)
+                plan.grad_targets = self._grad_views if i == 0 else self._grad_views2
+                overlap = self.ddp is not None and n_micro == 1 and self.ddp.overlap and self.ddp.world > 1
+                plan.bucket_of_param = self._plan_buckets() if overlap else None
+                plan.on_bucket = self.ddp.bucket_ready if overlap else None
             wait_for_batch(b)
-            loss, parts, F_out = self.forward_loss(b, d)
-            if n_micro > 1:
-                parts = tuple(p / n_micro for p in parts)         # :875-877
-                loss = self.pos_weight * parts[0] + self.finest_weight * parts[1] + self.neg_weight * parts[2]
-            loss.backward()
+            try:
+                loss, parts, F_out = self.forward_loss(b, d)
+                if n_micro > 1:
+                    parts = tuple(p / n_micro for p in parts)         # :875-877
+                    loss = self.pos_weight * parts[0] + self.finest_weight * parts[1] + self.neg_weight * parts[2]
+                loss.backward()
+            finally:
+                if plan is not None:
+                    plan.grad_targets = plan.bucket_of_param = plan.on_bucket = None
+            if plan is not None and i > 0:
+                self._flat_grad.add_(self._flat_grad2)
             release_batch(b)
             n_rows += F_out.shape[0]
             dl, dp = loss.detach(), tuple(p.detach() for p in parts)
@@ -640,6 +736,12 @@ def prefetch_to_device(batches, device, keys=("sinput_C", "sinput_F", "group", "
 def release_batch(batch):
     """The consumer is done ENQUEUING work that reads a prefetched batch: its staging slot may be overwritten once the
     current stream has passed this point (see ``prefetch_to_device``).  No-op for ordinary batches."""
+    ar = batch.get("_map_arena") if isinstance(batch, dict) else None
+    if ar is not None and ar["busy"]:      # the pooled arena of the batch's native maps (trainer._take_map_arena)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        with ar["lock"]:
+            ar["free"], ar["busy"] = ev, False
     st = batch.get("_h2d_slot") if isinstance(batch, dict) else None
     if st is None:
         return

@@ -75,15 +75,57 @@ class ResUNet2(ME.MinkowskiNetwork):
             t *= 2
         return specs
 
+    def native_map_specs(self):
+        """``map_specs`` + the identity pair list of the two kernel_size-1 heads: what CoordinateManager.build_native
+        builds in one call, in the order the whole-network plan indexes it."""
+        return self.map_specs() + [(1, 1, 1, (), True)]
+
+    _plan = None          # native.NetworkPlan once recorded; False when the graph is outside what the plan covers
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop("_plan", None)          # a native handle: rebuilt from the next recorded step
+        return state
+
+    def _use_tape(self, x):
+        ops = ME.ops
+        return (ops.TAPE_ENABLED and self.training and torch.is_grad_enabled() and self.NORM_TYPE == "BN"
+                and self.BLOCK_NORM_TYPE == "BN" and ME.FUSED_CONV_BN_NODE and not x.F.requires_grad
+                and self._all_training())
+
+    def plan_for(self, x):
+        """The native.NetworkPlan ``forward(x)`` will run (None: it takes the Tape / per-layer path): a plan recorded from
+        an earlier training step, the default arithmetic, and a coordinate manager built by build_native with this
+        model's ``native_map_specs``."""
+        from gcl_amd.MinkowskiEngine import native
+        plan = self.__dict__.get("_plan")
+        nm = x.coordinate_manager.native
+        if (not native.PLAN_ENABLED or not isinstance(plan, native.NetworkPlan) or nm is None
+                or nm.keys != plan.spec_keys or x.coordinate_map_key.tensor_stride != 1
+                or ME.ops.PRECISION != "fp16x3" or not self._use_tape(x)
+                or len(plan.params) != sum(1 for _ in self.parameters())):
+            return None
+        return plan
+
     def forward(self, x):
         ops = ME.ops
-        use_tape = (ops.TAPE_ENABLED and self.training and torch.is_grad_enabled() and self.NORM_TYPE == "BN"
-                    and self.BLOCK_NORM_TYPE == "BN" and ME.FUSED_CONV_BN_NODE and not x.F.requires_grad
-                    and self._all_training())
-        if not use_tape:
+        if not self._use_tape(x):
             return self._forward(x)
+        plan = self.plan_for(x)
+        if plan is not None:              # the whole pass is ONE native call (csrc/plan.hip)
+            F = plan.run(x.F, x.coordinate_manager.native)
+            return ME.SparseTensor(F, coordinate_map_key=ME.CoordinateMapKey(1 << plan.records[-1]["level_out"]),
+                                   coordinate_manager=x.coordinate_manager)
+        from gcl_amd.MinkowskiEngine import native
+        nm = x.coordinate_manager.native
         with ops.tape() as tp:          # the whole network as ONE autograd node (ops.Tape)
             out = self._forward(x)
+            if (native.PLAN_ENABLED and nm is not None and self.__dict__.get("_plan") is None
+                    and x.coordinate_map_key.tensor_stride == 1):
+                try:                    # this recorded pass becomes the plan of the following steps
+                    self._plan = native.NetworkPlan.from_tape(tp, self, x.F, 0, nm.keys)
+                except ValueError as e:
+                    self._plan, self._plan_error = False, str(e)
             F = tp.finish(out.F)
         return ME.SparseTensor(F, coordinate_map_key=out.coordinate_map_key, coordinate_manager=out.coordinate_manager)
 

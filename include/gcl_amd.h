@@ -410,6 +410,118 @@ int gcl_sc2_seed_trans(const float* src, const float* tgt, int32_t n, const int3
 int gcl_sc2_refine(const float* src, const float* tgt, int32_t n, float thr, int32_t iterations, double* partial,
                    int32_t* state, float* T, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Native step runtime (round 3): ONE call enqueues a whole pass.
+ *
+ * The per-operator entries above are what ME's operator surface binds; a training step calls ~560 of them, and from
+ * Python each costs ~40 us of interpreter + ctypes time -- the step was bound by the host.  The two families below issue
+ * the same launches, with the same arguments and in the same order, from C:
+ *   gcl_maps_*  everything CoordinateManager builds for a network (lib/colocation_trainer.py:843-845 -> ME's
+ *               coordinate manager: stride maps, kernel maps, mask-sorted tables, pair lists) in one call;
+ *   gcl_plan_*  the forward / backward pass of a network described as a list of operator records (what
+ *               model/resunet.py:173-232 and model/residual_block.py:37-53 call on the ME surface).
+ * Results are bitwise identical to the per-operator path (tests/test_gpu_plan.py).
+ * Memory stays with the caller: both families carve every tensor they need from an ARENA the caller passes (a device
+ * buffer; size from gcl_maps_arena_bytes / gcl_plan_arena_bytes); plan handles own host memory only.
+ * ---------------------------------------------------------------------------------------------- */
+#define GCL_MAX_LEVELS 8
+#define GCL_MAX_MAPS 16
+#define GCL_ERR_ARENA (-4)     /* the arena is too small */
+#define GCL_MAPS_PINNED_BYTES (512 * (GCL_MAX_MAPS + 1))
+
+/* one kernel map to build: CoordinateManager.get_kernel_map(t_in, kernel_size, stride);
+ * tables bit 0 / bit 1: gcl_table_sort of nbr / of nbr_t; pairs != 0: the weight gradient's pair lists.
+ * kernel_size 1 (stride 1): only the identity pair list of level t_in (pairs != 0). */
+typedef struct gcl_map_spec {
+  int32_t t_in, kernel_size, stride, tables, pairs;
+} gcl_map_spec;
+
+/* one kernel map as built; pointers are DEVICE pointers into the arena (NULL = not requested), seg_off HOST values */
+typedef struct gcl_map_desc {
+  int32_t t_in, kernel_size, stride, K;
+  int32_t level_in, level_out;          /* indices into gcl_maps_desc.n_rows (level i = tensor stride 2^i) */
+  int64_t n_in, n_out, n_pairs;
+  int32_t *nbr, *nbr_t, *counts;
+  int32_t *tbl_n, *order_n, *mask_n;    /* gcl_table_sort(nbr) */
+  int32_t *tbl_t, *order_t, *mask_t;    /* gcl_table_sort(nbr_t) */
+  int32_t *pair_in, *pair_out;
+  int64_t seg_off[128];                 /* padded prefix sums of the per-offset pair counts, K + 1 used */
+  int32_t counts_host[128];
+} gcl_map_desc;
+
+typedef struct gcl_maps_desc {
+  int32_t n_levels, n_maps;
+  int64_t n_rows[GCL_MAX_LEVELS];
+  int32_t* coords[GCL_MAX_LEVELS];      /* int32 [n_rows, 4] */
+  int64_t* table[GCL_MAX_LEVELS];       /* coordinate hash table of the level, int64 [cap, 2] */
+  int64_t cap[GCL_MAX_LEVELS];
+  int32_t status[4];                    /* HOST copy of gcl_coords_insert's status words */
+  int64_t arena_used;
+  gcl_map_desc maps[GCL_MAX_MAPS];
+} gcl_maps_desc;
+
+/* Upper bound of the arena gcl_maps_build needs for n stride-1 rows. */
+int64_t gcl_maps_arena_bytes(int64_t n, const gcl_map_spec* specs_host, int32_t n_specs, int32_t n_levels);
+/* Builds levels 0 .. n_levels-1 (tensor strides 1, 2, 4, ...) from `coords` (int32 [n,4], device) and every map of
+ * `specs_host`, with exactly the launches of the per-operator entries.  SYNCHRONISES `stream` twice (level sizes, pair
+ * counts) -- call it from a loader-side thread on a side stream.  pinned_host: >= GCL_MAPS_PINNED_BYTES of page-locked HOST
+ * memory used for the two read-backs.  Fills *out_host; returns GCL_ERR_ARG for duplicate / out-of-range coordinates
+ * (out_host->status tells which). */
+int gcl_maps_build(const int32_t* coords, int64_t n, const gcl_map_spec* specs_host, int32_t n_specs, int32_t n_levels,
+                   void* arena, int64_t arena_bytes, void* pinned_host, gcl_maps_desc* out_host, void* stream);
+
+/* Operator records of a network pass.  Tensors are numbered 0 .. n_tensors-1 (0 = the input features); every record
+ * names its input(s) and its output; parameters are numbered in the order of the `params` / `grads` pointer arrays. */
+#define GCL_OP_CONVBN 1    /* y = BatchNorm(conv(x)) (+ residual x2) (relu): MinkowskiConvolution(+Transpose) + MinkowskiBatchNorm */
+#define GCL_OP_CONV 2      /* y = conv(x) (+ bias) */
+#define GCL_OP_RELU 3      /* MEF.relu */
+#define GCL_OP_CAT 4       /* ME.cat(x, x2) */
+#define GCL_OP_ROWNORM 5   /* y = x / ||x||_2 per row (model/resunet.py:226-230) */
+typedef struct gcl_plan_op {
+  int32_t kind;
+  int32_t x, x2, y;          /* tensor ids; x2 = residual (CONVBN) / second input (CAT), -1 = none */
+  int32_t level_in, level_out, cin, cout;
+  int32_t map, transpose, K; /* map = index into gcl_maps_desc.maps (kernel_size 1: the identity-pair entry) */
+  int32_t w, bias;           /* parameter ids: kernel [K, cin, cout], bias [1, cout] or -1 */
+  int32_t bn_w, bn_b, bn;    /* parameter ids of the BatchNorm affine pair; bn = index of its running-statistics pair */
+  int32_t relu;
+  float momentum, eps;
+} gcl_plan_op;
+
+/* Plan handle: host memory only.  weight_order[n_weights] = parameter ids of the MFMA-shaped convolution kernels in
+ * the order their max-abs slots / packed images are laid out (WeightAmaxGroup).  NULL on error (gcl_last_error). */
+void* gcl_plan_create(const gcl_plan_op* ops_host, int32_t n_ops, int32_t n_tensors, int32_t n_params,
+                      const int32_t* weight_order_host, int32_t n_weights, int32_t presplit_min_c);
+void gcl_plan_destroy(void* plan);
+/* persistent DEVICE state the caller keeps for a plan (pointer / descriptor tables), bytes */
+int64_t gcl_plan_state_bytes(const void* plan);
+/* arena bytes of one forward + backward pass over `maps` */
+int64_t gcl_plan_arena_bytes(void* plan, const gcl_maps_desc* maps_host);
+/* Forward pass (training mode: batch statistics, running statistics updated).  x: features of tensor 0
+ * [n_rows[level_in of op 0], cin]; params_host[n_params]: DEVICE pointers of the parameters; bn_stats_host[2 * n_bn]:
+ * DEVICE pointers running_mean, running_var per BatchNorm.  *y_out_host receives the device pointer (inside the arena)
+ * of the last record's output.  The arena must stay untouched until gcl_plan_backward has run. */
+int gcl_plan_forward(void* plan, const gcl_maps_desc* maps_host, const float* x, void* const* params_host,
+                     void* const* bn_stats_host, void* state, void* arena, int64_t arena_bytes, float** y_out_host,
+                     void* stream);
+/* Backward pass of the records first_op <= i < last_op in reverse order (the caller may cut the pass into segments,
+ * highest records first, e.g. to start a gradient bucket's all-reduce in between).  dy: gradient of the forward output
+ * (read by the segment that contains the last record).  grads_host[n_params]: DEVICE pointers that RECEIVE (are
+ * overwritten with) the parameter gradients. */
+int gcl_plan_backward(void* plan, const float* dy, void* const* grads_host, int32_t first_op, int32_t last_op,
+                      void* stream);
+/* Per-launch timing of the convolution launches of the NEXT forward + backward pass (events on `stream`):
+ * gcl_plan_profile(plan, 1) arms it; after the stream has been synchronised gcl_plan_profile_read copies up to
+ * max_records records of 8 doubles {kind (0 fwd/dx, 1 dW), ms, pairs, cin, cout, n_in, n_out, K | flags} and returns
+ * their number. */
+int gcl_plan_profile(void* plan, int32_t enable);
+int gcl_plan_profile_read(void* plan, double* records_host, int32_t max_records);
+
+/* Elementwise helpers of the plan path (also used by the per-operator path so that both stay bitwise equal):
+ * gcl_col_sum: out[c] = sum over rows of x [n, c] (fp64 partials, ordered) -- the bias gradient of `final`
+ * (model/resunet.py:165-171); scratch: double[gcl_bn_scratch_len(n, c)]. */
+int gcl_col_sum(const float* x, int64_t n, int32_t c, double* scratch, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
