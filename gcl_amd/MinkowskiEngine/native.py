@@ -90,7 +90,14 @@ class NativeMaps:
 class _PlanRun:
     """One forward pass of a plan that is waiting for its backward pass (keeps the arena and the maps alive)."""
 
-    __slots__ = ("plan", "arena", "maps", "y", "x", "grad_targets", "segments")
+    __slots__ = ("plan", "arena", "maps", "y", "x", "grad_targets", "segments", "done")
+
+    def __del__(self):          # the output was dropped without a backward pass: un-park the pass on the native side
+        try:
+            if not self.done and self.plan is not None and self.plan.handle and self.arena is not None:
+                _lib.load().gcl_plan_release(self.plan.handle, ctypes.c_void_p(self.arena.data_ptr()))
+        except Exception:
+            pass
 
 
 class _PlanFn(torch.autograd.Function):
@@ -110,7 +117,7 @@ class _PlanFn(torch.autograd.Function):
         plan = run.plan
         grads = plan._backward(run, dy.contiguous())
         if grads is None:
-            return (None,) * (1 + len(plan.params))
+            return None, None
         return (None,) + tuple(grads)
 
 
@@ -145,6 +152,7 @@ class NetworkPlan:
         self._ptr_key = None
         self.profile_next = False
         self.last_profile = None
+        self._anchor = None
 
     def __del__(self):
         h, self.handle = getattr(self, "handle", None), None
@@ -299,12 +307,19 @@ class NetworkPlan:
         n_out = int(maps.desc.n_rows[self.records[-1]["level_out"]])
         off = y_ptr.value - arena.data_ptr()
         y = arena[off:off + n_out * self.out_channels * 4].view(torch.float32).view(n_out, self.out_channels)
-        if not torch.is_grad_enabled():
+        if not torch.is_grad_enabled():       # no backward pass will come: un-park the pass
+            lib.gcl_plan_release(self.handle, _lib.ptr(arena))
             return y
         run = _PlanRun()
         run.plan, run.arena, run.maps, run.y, run.x = self, arena, maps, y, x
-        run.grad_targets = self.grad_targets
+        run.grad_targets, run.done = self.grad_targets, False
         run.segments = self._segments()
+        if run.grad_targets is not None:
+            # seated gradients are written in place: the parameters stay out of the autograd node (autograd would run their
+            # accumulation hooks even for an undefined gradient); a private leaf makes the node differentiable
+            if self._anchor is None or self._anchor.device != dev:
+                self._anchor = torch.zeros(1, device=dev, requires_grad=True)
+            return _PlanFn.apply(run, self._anchor)
         return _PlanFn.apply(run, *self.params)
 
     def _segments(self):
@@ -343,14 +358,15 @@ class NetworkPlan:
         gp = (ctypes.c_void_p * len(targets))(*[t.data_ptr() for t in targets])
         st = _lib.stream()
         for first, last, buckets in run.segments:
-            _lib.check(lib.gcl_plan_backward(self.handle, _lib.ptr(dy, torch.float32), gp, first, last, st),
-                       "gcl_plan_backward")
+            _lib.check(lib.gcl_plan_backward(self.handle, _lib.ptr(run.arena), _lib.ptr(dy, torch.float32), gp, first,
+                                             last, st), "gcl_plan_backward")
             for b in buckets:
                 self.on_bucket(b)
         if self.profile_next:
             self.profile_next = False
             self._profile_pending = True
             lib.gcl_plan_profile(self.handle, 0)
+        run.done = True
         run.arena = run.maps = run.y = run.x = None
         return None if flat is None else targets
 

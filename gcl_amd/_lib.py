@@ -110,7 +110,8 @@ SIGNATURES = {
     "gcl_plan_state_bytes": (_i64, [_vp]),
     "gcl_plan_arena_bytes": (_i64, [_vp, _vp]),
     "gcl_plan_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
-    "gcl_plan_backward": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
+    "gcl_plan_backward": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "gcl_plan_release": (_i32, [_vp, _vp]),
     "gcl_plan_profile": (_i32, [_vp, _i32]),
     "gcl_plan_profile_read": (_i32, [_vp, _vp, _i32]),
     "gcl_sc2_chunks": (_i32, []),

@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include <new>
+#include <utility>
 #include <vector>
 
 namespace gcl {
@@ -296,19 +297,7 @@ struct ProfRec {
   double kind, pairs, cin, cout, n_in, n_out, K;
 };
 
-struct Plan {
-  std::vector<gcl_plan_op> ops;
-  int n_tensors = 0, n_params = 0, n_bn = 0, presplit = 128;
-  std::vector<int> worder;          // parameter ids of the MFMA-shaped kernels (amax slot / pack order)
-  std::vector<int> widx;            // parameter id -> position in worder, -1 otherwise
-  std::vector<int> wmode;           // per position: input-gradient pack mode (1 | 2), 0 = no input gradient needed
-  std::vector<long long> wK, wcin, wcout, off_fwd, off_bwd;
-  long long bytes_fwd = 0, bytes_bwd = 0, wgs_fwd = 0, wgs_bwd = 0;
-  int n_bwd = 0;
-  std::vector<char> made;           // tensor id -> produced by a record of the plan
-  // device tables (inside the caller's `state` buffer), re-uploaded when a parameter pointer changes
-  std::vector<long long> host_tables, uploaded;
-  // per pass
+struct PassState {        // everything one forward pass leaves behind for its backward pass
   const gcl_maps_desc* maps = nullptr;
   gcl_maps_desc maps_copy;
   std::vector<TState> t, g;
@@ -322,6 +311,22 @@ struct Plan {
   unsigned char *pack_fwd = nullptr, *pack_bwd = nullptr;
   void* state = nullptr;
   bool forward_done = false, bwd_packed = false;
+  void* key = nullptr;              // the pass's arena: how gcl_plan_backward / gcl_plan_release find it
+};
+
+struct Plan : PassState {   // the base part is the pass being enqueued right now
+  std::vector<PassState*> passes;   // passes waiting for their backward pass (several forwards may be outstanding)
+  std::vector<gcl_plan_op> ops;
+  int n_tensors = 0, n_params = 0, n_bn = 0, presplit = 128;
+  std::vector<int> worder;          // parameter ids of the MFMA-shaped kernels (amax slot / pack order)
+  std::vector<int> widx;            // parameter id -> position in worder, -1 otherwise
+  std::vector<int> wmode;           // per position: input-gradient pack mode (1 | 2), 0 = no input gradient needed
+  std::vector<long long> wK, wcin, wcout, off_fwd, off_bwd;
+  long long bytes_fwd = 0, bytes_bwd = 0, wgs_fwd = 0, wgs_bwd = 0;
+  int n_bwd = 0;
+  std::vector<char> made;           // tensor id -> produced by a record of the plan
+  // device tables (inside the caller's `state` buffer), re-uploaded when a parameter pointer changes
+  std::vector<long long> host_tables, uploaded;
   // profiling
   bool profile = false;
   std::vector<ProfRec> prof;
@@ -866,6 +871,7 @@ void gcl_plan_destroy(void* plan) {
     (void)hipEventDestroy(r.e0);
     (void)hipEventDestroy(r.e1);
   }
+  for (PassState* q : P->passes) delete q;
   delete P;
 }
 
@@ -925,25 +931,56 @@ int gcl_plan_forward(void* plan, const gcl_maps_desc* maps_host, const float* x,
   }
   rc = plan_forward(*P, x, bn_stats_host, y_out_host, (hipStream_t)stream);
   P->forward_done = rc == GCL_OK;
-  return rc;
+  if (rc != GCL_OK) return rc;
+  // park the pass under its arena until gcl_plan_backward / gcl_plan_release asks for it
+  PassState* slot = nullptr;
+  for (PassState* q : P->passes)
+    if (!q->forward_done || q->key == arena) slot = q;
+  if (!slot) {
+    slot = new (std::nothrow) PassState();
+    GCL_CHECK_ARG(slot, "gcl_plan_forward: out of host memory");
+    P->passes.push_back(slot);
+  }
+  P->key = arena;
+  *slot = std::move(static_cast<PassState&>(*P));
+  slot->maps = &slot->maps_copy;
+  static_cast<PassState&>(*P) = PassState();
+  return GCL_OK;
 }
 
-int gcl_plan_backward(void* plan, const float* dy, void* const* grads_host, int32_t first_op, int32_t last_op, void* stream) {
+int gcl_plan_release(void* plan, void* arena) {
+  Plan* P = (Plan*)plan;
+  GCL_CHECK_ARG(P, "gcl_plan_release: null plan");
+  for (PassState* q : P->passes)
+    if (q->forward_done && q->key == arena) *q = PassState();
+  return GCL_OK;
+}
+
+int gcl_plan_backward(void* plan, void* arena, const float* dy, void* const* grads_host, int32_t first_op,
+                      int32_t last_op, void* stream) {
   Plan* P = (Plan*)plan;
   GCL_CHECK_ARG(P && grads_host, "gcl_plan_backward: null pointer");
-  GCL_CHECK_ARG(P->forward_done, "gcl_plan_backward: no forward pass to differentiate");
+  PassState* slot = nullptr;
+  for (PassState* q : P->passes)
+    if (q->forward_done && q->key == arena) slot = q;
+  GCL_CHECK_ARG(slot, "gcl_plan_backward: no forward pass to differentiate in this arena");
   GCL_CHECK_ARG(first_op >= 0 && first_op < last_op && last_op <= (int)P->ops.size(), "gcl_plan_backward: bad record range");
   GCL_CHECK_ARG(last_op != (int)P->ops.size() || dy, "gcl_plan_backward: the last segment needs dy");
+  static_cast<PassState&>(*P) = std::move(*slot);
+  P->maps = &P->maps_copy;
   int rc = plan_backward(*P, dy, grads_host, first_op, last_op, (hipStream_t)stream);
   if (rc == GCL_OK && !P->A.fits()) {
     set_error("gcl_plan_backward: arena overrun");
-    return GCL_ERR_ARENA;
+    rc = GCL_ERR_ARENA;
   }
   if (rc == GCL_OK && P->slots_exhausted) {
     set_error("gcl_plan_backward: amax slot pool exhausted");
-    return GCL_ERR_ARG;
+    rc = GCL_ERR_ARG;
   }
-  if (first_op == 0) P->forward_done = false;
+  if (first_op == 0 || rc != GCL_OK) P->forward_done = false;      // the pass is finished (or broken): its slot is free again
+  *slot = std::move(static_cast<PassState&>(*P));
+  slot->maps = &slot->maps_copy;
+  static_cast<PassState&>(*P) = PassState();
   return rc;
 }
 

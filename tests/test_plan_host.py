@@ -72,7 +72,7 @@ def test_plan_create_accepts_a_resunet_shaped_graph_and_sizes_its_arena():
     assert lib.gcl_plan_arena_bytes(h, ctypes.byref(d)) < 0 and b"levels" in lib.gcl_last_error()
     # without a GPU the forward entry still validates its arguments before any HIP call
     assert lib.gcl_plan_forward(h, None, None, None, None, None, None, 0, None, None) == -1
-    assert lib.gcl_plan_backward(h, None, (ctypes.c_void_p * 18)(), 0, 10, None) == -1
+    assert lib.gcl_plan_backward(h, None, None, (ctypes.c_void_p * 18)(), 0, 10, None) == -1
     assert b"no forward pass" in lib.gcl_last_error()
     lib.gcl_plan_destroy(h)
 

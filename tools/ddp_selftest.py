@@ -49,6 +49,7 @@ def main():
     with torch.cuda.device(dev):
         for s in range(steps):
             b = tr._prefetch_maps(on_device(batches[rank][s]))        # native maps on the side stream, like train_steps
+            print(f'rank {rank} step {s} plan {type(tr.model._plan).__name__}', flush=True)
             loss, _, _ = tr.train_step(b, draws[rank][s])
             orders.append(list(getattr(tr.ddp, "last_launch_order", [])))
             plan = tr.model._plan
