@@ -21,6 +21,9 @@ from .. import _lib
 
 # the whole-network plan replaces the Tape after the first (recorded) training step of a model; GCL_PLAN=0 keeps the Tape
 PLAN_ENABLED = os.environ.get("GCL_PLAN", "1") == "1"
+# weight gradients of the plan's backward pass on a second stream ("0" off, "1" same priority [default], "low" lowest
+# priority): measured 14.48 -> 13.72 ms per step (same box, alternating runs; the optimizer is their only consumer)
+AUX_STREAM = {"0": "", "1": "1", "low": "low"}[os.environ.get("GCL_PLAN_AUX", "1")]
 
 
 def _addr(t):
@@ -153,6 +156,7 @@ class NetworkPlan:
         self.profile_next = False
         self.last_profile = None
         self._anchor = None
+        self._aux = None
 
     def __del__(self):
         h, self.handle = getattr(self, "handle", None), None
@@ -295,6 +299,11 @@ class NetworkPlan:
         if self._state is None or self._state.device != dev:
             self._state = torch.empty(int(lib.gcl_plan_state_bytes(self.handle)), dtype=torch.uint8, device=dev)
         pp, bp = self._pointers()
+        if AUX_STREAM and self._aux is None:
+            # weight gradients run on a second (lower-priority) stream beside the input-gradient chain
+            lo, _hi = torch.cuda.Stream.priority_range()
+            self._aux = torch.cuda.Stream(device=dev, priority=lo if AUX_STREAM == "low" else 0)
+            lib.gcl_plan_set_aux_stream(self.handle, ctypes.c_void_p(self._aux.cuda_stream))
         if self.profile_next:
             lib.gcl_plan_profile(self.handle, 1)
         y_ptr = ctypes.c_void_p()

@@ -112,6 +112,7 @@ SIGNATURES = {
     "gcl_plan_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "gcl_plan_backward": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "gcl_plan_release": (_i32, [_vp, _vp]),
+    "gcl_plan_set_aux_stream": (_i32, [_vp, _vp]),
     "gcl_plan_profile": (_i32, [_vp, _i32]),
     "gcl_plan_profile_read": (_i32, [_vp, _vp, _i32]),
     "gcl_sc2_chunks": (_i32, []),

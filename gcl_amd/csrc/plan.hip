@@ -327,6 +327,11 @@ struct Plan : PassState {   // the base part is the pass being enqueued right no
   std::vector<char> made;           // tensor id -> produced by a record of the plan
   // device tables (inside the caller's `state` buffer), re-uploaded when a parameter pointer changes
   std::vector<long long> host_tables, uploaded;
+  // optional second stream for the weight gradients (off the critical path of the backward pass)
+  hipStream_t aux = nullptr;
+  std::vector<hipEvent_t> events;
+  size_t events_used = 0;
+  bool aux_dirty = false;
   // profiling
   bool profile = false;
   std::vector<ProfRec> prof;
@@ -356,6 +361,36 @@ static int ensure_planes(Plan& P, TState& ts, long long n, int c, hipStream_t st
   if (ts.planes) return GCL_OK;
   ts.planes = A.take(n * c * 4);
   PLAN_CALL(gcl_split_planes(ts.ptr, n, c, ts.amax, ts.planes, (void*)st));
+  return GCL_OK;
+}
+
+// The weight gradient of a record is needed only by the optimizer: with an aux stream it is enqueued there, ordered
+// behind everything the main stream has issued so far (its operands), and the main stream goes on with the input-gradient
+// chain.  join_aux makes the main stream wait for all of it (end of a backward segment).
+static hipStream_t fork_aux(Plan& P, hipStream_t st) {
+  if (!P.aux || P.A.dry) return st;
+  if (P.events_used == P.events.size()) {
+    hipEvent_t e;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return st;
+    P.events.push_back(e);
+  }
+  hipEvent_t e = P.events[P.events_used++];
+  if (hipEventRecord(e, st) != hipSuccess || hipStreamWaitEvent(P.aux, e, 0) != hipSuccess) return st;
+  P.aux_dirty = true;
+  return P.aux;
+}
+
+static int join_aux(Plan& P, hipStream_t st) {
+  if (!P.aux || !P.aux_dirty || P.A.dry) return GCL_OK;
+  if (P.events_used == P.events.size()) {
+    hipEvent_t e;
+    GCL_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    P.events.push_back(e);
+  }
+  hipEvent_t e = P.events[P.events_used++];
+  GCL_CHECK_HIP(hipEventRecord(e, P.aux));
+  GCL_CHECK_HIP(hipStreamWaitEvent(st, e, 0));
+  P.aux_dirty = false;
   return GCL_OK;
 }
 
@@ -460,7 +495,8 @@ static int plan_forward(Plan& P, const float* x_in, void* const* bn_stats, float
   P.t.assign(P.n_tensors, TState());
   P.g.assign(P.n_tensors, TState());
   P.saved.assign(P.ops.size(), OpSaved());
-  if (P.profile && !A.dry) P.prof_used = 0;      // records of a profiled pass stay readable until the next profiled pass
+  if (P.profile && !A.dry) P.prof_used = 0;
+  if (!A.dry) P.events_used = 0;      // fork / join events are re-used pass after pass (recording re-arms them)      // records of a profiled pass stay readable until the next profiled pass
   // amax slots of the pass: one zero fill (ops.amax_slot hands out slots of a zero-filled pool)
   P.n_slots = 4 * (long long)P.n_tensors + 2 * (long long)P.ops.size() + 16;
   P.next_slot = 0;
@@ -585,14 +621,24 @@ static int conv_backward(Plan& P, int i, TState dy, void* const* grads, hipStrea
   int rc;
   if (is_stem(op, m)) {
     float* scratch = A.take_n<float>(gcl_stem_bwd_weight_scratch_len(op.K, op.cin, op.cout, n_out));
-    ProfScope ps(P, st, 2, (double)m.n_pairs, op.cin, op.cout, n_in, n_out, op.K);
-    PLAN_CALL(gcl_stem_bwd_weight(x.ptr, dy.ptr, m.nbr, n_out, op.K, op.cin, op.cout, scratch, dW, (void*)st));
+    hipStream_t ws = fork_aux(P, st);
+    ProfScope ps(P, ws, 2, (double)m.n_pairs, op.cin, op.cout, n_in, n_out, op.K);
+    PLAN_CALL(gcl_stem_bwd_weight(x.ptr, dy.ptr, m.nbr, n_out, op.K, op.cin, op.cout, scratch, dW, (void*)ws));
     return GCL_OK;
   }
   const int wi = P.widx[op.w];
   if ((rc = ensure_amax(P, dy, n_out * op.cout, st))) return rc;
   const int32_t* w_amax = P.w_amax + (long long)wi * GCL_AMAX_WORDS;
   const double pairs = (double)(m.kernel_size > 1 ? m.n_pairs : n_out);
+  const bool pl_w = op.cin >= P.presplit && op.cout >= P.presplit;      // weight gradient on plane images
+  const bool pl_x = op.cout >= P.presplit;                              // input gradient reads dy's plane image
+  if ((pl_w || (pl_x && P.made[op.x])) && (rc = ensure_planes(P, dy, n_out, op.cout, st))) return rc;
+  if (pl_w) {
+    x.amax = P.saved[i].x_amax;
+    if ((rc = ensure_planes(P, x, n_in, op.cin, st))) return rc;
+  }
+  // every operand of the weight gradient is enqueued: fork here, so that it runs beside the input gradient below
+  hipStream_t ws = fork_aux(P, st);
   if (P.made[op.x]) {      // input gradient: the same output-stationary kernel over the opposite table
     int mode;
     const int32_t *tbl = nullptr, *order = nullptr, *mask = nullptr;
@@ -602,8 +648,7 @@ static int conv_backward(Plan& P, int i, TState dy, void* const* grads, hipStrea
     else { mode = 1; tbl = m.tbl_t; order = m.order_t; mask = m.mask_t; }
     GCL_CHECK_ARG(mode == P.wmode[wi], "gcl_plan_backward: record %d: input-gradient pack mode mismatch", i);
     GCL_CHECK_ARG(A.dry || m.kernel_size == 1 || tbl, "gcl_plan_backward: record %d needs a sorted table the maps do not carry", i);
-    const bool pl = op.cout >= P.presplit;
-    if (pl && (rc = ensure_planes(P, dy, n_out, op.cout, st))) return rc;
+    const bool pl = pl_x;
     float* acc = P.g[op.x].ptr;       // a gradient that already reached x through another path: added in the epilogue
     float* dx = A.take_n<float>(n_in * op.cin);
     {
@@ -624,20 +669,15 @@ static int conv_backward(Plan& P, int i, TState dy, void* const* grads, hipStrea
     if (op.transpose) { pa = m.pair_out; pb = m.pair_in; }
     GCL_CHECK_ARG(A.dry || (pa && pb), "gcl_plan_backward: record %d needs pair lists the maps do not carry", i);
     float* scratch = A.take_n<float>(gcl_conv_bwd_weight_scratch_len(op.K, op.cin, op.cout, m.seg_off[op.K]));
-    const bool pl = op.cin >= P.presplit && op.cout >= P.presplit;
-    if (pl) {
-      x.amax = P.saved[i].x_amax;
-      if ((rc = ensure_planes(P, x, n_in, op.cin, st))) return rc;
-      if ((rc = ensure_planes(P, dy, n_out, op.cout, st))) return rc;
-    }
-    ProfScope ps(P, st, 2, pairs, op.cin, op.cout, n_in, n_out, op.K);
+    const bool pl = pl_w;
+    ProfScope ps(P, ws, 2, pairs, op.cin, op.cout, n_in, n_out, op.K);
     PLAN_CALL(gcl_conv_bwd_weight(pl ? (const float*)x.planes : x.ptr, n_in, pl ? (const float*)dy.planes : dy.ptr, n_out,
                                   pl ? 1 : 0, pa, pb, m.seg_off, op.K, op.cin, op.cout, 4, P.saved[i].x_amax, dy.amax, scratch,
-                                  dW, (void*)st));
+                                  dW, (void*)ws));
   }
   if (op.bias >= 0) {
     double* scratch = A.take_n<double>(gcl_bn_scratch_len(n_out, op.cout));
-    PLAN_CALL(gcl_col_sum(dy.ptr, n_out, op.cout, scratch, (float*)grads[op.bias], (void*)st));
+    PLAN_CALL(gcl_col_sum(dy.ptr, n_out, op.cout, scratch, (float*)grads[op.bias], (void*)ws));
   }
   return GCL_OK;
 }
@@ -722,7 +762,7 @@ static int plan_backward(Plan& P, const float* dy, void* const* grads, int first
         return GCL_ERR_ARG;
     }
   }
-  return GCL_OK;
+  return join_aux(P, st);      // the caller may hand the gradients of this segment to a collective / the optimizer next
 }
 
 static int check_maps(const Plan& P, const gcl_maps_desc* M) {
@@ -872,6 +912,7 @@ void gcl_plan_destroy(void* plan) {
     (void)hipEventDestroy(r.e1);
   }
   for (PassState* q : P->passes) delete q;
+  for (hipEvent_t e : P->events) (void)hipEventDestroy(e);
   delete P;
 }
 
@@ -982,6 +1023,13 @@ int gcl_plan_backward(void* plan, void* arena, const float* dy, void* const* gra
   slot->maps = &slot->maps_copy;
   static_cast<PassState&>(*P) = PassState();
   return rc;
+}
+
+int gcl_plan_set_aux_stream(void* plan, void* stream) {
+  Plan* P = (Plan*)plan;
+  GCL_CHECK_ARG(P, "gcl_plan_set_aux_stream: null plan");
+  P->aux = (hipStream_t)stream;
+  return GCL_OK;
 }
 
 int gcl_plan_profile(void* plan, int32_t enable) {

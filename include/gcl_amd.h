@@ -513,6 +513,10 @@ int gcl_plan_backward(void* plan, void* arena, const float* dy, void* const* gra
                       int32_t last_op, void* stream);
 /* Forget the forward pass parked under `arena` (its output was dropped without a backward pass). */
 int gcl_plan_release(void* plan, void* arena);
+/* Optional second stream: the weight gradients (needed only by the optimizer) are enqueued there, ordered behind their
+ * operands by events, while `stream` continues with the input-gradient chain; every gcl_plan_backward call ends with
+ * `stream` waiting for them.  NULL (default) = everything on one stream.  Results do not depend on it. */
+int gcl_plan_set_aux_stream(void* plan, void* stream);
 /* Per-launch timing of the convolution launches of the NEXT forward + backward pass (events on `stream`):
  * gcl_plan_profile(plan, 1) arms it; after the stream has been synchronised gcl_plan_profile_read copies up to
  * max_records records of 8 doubles {kind (0 fwd/dx, 1 dW), ms, pairs, cin, cout, n_in, n_out, K | flags} and returns

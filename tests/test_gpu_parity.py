@@ -711,7 +711,7 @@ def test_fp16x3_small_rows_elementwise():
     n = 4096
     C = torch.zeros((n, 4), dtype=torch.int32)
     C[:, 1] = torch.arange(n) * 4                # isolated voxels: every output row sees only its own input row
-    mgr, omgr = make_mgr(C), O.CoordinateManager(C)
+    mgr, omgr = make_mgr(C.numpy()), O.CoordinateManager(C.numpy())
     g = torch.Generator().manual_seed(11)
     x = torch.randn(n, 64, generator=g, dtype=torch.float64)
     small = torch.arange(n) % 16 == 0
