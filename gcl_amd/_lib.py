@@ -127,7 +127,8 @@ SIGNATURES = {
     "gcl_circle_group_fwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "gcl_circle_group_bwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _i32, _vp, _vp, _vp, _vp, _vp,
                                     _vp]),
-    "gcl_nn_rowmin": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "gcl_nn_rowmin_scratch_len": (_i64, [_i32, _i32]),
+    "gcl_nn_rowmin": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "gcl_neg_mask": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp]),
     "gcl_neg_loss_fwd": (_i32, [_vp, _vp, _i32, _f32, _vp, _vp]),
     "gcl_neg_loss_bwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _vp, _vp, _vp, _vp]),

@@ -313,11 +313,16 @@ __global__ void __launch_bounds__(64) k_circle_group_bwd(const float* __restrict
 constexpr int NN_TA = 64;    // A rows per workgroup
 constexpr int NN_TB = 128;   // B rows per LDS tile
 
+// Grid = (A tiles of 64 rows) x (B chunks): every workgroup scans ONE chunk of B (a multiple of NN_TB rows) for its 64 A
+// rows, so that a 1024 x 1024 search is 128 workgroups instead of 16 and a 5000 x 5000 one ~800 (256 CUs).  A chunk's
+// (minimum, lowest index) goes to part_v / part_i [chunk][row]; k_nn_merge folds the chunks in ascending order (strict <:
+// the lowest index wins ties, as torch.min over the reference's distance matrix does).  With one chunk the result is
+// written directly.  The distance keeps the exact (a - b)^2 form of lib/metrics.py:22-25 (no |a|^2 + |b|^2 - 2ab).
 template <int C>
 __global__ void __launch_bounds__(256) k_nn_rowmin(const float* __restrict__ a, const long long* __restrict__ rows_a,
                                                    int ma, const float* __restrict__ b,
-                                                   const long long* __restrict__ rows_b, int mb, int l2,
-                                                   float* dmin, int* argmin) {
+                                                   const long long* __restrict__ rows_b, int mb, int chunk, int l2,
+                                                   float* __restrict__ out_v, int* __restrict__ out_i) {
   __shared__ __attribute__((aligned(16))) float bt[NN_TB][C];
   __shared__ float rv[4][NN_TA];
   __shared__ int ri[4][NN_TA];
@@ -335,19 +340,21 @@ __global__ void __launch_bounds__(256) k_nn_rowmin(const float* __restrict__ a, 
   }
   float best = INFINITY;
   int besti = 0;
-  for (int j0 = 0; j0 < mb; j0 += NN_TB) {
+  const int jb = blockIdx.y * chunk;
+  const int je = (jb + chunk < mb) ? jb + chunk : mb;
+  for (int j0 = jb; j0 < je; j0 += NN_TB) {
     __syncthreads();
     for (int e = t; e < NN_TB * (C / 4); e += 256) {
       int r = e / (C / 4), q = e % (C / 4);
       float4 v = make_float4(0, 0, 0, 0);
-      if (j0 + r < mb) {
+      if (j0 + r < je) {
         long long src = rows_b ? rows_b[j0 + r] : (long long)(j0 + r);
         v = reinterpret_cast<const float4*>(b + src * C)[q];
       }
       reinterpret_cast<float4*>(&bt[r][0])[q] = v;
     }
     __syncthreads();
-    int jn = (mb - j0 < NN_TB) ? mb - j0 : NN_TB;
+    int jn = (je - j0 < NN_TB) ? je - j0 : NN_TB;
     for (int r = cg; r < jn; r += 4) {
       float d2 = 0.f;
 #pragma unroll
@@ -380,9 +387,41 @@ __global__ void __launch_bounds__(256) k_nn_rowmin(const float* __restrict__ a, 
         bi = i2;
       }
     }
-    dmin[arow] = l2 ? sqrtf(bv + 1e-7f) : bv;
-    argmin[arow] = bi;
+    if (gridDim.y == 1) {
+      out_v[arow] = l2 ? sqrtf(bv + 1e-7f) : bv;
+      out_i[arow] = bi;
+    } else {
+      out_v[(long long)blockIdx.y * ma + arow] = bv;
+      out_i[(long long)blockIdx.y * ma + arow] = bi;
+    }
   }
+}
+
+__global__ void __launch_bounds__(256) k_nn_merge(const float* __restrict__ part_v, const int* __restrict__ part_i, int ma,
+                                                  int n_chunks, int l2, float* __restrict__ dmin, int* __restrict__ argmin) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= ma) return;
+  float bv = part_v[r];
+  int bi = part_i[r];
+  for (int c = 1; c < n_chunks; ++c) {      // chunks hold ascending index ranges: strict < keeps the lowest index
+    const float v = part_v[(long long)c * ma + r];
+    if (v < bv) {
+      bv = v;
+      bi = part_i[(long long)c * ma + r];
+    }
+  }
+  dmin[r] = l2 ? sqrtf(bv + 1e-7f) : bv;
+  argmin[r] = bi;
+}
+
+// B rows per chunk: as many chunks as it takes to put ~1024 workgroups on the chip, each a multiple of NN_TB rows
+static int nn_chunk_rows(int ma, int mb) {
+  const long long a_tiles = cdiv(ma, NN_TA);
+  long long want = cdiv(1024, a_tiles);                 // chunks wanted
+  const long long tiles_b = cdiv(mb, NN_TB);
+  if (want > tiles_b) want = tiles_b;
+  if (want < 1) want = 1;
+  return (int)(cdiv(tiles_b, want) * NN_TB);
 }
 
 // ---- negative-pair mask ---------------------------------------------------------------------------------
@@ -545,20 +584,35 @@ int gcl_circle_group_bwd(const float* f, int32_t c, const int64_t* index, const 
   return GCL_OK;
 }
 
+int64_t gcl_nn_rowmin_scratch_len(int32_t ma, int32_t mb) {
+  if (ma <= 0 || mb <= 0) return 0;
+  const int chunk = nn_chunk_rows(ma, mb);
+  const long long n_chunks = cdiv(mb, chunk);
+  return n_chunks > 1 ? 2 * n_chunks * (long long)ma : 0;
+}
+
 int gcl_nn_rowmin(const float* a, const int64_t* rows_a, int32_t ma, const float* b, const int64_t* rows_b,
-                  int32_t mb, int32_t c, int32_t l2, float* dmin, int32_t* argmin, void* stream) {
+                  int32_t mb, int32_t c, int32_t l2, int32_t* scratch, float* dmin, int32_t* argmin, void* stream) {
   GCL_CHECK_ARG(a && b && dmin && argmin, "gcl_nn_rowmin: null pointer");
   GCL_CHECK_ARG(ma > 0 && mb > 0, "gcl_nn_rowmin: empty input");
   GCL_CHECK_ARG(c == 16 || c == 32 || c == 64, "gcl_nn_rowmin: feature width must be 16, 32 or 64 (got %d)", c);
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid((unsigned)cdiv(ma, NN_TA));
+  const int chunk = nn_chunk_rows(ma, mb);
+  const int n_chunks = (int)cdiv(mb, chunk);
+  GCL_CHECK_ARG(n_chunks == 1 || scratch, "gcl_nn_rowmin: scratch (int32[gcl_nn_rowmin_scratch_len]) is required");
+  dim3 grid((unsigned)cdiv(ma, NN_TA), (unsigned)n_chunks);
+  float* pv = n_chunks > 1 ? (float*)scratch : dmin;
+  int* pi = n_chunks > 1 ? scratch + (long long)n_chunks * ma : argmin;
 #define LAUNCH_NN(CC)                                                                                     \
   hipLaunchKernelGGL(k_nn_rowmin<CC>, grid, dim3(256), 0, st, a, (const long long*)rows_a, ma, b,         \
-                     (const long long*)rows_b, mb, l2, dmin, argmin)
+                     (const long long*)rows_b, mb, chunk, l2, pv, pi)
   if (c == 16) LAUNCH_NN(16);
   else if (c == 32) LAUNCH_NN(32);
   else LAUNCH_NN(64);
 #undef LAUNCH_NN
+  if (n_chunks > 1)
+    hipLaunchKernelGGL(k_nn_merge, dim3((unsigned)cdiv(ma, 256)), dim3(256), 0, st, (const float*)pv, (const int*)pi, ma,
+                       n_chunks, l2, dmin, argmin);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }

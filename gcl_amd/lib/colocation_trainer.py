@@ -62,9 +62,11 @@ class _GCLLossFn(torch.autograd.Function):
                    "gcl_group_loss_fwd")
         dmin = torch.empty(m, dtype=torch.float32, device=dev)
         arg = torch.empty(m, dtype=torch.int32, device=dev)     # hardest negative: fused pdist + row minimum (:510-512)
+        ns = lib.gcl_nn_rowmin_scratch_len(m, m)
+        nn_scratch = torch.empty(ns, dtype=torch.int32, device=dev) if ns else None
         _lib.check(lib.gcl_nn_rowmin(_lib.ptr(F), _lib.ptr(sel1, torch.int64), m, _lib.ptr(F),
-                                     _lib.ptr(sel2, torch.int64), m, c, 1, _lib.ptr(dmin), _lib.ptr(arg), st),
-                   "gcl_nn_rowmin")
+                                     _lib.ptr(sel2, torch.int64), m, c, 1, _lib.ptr(nn_scratch), _lib.ptr(dmin),
+                                     _lib.ptr(arg), st), "gcl_nn_rowmin")
         cap = 64
         while cap < 2 * m:
             cap *= 2

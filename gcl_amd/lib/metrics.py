@@ -40,8 +40,10 @@ def pdist_min(A, B, dist_type="L2", rows_a=None, rows_b=None):
     mb = B.shape[0] if rows_b is None else rows_b.shape[0]
     dmin = torch.empty(ma, dtype=torch.float32, device=A.device)
     arg = torch.empty(ma, dtype=torch.int32, device=A.device)
+    ns = lib.gcl_nn_rowmin_scratch_len(ma, mb)
+    scratch = torch.empty(ns, dtype=torch.int32, device=A.device) if ns else None
     _lib.check(lib.gcl_nn_rowmin(_lib.ptr(A, torch.float32), _lib.ptr(rows_a, torch.int64), ma,
                                  _lib.ptr(B, torch.float32), _lib.ptr(rows_b, torch.int64), mb, A.shape[1],
-                                 1 if dist_type == "L2" else 0, _lib.ptr(dmin), _lib.ptr(arg), _lib.stream()),
-               "gcl_nn_rowmin")
+                                 1 if dist_type == "L2" else 0, _lib.ptr(scratch), _lib.ptr(dmin), _lib.ptr(arg),
+                                 _lib.stream()), "gcl_nn_rowmin")
     return dmin, arg

@@ -361,9 +361,11 @@ int gcl_circle_group_bwd(const float* f, int32_t c, const int64_t* index, const 
 
 /* Row-wise nearest neighbour: for every row i of A[rows_a[i]] (rows_a may be NULL = identity) the column j
  * minimising sum_c (a - b)^2 over B[rows_b[j]]; ties -> lowest j.  dmin = that squared distance, or
- * sqrt(d2 + 1e-7) when l2 != 0 (lib/metrics.py:24-25). */
+ * sqrt(d2 + 1e-7) when l2 != 0 (lib/metrics.py:24-25).  The search runs as (64-row A tiles) x (chunks of B) workgroups
+ * followed by a merge over the chunks; scratch: int32[gcl_nn_rowmin_scratch_len(ma, mb)] (0 = none needed, NULL ok). */
+int64_t gcl_nn_rowmin_scratch_len(int32_t ma, int32_t mb);
 int gcl_nn_rowmin(const float* a, const int64_t* rows_a, int32_t ma, const float* b, const int64_t* rows_b,
-                  int32_t mb, int32_t c, int32_t l2, float* dmin, int32_t* argmin, void* stream);
+                  int32_t mb, int32_t c, int32_t l2, int32_t* scratch, float* dmin, int32_t* argmin, void* stream);
 
 /* keep[r] = (sel1[r] != sel2[arg[r]]) && the pair {sel1[r], sel2[arg[r]]} shares no positive group
  * (equivalent to the reference's `~np.isin(_neg_hash(...), index_hash)` :521-529: the symmetric key is

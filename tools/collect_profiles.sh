@@ -5,7 +5,7 @@
 # WRITE_SIZE.  The program itself follows "--" (no shell / env hop: the profiler's preload initialises the GPU first).
 TAG=${1:-x}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-A="--steps 8 --warmup 2 --no-cpu-baseline --no-kernel-events"
+A="--steps 8 --warmup 2 --no-cpu-baseline --no-kernel-events --no-secondary"
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof_final $R/gpurun_out/pmc_final1 $R/gpurun_out/pmc_final2 $R/gpurun_out/pmc_final3
 python3 $R/bench.py > $R/gpurun_out/r03_bench_$TAG.json 2> $R/gpurun_out/r03_bench_$TAG.log

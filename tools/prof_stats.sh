@@ -2,7 +2,7 @@
 # kernel-trace + stats pass only:  gpurun -- 'bash tools/prof_stats.sh <tag>'  -> gpurun_out/<tag>_stats.txt
 TAG=${1:-x}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-A="--steps 8 --warmup 2 --no-cpu-baseline --no-kernel-events"
+A="--steps 8 --warmup 2 --no-cpu-baseline --no-kernel-events --no-secondary"
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof_$TAG
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o r --output-format csv -- python3 $R/bench.py $A > $R/gpurun_out/prof_$TAG.log 2>&1
