@@ -752,8 +752,12 @@ class _RowNormalizeFn(torch.autograd.Function):
         y, norm = ctx.saved_tensors
         dy = dy.contiguous()
         dx = torch.empty_like(y)
+        slot = amax_slot(y.device) if PRECISION == "fp16x3" else None       # the consumer is `final`'s input gradient
         _lib.check(lib.gcl_row_normalize_bwd(_lib.ptr(y), _lib.ptr(dy, torch.float32), _lib.ptr(norm), y.shape[0],
-                                             y.shape[1], _lib.ptr(dx), _lib.stream()), "gcl_row_normalize_bwd")
+                                             y.shape[1], _lib.ptr(dx), _lib.ptr(slot), _lib.stream()),
+                   "gcl_row_normalize_bwd")
+        if slot is not None:
+            tag_amax(dx, slot)
         return dx
 
 

@@ -100,7 +100,7 @@ SIGNATURES = {
     "gcl_bn_bwd_reduce": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "gcl_bn_bwd_apply": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "gcl_row_normalize_fwd": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
-    "gcl_row_normalize_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "gcl_row_normalize_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     "gcl_sgd_multi": (_i32, [_vp, _vp, _i32, _f32, _f32, _f32, _i32, _vp]),
     "gcl_col_sum": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
     "gcl_maps_arena_bytes": (_i64, [_i64, _vp, _i32, _i32]),

@@ -115,27 +115,59 @@ __global__ void __launch_bounds__(256) k_bn_reduce(const float* __restrict__ x, 
 }
 
 // ordered (deterministic) sum of the per-workgroup partials of 4 channels by one 256-thread workgroup:
-// thread = (channel ch = t & 3, slice sl = t >> 2) sums partials sl, sl+64, ...; the 64 slices are then added in order.
+// thread = (channel ch = t & 3, slice sl = t >> 2) sums partials sl, sl+64, ... (all loads of a thread are independent
+// and issued together); the 64 slice sums are then added as 8 groups of 8 consecutive slices (threads sl < 8), and the 8
+// group sums in order by the thread with sl == 0 -- a fixed tree, so the result does not depend on timing.  (The former
+// single 64-step serial chain of LDS reads was most of these kernels' ~11 us.)
 __device__ __forceinline__ void reduce_partials4(const double* __restrict__ partial, int nwg, int c, int ch,
                                                  double& s, double& ss) {
   __shared__ double red[2][64][5];
+  __shared__ double red2[2][8][5];
   const int sl = threadIdx.x >> 2, cl = threadIdx.x & 3;
   double a = 0, b = 0;
-  if (ch < c)
-    for (int w = sl; w < nwg; w += 64) {
+  if (ch < c) {
+    double a1 = 0, b1 = 0, a2 = 0, b2 = 0, a3 = 0, b3 = 0;       // four independent chains: loads in flight together
+    int w = sl;
+    for (; w + 192 < nwg; w += 256) {
+      a += partial[(long long)w * 2 * c + ch];
+      b += partial[(long long)w * 2 * c + c + ch];
+      a1 += partial[(long long)(w + 64) * 2 * c + ch];
+      b1 += partial[(long long)(w + 64) * 2 * c + c + ch];
+      a2 += partial[(long long)(w + 128) * 2 * c + ch];
+      b2 += partial[(long long)(w + 128) * 2 * c + c + ch];
+      a3 += partial[(long long)(w + 192) * 2 * c + ch];
+      b3 += partial[(long long)(w + 192) * 2 * c + c + ch];
+    }
+    for (; w < nwg; w += 64) {
       a += partial[(long long)w * 2 * c + ch];
       b += partial[(long long)w * 2 * c + c + ch];
     }
+    a = (a + a1) + (a2 + a3);
+    b = (b + b1) + (b2 + b3);
+  }
   red[0][sl][cl] = a;
   red[1][sl][cl] = b;
   __syncthreads();
+  if (sl < 8) {
+    double u = 0, v = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      u += red[0][sl * 8 + q][cl];
+      v += red[1][sl * 8 + q][cl];
+    }
+    red2[0][sl][cl] = u;
+    red2[1][sl][cl] = v;
+  }
+  __syncthreads();
   s = 0;
   ss = 0;
-  if (sl == 0)
-    for (int q = 0; q < 64; ++q) {
-      s += red[0][q][cl];
-      ss += red[1][q][cl];
+  if (sl == 0) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      s += red2[0][q][cl];
+      ss += red2[1][q][cl];
     }
+  }
 }
 
 __global__ void __launch_bounds__(256) k_bn_stats_final(const double* __restrict__ partial, int nwg, long long n,
@@ -166,22 +198,47 @@ __global__ void __launch_bounds__(1024) k_bn_stats_direct(const float* __restric
                                                           float eps, float momentum, float* running_mean,
                                                           float* running_var, float* mean, float* rstd) {
   __shared__ double red[2][256][5];
+  __shared__ double red2[2][16][5];
   const int cl = threadIdx.x & 3, sl = threadIdx.x >> 2;
   const int ch = blockIdx.x * 4 + cl;
   double a = 0, b = 0;
-  if (ch < c)
-    for (int w = sl; w < n_part; w += 256) {
+  if (ch < c) {
+    double a1 = 0, b1 = 0;        // two independent chains per thread
+    int w = sl;
+    for (; w + 256 < n_part; w += 512) {
+      a += (double)partial[(long long)w * 2 * c + ch];
+      b += (double)partial[(long long)w * 2 * c + c + ch];
+      a1 += (double)partial[(long long)(w + 256) * 2 * c + ch];
+      b1 += (double)partial[(long long)(w + 256) * 2 * c + c + ch];
+    }
+    for (; w < n_part; w += 256) {
       a += (double)partial[(long long)w * 2 * c + ch];
       b += (double)partial[(long long)w * 2 * c + c + ch];
     }
+    a += a1;
+    b += b1;
+  }
   red[0][sl][cl] = a;
   red[1][sl][cl] = b;
   __syncthreads();
+  // fixed tree: 16 groups of 16 consecutive slices, then the 16 group sums in order (was one 256-step serial chain)
+  if (sl < 16) {
+    double u = 0, v = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      u += red[0][sl * 16 + q][cl];
+      v += red[1][sl * 16 + q][cl];
+    }
+    red2[0][sl][cl] = u;
+    red2[1][sl][cl] = v;
+  }
+  __syncthreads();
   if (sl != 0 || ch >= c) return;
   double s = 0, ss = 0;
-  for (int q = 0; q < 256; ++q) {
-    s += red[0][q][cl];
-    ss += red[1][q][cl];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    s += red2[0][q][cl];
+    ss += red2[1][q][cl];
   }
   double m = s / (double)n;
   double var = ss / (double)n - m * m;
@@ -320,7 +377,8 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const float* __restrict__ 
 template <bool BWD>
 __global__ void __launch_bounds__(256) k_row_normalize(const float* __restrict__ a, const float* __restrict__ dy,
                                                        const float* __restrict__ norm_in, long long n, int c,
-                                                       float* __restrict__ out, float* __restrict__ norm_out) {
+                                                       float* __restrict__ out, float* __restrict__ norm_out,
+                                                       int* out_amax) {
   const int lpr = c >> 2;
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long row = e / lpr;
@@ -332,17 +390,21 @@ __global__ void __launch_bounds__(256) k_row_normalize(const float* __restrict__
   }
   float s = BWD ? (v.x * g.x + v.y * g.y + v.z * g.z + v.w * g.w) : (v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
   for (int o = 1; o < lpr; o <<= 1) s += __shfl_xor(s, o);
-  if (!ok) return;
-  float4 o4;
-  if (!BWD) {
-    const float nr = sqrtf(s);
-    o4 = make_float4(v.x / nr, v.y / nr, v.z / nr, v.w / nr);
-    if ((e % lpr) == 0) norm_out[row] = nr;
-  } else {
-    const float nr = norm_in[row];
-    o4 = make_float4((g.x - v.x * s) / nr, (g.y - v.y * s) / nr, (g.z - v.z * s) / nr, (g.w - v.w * s) / nr);
+  float m = 0.f;
+  if (ok) {
+    float4 o4;
+    if (!BWD) {
+      const float nr = sqrtf(s);
+      o4 = make_float4(v.x / nr, v.y / nr, v.z / nr, v.w / nr);
+      if ((e % lpr) == 0) norm_out[row] = nr;
+    } else {
+      const float nr = norm_in[row];
+      o4 = make_float4((g.x - v.x * s) / nr, (g.y - v.y * s) / nr, (g.z - v.z * s) / nr, (g.w - v.w * s) / nr);
+    }
+    reinterpret_cast<float4*>(out)[e] = o4;
+    m = amax4(m, o4);
   }
-  reinterpret_cast<float4*>(out)[e] = o4;
+  if (out_amax) publish_amax(m, out_amax);      // every thread of the workgroup gets here
 }
 
 // ---- SGD with momentum and weight decay over a LIST of tensors in one launch ---------------------------------------
@@ -355,7 +417,28 @@ __global__ void __launch_bounds__(256) k_sgd_multi(const SgdPtrs* __restrict__ t
                                                    float lr, float momentum, float wd, int first) {
   const SgdPtrs t = table[blockIdx.y];
   const long long n = sizes[blockIdx.y];
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+  // float4 body when the three pointers are 16-byte aligned (tensors seated in a flat buffer at arbitrary offsets may not
+  // be), scalar tail / fallback; the arithmetic per element is the same either way
+  const bool vec = ((((unsigned long long)t.p) | ((unsigned long long)t.g) | ((unsigned long long)t.buf)) & 15ull) == 0;
+  const long long n4 = vec ? n / 4 : 0;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (long long)gridDim.x * blockDim.x) {
+    float4 p = reinterpret_cast<const float4*>(t.p)[e];
+    const float4 g = reinterpret_cast<const float4*>(t.g)[e];
+    float4 b = make_float4(0, 0, 0, 0);
+    if (!first) b = reinterpret_cast<const float4*>(t.buf)[e];
+    const float d0 = g.x + wd * p.x, d1 = g.y + wd * p.y, d2 = g.z + wd * p.z, d3 = g.w + wd * p.w;
+    b.x = first ? d0 : momentum * b.x + d0;
+    b.y = first ? d1 : momentum * b.y + d1;
+    b.z = first ? d2 : momentum * b.z + d2;
+    b.w = first ? d3 : momentum * b.w + d3;
+    reinterpret_cast<float4*>(t.buf)[e] = b;
+    p.x -= lr * b.x;
+    p.y -= lr * b.y;
+    p.z -= lr * b.z;
+    p.w -= lr * b.w;
+    reinterpret_cast<float4*>(t.p)[e] = p;
+  }
+  for (long long e = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
     const float p = t.p[e];
     const float d = t.g[e] + wd * p;
     const float b = first ? d : momentum * t.buf[e] + d;
@@ -477,18 +560,18 @@ int gcl_row_normalize_fwd(const float* x, int64_t n, int32_t c, float* y, float*
   GCL_CHECK_ARG(n > 0 && rownorm_c_ok(c), "gcl_row_normalize_fwd: c must be a power of two in [4, 256] (got %d)", c);
   long long total = n * (c / 4);
   hipLaunchKernelGGL(k_row_normalize<false>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
-                     (const float*)nullptr, (const float*)nullptr, (long long)n, c, y, norm);
+                     (const float*)nullptr, (const float*)nullptr, (long long)n, c, y, norm, (int*)nullptr);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }
 
 int gcl_row_normalize_bwd(const float* y, const float* dy, const float* norm, int64_t n, int32_t c, float* dx,
-                          void* stream) {
+                          int32_t* dx_amax, void* stream) {
   GCL_CHECK_ARG(y && dy && norm && dx, "gcl_row_normalize_bwd: null pointer");
   GCL_CHECK_ARG(n > 0 && rownorm_c_ok(c), "gcl_row_normalize_bwd: c must be a power of two in [4, 256] (got %d)", c);
   long long total = n * (c / 4);
   hipLaunchKernelGGL(k_row_normalize<true>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, y, dy,
-                     norm, (long long)n, c, dx, (float*)nullptr);
+                     norm, (long long)n, c, dx, (float*)nullptr, dx_amax);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }
@@ -510,7 +593,7 @@ int gcl_col_sum(const float* x, int64_t n, int32_t c, double* scratch, float* ou
 int gcl_sgd_multi(const void* table, const int64_t* sizes, int32_t n_tensors, float lr, float momentum,
                   float weight_decay, int32_t first, void* stream) {
   GCL_CHECK_ARG(table && sizes && n_tensors > 0 && n_tensors <= 65535, "gcl_sgd_multi: bad argument");
-  hipLaunchKernelGGL(k_sgd_multi, dim3(64, (unsigned)n_tensors), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(k_sgd_multi, dim3(128, (unsigned)n_tensors), dim3(256), 0, (hipStream_t)stream,
                      (const SgdPtrs*)table, (const long long*)sizes, lr, momentum, weight_decay, first);
   GCL_CHECK_LAUNCH();
   return GCL_OK;

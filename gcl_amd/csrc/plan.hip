@@ -24,8 +24,24 @@ namespace gcl {
 // ---------------------------------------------------------------------------------------------------
 // small elementwise kernels of the plan path
 // ---------------------------------------------------------------------------------------------------
-// MEF.relu: torch.relu semantics (NaN propagates)
-__global__ void __launch_bounds__(256) k_relu_fwd(const float4* __restrict__ x, long long n4, float4* __restrict__ y) {
+// max |v| of what a workgroup wrote -> the tensor's amax slot (same value gcl_amax would measure in a pass of its own)
+__device__ __forceinline__ float amax4p(float m, const float4& v) {
+  return fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+}
+__device__ __forceinline__ void publish_amax_wg(float m, int* slot) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  __shared__ float wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    amax_slot_publish(slot, __float_as_int(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))), blockIdx.x);
+}
+
+// MEF.relu: torch.relu semantics (NaN propagates); amax (optional): zero-initialised slot that receives max|y|
+__global__ void __launch_bounds__(256) k_relu_fwd(const float4* __restrict__ x, long long n4, float4* __restrict__ y,
+                                                  int* amax) {
+  float m = 0.f;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     float4 v = x[i];
     v.x = v.x < 0.f ? 0.f : v.x;
@@ -33,11 +49,14 @@ __global__ void __launch_bounds__(256) k_relu_fwd(const float4* __restrict__ x, 
     v.z = v.z < 0.f ? 0.f : v.z;
     v.w = v.w < 0.f ? 0.f : v.w;
     y[i] = v;
+    m = amax4p(m, v);
   }
+  if (amax) publish_amax_wg(m, amax);
 }
 // aten::threshold_backward(g, y, 0): g where y > 0, else 0
 __global__ void __launch_bounds__(256) k_relu_bwd(const float4* __restrict__ g, const float4* __restrict__ y, long long n4,
-                                                  float4* __restrict__ gx) {
+                                                  float4* __restrict__ gx, int* amax) {
+  float m = 0.f;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     float4 a = g[i];
     const float4 b = y[i];
@@ -46,18 +65,24 @@ __global__ void __launch_bounds__(256) k_relu_bwd(const float4* __restrict__ g, 
     a.z = b.z > 0.f ? a.z : 0.f;
     a.w = b.w > 0.f ? a.w : 0.f;
     gx[i] = a;
+    m = amax4p(m, a);
   }
+  if (amax) publish_amax_wg(m, amax);
 }
 // ME.cat(a, b): y[r] = a[r] | b[r]   (channel counts are multiples of 4)
 __global__ void __launch_bounds__(256) k_cat2(const float4* __restrict__ a, int ca4, const float4* __restrict__ b, int cb4,
-                                              long long n, float4* __restrict__ y) {
+                                              long long n, float4* __restrict__ y, int* amax) {
   const int c4 = ca4 + cb4;
   const long long total = n * c4;
+  float m = 0.f;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long r = i / c4;
     const int q = (int)(i - r * c4);
-    y[i] = q < ca4 ? a[r * ca4 + q] : b[r * cb4 + (q - ca4)];
+    const float4 v = q < ca4 ? a[r * ca4 + q] : b[r * cb4 + (q - ca4)];
+    y[i] = v;
+    m = amax4p(m, v);
   }
+  if (amax) publish_amax_wg(m, amax);
 }
 __global__ void __launch_bounds__(256) k_split2(const float4* __restrict__ g, int ca4, int cb4, long long n,
                                                 float4* __restrict__ ga, float4* __restrict__ gb) {
@@ -557,8 +582,10 @@ static int plan_forward(Plan& P, const float* x_in, void* const* bn_stats, float
       case GCL_OP_RELU: {
         const long long n4 = n_out * op.cout / 4;
         y.ptr = A.take_n<float>(n_out * op.cout);
+        y.amax = new_slot(P);        // published by the kernel itself: the consumer needs no gcl_amax pass
         if (!A.dry) {
-          hipLaunchKernelGGL(k_relu_fwd, dim3(grid_for(n4)), dim3(256), 0, st, (const float4*)P.t[op.x].ptr, n4, (float4*)y.ptr);
+          hipLaunchKernelGGL(k_relu_fwd, dim3(grid_for(n4)), dim3(256), 0, st, (const float4*)P.t[op.x].ptr, n4, (float4*)y.ptr,
+                             y.amax);
           GCL_CHECK_LAUNCH();
         }
         break;
@@ -566,9 +593,10 @@ static int plan_forward(Plan& P, const float* x_in, void* const* bn_stats, float
       case GCL_OP_CAT: {
         const int ca = op.cin, cb = op.cout - op.cin;
         y.ptr = A.take_n<float>(n_out * op.cout);
+        y.amax = new_slot(P);
         if (!A.dry) {
           hipLaunchKernelGGL(k_cat2, dim3(grid_for(n_out * op.cout / 4)), dim3(256), 0, st, (const float4*)P.t[op.x].ptr, ca / 4,
-                             (const float4*)P.t[op.x2].ptr, cb / 4, n_out, (float4*)y.ptr);
+                             (const float4*)P.t[op.x2].ptr, cb / 4, n_out, (float4*)y.ptr, y.amax);
           GCL_CHECK_LAUNCH();
         }
         break;
@@ -589,13 +617,14 @@ static int plan_forward(Plan& P, const float* x_in, void* const* bn_stats, float
 }
 
 // Tape.backward's give(): the first gradient of a tensor is kept, later ones are added in arrival order
-static int give(Plan& P, int tensor, float* gptr, long long numel, hipStream_t st) {
+static int give(Plan& P, int tensor, float* gptr, long long numel, hipStream_t st, int32_t* amax = nullptr) {
   Arena& A = P.A;
   if (tensor < 0 || !P.made[tensor] || !gptr) return GCL_OK;
   TState& g = P.g[tensor];
   if (!g.ptr) {
     g = TState();
     g.ptr = gptr;
+    g.amax = amax;        // published by the producing kernel (valid while the gradient stays this one tensor)
     return GCL_OK;
   }
   float* sum = A.take_n<float>(numel);
@@ -731,12 +760,13 @@ static int plan_backward(Plan& P, const float* dy, void* const* grads, int first
       case GCL_OP_RELU: {
         const long long numel = n_out * op.cout;
         float* gx = A.take_n<float>(numel);
+        int32_t* slot = new_slot(P);
         if (!A.dry) {
           hipLaunchKernelGGL(k_relu_bwd, dim3(grid_for(numel / 4)), dim3(256), 0, st, (const float4*)g.ptr,
-                             (const float4*)P.t[op.y].ptr, numel / 4, (float4*)gx);
+                             (const float4*)P.t[op.y].ptr, numel / 4, (float4*)gx, slot);
           GCL_CHECK_LAUNCH();
         }
-        if ((rc = give(P, op.x, gx, numel, st))) return rc;
+        if ((rc = give(P, op.x, gx, numel, st, slot))) return rc;
         break;
       }
       case GCL_OP_CAT: {
@@ -754,8 +784,9 @@ static int plan_backward(Plan& P, const float* dy, void* const* grads, int first
       }
       case GCL_OP_ROWNORM: {
         float* dx = A.take_n<float>(n_in * op.cin);
-        PLAN_CALL(gcl_row_normalize_bwd(P.t[op.y].ptr, g.ptr, P.saved[i].norm, n_out, op.cout, dx, (void*)st));
-        if ((rc = give(P, op.x, dx, n_in * op.cin, st))) return rc;
+        int32_t* slot = new_slot(P);
+        PLAN_CALL(gcl_row_normalize_bwd(P.t[op.y].ptr, g.ptr, P.saved[i].norm, n_out, op.cout, dx, slot, (void*)st));
+        if ((rc = give(P, op.x, dx, n_in * op.cin, st, slot))) return rc;
         break;
       }
       default:

