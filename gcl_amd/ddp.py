@@ -4,10 +4,13 @@ The reference is single-GPU; this is the new capability BASELINE
 naturally: every rank takes its own samples, builds its own coordinate maps, mines negatives inside its own batch
 (the reference's bs=4 semantics per rank) and keeps its own BatchNorm statistics (the reference has no SyncBN).
 The only exchange is the gradient: all parameters are re-seated as views of ONE flat fp32 buffer (35 MB), all-reduced
-in two large contiguous buckets (xGMI rings are per-link bound: few large collectives beat many small ones) -- the
-bucket of the decoder layers starts from a post-accumulate hook as soon as the backward pass has filled it and overlaps
-with the encoder half of backward -- followed by a scale by 1/world_size.  Parameters and BN buffers are broadcast
-from rank 0 once.
+in two large contiguous buckets (xGMI rings are per-link bound: few large collectives beat many small ones), followed by
+a scale by 1/world_size.  Overlap: with the native plan (gcl_amd/MinkowskiEngine/native.py) the backward pass is enqueued
+in two segments and ``bucket_ready`` starts the decoder bucket's all-reduce in between, so it runs under the encoder half
+of the backward pass.  With the whole-network Tape (GCL_PLAN=0, or a model's first, recorded step) every gradient leaves
+one autograd node at the END of the backward pass: the post-accumulate hooks then start both buckets back to back and
+nothing overlaps; with GCL_TAPE=0 (one autograd node per layer) the hooks start the decoder bucket early again.
+Parameters and BN buffers are broadcast from rank 0 once.
 Works with any torch.distributed backend (gloo on CPU in tests/test_ddp_gloo.py).
 """
 import os
