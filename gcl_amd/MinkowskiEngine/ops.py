@@ -381,11 +381,14 @@ class _SparseConvFn(torch.autograd.Function):
             else:
                 if kmap is None:
                     pa, pb, seg, seg_host = ctx.mgr.identity_pairs(x.shape[0])
+                    sorted_side = 0
                 else:
                     pin, pout, seg, seg_host = kmap.pairs()
                     pa, pb = (pout, pin) if transpose else (pin, pout)
-                scratch = torch.empty(lib.gcl_conv_bwd_weight_scratch_len(K, cin, cout, seg[-1]), dtype=torch.float32,
-                                      device=x.device)
+                    sorted_side = 1 if transpose else 2       # the map's OUT rows ascend inside every offset segment
+                n_sorted = (x.shape[0] if sorted_side == 1 else dy.shape[0]) if sorted_side else 0
+                scratch = torch.empty(lib.gcl_conv_bwd_weight_scratch_len(K, cin, cout, seg[-1], n_sorted),
+                                      dtype=torch.float32, device=x.device)
                 tile = f"{64 if cin % 64 == 0 else 32},{64 if cout % 64 == 0 else 32}"
                 use_pl = fp16x3 and _want_planes(cin) and _want_planes(cout)
                 name = "k_conv_bwd_weight_generic" if (cin % 32 or cout % 32) else \
@@ -397,7 +400,7 @@ class _SparseConvFn(torch.autograd.Function):
                     xa = planes_of(lib, x, x_amax) if use_pl else x
                     ya = planes_of(lib, dy, dy_amax) if use_pl else dy
                     _lib.check(lib.gcl_conv_bwd_weight(_lib.ptr(xa), x.shape[0], _lib.ptr(ya), dy.shape[0], int(use_pl),
-                                                       _lib.ptr(pa), _lib.ptr(pb), seg_host,
+                                                       sorted_side, _lib.ptr(pa), _lib.ptr(pb), seg_host,
                                                        K, cin, cout, prec, _lib.ptr(x_amax), _lib.ptr(dy_amax),
                                                        _lib.ptr(scratch), _lib.ptr(dW), _lib.stream()),
                                "gcl_conv_bwd_weight")

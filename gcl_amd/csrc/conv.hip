@@ -1438,14 +1438,21 @@ __device__ __forceinline__ void tr_mma_half(const unsigned (*baseA)[2], const un
 // Same decomposition as k_conv_bwd_weight (wave-private LDS tiles, per-wave slabs, no workgroup barrier), plus a
 // two-deep software pipeline: pair indices are fetched two chunks ahead and rows one chunk ahead of their use.
 // PRE (PL == 4 only): A and B point at plane images; see above.
-template <int TCA, int TCB, int PL, bool PRE = false>
+// RG ("range-grouped", round 3): instead of a contiguous run of the k-major pair list, a workgroup takes ONE (row range j,
+// offset k) cell -- the pairs of offset k whose row on the SORTED side of the list (the out rows of the kernel map) lies in
+// [j RR, (j+1) RR); `bounds` holds the cell limits.  The K cells of a range get consecutive slots of ONE XCD, so the
+// sorted side's rows (dY for a forward convolution) are fetched into that L2 once and re-read K - 1 times from there
+// instead of once per offset from the fabric: P (Ca + Cb) -> ~ P Ca + N Cb bytes.  One slab per cell, summed over the
+// ranges in order by k_bwd_weight_reduce_rg (deterministic).  Single channel tile only (Ca = TCA, Cb = TCB).
+template <int TCA, int TCB, int PL, bool PRE = false, bool RG = false>
 __global__ void __launch_bounds__(256) k_conv_bwd_weight_split(const float* __restrict__ A, const float* __restrict__ B,
                                                                const int* __restrict__ pair_a,
                                                                const int* __restrict__ pair_b, SegOffW seg, int K,
                                                                int ca, int cb, long long n_chunks, int per,
                                                                float* slabs, const int* __restrict__ a_amax,
                                                                const int* __restrict__ b_amax, int n_wg_x, int n_tiles,
-                                                               unsigned a_bytes, unsigned b_bytes) {
+                                                               unsigned a_bytes, unsigned b_bytes,
+                                                               const int* __restrict__ bounds = nullptr, int n_ranges = 0) {
   constexpr int NBI = TCA / 32, NBJ = TCB / 32;
   constexpr int PA = TCA / 4, PB = TCB / 4;         // 16-byte pieces per row
   constexpr int RA = 64 / PA, RB = 64 / PB;          // rows per load pass
@@ -1480,7 +1487,18 @@ __global__ void __launch_bounds__(256) k_conv_bwd_weight_split(const float* __re
   // XCD-aware launch order (1-D grid): workgroups are dealt round-robin to the 8 XCDs, so the n_tiles channel tiles
   // that re-read the SAME pair range are given consecutive slots of ONE XCD and share its L2
   int bx, by;
-  if (n_tiles > 0) {
+  long long rg_lo = 0, rg_hi = 0;
+  int rg_k = 0;
+  if (RG) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    rg_k = slot % K;
+    const int j = (slot / K) * 8 + xcd;
+    if (j >= n_ranges) return;
+    rg_lo = bounds[rg_k * (n_ranges + 1) + j];
+    rg_hi = bounds[rg_k * (n_ranges + 1) + j + 1];
+    bx = j * K;              // slab of the cell = bx + rg_k
+    by = 0;
+  } else if (n_tiles > 0) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     by = slot % n_tiles;
     bx = (slot / n_tiles) * 8 + xcd;
@@ -1491,9 +1509,10 @@ __global__ void __launch_bounds__(256) k_conv_bwd_weight_split(const float* __re
   }
   const int tiles_b = cb / TCB;
   const int ca0 = (by / tiles_b) * TCA, cb0 = (by % tiles_b) * TCB;
-  const long long c0 = (long long)bx * per;
-  const long long c1 = (c0 + per < n_chunks) ? c0 + per : n_chunks;
-  if (c0 >= c1) return;   // uniform over the workgroup
+  const long long c0 = RG ? 0 : (long long)bx * per;
+  const long long c1 = RG ? (rg_hi - rg_lo + GCL_PAIR_CHUNK - 1) / GCL_PAIR_CHUNK
+                          : ((c0 + per < n_chunks) ? c0 + per : n_chunks);
+  if (!RG && c0 >= c1) return;   // uniform over the workgroup (an empty RG cell still writes its zero slab)
 
   f32x16 acc[NBI][NBJ];
 #pragma unroll
@@ -1518,9 +1537,11 @@ __global__ void __launch_bounds__(256) k_conv_bwd_weight_split(const float* __re
     ia = -1;
     ib = -1;
     if (c < c1 && l < 32) {
-      long long p0 = c * GCL_PAIR_CHUNK + w * 32 + l;
-      ia = pair_a[p0];
-      ib = pair_b[p0];
+      long long p0 = (RG ? rg_lo : 0) + c * GCL_PAIR_CHUNK + w * 32 + l;
+      if (!RG || p0 < rg_hi) {
+        ia = pair_a[p0];
+        ib = pair_b[p0];
+      }
     }
   };
 
@@ -1543,15 +1564,16 @@ __global__ void __launch_bounds__(256) k_conv_bwd_weight_split(const float* __re
     }                                                                                                   \
   }
 
-  int kcur = 0;
-  while (seg.off[kcur + 1] <= c0 * GCL_PAIR_CHUNK) ++kcur;
+  int kcur = RG ? rg_k : 0;
+  if (!RG)
+    while (seg.off[kcur + 1] <= c0 * GCL_PAIR_CHUNK) ++kcur;
   int ia1, ib1, ia2, ib2;
   load_pairs(c0, ia1, ib1);
   load_pairs(c0 + 1, ia2, ib2);
   GCL_GATHER(ia1, ib1);
   for (long long c = c0; c < c1; ++c) {
     const long long pbase = c * GCL_PAIR_CHUNK;
-    if (pbase >= seg.off[kcur + 1]) {
+    if (!RG && pbase >= seg.off[kcur + 1]) {
       flush(kcur);
       while (seg.off[kcur + 1] <= pbase) ++kcur;
     }
@@ -1633,6 +1655,54 @@ __global__ void __launch_bounds__(256) k_bwd_weight_reduce(const float* __restri
   dw[(long long)k * mat + e] = s;
 }
 
+// RG mode: dw[k] = sum over the row ranges j of slab (j K + k), in order (four loads in flight, fixed tree)
+__global__ void __launch_bounds__(256) k_bwd_weight_reduce_rg(const float* __restrict__ slabs, int n_ranges, int K,
+                                                              long long mat, float* dw) {
+  const int k = blockIdx.y;
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= mat) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int j = 0;
+  for (; j + 3 < n_ranges; j += 4) {
+    s0 += slabs[((long long)j * K + k) * mat + e];
+    s1 += slabs[((long long)(j + 1) * K + k) * mat + e];
+    s2 += slabs[((long long)(j + 2) * K + k) * mat + e];
+    s3 += slabs[((long long)(j + 3) * K + k) * mat + e];
+  }
+  for (; j < n_ranges; ++j) s0 += slabs[((long long)j * K + k) * mat + e];
+  dw[(long long)k * mat + e] = (s0 + s1) + (s2 + s3);
+}
+
+// cell limits of the RG mode: bounds[k (n_ranges + 1) + j] = first position p of offset k's segment whose sorted-side row
+// is >= j rr (the segment ascends in that row and ends in -1 padding, which counts as +infinity)
+__global__ void __launch_bounds__(256) k_pair_bounds(const int* __restrict__ sorted_rows, SegOffW seg, int K, int rr,
+                                                     int n_ranges, int* __restrict__ bounds) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= K * (n_ranges + 1)) return;
+  const int k = t / (n_ranges + 1), j = t % (n_ranges + 1);
+  long long lo = seg.off[k], hi = seg.off[k + 1];
+  const long long want = (long long)j * rr;
+  while (lo < hi) {
+    const long long mid = (lo + hi) >> 1;
+    const int v = sorted_rows[mid];
+    if (v >= 0 && v < want) lo = mid + 1; else hi = mid;
+  }
+  bounds[t] = (int)lo;
+}
+
+// rows per range of the RG mode: a power of two in [512, 4096] that gives ~2048 or more (range, offset) cells
+static int dw_range_rows(long long n_rows, int K) {
+  long long want = n_rows * K / 2048;
+  int rr = 512;
+  while (rr < 4096 && rr * 2 <= want) rr *= 2;
+  return rr;
+}
+static bool dw_rg_shape(int K, int ca, int cb, int prec, int planes, int sorted_side, long long n_rows) {
+  static const int on = [] { const char* e = getenv("GCL_DW_RANGES"); return e ? atoi(e) : 1; }();
+  return on && sorted_side != 0 && K > 1 && K <= 27 && !planes && prec != 0 && (ca == 32 || ca == 64) &&
+         (cb == 32 || cb == 64) && n_rows >= 32768;
+}
+
 // columns per wave (32 NB) of a forward launch: 128 when Cout allows, but 64 when the 128-wide launch would have
 // 513..1024 workgroups -- a second, poorly filled round on 256 CUs x 2 resident workgroups -- where twice as many
 // half-width workgroups (3 resident per CU) finish earlier (measured -7 % on the 128->128 / 256->256 layers of the
@@ -1669,14 +1739,27 @@ __global__ void __launch_bounds__(256) k_stem_fwd(const float* __restrict__ x, c
   float acc[32];
 #pragma unroll
   for (int c = 0; c < 32; ++c) acc[c] = 0.f;
-#pragma unroll 5
-  for (int k = 0; k < K; ++k) {
-    int idx = nbr[(long long)k * n_out + v];
-    for (int ci = 0; ci < cin; ++ci) {
-      float xv = idx >= 0 ? x[(long long)idx * cin + ci] : 0.f;
-      const float* wr = w + (long long)(k * cin + ci) * cout + blockIdx.y * 32;     // blockIdx.y = 32-column block
+  // offsets in batches of STEM_B: all table reads of a batch are issued first, then all feature gathers, then the FMAs --
+  // the walk is bound by the latency of these two dependent loads (one table entry per offset and row, 265 MB at K = 125
+  // and 0.5 M rows), so the number in flight per thread is what counts (was 5: 221 us; the accumulation order per output
+  // element is unchanged: k ascending, ci ascending)
+  constexpr int STEM_B = 25;
+  for (int k0 = 0; k0 < K; k0 += STEM_B) {
+    int idx[STEM_B];
 #pragma unroll
-      for (int c = 0; c < 32; ++c) acc[c] = fmaf(xv, wr[c], acc[c]);
+    for (int j = 0; j < STEM_B; ++j) idx[j] = (k0 + j < K) ? nbr[(long long)(k0 + j) * n_out + v] : -1;
+    for (int ci = 0; ci < cin; ++ci) {
+      float xv[STEM_B];
+#pragma unroll
+      for (int j = 0; j < STEM_B; ++j) xv[j] = idx[j] >= 0 ? x[(long long)idx[j] * cin + ci] : 0.f;
+#pragma unroll
+      for (int j = 0; j < STEM_B; ++j) {
+        if (k0 + j < K) {      // wave-uniform
+          const float* wr = w + (long long)((k0 + j) * cin + ci) * cout + blockIdx.y * 32;     // blockIdx.y = 32-column block
+#pragma unroll
+          for (int c = 0; c < 32; ++c) acc[c] = fmaf(xv[j], wr[c], acc[c]);
+        }
+      }
     }
   }
   if ((long long)blockIdx.x * blockDim.x + threadIdx.x >= n_out) return;
@@ -2178,12 +2261,18 @@ int gcl_conv_fwd_halo(const float* x, int64_t n_in, const void* wp, int32_t prec
   return GCL_OK;
 }
 
-int64_t gcl_conv_bwd_weight_scratch_len(int32_t K, int32_t ca, int32_t cb, int64_t n_pairs_padded) {
+int64_t gcl_conv_bwd_weight_scratch_len(int32_t K, int32_t ca, int32_t cb, int64_t n_pairs_padded, int64_t n_sorted_rows) {
   long long nc = n_pairs_padded / GCL_PAIR_CHUNK;
-  return (long long)(bwd_weight_wgs(nc) + K) * ca * cb;
+  long long len = (long long)(bwd_weight_wgs(nc) + K) * ca * cb;
+  if (n_sorted_rows > 0 && K > 1 && K <= 27) {      // range-grouped mode: one slab per (row range, offset) + the cell limits
+    const long long nr = cdiv(n_sorted_rows, dw_range_rows(n_sorted_rows, K));
+    const long long rg = nr * K * ca * cb + (long long)K * (nr + 1) + 64;
+    if (rg > len) len = rg;
+  }
+  return len;
 }
 
-int gcl_conv_bwd_weight(const float* a, int64_t n_a, const float* b, int64_t n_b, int32_t planes,
+int gcl_conv_bwd_weight(const float* a, int64_t n_a, const float* b, int64_t n_b, int32_t planes, int32_t sorted_side,
                         const int32_t* pair_a, const int32_t* pair_b, const int64_t* seg_off_host, int32_t K,
                         int32_t ca, int32_t cb, int32_t prec,
                         const int32_t* a_amax, const int32_t* b_amax, float* scratch, float* dw, void* stream) {
@@ -2220,6 +2309,35 @@ int gcl_conv_bwd_weight(const float* a, int64_t n_a, const float* b, int64_t n_b
   long long mat = (long long)ca * cb;
   int W = bwd_weight_wgs(nc);
   int per = (int)cdiv(nc > 0 ? nc : 1, W);
+  GCL_CHECK_ARG(sorted_side >= 0 && sorted_side <= 2, "gcl_conv_bwd_weight: sorted_side must be 0, 1 (pair_a) or 2 (pair_b)");
+  const long long n_sorted = sorted_side == 1 ? n_a : n_b;
+  if (nc > 0 && dw_rg_shape(K, ca, cb, prec, planes, sorted_side, n_sorted)) {
+    const int rr = dw_range_rows(n_sorted, K);
+    const int nr = (int)cdiv(n_sorted, rr);
+    int* bounds = (int*)(scratch + (long long)nr * K * mat);
+    hipLaunchKernelGGL(k_pair_bounds, dim3((unsigned)cdiv((long long)K * (nr + 1), 256)), dim3(256), 0, st,
+                       sorted_side == 1 ? pair_a : pair_b, seg, K, rr, nr, bounds);
+    dim3 rgrid((unsigned)(cdiv(nr, 8) * 8 * K));
+#define LAUNCH_RG(TA, TB, PLV)                                                                                      \
+  hipLaunchKernelGGL((k_conv_bwd_weight_split<TA, TB, PLV, false, true>), rgrid, dim3(256), 0, st, a, b, pair_a, pair_b, \
+                     seg, K, ca, cb, nc, per, scratch, a_amax, b_amax, 0, 0, a_bytes, b_bytes, (const int*)bounds, nr)
+#define LAUNCH_RG_P(TA, TB)                                            \
+  {                                                                    \
+    if (prec == 2) LAUNCH_RG(TA, TB, 2);                               \
+    else if (prec == 3) LAUNCH_RG(TA, TB, 3);                          \
+    else LAUNCH_RG(TA, TB, 4);                                         \
+  }
+    if (ca == 64 && cb == 64) LAUNCH_RG_P(64, 64)
+    else if (ca == 64) LAUNCH_RG_P(64, 32)
+    else if (cb == 64) LAUNCH_RG_P(32, 64)
+    else LAUNCH_RG_P(32, 32)
+#undef LAUNCH_RG_P
+#undef LAUNCH_RG
+    hipLaunchKernelGGL(k_bwd_weight_reduce_rg, dim3((unsigned)cdiv(mat, 256), K), dim3(256), 0, st, (const float*)scratch,
+                       nr, K, mat, dw);
+    GCL_CHECK_LAUNCH();
+    return GCL_OK;
+  }
   if (nc > 0) {
     int tca = (ca % 64 == 0) ? 64 : 32, tcb = (cb % 64 == 0) ? 64 : 32;
     dim3 grid(W, (ca / tca) * (cb / tcb));

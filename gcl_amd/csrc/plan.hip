@@ -539,6 +539,18 @@ static int plan_forward(Plan& P, const float* x_in, void* const* bn_stats, float
     PLAN_CALL(gcl_amax_multi((const float* const*)tab, (const int64_t*)(tab + nw), (int32_t)nw, P.w_amax, (void*)st));
     PLAN_CALL(gcl_pack_weights_multi((const int64_t*)(tab + 2 * nw), (int32_t)nw, P.wgs_fwd, 4, P.w_amax, P.pack_fwd, (void*)st));
   }
+  // with an aux stream the input-gradient packs (needed by the first record of the backward pass) are made there now,
+  // beside the forward convolutions, instead of at the head of the backward pass
+  if (P.aux && P.n_bwd) {
+    P.pack_bwd = (unsigned char*)A.take(P.bytes_bwd);
+    if (!A.dry) {
+      hipStream_t ws = fork_aux(P, st);
+      const long long* tab = (const long long*)P.state;
+      PLAN_CALL(gcl_pack_weights_multi((const int64_t*)(tab + 2 * nw + 8 * nw), P.n_bwd, P.wgs_bwd, 4, P.w_amax, P.pack_bwd,
+                                       (void*)ws));
+    }
+    P.bwd_packed = true;
+  }
   P.t[0].ptr = (float*)x_in;
   for (size_t i = 0; i < P.ops.size(); ++i) {
     const gcl_plan_op& op = P.ops[i];
@@ -697,12 +709,14 @@ static int conv_backward(Plan& P, int i, TState dy, void* const* grads, hipStrea
     const int32_t *pa = m.pair_in, *pb = m.pair_out;
     if (op.transpose) { pa = m.pair_out; pb = m.pair_in; }
     GCL_CHECK_ARG(A.dry || (pa && pb), "gcl_plan_backward: record %d needs pair lists the maps do not carry", i);
-    float* scratch = A.take_n<float>(gcl_conv_bwd_weight_scratch_len(op.K, op.cin, op.cout, m.seg_off[op.K]));
+    const int sorted_side = m.kernel_size == 1 ? 0 : (op.transpose ? 1 : 2);     // the map's out rows ascend per offset
+    const long long n_sorted = sorted_side == 1 ? n_in : (sorted_side == 2 ? n_out : 0);
+    float* scratch = A.take_n<float>(gcl_conv_bwd_weight_scratch_len(op.K, op.cin, op.cout, m.seg_off[op.K], n_sorted));
     const bool pl = pl_w;
     ProfScope ps(P, ws, 2, pairs, op.cin, op.cout, n_in, n_out, op.K);
     PLAN_CALL(gcl_conv_bwd_weight(pl ? (const float*)x.planes : x.ptr, n_in, pl ? (const float*)dy.planes : dy.ptr, n_out,
-                                  pl ? 1 : 0, pa, pb, m.seg_off, op.K, op.cin, op.cout, 4, P.saved[i].x_amax, dy.amax, scratch,
-                                  dW, (void*)ws));
+                                  pl ? 1 : 0, sorted_side, pa, pb, m.seg_off, op.K, op.cin, op.cout, 4, P.saved[i].x_amax, dy.amax,
+                                  scratch, dW, (void*)ws));
   }
   if (op.bias >= 0) {
     double* scratch = A.take_n<double>(gcl_bn_scratch_len(n_out, op.cout));
@@ -718,6 +732,10 @@ static int plan_backward(Plan& P, const float* dy, void* const* grads, int first
   if (last == (int)P.ops.size()) {
     P.g[P.ops.back().y] = TState();
     P.g[P.ops.back().y].ptr = (float*)dy;
+  }
+  if (P.bwd_packed && last == (int)P.ops.size()) {
+    int rcj = join_aux(P, st);      // packs made on the aux stream during the forward pass
+    if (rcj) return rcj;
   }
   if (!P.bwd_packed) {       // input-gradient packs of all kernels in one launch (WeightAmaxGroup.packed("bwd"))
     P.pack_bwd = (unsigned char*)A.take(P.bytes_bwd);

@@ -137,7 +137,8 @@ def legacy_choice(n, k):
     return out
 
 
-def draw_selections(n_groups, n_out, max_pos_cluster, max_hn_samples, group_sizes=None, pair_positive=False):
+def draw_selections(n_groups, n_out, max_pos_cluster, max_hn_samples, group_sizes=None, pair_positive=False,
+                    random_negative=False):
     """The three host-side ``np.random.choice`` draws of finest_contrastive_loss, in the reference's order
     (lib/colocation_trainer.py:457, :506-507): selected positive groups, then the two negative row subsets.
     ``np.random.choice(n, k, replace=False)`` permutes all n rows (~4 ms at n = 0.5 M): the trainer therefore draws at
@@ -152,6 +153,10 @@ def draw_selections(n_groups, n_out, max_pos_cluster, max_hn_samples, group_size
         pair_pos = np.stack([np.random.choice(int(sizes[i]), 2, replace=False) for i in pos_sel]).astype(np.int32)
     sel_hn1 = legacy_choice(n_out, min(n_out, max_hn_samples))
     sel_hn2 = legacy_choice(n_out, min(n_out, max_hn_samples))
+    if random_negative:       # use_hard_negative == False: one random column per row, drawn after the two subsets (:514)
+        with NP_RANDOM_LOCK:
+            cols = np.array([np.random.choice(len(sel_hn2), 1)[0] for _ in range(len(sel_hn1))], dtype=np.int64)
+        return pos_sel, sel_hn1, sel_hn2, pair_pos, cols
     return pos_sel, sel_hn1, sel_hn2, pair_pos
 
 
@@ -175,24 +180,27 @@ def finest_contrastive_loss(F_out, group, index, index_hash, finest_flag, max_po
     (defaults = scripts/train_gcl_kitti.sh:96-105).  ``finest_term=False`` gives ``location_contrastive_loss``
     (:734-809) when combined with ``square_loss=False``.
 
-    ``draws=(pos_sel, sel_hn1, sel_hn2[, pair_pos])`` replays recorded selections; otherwise they are drawn from
-    ``np.random`` in the reference's order.  ``use_hard_negative=False`` is rejected: the reference indexes the
-    distance matrix with an [M, 1] tensor there (:514-515), which broadcasts to an [M, M] average -- an accidental
-    semantics of a debug switch that no script sets.  ``index_hash``, ``points`` and ``batch_lengths`` are unused
-    (see module docstring).
+    ``draws=(pos_sel, sel_hn1, sel_hn2[, pair_pos[, random_cols]])`` replays recorded selections; otherwise they are
+    drawn from ``np.random`` in the reference's order.  ``use_hard_negative=False`` (a debug switch no script sets)
+    reproduces what the reference's code computes there: it indexes the distance matrix with an [M, 1] tensor
+    (:514-515), which BROADCASTS -- every row j is paired with every drawn column c_i, the masks (:521-529) broadcast
+    the same way, and the loss is the mean of relu(neg_thresh - D[j, c_i])^2 over the kept (i, j) cells
+    (``random_negative_term``; pinned by a golden captured from the reference).  ``index_hash``, ``points`` and
+    ``batch_lengths`` are unused (see module docstring).
     """
     dev = F_out.device
     n_out = F_out.shape[0]
     group = torch.as_tensor(group)
     n_groups = int(group.shape[0])
-    if not use_hard_negative:
-        raise NotImplementedError("use_hard_negative=False is not built (see the docstring)")
     if draws is None:
         draws = draw_selections(n_groups, n_out, max_pos_cluster, max_hn_samples,
                                 group.cpu().numpy() if use_pair_group_positive_loss else None,
-                                use_pair_group_positive_loss)
+                                use_pair_group_positive_loss, random_negative=not use_hard_negative)
     pos_sel, sel_hn1, sel_hn2 = draws[:3]
     pair_pos = draws[3] if len(draws) > 3 else None
+    rand_cols = draws[4] if len(draws) > 4 else None
+    if not use_hard_negative and rand_cols is None:
+        raise ValueError("use_hard_negative=False needs the drawn columns (draws[4])")
     if use_pair_group_positive_loss and pair_pos is None:
         raise ValueError("use_pair_group_positive_loss needs the drawn member positions (draws[3])")
     if len(pos_sel) == 0:
@@ -210,7 +218,34 @@ def finest_contrastive_loss(F_out, group, index, index_hash, finest_flag, max_po
     pos, fin, neg = _GCLLossFn.apply(F_out, index, goff, flag, sel_all[:n_pos], sel_all[n_pos:n_pos + n_hn],
                                      sel_all[n_pos + n_hn:], float(pos_thresh), float(finest_thresh), float(neg_thresh),
                                      flags, to_dev32(pair_pos) if use_pair_group_positive_loss else None)
+    if not use_hard_negative:
+        neg = random_negative_term(F_out, sel_all[n_pos:n_pos + n_hn], sel_all[n_pos + n_hn:], rand_cols, group, index,
+                                   index_hash, float(neg_thresh))
     return pos.sum() / len(pos_sel), fin.sum() / len(pos_sel), neg
+
+
+def random_negative_term(F_out, sel1, sel2, cols, group, index, index_hash, neg_thresh):
+    """The negative term with ``use_hard_negative == False`` exactly as the reference's code evaluates it
+    (lib/colocation_trainer.py:513-530): ``D_fs[torch.arange(M), D_fs_ind]`` with ``D_fs_ind`` of shape [M, 1]
+    broadcasts to ``out[i, j] = D_fs[j, c_i]``, and ``sel_hn2[D_fs_ind]`` / ``_neg_hash`` / ``np.isin`` broadcast
+    alike: the loss is the mean over ALL (i, j) of relu(neg_thresh - D_fs[j, c_i])^2 whose pair (sel1[j], sel2[c_i]) is
+    neither the same row nor inside one positive group.  Distances in the exact (a - b)^2 form of lib/metrics.py:22-29
+    (torch on the device, differentiable); the positive-pair keys are ``index_hash`` when the loader supplies it, else
+    ``_exhaustive_hash(group, index)`` (util/misc.py:29-36).  A debug path: [M, M, C] temporaries, no HIP kernel."""
+    from gcl_amd.util.misc import _exhaustive_hash
+    dev = F_out.device
+    n_out = F_out.shape[0]
+    cols_d = torch.as_tensor(np.asarray(cols, dtype=np.int64)).to(dev)
+    rows_j, rows_i = sel1, sel2[cols_d]                                          # sel1[j], sel2[c_i]
+    D = torch.sqrt(((F_out[rows_i].unsqueeze(1) - F_out[rows_j].unsqueeze(0)) ** 2).sum(2) + 1e-7)    # [i, j] = D_fs[j, c_i]
+    a, b = rows_j.unsqueeze(0), rows_i.unsqueeze(1)
+    keys = torch.minimum(a * n_out + b, a + b * n_out)                          # _neg_hash (util/misc.py:39-40)
+    if index_hash is None:
+        split = torch.split(torch.as_tensor(index).cpu(), tuple(int(g) for g in torch.as_tensor(group).tolist()))
+        index_hash = _exhaustive_hash(split, n_out)
+    pos_keys = torch.as_tensor(np.asarray(index_hash, dtype=np.int64)).to(dev)
+    keep = (a != b) & ~torch.isin(keys, pos_keys)
+    return torch.relu(neg_thresh - D[keep]).pow(2).mean()
 
 
 def location_contrastive_loss(F_out, group, index, index_hash, finest_flag, max_pos_cluster=256, max_hn_samples=2048,
@@ -330,8 +365,6 @@ class FinestContrastiveLossTrainer:
         self.config = config or make_config()
         cfg = self.config
         self.device = torch.device(device if device is not None else "cuda:0")
-        if not cfg.use_hard_negative:
-            raise NotImplementedError("use_hard_negative=False is not built (see finest_contrastive_loss)")
         if model is None:
             Model = load_model(cfg.model)
             model = Model(1, cfg.model_n_out, bn_momentum=cfg.bn_momentum, normalize_feature=cfg.normalize_feature,
@@ -448,7 +481,7 @@ class FinestContrastiveLossTrainer:
             sizes = torch.as_tensor(input_dict["group"]).cpu().numpy()
         return draw_selections(len(input_dict["group"]), len(input_dict["sinput_C"]),
                                cfg.num_pos_per_batch * cfg.batch_size, cfg.num_hn_samples_per_batch * cfg.batch_size,
-                               sizes, cfg.use_pair_group_positive_loss)
+                               sizes, cfg.use_pair_group_positive_loss, random_negative=not cfg.use_hard_negative)
 
     def _prefetch_maps(self, batch):
         """Loader-side work for a coming batch that is already on the device: its coordinate manager with every kernel

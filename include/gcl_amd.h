@@ -254,9 +254,14 @@ int gcl_conv_fwd_halo(const float* x, int64_t n_in, const void* wp, int32_t prec
  * on the fly for prec 2 / 3).
  * planes != 0 (prec 4 only): a AND b point at gcl_split_planes images (no split, hardware-transposed LDS reads).
  * A has n_a rows, B n_b rows (each tensor < 4 GiB: rows are gathered through buffer resources, padding pairs read 0).
- * scratch: float[gcl_conv_bwd_weight_scratch_len(...)]. */
-int64_t gcl_conv_bwd_weight_scratch_len(int32_t K, int32_t ca, int32_t cb, int64_t n_pairs_padded);
-int gcl_conv_bwd_weight(const float* a, int64_t n_a, const float* b, int64_t n_b, int32_t planes,
+ * sorted_side: 0 = nothing known about the pair order; 1 / 2 = pair_a / pair_b ascends inside every offset segment (the
+ *   out rows of gcl_kernel_map_pairs: pair_b for a forward convolution, pair_a for a transposed one).  With it, and Ca, Cb
+ *   in {32, 64}, 1 < K <= 27, no plane images and >= 32768 rows on that side, the launch is "range-grouped": a workgroup
+ *   takes the pairs of ONE offset whose sorted-side row lies in one row range, the K workgroups of a range share an XCD,
+ *   and the sorted side's rows are fetched from the fabric once per range instead of once per offset (same sums, other
+ *   fixed order).  scratch: float[gcl_conv_bwd_weight_scratch_len(K, ca, cb, n_pairs_padded, rows of the sorted side or 0)]. */
+int64_t gcl_conv_bwd_weight_scratch_len(int32_t K, int32_t ca, int32_t cb, int64_t n_pairs_padded, int64_t n_sorted_rows);
+int gcl_conv_bwd_weight(const float* a, int64_t n_a, const float* b, int64_t n_b, int32_t planes, int32_t sorted_side,
                         const int32_t* pair_a, const int32_t* pair_b, const int64_t* seg_off_host, int32_t K,
                         int32_t ca, int32_t cb, int32_t prec, const int32_t* a_amax, const int32_t* b_amax, float* scratch, float* dw,
                         void* stream);

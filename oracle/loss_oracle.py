@@ -78,9 +78,9 @@ def positional_hash(arr, M):
 def finest_contrastive_loss(F_out, group, index, index_hash, finest_flag, max_pos_cluster=256,
                             max_hn_samples=2048, pos_thresh=0.1, neg_thresh=1.4, finest_thresh=0.2,
                             draws=None, square_loss=True, block_finest_gradient=False,
-                            use_pair_group_positive_loss=False, finest_term=True):
-    """lib/colocation_trainer.py:430-535 with its config switches (:466-488; use_hard_negative is always True, see
-    tests/golden/make_golden.py); ``finest_term=False`` with ``square_loss=False`` is location_contrastive_loss
+                            use_pair_group_positive_loss=False, finest_term=True, use_hard_negative=True):
+    """lib/colocation_trainer.py:430-535 with its config switches (:466-488, and use_hard_negative == False as the
+    reference's code evaluates it: the [M, 1] index tensor of :514-515 broadcasts; draws[4] = the drawn columns); ``finest_term=False`` with ``square_loss=False`` is location_contrastive_loss
     (:734-809).  ``draws`` = (pos_sel, sel_hn1, sel_hn2[, pair_pos]) replays recorded RNG draws; when None they are
     drawn from ``np.random`` in the reference's order (:457, :467, :506-507)."""
     N_out = len(F_out)
@@ -127,8 +127,14 @@ def finest_contrastive_loss(F_out, group, index, index_hash, finest_flag, max_po
         sel_hn1 = np.random.choice(N_out, min(N_out, max_hn_samples), replace=False)
         sel_hn2 = np.random.choice(N_out, min(N_out, max_hn_samples), replace=False)
     D = pdist(F_out[sel_hn1], F_out[sel_hn2], "L2")                                                    # :510
-    Dmin, Dind = D.min(1)                                                                              # :512
-    Dind = Dind.numpy()
+    if use_hard_negative:
+        Dmin, Dind = D.min(1)                                                                          # :512
+        Dind = Dind.numpy()
+    else:                                                                                              # :514-515
+        cols = draws[4] if (draws is not None and len(draws) > 4) else \
+            np.array([np.random.choice(D.shape[1], 1)[0] for _ in range(D.shape[0])])
+        Dind = np.asarray(cols, dtype=np.int64).reshape(-1, 1)            # [M, 1]: everything below broadcasts to [M, M]
+        Dmin = D[torch.arange(D.shape[0]), torch.from_numpy(Dind)]
     closest = sel_hn2[Dind]
     mask_self = sel_hn1 != closest                                                                     # :521
     neg_keys = neg_hash(sel_hn1, closest, N_out)                                                       # :526

@@ -78,6 +78,9 @@ def main():
     global _TRAINER_AND_HASH
     _TRAINER_AND_HASH = (Trainer, _exhaustive_hash)
     torch.set_num_threads(4)
+    only = os.environ.get("GCL_GOLDEN_ONLY")       # e.g. rand_s7: (re)generate ONE finest_loss case, leave the rest alone
+    if only:
+        return _finest_cases(Trainer, _exhaustive_hash, only)
 
     # ---- pdist ---------------------------------------------------------------------------------
     g = torch.Generator().manual_seed(0)
@@ -111,6 +114,10 @@ def main():
                         exhaustive=_exhaustive_hash(split, M), i1=i1, i2=i2, neg=_neg_hash(i1, i2, M),
                         arr=arr, hash_arr=_hash(arr, 97), hash_list=_hash([arr[:, 0], arr[:, 1]], 97))
 
+    _finest_cases(Trainer, _exhaustive_hash, None)
+
+
+def _finest_cases(Trainer, _exhaustive_hash, only):
     # ---- finest_contrastive_loss ---------------------------------------------------------------
     cases = {
         "var_s0": dict(seed=0, N=4000, n_groups=200, sizes=[2, 3, 5, 7, 16, 35], max_pos=64, max_hn=512),
@@ -125,14 +132,16 @@ def main():
         "sqrt_s4": dict(base, seed=4, square_loss=False),
         "block_s5": dict(base, seed=5, block_finest_gradient=True),
         "pair_s6": dict(base, seed=6, use_pair_group_positive_loss=True),
-        # use_hard_negative=False is not captured: the reference indexes D_fs with an [M, 1] index tensor (:514-515),
-        # which broadcasts to an [M, M] average over (row, drawn column) pairs -- an accidental semantics of a debug
-        # switch no script sets; the build rejects it
+        # use_hard_negative=False: the reference indexes D_fs with an [M, 1] index tensor (:514-515), which broadcasts to
+        # an [M, M] average over (row, drawn column) pairs; captured as the code evaluates it
+        "rand_s7": dict(base, seed=7, use_hard_negative=False),
         "all_s8": dict(base, seed=8, square_loss=False, block_finest_gradient=True,
                        use_pair_group_positive_loss=True),
         "loc_s9": dict(base, seed=9, fn="location_contrastive_loss", square_loss=False),   # always the sqrt form
     })
     for name, c in cases.items():
+        if only and name != only:
+            continue
         rng = np.random.RandomState(c["seed"])
         gt = torch.Generator().manual_seed(c["seed"])
         N = c["N"]
@@ -174,6 +183,8 @@ def main():
             extra["pair_pos"] = np.stack([np.random.choice(int(group[i]), 2, replace=False) for i in pos_sel])
         sel1 = np.random.choice(N, min(N, c["max_hn"]), replace=False)
         sel2 = np.random.choice(N, min(N, c["max_hn"]), replace=False)
+        if not tr.use_hard_negative:
+            extra["random_cols"] = np.array([np.random.choice(len(sel2), 1)[0] for _ in range(len(sel1))])
         np.savez_compressed(os.path.join(HERE, f"finest_loss_{name}.npz"),
                             F_out=Fo.detach().numpy(), group=group, index=index, finest_flag=finest,
                             index_hash=index_hash, np_seed=c["seed"] + 100,
@@ -181,6 +192,7 @@ def main():
                             pos_sel=pos_sel, sel_hn1=sel1, sel_hn2=sel2,
                             square_loss=tr.square_loss, block_finest_gradient=tr.block_finest_gradient,
                             use_pair_group_positive_loss=tr.use_pair_group_positive_loss,
+                            use_hard_negative=tr.use_hard_negative,
                             finest_term=c.get("fn", "") != "location_contrastive_loss",
                             pos=pos.item(), finest=fin.item(), neg=neg.item(), grad=Fo.grad.numpy(), **extra)
         print(name, pos.item(), fin.item(), neg.item(), float(Fo.grad.abs().sum()))
@@ -336,6 +348,8 @@ def validation_golden(Trainer):
 
 if __name__ == "__main__":
     main()
+    if os.environ.get("GCL_GOLDEN_ONLY"):
+        sys.exit(0)
     hardest_golden()
     sc2pcr_golden()
     circle_golden(*_TRAINER_AND_HASH)

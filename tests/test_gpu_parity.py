@@ -243,6 +243,41 @@ def test_conv_ragged_row_counts(n, precision):
     assert rel_l2(conv.kernel.grad.cpu(), W.grad) < PREC_TOL[precision]
 
 
+@pytest.mark.parametrize("cin,cout,stride,transpose", [(32, 32, 1, False), (64, 64, 1, False), (32, 64, 1, False),
+                                                        (64, 32, 2, False), (64, 64, 2, True)])
+def test_weight_gradient_range_grouped_mode(cin, cout, stride, transpose):
+    """Levels with >= 32768 rows on the sorted side of the pair lists take the range-grouped weight-gradient launch
+    (one (row range, offset) cell per workgroup, the K cells of a range on one XCD; csrc/conv.hip RG mode): dW against
+    the fp64 oracle at the per-operator bound, bitwise reproducible, and equal to the k-major launch to rounding.  The
+    stride-2 forward case has too few out rows and stays on the k-major launch (same assertions)."""
+    import gcl_amd.MinkowskiEngine as ME
+    assert ME.ops.PRECISION == "fp16x3"
+    C = random_cloud(77, n=60000, extent=40, batch=1, sheet=False)
+    assert len(C) > 40000
+    mgr, omgr = make_mgr(C), O.CoordinateManager(C)
+    g = torch.Generator().manual_seed(cin + cout)
+    cls = ME.MinkowskiConvolutionTranspose if transpose else ME.MinkowskiConvolution
+    conv = cls(cin, cout, kernel_size=3, stride=stride, dimension=3).to(DEV)
+    t_in = stride if transpose else 1
+    n_in = mgr.num_rows(t_in)
+    x = torch.randn(n_in, cin, generator=g, dtype=torch.float64)
+    W = conv.kernel.detach().cpu().double().requires_grad_(True)
+    km = omgr.get_kernel_map(1, 3, stride)
+    n_out = len(C) if transpose else len(omgr.get_coords(stride))
+    yo = O.sparse_conv(x.float().double(), W, km, n_out, transpose=transpose)
+    gy = torch.randn(yo.shape, generator=g, dtype=torch.float64)
+    yo.backward(gy)
+    grads = []
+    for _ in range(2):
+        conv.kernel.grad = None
+        xs = x.float().to(DEV)
+        y = conv(ME.SparseTensor(xs, coordinate_map_key=ME.CoordinateMapKey(t_in), coordinate_manager=mgr)).F
+        y.backward(gy.float().to(DEV))
+        grads.append(conv.kernel.grad.clone())
+    assert torch.equal(grads[0], grads[1]), "deterministic"
+    assert rel_l2(grads[0].cpu(), W.grad) < 2e-6
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # batch norm (+ residual, + relu)
 # ---------------------------------------------------------------------------------------------------------------
@@ -356,8 +391,10 @@ def test_resunet_forward_backward_vs_oracle(kind, precision):
 def _loss_case(z):
     """(draws, switches) recorded in a finest_loss_*.npz fixture (tests/golden/make_golden.py)."""
     sw = {k: bool(z[k]) for k in ("square_loss", "block_finest_gradient", "use_pair_group_positive_loss",
-                                  "finest_term") if k in z.files}
+                                  "finest_term", "use_hard_negative") if k in z.files}
     draws = (z["pos_sel"], z["sel_hn1"], z["sel_hn2"], z["pair_pos"] if "pair_pos" in z.files else None)
+    if "random_cols" in z.files:          # use_hard_negative == False: the drawn columns (:514)
+        draws = draws + (z["random_cols"],)
     return draws, sw
 
 

@@ -48,8 +48,10 @@ def test_hash_golden():
 def _loss_case(z):
     """(draws, switches) recorded in a finest_loss_*.npz fixture (tests/golden/make_golden.py)."""
     sw = {k: bool(z[k]) for k in ("square_loss", "block_finest_gradient", "use_pair_group_positive_loss",
-                                  "finest_term") if k in z.files}
+                                  "finest_term", "use_hard_negative") if k in z.files}
     draws = (z["pos_sel"], z["sel_hn1"], z["sel_hn2"], z["pair_pos"] if "pair_pos" in z.files else None)
+    if "random_cols" in z.files:          # use_hard_negative == False: the drawn columns (:514)
+        draws = draws + (z["random_cols"],)
     return draws, sw
 
 
