@@ -613,7 +613,11 @@ __global__ void __launch_bounds__(256, GCL_FWD_MIN_WAVES(NB, PL)) k_conv_fwd_spl
     __syncthreads();
     int buf = 0;
     bool mine_cur = mine0;
+#ifdef GCL_STAMPS
+    unsigned long long st_c = 0, st_w = 0, st_i = 0, st_b = 0, st_n = 0, st_m = 0;
+#endif
     while (true) {
+      STAMP(ts0)
       // ---- compute the current step from Asm[w] (own tile) and Bsm[buf]
       if (mine_cur) {
         WAVE_FENCE();
@@ -639,10 +643,12 @@ __global__ void __launch_bounds__(256, GCL_FWD_MIN_WAVES(NB, PL)) k_conv_fwd_spl
           }
         }
       }
+      STAMP(ts1)
       if (!has1) break;   // no step staged in registers: done
       // ---- next step: registers -> LDS (A: own tile, after this wave's reads; B: the buffer nobody reads)
       WAVE_FENCE();
       GCL_STORE_LDS(mine1, buf ^ 1);
+      STAMP(ts2)
       // ---- the step after: issue its loads (in flight across the barrier and the next compute phase)
       int k2 = k1, c2 = c1;
       bool has2 = true, mine2 = false;
@@ -652,7 +658,14 @@ __global__ void __launch_bounds__(256, GCL_FWD_MIN_WAVES(NB, PL)) k_conv_fwd_spl
         if (mine2) GCL_GATHER_A(k2, c2);
         GCL_LOAD_B(k2, c2);
       }
+      STAMP(ts3)
       __syncthreads();   // publishes the weight block just written; its buffer was last read two steps ago
+#ifdef GCL_STAMPS
+      {
+        STAMP(ts4)
+        st_c += ts1 - ts0; st_w += ts2 - ts1; st_i += ts3 - ts2; st_b += ts4 - ts3; st_n += 1; st_m += mine_cur ? 1 : 0;
+      }
+#endif
       buf ^= 1;
       mine_cur = mine1;
       mine1 = mine2;
@@ -660,6 +673,12 @@ __global__ void __launch_bounds__(256, GCL_FWD_MIN_WAVES(NB, PL)) k_conv_fwd_spl
       c1 = c2;
       has1 = has2;
     }
+#ifdef GCL_STAMPS
+    if (l == 0) {      // [0] MFMA phase  [1] wait for the gather + LDS writes  [2] load issue  [3] barrier  [6] steps  [7] own steps
+      atomicAdd(&g_stamps[0], st_c); atomicAdd(&g_stamps[1], st_w); atomicAdd(&g_stamps[2], st_i);
+      atomicAdd(&g_stamps[3], st_b); atomicAdd(&g_stamps[6], st_n); atomicAdd(&g_stamps[7], st_m);
+    }
+#endif
   }
 #undef GCL_GATHER_A
 #undef GCL_LOAD_B

@@ -15,7 +15,7 @@ CSRC = os.path.join(ROOT, "gcl_amd", "csrc")
 LIB = os.path.join("/tmp", "libgcl_hip_stamps.so")
 os.makedirs(os.path.dirname(LIB), exist_ok=True)
 subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DGCL_STAMPS", "-o", LIB] +
-               [os.path.join(CSRC, f) for f in ("coords.hip", "conv.hip", "norm.hip", "loss.hip", "data.hip", "sc2pcr.hip")], check=True)
+               [os.path.join(CSRC, f) for f in ("coords.hip", "conv.hip", "norm.hip", "loss.hip", "data.hip", "sc2pcr.hip", "plan.hip")], check=True)
 os.environ["GCL_LIB_PATH"] = LIB
 
 import torch  # noqa: E402
@@ -29,7 +29,7 @@ batch = synthetic.make_train_batch(100, batch_size=4, group_mode="fixed16")
 dev = "cuda:0"
 C = batch["sinput_C"].to(dev)
 mgr = ME.CoordinateManager(C)
-names = ["wait_barrier1", "lds_write+issue", "wait_barrier2", "read+split+mfma", "prologue", "-", "wave_steps", "mine_steps"]
+names = ["lds_read+mfma", "gather_wait+lds_write", "load_issue", "barrier", "prologue", "-", "wave_steps", "mine_steps"]
 for (t, cin, cout, stride, tr) in [(1, 32, 32, 1, False), (1, 64, 64, 1, False), (2, 64, 64, 1, False),
                                    (4, 128, 128, 1, False), (8, 256, 256, 1, False), (4, 128, 256, 2, False),
                                    (8, 256, 128, 2, True)]:
@@ -54,4 +54,4 @@ for (t, cin, cout, stride, tr) in [(1, 32, 32, 1, False), (1, 64, 64, 1, False),
     steps = max(v[6], 1)
     print(f"t={t} {cin}->{cout} s{stride}{' tr' if tr else ''} n={n}: {e0.elapsed_time(e1) / 5 * 1e3:.0f} us/launch (stamped build) | "
           + " ".join(f"{names[q]}={v[q] / tot * 100:.0f}%({v[q] / steps:.0f}cyc/step)" for q in range(4))
-          + f" | mine {v[7] / steps * 100:.0f}% of {steps / 5:.0f} wave-steps/launch, prologue {v[4] / steps:.0f} cyc/step-equiv")
+          + f" | mine {v[7] / steps * 100:.0f}% of {steps / 5:.0f} wave-steps/launch")
