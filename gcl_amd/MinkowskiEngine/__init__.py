@@ -193,6 +193,23 @@ def conv_bn(conv, norm, x, residual=None, relu=False):
     """``norm(conv(x))`` with the fused residual add / ReLU of MinkowskiBatchNorm.forward.  In inference (module in eval
     mode, autograd off, BatchNorm, default arithmetic) convolution + BatchNorm + residual + ReLU are ONE launch
     (gcl_conv_fwd_fused); otherwise the two modules run one after the other."""
+    trace = ops._EVAL_TRACE
+    if trace is not None and not torch.is_grad_enabled():
+        # inference trace (ops._EVAL_TRACE): run the layer as usual with the trace suspended, then record it as ONE entry
+        if not isinstance(norm, MinkowskiBatchNorm) or conv.training or norm.training or conv.bias is not None:
+            raise ValueError("the inference plan covers bias-free convolutions followed by a BatchNorm in eval mode")
+        ops._EVAL_TRACE = None
+        try:
+            out = conv_bn(conv, norm, x, residual, relu)
+        finally:
+            ops._EVAL_TRACE = trace
+        _, _, kmap, _ = conv._maps(x)
+        c2 = ops._SubCtx()
+        c2.relu = bool(relu)
+        c2.bn_extra = (norm.bn.running_mean, norm.bn.running_var, norm.bn.momentum, norm.bn.eps, norm)
+        trace.add("convbn", out.F, ops._TraceCtx(kmap, conv.TRANSPOSE, conv.kernel), c2, x.F,
+                  residual.F if residual is not None else None, (conv.kernel, norm.bn.weight, norm.bn.bias))
+        return out
     fused = (not conv.training and not norm.training and not torch.is_grad_enabled()
              and isinstance(norm, MinkowskiBatchNorm) and conv.bias is None and conv.in_channels > 4
              and ops.PRECISION == "fp16x3")

@@ -157,6 +157,7 @@ class NetworkPlan:
         self.last_profile = None
         self._anchor = None
         self._aux = None
+        self._eval_key = None
 
     def __del__(self):
         h, self.handle = getattr(self, "handle", None), None
@@ -296,8 +297,7 @@ class NetworkPlan:
         if need < 0:
             raise RuntimeError("gcl_plan_arena_bytes: " + lib.gcl_last_error().decode())
         arena = torch.empty(int(need), dtype=torch.uint8, device=dev)
-        if self._state is None or self._state.device != dev:
-            self._state = torch.empty(int(lib.gcl_plan_state_bytes(self.handle)), dtype=torch.uint8, device=dev)
+        self._ensure_state(lib, dev)
         pp, bp = self._pointers()
         if AUX_STREAM and self._aux is None:
             # weight gradients run on a second (lower-priority) stream beside the input-gradient chain
@@ -330,6 +330,49 @@ class NetworkPlan:
                 self._anchor = torch.zeros(1, device=dev, requires_grad=True)
             return _PlanFn.apply(run, self._anchor)
         return _PlanFn.apply(run, *self.params)
+
+    def _ensure_state(self, lib, dev):
+        if self._state is None or self._state.device != dev:     # tables + (inference) the persistent packed kernels
+            self._state = torch.empty(int(lib.gcl_plan_eval_state_bytes(self.handle)), dtype=torch.uint8, device=dev)
+            self._eval_key = None
+
+    def run_eval(self, x_feats, maps):
+        """Inference pass (model.eval(), torch.no_grad()): ONE gcl_plan_forward_eval call; every conv + BatchNorm
+        (+ residual)(+ ReLU) of the network is one fused launch.  Bitwise equal to the per-operator eval path."""
+        from . import ops
+        lib = _lib.require_gpu()
+        if maps.keys != self.spec_keys:
+            raise ValueError("the maps were built for a different map specification than the plan")
+        x = x_feats.contiguous()
+        dev = x.device
+        need = lib.gcl_plan_eval_arena_bytes(self.handle, ctypes.byref(maps.desc))
+        if need < 0:
+            raise RuntimeError("gcl_plan_eval_arena_bytes: " + lib.gcl_last_error().decode())
+        arena = torch.empty(int(need), dtype=torch.uint8, device=dev)
+        self._ensure_state(lib, dev)
+        pp, _ = self._pointers()
+        # BatchNorm in eval mode: (scale, shift) cached by the modules, (mean, rstd) for the un-fused first layer
+        aff, ptrs = [], []
+        for m in self.bn_modules:
+            scale, shift = m.eval_affine()
+            rstd = getattr(m, "_eval_rstd", None)
+            if rstd is None or rstd[0] is not scale:
+                with torch.no_grad():
+                    rstd = m._eval_rstd = (scale, torch.rsqrt(m.bn.running_var.detach() + m.bn.eps).contiguous())
+            aff.append((scale, shift, rstd[1]))
+            ptrs += [scale.data_ptr(), shift.data_ptr(), m.bn.running_mean.data_ptr(), rstd[1].data_ptr()]
+        bn = (ctypes.c_void_p * len(ptrs))(*ptrs)
+        # the packed kernels persist in the state buffer: re-pack when a parameter (or the amax epoch) changed
+        key = (tuple(p._version for p in self.params), tuple(p.data_ptr() for p in self.params), ops._AMAX_EPOCH)
+        repack = int(key != self._eval_key)
+        y_ptr = ctypes.c_void_p()
+        _lib.check(lib.gcl_plan_forward_eval(self.handle, ctypes.byref(maps.desc), _lib.ptr(x, torch.float32), pp, bn, repack,
+                                             _lib.ptr(self._state), _lib.ptr(arena), arena.numel(), ctypes.byref(y_ptr),
+                                             _lib.stream()), "gcl_plan_forward_eval")
+        self._eval_key = key
+        n_out = int(maps.desc.n_rows[self.records[-1]["level_out"]])
+        off = y_ptr.value - arena.data_ptr()
+        return arena[off:off + n_out * self.out_channels * 4].view(torch.float32).view(n_out, self.out_channels)
 
     def _segments(self):
         """[(first_op, last_op, [buckets complete after it])], highest records first.  A bucket is complete once the

@@ -423,9 +423,30 @@ def _col_sum(lib, dy):
     return out
 
 
+class _TraceCtx:
+    """What NetworkPlan.from_tape reads of a convolution entry (a stand-in for the autograd ctx of the training Tape)."""
+
+    def __init__(self, kmap, transpose, W):
+        Wk = W if W.dim() == 3 else W.unsqueeze(0)
+        K, cin, cout = Wk.shape
+        self.kmap, self.transpose = kmap, bool(transpose)
+        self.stem = cin <= 4 and cout % 32 == 0 and not transpose and kmap is not None
+        self.generic = (not self.stem) and (cin % 32 != 0 or cout % 32 != 0 or K > 27)
+
+
+# Inference trace: the layer calls of ONE eval-mode forward pass (model.eval(), torch.no_grad()) recorded in the Tape's
+# entry format, so that NetworkPlan.from_tape can turn them into the operator records of gcl_plan_forward_eval.  Nothing
+# is replayed from it (there is no backward pass); ME.conv_bn adds the "convbn" entries itself.
+_EVAL_TRACE = None
+
+
 def sparse_conv(x, W, kmap, n_out, transpose, bias, mgr, want_stats=False):
     """Returns (y, stats): ``stats`` = per-tile column sums for a following BatchNorm (None unless requested and
     available in the current precision)."""
+    if _EVAL_TRACE is not None and not torch.is_grad_enabled():
+        y, stats = _SparseConvFn.apply(x, W, bias, kmap, n_out, transpose, mgr, want_stats)
+        _EVAL_TRACE.add("conv", y, _TraceCtx(kmap, transpose, W), x, (W, bias))
+        return y, (stats if stats.numel() else None)
     if _TAPE is not None:
         with torch.no_grad():
             c1 = _SubCtx()
@@ -717,6 +738,8 @@ def conv_bn_train(x, W, kmap, n_out, transpose, mgr, bn_w, bn_b, running_mean, r
 
 def relu(x):
     """ReLU of a feature matrix (tape-aware; MEF.relu)."""
+    if _EVAL_TRACE is not None and id(x) in _EVAL_TRACE.made:
+        return _EVAL_TRACE.add("relu", torch.relu(x), x, ())
     if _TAPE is not None and id(x) in _TAPE.made:
         with torch.no_grad():
             y = torch.relu(x)
@@ -726,6 +749,8 @@ def relu(x):
 
 def cat_features(tensors):
     """Channel concatenation of feature matrices (tape-aware; ME.cat)."""
+    if _EVAL_TRACE is not None and any(id(t) in _EVAL_TRACE.made for t in tensors):
+        return _EVAL_TRACE.add("cat", torch.cat(tensors, dim=1), tuple(tensors), ())
     if _TAPE is not None and any(id(t) in _TAPE.made for t in tensors):
         with torch.no_grad():
             y = torch.cat(tensors, dim=1)
@@ -768,6 +793,8 @@ def l2_normalize_rows(x):
     """``x / torch.norm(x, p=2, dim=1, keepdim=True)``; widths the kernel does not cover use that expression."""
     c = x.shape[1]
     if x.dim() == 2 and x.shape[0] > 0 and 4 <= c <= 256 and (c & (c - 1)) == 0 and x.dtype == torch.float32:
+        if _EVAL_TRACE is not None and id(x) in _EVAL_TRACE.made:
+            return _EVAL_TRACE.add("rownorm", _RowNormalizeFn.apply(x), None, x, ())
         if _TAPE is not None and id(x) in _TAPE.made:
             with torch.no_grad():
                 cx = _SubCtx()

@@ -110,6 +110,9 @@ SIGNATURES = {
     "gcl_plan_state_bytes": (_i64, [_vp]),
     "gcl_plan_arena_bytes": (_i64, [_vp, _vp]),
     "gcl_plan_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "gcl_plan_eval_state_bytes": (_i64, [_vp]),
+    "gcl_plan_eval_arena_bytes": (_i64, [_vp, _vp]),
+    "gcl_plan_forward_eval": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _vp, _vp]),
     "gcl_plan_backward": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "gcl_plan_release": (_i32, [_vp, _vp]),
     "gcl_plan_set_aux_stream": (_i32, [_vp, _vp]),

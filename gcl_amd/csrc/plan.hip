@@ -352,6 +352,10 @@ struct Plan : PassState {   // the base part is the pass being enqueued right no
   std::vector<char> made;           // tensor id -> produced by a record of the plan
   // device tables (inside the caller's `state` buffer), re-uploaded when a parameter pointer changes
   std::vector<long long> host_tables, uploaded;
+  // inference passes (gcl_plan_forward_eval): BatchNorm in eval mode folded into the convolution epilogue
+  bool eval = false;
+  void* const* bn_eval = nullptr;   // per BatchNorm: scale, shift, mean, rstd (device pointers)
+  bool eval_repack = true;
   // optional second stream for the weight gradients (off the critical path of the backward pass)
   hipStream_t aux = nullptr;
   std::vector<hipEvent_t> events;
@@ -529,19 +533,27 @@ static int plan_forward(Plan& P, const float* x_in, void* const* bn_stats, float
   P.slot_pool = A.take_n<int32_t>(P.n_slots * GCL_AMAX_WORDS);
   if (!A.dry) GCL_CHECK_HIP(hipMemsetAsync(P.slot_pool, 0, (size_t)P.n_slots * GCL_AMAX_WORDS * sizeof(int32_t), st));
   // all convolution kernels: max|W| in one launch, forward packs in one launch (WeightAmaxGroup)
-  P.w_amax = A.take_n<int32_t>((long long)nw * GCL_AMAX_WORDS);
-  P.pack_fwd = (unsigned char*)A.take(P.bytes_fwd);
+  if (P.eval) {      // inference: max|W| and the packed kernels persist in the caller's state buffer from pass to pass
+    char* base = (char*)P.state + ((state_words(P) * 8 + 255) & ~255ll);
+    P.w_amax = (int32_t*)base;
+    P.pack_fwd = (unsigned char*)(base + (((long long)nw * GCL_AMAX_WORDS * 4 + 255) & ~255ll));
+  } else {
+    P.w_amax = A.take_n<int32_t>((long long)nw * GCL_AMAX_WORDS);
+    P.pack_fwd = (unsigned char*)A.take(P.bytes_fwd);
+  }
   P.bwd_packed = false;
   if (nw && !A.dry) {
     int rc = upload_tables(P, st);
     if (rc) return rc;
-    const long long* tab = (const long long*)P.state;
-    PLAN_CALL(gcl_amax_multi((const float* const*)tab, (const int64_t*)(tab + nw), (int32_t)nw, P.w_amax, (void*)st));
-    PLAN_CALL(gcl_pack_weights_multi((const int64_t*)(tab + 2 * nw), (int32_t)nw, P.wgs_fwd, 4, P.w_amax, P.pack_fwd, (void*)st));
+    if (!P.eval || P.eval_repack) {
+      const long long* tab = (const long long*)P.state;
+      PLAN_CALL(gcl_amax_multi((const float* const*)tab, (const int64_t*)(tab + nw), (int32_t)nw, P.w_amax, (void*)st));
+      PLAN_CALL(gcl_pack_weights_multi((const int64_t*)(tab + 2 * nw), (int32_t)nw, P.wgs_fwd, 4, P.w_amax, P.pack_fwd, (void*)st));
+    }
   }
   // with an aux stream the input-gradient packs (needed by the first record of the backward pass) are made there now,
   // beside the forward convolutions, instead of at the head of the backward pass
-  if (P.aux && P.n_bwd) {
+  if (!P.eval && P.aux && P.n_bwd) {
     P.pack_bwd = (unsigned char*)A.take(P.bytes_bwd);
     if (!A.dry) {
       hipStream_t ws = fork_aux(P, st);
@@ -559,6 +571,39 @@ static int plan_forward(Plan& P, const float* x_in, void* const* bn_stats, float
     int rc;
     switch (op.kind) {
       case GCL_OP_CONVBN: {
+        if (P.eval) {      // ME.conv_bn in inference (ops.conv_bn_eval): conv + BatchNorm(running stats) + residual + ReLU, one launch
+          const gcl_map_desc& m = M.maps[op.map];
+          const long long n_in = M.n_rows[op.level_in];
+          TState& x = P.t[op.x];
+          const int c = op.cout;
+          const float* res = op.x2 >= 0 ? P.t[op.x2].ptr : nullptr;
+          y.ptr = A.take_n<float>(n_out * c);
+          y.amax = new_slot(P);
+          void* const* be = P.bn_eval ? P.bn_eval + 4 * op.bn : nullptr;
+          if (is_stem(op, m)) {      // the Cin <= 4 first layer: VALU convolution, then the BatchNorm apply pass
+            float* cy = A.take_n<float>(n_out * c);
+            unsigned long long* mask = op.relu ? A.take_n<unsigned long long>(gcl_bn_mask_len(n_out, c)) : nullptr;
+            PLAN_CALL(gcl_stem_fwd(x.ptr, (const float*)P.params[op.w], m.nbr, n_out, op.K, op.cin, c, cy, (void*)st));
+            PLAN_CALL(gcl_bn_apply(cy, n_out, c, (const float*)be[2], (const float*)be[3], (const float*)P.params[op.bn_w],
+                                   (const float*)P.params[op.bn_b], res, op.relu, y.ptr, (uint64_t*)mask, y.amax, (void*)st));
+            break;
+          }
+          const int wi = P.widx[op.w];
+          if ((rc = ensure_amax(P, x, n_in * op.cin, st))) return rc;
+          const int32_t *tbl = nullptr, *order = nullptr, *mask = nullptr;
+          if (m.kernel_size > 1) {
+            tbl = op.transpose ? m.tbl_t : m.tbl_n;
+            order = op.transpose ? m.order_t : m.order_n;
+            mask = op.transpose ? m.mask_t : m.mask_n;
+            GCL_CHECK_ARG(A.dry || tbl, "gcl_plan_forward_eval: record %d needs a sorted table the maps do not carry", (int)i);
+          }
+          ProfScope ps(P, st, 0, (double)(m.kernel_size > 1 ? m.n_pairs : n_out), op.cin, c, n_in, n_out, op.K);
+          PLAN_CALL(gcl_conv_fwd_fused(x.ptr, n_in, 0, P.pack_fwd + P.off_fwd[wi], 4, x.amax,
+                                       P.w_amax + (long long)wi * GCL_AMAX_WORDS, tbl, order, mask, n_out, op.K, op.cin, c,
+                                       (const float*)be[1], (const float*)be[0], res, op.relu, y.amax, y.ptr, nullptr, 0,
+                                       (void*)st));
+          break;
+        }
         float *cy, *stats;
         if ((rc = conv_forward(P, (int)i, &cy, &stats, st))) return rc;
         OpSaved& sv = P.saved[i];
@@ -1036,6 +1081,75 @@ int gcl_plan_forward(void* plan, const gcl_maps_desc* maps_host, const float* x,
   slot->maps = &slot->maps_copy;
   static_cast<PassState&>(*P) = PassState();
   return GCL_OK;
+}
+
+int64_t gcl_plan_eval_state_bytes(const void* plan) {
+  if (!plan) return -1;
+  const Plan& P = *(const Plan*)plan;
+  return ((state_words(P) * 8 + 255) & ~255ll) + (((long long)P.worder.size() * GCL_AMAX_WORDS * 4 + 255) & ~255ll) +
+         P.bytes_fwd + 256;
+}
+
+int64_t gcl_plan_eval_arena_bytes(void* plan, const gcl_maps_desc* maps_host) {
+  Plan* P = (Plan*)plan;
+  if (!P || check_maps(*P, maps_host) != GCL_OK) return -1;
+  P->maps = maps_host;
+  P->A = Arena{DRY_BASE, 0, 0, true};
+  P->params.assign(P->n_params, nullptr);
+  P->eval = true;
+  P->bn_eval = nullptr;
+  P->state = DRY_BASE;
+  std::vector<void*> nulls(2 * (P->n_bn > 0 ? P->n_bn : 1), nullptr);
+  float* y = nullptr;
+  const bool prof = P->profile;
+  P->profile = false;
+  int rc = plan_forward(*P, nullptr, nulls.data(), &y, nullptr);
+  P->profile = prof;
+  P->eval = false;
+  P->forward_done = false;
+  return rc == GCL_OK ? P->A.off + 4096 : -1;
+}
+
+int gcl_plan_forward_eval(void* plan, const gcl_maps_desc* maps_host, const float* x, void* const* params_host,
+                          void* const* bn_eval_host, int32_t repack, void* state, void* arena, int64_t arena_bytes,
+                          float** y_out_host, void* stream) {
+  Plan* P = (Plan*)plan;
+  GCL_CHECK_ARG(P && maps_host && x && params_host && bn_eval_host && state && arena && y_out_host,
+                "gcl_plan_forward_eval: null pointer");
+  int rc = check_maps(*P, maps_host);
+  if (rc) return rc;
+  P->maps_copy = *maps_host;
+  P->maps = &P->maps_copy;
+  P->params.assign(params_host, params_host + P->n_params);
+  P->state = state;
+  P->eval = true;
+  P->bn_eval = bn_eval_host;
+  P->eval_repack = repack != 0;
+  std::vector<void*> nulls(2 * (P->n_bn > 0 ? P->n_bn : 1), nullptr);
+  P->A = Arena{DRY_BASE, 0, 0, true};      // size check first
+  float* yy = nullptr;
+  const bool prof = P->profile;
+  P->profile = false;
+  rc = plan_forward(*P, x, nulls.data(), &yy, nullptr);
+  P->profile = prof;
+  const long long need = P->A.off;
+  if (rc == GCL_OK && need > arena_bytes) {
+    set_error("gcl_plan_forward_eval: arena too small (%lld bytes needed, %lld given)", need, (long long)arena_bytes);
+    rc = GCL_ERR_ARENA;
+  }
+  if (rc == GCL_OK) {
+    P->A = Arena{(char*)arena, arena_bytes, 0, false};
+    rc = plan_forward(*P, x, nulls.data(), y_out_host, (hipStream_t)stream);
+  }
+  if (rc == GCL_OK && P->slots_exhausted) {
+    set_error("gcl_plan_forward_eval: amax slot pool exhausted");
+    rc = GCL_ERR_ARG;
+  }
+  P->eval = false;
+  P->bn_eval = nullptr;
+  P->forward_done = false;
+  static_cast<PassState&>(*P) = PassState();      // nothing waits for a backward pass
+  return rc;
 }
 
 int gcl_plan_release(void* plan, void* arena) {

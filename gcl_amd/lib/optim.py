@@ -57,4 +57,14 @@ class FusedSGD(torch.optim.SGD):
             _lib.check(lib.gcl_sgd_multi(_lib.ptr(table), _lib.ptr(sizes), len(ps), float(group["lr"]),
                                          float(group["momentum"]), float(group["weight_decay"]), int(first),
                                          _lib.stream()), "gcl_sgd_multi")
+            # the kernel wrote the parameters through raw pointers: bump their version counters like an in-place torch
+            # op would, so that everything keyed on ``p._version`` (packed kernels / max|W| of the eval path, the
+            # BatchNorm eval affine cache) sees the update
+            bump = getattr(torch.autograd.graph, "increment_version", None)
+            if bump is not None:
+                for p in ps:
+                    bump(p)
+            else:
+                from gcl_amd.MinkowskiEngine import ops
+                ops.invalidate_amax()
         return None

@@ -75,14 +75,15 @@ class ResUNet2(ME.MinkowskiNetwork):
             t *= 2
         return specs
 
-    def native_map_specs(self):
+    def native_map_specs(self, training=True):
         """``map_specs`` + the identity pair list of the two kernel_size-1 heads: what CoordinateManager.build_native
-        builds in one call, in the order the whole-network plan indexes it."""
+        builds in one call, in the order the whole-network plan indexes it.  ``training=False``: the same maps and
+        tables without the weight gradient's pair lists (inference)."""
         merged = {}
         for t_in, ks, stride, tables, pairs in self.map_specs() + [(1, 1, 1, (), True)]:
             key = (t_in, ks, stride)          # conv1 with kernel 3 shares its map with block1
             old = merged.get(key, ((), False))
-            merged[key] = (tuple(sorted(set(old[0]) | set(bool(t) for t in tables))), old[1] or bool(pairs))
+            merged[key] = (tuple(sorted(set(old[0]) | set(bool(t) for t in tables))), (old[1] or bool(pairs)) and training)
         return [k + v for k, v in merged.items()]
 
     _plan = None          # native.NetworkPlan once recorded; False when the graph is outside what the plan covers
@@ -112,8 +113,49 @@ class ResUNet2(ME.MinkowskiNetwork):
             return None
         return plan
 
+    def _forward_eval(self, x):
+        """Inference through the native plan (ONE gcl_maps_build + ONE gcl_plan_forward_eval call per pass), or None when
+        the pass has to take the per-operator path: BatchNorm models in eval mode under torch.no_grad(), default
+        arithmetic, a stride-1 input whose coordinate manager is native or still empty (then it is rebuilt natively).
+        The first such pass is traced (ops._EVAL_TRACE) to derive the plan unless a training step already recorded one."""
+        from gcl_amd.MinkowskiEngine import native
+        ops = ME.ops
+        if (self.training or torch.is_grad_enabled() or not native.PLAN_ENABLED or ops.PRECISION != "fp16x3"
+                or self.NORM_TYPE != "BN" or self.BLOCK_NORM_TYPE != "BN" or x.coordinate_map_key.tensor_stride != 1
+                or self.__dict__.get("_plan") is False or any(m.training for m in self.modules())
+                or ME.core.HALO or ME.core.SORT_WINDOW or ME.core.SPATIAL_MAX_STRIDE):
+            return None
+        mgr = x.coordinate_manager
+        if mgr.native is None:
+            if mgr._kmaps or len(mgr._maps) > 1:      # maps already built from Python: keep using them
+                return None
+            mgr = ME.CoordinateManager.build_native(mgr.get_coords(1), self.native_map_specs(training=False))
+            x = ME.SparseTensor(x.F, coordinate_map_key=x.coordinate_map_key, coordinate_manager=mgr)
+        plan = self.__dict__.get("_plan")
+        if isinstance(plan, native.NetworkPlan):
+            if mgr.native.keys != plan.spec_keys or len(plan.params) != sum(1 for _ in self.parameters()):
+                return None
+            F = plan.run_eval(x.F, mgr.native)
+            return ME.SparseTensor(F, coordinate_map_key=ME.CoordinateMapKey(1 << plan.records[-1]["level_out"]),
+                                   coordinate_manager=mgr)
+        trace, ops._EVAL_TRACE = ops.Tape(), None
+        ops._EVAL_TRACE = trace
+        try:
+            out = self._forward(x)
+        finally:
+            ops._EVAL_TRACE = None
+        try:
+            self._plan = native.NetworkPlan.from_tape(trace, self, x.F, 0, mgr.native.keys)
+        except ValueError as e:
+            self._plan, self._plan_error = False, str(e)
+        return out
+
     def forward(self, x):
         ops = ME.ops
+        if not self.training and not torch.is_grad_enabled():
+            out = self._forward_eval(x)
+            if out is not None:
+                return out
         if not self._use_tape(x):
             return self._forward(x)
         plan = self.plan_for(x)

@@ -513,6 +513,18 @@ int64_t gcl_plan_arena_bytes(void* plan, const gcl_maps_desc* maps_host);
 int gcl_plan_forward(void* plan, const gcl_maps_desc* maps_host, const float* x, void* const* params_host,
                      void* const* bn_stats_host, void* state, void* arena, int64_t arena_bytes, float** y_out_host,
                      void* stream);
+/* Inference pass of the same records (model.eval(), torch.no_grad(): util/misc.py:58-130, scripts/test_kitti.py:141-152):
+ * every GCL_OP_CONVBN is ONE gcl_conv_fwd_fused launch -- BatchNorm with running statistics folded into the epilogue as
+ * y = relu?(conv * scale + shift (+ residual)) -- the Cin <= 4 first layer is gcl_stem_fwd + gcl_bn_apply(mean, rstd).
+ * bn_eval_host[4 * n_bn]: DEVICE pointers scale, shift, mean, rstd per BatchNorm (scale = gamma rsqrt(var + eps),
+ * shift = beta - mean scale, rstd = rsqrt(var + eps)).  The packed kernels and their max-abs slots persist in `state`
+ * (gcl_plan_eval_state_bytes) from pass to pass: repack != 0 re-measures and re-packs them (first pass, or after the
+ * parameters changed).  No backward pass follows; the arena may be released once the output has been consumed. */
+int64_t gcl_plan_eval_state_bytes(const void* plan);
+int64_t gcl_plan_eval_arena_bytes(void* plan, const gcl_maps_desc* maps_host);
+int gcl_plan_forward_eval(void* plan, const gcl_maps_desc* maps_host, const float* x, void* const* params_host,
+                          void* const* bn_eval_host, int32_t repack, void* state, void* arena, int64_t arena_bytes,
+                          float** y_out_host, void* stream);
 /* Backward pass of the forward pass that ran in `arena` (several forward passes of one plan may be outstanding, each in
  * its own arena): the records first_op <= i < last_op in reverse order (the caller may cut the pass into segments,
  * highest records first, e.g. to start a gradient bucket's all-reduce in between).  dy: gradient of the forward output

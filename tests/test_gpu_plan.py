@@ -143,6 +143,63 @@ def test_plan_pass_equals_the_tape_bitwise(k1):
         torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("k1", [5, 3])
+def test_inference_plan_equals_the_per_operator_eval_path(k1):
+    """model.eval() under torch.no_grad(): ONE gcl_maps_build + ONE gcl_plan_forward_eval (every conv + BatchNorm
+    (+ residual)(+ ReLU) a single fused launch, packed kernels persistent across passes) gives bitwise the features of the
+    per-operator eval path -- on the traced first pass, on later passes, on other clouds, after the parameters changed
+    (a training step with FusedSGD, which bumps the parameter versions), and through forward_clouds' batching."""
+    import gcl_amd.MinkowskiEngine as ME
+    from gcl_amd.MinkowskiEngine import native
+    from gcl_amd.scripts.test_kitti import forward_clouds
+    clouds = [torch.from_numpy(_cloud(s, 4000 + 500 * s, 1)).to(DEV) for s in (11, 12, 13)]
+    feats = [torch.ones(len(c), 1, device=DEV) for c in clouds]
+    with torch.cuda.device(DEV):
+        m = _model(k1)
+        # make the running statistics and the affine parameters non-trivial
+        g = torch.Generator().manual_seed(3)
+        with torch.no_grad():
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.BatchNorm1d):
+                    mod.running_mean.copy_(0.1 * torch.randn(mod.num_features, generator=g))
+                    mod.running_var.copy_(0.5 + torch.rand(mod.num_features, generator=g))
+                    mod.weight.copy_(0.5 + torch.rand(mod.num_features, generator=g))
+                    mod.bias.copy_(0.1 * torch.randn(mod.num_features, generator=g))
+        m.eval()
+
+        def reference(C, F):
+            old, native.PLAN_ENABLED = native.PLAN_ENABLED, False
+            try:
+                with torch.no_grad():
+                    return m(ME.SparseTensor(F, coordinates=C)).F.clone()
+            finally:
+                native.PLAN_ENABLED = old
+
+        refs = [reference(c, f) for c, f in zip(clouds, feats)]
+        with torch.no_grad():
+            assert m._plan is None
+            first = m(ME.SparseTensor(feats[0], coordinates=clouds[0])).F.clone()          # traced pass
+            assert isinstance(m._plan, native.NetworkPlan), getattr(m, "_plan_error", None)
+            assert torch.equal(first, refs[0])
+            for c, f, r in zip(clouds, feats, refs):                                       # plan passes
+                assert torch.equal(m(ME.SparseTensor(f, coordinates=c)).F, r)
+            batched = forward_clouds(m, [(f, c) for f, c in zip(feats, clouds)])
+            for got, r in zip(batched, refs):
+                assert torch.equal(got, r)
+        # parameters change behind the persistent packed kernels: one optimizer step through the fused SGD kernel
+        from gcl_amd.lib.optim import FusedSGD
+        m.train()
+        opt = FusedSGD(m.parameters(), lr=0.05, momentum=0.8, weight_decay=1e-4)
+        out = m(ME.SparseTensor(feats[1], coordinates=clouds[1])).F
+        out.square().mean().backward()
+        opt.step()
+        m.eval()
+        with torch.no_grad():
+            after = m(ME.SparseTensor(feats[2], coordinates=clouds[2])).F
+            assert not torch.equal(after, refs[2])
+            assert torch.equal(after, reference(clouds[2], feats[2]))
+
+
 def _train(cfg_kw, n_steps, plan, batches, iter_size=1, seed=3):
     from gcl_amd.MinkowskiEngine import native
     from gcl_amd.lib.colocation_trainer import FinestContrastiveLossTrainer, make_config, prefetch_to_device
