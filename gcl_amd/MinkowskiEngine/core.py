@@ -200,7 +200,14 @@ class CoordinateManager:
         km.n_in, km.n_out, km.K = n_in, n_out, K
         km.same_map = km.nbr_t is None
         km._counts_dev = nm.view(m.counts, (K,), i32)
-        km._counts = [int(m.counts_host[k]) for k in range(K)]
+        if m.pair_in or int(m.n_pairs) > 0:
+            km._counts = [int(m.counts_host[k]) for k in range(K)]
+        else:     # built without pair lists (inference): the counts were never read back -- fetch them lazily like __init__
+            km._counts = None
+            km._counts_host = torch.empty(K, dtype=torch.int32, pin_memory=True)
+            km._counts_host.copy_(km._counts_dev, non_blocking=True)
+            km._counts_event = torch.cuda.Event()
+            km._counts_event.record()
         km._sorted, km._pairs = {}, None
         for tag, (a, b, c), rows in (("n", (m.tbl_n, m.order_n, m.mask_n), n_out), ("t", (m.tbl_t, m.order_t, m.mask_t), n_in)):
             if a:

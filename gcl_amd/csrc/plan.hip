@@ -254,8 +254,11 @@ static int maps_build(const int32_t* coords, long long n, const gcl_map_spec* sp
       else { d.tbl_n = sorted; d.order_n = order; d.mask_n = mask; }
     }
   }
-  // the second host sync: per-offset pair counts -> padded segment offsets -> pair lists (KernelMap.pairs)
-  if (!A.dry) GCL_CHECK_HIP(hipStreamSynchronize(st));
+  // the second host sync: per-offset pair counts -> padded segment offsets -> pair lists (KernelMap.pairs); skipped when
+  // no map asks for pair lists (inference): counts_host / n_pairs / seg_off then stay zero
+  bool any_pairs = false;
+  for (int s = 0; s < n_specs; ++s) any_pairs = any_pairs || (specs[s].pairs != 0 && specs[s].kernel_size > 1);
+  if (!A.dry && any_pairs) GCL_CHECK_HIP(hipStreamSynchronize(st));
   for (int s = 0; s < n_specs; ++s) {
     const gcl_map_spec& sp = specs[s];
     gcl_map_desc& d = out->maps[s];
@@ -274,6 +277,7 @@ static int maps_build(const int32_t* coords, long long n, const gcl_map_spec* sp
       }
       continue;
     }
+    if (!any_pairs && !A.dry) continue;
     long long total = 0;
     d.seg_off[0] = 0;
     for (int k = 0; k < d.K; ++k) {
