@@ -936,10 +936,11 @@ def test_row_normalize_matches_torch_expression(n, c):
 
 @pytest.mark.parametrize("overrides", [dict(block_finest_gradient=True), dict(square_loss=False),
                                        dict(use_pair_group_positive_loss=True), dict(finest_weight=0),
-                                       dict(use_group_circle_loss=True, block_finest_gradient=True)])
+                                       dict(use_group_circle_loss=True, block_finest_gradient=True),
+                                       dict(use_hard_negative=False)])
 def test_trainer_accepts_the_other_loss_switches(overrides):
     """config.py:38-43 / :158 switches other than the training script's selection run through the trainer (the
-    switch-by-switch values are pinned by the golden tests above); the two unbuilt ones are rejected loudly."""
+    switch-by-switch values are pinned by the golden tests above, use_hard_negative=False included since round 3)."""
     from gcl_amd import synthetic
     from gcl_amd.lib.colocation_trainer import FinestContrastiveLossTrainer, make_config
     batch = synthetic.make_train_batch(77, batch_size=1, num_neighborhood=2, n_boxes=12)
@@ -950,8 +951,7 @@ def test_trainer_accepts_the_other_loss_switches(overrides):
     assert torch.isfinite(loss).item() and pos.item() >= 0
     if overrides.get("finest_weight", 1) == 0:
         assert fin.item() == 0.0
-    with pytest.raises(NotImplementedError):
-        FinestContrastiveLossTrainer(make_config(use_hard_negative=False), device=DEV)
+    assert all(torch.isfinite(p).all() for p in tr.model.parameters())
 
 
 def test_instance_norm_matches_per_cloud_formula():
