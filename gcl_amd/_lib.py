@@ -78,6 +78,7 @@ SIGNATURES = {
     "gcl_pack_weights": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "gcl_table_sort_scratch_len": (_i64, [_i64]),
     "gcl_table_sort": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "gcl_table_sort_multi": (_i32, [_vp, _i32, _vp]),
     "gcl_spatial_order": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
     "gcl_table_sort_pre": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gcl_conv_fwd_fused": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp,

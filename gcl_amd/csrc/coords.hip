@@ -420,26 +420,31 @@ __global__ void __launch_bounds__(256) k_pairs_emit(const int* __restrict__ nbr,
 #endif
 constexpr int RS_BLOCK = GCL_RS_BLOCK;   // one wave per block: small blocks => >= 4 waves per CU at 0.5 M rows
 
-__global__ void k_row_masks(const int* __restrict__ tbl, int K, long long n, unsigned* keys, int* vals) {
-  long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void row_masks_body(const int* __restrict__ tbl, int K, long long n, unsigned* keys, int* vals,
+                                               unsigned bx) {
+  long long v = (long long)bx * blockDim.x + threadIdx.x;
   if (v >= n) return;
   unsigned m = 0;
   for (int k = 0; k < K; ++k) m |= (tbl[(long long)k * n + v] >= 0 ? 1u : 0u) << k;
   keys[v] = m;
   vals[v] = (int)v;
 }
+__global__ void k_row_masks(const int* __restrict__ tbl, int K, long long n, unsigned* keys, int* vals) {
+  row_masks_body(tbl, K, n, keys, vals, blockIdx.x);
+}
 
 // bit_count[k] (32 zero-initialised ints) += number of rows whose mask has offset k.  A small fixed grid walks the
 // masks, every thread counts in registers, the workgroup adds up in LDS and issues ONE integer atomic per offset
 // (512 x 27 atomics per table: same-address atomics serialise at ~10 ns each, one per wave cost 2 ms per table)
-__global__ void __launch_bounds__(256) k_mask_bit_count(const unsigned* __restrict__ keys, long long n, int K, int* bit_count) {
+__device__ __forceinline__ void mask_bit_count_body(const unsigned* __restrict__ keys, long long n, int K, int* bit_count,
+                                                    unsigned bx, unsigned nbx) {
   __shared__ int tot[32];
   if (threadIdx.x < 32) tot[threadIdx.x] = 0;
   __syncthreads();
   int c[27];
 #pragma unroll
   for (int k = 0; k < 27; ++k) c[k] = 0;
-  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long long)gridDim.x * blockDim.x) {
+  for (long long v = (long long)bx * blockDim.x + threadIdx.x; v < n; v += (long long)nbx * blockDim.x) {
     const unsigned m = keys[v];
 #pragma unroll
     for (int k = 0; k < 27; ++k) c[k] += (int)((m >> k) & 1u);
@@ -454,6 +459,9 @@ __global__ void __launch_bounds__(256) k_mask_bit_count(const unsigned* __restri
   __syncthreads();
   if ((int)threadIdx.x < K && tot[threadIdx.x]) atomicAdd(&bit_count[threadIdx.x], tot[threadIdx.x]);
 }
+__global__ void __launch_bounds__(256) k_mask_bit_count(const unsigned* __restrict__ keys, long long n, int K, int* bit_count) {
+  mask_bit_count_body(keys, n, K, bit_count, blockIdx.x, gridDim.x);
+}
 
 // Sort key = the mask with its bits re-ordered by how often each offset occurs in THIS table: the rarest offset
 // becomes the most significant bit, the most frequent one the least significant (ties: lower offset index lower).
@@ -461,8 +469,8 @@ __global__ void __launch_bounds__(256) k_mask_bit_count(const unsigned* __restri
 // trailing (frequent) bits are set in most rows anyway.  Measured on the KITTI batch against the offset-index order:
 // 7.75 vs 8.26 units per 32-row tile at tensor stride 1, 9.88 vs 10.99 at stride 4, 11.41 vs 13.11 at stride 8
 // (exact sparse work: 6.3 / 7.3 / 7.7).  pos[k] = key bit of offset k, written for k_tile_masks.
-__global__ void __launch_bounds__(256) k_mask_keys(unsigned* keys, long long n, int K, const int* __restrict__ bit_count,
-                                                   int* pos_out) {
+__device__ __forceinline__ void mask_keys_body(unsigned* keys, long long n, int K, const int* __restrict__ bit_count,
+                                               int* pos_out, unsigned bx) {
   __shared__ int pos[32];
   if (threadIdx.x < 32) {
     const int k = threadIdx.x;
@@ -475,10 +483,10 @@ __global__ void __launch_bounds__(256) k_mask_keys(unsigned* keys, long long n, 
       }
     }
     pos[k] = p;
-    if (blockIdx.x == 0 && k < K) pos_out[k] = p;
+    if (bx == 0 && k < K) pos_out[k] = p;
   }
   __syncthreads();
-  long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long v = (long long)bx * blockDim.x + threadIdx.x;
   if (v >= n) return;
   const unsigned m = keys[v];
   unsigned key = 0;
@@ -487,29 +495,37 @@ __global__ void __launch_bounds__(256) k_mask_keys(unsigned* keys, long long n, 
   // but its pseudo-random low digits turn every radix scatter into 64 single-row writes per wave: +1 .. 2 ms per step)
   keys[v] = key;
 }
+__global__ void __launch_bounds__(256) k_mask_keys(unsigned* keys, long long n, int K, const int* __restrict__ bit_count,
+                                                   int* pos_out) {
+  mask_keys_body(keys, n, K, bit_count, pos_out, blockIdx.x);
+}
 
-__global__ void __launch_bounds__(64) k_radix_hist(const unsigned* __restrict__ keys, long long n, int shift,
-                                                   int nblk, int* hist) {
+__device__ __forceinline__ void radix_hist_body(const unsigned* __restrict__ keys, long long n, int shift, int nblk, int* hist,
+                                                unsigned bx) {
   __shared__ int cnt[256];
   const int lane = threadIdx.x;
   for (int d = lane; d < 256; d += 64) cnt[d] = 0;
   __syncthreads();
-  const long long base = (long long)blockIdx.x * RS_BLOCK;
+  const long long base = (long long)bx * RS_BLOCK;
   for (int c = 0; c < RS_BLOCK / 64; ++c) {
     long long i = base + c * 64 + lane;
     if (i < n) atomicAdd(&cnt[(keys[i] >> shift) & 255u], 1);
   }
   __syncthreads();
-  for (int d = lane; d < 256; d += 64) hist[(long long)d * nblk + blockIdx.x] = cnt[d];
+  for (int d = lane; d < 256; d += 64) hist[(long long)d * nblk + bx] = cnt[d];
+}
+__global__ void __launch_bounds__(64) k_radix_hist(const unsigned* __restrict__ keys, long long n, int shift,
+                                                   int nblk, int* hist) {
+  radix_hist_body(keys, n, shift, nblk, hist, blockIdx.x);
 }
 
 // one workgroup per digit d: within[d][b] = sum_{b' < b} hist[d][b'], total[d] = sum_b hist[d][b]  (the digit bases,
 // a 256-entry prefix sum of the totals, are formed by every scatter block itself: one launch instead of a 3-kernel
 // scan over the whole 256 x nblk histogram)
-__global__ void __launch_bounds__(256) k_radix_digit_scan(const int* __restrict__ hist, int nblk, int* within,
-                                                          int* total) {
+__device__ __forceinline__ void radix_digit_scan_body(const int* __restrict__ hist, int nblk, int* within, int* total,
+                                                      unsigned bx) {
   __shared__ int part[256];
-  const int d = blockIdx.x, t = threadIdx.x;
+  const int d = (int)bx, t = threadIdx.x;
   const int per = (nblk + 255) / 256;
   const int b0 = t * per, b1 = min(nblk, b0 + per);
   const int* h = hist + (long long)d * nblk;
@@ -531,11 +547,15 @@ __global__ void __launch_bounds__(256) k_radix_digit_scan(const int* __restrict_
   }
   if (t == 255) total[d] = part[255];
 }
+__global__ void __launch_bounds__(256) k_radix_digit_scan(const int* __restrict__ hist, int nblk, int* within,
+                                                          int* total) {
+  radix_digit_scan_body(hist, nblk, within, total, blockIdx.x);
+}
 
-__global__ void __launch_bounds__(64) k_radix_scatter(const unsigned* __restrict__ keys, const int* __restrict__ vals,
-                                                      long long n, int shift, int nblk,
-                                                      const int* __restrict__ within, const int* __restrict__ total,
-                                                      unsigned* keys_out, int* vals_out) {
+__device__ __forceinline__ void radix_scatter_body(const unsigned* __restrict__ keys, const int* __restrict__ vals,
+                                                   long long n, int shift, int nblk, const int* __restrict__ within,
+                                                   const int* __restrict__ total, unsigned* keys_out, int* vals_out,
+                                                   unsigned bx) {
   __shared__ int base_[256];
   const int lane = threadIdx.x;
   {   // digit bases = exclusive prefix sum of total[0..255]: lane l owns digits 4l .. 4l+3
@@ -547,14 +567,14 @@ __global__ void __launch_bounds__(64) k_radix_scatter(const unsigned* __restrict
       if (lane >= o) inc += v;
     }
     const int ex = inc - mine;
-    const long long bb = blockIdx.x;
+    const long long bb = bx;
     base_[4 * lane] = ex + within[(long long)(4 * lane) * nblk + bb];
     base_[4 * lane + 1] = ex + t0 + within[(long long)(4 * lane + 1) * nblk + bb];
     base_[4 * lane + 2] = ex + t0 + t1 + within[(long long)(4 * lane + 2) * nblk + bb];
     base_[4 * lane + 3] = ex + t0 + t1 + t2 + within[(long long)(4 * lane + 3) * nblk + bb];
   }
   __syncthreads();
-  const long long base = (long long)blockIdx.x * RS_BLOCK;
+  const long long base = (long long)bx * RS_BLOCK;
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   for (int c = 0; c < RS_BLOCK / 64; ++c) {
     long long i = base + c * 64 + lane;
@@ -579,6 +599,12 @@ __global__ void __launch_bounds__(64) k_radix_scatter(const unsigned* __restrict
       vals_out[pos] = val;
     }
   }
+}
+__global__ void __launch_bounds__(64) k_radix_scatter(const unsigned* __restrict__ keys, const int* __restrict__ vals,
+                                                      long long n, int shift, int nblk,
+                                                      const int* __restrict__ within, const int* __restrict__ total,
+                                                      unsigned* keys_out, int* vals_out) {
+  radix_scatter_body(keys, vals, n, shift, nblk, within, total, keys_out, vals_out, blockIdx.x);
 }
 
 // Windowed variant: rows are mask-sorted only INSIDE windows of WIN consecutive rows of the loader's order, which is
@@ -804,21 +830,24 @@ __global__ void __launch_bounds__(256) k_halo_build(const int* __restrict__ tbl_
 
 // tile_mask (optional): an offset missing from a 32-row tile's mask is -1 for all of its rows by definition -- written
 // without the (scattered, 4-byte) read of the source table: ~19 of 27 offsets on the KITTI batch
-__global__ void k_permute_table(const int* __restrict__ tbl, const int* __restrict__ order, long long n,
-                                int* tbl_sorted, const int* __restrict__ tile_mask) {
-  long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  int k = blockIdx.y;
+__device__ __forceinline__ void permute_table_body(const int* __restrict__ tbl, const int* __restrict__ order, long long n,
+                                                   int* tbl_sorted, const int* __restrict__ tile_mask, unsigned bx, int k) {
+  long long j = (long long)bx * blockDim.x + threadIdx.x;
   if (j >= n) return;
   int v = -1;
   if (!tile_mask || ((tile_mask[j >> 5] >> k) & 1)) v = tbl[(long long)k * n + order[j]];
   tbl_sorted[(long long)k * n + j] = v;
 }
+__global__ void k_permute_table(const int* __restrict__ tbl, const int* __restrict__ order, long long n,
+                                int* tbl_sorted, const int* __restrict__ tile_mask) {
+  permute_table_body(tbl, order, n, tbl_sorted, tile_mask, blockIdx.x, (int)blockIdx.y);
+}
 
 // pos (optional): the keys are masks with bit k moved to pos[k] (k_mask_keys); the tile mask is returned in offset order.
 // Lane = row (coalesced key reads), OR over the 32 lanes of a tile by butterfly shuffles.
-__global__ void __launch_bounds__(256) k_tile_masks(const unsigned* __restrict__ keys_sorted, long long n, long long n_tiles,
-                                                    int* tile_mask, const int* __restrict__ pos, int K) {
-  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void tile_masks_body(const unsigned* __restrict__ keys_sorted, long long n, long long n_tiles,
+                                                int* tile_mask, const int* __restrict__ pos, int K, unsigned bx) {
+  const long long j = (long long)bx * blockDim.x + threadIdx.x;
   unsigned m = (j < n) ? keys_sorted[j] : 0u;
 #pragma unroll
   for (int o = 16; o > 0; o >>= 1) m |= __shfl_xor(m, o);
@@ -831,6 +860,70 @@ __global__ void __launch_bounds__(256) k_tile_masks(const unsigned* __restrict__
     m = u;
   }
   tile_mask[t] = (int)m;
+}
+__global__ void __launch_bounds__(256) k_tile_masks(const unsigned* __restrict__ keys_sorted, long long n, long long n_tiles,
+                                                    int* tile_mask, const int* __restrict__ pos, int K) {
+  tile_masks_body(keys_sorted, n, n_tiles, tile_mask, pos, K, blockIdx.x);
+}
+
+// ---- the same mask sort for SEVERAL tables per launch (gcl_table_sort_multi) --------------------------------------
+// blockIdx.y (permute: z) = table; a table's blocks beyond its own grid return at once.  Same bodies, same results: what
+// changes is the number of launches -- a network's 12 tables take 14 launches instead of 168, which is what a
+// single-cloud inference pass (a chain of tiny dependent launches) and the trainer's map stream are made of.
+constexpr int SORT_MAX_JOBS = 16;
+struct SortJob {
+  const int* tbl;
+  long long n;
+  int K, nblk, shift;
+  const unsigned* kin;
+  unsigned* kout;
+  const int* vin;
+  int* vout;
+  int *hist, *offs, *bs, *bit_count, *key_pos, *order, *tbl_sorted, *tile_mask;
+};
+struct SortJobs {
+  int count;
+  SortJob j[SORT_MAX_JOBS];
+};
+__global__ void __launch_bounds__(256) k_row_masks_multi(SortJobs J) {
+  const SortJob& q = J.j[blockIdx.y];
+  if (blockIdx.x == 0 && threadIdx.x < 32 && q.bit_count) q.bit_count[threadIdx.x] = 0;      // read by the NEXT launch
+  if ((long long)blockIdx.x * 256 >= q.n) return;
+  row_masks_body(q.tbl, q.K, q.n, q.kout, q.vout, blockIdx.x);
+}
+__global__ void __launch_bounds__(256) k_mask_bit_count_multi(SortJobs J) {
+  const SortJob& q = J.j[blockIdx.y];
+  mask_bit_count_body(q.kin, q.n, q.K, q.bit_count, blockIdx.x, gridDim.x);
+}
+__global__ void __launch_bounds__(256) k_mask_keys_multi(SortJobs J) {
+  const SortJob& q = J.j[blockIdx.y];
+  if ((long long)blockIdx.x * 256 >= q.n) return;
+  mask_keys_body(q.kout, q.n, q.K, q.bit_count, q.key_pos, blockIdx.x);
+}
+__global__ void __launch_bounds__(64) k_radix_hist_multi(SortJobs J) {
+  const SortJob& q = J.j[blockIdx.y];
+  if ((int)blockIdx.x >= q.nblk) return;
+  radix_hist_body(q.kin, q.n, q.shift, q.nblk, q.hist, blockIdx.x);
+}
+__global__ void __launch_bounds__(256) k_radix_digit_scan_multi(SortJobs J) {
+  const SortJob& q = J.j[blockIdx.y];
+  radix_digit_scan_body(q.hist, q.nblk, q.offs, q.bs, blockIdx.x);
+}
+__global__ void __launch_bounds__(64) k_radix_scatter_multi(SortJobs J) {
+  const SortJob& q = J.j[blockIdx.y];
+  if ((int)blockIdx.x >= q.nblk) return;
+  radix_scatter_body(q.kin, q.vin, q.n, q.shift, q.nblk, q.offs, q.bs, q.kout, q.vout, blockIdx.x);
+}
+__global__ void __launch_bounds__(256) k_tile_masks_multi(SortJobs J) {
+  const SortJob& q = J.j[blockIdx.y];
+  const long long n_tiles = (q.n + 31) / 32;
+  if ((long long)blockIdx.x * 256 >= n_tiles * 32) return;
+  tile_masks_body(q.kin, q.n, n_tiles, q.tile_mask, q.key_pos, q.K, blockIdx.x);
+}
+__global__ void __launch_bounds__(256) k_permute_table_multi(SortJobs J) {
+  const SortJob& q = J.j[blockIdx.z];
+  if ((long long)blockIdx.x * 256 >= q.n || (int)blockIdx.y >= q.K) return;
+  permute_table_body(q.tbl, q.order, q.n, q.tbl_sorted, q.tile_mask, blockIdx.x, (int)blockIdx.y);
 }
 
 }  // namespace gcl
@@ -1083,6 +1176,76 @@ int gcl_table_sort_pre(const int32_t* tbl, int32_t K, int64_t n, int32_t window,
   hipLaunchKernelGGL(k_permute_table, dim3((unsigned)cdiv(n, 256), K), dim3(256), 0, st, tbl, (const int*)order,
                      (long long)n, tbl_sorted, (const int*)tile_mask);
   GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int gcl_table_sort_multi(const gcl_sort_job* jobs_host, int32_t n_jobs, void* stream) {
+  GCL_CHECK_ARG(jobs_host && n_jobs >= 1, "gcl_table_sort_multi: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  static const int max_passes = [] { const char* e = getenv("GCL_SORT_PASSES"); int v = e ? atoi(e) : 3; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
+  for (int j0 = 0; j0 < n_jobs; j0 += SORT_MAX_JOBS) {
+    const int T = (n_jobs - j0 < SORT_MAX_JOBS) ? n_jobs - j0 : SORT_MAX_JOBS;
+    SortJobs J;
+    J.count = T;
+    long long n_max = 0;
+    int nblk_max = 0, K0 = jobs_host[j0].K;
+    unsigned* ka[SORT_MAX_JOBS];
+    unsigned* kb[SORT_MAX_JOBS];
+    int* va[SORT_MAX_JOBS];
+    int* vb[SORT_MAX_JOBS];
+    for (int t = 0; t < T; ++t) {
+      const gcl_sort_job& g = jobs_host[j0 + t];
+      GCL_CHECK_ARG(g.tbl && g.scratch && g.order && g.tbl_sorted && g.tile_mask, "gcl_table_sort_multi: null pointer");
+      GCL_CHECK_ARG(g.K >= 1 && g.K <= 27 && g.n > 0 && g.K == K0, "gcl_table_sort_multi: tables of one call share K <= 27");
+      SortJob& q = J.j[t];
+      const long long n = g.n;
+      const int nblk = (int)cdiv(n, RS_BLOCK);
+      const long long hist_len = 256ll * nblk;
+      ka[t] = (unsigned*)g.scratch;
+      kb[t] = ka[t] + n;
+      va[t] = g.scratch + 2 * n;
+      vb[t] = g.scratch + 3 * n;
+      q.tbl = g.tbl; q.n = n; q.K = g.K; q.nblk = nblk; q.shift = 0;
+      q.hist = g.scratch + 4 * n;
+      q.offs = q.hist + hist_len;
+      q.bs = q.offs + hist_len;
+      q.bit_count = g.scratch + gcl_table_sort_scratch_len(n) - 64;
+      q.key_pos = q.bit_count + 32;
+      q.order = g.order; q.tbl_sorted = g.tbl_sorted; q.tile_mask = g.tile_mask;
+      q.kin = ka[t]; q.kout = ka[t]; q.vin = va[t]; q.vout = va[t];
+      if (n > n_max) n_max = n;
+      if (nblk > nblk_max) nblk_max = nblk;
+    }
+    const unsigned gn = (unsigned)cdiv(n_max, 256);
+    hipLaunchKernelGGL(k_row_masks_multi, dim3(gn, T), dim3(256), 0, st, J);            // masks -> ka, row ids -> va
+    hipLaunchKernelGGL(k_mask_bit_count_multi, dim3(512, T), dim3(256), 0, st, J);
+    hipLaunchKernelGGL(k_mask_keys_multi, dim3(gn, T), dim3(256), 0, st, J);             // ka: masks -> sort keys
+    int passes = (K0 + 7) / 8, base = 0;
+    if (passes > max_passes) {
+      base = K0 - 8 * max_passes;
+      passes = max_passes;
+    }
+    for (int p = 0; p < passes; ++p) {
+      for (int t = 0; t < T; ++t) {
+        SortJob& q = J.j[t];
+        q.shift = base + 8 * p;
+        q.kin = ka[t]; q.vin = va[t];
+        q.kout = kb[t];
+        q.vout = (p == passes - 1) ? q.order : vb[t];
+      }
+      hipLaunchKernelGGL(k_radix_hist_multi, dim3(nblk_max, T), dim3(64), 0, st, J);
+      hipLaunchKernelGGL(k_radix_digit_scan_multi, dim3(256, T), dim3(256), 0, st, J);
+      hipLaunchKernelGGL(k_radix_scatter_multi, dim3(nblk_max, T), dim3(64), 0, st, J);
+      for (int t = 0; t < T; ++t) {
+        unsigned* tk = ka[t]; ka[t] = kb[t]; kb[t] = tk;
+        if (p != passes - 1) { int* tv = va[t]; va[t] = vb[t]; vb[t] = tv; }
+      }
+    }
+    for (int t = 0; t < T; ++t) J.j[t].kin = ka[t];                                      // the sorted keys
+    hipLaunchKernelGGL(k_tile_masks_multi, dim3((unsigned)cdiv(cdiv(n_max, 32) * 32, 256), T), dim3(256), 0, st, J);
+    hipLaunchKernelGGL(k_permute_table_multi, dim3(gn, K0, T), dim3(256), 0, st, J);
+    GCL_CHECK_LAUNCH();
+  }
   return GCL_OK;
 }
 

@@ -143,6 +143,18 @@ int gcl_kernel_map_pairs(const int32_t* nbr, int32_t K, int64_t n_out, const int
 int64_t gcl_table_sort_scratch_len(int64_t n);
 int gcl_table_sort(const int32_t* tbl, int32_t K, int64_t n, int32_t window, int32_t* scratch, int32_t* order,
                    int32_t* tbl_sorted, int32_t* tile_mask, void* stream);
+/* gcl_table_sort (global mode, window 0) of SEVERAL tables in one sequence of 14 launches (a network has 12 such tables:
+ * 168 launches one by one).  Same results bit for bit.  All tables of a call share K. */
+typedef struct gcl_sort_job {
+  const int32_t* tbl;
+  int32_t K;
+  int64_t n;
+  int32_t* scratch;      /* int32[gcl_table_sort_scratch_len(n)] */
+  int32_t* order;
+  int32_t* tbl_sorted;
+  int32_t* tile_mask;
+} gcl_sort_job;
+int gcl_table_sort_multi(const gcl_sort_job* jobs_host, int32_t n_jobs, void* stream);
 /* Spatial pre-order of the rows of a coordinate map at tensor stride `tensor_stride`: order[j] = row at position j when
  * rows are sorted by (cloud id, Morton code of the 4^3-voxel cell); stable, deterministic.  gcl_table_sort_pre with
  * window = 2048 | 4096 then mask-sorts inside windows of THAT order: the rows a workgroup (and, with
