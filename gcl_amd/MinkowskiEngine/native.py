@@ -291,6 +291,7 @@ class NetworkPlan:
         lib = _lib.require_gpu()
         if maps.keys != self.spec_keys:
             raise ValueError("the maps were built for a different map specification than the plan")
+        self._check_input(x_feats, maps)
         x = x_feats.contiguous()
         dev = x.device
         need = lib.gcl_plan_arena_bytes(self.handle, ctypes.byref(maps.desc))
@@ -331,6 +332,13 @@ class NetworkPlan:
             return _PlanFn.apply(run, self._anchor)
         return _PlanFn.apply(run, *self.params)
 
+    def _check_input(self, x_feats, maps):
+        r0 = self.records[0]
+        if x_feats.dim() != 2 or x_feats.shape[1] != r0["cin"]:
+            raise ValueError(f"the plan was recorded for {r0['cin']} input channels, got a tensor of shape {tuple(x_feats.shape)}")
+        if x_feats.shape[0] != int(maps.desc.n_rows[r0["level_in"]]):
+            raise ValueError("features and coordinate maps differ in length")
+
     def _ensure_state(self, lib, dev):
         if self._state is None or self._state.device != dev:     # tables + (inference) the persistent packed kernels
             self._state = torch.empty(int(lib.gcl_plan_eval_state_bytes(self.handle)), dtype=torch.uint8, device=dev)
@@ -343,6 +351,7 @@ class NetworkPlan:
         lib = _lib.require_gpu()
         if maps.keys != self.spec_keys:
             raise ValueError("the maps were built for a different map specification than the plan")
+        self._check_input(x_feats, maps)
         x = x_feats.contiguous()
         dev = x.device
         need = lib.gcl_plan_eval_arena_bytes(self.handle, ctypes.byref(maps.desc))
