@@ -200,6 +200,55 @@ def test_inference_plan_equals_the_per_operator_eval_path(k1):
             assert torch.equal(after, reference(clouds[2], feats[2]))
 
 
+@pytest.mark.parametrize("n", [1, 37, 300])
+def test_plan_on_tiny_clouds(n):
+    """Edge sizes (one voxel, fewer rows than a 32-row wave tile / a 128-row workgroup tile, coarse levels of one or two
+    rows): the native maps + plan -- training pass and inference pass -- equal the per-operator path bit for bit."""
+    import gcl_amd.MinkowskiEngine as ME
+    from gcl_amd.MinkowskiEngine import native
+    rng = np.random.RandomState(n)
+    pts = np.unique(rng.randint(-5, 5, (4 * n + 8, 3)), axis=0)[:n]
+    C = torch.from_numpy(np.concatenate([np.zeros((len(pts), 1), int), pts], 1).astype(np.int32)).to(DEV)
+    F = torch.ones(len(C), 1, device=DEV)
+    dF = torch.randn(len(C), 32, generator=torch.Generator().manual_seed(n)).to(DEV)
+    with torch.cuda.device(DEV):
+        m = _model(3)
+        state0 = {k: v.clone() for k, v in m.state_dict().items()}
+
+        def train_pass(plan_on):
+            m.load_state_dict(state0)
+            m.train()
+            for p in m.parameters():
+                p.grad = None
+            old, native.PLAN_ENABLED = native.PLAN_ENABLED, plan_on
+            try:
+                mgr = ME.CoordinateManager.build_native(C, m.native_map_specs()) if plan_on else ME.CoordinateManager(C)
+                out = m(ME.SparseTensor(F, coordinates=C, coordinate_manager=mgr)).F
+                out.backward(dF)
+            finally:
+                native.PLAN_ENABLED = old
+            torch.cuda.synchronize()
+            return out.detach().clone(), [p.grad.clone() for p in m.parameters()]
+
+        ref = train_pass(False)
+        train_pass(True)                      # recorded by the Tape on native maps
+        got = train_pass(True)                # through the plan
+        assert isinstance(m._plan, native.NetworkPlan), getattr(m, "_plan_error", None)
+        assert torch.equal(ref[0], got[0])
+        for (name, _), a, b in zip(m.named_parameters(), ref[1], got[1]):
+            assert torch.equal(a, b), name
+        m.load_state_dict(state0)
+        m.eval()
+        with torch.no_grad():
+            e_plan = m(ME.SparseTensor(F, coordinates=C)).F.clone()
+            old, native.PLAN_ENABLED = native.PLAN_ENABLED, False
+            try:
+                e_ref = m(ME.SparseTensor(F, coordinates=C)).F.clone()
+            finally:
+                native.PLAN_ENABLED = old
+        assert torch.equal(e_plan, e_ref)
+
+
 def _train(cfg_kw, n_steps, plan, batches, iter_size=1, seed=3):
     from gcl_amd.MinkowskiEngine import native
     from gcl_amd.lib.colocation_trainer import FinestContrastiveLossTrainer, make_config, prefetch_to_device
