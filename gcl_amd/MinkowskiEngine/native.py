@@ -51,6 +51,8 @@ class NativeMaps:
         for a, s in zip(arr, specs):
             a.t_in, a.kernel_size, a.stride = int(s[0]), int(s[1]), int(s[2])
             a.tables = sum(1 << int(bool(tr)) for tr in set(bool(t) for t in s[3]))
+            if len(s) > 5 and s[5] == "presence":      # presence words of nbr (first-layer occupancy path)
+                a.tables |= 4
             a.pairs = int(bool(s[4]))
         need = lib.gcl_maps_arena_bytes(n, arr, len(specs), self.n_levels)
         if need < 0:

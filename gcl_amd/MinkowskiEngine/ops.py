@@ -299,7 +299,7 @@ class _SparseConvFn(torch.autograd.Function):
         if ctx.stem:
             y = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
             _lib.check(lib.gcl_stem_fwd(_lib.ptr(x, torch.float32), _lib.ptr(Wk), _lib.ptr(kmap.nbr), n_out, K, cin,
-                                        cout, _lib.ptr(y), _lib.stream()), "gcl_stem_fwd")
+                                        cout, _lib.ptr(y), None, None, _lib.stream()), "gcl_stem_fwd")
         else:
             tbl = None if kmap is None else kmap.sorted_table(transposed=transpose)
             b = bias.detach().contiguous().view(-1) if bias is not None else None
@@ -376,7 +376,7 @@ class _SparseConvFn(torch.autograd.Function):
                 scratch = torch.empty(lib.gcl_stem_bwd_weight_scratch_len(K, cin, cout, n_out), dtype=torch.float32,
                                       device=x.device)
                 _lib.check(lib.gcl_stem_bwd_weight(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(kmap.nbr), n_out, K, cin, cout,
-                                                   _lib.ptr(scratch), _lib.ptr(dW), _lib.stream()),
+                                                   _lib.ptr(scratch), _lib.ptr(dW), None, None, _lib.stream()),
                            "gcl_stem_bwd_weight")
             else:
                 if kmap is None:

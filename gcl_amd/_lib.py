@@ -30,7 +30,8 @@ class MapDesc(ctypes.Structure):      # gcl_map_desc
                 ("level_out", _i32), ("n_in", _i64), ("n_out", _i64), ("n_pairs", _i64),
                 ("nbr", _vp), ("nbr_t", _vp), ("counts", _vp),
                 ("tbl_n", _vp), ("order_n", _vp), ("mask_n", _vp), ("tbl_t", _vp), ("order_t", _vp), ("mask_t", _vp),
-                ("pair_in", _vp), ("pair_out", _vp), ("seg_off", _i64 * 128), ("counts_host", _i32 * 128)]
+                ("pair_in", _vp), ("pair_out", _vp), ("presence", _vp), ("seg_off", _i64 * 128),
+                ("counts_host", _i32 * 128)]
 
 
 class MapsDesc(ctypes.Structure):     # gcl_maps_desc
@@ -89,9 +90,11 @@ SIGNATURES = {
     "gcl_conv_bwd_weight_scratch_len": (_i64, [_i32, _i32, _i32, _i64, _i64]),
     "gcl_conv_bwd_weight": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, ctypes.POINTER(_i64), _i32, _i32, _i32, _i32, _vp,
                                    _vp, _vp, _vp, _vp]),
-    "gcl_stem_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
+    "gcl_presence_bits": (_i32, [_vp, _i32, _i64, _vp, _vp]),
+    "gcl_not_all_ones": (_i32, [_vp, _i64, _vp, _vp]),
+    "gcl_stem_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "gcl_stem_bwd_weight_scratch_len": (_i64, [_i32, _i32, _i32, _i64]),
-    "gcl_stem_bwd_weight": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "gcl_stem_bwd_weight": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "gcl_bn_scratch_len": (_i64, [_i64, _i32]),
     "gcl_bn_stats": (_i32, [_vp, _i64, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gcl_bn_tiles_scratch_len": (_i64, [_i64, _i32]),

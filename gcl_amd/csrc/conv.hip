@@ -1748,9 +1748,16 @@ static int bwd_weight_wgs(long long n_chunks) {
 // ---------------------------------------------------------------------------------------------------
 // first layer (Cin <= 4 -> 32): VALU kernels over the neighbour table
 // ---------------------------------------------------------------------------------------------------
+// OCCUPANCY INPUT (presence != NULL, *not_ones == 0, cin == 1): every feature is exactly 1.0f -- what all of the
+// reference's loaders feed (lib/colocation_data_loader.py:401,412: torch.ones((n, 1))).  x[nbr[k][v]] is then 1 where the
+// neighbour exists and 0 where it does not, i.e. bit k of the row's presence word: the kernels skip the 4-byte table
+// entry per (offset, row) (265 MB at K = 125 and 0.5 M rows) and the dependent feature gather.  Same FMAs / MFMAs on the
+// same values in the same order: bitwise identical to the general path, which any other input takes (device-side flag, no
+// host decision).
 __global__ void __launch_bounds__(256) k_stem_fwd(const float* __restrict__ x, const float* __restrict__ w,
                                                   const int* __restrict__ nbr, long long n_out, int K, int cin,
-                                                  int cout, float* __restrict__ y) {
+                                                  int cout, float* __restrict__ y, const unsigned* __restrict__ presence,
+                                                  const int* __restrict__ not_ones) {
   // thread = output row; the weights W[k][ci][0..31] are wave-uniform and come through the scalar cache (s_load),
   // so the inner product costs one v_fmac with an SGPR operand per (offset, channel) and no LDS traffic
   long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1758,11 +1765,22 @@ __global__ void __launch_bounds__(256) k_stem_fwd(const float* __restrict__ x, c
   float acc[32];
 #pragma unroll
   for (int c = 0; c < 32; ++c) acc[c] = 0.f;
+  constexpr int STEM_B = 25;
+  if (presence && cin == 1 && *not_ones == 0) {      // wave-uniform
+    const int words = (K + 31) >> 5;
+    unsigned bits[4] = {0u, 0u, 0u, 0u};
+    for (int q = 0; q < words && q < 4; ++q) bits[q] = presence[v * words + q];
+    for (int k = 0; k < K; ++k) {
+      const float xv = ((bits[k >> 5] >> (k & 31)) & 1u) ? 1.f : 0.f;
+      const float* wr = w + (long long)k * cout + blockIdx.y * 32;
+#pragma unroll
+      for (int c = 0; c < 32; ++c) acc[c] = fmaf(xv, wr[c], acc[c]);
+    }
+  } else {
   // offsets in batches of STEM_B: all table reads of a batch are issued first, then all feature gathers, then the FMAs --
   // the walk is bound by the latency of these two dependent loads (one table entry per offset and row, 265 MB at K = 125
   // and 0.5 M rows), so the number in flight per thread is what counts (was 5: 221 us; the accumulation order per output
   // element is unchanged: k ascending, ci ascending)
-  constexpr int STEM_B = 25;
   for (int k0 = 0; k0 < K; k0 += STEM_B) {
     int idx[STEM_B];
 #pragma unroll
@@ -1781,6 +1799,7 @@ __global__ void __launch_bounds__(256) k_stem_fwd(const float* __restrict__ x, c
       }
     }
   }
+  }
   if ((long long)blockIdx.x * blockDim.x + threadIdx.x >= n_out) return;
   float4* yo = reinterpret_cast<float4*>(y + v * cout + blockIdx.y * 32);
 #pragma unroll
@@ -1798,7 +1817,10 @@ constexpr int STEM_KMAX = 125;
 constexpr int STEM_TILE = 128, STEM_LD = STEM_TILE + 1;
 __global__ void __launch_bounds__(256) k_stem_bwd_weight(const float* __restrict__ x, const float* __restrict__ dy,
                                                          const int* __restrict__ nbr, long long n_out, int K,
-                                                         int cin, int cout, float* slabs) {
+                                                         int cin, int cout, float* slabs,
+                                                         const unsigned* __restrict__ presence,
+                                                         const int* __restrict__ not_ones) {
+  const bool occupancy = presence && cin == 1 && *not_ones == 0;      // see k_stem_fwd
   __shared__ float As[128 * STEM_LD];
   const int cb0 = blockIdx.y * 32;             // 32-column block of dY / dW          // 66 KB; reused as the cross-wave reduction buffer [4][4*16*64]
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1818,6 +1840,16 @@ __global__ void __launch_bounds__(256) k_stem_bwd_weight(const float* __restrict
         const int r = threadIdx.x & (STEM_TILE - 1), kq = threadIdx.x >> 7;
         const long long row = r0 + r;
         const bool rv = row < r_end;
+        if (occupancy) {      // A[k][row] = bit k of the row's presence words (1.0 / 0.0), no table read, no gather
+          const int words = (K + 31) >> 5;
+          unsigned bits[4] = {0u, 0u, 0u, 0u};
+          if (rv)
+            for (int q = 0; q < words && q < 4; ++q) bits[q] = presence[row * words + q];
+          for (int j = 0; j < 64; ++j) {
+            const int k = kq + 2 * j;
+            As[k * STEM_LD + r] = (k < K && ((bits[k >> 5] >> (k & 31)) & 1u)) ? 1.f : 0.f;
+          }
+        } else
         for (int j0 = 0; j0 < 64; j0 += 16) {
           int idx[16];
 #pragma unroll
@@ -2392,12 +2424,13 @@ int gcl_conv_bwd_weight(const float* a, int64_t n_a, const float* b, int64_t n_b
 }
 
 int gcl_stem_fwd(const float* x, const float* w, const int32_t* nbr, int64_t n_out, int32_t K, int32_t cin,
-                 int32_t cout, float* y, void* stream) {
+                 int32_t cout, float* y, const uint32_t* presence, const int32_t* not_ones, void* stream) {
+  GCL_CHECK_ARG((presence == nullptr) == (not_ones == nullptr), "gcl_stem_fwd: presence and not_ones go together");
   GCL_CHECK_ARG(x && w && nbr && y, "gcl_stem_fwd: null pointer");
   GCL_CHECK_ARG(cin >= 1 && cin <= 4 && cout > 0 && cout % 32 == 0 && K >= 1 && K <= STEM_KMAX && n_out > 0,
                 "gcl_stem_fwd: supports Cin <= 4, Cout a multiple of 32, K <= 125 (got %d, %d, %d)", cin, cout, K);
   hipLaunchKernelGGL(k_stem_fwd, dim3((unsigned)cdiv(n_out, 256), (unsigned)(cout / 32)), dim3(256), 0, (hipStream_t)stream,
-                     x, w, nbr, (long long)n_out, K, cin, cout, y);
+                     x, w, nbr, (long long)n_out, K, cin, cout, y, (const unsigned*)presence, (const int*)not_ones);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }
@@ -2407,7 +2440,9 @@ int64_t gcl_stem_bwd_weight_scratch_len(int32_t K, int32_t cin, int32_t cout, in
 }
 
 int gcl_stem_bwd_weight(const float* x, const float* dy, const int32_t* nbr, int64_t n_out, int32_t K, int32_t cin,
-                        int32_t cout, float* scratch, float* dw, void* stream) {
+                        int32_t cout, float* scratch, float* dw, const uint32_t* presence, const int32_t* not_ones,
+                        void* stream) {
+  GCL_CHECK_ARG((presence == nullptr) == (not_ones == nullptr), "gcl_stem_bwd_weight: presence and not_ones go together");
   GCL_CHECK_ARG(x && dy && nbr && scratch && dw, "gcl_stem_bwd_weight: null pointer");
   GCL_CHECK_ARG(cin >= 1 && cin <= 4 && cout > 0 && cout % 32 == 0 && K >= 1 && K <= STEM_KMAX && n_out > 0,
                 "gcl_stem_bwd_weight: supports Cin <= 4, Cout a multiple of 32, K <= 125 (got %d, %d, %d)", cin, cout, K);
@@ -2415,7 +2450,7 @@ int gcl_stem_bwd_weight(const float* x, const float* dy, const int32_t* nbr, int
   int nwg = (int)cdiv(n_out, STEM_ROWS_PER_WG);
   long long mat = (long long)K * cin * cout;
   hipLaunchKernelGGL(k_stem_bwd_weight, dim3(nwg, (unsigned)(cout / 32)), dim3(256), 0, st, x, dy, nbr, (long long)n_out, K,
-                     cin, cout, scratch);
+                     cin, cout, scratch, (const unsigned*)presence, (const int*)not_ones);
   hipLaunchKernelGGL(k_stem_reduce, dim3((unsigned)cdiv(mat, 64)), dim3(256), 0, st, (const float*)scratch, nwg, mat,
                      dw);
   GCL_CHECK_LAUNCH();

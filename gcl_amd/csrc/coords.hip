@@ -866,6 +866,26 @@ __global__ void __launch_bounds__(256) k_tile_masks(const unsigned* __restrict__
   tile_masks_body(keys_sorted, n, n_tiles, tile_mask, pos, K, blockIdx.x);
 }
 
+// presence words of a neighbour table: bit (k & 31) of bits[v][k >> 5] = nbr[k][v] >= 0 (the first layer's occupancy path)
+__global__ void __launch_bounds__(256) k_presence_bits(const int* __restrict__ nbr, int K, long long n, unsigned* bits) {
+  const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n) return;
+  const int words = (K + 31) >> 5;
+  for (int q = 0; q < words; ++q) {
+    unsigned m = 0;
+    const int k1 = (q * 32 + 32 < K) ? q * 32 + 32 : K;
+    for (int k = q * 32; k < k1; ++k) m |= (nbr[(long long)k * n + v] >= 0 ? 1u : 0u) << (k & 31);
+    bits[v * words + q] = m;
+  }
+}
+// *flag = 1 when some element differs from 1.0f (flag zero-initialised by the caller)
+__global__ void __launch_bounds__(256) k_not_all_ones(const float* __restrict__ x, long long n, int* flag) {
+  bool bad = false;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    bad = bad || (x[i] != 1.0f);
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicExch(flag, 1);
+}
+
 // ---- the same mask sort for SEVERAL tables per launch (gcl_table_sort_multi) --------------------------------------
 // blockIdx.y (permute: z) = table; a table's blocks beyond its own grid return at once.  Same bodies, same results: what
 // changes is the number of launches -- a network's 12 tables take 14 launches instead of 168, which is what a
@@ -1175,6 +1195,24 @@ int gcl_table_sort_pre(const int32_t* tbl, int32_t K, int64_t n, int32_t window,
                      (long long)n, n_tiles, tile_mask, (const int*)key_pos, K);
   hipLaunchKernelGGL(k_permute_table, dim3((unsigned)cdiv(n, 256), K), dim3(256), 0, st, tbl, (const int*)order,
                      (long long)n, tbl_sorted, (const int*)tile_mask);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int gcl_presence_bits(const int32_t* nbr, int32_t K, int64_t n, uint32_t* bits, void* stream) {
+  GCL_CHECK_ARG(nbr && bits && K >= 1 && K <= 128 && n > 0, "gcl_presence_bits: bad argument");
+  hipLaunchKernelGGL(k_presence_bits, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, nbr, K, (long long)n,
+                     (unsigned*)bits);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int gcl_not_all_ones(const float* x, int64_t n, int32_t* flag, void* stream) {
+  GCL_CHECK_ARG(x && flag && n > 0, "gcl_not_all_ones: bad argument");
+  long long g = cdiv(n, 256 * 8);
+  if (g > 256) g = 256;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(k_not_all_ones, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, (long long)n, flag);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }

@@ -258,6 +258,12 @@ static int maps_build(const int32_t* coords, long long n, const gcl_map_spec* sp
     }
   }
   static const int sort_multi = [] { const char* e = getenv("GCL_SORT_MULTI"); return e ? atoi(e) : 1; }();
+  for (int s = 0; s < n_specs; ++s) {      // presence words of the first layer's table (occupancy path of the stem kernels)
+    if (!(specs[s].tables & 4) || specs[s].kernel_size == 1) continue;
+    gcl_map_desc& d = out->maps[s];
+    d.presence = A.take_n<uint32_t>(d.n_out * ((d.K + 31) / 32));
+    PLAN_CALL(gcl_presence_bits(d.nbr, d.K, d.n_out, d.presence, stream));
+  }
   if (n_jobs && sort_multi) PLAN_CALL(gcl_table_sort_multi(jobs, n_jobs, stream));
   if (n_jobs && !sort_multi)
     for (int q = 0; q < n_jobs; ++q)
@@ -349,6 +355,7 @@ struct PassState {        // everything one forward pass leaves behind for its b
   unsigned char *pack_fwd = nullptr, *pack_bwd = nullptr;
   void* state = nullptr;
   bool forward_done = false, bwd_packed = false;
+  int32_t* not_ones = nullptr;      // device flag of the pass: some input feature differs from 1.0f (occupancy path off)
   void* key = nullptr;              // the pass's arena: how gcl_plan_backward / gcl_plan_release find it
 };
 
@@ -459,6 +466,15 @@ static bool is_stem(const gcl_plan_op& op, const gcl_map_desc& m) {
   return op.cin <= 4 && (op.cout % 32) == 0 && !op.transpose && m.kernel_size > 1 && op.bias < 0;
 }
 
+// occupancy path of the first layer: measure once per pass whether every input feature is exactly 1.0f (device flag)
+static int stem_flag(Plan& P, const gcl_plan_op& op, const gcl_map_desc& m, const TState& x, long long n_in, hipStream_t st) {
+  Arena& A = P.A;
+  if (!m.presence || P.not_ones) return GCL_OK;
+  P.not_ones = new_slot(P);        // a zeroed word of the slot pool
+  PLAN_CALL(gcl_not_all_ones(x.ptr, n_in * op.cin, P.not_ones, (void*)st));
+  return GCL_OK;
+}
+
 // the convolution of a CONVBN / CONV record (ops._SparseConvFn.forward); returns its output in *y_out
 static int conv_forward(Plan& P, int i, float** y_out, float** stats_out, hipStream_t st) {
   Arena& A = P.A;
@@ -472,7 +488,10 @@ static int conv_forward(Plan& P, int i, float** y_out, float** stats_out, hipStr
   *stats_out = nullptr;
   const float* W = (const float*)P.params[op.w];
   if (is_stem(op, m)) {
-    PLAN_CALL(gcl_stem_fwd(x.ptr, W, m.nbr, n_out, op.K, op.cin, op.cout, y, (void*)st));
+    int rcs = stem_flag(P, op, m, x, n_in, st);
+    if (rcs) return rcs;
+    PLAN_CALL(gcl_stem_fwd(x.ptr, W, m.nbr, n_out, op.K, op.cin, op.cout, y, m.presence, m.presence ? P.not_ones : nullptr,
+                           (void*)st));
     return GCL_OK;
   }
   const int wi = P.widx[op.w];
@@ -543,6 +562,7 @@ static int plan_forward(Plan& P, const float* x_in, void* const* bn_stats, float
   P.n_slots = 4 * (long long)P.n_tensors + 2 * (long long)P.ops.size() + 16;
   P.next_slot = 0;
   P.slots_exhausted = false;
+  P.not_ones = nullptr;
   P.slot_pool = A.take_n<int32_t>(P.n_slots * GCL_AMAX_WORDS);
   if (!A.dry) GCL_CHECK_HIP(hipMemsetAsync(P.slot_pool, 0, (size_t)P.n_slots * GCL_AMAX_WORDS * sizeof(int32_t), st));
   // all convolution kernels: max|W| in one launch, forward packs in one launch (WeightAmaxGroup)
@@ -596,7 +616,9 @@ static int plan_forward(Plan& P, const float* x_in, void* const* bn_stats, float
           if (is_stem(op, m)) {      // the Cin <= 4 first layer: VALU convolution, then the BatchNorm apply pass
             float* cy = A.take_n<float>(n_out * c);
             unsigned long long* mask = op.relu ? A.take_n<unsigned long long>(gcl_bn_mask_len(n_out, c)) : nullptr;
-            PLAN_CALL(gcl_stem_fwd(x.ptr, (const float*)P.params[op.w], m.nbr, n_out, op.K, op.cin, c, cy, (void*)st));
+            if ((rc = stem_flag(P, op, m, x, n_in, st))) return rc;
+            PLAN_CALL(gcl_stem_fwd(x.ptr, (const float*)P.params[op.w], m.nbr, n_out, op.K, op.cin, c, cy, m.presence,
+                                   m.presence ? P.not_ones : nullptr, (void*)st));
             PLAN_CALL(gcl_bn_apply(cy, n_out, c, (const float*)be[2], (const float*)be[3], (const float*)P.params[op.bn_w],
                                    (const float*)P.params[op.bn_b], res, op.relu, y.ptr, (uint64_t*)mask, y.amax, (void*)st));
             break;
@@ -722,7 +744,8 @@ static int conv_backward(Plan& P, int i, TState dy, void* const* grads, hipStrea
     float* scratch = A.take_n<float>(gcl_stem_bwd_weight_scratch_len(op.K, op.cin, op.cout, n_out));
     hipStream_t ws = fork_aux(P, st);
     ProfScope ps(P, ws, 2, (double)m.n_pairs, op.cin, op.cout, n_in, n_out, op.K);
-    PLAN_CALL(gcl_stem_bwd_weight(x.ptr, dy.ptr, m.nbr, n_out, op.K, op.cin, op.cout, scratch, dW, (void*)ws));
+    PLAN_CALL(gcl_stem_bwd_weight(x.ptr, dy.ptr, m.nbr, n_out, op.K, op.cin, op.cout, scratch, dW, m.presence,
+                                  m.presence ? P.not_ones : nullptr, (void*)ws));
     return GCL_OK;
   }
   const int wi = P.widx[op.w];

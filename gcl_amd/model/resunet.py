@@ -84,7 +84,11 @@ class ResUNet2(ME.MinkowskiNetwork):
             key = (t_in, ks, stride)          # conv1 with kernel 3 shares its map with block1
             old = merged.get(key, ((), False))
             merged[key] = (tuple(sorted(set(old[0]) | set(bool(t) for t in tables))), (old[1] or bool(pairs)) and training)
-        return [k + v for k, v in merged.items()]
+        out = [k + v for k, v in merged.items()]
+        if self.conv1.in_channels <= 4:      # occupancy path of the first layer: presence words of its table ("presence" flag)
+            k1 = (1, self.conv1.kernel_size, 1)
+            out = [(s + ("presence",)) if s[:3] == k1 else s for s in out]
+        return out
 
     _plan = None          # native.NetworkPlan once recorded; False when the graph is outside what the plan covers
 

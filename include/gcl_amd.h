@@ -280,11 +280,20 @@ int gcl_conv_bwd_weight(const float* a, int64_t n_a, const float* b, int64_t n_b
 
 /* First layer (Cin <= 4, Cout a multiple of 32, any ks <= 5): VALU kernels over the nbr table (one 32-column block per
  * workgroup column).  Other first-layer widths go through gcl_conv_fwd / gcl_conv_bwd_weight (generic shapes). */
+/* Occupancy input: `presence` (uint32 [n_out][ceil(K / 32)], gcl_presence_bits of `nbr`) and `not_ones` (device int32,
+ * 0 = every input feature equals 1.0f; gcl_not_all_ones) are optional and go together.  When given, cin == 1 and the flag
+ * is 0 -- the input every loader of the reference produces (lib/colocation_data_loader.py:401: torch.ones((n, 1))) -- the
+ * kernels take x[nbr[k][v]] from bit k of the row's presence words instead of reading the table entry and gathering the
+ * feature: same arithmetic on the same values in the same order (bitwise identical results), 265 MB less to read per
+ * launch at K = 125 and 0.5 M rows.  Any other input takes the general path (the flag is read on the device). */
+int gcl_presence_bits(const int32_t* nbr, int32_t K, int64_t n, uint32_t* bits, void* stream);
+int gcl_not_all_ones(const float* x, int64_t n, int32_t* flag, void* stream);      /* flag must be zero on entry */
 int gcl_stem_fwd(const float* x, const float* w, const int32_t* nbr, int64_t n_out, int32_t K,
-                 int32_t cin, int32_t cout, float* y, void* stream);
+                 int32_t cin, int32_t cout, float* y, const uint32_t* presence, const int32_t* not_ones, void* stream);
 int64_t gcl_stem_bwd_weight_scratch_len(int32_t K, int32_t cin, int32_t cout, int64_t n_out);
 int gcl_stem_bwd_weight(const float* x, const float* dy, const int32_t* nbr, int64_t n_out, int32_t K,
-                        int32_t cin, int32_t cout, float* scratch, float* dw, void* stream);
+                        int32_t cin, int32_t cout, float* scratch, float* dw, const uint32_t* presence,
+                        const int32_t* not_ones, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * BatchNorm over rows of [n, c] fused with the residual add and ReLU of BasicBlock.
@@ -451,7 +460,8 @@ int gcl_sc2_refine(const float* src, const float* tgt, int32_t n, float thr, int
 #define GCL_MAPS_PINNED_BYTES (512 * (GCL_MAX_MAPS + 1))
 
 /* one kernel map to build: CoordinateManager.get_kernel_map(t_in, kernel_size, stride);
- * tables bit 0 / bit 1: gcl_table_sort of nbr / of nbr_t; pairs != 0: the weight gradient's pair lists.
+ * tables bit 0 / bit 1: gcl_table_sort of nbr / of nbr_t; bit 2: presence words of nbr (the Cin <= 4 first layer's
+ * occupancy path); pairs != 0: the weight gradient's pair lists.
  * kernel_size 1 (stride 1): only the identity pair list of level t_in (pairs != 0). */
 typedef struct gcl_map_spec {
   int32_t t_in, kernel_size, stride, tables, pairs;
@@ -466,6 +476,7 @@ typedef struct gcl_map_desc {
   int32_t *tbl_n, *order_n, *mask_n;    /* gcl_table_sort(nbr) */
   int32_t *tbl_t, *order_t, *mask_t;    /* gcl_table_sort(nbr_t) */
   int32_t *pair_in, *pair_out;
+  uint32_t* presence;                   /* gcl_presence_bits(nbr) when the spec asks for it (tables bit 2), else NULL */
   int64_t seg_off[128];                 /* padded prefix sums of the per-offset pair counts, K + 1 used */
   int32_t counts_host[128];
 } gcl_map_desc;

@@ -56,7 +56,7 @@ def test_version_and_error_string_without_gpu():
     assert rc == -1 and b"plane images" in lib.gcl_last_error()
     assert lib.gcl_pack_weights_bytes(1, 64, 16, 4) == 64 * 16 * 4          # fp32 W_eff for the generic kernels
     assert lib.gcl_pack_weights_bytes(125, 32, 32, 4) == 125 * 32 * 32 * 4
-    rc = lib.gcl_stem_fwd(p8, p8, p8, 10, 27, 1, 48, p8, None)
+    rc = lib.gcl_stem_fwd(p8, p8, p8, 10, 27, 1, 48, p8, None, None, None)
     assert rc == -1 and b"multiple of 32" in lib.gcl_last_error()
     rc = lib.gcl_conv_fwd(p8, 10, 0, p8, 3, None, None, p8, p8, None, 10, 27, 32, 32, None, p8, None, 0, None)
     assert rc == -1 and b"go together" in lib.gcl_last_error()
