@@ -386,7 +386,7 @@ class CoordinateManager:
         KernelMap.sorted_table and ``pairs`` whether the weight gradient's pair lists are needed.  A trainer calls this
         for batch i+1 on a side stream while batch i trains (the maps depend on the coordinates only), which takes the
         ~150 small integer launches and the level-size read-back off the training stream's critical path."""
-        for t_in, ks, stride, tables, pairs in specs:
+        for t_in, ks, stride, tables, pairs in (s[:5] for s in specs):
             km = self.get_kernel_map(t_in, ks, stride)
             for tr in tables:
                 km.sorted_table(transposed=bool(tr))

@@ -1748,12 +1748,13 @@ static int bwd_weight_wgs(long long n_chunks) {
 // ---------------------------------------------------------------------------------------------------
 // first layer (Cin <= 4 -> 32): VALU kernels over the neighbour table
 // ---------------------------------------------------------------------------------------------------
-// OCCUPANCY INPUT (presence != NULL, *not_ones == 0, cin == 1): every feature is exactly 1.0f -- what all of the
-// reference's loaders feed (lib/colocation_data_loader.py:401,412: torch.ones((n, 1))).  x[nbr[k][v]] is then 1 where the
-// neighbour exists and 0 where it does not, i.e. bit k of the row's presence word: the kernels skip the 4-byte table
-// entry per (offset, row) (265 MB at K = 125 and 0.5 M rows) and the dependent feature gather.  Same FMAs / MFMAs on the
-// same values in the same order: bitwise identical to the general path, which any other input takes (device-side flag, no
-// host decision).
+// OCCUPANCY INPUT (presence != NULL, *not_ones == 0, cin == 1): every feature is exactly 1.0f -- what the reference's
+// test loaders and scripts feed (torch.ones((n, 1)), no transform; its training loaders add lib/transforms.py:18 Jitter to
+// the centre cloud, so training takes the table path).  x[nbr[k][v]] is then bit k of the row's presence words: the
+// forward adds W[k] over the set bits (k_stem_fwd_occ; this kernel returns at once), the weight gradient fills its 0/1
+// tile from the words.  Same values in the same order: bitwise identical to the table path, which any other input takes
+// (device-side flag, no host decision).  Measured at 0.53 M rows, K = 125: forward 150 -> 48 us, weight gradient
+// 195 -> 157 us (tools/micro/stem_time.py).
 __global__ void __launch_bounds__(256) k_stem_fwd(const float* __restrict__ x, const float* __restrict__ w,
                                                   const int* __restrict__ nbr, long long n_out, int K, int cin,
                                                   int cout, float* __restrict__ y, const unsigned* __restrict__ presence,
@@ -1766,17 +1767,8 @@ __global__ void __launch_bounds__(256) k_stem_fwd(const float* __restrict__ x, c
 #pragma unroll
   for (int c = 0; c < 32; ++c) acc[c] = 0.f;
   constexpr int STEM_B = 25;
-  if (presence && cin == 1 && *not_ones == 0) {      // wave-uniform
-    const int words = (K + 31) >> 5;
-    unsigned bits[4] = {0u, 0u, 0u, 0u};
-    for (int q = 0; q < words && q < 4; ++q) bits[q] = presence[v * words + q];
-    for (int k = 0; k < K; ++k) {
-      const float xv = ((bits[k >> 5] >> (k & 31)) & 1u) ? 1.f : 0.f;
-      const float* wr = w + (long long)k * cout + blockIdx.y * 32;
-#pragma unroll
-      for (int c = 0; c < 32; ++c) acc[c] = fmaf(xv, wr[c], acc[c]);
-    }
-  } else {
+  if (presence && cin == 1 && *not_ones == 0) return;      // k_stem_fwd_occ, enqueued right behind, produces y
+  {
   // offsets in batches of STEM_B: all table reads of a batch are issued first, then all feature gathers, then the FMAs --
   // the walk is bound by the latency of these two dependent loads (one table entry per offset and row, 265 MB at K = 125
   // and 0.5 M rows), so the number in flight per thread is what counts (was 5: 221 us; the accumulation order per output
@@ -1804,6 +1796,44 @@ __global__ void __launch_bounds__(256) k_stem_fwd(const float* __restrict__ x, c
   float4* yo = reinterpret_cast<float4*>(y + v * cout + blockIdx.y * 32);
 #pragma unroll
   for (int c4 = 0; c4 < 8; ++c4) yo[c4] = make_float4(acc[4 * c4], acc[4 * c4 + 1], acc[4 * c4 + 2], acc[4 * c4 + 3]);
+}
+
+// Occupancy input, forward: y[v][c] = sum over the SET bits k of the row's presence words of W[k][c], k ascending -- the
+// order in which the general kernel adds the same terms (its absent offsets add fma(0, w, acc) = acc), so the result is
+// bitwise identical.  8 lanes per row (4 columns each), the 32-column slice of W in LDS (one ds_read_b128 per set bit
+// and lane): ~20 adds per row instead of 125 table reads + gathers + 4000 FMAs.
+constexpr int STEM_OCC_ROWS = 256;      // rows per workgroup (8 passes of 32)
+__global__ void __launch_bounds__(256) k_stem_fwd_occ(const float* __restrict__ w, const unsigned* __restrict__ presence,
+                                                      const int* __restrict__ not_ones, long long n_out, int K, int cout,
+                                                      float* __restrict__ y) {
+  __shared__ __attribute__((aligned(16))) float Ws[128 * 32];
+  if (*not_ones != 0) return;
+  const int cb0 = blockIdx.y * 32;
+  for (int e = threadIdx.x; e < K * 8; e += 256) {
+    const int k = e >> 3, q = e & 7;
+    *reinterpret_cast<float4*>(&Ws[k * 32 + q * 4]) = *reinterpret_cast<const float4*>(w + (long long)k * cout + cb0 + q * 4);
+  }
+  __syncthreads();
+  const int words = (K + 31) >> 5;
+  const int sub = threadIdx.x & 7;
+  for (int pass = 0; pass < STEM_OCC_ROWS / 32; ++pass) {
+    const long long v = (long long)blockIdx.x * STEM_OCC_ROWS + pass * 32 + (threadIdx.x >> 3);
+    if (v >= n_out) continue;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < words; ++q) {
+      unsigned bits = presence[v * words + q];
+      while (bits) {
+        const int k = q * 32 + __builtin_ctz(bits);
+        bits &= bits - 1;
+        const float4 wv = *reinterpret_cast<const float4*>(&Ws[k * 32 + sub * 4]);
+        acc.x = fmaf(1.f, wv.x, acc.x);
+        acc.y = fmaf(1.f, wv.y, acc.y);
+        acc.z = fmaf(1.f, wv.z, acc.z);
+        acc.w = fmaf(1.f, wv.w, acc.w);
+      }
+    }
+    *reinterpret_cast<float4*>(y + v * cout + cb0 + sub * 4) = acc;
+  }
 }
 
 constexpr int STEM_ROWS_PER_WG = 1024;
@@ -1865,14 +1895,18 @@ __global__ void __launch_bounds__(256) k_stem_bwd_weight(const float* __restrict
         }
       }
       __syncthreads();
+      float bv[16];      // the lane's 16 dY values of the tile: all loads in flight before the first MFMA (they were one
+#pragma unroll          // dependent load per MFMA step: 16 round trips per tile and wave)
+      for (int s = 0; s < 16; ++s) {
+        const long long row = r0 + w * 32 + 2 * s + h;
+        bv[s] = (row < r_end) ? dy[row * cout + cb0 + i] : 0.f;
+      }
 #pragma unroll 4
       for (int s = 0; s < 16; ++s) {
         const int rl = w * 32 + 2 * s + h;
-        const long long row = r0 + rl;
-        const float b = (row < r_end) ? dy[row * cout + cb0 + i] : 0.f;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
-          acc[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(kb * 32 + i) * STEM_LD + rl], b, acc[kb], 0, 0, 0);
+          acc[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(kb * 32 + i) * STEM_LD + rl], bv[s], acc[kb], 0, 0, 0);
       }
     }
     __syncthreads();
@@ -2432,6 +2466,13 @@ int gcl_stem_fwd(const float* x, const float* w, const int32_t* nbr, int64_t n_o
   hipLaunchKernelGGL(k_stem_fwd, dim3((unsigned)cdiv(n_out, 256), (unsigned)(cout / 32)), dim3(256), 0, (hipStream_t)stream,
                      x, w, nbr, (long long)n_out, K, cin, cout, y, (const unsigned*)presence, (const int*)not_ones);
   GCL_CHECK_LAUNCH();
+  if (presence && cin == 1) {
+    // both kernels are enqueued and the device flag picks the one that works: the general kernel returns at once when
+    // the input is all ones, the occupancy kernel when it is not (no host read of the flag)
+    hipLaunchKernelGGL(k_stem_fwd_occ, dim3((unsigned)cdiv(n_out, STEM_OCC_ROWS), (unsigned)(cout / 32)), dim3(256), 0,
+                       (hipStream_t)stream, w, (const unsigned*)presence, (const int*)not_ones, (long long)n_out, K, cout, y);
+    GCL_CHECK_LAUNCH();
+  }
   return GCL_OK;
 }
 

@@ -85,7 +85,11 @@ class ResUNet2(ME.MinkowskiNetwork):
             old = merged.get(key, ((), False))
             merged[key] = (tuple(sorted(set(old[0]) | set(bool(t) for t in tables))), (old[1] or bool(pairs)) and training)
         out = [k + v for k, v in merged.items()]
-        if self.conv1.in_channels <= 4:      # occupancy path of the first layer: presence words of its table ("presence" flag)
+        if self.conv1.in_channels == 1 and not training:
+            # inference feeds occupancy features (lib/data_loaders.py test sets / scripts/test_kitti.py: torch.ones((n, 1)),
+            # no transform): presence words of the first layer's table, its kernels then add W[k] over the set bits.
+            # Training batches carry lib/transforms.py:18 Jitter on the centre cloud, so they would pay for the words and
+            # take the table path anyway.
             k1 = (1, self.conv1.kernel_size, 1)
             out = [(s + ("presence",)) if s[:3] == k1 else s for s in out]
         return out

@@ -282,10 +282,11 @@ int gcl_conv_bwd_weight(const float* a, int64_t n_a, const float* b, int64_t n_b
  * workgroup column).  Other first-layer widths go through gcl_conv_fwd / gcl_conv_bwd_weight (generic shapes). */
 /* Occupancy input: `presence` (uint32 [n_out][ceil(K / 32)], gcl_presence_bits of `nbr`) and `not_ones` (device int32,
  * 0 = every input feature equals 1.0f; gcl_not_all_ones) are optional and go together.  When given, cin == 1 and the flag
- * is 0 -- the input every loader of the reference produces (lib/colocation_data_loader.py:401: torch.ones((n, 1))) -- the
- * kernels take x[nbr[k][v]] from bit k of the row's presence words instead of reading the table entry and gathering the
- * feature: same arithmetic on the same values in the same order (bitwise identical results), 265 MB less to read per
- * launch at K = 125 and 0.5 M rows.  Any other input takes the general path (the flag is read on the device). */
+ * is 0 -- the input of the reference's test loaders and scripts (torch.ones((n, 1)), no transform; its training loaders
+ * add lib/transforms.py:18 Jitter to the centre cloud) -- x[nbr[k][v]] is bit k of the row's presence words:
+ * gcl_stem_fwd adds W[k] over the SET bits, k ascending (k_stem_fwd_occ; the table kernel is enqueued too and returns at
+ * once), gcl_stem_bwd_weight fills its 0/1 tile from the words.  Same values added in the same order: bitwise identical
+ * to the table path, which any other input takes (the flag is read on the device, no host decision). */
 int gcl_presence_bits(const int32_t* nbr, int32_t K, int64_t n, uint32_t* bits, void* stream);
 int gcl_not_all_ones(const float* x, int64_t n, int32_t* flag, void* stream);      /* flag must be zero on entry */
 int gcl_stem_fwd(const float* x, const float* w, const int32_t* nbr, int64_t n_out, int32_t K,

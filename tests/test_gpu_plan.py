@@ -49,7 +49,7 @@ def test_native_maps_equal_the_per_operator_maps(seed, n, batch):
         assert nat.native is not None and nat.native.desc.arena_used <= nat.native.arena.numel()
         for t in (1, 2, 4, 8):
             assert torch.equal(ref.get_coords(t), nat.get_coords(t)), t
-        for t_in, ks, stride, tables, pairs in specs:
+        for t_in, ks, stride, tables, pairs in (s[:5] for s in specs):
             if ks == 1:
                 a, b = ref.identity_pairs(len(C)), nat.identity_pairs(len(C))
                 assert torch.equal(a[0], b[0]) and a[2] == b[2]
@@ -65,6 +65,22 @@ def test_native_maps_equal_the_per_operator_maps(seed, n, batch):
             if pairs:
                 pa, pb = ka.pairs(), kb.pairs()
                 assert pa[2] == pb[2] and torch.equal(pa[0], pb[0]) and torch.equal(pa[1], pb[1])
+        # inference specs: no pair lists, presence words of the first layer's table (bit k of row v = nbr[k][v] >= 0)
+        ispecs = _model().native_map_specs(training=False)
+        assert not any(s[4] for s in ispecs) and sum(len(s) > 5 for s in ispecs) == 1
+        inf = ME.CoordinateManager.build_native(C, ispecs).native
+        for i, sp in enumerate(ispecs):
+            d = inf.desc.maps[i]
+            assert bool(d.presence) == (len(sp) > 5) and d.n_pairs == 0
+            if len(sp) > 5:
+                K, n_out = int(d.K), int(d.n_out)
+                words = (K + 31) // 32
+                got = inf.view(d.presence, (n_out, words), torch.int32).cpu().numpy().view(np.uint32)
+                nb = inf.view(d.nbr, (K, n_out), torch.int32).cpu().numpy()
+                want = np.zeros((n_out, words), np.uint32)
+                for k in range(K):
+                    want[:, k // 32] |= (nb[k] >= 0).astype(np.uint32) << np.uint32(k % 32)
+                assert np.array_equal(got, want)
 
 
 def test_native_maps_reject_bad_coordinates():

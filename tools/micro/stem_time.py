@@ -1,21 +1,42 @@
-"""DIAGNOSTIC: time of the first-layer kernels on the synthetic training batch (GPU box only)."""
+"""DIAGNOSTIC: time of the first-layer kernels on the synthetic training batch, table path against occupancy path
+(GPU box only)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import gcl_amd.MinkowskiEngine as ME
-from gcl_amd import synthetic
+from gcl_amd import synthetic, _lib
+lib = _lib.load()
 batch = synthetic.make_train_batch(100, batch_size=4, group_mode="fixed16")
 dev = "cuda:0"
 C = batch["sinput_C"].to(dev)
-conv = ME.MinkowskiConvolution(1, 32, kernel_size=5, stride=1, dimension=3).to(dev)
-x = ME.SparseTensor(torch.ones(len(C), 1, device=dev), coordinates=C)
-y = conv(x)
-g = torch.randn_like(y.F)
-for name, fn in (("fwd", lambda: conv(x)), ("fwd+bwd", lambda: conv(x).F.backward(g))):
+mgr = ME.CoordinateManager(C)
+km = mgr.get_kernel_map(1, 5, 1)
+K, n = km.nbr.shape[0], len(C)
+words = (K + 31) // 32
+x = torch.ones(n, 1, device=dev)
+W = torch.randn(K, 1, 32, device=dev)
+dy = torch.randn(n, 32, device=dev)
+y = torch.empty(n, 32, device=dev)
+dw = torch.empty(K, 1, 32, device=dev)
+bits = torch.empty(n * words, dtype=torch.int32, device=dev)
+flag = torch.zeros(1, dtype=torch.int32, device=dev)
+scratch = torch.empty(lib.gcl_stem_bwd_weight_scratch_len(K, 1, 32, n), dtype=torch.float32, device=dev)
+s = _lib.stream()
+p = _lib.ptr
+
+
+def timed(name, fn):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(10):
+    for _ in range(20):
         fn()
     e1.record(); torch.cuda.synchronize()
-    print(name, f"{e0.elapsed_time(e1) / 10 * 1e3:.0f} us")
+    print(f"{name:28s} {e0.elapsed_time(e1) / 20 * 1e3:7.0f} us   (n = {n}, K = {K})")
+
+
+timed("presence_bits", lambda: lib.gcl_presence_bits(p(km.nbr), K, n, p(bits), s))
+timed("not_all_ones", lambda: lib.gcl_not_all_ones(p(x), n, p(flag), s))
+for name, pb, pf in (("table", None, None), ("occupancy", p(bits), p(flag))):
+    timed("fwd " + name, lambda: lib.gcl_stem_fwd(p(x), p(W), p(km.nbr), n, K, 1, 32, p(y), pb, pf, s))
+    timed("bwd_weight " + name, lambda: lib.gcl_stem_bwd_weight(p(x), p(dy), p(km.nbr), n, K, 1, 32, p(scratch), p(dw), pb, pf, s))
