@@ -294,6 +294,38 @@ __device__ __forceinline__ float amax4(float m, const float4& v) {
   return fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
 }
 
+// Both apply kernels: thread -> element quads e, e + S, e + 2S, ... with S = gridDim.x * 256.  HOIST (S a multiple of
+// c / 4, the case for every power-of-two width): the thread's channel quad never changes, so its per-channel constants are
+// loaded once instead of per quad (the 64-bit e % (c/4) and four to five 16-byte loads per quad went with them).  Two
+// quads are in flight per thread (all loads of a pair issued before the first use).  Per-element arithmetic unchanged.
+struct BnFwdC { float4 mu, rs, wv, bv; };
+__device__ __forceinline__ BnFwdC bn_fwd_c(const float* mean, const float* rstd, const float* weight, const float* bias, int cq) {
+  BnFwdC k;
+  k.mu = reinterpret_cast<const float4*>(mean)[cq]; k.rs = reinterpret_cast<const float4*>(rstd)[cq];
+  k.wv = reinterpret_cast<const float4*>(weight)[cq]; k.bv = reinterpret_cast<const float4*>(bias)[cq];
+  return k;
+}
+__device__ __forceinline__ float4 bn_fwd_one(const float4& xv, const float4& rv, bool has_res, int relu, const BnFwdC& k) {
+  float4 o;
+  o.x = (xv.x - k.mu.x) * k.rs.x * k.wv.x + k.bv.x;
+  o.y = (xv.y - k.mu.y) * k.rs.y * k.wv.y + k.bv.y;
+  o.z = (xv.z - k.mu.z) * k.rs.z * k.wv.z + k.bv.z;
+  o.w = (xv.w - k.mu.w) * k.rs.w * k.wv.w + k.bv.w;
+  if (has_res) { o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w; }
+  if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+  return o;
+}
+__device__ __forceinline__ void bn_mask_store(unsigned long long* __restrict__ mask, long long e, const float4& o, bool ok) {
+  // e - lane is a multiple of 64 (grid stride and block size are): one ballot per component
+  unsigned long long b0 = __ballot(ok && o.x > 0.f), b1 = __ballot(ok && o.y > 0.f), b2 = __ballot(ok && o.z > 0.f),
+                     b3 = __ballot(ok && o.w > 0.f);
+  if (ok && (threadIdx.x & 63) == 0) {
+    unsigned long long* m = mask + (e >> 6) * 4;
+    m[0] = b0; m[1] = b1; m[2] = b2; m[3] = b3;
+  }
+}
+
+template <bool HOIST>
 __global__ void __launch_bounds__(256) k_bn_apply(const float* __restrict__ x, long long total4, int c,
                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
                                                   const float* __restrict__ weight, const float* __restrict__ bias,
@@ -301,39 +333,62 @@ __global__ void __launch_bounds__(256) k_bn_apply(const float* __restrict__ x, l
                                                   float* __restrict__ y, unsigned long long* __restrict__ mask,
                                                   int* amax_bits) {
   const int cq_n = c >> 2;
+  const long long S = (long long)gridDim.x * blockDim.x;
+  const long long e0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const float4 z4 = make_float4(0, 0, 0, 0);
   float am = 0.f;
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total4;
-       e += (long long)gridDim.x * blockDim.x) {
-    int cq = (int)(e % cq_n);
-    float4 mu = reinterpret_cast<const float4*>(mean)[cq], rs = reinterpret_cast<const float4*>(rstd)[cq];
-    float4 wv = reinterpret_cast<const float4*>(weight)[cq], bv = reinterpret_cast<const float4*>(bias)[cq];
-    float4 xv = reinterpret_cast<const float4*>(x)[e];
-    float4 o;
-    o.x = (xv.x - mu.x) * rs.x * wv.x + bv.x;
-    o.y = (xv.y - mu.y) * rs.y * wv.y + bv.y;
-    o.z = (xv.z - mu.z) * rs.z * wv.z + bv.z;
-    o.w = (xv.w - mu.w) * rs.w * wv.w + bv.w;
+  BnFwdC ka, kb;
+  if (HOIST) ka = kb = bn_fwd_c(mean, rstd, weight, bias, (int)(e0 % cq_n));
+  // wave-uniform trip count (e - lane is the same for the wave's lanes; the ballots need the whole wave)
+  for (long long e = e0; e - (threadIdx.x & 63) < total4; e += 2 * S) {
+    const long long f = e + S;
+    const bool oka = e < total4, okb = f < total4;
+    if (!HOIST) {
+      ka = bn_fwd_c(mean, rstd, weight, bias, (int)((oka ? e : 0) % cq_n));
+      kb = bn_fwd_c(mean, rstd, weight, bias, (int)((okb ? f : 0) % cq_n));
+    }
+    float4 xa = z4, xb = z4, ra = z4, rb = z4;
+    if (oka) xa = reinterpret_cast<const float4*>(x)[e];
+    if (okb) xb = reinterpret_cast<const float4*>(x)[f];
     if (residual) {
-      float4 rv = reinterpret_cast<const float4*>(residual)[e];
-      o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+      if (oka) ra = reinterpret_cast<const float4*>(residual)[e];
+      if (okb) rb = reinterpret_cast<const float4*>(residual)[f];
     }
-    if (relu) {
-      o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
-    }
-    reinterpret_cast<float4*>(y)[e] = o;
-    am = amax4(am, o);
-    if (mask) {   // e - lane is a multiple of 64 (grid stride and block size are): one ballot per component
-      unsigned long long b0 = __ballot(o.x > 0.f), b1 = __ballot(o.y > 0.f), b2 = __ballot(o.z > 0.f),
-                         b3 = __ballot(o.w > 0.f);
-      if ((threadIdx.x & 63) == 0) {
-        unsigned long long* m = mask + (e >> 6) * 4;
-        m[0] = b0; m[1] = b1; m[2] = b2; m[3] = b3;
-      }
+    const float4 oa = bn_fwd_one(xa, ra, residual != nullptr, relu, ka);
+    const float4 ob = bn_fwd_one(xb, rb, residual != nullptr, relu, kb);
+    if (oka) { reinterpret_cast<float4*>(y)[e] = oa; am = amax4(am, oa); }
+    if (okb) { reinterpret_cast<float4*>(y)[f] = ob; am = amax4(am, ob); }
+    if (mask) {
+      bn_mask_store(mask, e, oa, oka);
+      if (f - (threadIdx.x & 63) < total4) bn_mask_store(mask, f, ob, okb);
     }
   }
   if (amax_bits) publish_amax(am, amax_bits);
 }
 
+struct BnBwdC { float4 mu, rs, wv, sg, sx; };
+__device__ __forceinline__ BnBwdC bn_bwd_c(const float* mean, const float* rstd, const float* weight, const float* sum_g,
+                                           const float* sum_gx, int cq) {
+  BnBwdC k;
+  k.mu = reinterpret_cast<const float4*>(mean)[cq]; k.rs = reinterpret_cast<const float4*>(rstd)[cq];
+  k.wv = reinterpret_cast<const float4*>(weight)[cq];
+  k.sg = reinterpret_cast<const float4*>(sum_g)[cq]; k.sx = reinterpret_cast<const float4*>(sum_gx)[cq];
+  return k;
+}
+__device__ __forceinline__ float4 bn_bwd_one(const float4& xv, const float4& g, float inv_n, const BnBwdC& k) {
+  float4 o;
+  o.x = k.wv.x * k.rs.x * (g.x - k.sg.x * inv_n - (xv.x - k.mu.x) * k.rs.x * k.sx.x * inv_n);
+  o.y = k.wv.y * k.rs.y * (g.y - k.sg.y * inv_n - (xv.y - k.mu.y) * k.rs.y * k.sx.y * inv_n);
+  o.z = k.wv.z * k.rs.z * (g.z - k.sg.z * inv_n - (xv.z - k.mu.z) * k.rs.z * k.sx.z * inv_n);
+  o.w = k.wv.w * k.rs.w * (g.w - k.sg.w * inv_n - (xv.w - k.mu.w) * k.rs.w * k.sx.w * inv_n);
+  return o;
+}
+__device__ __forceinline__ void relu_gate(float4& g, const float4& yv) {
+  g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
+  g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+}
+
+template <bool HOIST>
 __global__ void __launch_bounds__(256) k_bn_bwd_apply(const float* __restrict__ x, const float* __restrict__ dy,
                                                       const float* __restrict__ y, long long total4, int c,
                                                       float inv_n, const float* __restrict__ mean,
@@ -345,28 +400,41 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const float* __restrict__ 
                                                       float* __restrict__ dx, float* __restrict__ dres,
                                                       int* amax_bits) {
   const int cq_n = c >> 2;
+  const long long S = (long long)gridDim.x * blockDim.x;
+  const long long e0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const float4 z4 = make_float4(0, 0, 0, 0);
   float am = 0.f;
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total4;
-       e += (long long)gridDim.x * blockDim.x) {
-    int cq = (int)(e % cq_n);
-    float4 mu = reinterpret_cast<const float4*>(mean)[cq], rs = reinterpret_cast<const float4*>(rstd)[cq];
-    float4 wv = reinterpret_cast<const float4*>(weight)[cq];
-    float4 sg = reinterpret_cast<const float4*>(sum_g)[cq], sx = reinterpret_cast<const float4*>(sum_gx)[cq];
-    float4 xv = reinterpret_cast<const float4*>(x)[e];
-    float4 g = reinterpret_cast<const float4*>(dy)[e];
-    if (relu) {
-      float4 yv = mask ? mask_as_y(mask, e) : reinterpret_cast<const float4*>(y)[e];
-      g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
-      g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+  BnBwdC ka, kb;
+  if (HOIST) ka = kb = bn_bwd_c(mean, rstd, weight, sum_g, sum_gx, (int)(e0 % cq_n));
+  for (long long e = e0; e < total4; e += 2 * S) {
+    const long long f = e + S;
+    const bool okb = f < total4;
+    if (!HOIST) {
+      ka = bn_bwd_c(mean, rstd, weight, sum_g, sum_gx, (int)(e % cq_n));
+      kb = bn_bwd_c(mean, rstd, weight, sum_g, sum_gx, (int)((okb ? f : 0) % cq_n));
     }
-    float4 o;
-    o.x = wv.x * rs.x * (g.x - sg.x * inv_n - (xv.x - mu.x) * rs.x * sx.x * inv_n);
-    o.y = wv.y * rs.y * (g.y - sg.y * inv_n - (xv.y - mu.y) * rs.y * sx.y * inv_n);
-    o.z = wv.z * rs.z * (g.z - sg.z * inv_n - (xv.z - mu.z) * rs.z * sx.z * inv_n);
-    o.w = wv.w * rs.w * (g.w - sg.w * inv_n - (xv.w - mu.w) * rs.w * sx.w * inv_n);
-    reinterpret_cast<float4*>(dx)[e] = o;
-    am = amax4(am, o);
-    if (dres) reinterpret_cast<float4*>(dres)[e] = g;
+    float4 xa = reinterpret_cast<const float4*>(x)[e], ga = reinterpret_cast<const float4*>(dy)[e];
+    float4 xb = z4, gb = z4, ya = z4, yb = z4;
+    if (okb) {
+      xb = reinterpret_cast<const float4*>(x)[f];
+      gb = reinterpret_cast<const float4*>(dy)[f];
+    }
+    if (relu) {
+      ya = mask ? mask_as_y(mask, e) : reinterpret_cast<const float4*>(y)[e];
+      if (okb) yb = mask ? mask_as_y(mask, f) : reinterpret_cast<const float4*>(y)[f];
+      relu_gate(ga, ya);
+      relu_gate(gb, yb);
+    }
+    const float4 oa = bn_bwd_one(xa, ga, inv_n, ka);
+    reinterpret_cast<float4*>(dx)[e] = oa;
+    am = amax4(am, oa);
+    if (dres) reinterpret_cast<float4*>(dres)[e] = ga;
+    if (okb) {
+      const float4 ob = bn_bwd_one(xb, gb, inv_n, kb);
+      reinterpret_cast<float4*>(dx)[f] = ob;
+      am = amax4(am, ob);
+      if (dres) reinterpret_cast<float4*>(dres)[f] = gb;
+    }
   }
   if (amax_bits) publish_amax(am, amax_bits);
 }
@@ -512,8 +580,12 @@ int gcl_bn_apply(const float* x, int64_t n, int32_t c, const float* mean, const 
   long long total4 = n * (c / 4);
   long long g = cdiv(total4, 256);
   if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(k_bn_apply, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, total4, c, mean, rstd,
-                     weight, bias, residual, relu, y, (unsigned long long*)(relu ? relu_mask : nullptr), y_amax);
+  if ((g * 256) % (c / 4) == 0)
+    hipLaunchKernelGGL(k_bn_apply<true>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, total4, c, mean, rstd,
+                       weight, bias, residual, relu, y, (unsigned long long*)(relu ? relu_mask : nullptr), y_amax);
+  else
+    hipLaunchKernelGGL(k_bn_apply<false>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, total4, c, mean, rstd,
+                       weight, bias, residual, relu, y, (unsigned long long*)(relu ? relu_mask : nullptr), y_amax);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }
@@ -546,9 +618,14 @@ int gcl_bn_bwd_apply(const float* x, const float* dy, const float* y, const uint
   long long total4 = n * (c / 4);
   long long g = cdiv(total4, 256);
   if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, dy, y, total4, c,
-                     1.0f / (float)n, mean, rstd, weight, sum_g, sum_gx, relu, (const unsigned long long*)relu_mask, dx, dres,
-                     dx_amax);
+  if ((g * 256) % (c / 4) == 0)
+    hipLaunchKernelGGL(k_bn_bwd_apply<true>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, dy, y, total4, c,
+                       1.0f / (float)n, mean, rstd, weight, sum_g, sum_gx, relu, (const unsigned long long*)relu_mask, dx,
+                       dres, dx_amax);
+  else
+    hipLaunchKernelGGL(k_bn_bwd_apply<false>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, dy, y, total4, c,
+                       1.0f / (float)n, mean, rstd, weight, sum_g, sum_gx, relu, (const unsigned long long*)relu_mask, dx,
+                       dres, dx_amax);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }
