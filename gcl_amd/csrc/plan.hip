@@ -355,6 +355,8 @@ struct PassState {        // everything one forward pass leaves behind for its b
   unsigned char *pack_fwd = nullptr, *pack_bwd = nullptr;
   void* state = nullptr;
   bool forward_done = false, bwd_packed = false;
+  hipEvent_t fwd_packs = nullptr;      // recorded on the aux stream behind the forward packs of the pass
+  bool fwd_packs_pending = false;
   int32_t* not_ones = nullptr;      // device flag of the pass: some input feature differs from 1.0f (occupancy path off)
   void* key = nullptr;              // the pass's arena: how gcl_plan_backward / gcl_plan_release find it
 };
@@ -495,6 +497,10 @@ static int conv_forward(Plan& P, int i, float** y_out, float** stats_out, hipStr
     return GCL_OK;
   }
   const int wi = P.widx[op.w];
+  if (P.fwd_packs_pending && !A.dry) {      // first convolution that reads packed weights
+    GCL_CHECK_HIP(hipStreamWaitEvent(st, P.fwd_packs, 0));
+    P.fwd_packs_pending = false;
+  }
   int rc = ensure_amax(P, x, n_in * op.cin, st);
   if (rc) return rc;
   P.saved[i].x_amax = x.amax;
@@ -563,6 +569,7 @@ static int plan_forward(Plan& P, const float* x_in, void* const* bn_stats, float
   P.next_slot = 0;
   P.slots_exhausted = false;
   P.not_ones = nullptr;
+  P.fwd_packs_pending = false;
   P.slot_pool = A.take_n<int32_t>(P.n_slots * GCL_AMAX_WORDS);
   if (!A.dry) GCL_CHECK_HIP(hipMemsetAsync(P.slot_pool, 0, (size_t)P.n_slots * GCL_AMAX_WORDS * sizeof(int32_t), st));
   // all convolution kernels: max|W| in one launch, forward packs in one launch (WeightAmaxGroup)
@@ -580,8 +587,22 @@ static int plan_forward(Plan& P, const float* x_in, void* const* bn_stats, float
     if (rc) return rc;
     if (!P.eval || P.eval_repack) {
       const long long* tab = (const long long*)P.state;
-      PLAN_CALL(gcl_amax_multi((const float* const*)tab, (const int64_t*)(tab + nw), (int32_t)nw, P.w_amax, (void*)st));
-      PLAN_CALL(gcl_pack_weights_multi((const int64_t*)(tab + 2 * nw), (int32_t)nw, P.wgs_fwd, 4, P.w_amax, P.pack_fwd, (void*)st));
+      // training with an aux stream: max|W| and the forward packs are made THERE, beside the first layer (whose kernels
+      // read the fp32 weights); the main stream waits for them in front of its first packed convolution (conv_forward)
+      hipStream_t ps = st;
+      if (!P.eval && P.aux && P.n_bwd) ps = fork_aux(P, st);
+      PLAN_CALL(gcl_amax_multi((const float* const*)tab, (const int64_t*)(tab + nw), (int32_t)nw, P.w_amax, (void*)ps));
+      PLAN_CALL(gcl_pack_weights_multi((const int64_t*)(tab + 2 * nw), (int32_t)nw, P.wgs_fwd, 4, P.w_amax, P.pack_fwd, (void*)ps));
+      if (ps != st) {
+        if (P.events_used == P.events.size()) {
+          hipEvent_t e;
+          GCL_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+          P.events.push_back(e);
+        }
+        P.fwd_packs = P.events[P.events_used++];
+        GCL_CHECK_HIP(hipEventRecord(P.fwd_packs, ps));
+        P.fwd_packs_pending = true;
+      }
     }
   }
   // with an aux stream the input-gradient packs (needed by the first record of the backward pass) are made there now,
