@@ -34,5 +34,8 @@ for (t, cin, cout, stride, tr) in LAYERS:
         torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 10 * 1e3
     tot += us
-    print(f"t={t} {cin:3d}->{cout:3d} s{stride}{' tr' if tr else '   '} n={n:7d}: {us:7.1f} us  checksum {float(y.double().sum()):.6e}")
+    pairs = mgr.get_kernel_map(t // 2 if tr else t, 3, stride).n_pairs
+    print(f"t={t} {cin:3d}->{cout:3d} s{stride}{' tr' if tr else '   '} n={n:7d} pairs={pairs:8d}: {us:7.1f} us  "
+          f"{2e-6 * pairs * cin * cout / us:6.1f} TF/s fp32-equivalent (x3 MFMA terms), "
+          f"{(pairs * cin + len(y) * cout) * 4e-6 / us:5.2f} TB/s gathered+written  checksum {float(y.double().sum()):.6e}")
 print(f"sum {tot:.1f} us")
