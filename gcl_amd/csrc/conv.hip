@@ -192,6 +192,10 @@ __global__ void __launch_bounds__(256) k_conv_fwd(const float* __restrict__ X, c
 // [0] wait at barrier #1  [1] LDS writes + next-step load issue  [2] wait at barrier #2  [3] LDS reads + split + MFMA
 // [4] prologue  [5] epilogue  [6] wave-steps  [7] wave-steps with MFMA work
 __device__ unsigned long long g_stamps[8];
+// per workgroup of the LAST k_conv_fwd_split launch: {start, end (s_memrealtime, 100 MHz), steps, tile | column block << 32}
+// (tools/wg_trace.py)
+constexpr int WG_TRACE_MAX = 16384;
+__device__ unsigned long long g_wgtrace[WG_TRACE_MAX * 4];
 #define STAMP(V)                                  \
   __builtin_amdgcn_sched_barrier(0);              \
   unsigned long long V = __builtin_amdgcn_s_memtime(); \
@@ -591,6 +595,10 @@ __global__ void __launch_bounds__(256, GCL_FWD_MIN_WAVES(NB, PL)) k_conv_fwd_spl
     }                                        \
   }
 
+#ifdef GCL_STAMPS
+  const unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long wg_steps = 0;
+#endif
   if (wgmask != 0u) {
     unsigned m_rest = wgmask & (wgmask - 1);
     float4 st[4];
@@ -674,6 +682,7 @@ __global__ void __launch_bounds__(256, GCL_FWD_MIN_WAVES(NB, PL)) k_conv_fwd_spl
       has1 = has2;
     }
 #ifdef GCL_STAMPS
+    wg_steps = st_n;
     if (l == 0) {      // [0] MFMA phase  [1] wait for the gather + LDS writes  [2] load issue  [3] barrier  [6] steps  [7] own steps
       atomicAdd(&g_stamps[0], st_c); atomicAdd(&g_stamps[1], st_w); atomicAdd(&g_stamps[2], st_i);
       atomicAdd(&g_stamps[3], st_b); atomicAdd(&g_stamps[6], st_n); atomicAdd(&g_stamps[7], st_m);
@@ -684,6 +693,12 @@ __global__ void __launch_bounds__(256, GCL_FWD_MIN_WAVES(NB, PL)) k_conv_fwd_spl
 #undef GCL_LOAD_B
 #undef GCL_STORE_LDS
 #undef GCL_ADVANCE
+#ifdef GCL_STAMPS
+  if (t == 0 && blockIdx.x < WG_TRACE_MAX && gridDim.y == 1) {
+    unsigned long long* o = g_wgtrace + (long long)blockIdx.x * 4;
+    o[0] = wg_t0; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = wg_steps; o[3] = ((unsigned long long)byy << 32) | bxx;
+  }
+#endif
   if (!active && !stats) return;
   int orow_l = -1;
   if (active && (l < 32) && (row0 + l < n_out)) orow_l = order ? order[row0 + l] : (int)(row0 + l);
@@ -2082,6 +2097,11 @@ using namespace gcl;
 extern "C" {
 
 #ifdef GCL_STAMPS
+int gcl_debug_wgtrace(unsigned long long* out_host, int n_wg) {
+  if (n_wg > WG_TRACE_MAX) n_wg = WG_TRACE_MAX;
+  GCL_CHECK_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_wgtrace), sizeof(unsigned long long) * 4 * n_wg));
+  return GCL_OK;
+}
 int gcl_debug_stamps(unsigned long long* out_host, int reset) {
   if (out_host) GCL_CHECK_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 8));
   if (reset) {

@@ -9,7 +9,7 @@ import torch  # noqa: E402
 import gcl_amd.MinkowskiEngine as ME  # noqa: E402
 from gcl_amd import synthetic  # noqa: E402
 
-batch = synthetic.make_train_batch(100, batch_size=4, group_mode="fixed16")
+batch = synthetic.make_train_batch(100, batch_size=int(os.environ.get("LB_BATCH", "4")), group_mode="fixed16")
 dev = "cuda:0"
 C = batch["sinput_C"].to(dev)
 LAYERS = [(1, 32, 32, 1, False), (1, 64, 64, 1, False), (2, 64, 64, 1, False), (1, 32, 64, 2, False), (2, 64, 128, 2, False),

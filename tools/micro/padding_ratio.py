@@ -26,6 +26,10 @@ for t_in, ks, stride, tables, pairs in m.map_specs():
             tt = np.concatenate([t, np.zeros((K, pad), bool)], 1).reshape(K, -1, rows)
             return int(tt.any(2).sum()) * rows
         u32, u16, u64 = units(32), units(16), units(64)
+        pad = (-n) % 128
+        wg = np.concatenate([t, np.zeros((K, pad), bool)], 1).reshape(K, -1, 128).any(2).sum(0)      # offsets per 128-row workgroup
+        print(f"    workgroup (128 rows) offset unions: tiles {len(wg)} mean {wg.mean():.1f} p50 {np.percentile(wg, 50):.0f} "
+              f"p90 {np.percentile(wg, 90):.0f} max {wg.max()}  sum {int(wg.sum())}")
         print(f"map ({t_in},{ks},{stride}) {'T' if tr else 'N'}: rows {n:7d} K {K:2d} pairs {real:9d}  "
               f"visited/pairs: 64-row {u64 / real:5.2f}  32-row {u32 / real:5.2f}  16-row {u16 / real:5.2f}   "
               f"pairs/row {real / n:5.2f}")
