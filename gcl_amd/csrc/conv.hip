@@ -765,6 +765,233 @@ __global__ void __launch_bounds__(256, GCL_FWD_MIN_WAVES(NB, PL)) k_conv_fwd_spl
 
 // ---------------------------------------------------------------------------------------------------
 // HALO-TILE forward kernel (stride-1 3^3 maps; tiles from gcl_table_sort_halo).  The (offset, slice) loop of
+// ---- the same product with EIGHT waves per workgroup: 128 rows x 128 output columns (fp16x3 on plane images only) --------
+// k_conv_fwd_split<NB = 2> covers 128 rows x 64 columns per workgroup, so a layer with Cout = 256 gathers every neighbour
+// row four times (once per column block; from the XCD's L2 after the first, but the L2 -> CU gather path is what these
+// launches load most).  Here the four row tiles are shared by two waves each -- wave (tile wt, column half ch) owns 32 rows
+// x 64 columns like a wave of the NB = 2 instance, same registers -- so a gathered row feeds 128 columns, the pair
+// splits the tile's gather (2 instead of 4 loads per lane and step) and the weight block of a step is 128 columns wide
+// (2 loads per lane as before).  A tiles are double-buffered (the partner may still be reading), the index table holds all
+// 27 offsets: 77.5 KB of LDS, two workgroups = 16 waves per CU as before.
+template <bool PRE, bool EPI>
+__global__ void __launch_bounds__(512, 2) k_conv_fwd_wide(const float* __restrict__ X, const u32x4* __restrict__ Wp,
+                                                          const int* __restrict__ tbl, const int* __restrict__ order,
+                                                          const int* __restrict__ tile_mask, long long n_out, int K, int cin,
+                                                          int cout, const float* __restrict__ bias, float* __restrict__ Y,
+                                                          int swizzle, float* __restrict__ stats,
+                                                          const int* __restrict__ x_amax, const int* __restrict__ w_amax,
+                                                          unsigned x_bytes, ConvEpi epi) {
+  static_assert(PRE, "plane images only");
+  constexpr int PL = 4, NPL = 2, NB = 2, NBT = 4;
+  constexpr int BLK = NBT * 2 * NPL * 64;               // 1024 uint4 per (k, cc) weight block of the workgroup
+  const float a_scale = amax_scale(x_amax);
+  const float out_scale = 1.f / (a_scale * amax_scale(w_amax));
+  __shared__ __attribute__((aligned(16))) float Asm[2][4][32][32];
+  __shared__ __attribute__((aligned(16))) u32x4 Bsm[2][BLK];
+  __shared__ __attribute__((aligned(16))) int Ism[4][27][32];
+  __shared__ unsigned wmask[4];
+  const int t = threadIdx.x, l = t & 63, w8 = t >> 6, wt = w8 & 3, ch = w8 >> 2;
+  const int i = l & 31, h = l >> 5;
+  unsigned bxx = blockIdx.x, byy;
+  const bool heavy_first = (swizzle & 16) != 0;
+  const unsigned nrw = (unsigned)((n_out + CONV_ROWS - 1) / CONV_ROWS);
+  {
+    const unsigned ncb = (unsigned)(cout / (32 * NBT));
+    const unsigned xcd = bxx & 7u, slot = bxx >> 3;
+    byy = slot % ncb;
+    bxx = (slot / ncb) * 8u + xcd;
+    if (bxx >= nrw) return;
+  }
+  if (heavy_first) bxx = nrw - 1u - bxx;
+  const long long tile = (long long)bxx * 4 + wt;
+  const long long row0 = tile * 32;
+  const bool active = row0 < n_out;
+  const int nb0 = byy * NBT;
+  const int TNB = cout >> 5, CC = cin >> 5;
+  const int p = l & 7, rsub = l >> 3;
+
+  f32x16 acc[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+
+  unsigned mymask = 0u;
+  if (active) mymask = tile_mask ? (unsigned)tile_mask[tile] : ((1u << K) - 1u);
+  mymask = __builtin_amdgcn_readfirstlane(mymask);
+  if (l == 0 && ch == 0) wmask[wt] = mymask;
+  for (int e = l + 64 * ch; e < K * 32; e += 128) {
+    const int k = e >> 5, r = e & 31;
+    int v = -1;
+    if (active && ((mymask >> k) & 1u) && row0 + r < n_out) v = tbl ? tbl[(long long)k * n_out + row0 + r] : (int)(row0 + r);
+    Ism[wt][k][(r & 7) * 4 + (r >> 3)] = v;
+  }
+  __syncthreads();
+  const unsigned wgmask = wmask[0] | wmask[1] | wmask[2] | wmask[3];
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)x_bytes, 0x00020000);
+  const unsigned row_bytes = (unsigned)cin * 4u;
+#define GCLW_GATHER_A(KK, CCV)                                                                                  \
+  {                                                                                                             \
+    const int4 ri_ = *reinterpret_cast<const int4*>(&Ism[wt][(KK)][rsub * 4]);                                 \
+    const unsigned co_ = (unsigned)(CCV)*128u + (unsigned)p * 16u;                                              \
+    const unsigned r0_ = (unsigned)(ch ? ri_.z : ri_.x), r1_ = (unsigned)(ch ? ri_.w : ri_.y);                  \
+    st[0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(r0_ * row_bytes + co_), 0, 0)); \
+    st[1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(r1_ * row_bytes + co_), 0, 0)); \
+  }
+#define GCLW_LOAD_B(KK, CCV)                                                                     \
+  {                                                                                              \
+    const u32x4* src_ = Wp + (((long long)(KK)*CC + (CCV)) * TNB + nb0) * (2 * NPL * 64);        \
+    br[0] = src_[t];                                                                             \
+    br[1] = src_[512 + t];                                                                       \
+  }
+#define GCLW_STORE_LDS(MINE, BUF)                                                                            \
+  {                                                                                                          \
+    if (MINE) {                                                                                              \
+      _Pragma("unroll") for (int ps = 0; ps < 2; ++ps) {                                                     \
+        const int row_ = rsub + 8 * (2 * ch + ps);                                                           \
+        *reinterpret_cast<float4*>(&Asm[BUF][wt][row_][(p ^ a_swz(row_)) << 2]) = st[ps];                    \
+      }                                                                                                      \
+    }                                                                                                        \
+    Bsm[BUF][t] = br[0];                                                                                     \
+    Bsm[BUF][512 + t] = br[1];                                                                               \
+  }
+#define GCLW_ADVANCE(KV, CV, HAS)            \
+  {                                          \
+    CV += 1;                                 \
+    if (CV == CC) {                          \
+      CV = 0;                                \
+      if (m_rest) {                          \
+        KV = __builtin_ctz(m_rest);          \
+        m_rest &= m_rest - 1;                \
+      } else {                               \
+        HAS = false;                         \
+      }                                      \
+    }                                        \
+  }
+  if (wgmask != 0u) {
+    unsigned m_rest = wgmask & (wgmask - 1);
+    float4 st[2];
+    u32x4 br[2];
+    int k0 = __builtin_ctz(wgmask);
+    bool mine0 = (mymask >> k0) & 1u;
+    if (mine0) GCLW_GATHER_A(k0, 0);
+    GCLW_LOAD_B(k0, 0);
+    int k1 = k0, c1 = 0;
+    bool has1 = true;
+    GCLW_ADVANCE(k1, c1, has1);
+    GCLW_STORE_LDS(mine0, 0);
+    bool mine1 = false;
+    if (has1) {
+      mine1 = (mymask >> k1) & 1u;
+      if (mine1) GCLW_GATHER_A(k1, c1);
+      GCLW_LOAD_B(k1, c1);
+    }
+    __syncthreads();
+    int buf = 0;
+    bool mine_cur = mine0;
+    while (true) {
+      if (mine_cur) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          u32x4 ap[3];
+          ap[0] = *reinterpret_cast<const u32x4*>(&Asm[buf][wt][i][((2 * m + h) ^ a_swz(i)) << 2]);
+          ap[1] = *reinterpret_cast<const u32x4*>(&Asm[buf][wt][i][((4 + 2 * m + h) ^ a_swz(i)) << 2]);
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            const u32x4* bb = &Bsm[buf][(((ch * 2 + b) * 2 + m) * NPL) * 64 + l];
+            u32x4 bp[3];
+            bp[0] = bb[0];
+            bp[1] = bb[64];
+            mfma_terms<PL>(ap, bp, acc[b]);
+          }
+        }
+      }
+      if (!has1) break;
+      // next step: registers -> the OTHER buffers (the partner wave may still be reading this step's A tile)
+      GCLW_STORE_LDS(mine1, buf ^ 1);
+      int k2 = k1, c2 = c1;
+      bool has2 = true, mine2 = false;
+      GCLW_ADVANCE(k2, c2, has2);
+      if (has2) {
+        mine2 = (mymask >> k2) & 1u;
+        if (mine2) GCLW_GATHER_A(k2, c2);
+        GCLW_LOAD_B(k2, c2);
+      }
+      __syncthreads();
+      buf ^= 1;
+      mine_cur = mine1;
+      mine1 = mine2;
+      k1 = k2;
+      c1 = c2;
+      has1 = has2;
+    }
+  }
+#undef GCLW_GATHER_A
+#undef GCLW_LOAD_B
+#undef GCLW_STORE_LDS
+#undef GCLW_ADVANCE
+  if (!active && !stats) return;
+  int orow_l = -1;
+  if (active && (l < 32) && (row0 + l < n_out)) orow_l = order ? order[row0 + l] : (int)(row0 + l);
+  float ymax = 0.f;
+  if (stats) __syncthreads();      // every wave is done with the A tiles: they become the column-sum scratch
+  float* const ssc = &Asm[ch][wt][0][0];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int col = (nb0 + ch * 2 + b) * 32 + i;
+    float bvv = bias ? bias[col] : 0.f;
+    float csc = (EPI && epi.col_scale) ? epi.col_scale[col] * out_scale : out_scale;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(bvv) : "v"(bvv));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(csc) : "v"(csc));
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int orow = __shfl(orow_l, (r & 3) + 8 * (r >> 2) + 4 * h);
+      if (orow >= 0) {
+        float v = acc[b][r] * csc + bvv;
+        if (EPI && epi.residual) v += epi.residual[(long long)orow * cout + col];
+        if (EPI && epi.relu) v = fmaxf(v, 0.f);
+        Y[(long long)orow * cout + col] = v;
+        s1 += v;
+        s2 += v * v;
+        if (EPI) ymax = fmaxf(ymax, fabsf(v));
+      }
+    }
+    if (stats) {
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (h == 0) {
+        ssc[b * 32 + i] = s1;
+        ssc[NB * 32 + b * 32 + i] = s2;
+      }
+    }
+  }
+  if (stats) {
+    __syncthreads();
+    if (wt == 0 && h == 0) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int col = (nb0 + ch * 2 + b) * 32 + i;
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {      // the four row tiles in order, as the 4-wave kernel adds its waves
+          const float* o = &Asm[ch][ww][0][0];
+          t1 += o[b * 32 + i];
+          t2 += o[NB * 32 + b * 32 + i];
+        }
+        stats[((long long)bxx * 2 + 0) * cout + col] = t1;
+        stats[((long long)bxx * 2 + 1) * cout + col] = t2;
+      }
+    }
+    if (!active) return;
+  }
+  if (EPI && epi.y_amax) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o));
+    if (l == 0) amax_slot_publish(epi.y_amax, __float_as_int(ymax), (unsigned)(tile * 2 + ch));
+  }
+}
+
 // k_conv_fwd_split gathers every neighbour INSTANCE of a 128-row tile from memory (~8 per output row and slice on the
 // KITTI batch, served by the Infinity Cache at its gather rate -- that rate, not the MFMA pipe, bounds those kernels).
 // Here the tile is a compact blob of 128 rows in fine spatial order: its ~170 DISTINCT input rows (the halo) are
@@ -2308,6 +2535,23 @@ int gcl_conv_fwd_fused(const float* x, int64_t n_in, int32_t x_is_planes, const 
 #define LAUNCH_SPLIT_NB2(PLV)                                                            \
   {                                                                                      \
     if (nb >= 2) LAUNCH_SPLIT(2, PLV); else LAUNCH_SPLIT(1, PLV);                        \
+  }
+  // TUNING KNOB, default off: eight-wave workgroups (128 rows x 128 columns, k_conv_fwd_wide) for plane-image launches with
+  // Cout a multiple of 128 (GCL_FWD_WIDE=1 or flag GCL_CONV_WIDE).  Bitwise the same results with half the gathered bytes
+  // and 88 instead of 104 VGPRs -- and the same launch times (profiles/r03_conv_experiments.txt, 13).
+  static const int wide = [] { const char* e = getenv("GCL_FWD_WIDE"); return e ? atoi(e) : 0; }();
+  if ((wide || (flags & GCL_CONV_WIDE)) && prec == 4 && x_is_planes && cout % 128 == 0 && colgroup && !swz && !ranges &&
+      units < 2) {
+    const dim3 wgrid((unsigned)(cdiv(gx, 8) * 8 * (cout / 128)));
+    const int wswz = 2 | ((heavy_first && tile_mask) ? 16 : 0);
+    if (use_epi)
+      hipLaunchKernelGGL((k_conv_fwd_wide<true, true>), wgrid, dim3(512), 0, st, x, (const u32x4*)wp, tbl, order, tile_mask,
+                         (long long)n_out, K, cin, cout, bias, y, wswz, stats, x_amax, w_amax, x_bytes, epi);
+    else
+      hipLaunchKernelGGL((k_conv_fwd_wide<true, false>), wgrid, dim3(512), 0, st, x, (const u32x4*)wp, tbl, order, tile_mask,
+                         (long long)n_out, K, cin, cout, bias, y, wswz, stats, x_amax, w_amax, x_bytes, epi);
+    GCL_CHECK_LAUNCH();
+    return GCL_OK;
   }
   if (prec == 0) {
     if (nb == 4) LAUNCH_F32(4); else if (nb == 2) LAUNCH_F32(2); else LAUNCH_F32(1);

@@ -224,6 +224,9 @@ int gcl_split_planes(const float* x, int64_t n, int32_t c, const int32_t* amax, 
  * CONTIGUOUS range of row tiles, so that the input rows a tile gathers are mostly the ones its neighbours on the same XCD
  * just gathered.  Launch-order hint only. */
 #define GCL_CONV_XCD_RANGES 1
+#define GCL_CONV_WIDE 2     /* run the eight-wave kernel (128 rows x 128 columns per workgroup) where it applies: fp16x3 on
+                               plane images, Cout a multiple of 128; bitwise the same results as the four-wave kernel
+                               (same as GCL_FWD_WIDE=1; measured neither faster nor slower) */
 int gcl_conv_fwd(const float* x, int64_t n_in, int32_t x_is_planes, const void* wp, int32_t prec, const int32_t* x_amax,
                  const int32_t* w_amax, const int32_t* tbl, const int32_t* order, const int32_t* tile_mask,
                  int64_t n_out, int32_t K,
