@@ -438,6 +438,7 @@ class _TraceCtx:
 # entry format, so that NetworkPlan.from_tape can turn them into the operator records of gcl_plan_forward_eval.  Nothing
 # is replayed from it (there is no backward pass); ME.conv_bn adds the "convbn" entries itself.
 _EVAL_TRACE = None
+CONV_TALL = 4      # include/gcl_amd.h GCL_CONV_TALL: inference launches (conv_bn_eval here, the plan's eval records)
 
 
 def sparse_conv(x, W, kmap, n_out, transpose, bias, mgr, want_stats=False):
@@ -917,7 +918,7 @@ def conv_bn_eval(x, W, kmap, n_out, transpose, scale, shift, residual=None, relu
                                       _lib.ptr(w_amax), _lib.ptr(tbl), _lib.ptr(order), _lib.ptr(tile_mask), n_out, K,
                                       cin, cout, _lib.ptr(shift, torch.float32), _lib.ptr(scale, torch.float32),
                                       _lib.ptr(res), int(relu), _lib.ptr(slot), _lib.ptr(y), None,
-                                      getattr(tbl, "_gcl_flags", 0), _lib.stream()),
+                                      getattr(tbl, "_gcl_flags", 0) | CONV_TALL, _lib.stream()),
                "gcl_conv_fwd_fused")
     tag_amax(y, slot)
     return y

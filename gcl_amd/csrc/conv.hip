@@ -765,6 +765,238 @@ __global__ void __launch_bounds__(256, GCL_FWD_MIN_WAVES(NB, PL)) k_conv_fwd_spl
 
 // ---------------------------------------------------------------------------------------------------
 // HALO-TILE forward kernel (stride-1 3^3 maps; tiles from gcl_table_sort_halo).  The (offset, slice) loop of
+// ---- inference on small clouds: SIXTEEN waves per workgroup, the offsets of a tile cut into four fixed groups -----------
+// A pass over one or two clouds launches a handful of workgroups on the deep layers (17 k voxels: 28 row tiles at stride 4, 8
+// at stride 8), and each of them walks up to 27 offsets x Cin / 32 dependent steps alone on its CU: 9 launches of ~136 us
+// were half of a 2.4 ms pass.  Here four groups of four waves share the 128 rows of a tile; group g runs the offsets
+// k with 4 k / K == g (FIXED ranges of the offset index, not of the tile's mask) exactly like a k_conv_fwd_split
+// workgroup -- own weight blocks, own wave-private A tiles -- and the four partial accumulators are added through LDS in
+// group order: y = ((g0 + g1) + g2) + g3.  A row's result therefore depends on the layer's shape only, never on the rows
+// it shares a tile or a batch with (batching clouds stays bitwise neutral), and nothing leaves the CU (no scratch, no
+// atomics).  fp16x3 on fp32 rows (split in the kernel), 64 columns per workgroup, no BatchNorm statistics: the inference
+// launches.  141.5 KB of LDS: one workgroup = 16 waves per CU, as many waves as four k_conv_fwd_split workgroups.
+template <bool EPI>
+__global__ void __launch_bounds__(1024, 1) k_conv_fwd_tall(const float* __restrict__ X, const u32x4* __restrict__ Wp,
+                                                          const int* __restrict__ tbl, const int* __restrict__ order,
+                                                          const int* __restrict__ tile_mask, long long n_out, int K, int cin,
+                                                          int cout, const float* __restrict__ bias, float* __restrict__ Y,
+                                                          int swizzle, const int* __restrict__ x_amax,
+                                                          const int* __restrict__ w_amax, unsigned x_bytes, ConvEpi epi) {
+  constexpr int PL = 4, NPL = 2, NB = 2, G = 4;
+  constexpr int BLK = NB * 2 * NPL * 64;                // 512 uint4 per (k, cc) weight block of a group
+  const float a_scale = amax_scale(x_amax);
+  const float out_scale = 1.f / (a_scale * amax_scale(w_amax));
+  // [A tiles: 16 waves x 4 KB][weight blocks: 4 groups x 2 buffers x 8 KB]; after the loop the same 128 KB hold the partial
+  // accumulators of groups 1 - 3 (96 KB)
+  __shared__ __attribute__((aligned(16))) float lds[16 * 1024 + G * 2 * BLK * 4];
+  __shared__ __attribute__((aligned(16))) int Ism[4][27][32];
+  __shared__ unsigned wmask[G][4];
+  float (*Asm)[32][32] = reinterpret_cast<float (*)[32][32]>(lds);
+  u32x4* const Ball = reinterpret_cast<u32x4*>(lds + 16 * 1024);
+  const int t = threadIdx.x, l = t & 63, w16 = t >> 6, wt = w16 & 3, g = w16 >> 2, tg = t & 255;
+  const int i = l & 31, h = l >> 5;
+  u32x4* const Bg = Ball + g * 2 * BLK;
+  unsigned bxx = blockIdx.x, byy;
+  const bool heavy_first = (swizzle & 16) != 0;
+  const unsigned nrw = (unsigned)((n_out + CONV_ROWS - 1) / CONV_ROWS);
+  {
+    const unsigned ncb = (unsigned)(cout / (32 * NB));
+    const unsigned xcd = bxx & 7u, slot = bxx >> 3;
+    byy = slot % ncb;
+    bxx = (slot / ncb) * 8u + xcd;
+    if (bxx >= nrw) return;
+  }
+  if (heavy_first) bxx = nrw - 1u - bxx;
+  const long long tile = (long long)bxx * 4 + wt;
+  const long long row0 = tile * 32;
+  const bool active = row0 < n_out;
+  const int nb0 = byy * NB;
+  const int TNB = cout >> 5, CC = cin >> 5;
+  const int p = l & 7, rsub = l >> 3;
+  // offsets of group g: k with 4 k / K == g
+  unsigned gsel = 0u;
+  for (int k = 0; k < K; ++k)
+    if (4 * k / K == g) gsel |= 1u << k;
+
+  f32x16 acc[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+
+  unsigned tmask = 0u;
+  if (active) tmask = tile_mask ? (unsigned)tile_mask[tile] : ((1u << K) - 1u);
+  tmask = __builtin_amdgcn_readfirstlane(tmask);
+  const unsigned mymask = tmask & gsel;
+  if (l == 0) wmask[g][wt] = mymask;
+  for (int e = l + 64 * g; e < K * 32; e += 64 * G) {      // the four waves of a tile share the index loads
+    const int k = e >> 5, r = e & 31;
+    int v = -1;
+    if (active && ((tmask >> k) & 1u) && row0 + r < n_out) v = tbl[(long long)k * n_out + row0 + r];
+    Ism[wt][k][(r & 7) * 4 + (r >> 3)] = v;
+  }
+  __syncthreads();
+  const unsigned wgmask = wmask[g][0] | wmask[g][1] | wmask[g][2] | wmask[g][3];
+  int n_iter = 0;      // barriers every wave takes: the longest group's steps
+#pragma unroll
+  for (int q = 0; q < G; ++q) {
+    const int c = __builtin_popcount(wmask[q][0] | wmask[q][1] | wmask[q][2] | wmask[q][3]) * CC;
+    n_iter = c > n_iter ? c : n_iter;
+  }
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)x_bytes, 0x00020000);
+  const unsigned row_bytes = (unsigned)cin * 4u;
+#define GCLT_GATHER_A(KK, CCV)                                                                                  \
+  {                                                                                                             \
+    const int4 ri_ = *reinterpret_cast<const int4*>(&Ism[wt][(KK)][rsub * 4]);                                 \
+    const unsigned co_ = (unsigned)(CCV)*128u + (unsigned)p * 16u;                                              \
+    st[0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)((unsigned)ri_.x * row_bytes + co_), 0, 0)); \
+    st[1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)((unsigned)ri_.y * row_bytes + co_), 0, 0)); \
+    st[2] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)((unsigned)ri_.z * row_bytes + co_), 0, 0)); \
+    st[3] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)((unsigned)ri_.w * row_bytes + co_), 0, 0)); \
+  }
+#define GCLT_LOAD_B(KK, CCV)                                                                     \
+  {                                                                                              \
+    const u32x4* src_ = Wp + (((long long)(KK)*CC + (CCV)) * TNB + nb0) * (2 * NPL * 64);        \
+    br[0] = src_[tg];                                                                            \
+    br[1] = src_[256 + tg];                                                                      \
+  }
+#define GCLT_STORE_LDS(MINE, BUF)                                                                            \
+  {                                                                                                          \
+    if (MINE) {                                                                                              \
+      _Pragma("unroll") for (int ps = 0; ps < 4; ++ps)                                                       \
+          *reinterpret_cast<float4*>(&Asm[w16][rsub + 8 * ps][(p ^ a_swz(rsub + 8 * ps)) << 2]) = st[ps];    \
+    }                                                                                                        \
+    Bg[(BUF)*BLK + tg] = br[0];                                                                              \
+    Bg[(BUF)*BLK + 256 + tg] = br[1];                                                                        \
+  }
+#define GCLT_ADVANCE(KV, CV, HAS)            \
+  {                                          \
+    CV += 1;                                 \
+    if (CV == CC) {                          \
+      CV = 0;                                \
+      if (m_rest) {                          \
+        KV = __builtin_ctz(m_rest);          \
+        m_rest &= m_rest - 1;                \
+      } else {                               \
+        HAS = false;                         \
+      }                                      \
+    }                                        \
+  }
+  if (n_iter > 0) {
+    unsigned m_rest = wgmask ? (wgmask & (wgmask - 1)) : 0u;
+    float4 st[4];
+    u32x4 br[2];
+    bool has0 = wgmask != 0u;
+    int k0 = has0 ? __builtin_ctz(wgmask) : 0;
+    bool mine0 = has0 && ((mymask >> k0) & 1u);
+    int k1 = k0, c1 = 0;
+    bool has1 = has0;
+    if (has0) {
+      if (mine0) GCLT_GATHER_A(k0, 0);
+      GCLT_LOAD_B(k0, 0);
+      GCLT_ADVANCE(k1, c1, has1);
+      GCLT_STORE_LDS(mine0, 0);
+    }
+    bool mine1 = false;
+    if (has1) {
+      mine1 = (mymask >> k1) & 1u;
+      if (mine1) GCLT_GATHER_A(k1, c1);
+      GCLT_LOAD_B(k1, c1);
+    }
+    __syncthreads();
+    int buf = 0;
+    bool mine_cur = mine0, has_cur = has0;
+    for (int it = 0; it < n_iter; ++it) {
+      if (mine_cur) {
+        WAVE_FENCE();
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          u32x4 ap[3];
+          float4 f0 = *reinterpret_cast<const float4*>(&Asm[w16][i][((4 * m + 2 * h) ^ a_swz(i)) << 2]);
+          float4 f1 = *reinterpret_cast<const float4*>(&Asm[w16][i][((4 * m + 2 * h + 1) ^ a_swz(i)) << 2]);
+          split8<PL>(f0, f1, a_scale, ap);
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            const u32x4* bb = &Bg[buf * BLK + ((b * 2 + m) * NPL) * 64 + l];
+            u32x4 bp[3];
+            bp[0] = bb[0];
+            bp[1] = bb[64];
+            mfma_terms<PL>(ap, bp, acc[b]);
+          }
+        }
+      }
+      (void)has_cur;
+      if (has1) {      // next step: registers -> LDS (A: own tile, after this wave's reads; B: the group's other buffer)
+        WAVE_FENCE();
+        GCLT_STORE_LDS(mine1, buf ^ 1);
+      }
+      int k2 = k1, c2 = c1;
+      bool has2 = has1, mine2 = false;
+      if (has1) GCLT_ADVANCE(k2, c2, has2);
+      if (has2) {
+        mine2 = (mymask >> k2) & 1u;
+        if (mine2) GCLT_GATHER_A(k2, c2);
+        GCLT_LOAD_B(k2, c2);
+      }
+      __syncthreads();
+      buf ^= 1;
+      has_cur = has1;
+      mine_cur = has1 && mine1;
+      mine1 = mine2;
+      k1 = k2;
+      c1 = c2;
+      has1 = has2;
+    }
+  }
+#undef GCLT_GATHER_A
+#undef GCLT_LOAD_B
+#undef GCLT_STORE_LDS
+#undef GCLT_ADVANCE
+  // partial accumulators of groups 1 - 3 through LDS (the loop's last barrier has passed: tiles and weight blocks are free)
+  float* const red = lds;      // [g - 1][wt][b * 16 + r][64 lanes]
+  if (g > 0) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(((g - 1) * 4 + wt) * (NB * 16) + b * 16 + r) * 64 + l] = acc[b][r];
+  }
+  __syncthreads();
+  if (g > 0 || !active) return;
+#pragma unroll
+  for (int q = 0; q < G - 1; ++q)      // group order: ((g0 + g1) + g2) + g3
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[b][r] += red[((q * 4 + wt) * (NB * 16) + b * 16 + r) * 64 + l];
+  int orow_l = -1;
+  if ((l < 32) && (row0 + l < n_out)) orow_l = order ? order[row0 + l] : (int)(row0 + l);
+  float ymax = 0.f;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int col = (nb0 + b) * 32 + i;
+    float bvv = bias ? bias[col] : 0.f;
+    float csc = (EPI && epi.col_scale) ? epi.col_scale[col] * out_scale : out_scale;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(bvv) : "v"(bvv));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(csc) : "v"(csc));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int orow = __shfl(orow_l, (r & 3) + 8 * (r >> 2) + 4 * h);
+      if (orow >= 0) {
+        float v = acc[b][r] * csc + bvv;
+        if (EPI && epi.residual) v += epi.residual[(long long)orow * cout + col];
+        if (EPI && epi.relu) v = fmaxf(v, 0.f);
+        Y[(long long)orow * cout + col] = v;
+        if (EPI) ymax = fmaxf(ymax, fabsf(v));
+      }
+    }
+  }
+  if (EPI && epi.y_amax) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o));
+    if (l == 0) amax_slot_publish(epi.y_amax, __float_as_int(ymax), (unsigned)tile);
+  }
+}
+
 // ---- the same product with EIGHT waves per workgroup: 128 rows x 128 output columns (fp16x3 on plane images only) --------
 // k_conv_fwd_split<NB = 2> covers 128 rows x 64 columns per workgroup, so a layer with Cout = 256 gathers every neighbour
 // row four times (once per column block; from the XCD's L2 after the first, but the L2 -> CU gather path is what these
@@ -2535,6 +2767,25 @@ int gcl_conv_fwd_fused(const float* x, int64_t n_in, int32_t x_is_planes, const 
 #define LAUNCH_SPLIT_NB2(PLV)                                                            \
   {                                                                                      \
     if (nb >= 2) LAUNCH_SPLIT(2, PLV); else LAUNCH_SPLIT(1, PLV);                        \
+  }
+  // inference launches (flag GCL_CONV_TALL): sixteen-wave workgroups, the tile's offsets in four fixed groups, for layers
+  // with at least tall_min = 108 steps per full tile (27 offsets x Cin / 32 >= 4).  Decided by the layer's shape only, so that
+  // a row's bits never depend on the launch it is in.  Measured (bench.py secondary, one pair / eight pairs per pass,
+  // M voxels/s): off 15.5 / 80.3, Cin >= 128 (default) 20.1 / 77.0, Cin >= 64 20.9 / 65.6; eval_pairs 146 -> 163 pairs/s.
+  static const int tall = [] { const char* e = getenv("GCL_FWD_TALL"); return e ? atoi(e) : 1; }();
+  static const int tall_min = [] { const char* e = getenv("GCL_FWD_TALL_MIN_STEPS"); return e ? atoi(e) : 108; }();
+  if (tall && (flags & GCL_CONV_TALL) && prec == 4 && !x_is_planes && !stats && tbl && tile_mask && K >= 8 &&
+      K * (cin / 32) >= tall_min && cout % 64 == 0 && colgroup && !swz && !ranges) {
+    const dim3 tgrid((unsigned)(cdiv(gx, 8) * 8 * (cout / 64)));
+    const int tswz = 2 | (heavy_first ? 16 : 0);
+    if (use_epi)
+      hipLaunchKernelGGL((k_conv_fwd_tall<true>), tgrid, dim3(1024), 0, st, x, (const u32x4*)wp, tbl, order, tile_mask,
+                         (long long)n_out, K, cin, cout, bias, y, tswz, x_amax, w_amax, x_bytes, epi);
+    else
+      hipLaunchKernelGGL((k_conv_fwd_tall<false>), tgrid, dim3(1024), 0, st, x, (const u32x4*)wp, tbl, order, tile_mask,
+                         (long long)n_out, K, cin, cout, bias, y, tswz, x_amax, w_amax, x_bytes, epi);
+    GCL_CHECK_LAUNCH();
+    return GCL_OK;
   }
   // TUNING KNOB, default off: eight-wave workgroups (128 rows x 128 columns, k_conv_fwd_wide) for plane-image launches with
   // Cout a multiple of 128 (GCL_FWD_WIDE=1 or flag GCL_CONV_WIDE).  Bitwise the same results with half the gathered bytes

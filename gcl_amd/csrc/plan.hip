@@ -656,8 +656,8 @@ static int plan_forward(Plan& P, const float* x_in, void* const* bn_stats, float
           ProfScope ps(P, st, 0, (double)(m.kernel_size > 1 ? m.n_pairs : n_out), op.cin, c, n_in, n_out, op.K);
           PLAN_CALL(gcl_conv_fwd_fused(x.ptr, n_in, 0, P.pack_fwd + P.off_fwd[wi], 4, x.amax,
                                        P.w_amax + (long long)wi * GCL_AMAX_WORDS, tbl, order, mask, n_out, op.K, op.cin, c,
-                                       (const float*)be[1], (const float*)be[0], res, op.relu, y.amax, y.ptr, nullptr, 0,
-                                       (void*)st));
+                                       (const float*)be[1], (const float*)be[0], res, op.relu, y.amax, y.ptr, nullptr,
+                                       GCL_CONV_TALL, (void*)st));
           break;
         }
         float *cy, *stats;

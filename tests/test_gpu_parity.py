@@ -290,6 +290,55 @@ def test_conv_ragged_row_counts(n, precision):
     assert rel_l2(conv.kernel.grad.cpu(), W.grad) < PREC_TOL[precision]
 
 
+@pytest.mark.parametrize("cin,cout", [(128, 128), (256, 256), (128, 64), (256, 128)])
+def test_inference_launch_with_offset_groups(cin, cout):
+    """Flag GCL_CONV_TALL (inference launches): sixteen waves per workgroup, the offsets of a tile in four fixed groups whose
+    partial sums are added in group order.  Against the launch without the flag: equal to rounding (another summation
+    order); repeatable bit for bit; and a row's result does not depend on what else is in the launch -- two clouds run
+    together give, row for row, the bits they give one by one (fused epilogue included)."""
+    from gcl_amd import _lib
+    import gcl_amd.MinkowskiEngine as ME
+    lib = _lib.load()
+    K = 27
+    g = torch.Generator().manual_seed(cin + cout)
+    ca, cb = random_cloud(21, n=1800, extent=14, batch=1), random_cloud(22, n=700, extent=9, batch=1)
+    cb = cb.copy()
+    cb[:, 0] = 1
+    both = np.concatenate([ca, cb])
+
+    def run(C, x, res, flags):
+        mgr = make_mgr(C)
+        tbl, order, mask = mgr.get_kernel_map(1, 3, 1).sorted_table()
+        n_out = len(C)
+        y = torch.full((n_out, cout), float("nan"), device=DEV)
+        slot = ME.ops.amax_slot(x.device)
+        _lib.check(lib.gcl_conv_fwd_fused(_lib.ptr(x), n_out, 0, _lib.ptr(wp), 4, _lib.ptr(xa), _lib.ptr(wa), _lib.ptr(tbl),
+                                          _lib.ptr(order), _lib.ptr(mask), n_out, K, cin, cout, _lib.ptr(shift), _lib.ptr(scale),
+                                          _lib.ptr(res), 1, _lib.ptr(slot), _lib.ptr(y), None, flags, _lib.stream()),
+                   "gcl_conv_fwd_fused")
+        return y
+
+    with torch.cuda.device(DEV):
+        x = torch.randn(len(both), cin, generator=g).to(DEV)
+        res = torch.randn(len(both), cout, generator=g).to(DEV)
+        W = (0.1 * torch.randn(K, cin, cout, generator=g)).to(DEV)
+        scale, shift = (0.5 + torch.rand(cout, generator=g)).to(DEV), (0.1 * torch.randn(cout, generator=g)).to(DEV)
+        xa, wa = ME.ops.amax_slot(x.device), ME.ops.amax_slot(x.device)
+        _lib.check(lib.gcl_amax(_lib.ptr(x), x.numel(), _lib.ptr(xa), 1, _lib.stream()), "gcl_amax")     # one scale for all runs
+        _lib.check(lib.gcl_amax(_lib.ptr(W), W.numel(), _lib.ptr(wa), 1, _lib.stream()), "gcl_amax")
+        wp = torch.empty(lib.gcl_pack_weights_bytes(K, cin, cout, 4), dtype=torch.uint8, device=DEV)
+        _lib.check(lib.gcl_pack_weights(_lib.ptr(W), K, cin, cout, 0, 4, _lib.ptr(wa), _lib.ptr(wp), _lib.stream()), "pack")
+        na = len(ca)
+        plain = run(both, x, res, 0)
+        tall = run(both, x, res, 4)
+        assert torch.isfinite(tall).all() and torch.equal(tall, run(both, x, res, 4))
+        assert not torch.equal(tall, plain)                      # the flag did select the other kernel
+        assert rel_l2(tall.cpu().double(), plain.cpu().double()) < 5e-7
+        ya = run(ca, x[:na].contiguous(), res[:na].contiguous(), 4)
+        yb = run(cb, x[na:].contiguous(), res[na:].contiguous(), 4)
+        assert torch.equal(tall[:na], ya) and torch.equal(tall[na:], yb)
+
+
 @pytest.mark.parametrize("cin,cout,n", [(128, 128, 3000), (256, 256, 1500), (128, 256, 700), (256, 128, 129), (128, 128, 1)])
 def test_eight_wave_forward_kernel_is_bitwise_the_four_wave_kernel(cin, cout, n):
     """Flag GCL_CONV_WIDE runs plane-image launches with Cout a multiple of 128 on k_conv_fwd_wide (eight waves: 128 rows x

@@ -1,0 +1,27 @@
+"""DIAGNOSTIC (GPU box): one inference pass (a pair of clouds per forward, configs[1] at one pair per pass), repeated;
+run it under `rocprofv3 --kernel-trace --stats` to see what the pass is made of.  Prints the wall time per pass."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+from gcl_amd import synthetic
+from gcl_amd.model import load_model
+from gcl_amd.scripts.test_kitti import forward_clouds
+dev = torch.device("cuda:0")
+torch.manual_seed(0); np.random.seed(0)
+model = load_model("ResUNetBN2C")(1, 32, bn_momentum=0.05, normalize_feature=True, conv1_kernel_size=5, D=3).to(dev).eval()
+pairs = [synthetic.make_eval_pair(100 + s, baseline=15.0 + 5.0 * (s % 6)) for s in range(4)]
+d = [{k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in p.items()} for p in pairs]
+N = int(os.environ.get("EP_PASSES", "40"))
+with torch.no_grad(), torch.cuda.device(dev):
+    def one(j):
+        forward_clouds(model, [(d[j % 4][f"sinput{k}_F"], d[j % 4][f"sinput{k}_C"]) for k in (0, 1)])
+    for j in range(4):
+        one(j)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for j in range(N):
+        one(j)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / N
+nv = np.mean([len(p["sinput0_C"]) + len(p["sinput1_C"]) for p in pairs])
+print(f"{dt * 1e3:.3f} ms per pass of {nv:.0f} voxels = {nv / dt / 1e6:.1f} M voxels/s")
