@@ -6,6 +6,7 @@ spelled out; BN + ReLU (+ residual) sites use the fused kernels of gcl_amd.Minko
 The IN variants (:269-291: BatchNorm after the level convolutions, InstanceNorm inside the residual blocks) are built
 too; the ``KERNEL_SIZES[0]`` "extra" branch (:48-57, :141-151) is not (unused by GCL's scripts).
 """
+import os
 import torch
 
 import gcl_amd.MinkowskiEngine as ME
@@ -85,7 +86,7 @@ class ResUNet2(ME.MinkowskiNetwork):
             old = merged.get(key, ((), False))
             merged[key] = (tuple(sorted(set(old[0]) | set(bool(t) for t in tables))), (old[1] or bool(pairs)) and training)
         out = [k + v for k, v in merged.items()]
-        if self.conv1.in_channels == 1 and not training:
+        if self.conv1.in_channels == 1 and not training and os.environ.get("GCL_STEM_OCC", "1") != "0":
             # inference feeds occupancy features (lib/data_loaders.py test sets / scripts/test_kitti.py: torch.ones((n, 1)),
             # no transform): presence words of the first layer's table, its kernels then add W[k] over the set bits.
             # Training batches carry lib/transforms.py:18 Jitter on the centre cloud, so they would pay for the words and
