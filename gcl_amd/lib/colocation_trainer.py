@@ -498,7 +498,10 @@ class FinestContrastiveLossTrainer:
             with torch.cuda.device(self.device):
                 if getattr(self, "_side", None) is None:
                     lo, hi = torch.cuda.Stream.priority_range()         # (lowest priority, highest priority)
-                    prio = {"low": lo, "high": hi}.get(os.environ.get("GCL_SIDE_PRIORITY", "high"), 0)
+                    # low: with the helpers two steps ahead nothing waits for the maps, and at high priority their kernels
+                    # took the chip from the training stream (13.0 -> 12.7 ms per step; with the maps of a batch cached, a
+                    # diagnostic, the step is 11.95 ms: building them still costs ~0.75 ms of a step)
+                    prio = {"low": lo, "high": hi}.get(os.environ.get("GCL_SIDE_PRIORITY", "low"), 0)
                     self._side = torch.cuda.Stream(device=self.device, priority=prio)
                 from gcl_amd.MinkowskiEngine import native
                 nspecs = getattr(self.model, "native_map_specs", None)
