@@ -905,8 +905,8 @@ __global__ void __launch_bounds__(1024, 1) k_conv_fwd_tall(const float* __restri
     }
     __syncthreads();
     int buf = 0;
-    bool mine_cur = mine0, has_cur = has0;
-    for (int it = 0; it < n_iter; ++it) {
+    bool mine_cur = mine0;
+    for (int it = 0; it < n_iter; ++it) {      // every wave takes n_iter barriers; a group that has run out of steps idles
       if (mine_cur) {
         WAVE_FENCE();
 #pragma unroll
@@ -925,7 +925,6 @@ __global__ void __launch_bounds__(1024, 1) k_conv_fwd_tall(const float* __restri
           }
         }
       }
-      (void)has_cur;
       if (has1) {      // next step: registers -> LDS (A: own tile, after this wave's reads; B: the group's other buffer)
         WAVE_FENCE();
         GCLT_STORE_LDS(mine1, buf ^ 1);
@@ -940,7 +939,6 @@ __global__ void __launch_bounds__(1024, 1) k_conv_fwd_tall(const float* __restri
       }
       __syncthreads();
       buf ^= 1;
-      has_cur = has1;
       mine_cur = has1 && mine1;
       mine1 = mine2;
       k1 = k2;
