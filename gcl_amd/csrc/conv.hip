@@ -769,7 +769,8 @@ __global__ void __launch_bounds__(256, GCL_FWD_MIN_WAVES(NB, PL)) k_conv_fwd_spl
 // A pass over one or two clouds launches a handful of workgroups on the deep layers (17 k voxels: 28 row tiles at stride 4, 8
 // at stride 8), and each of them walks up to 27 offsets x Cin / 32 dependent steps alone on its CU: 9 launches of ~136 us
 // were half of a 2.4 ms pass.  Here four groups of four waves share the 128 rows of a tile; group g runs the offsets
-// k with 4 k / K == g (FIXED ranges of the offset index, not of the tile's mask) exactly like a k_conv_fwd_split
+// k with k mod 4 == g (FIXED by the offset index, not by the tile's mask; interleaved, so that the groups of a tile are
+// about equally long: with the ranges 4 k / K == g eight pairs per pass ran at 77 instead of 80 M voxels/s) exactly like a k_conv_fwd_split
 // workgroup -- own weight blocks, own wave-private A tiles -- and the four partial accumulators are added through LDS in
 // group order: y = ((g0 + g1) + g2) + g3.  A row's result therefore depends on the layer's shape only, never on the rows
 // it shares a tile or a batch with (batching clouds stays bitwise neutral), and nothing leaves the CU (no scratch, no
@@ -813,10 +814,10 @@ __global__ void __launch_bounds__(1024, 1) k_conv_fwd_tall(const float* __restri
   const int nb0 = byy * NB;
   const int TNB = cout >> 5, CC = cin >> 5;
   const int p = l & 7, rsub = l >> 3;
-  // offsets of group g: k with 4 k / K == g
+  // offsets of group g: k with k mod 4 == g
   unsigned gsel = 0u;
   for (int k = 0; k < K; ++k)
-    if (4 * k / K == g) gsel |= 1u << k;
+    if ((k & 3) == g) gsel |= 1u << k;
 
   f32x16 acc[NB];
 #pragma unroll
@@ -2769,7 +2770,8 @@ int gcl_conv_fwd_fused(const float* x, int64_t n_in, int32_t x_is_planes, const 
   // inference launches (flag GCL_CONV_TALL): sixteen-wave workgroups, the tile's offsets in four fixed groups, for layers
   // with at least tall_min = 108 steps per full tile (27 offsets x Cin / 32 >= 4).  Decided by the layer's shape only, so that
   // a row's bits never depend on the launch it is in.  Measured (bench.py secondary, one pair / eight pairs per pass,
-  // M voxels/s): off 15.5 / 80.3, Cin >= 128 (default) 20.1 / 77.0, Cin >= 64 20.9 / 65.6; eval_pairs 146 -> 163 pairs/s.
+  // M voxels/s): off 15.5 / 80.3, Cin >= 128 (default) 20.1 / 80 (77.0 with ranges of k instead of k mod 4), Cin >= 64 20.9 / 65.6;
+  // eval_pairs 146 -> 160 - 165 pairs/s.
   static const int tall = [] { const char* e = getenv("GCL_FWD_TALL"); return e ? atoi(e) : 1; }();
   static const int tall_min = [] { const char* e = getenv("GCL_FWD_TALL_MIN_STEPS"); return e ? atoi(e) : 108; }();
   if (tall && (flags & GCL_CONV_TALL) && prec == 4 && !x_is_planes && !stats && tbl && tile_mask && K >= 8 &&

@@ -225,7 +225,7 @@ int gcl_split_planes(const float* x, int64_t n, int32_t c, const int32_t* amax, 
  * just gathered.  Launch-order hint only. */
 #define GCL_CONV_XCD_RANGES 1
 #define GCL_CONV_TALL 4     /* inference launches: sixteen waves per workgroup, a tile's offsets in four FIXED groups (k with
-                               4 k / K == g) whose partial sums are added in group order -- shortens the chain of dependent
+                               k mod 4 == g) whose partial sums are added in group order -- shortens the chain of dependent
                                steps a small cloud's deep layers are made of; a row's result depends on the layer's shape only
                                (batching stays bitwise neutral).  fp16x3 on fp32 rows, no BatchNorm statistics, K >= 8,
                                K Cin / 32 >= 108 (Cin >= 128 at K = 27), Cout a multiple of 64; ignored elsewhere.  Results differ from the launch

@@ -292,8 +292,8 @@ def test_conv_ragged_row_counts(n, precision):
 
 @pytest.mark.parametrize("cin,cout", [(128, 128), (256, 256), (128, 64), (256, 128)])
 def test_inference_launch_with_offset_groups(cin, cout):
-    """Flag GCL_CONV_TALL (inference launches): sixteen waves per workgroup, the offsets of a tile in four fixed groups whose
-    partial sums are added in group order.  Against the launch without the flag: equal to rounding (another summation
+    """Flag GCL_CONV_TALL (inference launches): sixteen waves per workgroup, the offsets of a tile in four fixed groups
+    (k mod 4) whose partial sums are added in group order.  Against the launch without the flag: equal to rounding (another summation
     order); repeatable bit for bit; and a row's result does not depend on what else is in the launch -- two clouds run
     together give, row for row, the bits they give one by one (fused epilogue included)."""
     from gcl_amd import _lib
@@ -333,7 +333,7 @@ def test_inference_launch_with_offset_groups(cin, cout):
         tall = run(both, x, res, 4)
         assert torch.isfinite(tall).all() and torch.equal(tall, run(both, x, res, 4))
         assert not torch.equal(tall, plain)                      # the flag did select the other kernel
-        assert rel_l2(tall.cpu().double(), plain.cpu().double()) < 5e-7
+        assert rel_l2(tall.cpu().double(), plain.cpu().double()) < 1e-6      # two fp32 summation orders of the same products
         ya = run(ca, x[:na].contiguous(), res[:na].contiguous(), 4)
         yb = run(cb, x[na:].contiguous(), res[na:].contiguous(), 4)
         assert torch.equal(tall[:na], ya) and torch.equal(tall[na:], yb)
