@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(256) k_conv_fwd(const float* __restrict__ X, c
 // [0] wait at barrier #1  [1] LDS writes + next-step load issue  [2] wait at barrier #2  [3] LDS reads + split + MFMA
 // [4] prologue  [5] epilogue  [6] wave-steps  [7] wave-steps with MFMA work
 __device__ unsigned long long g_stamps[8];
-// per workgroup of the LAST k_conv_fwd_split launch: {start, end (s_memrealtime, 100 MHz), steps, tile | column block << 32}
+// per workgroup of the LAST k_conv_fwd_split launch: {start, end (s_memrealtime, 100 MHz), steps, s_memtime ticks start -> end}
 // (tools/wg_trace.py)
 constexpr int WG_TRACE_MAX = 16384;
 __device__ unsigned long long g_wgtrace[WG_TRACE_MAX * 4];
@@ -596,7 +596,7 @@ __global__ void __launch_bounds__(256, GCL_FWD_MIN_WAVES(NB, PL)) k_conv_fwd_spl
   }
 
 #ifdef GCL_STAMPS
-  const unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime(), wg_c0 = __builtin_amdgcn_s_memtime();
   unsigned long long wg_steps = 0;
 #endif
   if (wgmask != 0u) {
@@ -696,7 +696,7 @@ __global__ void __launch_bounds__(256, GCL_FWD_MIN_WAVES(NB, PL)) k_conv_fwd_spl
 #ifdef GCL_STAMPS
   if (t == 0 && blockIdx.x < WG_TRACE_MAX && gridDim.y == 1) {
     unsigned long long* o = g_wgtrace + (long long)blockIdx.x * 4;
-    o[0] = wg_t0; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = wg_steps; o[3] = ((unsigned long long)byy << 32) | bxx;
+    o[0] = wg_t0; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = wg_steps; o[3] = __builtin_amdgcn_s_memtime() - wg_c0;
   }
 #endif
   if (!active && !stats) return;

@@ -54,6 +54,10 @@ for (t, cin, cout, stride, tr) in [(8, 256, 256, 1, False), (4, 128, 128, 1, Fal
     late = np.argsort(-end)[:6]
     print("   last to finish            (start, end, steps, us/step): " +
           "  ".join(f"({start[i]:.0f}, {end[i]:.0f}, {steps[i]}, {dur[i] / steps[i]:.2f})" for i in late))
+    ticks = sel[:, 3].astype(np.float64)
+    ok = dur > 20
+    print(f"   s_memtime ticks per microsecond of s_memrealtime over the workgroups' lifetimes: median "
+          f"{np.median(ticks[ok] / dur[ok]):.1f} (p10 {np.percentile(ticks[ok] / dur[ok], 10):.1f}, p90 {np.percentile(ticks[ok] / dur[ok], 90):.1f})")
     q = np.percentile(end, [50, 90, 99])
     print(f"   workgroup end times p50 / p90 / p99 / max: {q[0]:.0f} / {q[1]:.0f} / {q[2]:.0f} / {span:.0f} us; "
           f"started after t = 10 us: {(start > 10).sum()}")
