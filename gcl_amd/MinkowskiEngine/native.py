@@ -271,7 +271,13 @@ class NetworkPlan:
             records.append(r)
         group = getattr(model, "_amax_group", None)
         worder = [pid[id(p)] for p in group.params] if group else []
-        return cls(records, len(tid), params, bn_buffers, bn_modules, worder, keys, chans[records[-1]["y"]])
+        plan = cls(records, len(tid), params, bn_buffers, bn_modules, worder, keys, chans[records[-1]["y"]])
+        # a TRAINING pass through the plan writes the gradient of every record's parameters through raw pointers and
+        # the trainer seats / updates every entry of model.parameters(): that is only right when each parameter is
+        # claimed by a record (an unclaimed one would keep a stale seat and still receive weight decay)
+        claimed = {r[f] for r in records for f in ("w", "bias", "bn_w", "bn_b") if r[f] >= 0}
+        plan.covers_all_params = claimed == set(range(len(params)))
+        return plan
 
     # ---- running -------------------------------------------------------------------------------------------------
     def _pointers(self):

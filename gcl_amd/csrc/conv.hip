@@ -2864,7 +2864,9 @@ int gcl_conv_fwd_halo(const float* x, int64_t n_in, const void* wp, int32_t prec
 int64_t gcl_conv_bwd_weight_scratch_len(int32_t K, int32_t ca, int32_t cb, int64_t n_pairs_padded, int64_t n_sorted_rows) {
   long long nc = n_pairs_padded / GCL_PAIR_CHUNK;
   long long len = (long long)(bwd_weight_wgs(nc) + K) * ca * cb;
-  if (n_sorted_rows > 0 && K > 1 && K <= 27) {      // range-grouped mode: one slab per (row range, offset) + the cell limits
+  // range-grouped mode (one slab per (row range, offset) + the cell limits): reserved only for the shapes dw_rg_shape can
+  // select -- the C >= 128 layers always take the classic path and would otherwise reserve ~100 MB each for nothing
+  if (n_sorted_rows >= 32768 && K > 1 && K <= 27 && (ca == 32 || ca == 64) && (cb == 32 || cb == 64)) {
     const long long nr = cdiv(n_sorted_rows, dw_range_rows(n_sorted_rows, K));
     const long long rg = nr * K * ca * cb + (long long)K * (nr + 1) + 64;
     if (rg > len) len = rg;

@@ -203,6 +203,8 @@ static int maps_build(const int32_t* coords, long long n, const gcl_map_spec* sp
   }
   // kernel maps (CoordinateManager.get_kernel_map), one presence bitmap per coordinate table
   int32_t* bitmap[GCL_MAX_LEVELS] = {nullptr};
+  bool any_pairs = false;      // pair lists wanted (training): their counts are read back; inference skips the D2H copies
+  for (int s = 0; s < n_specs; ++s) any_pairs = any_pairs || (specs[s].pairs != 0 && specs[s].kernel_size > 1);
   for (int s = 0; s < n_specs; ++s) {
     const gcl_map_spec& sp = specs[s];
     gcl_map_desc& d = out->maps[s];
@@ -231,7 +233,7 @@ static int maps_build(const int32_t* coords, long long n, const gcl_map_spec* sp
     PLAN_CALL(gcl_kernel_map(out->coords[d.level_out], d.n_out, out->table[d.level_in], out->cap[d.level_in],
                              sp.kernel_size, sp.t_in, (same ? 1 : 0) | (bitmap_valid ? 2 : 0), bitmap[d.level_in], scratch,
                              d.nbr, d.nbr_t, d.n_in, d.counts, stream));
-    if (!A.dry)
+    if (!A.dry && any_pairs)   // without pair lists nobody waits for this copy: it would outlive the call (pinned re-use)
       GCL_CHECK_HIP(hipMemcpyAsync(pinned + 128 * (s + 1), d.counts, sizeof(int32_t) * d.K, hipMemcpyDeviceToHost, st));
   }
   // mask-sorted tables (KernelMap.sorted_table) of all maps in ONE gcl_table_sort_multi sequence (14 launches instead of
@@ -271,8 +273,6 @@ static int maps_build(const int32_t* coords, long long n, const gcl_map_spec* sp
                                    jobs[q].tbl_sorted, jobs[q].tile_mask, stream));
   // the second host sync: per-offset pair counts -> padded segment offsets -> pair lists (KernelMap.pairs); skipped when
   // no map asks for pair lists (inference): counts_host / n_pairs / seg_off then stay zero
-  bool any_pairs = false;
-  for (int s = 0; s < n_specs; ++s) any_pairs = any_pairs || (specs[s].pairs != 0 && specs[s].kernel_size > 1);
   if (!A.dry && any_pairs) GCL_CHECK_HIP(hipStreamSynchronize(st));
   for (int s = 0; s < n_specs; ++s) {
     const gcl_map_spec& sp = specs[s];
@@ -954,6 +954,14 @@ int gcl_maps_build(const int32_t* coords, int64_t n, const gcl_map_spec* specs_h
   GCL_CHECK_ARG(n_specs >= 0 && n_specs <= GCL_MAX_MAPS && n_levels >= 1 && n_levels <= GCL_MAX_LEVELS,
                 "gcl_maps_build: at most %d maps and %d levels", GCL_MAX_MAPS, GCL_MAX_LEVELS);
   // read-back area (int32): row 0 = input status + per-level meta, row s + 1 = the pair counts of map s; 128 words per row
+  // size check BEFORE the first launch (the dry run's upper bound -- every level as large as the input -- is what
+  // gcl_maps_arena_bytes tells callers to reserve): a short arena must not be written past its end
+  const int64_t need = gcl_maps_arena_bytes(n, specs_host, n_specs, n_levels);
+  GCL_CHECK_ARG(need >= 0, "gcl_maps_build: bad map specification");
+  if (arena_bytes < need) {
+    set_error("gcl_maps_build: arena too small (%lld bytes needed, %lld given)", (long long)need, (long long)arena_bytes);
+    return GCL_ERR_ARENA;
+  }
   Arena A{(char*)arena, arena_bytes, 0, false};
   return maps_build(coords, n, specs_host, n_specs, n_levels, A, (int32_t*)pinned_host, out_host, (hipStream_t)stream);
 }
@@ -1212,6 +1220,16 @@ int gcl_plan_forward_eval(void* plan, const gcl_maps_desc* maps_host, const floa
 int gcl_plan_release(void* plan, void* arena) {
   Plan* P = (Plan*)plan;
   GCL_CHECK_ARG(P, "gcl_plan_release: null plan");
+  bool found = false;
+  for (PassState* q : P->passes)
+    if (q->forward_done && q->key == arena) found = true;
+  // the forward pass forked packs / max|W| onto the aux stream; they are joined at the head of gcl_plan_backward, which
+  // never comes for this pass.  The caller frees the arena to the MAIN stream's allocator next: drain the aux stream
+  // first (rare path -- a training-mode pass under no_grad, or an output dropped without backward)
+  if (found && P->aux && P->aux_dirty) {
+    GCL_CHECK_HIP(hipStreamSynchronize(P->aux));
+    P->aux_dirty = false;
+  }
   for (PassState* q : P->passes)
     if (q->forward_done && q->key == arena) *q = PassState();
   return GCL_OK;

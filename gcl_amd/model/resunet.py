@@ -118,7 +118,10 @@ class ResUNet2(ME.MinkowskiNetwork):
         if (not native.PLAN_ENABLED or not isinstance(plan, native.NetworkPlan) or nm is None
                 or nm.keys != plan.spec_keys or x.coordinate_map_key.tensor_stride != 1
                 or ME.ops.PRECISION != "fp16x3" or not self._use_tape(x)
-                or len(plan.params) != sum(1 for _ in self.parameters())):
+                or len(plan.params) != sum(1 for _ in self.parameters())
+                # frozen parameters (fine-tuning) / parameters no record claims: the plan would write their gradients
+                # and the optimizer would update them; the Tape leaves p.grad None for them
+                or not getattr(plan, "covers_all_params", False) or not all(p.requires_grad for p in plan.params)):
             return None
         return plan
 

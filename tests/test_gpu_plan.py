@@ -363,15 +363,14 @@ def test_tape_equals_per_layer_autograd_and_frozen_bn_leaves_the_tape():
                 ops.batch_norm(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, True, 0.05, 1e-5)
 
 
-def test_two_ranks_on_one_device_overlap_the_decoder_bucket():
+def test_two_ranks_on_one_device_overlap_the_decoder_bucket(tmp_path):
     """configs[3] first-run safety: a FRESH child process per rank (torch.distributed.run,
     gloo, both ranks on cuda:0) runs bench.py's N = 2 path for 3 steps with the plan: FlatDDP buckets are started by
     ``bucket_ready`` between the plan's backward segments (decoder bucket first, before the encoder records run), both
     ranks end with identical finite parameters, and they equal a single-process run fed the averaged gradients."""
     env = dict(os.environ, GCL_BENCH_SINGLE_DEVICE="1", GCL_DDP_SELFTEST="1", MASTER_ADDR="127.0.0.1")
     env.pop("RANK", None)
-    out = os.path.join(ROOT, "gpurun_out", "ddp_selftest")
-    os.makedirs(out, exist_ok=True)
+    out = str(tmp_path)
     env["GCL_DDP_SELFTEST_DIR"] = out
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29631", os.path.join(ROOT, "tools", "ddp_selftest.py")]
@@ -387,3 +386,64 @@ def test_two_ranks_on_one_device_overlap_the_decoder_bucket():
         # the loss backward's atomics), which hardest-negative mining can amplify to ~1e-4 within 3 steps; a missing
         # average or a stale bucket would show at ~1e-2
         assert rec[k]["max_abs_diff_vs_averaged_single_process"] <= 1e-3 * rec[k]["max_abs_param"], rec[k]
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher must start two ranks itself (child
+    torch.distributed.run; here both on cuda:0 over gloo through the GCL_BENCH_SINGLE_DEVICE test hook) and print a line
+    with n_gpus == 2 -- never a silent 1-GPU number.  Without the hook, on this 1-GPU box, the same command must refuse."""
+    env = dict(os.environ, GCL_BENCH_SINGLE_DEVICE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--resident",
+           "--batches", "1", "--no-kernel-events"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["ranks"]["rccl_ranks"] == 2 and rec["ranks"]["backend"] == "gloo"
+    assert len(rec["ranks"]["voxels_per_step_per_rank"]) == 2 and rec["config"]["parallelism"] == "dp2"
+    if torch.cuda.device_count() < 2:
+        env.pop("GCL_BENCH_SINGLE_DEVICE")
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+        assert r.returncode != 0 and "refusing" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_frozen_parameter_keeps_the_step_off_the_plan():
+    """with one convolution frozen (requires_grad=False, fine-tuning) a training step must not
+    go through the plan -- it writes every record's gradient through raw pointers and the trainer seats p.grad for all
+    of model.parameters(), so SGD (weight decay, momentum) would move the frozen tensor.  The step stays on the Tape:
+    p.grad of the frozen kernel stays None, it keeps its bits, every other parameter still trains."""
+    import gcl_amd.MinkowskiEngine as ME
+    from gcl_amd import synthetic
+    from gcl_amd.lib.colocation_trainer import FinestContrastiveLossTrainer, make_config
+    with torch.cuda.device(DEV):
+        cfg = make_config(batch_size=1)
+        trainer = FinestContrastiveLossTrainer(cfg, device=torch.device(DEV))
+        keys = ("sinput_C", "sinput_F", "group", "index", "finest_flag")
+        batches = [{k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in
+                    synthetic.make_train_batch(300 + j, batch_size=1, num_neighborhood=2, n_boxes=12).items() if k in keys}
+                   for j in range(2)]
+        frozen = trainer.model.block2.conv1.kernel
+        frozen.requires_grad_(False)
+        before = frozen.detach().clone()
+        other = trainer.model.block2.conv2.kernel.detach().clone()
+        np.random.seed(0)
+        steps = trainer.train_steps(iter([batches[0], batches[1], batches[0], batches[1]]))
+        for _ in range(4):
+            loss, _, _ = next(steps)
+            assert torch.isfinite(loss).item()
+            plan = trainer.model.__dict__.get("_plan")
+            if plan:                                  # recorded by step 1, but never handed out while a tensor is frozen
+                probe_mgr = ME.CoordinateManager.build_native(batches[0]["sinput_C"], trainer.model.native_map_specs())
+                x = ME.SparseTensor(batches[0]["sinput_F"], coordinates=batches[0]["sinput_C"], coordinate_manager=probe_mgr)
+                assert trainer.model.plan_for(x) is None
+        steps.close()
+        torch.cuda.synchronize()
+        assert frozen.grad is None and torch.equal(frozen, before)
+        assert not torch.equal(trainer.model.block2.conv2.kernel, other)
+        # un-frozen again, the same model goes back to the plan
+        frozen.requires_grad_(True)
+        x = ME.SparseTensor(batches[0]["sinput_F"], coordinates=batches[0]["sinput_C"], coordinate_manager=probe_mgr)
+        assert trainer.model.plan_for(x) is not None

@@ -1,7 +1,9 @@
 """Host-side (CPU) logic of the product package: ME.utils, hashes, synthetic input contracts, model registry."""
 import os
+import sys
 
 import numpy as np
+import pytest
 import torch
 
 from gcl_amd import synthetic
@@ -10,6 +12,7 @@ from gcl_amd.util import misc
 from oracle import loss_oracle as LO
 
 G = os.path.join(os.path.dirname(__file__), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_sparse_quantize_first_occurrence_and_floor():
@@ -148,3 +151,17 @@ def test_native_legacy_choice_is_numpy_bit_for_bit():
     want = (np.random.choice(20000, 1024, replace=False), np.random.choice(530000, 1024, replace=False),
             np.random.choice(530000, 1024, replace=False))
     assert all(np.array_equal(g, w) for g, w in zip(got[:3], want))
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus 2` without a launcher on a box with fewer than 2 devices: non-zero exit, no JSON line
+    (VERDICT round 3, weak #5: it used to time one GPU and print it)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "GCL_BENCH_SINGLE_DEVICE")}
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two devices visible")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "refusing" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
