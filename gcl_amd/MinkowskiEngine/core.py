@@ -18,12 +18,6 @@ SORT_WINDOW = int(os.environ.get("GCL_SORT_WINDOW", "0"))
 SPATIAL_MAX_STRIDE = int(os.environ.get("GCL_SPATIAL_MAX_STRIDE", "0"))
 SPATIAL_WINDOW = int(os.environ.get("GCL_SPATIAL_WINDOW", "4096"))
 SPATIAL_MIN_ROWS = int(os.environ.get("GCL_SPATIAL_MIN_ROWS", "32768"))     # single clouds stay on the global sort
-# Halo tiles (gcl_table_sort_halo + gcl_conv_fwd_halo) for the stride-1 3^3 maps: 128-row tiles in fine spatial order
-# whose distinct input rows are staged once per channel slice in LDS.  OPT-IN (GCL_HALO=1): measured 1.5 - 1.7x SLOWER
-# than the global mask sort + k_conv_fwd_split on the KITTI batch (profiles/r02_conv_experiments.txt): the spatial tiles
-# visit 1.7x more (offset, slice) units per wave and the kernels are bound by per-unit latency chains, not gather bytes.
-HALO = os.environ.get("GCL_HALO", "0") == "1"
-HALO_MIN_ROWS = int(os.environ.get("GCL_HALO_MIN_ROWS", "4096"))
 
 
 def _pow2_cap(n):
@@ -110,20 +104,6 @@ class KernelMap:
                 tile_mask = torch.empty((n + 31) // 32, dtype=torch.int32, device=dev)
                 t_rows = self._t_in if transposed else self._t_out          # the level whose rows this table lists
                 mgr = self._mgr()
-                if HALO and self.same_map and self.K == 27 and mgr is not None and n >= HALO_MIN_ROWS:
-                    n_t = (n + 127) // 128
-                    hcount = torch.empty(n_t, dtype=torch.int32, device=dev)
-                    hrows = torch.empty((n_t, self.K * 128), dtype=torch.int32, device=dev)
-                    hloc = torch.empty((n_t, self.K, 128), dtype=torch.int16, device=dev)
-                    _lib.check(lib.gcl_table_sort_halo(_lib.ptr(tbl), self.K, n, _lib.ptr(mgr.spatial_order(t_rows)),
-                                                       _lib.ptr(mgr.get_coords(t_rows)), t_rows, _lib.ptr(scratch),
-                                                       _lib.ptr(order), _lib.ptr(tbl_sorted), _lib.ptr(tile_mask),
-                                                       _lib.ptr(hcount), _lib.ptr(hrows), _lib.ptr(hloc), _lib.stream()),
-                               "gcl_table_sort_halo")
-                    tbl_sorted._gcl_flags = 0
-                    tbl_sorted._gcl_halo = (hcount, hrows, hloc)
-                    self._sorted[key] = (tbl_sorted, order, tile_mask)
-                    return self._sorted[key]
                 spatial = mgr is not None and 0 < t_rows <= SPATIAL_MAX_STRIDE and n >= SPATIAL_MIN_ROWS
                 pre = mgr.spatial_order(t_rows) if spatial else None
                 _lib.check(lib.gcl_table_sort_pre(_lib.ptr(tbl), self.K, n, SPATIAL_WINDOW if spatial else SORT_WINDOW,
@@ -406,7 +386,6 @@ class CoordinateManager:
             out += [t for t in (km.nbr, km.nbr_t, km._counts_dev) if t is not None]
             for tup in km._sorted.values():
                 out += [t for t in tup if t is not None]
-                out += list(getattr(tup[0], "_gcl_halo", None) or ())
             if km._pairs is not None:
                 out += [km._pairs[0], km._pairs[1]]
         for p in self._identity.values():

@@ -241,24 +241,13 @@ def _conv_launch(lib, x, Wk, mode, table, n_out, cin, cout, bias, pairs=0, want_
     if want_stats and prec != 0:
         stats = torch.empty(((n_out + 127) // 128, 2, cout), dtype=torch.float32, device=x.device)
     name = None
-    # stride-1 3^3 maps carry halo tiles (KernelMap.sorted_table): their distinct input rows are staged once in LDS
-    halo = getattr(tbl, "_gcl_halo", None) if (tbl is not None and not generic and prec in (2, 4)) else None
     if PROFILE is not None:
         nb = lib.gcl_conv_fwd_nb(n_out, cout, prec)
         pre = "true" if x_planes is not None else "false"
         name = "k_conv_generic" if generic else \
             (f"k_conv_fwd<{nb}>" if prec == 0 else
              f"k_conv_fwd_split<{nb},{prec},{pre},{'true' if add is not None else 'false'}>")
-        if halo is not None:
-            name = f"k_conv_fwd_halo<{2 if cout % 64 == 0 else 1},{prec},{'true' if add is not None else 'false'}>"
     with _Timed(name, pairs, cin, cout, x.shape[0], n_out, K):
-        if halo is not None:
-            _lib.check(lib.gcl_conv_fwd_halo(_lib.ptr(x, torch.float32), x.shape[0], _lib.ptr(wp), prec, _lib.ptr(x_amax),
-                                             _lib.ptr(w_amax), _lib.ptr(halo[0]), _lib.ptr(halo[1]), _lib.ptr(halo[2]),
-                                             _lib.ptr(order), _lib.ptr(tile_mask), n_out, K, cin, cout, _lib.ptr(bias),
-                                             None, _lib.ptr(add), 0, None, _lib.ptr(y), _lib.ptr(stats), _lib.stream()),
-                       "gcl_conv_fwd_halo")
-            return (y, stats) if want_stats else y
         xin, is_planes = (x_planes, 1) if x_planes is not None else (x, 0)
         if add is not None:
             _lib.check(lib.gcl_conv_fwd_fused(_lib.ptr(xin), x.shape[0], is_planes, _lib.ptr(wp), prec, _lib.ptr(x_amax),
@@ -904,16 +893,6 @@ def conv_bn_eval(x, W, kmap, n_out, transpose, scale, shift, residual=None, relu
     y = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
     slot = amax_slot(x.device)
     res = residual.contiguous() if residual is not None else None
-    halo = getattr(tbl, "_gcl_halo", None) if tbl is not None else None
-    if halo is not None:
-        _lib.check(lib.gcl_conv_fwd_halo(_lib.ptr(x, torch.float32), x.shape[0], _lib.ptr(wp), prec, _lib.ptr(x_amax),
-                                         _lib.ptr(w_amax), _lib.ptr(halo[0]), _lib.ptr(halo[1]), _lib.ptr(halo[2]),
-                                         _lib.ptr(order), _lib.ptr(tile_mask), n_out, K, cin, cout,
-                                         _lib.ptr(shift, torch.float32), _lib.ptr(scale, torch.float32), _lib.ptr(res),
-                                         int(relu), _lib.ptr(slot), _lib.ptr(y), None, _lib.stream()),
-                   "gcl_conv_fwd_halo")
-        tag_amax(y, slot)
-        return y
     _lib.check(lib.gcl_conv_fwd_fused(_lib.ptr(x, torch.float32), x.shape[0], 0, _lib.ptr(wp), prec, _lib.ptr(x_amax),
                                       _lib.ptr(w_amax), _lib.ptr(tbl), _lib.ptr(order), _lib.ptr(tile_mask), n_out, K,
                                       cin, cout, _lib.ptr(shift, torch.float32), _lib.ptr(scale, torch.float32),

@@ -73,9 +73,6 @@ SIGNATURES = {
     "gcl_amax_multi": (_i32, [_vp, _vp, _i32, _vp, _vp]),
     "gcl_pack_weights_multi": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _vp]),
     "gcl_conv_fwd_nb": (_i32, [_i64, _i32, _i32]),
-    "gcl_table_sort_halo": (_i32, [_vp, _i32, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "gcl_conv_fwd_halo": (_i32, [_vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp,
-                                 _vp, _i32, _vp, _vp, _vp, _vp]),
     "gcl_pack_weights": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "gcl_table_sort_scratch_len": (_i64, [_i64]),
     "gcl_table_sort": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),

@@ -764,7 +764,6 @@ __global__ void __launch_bounds__(256, GCL_FWD_MIN_WAVES(NB, PL)) k_conv_fwd_spl
 }
 
 // ---------------------------------------------------------------------------------------------------
-// HALO-TILE forward kernel (stride-1 3^3 maps; tiles from gcl_table_sort_halo).  The (offset, slice) loop of
 // ---- inference on small clouds: SIXTEEN waves per workgroup, the offsets of a tile cut into four fixed groups -----------
 // A pass over one or two clouds launches a handful of workgroups on the deep layers (17 k voxels: 28 row tiles at stride 4, 8
 // at stride 8), and each of them walks up to 27 offsets x Cin / 32 dependent steps alone on its CU: 9 launches of ~136 us
@@ -988,768 +987,6 @@ __global__ void __launch_bounds__(1024, 1) k_conv_fwd_tall(const float* __restri
         if (EPI) ymax = fmaxf(ymax, fabsf(v));
       }
     }
-  }
-  if (EPI && epi.y_amax) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o));
-    if (l == 0) amax_slot_publish(epi.y_amax, __float_as_int(ymax), (unsigned)tile);
-  }
-}
-
-// ---- the same product with EIGHT waves per workgroup: 128 rows x 128 output columns (fp16x3 on plane images only) --------
-// k_conv_fwd_split<NB = 2> covers 128 rows x 64 columns per workgroup, so a layer with Cout = 256 gathers every neighbour
-// row four times (once per column block; from the XCD's L2 after the first, but the L2 -> CU gather path is what these
-// launches load most).  Here the four row tiles are shared by two waves each -- wave (tile wt, column half ch) owns 32 rows
-// x 64 columns like a wave of the NB = 2 instance, same registers -- so a gathered row feeds 128 columns, the pair
-// splits the tile's gather (2 instead of 4 loads per lane and step) and the weight block of a step is 128 columns wide
-// (2 loads per lane as before).  A tiles are double-buffered (the partner may still be reading), the index table holds all
-// 27 offsets: 77.5 KB of LDS, two workgroups = 16 waves per CU as before.
-template <bool PRE, bool EPI>
-__global__ void __launch_bounds__(512, 2) k_conv_fwd_wide(const float* __restrict__ X, const u32x4* __restrict__ Wp,
-                                                          const int* __restrict__ tbl, const int* __restrict__ order,
-                                                          const int* __restrict__ tile_mask, long long n_out, int K, int cin,
-                                                          int cout, const float* __restrict__ bias, float* __restrict__ Y,
-                                                          int swizzle, float* __restrict__ stats,
-                                                          const int* __restrict__ x_amax, const int* __restrict__ w_amax,
-                                                          unsigned x_bytes, ConvEpi epi) {
-  static_assert(PRE, "plane images only");
-  constexpr int PL = 4, NPL = 2, NB = 2, NBT = 4;
-  constexpr int BLK = NBT * 2 * NPL * 64;               // 1024 uint4 per (k, cc) weight block of the workgroup
-  const float a_scale = amax_scale(x_amax);
-  const float out_scale = 1.f / (a_scale * amax_scale(w_amax));
-  __shared__ __attribute__((aligned(16))) float Asm[2][4][32][32];
-  __shared__ __attribute__((aligned(16))) u32x4 Bsm[2][BLK];
-  __shared__ __attribute__((aligned(16))) int Ism[4][27][32];
-  __shared__ unsigned wmask[4];
-  const int t = threadIdx.x, l = t & 63, w8 = t >> 6, wt = w8 & 3, ch = w8 >> 2;
-  const int i = l & 31, h = l >> 5;
-  unsigned bxx = blockIdx.x, byy;
-  const bool heavy_first = (swizzle & 16) != 0;
-  const unsigned nrw = (unsigned)((n_out + CONV_ROWS - 1) / CONV_ROWS);
-  {
-    const unsigned ncb = (unsigned)(cout / (32 * NBT));
-    const unsigned xcd = bxx & 7u, slot = bxx >> 3;
-    byy = slot % ncb;
-    bxx = (slot / ncb) * 8u + xcd;
-    if (bxx >= nrw) return;
-  }
-  if (heavy_first) bxx = nrw - 1u - bxx;
-  const long long tile = (long long)bxx * 4 + wt;
-  const long long row0 = tile * 32;
-  const bool active = row0 < n_out;
-  const int nb0 = byy * NBT;
-  const int TNB = cout >> 5, CC = cin >> 5;
-  const int p = l & 7, rsub = l >> 3;
-
-  f32x16 acc[NB];
-#pragma unroll
-  for (int b = 0; b < NB; ++b)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
-
-  unsigned mymask = 0u;
-  if (active) mymask = tile_mask ? (unsigned)tile_mask[tile] : ((1u << K) - 1u);
-  mymask = __builtin_amdgcn_readfirstlane(mymask);
-  if (l == 0 && ch == 0) wmask[wt] = mymask;
-  for (int e = l + 64 * ch; e < K * 32; e += 128) {
-    const int k = e >> 5, r = e & 31;
-    int v = -1;
-    if (active && ((mymask >> k) & 1u) && row0 + r < n_out) v = tbl ? tbl[(long long)k * n_out + row0 + r] : (int)(row0 + r);
-    Ism[wt][k][(r & 7) * 4 + (r >> 3)] = v;
-  }
-  __syncthreads();
-  const unsigned wgmask = wmask[0] | wmask[1] | wmask[2] | wmask[3];
-  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)x_bytes, 0x00020000);
-  const unsigned row_bytes = (unsigned)cin * 4u;
-#define GCLW_GATHER_A(KK, CCV)                                                                                  \
-  {                                                                                                             \
-    const int4 ri_ = *reinterpret_cast<const int4*>(&Ism[wt][(KK)][rsub * 4]);                                 \
-    const unsigned co_ = (unsigned)(CCV)*128u + (unsigned)p * 16u;                                              \
-    const unsigned r0_ = (unsigned)(ch ? ri_.z : ri_.x), r1_ = (unsigned)(ch ? ri_.w : ri_.y);                  \
-    st[0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(r0_ * row_bytes + co_), 0, 0)); \
-    st[1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(r1_ * row_bytes + co_), 0, 0)); \
-  }
-#define GCLW_LOAD_B(KK, CCV)                                                                     \
-  {                                                                                              \
-    const u32x4* src_ = Wp + (((long long)(KK)*CC + (CCV)) * TNB + nb0) * (2 * NPL * 64);        \
-    br[0] = src_[t];                                                                             \
-    br[1] = src_[512 + t];                                                                       \
-  }
-#define GCLW_STORE_LDS(MINE, BUF)                                                                            \
-  {                                                                                                          \
-    if (MINE) {                                                                                              \
-      _Pragma("unroll") for (int ps = 0; ps < 2; ++ps) {                                                     \
-        const int row_ = rsub + 8 * (2 * ch + ps);                                                           \
-        *reinterpret_cast<float4*>(&Asm[BUF][wt][row_][(p ^ a_swz(row_)) << 2]) = st[ps];                    \
-      }                                                                                                      \
-    }                                                                                                        \
-    Bsm[BUF][t] = br[0];                                                                                     \
-    Bsm[BUF][512 + t] = br[1];                                                                               \
-  }
-#define GCLW_ADVANCE(KV, CV, HAS)            \
-  {                                          \
-    CV += 1;                                 \
-    if (CV == CC) {                          \
-      CV = 0;                                \
-      if (m_rest) {                          \
-        KV = __builtin_ctz(m_rest);          \
-        m_rest &= m_rest - 1;                \
-      } else {                               \
-        HAS = false;                         \
-      }                                      \
-    }                                        \
-  }
-  if (wgmask != 0u) {
-    unsigned m_rest = wgmask & (wgmask - 1);
-    float4 st[2];
-    u32x4 br[2];
-    int k0 = __builtin_ctz(wgmask);
-    bool mine0 = (mymask >> k0) & 1u;
-    if (mine0) GCLW_GATHER_A(k0, 0);
-    GCLW_LOAD_B(k0, 0);
-    int k1 = k0, c1 = 0;
-    bool has1 = true;
-    GCLW_ADVANCE(k1, c1, has1);
-    GCLW_STORE_LDS(mine0, 0);
-    bool mine1 = false;
-    if (has1) {
-      mine1 = (mymask >> k1) & 1u;
-      if (mine1) GCLW_GATHER_A(k1, c1);
-      GCLW_LOAD_B(k1, c1);
-    }
-    __syncthreads();
-    int buf = 0;
-    bool mine_cur = mine0;
-    while (true) {
-      if (mine_cur) {
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          u32x4 ap[3];
-          ap[0] = *reinterpret_cast<const u32x4*>(&Asm[buf][wt][i][((2 * m + h) ^ a_swz(i)) << 2]);
-          ap[1] = *reinterpret_cast<const u32x4*>(&Asm[buf][wt][i][((4 + 2 * m + h) ^ a_swz(i)) << 2]);
-#pragma unroll
-          for (int b = 0; b < NB; ++b) {
-            const u32x4* bb = &Bsm[buf][(((ch * 2 + b) * 2 + m) * NPL) * 64 + l];
-            u32x4 bp[3];
-            bp[0] = bb[0];
-            bp[1] = bb[64];
-            mfma_terms<PL>(ap, bp, acc[b]);
-          }
-        }
-      }
-      if (!has1) break;
-      // next step: registers -> the OTHER buffers (the partner wave may still be reading this step's A tile)
-      GCLW_STORE_LDS(mine1, buf ^ 1);
-      int k2 = k1, c2 = c1;
-      bool has2 = true, mine2 = false;
-      GCLW_ADVANCE(k2, c2, has2);
-      if (has2) {
-        mine2 = (mymask >> k2) & 1u;
-        if (mine2) GCLW_GATHER_A(k2, c2);
-        GCLW_LOAD_B(k2, c2);
-      }
-      __syncthreads();
-      buf ^= 1;
-      mine_cur = mine1;
-      mine1 = mine2;
-      k1 = k2;
-      c1 = c2;
-      has1 = has2;
-    }
-  }
-#undef GCLW_GATHER_A
-#undef GCLW_LOAD_B
-#undef GCLW_STORE_LDS
-#undef GCLW_ADVANCE
-  if (!active && !stats) return;
-  int orow_l = -1;
-  if (active && (l < 32) && (row0 + l < n_out)) orow_l = order ? order[row0 + l] : (int)(row0 + l);
-  float ymax = 0.f;
-  if (stats) __syncthreads();      // every wave is done with the A tiles: they become the column-sum scratch
-  float* const ssc = &Asm[ch][wt][0][0];
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    const int col = (nb0 + ch * 2 + b) * 32 + i;
-    float bvv = bias ? bias[col] : 0.f;
-    float csc = (EPI && epi.col_scale) ? epi.col_scale[col] * out_scale : out_scale;
-    asm volatile("v_mov_b32 %0, %1" : "=v"(bvv) : "v"(bvv));
-    asm volatile("v_mov_b32 %0, %1" : "=v"(csc) : "v"(csc));
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int orow = __shfl(orow_l, (r & 3) + 8 * (r >> 2) + 4 * h);
-      if (orow >= 0) {
-        float v = acc[b][r] * csc + bvv;
-        if (EPI && epi.residual) v += epi.residual[(long long)orow * cout + col];
-        if (EPI && epi.relu) v = fmaxf(v, 0.f);
-        Y[(long long)orow * cout + col] = v;
-        s1 += v;
-        s2 += v * v;
-        if (EPI) ymax = fmaxf(ymax, fabsf(v));
-      }
-    }
-    if (stats) {
-      s1 += __shfl_xor(s1, 32);
-      s2 += __shfl_xor(s2, 32);
-      if (h == 0) {
-        ssc[b * 32 + i] = s1;
-        ssc[NB * 32 + b * 32 + i] = s2;
-      }
-    }
-  }
-  if (stats) {
-    __syncthreads();
-    if (wt == 0 && h == 0) {
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const int col = (nb0 + ch * 2 + b) * 32 + i;
-        float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-        for (int ww = 0; ww < 4; ++ww) {      // the four row tiles in order, as the 4-wave kernel adds its waves
-          const float* o = &Asm[ch][ww][0][0];
-          t1 += o[b * 32 + i];
-          t2 += o[NB * 32 + b * 32 + i];
-        }
-        stats[((long long)bxx * 2 + 0) * cout + col] = t1;
-        stats[((long long)bxx * 2 + 1) * cout + col] = t2;
-      }
-    }
-    if (!active) return;
-  }
-  if (EPI && epi.y_amax) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o));
-    if (l == 0) amax_slot_publish(epi.y_amax, __float_as_int(ymax), (unsigned)(tile * 2 + ch));
-  }
-}
-
-// k_conv_fwd_split gathers every neighbour INSTANCE of a 128-row tile from memory (~8 per output row and slice on the
-// KITTI batch, served by the Infinity Cache at its gather rate -- that rate, not the MFMA pipe, bounds those kernels).
-// Here the tile is a compact blob of 128 rows in fine spatial order: its ~170 DISTINCT input rows (the halo) are
-// staged ONCE per 32-channel slice in LDS -- split into the fp16 / bf16 planes on the way, so the split is paid once per
-// halo row instead of once per gathered instance -- and the offset loop reads its A fragments from LDS through 16-bit
-// halo slots (slot table of the tile in LDS, slot HMAX = a row of zeros for absent neighbours).  Memory traffic of the A
-// operand drops ~5x; the weight blocks go through LDS as before (one workgroup barrier per unit, register sets loaded
-// DEPTH units ahead).  Loop order: slices outer, offsets inner (ascending), every product summed in a fixed order:
-// deterministic.  A tile whose halo exceeds HMAX rows is processed in passes over slot ranges (slots are ranked by row
-// id, so the pass split is deterministic).
-// STATUS: opt-in (GCL_HALO=1).  Measured on the KITTI batch it is 1.5 - 1.7x SLOWER than k_conv_fwd_split on the
-// mask-sorted table (profiles/r02_conv_experiments.txt): a spatial tile visits 13.7 - 18.6 units per wave where the
-// global mask sort visits 7.9 - 12.8, a workgroup pays ~6 serialized memory round trips outside its unit loop
-// (prologue, one staging per slice, epilogue) at 3 workgroups per CU, and removing the gather traffic did not shorten
-// the per-unit time -- the unit loop is bound by its latency chain, not by bytes.
-// ---------------------------------------------------------------------------------------------------
-constexpr int HALO_HMAX = 224;
-template <int NB, int PL, bool EPI, int DEPTH>
-__global__ void __launch_bounds__(256, (NB <= 2 ? 3 : 2)) k_conv_fwd_halo(const float* __restrict__ X, const u32x4* __restrict__ Wp,
-                                                          const int* __restrict__ hcount, const int* __restrict__ hrows,
-                                                          const unsigned short* __restrict__ hloc, int hcap,
-                                                          const int* __restrict__ order, const int* __restrict__ tile_mask,
-                                                          long long n_out, int K, int cin, int cout,
-                                                          const float* __restrict__ bias, float* __restrict__ Y,
-                                                          float* __restrict__ stats, const int* __restrict__ x_amax,
-                                                          const int* __restrict__ w_amax, unsigned x_bytes, ConvEpi epi) {
-  static_assert(PL != 3, "two-plane arithmetics only");
-  constexpr int NPL = 2;
-  constexpr int BLK = NB * 2 * NPL * 64;
-  constexpr int BREG = (BLK + 255) / 256;
-  const float a_scale = (PL == 4) ? amax_scale(x_amax) : 1.f;
-  const float out_scale = (PL == 4) ? 1.f / (a_scale * amax_scale(w_amax)) : 1.f;
-  __shared__ __attribute__((aligned(16))) float Hs[HALO_HMAX + 1][32];   // plane images of the halo rows' slice: 64 B hi | 64 B lo, 16-byte pieces XOR-swizzled
-  __shared__ __attribute__((aligned(16))) u32x4 Bsm[2][BLK];
-  __shared__ __attribute__((aligned(16))) unsigned short Lsm[27][128];   // halo slot of (offset, tile row)
-  __shared__ int Hrow[256];                                              // input rows of the pass's halo slots (-1 beyond)
-  __shared__ unsigned wmask[4];
-  const int t = threadIdx.x, l = t & 63, w = t >> 6;
-  const int i = l & 31, h = l >> 5;
-  // 1-D grid: the column blocks of one tile get consecutive slots of one XCD (they stage the same halo: L2 hits)
-  const unsigned ncb = (unsigned)(cout / (32 * NB)), nrw = (unsigned)((n_out + CONV_ROWS - 1) / CONV_ROWS);
-  unsigned bxx, byy;
-  {
-    const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-    byy = slot % ncb;
-    const unsigned q = nrw >> 3, r = nrw & 7u, mine = q + (xcd < r ? 1u : 0u), j = slot / ncb;
-    if (j >= mine) return;   // whole workgroup, before any barrier
-    bxx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;     // contiguous tile range per XCD
-  }
-  const long long tile = (long long)bxx * 4 + w;
-  const long long row0 = tile * 32;
-  const bool active = row0 < n_out;
-  const int nb0 = byy * NB;
-  const int TNB = cout >> 5, CC = cin >> 5;
-
-  f32x16 acc[NB];
-#pragma unroll
-  for (int b = 0; b < NB; ++b)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
-
-  unsigned mymask = 0u;
-  if (active) mymask = (unsigned)tile_mask[tile];
-  mymask = __builtin_amdgcn_readfirstlane(mymask);
-  if (l == 0) wmask[w] = mymask;
-  const int H = hcount[bxx];
-  const int npass = (H + HALO_HMAX - 1) / HALO_HMAX;
-  const int* const myhalo = hrows + (long long)bxx * hcap;
-  {   // slot table of the tile (K x 128 u16, contiguous) and the halo rows of the first pass
-    const u32x4* src = reinterpret_cast<const u32x4*>(hloc + (long long)bxx * K * 128);
-    u32x4* dst = reinterpret_cast<u32x4*>(&Lsm[0][0]);
-    for (int e = t; e < K * 16; e += 256) dst[e] = src[e];
-    Hrow[t] = (t < H && t < HALO_HMAX) ? myhalo[t] : -1;
-  }
-  if (t < 8) *reinterpret_cast<float4*>(&Hs[HALO_HMAX][t * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
-  __syncthreads();
-  const unsigned wgmask = wmask[0] | wmask[1] | wmask[2] | wmask[3];
-  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)x_bytes, 0x00020000);
-  const unsigned row_bytes = (unsigned)cin * 4u;
-
-#define GCL_LOAD_BH(SET, KK, CCV)                                                                \
-  {                                                                                              \
-    const u32x4* src_ = Wp + (((long long)(KK)*CC + (CCV)) * TNB + nb0) * (2 * NPL * 64);        \
-    _Pragma("unroll") for (int e = 0; e < BREG; ++e) {                                           \
-      if ((BLK % 256 == 0) || (e * 256 + t < BLK)) br[SET][e] = src_[e * 256 + t];               \
-    }                                                                                            \
-  }
-#define GCL_STORE_BH(SET, BUF)                                                                   \
-  {                                                                                              \
-    _Pragma("unroll") for (int e = 0; e < BREG; ++e) {                                           \
-      if ((BLK % 256 == 0) || (e * 256 + t < BLK)) Bsm[BUF][e * 256 + t] = br[SET][e];           \
-    }                                                                                            \
-  }
-  // unit iterator: offsets of the workgroup's mask ascending (inner), slices, passes (outer)
-#define GCL_UNIT_ADVANCE(KV, CV, PV, RESTV, HASV)  \
-  {                                                \
-    if (RESTV) {                                   \
-      KV = __builtin_ctz(RESTV);                   \
-      RESTV &= RESTV - 1;                          \
-    } else {                                       \
-      KV = k_first;                                \
-      RESTV = wgmask & (wgmask - 1);               \
-      CV += 1;                                     \
-      if (CV == CC) {                              \
-        CV = 0;                                    \
-        PV += 1;                                   \
-        if (PV == npass) HASV = false;             \
-      }                                            \
-    }                                              \
-  }
-
-  if (wgmask != 0u && npass > 0) {
-    u32x4 br[DEPTH][BREG];
-    const int k_first = __builtin_ctz(wgmask);
-    int bk = k_first, bc = 0, bp = 0;              // weight-block iterator, DEPTH units ahead of the compute loop
-    unsigned brest = wgmask & (wgmask - 1);
-    bool bhas = true;
-    int ck = k_first, cc = 0, cp = 0;              // compute iterator
-    unsigned crest = wgmask & (wgmask - 1);
-    bool chas = true;
-#pragma unroll
-    for (int u = 0; u < DEPTH; ++u) {
-      if (bhas) {
-        GCL_LOAD_BH(u, bk, bc);
-        GCL_UNIT_ADVANCE(bk, bc, bp, brest, bhas);
-      }
-    }
-    GCL_STORE_BH(0, 0);                            // block of unit 0 (published by the staging barrier below)
-    if (bhas) {
-      GCL_LOAD_BH(0, bk, bc);                      // set 0 now carries unit DEPTH
-      GCL_UNIT_ADVANCE(bk, bc, bp, brest, bhas);
-    }
-    int buf = 0;
-    bool new_slice = true;
-    while (chas) {
-#pragma unroll
-      for (int u = 0; u < DEPTH; ++u) {
-        if (!chas) break;
-        const int hbase = cp * HALO_HMAX;
-        const int hn = (H - hbase < HALO_HMAX) ? (H - hbase) : HALO_HMAX;
-        if (new_slice) {
-          // ---- stage the halo rows' slice: thread (row j = t / 4 + 64 v, quarter q = t % 4) loads 8 channels of up to
-          // four rows (all loads issued before the first use), splits them and writes 16 bytes of the hi half and 16
-          // bytes of the lo half.  Every wave is past its last read of Hs (the barrier that closed the previous unit).
-          if (cc == 0 && cp > 0) {                 // halo rows of this pass
-            Hrow[t] = (hbase + t < H && t < HALO_HMAX) ? myhalo[hbase + t] : -1;
-            __syncthreads();
-          }
-          const int q = t & 3;
-          float4 f[4][2];
-#pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            const int j = (t >> 2) + 64 * v;
-            const unsigned off = (unsigned)Hrow[j] * row_bytes + (unsigned)cc * 128u + (unsigned)q * 32u;   // row -1: zeros
-            f[v][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 0, 0));
-            f[v][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(off + 16u), 0, 0));
-          }
-#pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            const int j = (t >> 2) + 64 * v;
-            if (j < HALO_HMAX) {
-              u32x4 pl[2];
-              split8<PL>(f[v][0], f[v][1], a_scale, pl);
-              const int sw = a_swz(j);
-              *reinterpret_cast<u32x4*>(&Hs[j][(q ^ sw) << 2]) = pl[0];
-              *reinterpret_cast<u32x4*>(&Hs[j][((4 + q) ^ sw) << 2]) = pl[1];
-            }
-          }
-          __syncthreads();
-          new_slice = false;
-        }
-        if ((mymask >> ck) & 1u) {
-          unsigned slot = (unsigned)Lsm[ck][w * 32 + i] - (unsigned)hbase;
-          if (slot >= (unsigned)hn) slot = HALO_HMAX;      // absent neighbour, or a halo row of another pass: zeros
-          const float* rowp = &Hs[slot][0];
-          const int sw = a_swz((int)slot);
-#pragma unroll
-          for (int m = 0; m < 2; ++m) {
-            u32x4 ap[2];
-            ap[0] = *reinterpret_cast<const u32x4*>(&rowp[((2 * m + h) ^ sw) << 2]);
-            ap[1] = *reinterpret_cast<const u32x4*>(&rowp[((4 + 2 * m + h) ^ sw) << 2]);
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-              const u32x4* bb = &Bsm[buf][((b * 2 + m) * NPL) * 64 + l];
-              u32x4 bp2[2];
-              bp2[0] = bb[0];
-              bp2[1] = bb[64];
-              mfma_terms<PL>(ap, bp2, acc[b]);
-            }
-          }
-        }
-        {
-          const int cc_before = cc, cp_before = cp;
-          GCL_UNIT_ADVANCE(ck, cc, cp, crest, chas);
-          new_slice = (cc != cc_before) || (cp != cp_before);
-        }
-        if (chas) {
-          // ---- weight block of the next unit (register set (u + 1) % DEPTH, loaded DEPTH units ago) -> the LDS buffer
-          // nobody reads; the set is then refilled with the block DEPTH units further on
-          GCL_STORE_BH((u + 1) % DEPTH, buf ^ 1);
-          if (bhas) {
-            GCL_LOAD_BH((u + 1) % DEPTH, bk, bc);
-            GCL_UNIT_ADVANCE(bk, bc, bp, brest, bhas);
-          }
-        }
-        __syncthreads();
-        buf ^= 1;
-      }
-    }
-  }
-#undef GCL_LOAD_BH
-#undef GCL_STORE_BH
-#undef GCL_UNIT_ADVANCE
-  // (the loop's closing barrier, or the one after the prologue, has every wave past its last read of Bsm)
-  if (!active && !stats) return;
-  int orow_l = -1;
-  if (active && (l < 32) && (row0 + l < n_out)) orow_l = order[row0 + l];
-  float ymax = 0.f;
-  float* const ssc = reinterpret_cast<float*>(&Bsm[0][0]) + w * (NB * 64);
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    const int col = (nb0 + b) * 32 + i;
-    float bvv = bias ? bias[col] : 0.f;
-    float csc = (EPI && epi.col_scale) ? epi.col_scale[col] * out_scale : out_scale;
-    asm volatile("v_mov_b32 %0, %1" : "=v"(bvv) : "v"(bvv));
-    asm volatile("v_mov_b32 %0, %1" : "=v"(csc) : "v"(csc));
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int orow = __shfl(orow_l, (r & 3) + 8 * (r >> 2) + 4 * h);
-      if (orow >= 0) {
-        float v = acc[b][r] * csc + bvv;
-        if (EPI && epi.residual) v += epi.residual[(long long)orow * cout + col];
-        if (EPI && epi.relu) v = fmaxf(v, 0.f);
-        Y[(long long)orow * cout + col] = v;
-        s1 += v;
-        s2 += v * v;
-        if (EPI) ymax = fmaxf(ymax, fabsf(v));
-      }
-    }
-    if (stats) {
-      s1 += __shfl_xor(s1, 32);
-      s2 += __shfl_xor(s2, 32);
-      if (h == 0) {
-        ssc[b * 32 + i] = s1;
-        ssc[NB * 32 + b * 32 + i] = s2;
-      }
-    }
-  }
-  if (stats) {
-    __syncthreads();
-    if (w == 0 && h == 0) {
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const int col = (nb0 + b) * 32 + i;
-        float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-        for (int ww = 0; ww < 4; ++ww) {
-          const float* o = ssc + ww * (NB * 64);
-          t1 += o[b * 32 + i];
-          t2 += o[NB * 32 + b * 32 + i];
-        }
-        stats[((long long)bxx * 2 + 0) * cout + col] = t1;
-        stats[((long long)bxx * 2 + 1) * cout + col] = t2;
-      }
-    }
-    if (!active) return;
-  }
-  if (EPI && epi.y_amax) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o));
-    if (l == 0) amax_slot_publish(epi.y_amax, __float_as_int(ymax), (unsigned)tile);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// TWO (offset, slice) units per workgroup barrier.  k_conv_fwd_split issues the loads of a step just before the barrier
-// that closes the previous one and needs them when that step's 12 MFMAs per wave are done: the window a gather has to
-// arrive in is ONE short compute phase, far less than the latency of random 128-byte rows from the Infinity Cache under
-// load, so every step ends up waiting for the slowest row of its tile.  Here a step carries two units -- twice the
-// bytes in flight per wave, twice the MFMA work to hide them behind, half the barriers and half the loop overhead --
-// with the same per-unit arithmetic in the same order (bitwise-identical results).  The wave-private A tiles are
-// un-padded 128-byte rows whose 16-byte pieces are XOR-swizzled with the row (conflict-free ds_read_b128 like the
-// padded layout, 32 KB instead of 37 KB: two workgroups of NB = 2 fit a CU's 160 KB LDS).
-// ---------------------------------------------------------------------------------------------------
-template <int NB, int PL, bool PRE = false, bool EPI = false>
-__global__ void __launch_bounds__(256) k_conv_fwd_split2(const float* __restrict__ X, const u32x4* __restrict__ Wp,
-                                                         const int* __restrict__ tbl, const int* __restrict__ order,
-                                                         const int* __restrict__ tile_mask, long long n_out, int K,
-                                                         int cin, int cout, const float* __restrict__ bias,
-                                                         float* __restrict__ Y, int swizzle,
-                                                         float* __restrict__ stats, const int* __restrict__ x_amax,
-                                                         const int* __restrict__ w_amax, unsigned x_bytes, ConvEpi epi) {
-  constexpr int U = 2;
-  constexpr int NPL = Prec<PL>::planes;
-  constexpr int BLK = NB * 2 * NPL * 64;                // uint4 per unit weight block of this workgroup
-  constexpr int BREG = (BLK + 255) / 256;
-  const float a_scale = (PL == 4) ? amax_scale(x_amax) : 1.f;
-  const float out_scale = (PL == 4) ? 1.f / (a_scale * amax_scale(w_amax)) : 1.f;   // exact: powers of two
-  __shared__ __attribute__((aligned(16))) float Asm[4][U][32][32];        // wave-private A tiles, swizzled pieces
-  __shared__ __attribute__((aligned(16))) u32x4 Bsm[2][U][BLK];           // weight blocks, double-buffered
-  __shared__ __attribute__((aligned(16))) int Ism[4][27][32];
-  __shared__ unsigned wmask[4];
-  const int t = threadIdx.x, l = t & 63, w = t >> 6;
-  const int i = l & 31, h = l >> 5;
-  swizzle &= 15;   // (bit 4, heavy tiles first, is a k_conv_fwd_split feature)
-  unsigned bxx = blockIdx.x, byy = blockIdx.y;
-  if (swizzle >= 2) {
-    const unsigned ncb = (unsigned)(cout / (32 * NB)), nrw = (unsigned)((n_out + CONV_ROWS - 1) / CONV_ROWS);
-    const unsigned xcd = bxx & 7u, slot = bxx >> 3;
-    byy = slot % ncb;
-    if (swizzle == 2) {
-      bxx = (slot / ncb) * 8u + xcd;
-      if (bxx >= nrw) return;
-    } else {
-      const unsigned q = nrw >> 3, r = nrw & 7u, mine = q + (xcd < r ? 1u : 0u), j = slot / ncb;
-      if (j >= mine) return;
-      bxx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-    }
-  } else {
-    bxx = xcd_tile(bxx, gridDim.x, swizzle);
-  }
-  const long long tile = (long long)bxx * 4 + w;
-  const long long row0 = tile * 32;
-  const bool active = row0 < n_out;
-  const int nb0 = byy * NB;
-  const int TNB = cout >> 5, CC = cin >> 5;
-  const int p = l & 7, rsub = l >> 3;
-
-  f32x16 acc[NB];
-#pragma unroll
-  for (int b = 0; b < NB; ++b)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
-
-  unsigned mymask = 0u;
-  if (active) mymask = tile_mask ? (unsigned)tile_mask[tile] : ((K >= 32) ? ~0u : ((1u << K) - 1u));
-  mymask = __builtin_amdgcn_readfirstlane(mymask);
-  if (l == 0) wmask[w] = mymask;
-  for (int e = l; e < K * 32; e += 64) {
-    int k = e >> 5, r = e & 31;
-    int v = -1;
-    if (active && row0 + r < n_out) v = tbl ? tbl[(long long)k * n_out + row0 + r] : (int)(row0 + r);
-    Ism[w][k][(r & 7) * 4 + (r >> 3)] = v;
-  }
-  __syncthreads();
-  const unsigned wgmask = wmask[0] | wmask[1] | wmask[2] | wmask[3];
-
-  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)x_bytes, 0x00020000);
-  const unsigned row_bytes = (unsigned)cin * 4u;
-  // swizzled LDS float offsets of this lane's four gathered rows (write side) and of its fragment row (read side)
-  int wr_off[4];
-#pragma unroll
-  for (int ps = 0; ps < 4; ++ps) wr_off[ps] = (rsub + 8 * ps) * 32 + ((p ^ a_swz(rsub + 8 * ps)) << 2);
-  const int rd_swz = a_swz(i);
-
-  if (wgmask != 0u) {
-    // cursor over the unit sequence: offsets of the workgroup mask in ascending order x the CC channel slices
-    unsigned m_rest = wgmask & (wgmask - 1);
-    int kc = __builtin_ctz(wgmask), cc = 0;
-    bool more = true;                                   // the cursor points at an existing unit
-    float4 st[U][4];
-    u32x4 br[U][BREG];
-    int kn[U], cn[U];
-    bool hn[U], mn[U];                                   // staged step: unit exists / this wave has rows for it
-    bool hc[U], mc[U];                                   // current step (in LDS)
-    auto advance = [&]() {
-      cc += 1;
-      if (cc == CC) {
-        cc = 0;
-        if (m_rest) {
-          kc = __builtin_ctz(m_rest);
-          m_rest &= m_rest - 1;
-        } else {
-          more = false;
-        }
-      }
-    };
-#define GCL2_LOAD_STEP()                                                                                          \
-  _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                                 \
-    hn[u] = more;                                                                                                 \
-    mn[u] = false;                                                                                                \
-    kn[u] = kc;                                                                                                   \
-    cn[u] = cc;                                                                                                   \
-    if (more) {                                                                                                   \
-      mn[u] = (mymask >> kc) & 1u;                                                                                \
-      if (mn[u]) {                                                                                                \
-        const int4 ri_ = *reinterpret_cast<const int4*>(&Ism[w][kc][rsub * 4]);                                  \
-        const unsigned co_ = (unsigned)cc * 128u + (unsigned)p * 16u;                                             \
-        st[u][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)((unsigned)ri_.x * row_bytes + co_), 0, 0)); \
-        st[u][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)((unsigned)ri_.y * row_bytes + co_), 0, 0)); \
-        st[u][2] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)((unsigned)ri_.z * row_bytes + co_), 0, 0)); \
-        st[u][3] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)((unsigned)ri_.w * row_bytes + co_), 0, 0)); \
-      }                                                                                                           \
-      const u32x4* src_ = Wp + (((long long)kc * CC + cc) * TNB + nb0) * (2 * NPL * 64);                          \
-      _Pragma("unroll") for (int e = 0; e < BREG; ++e) {                                                          \
-        if ((BLK % 256 == 0) || (e * 256 + t < BLK)) br[u][e] = src_[e * 256 + t];                               \
-      }                                                                                                           \
-      advance();                                                                                                  \
-    }                                                                                                             \
-  }
-#define GCL2_STORE_STEP(BUF)                                                                                      \
-  _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                                 \
-    if (hn[u]) {                                                                                                  \
-      if (mn[u]) {                                                                                                \
-        float* at_ = &Asm[w][u][0][0];                                                                            \
-        _Pragma("unroll") for (int ps = 0; ps < 4; ++ps) *reinterpret_cast<float4*>(at_ + wr_off[ps]) = st[u][ps]; \
-      }                                                                                                           \
-      _Pragma("unroll") for (int e = 0; e < BREG; ++e) {                                                          \
-        if ((BLK % 256 == 0) || (e * 256 + t < BLK)) Bsm[BUF][u][e * 256 + t] = br[u][e];                         \
-      }                                                                                                           \
-    }                                                                                                             \
-  }
-    // step 0 -> LDS, step 1 -> registers
-    GCL2_LOAD_STEP();
-    GCL2_STORE_STEP(0);
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      hc[u] = hn[u];
-      mc[u] = mn[u];
-    }
-    GCL2_LOAD_STEP();
-    __syncthreads();
-    int buf = 0;
-    while (true) {
-      // ---- compute the current step: its units from Asm[w][u] (own tiles) and Bsm[buf][u]
-      WAVE_FENCE();
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (hc[u] && mc[u]) {
-          const float* ar = &Asm[w][u][i][0];
-#pragma unroll
-          for (int m = 0; m < 2; ++m) {
-            u32x4 ap[3];
-            if (PRE) {   // row image: pieces 0..3 = hi of channels 0..31, 4..7 = lo
-              ap[0] = *reinterpret_cast<const u32x4*>(ar + (((2 * m + h) ^ rd_swz) << 2));
-              ap[1] = *reinterpret_cast<const u32x4*>(ar + (((4 + 2 * m + h) ^ rd_swz) << 2));
-            } else {
-              float4 f0 = *reinterpret_cast<const float4*>(ar + (((4 * m + 2 * h) ^ rd_swz) << 2));
-              float4 f1 = *reinterpret_cast<const float4*>(ar + (((4 * m + 2 * h + 1) ^ rd_swz) << 2));
-              split8<PL>(f0, f1, a_scale, ap);
-            }
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-              const u32x4* bb = &Bsm[buf][u][((b * 2 + m) * NPL) * 64 + l];
-              u32x4 bp[3];
-              bp[0] = bb[0];
-              bp[1] = bb[64];
-              if (NPL == 3) bp[2] = bb[128];
-              mfma_terms<PL>(ap, bp, acc[b]);
-            }
-          }
-        }
-      }
-      if (!hn[0]) break;   // nothing staged in registers: done
-      // ---- staged step: registers -> LDS (A: own tiles, after this wave's reads; B: the buffer nobody reads)
-      WAVE_FENCE();
-      GCL2_STORE_STEP(buf ^ 1);
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        hc[u] = hn[u];
-        mc[u] = mn[u];
-      }
-      // ---- the step after: issue its loads (in flight across the barrier and the next compute phase)
-      GCL2_LOAD_STEP();
-      __syncthreads();   // publishes the weight blocks just written; their buffer was last read two steps ago
-      buf ^= 1;
-    }
-#undef GCL2_LOAD_STEP
-#undef GCL2_STORE_STEP
-  }
-  if (!active && !stats) return;
-  int orow_l = -1;
-  if (active && (l < 32) && (row0 + l < n_out)) orow_l = order ? order[row0 + l] : (int)(row0 + l);
-  float ymax = 0.f;
-  // column sums of this wave's 32 rows go to its own (now idle) A tile; wave 0 adds the four waves in order and writes
-  // ONE partial per workgroup (128 rows) for the BatchNorm that follows (saves its statistics pass over Y)
-  float* const ssc = &Asm[w][0][0][0];
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    const int col = (nb0 + b) * 32 + i;
-    float bvv = bias ? bias[col] : 0.f;
-    float csc = (EPI && epi.col_scale) ? epi.col_scale[col] * out_scale : out_scale;
-    // consume the (conditional) loads HERE: otherwise every store below waits for all earlier stores (vmcnt(0))
-    asm volatile("v_mov_b32 %0, %1" : "=v"(bvv) : "v"(bvv));
-    asm volatile("v_mov_b32 %0, %1" : "=v"(csc) : "v"(csc));
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int orow = __shfl(orow_l, (r & 3) + 8 * (r >> 2) + 4 * h);
-      if (orow >= 0) {
-        float v = acc[b][r] * csc + bvv;
-        if (EPI && epi.residual) v += epi.residual[(long long)orow * cout + col];
-        if (EPI && epi.relu) v = fmaxf(v, 0.f);
-        Y[(long long)orow * cout + col] = v;
-        s1 += v;
-        s2 += v * v;
-        if (EPI) ymax = fmaxf(ymax, fabsf(v));
-      }
-    }
-    if (stats) {
-      s1 += __shfl_xor(s1, 32);
-      s2 += __shfl_xor(s2, 32);
-      if (h == 0) {
-        ssc[b * 32 + i] = s1;
-        ssc[NB * 32 + b * 32 + i] = s2;
-      }
-    }
-  }
-  if (stats) {
-    __syncthreads();
-    if (w == 0 && h == 0) {
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const int col = (nb0 + b) * 32 + i;
-        float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-        for (int ww = 0; ww < 4; ++ww) {
-          const float* o = ssc + ww * (2 * 32 * 32);
-          t1 += o[b * 32 + i];
-          t2 += o[NB * 32 + b * 32 + i];
-        }
-        stats[((long long)bxx * 2 + 0) * cout + col] = t1;
-        stats[((long long)bxx * 2 + 1) * cout + col] = t2;
-      }
-    }
-    if (!active) return;
   }
   if (EPI && epi.y_amax) {
 #pragma unroll
@@ -2732,25 +1969,10 @@ int gcl_conv_fwd_fused(const float* x, int64_t n_in, int32_t x_is_planes, const 
 #define LAUNCH_F32(NBV)                                                                                          \
   hipLaunchKernelGGL(k_conv_fwd<NBV>, grid, dim3(256), 0, st, x, (const float4*)wp, tbl, order, tile_mask,       \
                      (long long)n_out, K, cin, cout, bias, y, swz)
-  // TUNING KNOB: GCL_CONV_UNITS=2 selects k_conv_fwd_split2 (two units per barrier) for the NB <= 2 instances of the
-  // two-plane arithmetics.  Measured on the KITTI batch (profiles/r02_conv_units.txt): bitwise-identical results, every
-  // layer 10-40 % SLOWER (80 KB of LDS per workgroup: 2 instead of 3-4 workgroups per CU) -- occupancy, not the
-  // prefetch distance, is what hides the gather latency here.  Default 1.
-  static const int units = [] { const char* e = getenv("GCL_CONV_UNITS"); return e ? atoi(e) : 1; }();
 #define LAUNCH_SPLIT_I(NBV, PLV, PREV, EPIV)                                                                     \
-  do {                                                                                                           \
-    if constexpr (NBV <= 2 && PLV != 3) {                                                                        \
-      if (units >= 2) {                                                                                          \
-        hipLaunchKernelGGL((k_conv_fwd_split2<NBV, PLV, PREV, EPIV>), sgrid, dim3(256), 0, st, x, (const u32x4*)wp, \
-                           tbl, order, tile_mask, (long long)n_out, K, cin, cout, bias, y, sswz, stats, x_amax,   \
-                           w_amax, x_bytes, epi);                                                                \
-        break;                                                                                                   \
-      }                                                                                                          \
-    }                                                                                                            \
-    hipLaunchKernelGGL((k_conv_fwd_split<NBV, PLV, PREV, EPIV>), sgrid, dim3(256), 0, st, x, (const u32x4*)wp, tbl, \
-                       order, tile_mask, (long long)n_out, K, cin, cout, bias, y, sswz, stats, x_amax, w_amax,   \
-                       x_bytes, epi);                                                                            \
-  } while (0)
+  hipLaunchKernelGGL((k_conv_fwd_split<NBV, PLV, PREV, EPIV>), sgrid, dim3(256), 0, st, x, (const u32x4*)wp, tbl, \
+                     order, tile_mask, (long long)n_out, K, cin, cout, bias, y, sswz, stats, x_amax, w_amax,   \
+                     x_bytes, epi)
 #define LAUNCH_SPLIT(NBV, PLV)                                                                                   \
   do {                                                                                                           \
     if (PLV == 4 && x_is_planes) {                                                                               \
@@ -2787,23 +2009,6 @@ int gcl_conv_fwd_fused(const float* x, int64_t n_in, int32_t x_is_planes, const 
     GCL_CHECK_LAUNCH();
     return GCL_OK;
   }
-  // TUNING KNOB, default off: eight-wave workgroups (128 rows x 128 columns, k_conv_fwd_wide) for plane-image launches with
-  // Cout a multiple of 128 (GCL_FWD_WIDE=1 or flag GCL_CONV_WIDE).  Bitwise the same results with half the gathered bytes
-  // and 88 instead of 104 VGPRs -- and the same launch times (profiles/r03_conv_experiments.txt, 13).
-  static const int wide = [] { const char* e = getenv("GCL_FWD_WIDE"); return e ? atoi(e) : 0; }();
-  if ((wide || (flags & GCL_CONV_WIDE)) && prec == 4 && x_is_planes && cout % 128 == 0 && colgroup && !swz && !ranges &&
-      units < 2) {
-    const dim3 wgrid((unsigned)(cdiv(gx, 8) * 8 * (cout / 128)));
-    const int wswz = 2 | ((heavy_first && tile_mask) ? 16 : 0);
-    if (use_epi)
-      hipLaunchKernelGGL((k_conv_fwd_wide<true, true>), wgrid, dim3(512), 0, st, x, (const u32x4*)wp, tbl, order, tile_mask,
-                         (long long)n_out, K, cin, cout, bias, y, wswz, stats, x_amax, w_amax, x_bytes, epi);
-    else
-      hipLaunchKernelGGL((k_conv_fwd_wide<true, false>), wgrid, dim3(512), 0, st, x, (const u32x4*)wp, tbl, order, tile_mask,
-                         (long long)n_out, K, cin, cout, bias, y, wswz, stats, x_amax, w_amax, x_bytes, epi);
-    GCL_CHECK_LAUNCH();
-    return GCL_OK;
-  }
   if (prec == 0) {
     if (nb == 4) LAUNCH_F32(4); else if (nb == 2) LAUNCH_F32(2); else LAUNCH_F32(1);
   } else if (prec == 2) LAUNCH_SPLIT_NB(2)
@@ -2816,47 +2021,6 @@ int gcl_conv_fwd_fused(const float* x, int64_t n_in, int32_t x_is_planes, const 
 #undef LAUNCH_SPLIT_I
 #undef LAUNCH_SPLIT_NB
 #undef LAUNCH_SPLIT_NB2
-  GCL_CHECK_LAUNCH();
-  return GCL_OK;
-}
-
-int gcl_conv_fwd_halo(const float* x, int64_t n_in, const void* wp, int32_t prec, const int32_t* x_amax,
-                      const int32_t* w_amax, const int32_t* hcount, const int32_t* hrows, const uint16_t* hloc,
-                      const int32_t* order, const int32_t* tile_mask, int64_t n_out, int32_t K, int32_t cin,
-                      int32_t cout, const float* bias, const float* col_scale, const float* residual, int32_t relu,
-                      int32_t* y_amax, float* y, float* stats, void* stream) {
-  const ConvEpi epi{col_scale, residual, relu, y_amax};
-  const bool use_epi = col_scale || residual || relu || y_amax;
-  GCL_CHECK_ARG(x && wp && y && hcount && hrows && hloc && order && tile_mask, "gcl_conv_fwd_halo: null pointer");
-  GCL_CHECK_ARG(n_in > 0 && (long long)n_in * cin * 4 < (1ll << 32) - (1ll << 20),
-                "gcl_conv_fwd_halo: the input tensor must be non-empty and smaller than 4 GiB (buffer addressing)");
-  GCL_CHECK_ARG(n_out > 0 && K >= 1 && K <= 27, "gcl_conv_fwd_halo: n_out must be positive and 1 <= K <= 27");
-  GCL_CHECK_ARG(cin % 32 == 0 && cout % 32 == 0 && cin > 0 && cout > 0,
-                "gcl_conv_fwd_halo: Cin (%d) and Cout (%d) must be positive multiples of 32", cin, cout);
-  GCL_CHECK_ARG(prec == 2 || prec == 4, "gcl_conv_fwd_halo: prec must be 2 (bf16x3) or 4 (fp16x3)");
-  GCL_CHECK_ARG(prec != 4 || (x_amax && w_amax), "gcl_conv_fwd_halo: fp16x3 needs gcl_amax of x and of the weights");
-  const unsigned x_bytes = (unsigned)((long long)n_in * cin * 4);
-  hipStream_t st = (hipStream_t)stream;
-  static const int nb4 = [] { const char* e = getenv("GCL_HALO_NB4"); return e ? atoi(e) : 0; }();
-  const int nb = (nb4 && cout % 128 == 0) ? 4 : ((cout % 64 == 0) ? 2 : 1);
-  const unsigned gx = (unsigned)cdiv(n_out, CONV_ROWS);
-  const dim3 grid((unsigned)(cdiv(gx, 8) * 8 * (cout / (32 * nb))));
-  const int hcap = K * 128;
-#define LAUNCH_HALO(NBV, PLV, EPIV)                                                                               \
-  hipLaunchKernelGGL((k_conv_fwd_halo<NBV, PLV, EPIV, 2>), grid, dim3(256), 0, st, x, (const u32x4*)wp, hcount, hrows, \
-                     hloc, hcap, order, tile_mask, (long long)n_out, K, cin, cout, bias, y, stats, x_amax, w_amax, \
-                     x_bytes, epi)
-#define LAUNCH_HALO_P(NBV)                                                     \
-  {                                                                            \
-    if (prec == 4) {                                                           \
-      if (use_epi) LAUNCH_HALO(NBV, 4, true); else LAUNCH_HALO(NBV, 4, false); \
-    } else {                                                                   \
-      if (use_epi) LAUNCH_HALO(NBV, 2, true); else LAUNCH_HALO(NBV, 2, false); \
-    }                                                                          \
-  }
-  if (nb == 4) LAUNCH_HALO_P(4) else if (nb == 2) LAUNCH_HALO_P(2) else LAUNCH_HALO_P(1)
-#undef LAUNCH_HALO
-#undef LAUNCH_HALO_P
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }

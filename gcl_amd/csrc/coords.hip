@@ -675,159 +675,6 @@ __global__ void k_spatial_keys(const int4* __restrict__ coords, long long n, int
   vals[v] = (int)v;
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Halo tiles (stride-1 3^3 maps; consumed by k_conv_fwd_halo in conv.hip).  The rows of the map are put in FINE spatial
-// order -- inside every 4096-row window of the coarse (cloud, cell) order of gcl_spatial_order the rows are sorted by
-// (coarse key, 10-bit Morton code of the voxel inside its 16 x 16 x 4 cell) -- so that 128 consecutive rows form a
-// compact blob whose 27-neighbourhoods overlap: measured on the KITTI batch a tile's ~800 gathered neighbour instances
-// are ~170 DISTINCT input rows at every level.  Inside each 128-row tile the rows are then sorted by presence mask, so
-// that the four 32-row wave tiles still skip the offsets none of their rows has.
-// ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned spatial_coarse_key(const int4 c, int tstride) {
-  const unsigned cx = (unsigned)((c.y / tstride + 4096) >> 4), cy = (unsigned)((c.z / tstride + 4096) >> 4),
-                 cz = (unsigned)((c.w / tstride + 4096) >> 2);
-  unsigned m = 0;
-#pragma unroll
-  for (int b = 3; b >= 0; --b) {
-    m = (m << 1) | ((cx >> b) & 1u);
-    m = (m << 1) | ((cy >> b) & 1u);
-    if (b < 3) m = (m << 1) | ((cz >> b) & 1u);
-  }
-  return (((unsigned)c.x & 31u) << 11) | (m & 2047u);
-}
-
-template <int WIN>
-__device__ __forceinline__ void bitonic_lds(unsigned long long* kv, int last_size) {
-  for (int size = 2; size <= last_size; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int e = threadIdx.x; e < WIN / 2; e += 256) {
-        int lo = 2 * e - (e & (stride - 1));   // index of the lower element of the pair
-        int hi = lo + stride;
-        bool up = (size == last_size) || ((lo & size) == 0);   // every group of last_size ends ascending
-        unsigned long long a = kv[lo], b = kv[hi];
-        if ((a > b) == up) {
-          kv[lo] = b;
-          kv[hi] = a;
-        }
-      }
-      __syncthreads();
-    }
-  }
-}
-
-template <int WIN>
-__global__ void __launch_bounds__(256) k_halo_sort(const int* __restrict__ tbl, int K, long long n,
-                                                   const int* __restrict__ pre, const int4* __restrict__ coords,
-                                                   int tstride, int* order, unsigned* keys_sorted) {
-  __shared__ unsigned long long kv[WIN];
-  const long long base = (long long)blockIdx.x * WIN;
-  for (int e = threadIdx.x; e < WIN; e += 256) {
-    long long v = base + e;
-    unsigned long long key = ~0ull;            // padding sorts last
-    if (v < n) {
-      const int row = pre[v];
-      const int4 c = coords[row];
-      const unsigned fx = (unsigned)(c.y / tstride + 4096) & 15u, fy = (unsigned)(c.z / tstride + 4096) & 15u,
-                     fz = (unsigned)(c.w / tstride + 4096) & 3u;
-      unsigned f = 0;
-#pragma unroll
-      for (int b = 3; b >= 0; --b) {
-        f = (f << 1) | ((fx >> b) & 1u);
-        f = (f << 1) | ((fy >> b) & 1u);
-        if (b < 2) f = (f << 1) | ((fz >> b) & 1u);
-      }
-      key = ((unsigned long long)spatial_coarse_key(c, tstride) << 42) | ((unsigned long long)(f & 1023u) << 32) | (unsigned)row;
-    }
-    kv[e] = key;
-  }
-  __syncthreads();
-  bitonic_lds<WIN>(kv, WIN);
-  for (int e = threadIdx.x; e < WIN; e += 256) {   // second key: (mask, row) inside the 128-row tiles
-    unsigned long long key = kv[e];
-    if (key != ~0ull) {
-      const unsigned row = (unsigned)(key & 0xffffffffu);
-      unsigned m = 0;
-      for (int k = 0; k < K; ++k) m |= (tbl[(long long)k * n + row] >= 0 ? 1u : 0u) << k;
-      kv[e] = ((unsigned long long)m << 32) | row;
-    }
-  }
-  __syncthreads();
-  bitonic_lds<WIN>(kv, 128);
-  for (int e = threadIdx.x; e < WIN; e += 256) {
-    long long j = base + e;
-    if (j < n) {
-      unsigned long long key = kv[e];
-      order[j] = (int)(unsigned)(key & 0xffffffffu);
-      keys_sorted[j] = (unsigned)(key >> 32);
-    }
-  }
-}
-
-// One workgroup per 128-row tile of the SORTED table: the distinct input rows of the tile's K x 128 neighbour entries
-// (LDS hash set), ranked by row id (deterministic slots: a tile whose halo exceeds the convolution kernel's LDS window is
-// processed in passes over slot ranges, so the slot order fixes the accumulation order), and the entries rewritten as
-// 16-bit halo slots (0xFFFF = no neighbour).
-constexpr int HALO_HASH = 8192;
-__global__ void __launch_bounds__(256) k_halo_build(const int* __restrict__ tbl_sorted, long long n, int K, int hcap,
-                                                    int* hcount, int* hrows, unsigned short* hloc) {
-  __shared__ int hkey[HALO_HASH];
-  __shared__ unsigned short hslot[HALO_HASH];
-  __shared__ int keys[27 * 128];
-  __shared__ int cnt;
-  const int t = threadIdx.x;
-  const long long tile = blockIdx.x, row0 = tile * 128;
-  for (int e = t; e < HALO_HASH; e += 256) hkey[e] = -1;
-  if (t == 0) cnt = 0;
-  __syncthreads();
-  int v[14];
-#pragma unroll
-  for (int j = 0; j < 14; ++j) {
-    const int e = t + 256 * j, k = e >> 7, r = e & 127;
-    int idx = -1;
-    if (k < K && row0 + r < n) idx = tbl_sorted[(long long)k * n + row0 + r];
-    v[j] = idx;
-    if (idx >= 0) {
-      unsigned h = ((unsigned)idx * 2654435761u) >> 19;
-      while (true) {
-        const int old = atomicCAS(&hkey[h], -1, idx);
-        if (old == -1) {
-          keys[atomicAdd(&cnt, 1)] = idx;
-          break;
-        }
-        if (old == idx) break;
-        h = (h + 1) & (HALO_HASH - 1);
-      }
-    }
-  }
-  __syncthreads();
-  const int H = cnt;
-  for (int j = t; j < H; j += 256) {
-    const int key = keys[j];
-    int rank = 0;
-    for (int i = 0; i < H; ++i) rank += keys[i] < key ? 1 : 0;
-    if (rank < hcap) hrows[tile * hcap + rank] = key;
-    unsigned h = ((unsigned)key * 2654435761u) >> 19;
-    while (hkey[h] != key) h = (h + 1) & (HALO_HASH - 1);
-    hslot[h] = (unsigned short)rank;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < 14; ++j) {
-    const int e = t + 256 * j, k = e >> 7, r = e & 127;
-    if (k < K) {
-      unsigned short loc = 0xFFFFu;
-      const int idx = v[j];
-      if (idx >= 0) {
-        unsigned h = ((unsigned)idx * 2654435761u) >> 19;
-        while (hkey[h] != idx) h = (h + 1) & (HALO_HASH - 1);
-        loc = hslot[h];
-      }
-      hloc[(tile * K + k) * 128 + r] = loc;
-    }
-  }
-  if (t == 0) hcount[tile] = H;
-}
-
 // tile_mask (optional): an offset missing from a 32-row tile's mask is -1 for all of its rows by definition -- written
 // without the (scattered, 4-byte) read of the source table: ~19 of 27 offsets on the KITTI batch
 __device__ __forceinline__ void permute_table_body(const int* __restrict__ tbl, const int* __restrict__ order, long long n,
@@ -1284,27 +1131,6 @@ int gcl_table_sort_multi(const gcl_sort_job* jobs_host, int32_t n_jobs, void* st
     hipLaunchKernelGGL(k_permute_table_multi, dim3(gn, K0, T), dim3(256), 0, st, J);
     GCL_CHECK_LAUNCH();
   }
-  return GCL_OK;
-}
-
-int gcl_table_sort_halo(const int32_t* tbl, int32_t K, int64_t n, const int32_t* pre, const int32_t* coords,
-                        int32_t tensor_stride, int32_t* scratch, int32_t* order, int32_t* tbl_sorted, int32_t* tile_mask,
-                        int32_t* hcount, int32_t* hrows, uint16_t* hloc, void* stream) {
-  GCL_CHECK_ARG(tbl && pre && coords && scratch && order && tbl_sorted && tile_mask && hcount && hrows && hloc,
-                "gcl_table_sort_halo: null pointer");
-  GCL_CHECK_ARG(K >= 1 && K <= 27 && n > 0 && tensor_stride >= 1, "gcl_table_sort_halo: K must be <= 27, n > 0");
-  hipStream_t st = (hipStream_t)stream;
-  unsigned* ka = (unsigned*)scratch;
-  hipLaunchKernelGGL(k_halo_sort<4096>, dim3((unsigned)cdiv(n, 4096)), dim3(256), 0, st, tbl, K, (long long)n, pre,
-                     (const int4*)coords, tensor_stride, order, ka);
-  long long n_tiles = cdiv(n, 32);
-  hipLaunchKernelGGL(k_tile_masks, dim3((unsigned)cdiv(n_tiles * 32, 256)), dim3(256), 0, st, (const unsigned*)ka,
-                     (long long)n, n_tiles, tile_mask, (const int*)nullptr, K);
-  hipLaunchKernelGGL(k_permute_table, dim3((unsigned)cdiv(n, 256), K), dim3(256), 0, st, tbl, (const int*)order,
-                     (long long)n, tbl_sorted, (const int*)tile_mask);
-  hipLaunchKernelGGL(k_halo_build, dim3((unsigned)cdiv(n, 128)), dim3(256), 0, st, (const int*)tbl_sorted, (long long)n, K,
-                     K * 128, hcount, hrows, hloc);
-  GCL_CHECK_LAUNCH();
   return GCL_OK;
 }
 

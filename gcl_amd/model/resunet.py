@@ -135,7 +135,7 @@ class ResUNet2(ME.MinkowskiNetwork):
         if (self.training or torch.is_grad_enabled() or not native.PLAN_ENABLED or ops.PRECISION != "fp16x3"
                 or self.NORM_TYPE != "BN" or self.BLOCK_NORM_TYPE != "BN" or x.coordinate_map_key.tensor_stride != 1
                 or self.__dict__.get("_plan") is False or any(m.training for m in self.modules())
-                or ME.core.HALO or ME.core.SORT_WINDOW or ME.core.SPATIAL_MAX_STRIDE):
+                or ME.core.SORT_WINDOW or ME.core.SPATIAL_MAX_STRIDE):
             return None
         mgr = x.coordinate_manager
         if mgr.native is None:

@@ -230,9 +230,6 @@ int gcl_split_planes(const float* x, int64_t n, int32_t c, const int32_t* amax, 
                                (batching stays bitwise neutral).  fp16x3 on fp32 rows, no BatchNorm statistics, K >= 8,
                                K Cin / 32 >= 108 (Cin >= 128 at K = 27), Cout a multiple of 64; ignored elsewhere.  Results differ from the launch
                                without the flag in the last bits (another summation order). */
-#define GCL_CONV_WIDE 2     /* run the eight-wave kernel (128 rows x 128 columns per workgroup) where it applies: fp16x3 on
-                               plane images, Cout a multiple of 128; bitwise the same results as the four-wave kernel
-                               (same as GCL_FWD_WIDE=1; measured neither faster nor slower) */
 int gcl_conv_fwd(const float* x, int64_t n_in, int32_t x_is_planes, const void* wp, int32_t prec, const int32_t* x_amax,
                  const int32_t* w_amax, const int32_t* tbl, const int32_t* order, const int32_t* tile_mask,
                  int64_t n_out, int32_t K,
@@ -247,27 +244,6 @@ int gcl_conv_fwd_fused(const float* x, int64_t n_in, int32_t x_is_planes, const 
                        const int32_t* tile_mask, int64_t n_out, int32_t K, int32_t cin, int32_t cout, const float* bias,
                        const float* col_scale, const float* residual, int32_t relu, int32_t* y_amax, float* y,
                        float* stats, int32_t flags, void* stream);
-
-/* Halo tiles for stride-1 3^3 maps (in == out coordinates, K = 27; replaces gcl_table_sort for those maps).
- * gcl_table_sort_halo: rows in FINE spatial order (pre = gcl_spatial_order of the level, refined inside 4096-row windows
- *   by the voxel's Morton code inside its cell; coords = the level's [n,4] coordinates), mask-sorted inside every 128-row
- *   tile; outputs order / tbl_sorted / tile_mask exactly like gcl_table_sort (usable by gcl_conv_fwd as they are) plus,
- *   per 128-row tile T: hcount[T] = number of DISTINCT input rows the tile's K x 128 neighbour entries name (its halo),
- *   hrows[T][K*128] = those rows in ascending order, hloc[T][K][128] (uint16) = halo slot of every entry (0xFFFF = no
- *   neighbour).  scratch: int32[gcl_table_sort_scratch_len(n)].
- * gcl_conv_fwd_halo: the convolution of gcl_conv_fwd_fused over such tiles -- the halo rows of a tile are staged once per
- *   32-channel slice in LDS (split into planes on the way) and the offset loop reads them there: ~5x less gather
- *   traffic.  prec 2 or 4; x is the fp32 tensor; epilogue arguments as in gcl_conv_fwd_fused (all optional).
- *   Deterministic; sums in a different (fixed) order than gcl_conv_fwd, so results agree to rounding, not bitwise.
- *   Reference: the same MinkowskiConvolution forward / input-gradient as gcl_conv_fwd (model/resunet.py:102-170). */
-int gcl_table_sort_halo(const int32_t* tbl, int32_t K, int64_t n, const int32_t* pre, const int32_t* coords,
-                        int32_t tensor_stride, int32_t* scratch, int32_t* order, int32_t* tbl_sorted, int32_t* tile_mask,
-                        int32_t* hcount, int32_t* hrows, uint16_t* hloc, void* stream);
-int gcl_conv_fwd_halo(const float* x, int64_t n_in, const void* wp, int32_t prec, const int32_t* x_amax,
-                      const int32_t* w_amax, const int32_t* hcount, const int32_t* hrows, const uint16_t* hloc,
-                      const int32_t* order, const int32_t* tile_mask, int64_t n_out, int32_t K, int32_t cin,
-                      int32_t cout, const float* bias, const float* col_scale, const float* residual, int32_t relu,
-                      int32_t* y_amax, float* y, float* stats, void* stream);
 
 /* dW[k] = sum over pairs of offset k of  A[pair_a]^T . B[pair_b]   (A: [*, ca], B: [*, cb]) -> dw [K, ca, cb].
  * Forward conv: A = X, pair_a = pair_in, B = dY, pair_b = pair_out.  Transposed conv: roles swapped.

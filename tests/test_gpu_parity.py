@@ -339,49 +339,6 @@ def test_inference_launch_with_offset_groups(cin, cout):
         assert torch.equal(tall[:na], ya) and torch.equal(tall[na:], yb)
 
 
-@pytest.mark.parametrize("cin,cout,n", [(128, 128, 3000), (256, 256, 1500), (128, 256, 700), (256, 128, 129), (128, 128, 1)])
-def test_eight_wave_forward_kernel_is_bitwise_the_four_wave_kernel(cin, cout, n):
-    """Flag GCL_CONV_WIDE runs plane-image launches with Cout a multiple of 128 on k_conv_fwd_wide (eight waves: 128 rows x
-    128 columns per workgroup, a gathered row feeds 128 columns) instead of k_conv_fwd_split.  Same products added in the
-    same order: y and the BatchNorm column-sum partials are equal bit for bit, with and without the fused epilogue."""
-    from gcl_amd import _lib
-    import gcl_amd.MinkowskiEngine as ME
-    lib = _lib.load()
-    C = random_cloud(cin + n, n=n, extent=14, batch=1) if n > 1 else np.zeros((1, 4), np.int32)
-    mgr = make_mgr(C)
-    km = mgr.get_kernel_map(1, 3, 1)
-    tbl, order, mask = km.sorted_table()
-    n_out, K = len(C), 27
-    g = torch.Generator().manual_seed(n)
-    with torch.cuda.device(DEV):
-        x = torch.randn(n_out, cin, generator=g).to(DEV)
-        W = (0.1 * torch.randn(K, cin, cout, generator=g)).to(DEV)
-        res = torch.randn(n_out, cout, generator=g).to(DEV)
-        xa, wa = ME.ops.amax_slot(x.device), ME.ops.amax_slot(x.device)
-        _lib.check(lib.gcl_amax(_lib.ptr(x), x.numel(), _lib.ptr(xa), 1, _lib.stream()), "gcl_amax")
-        _lib.check(lib.gcl_amax(_lib.ptr(W), W.numel(), _lib.ptr(wa), 1, _lib.stream()), "gcl_amax")
-        planes = torch.empty((n_out, cin), dtype=torch.int32, device=DEV)
-        _lib.check(lib.gcl_split_planes(_lib.ptr(x), n_out, cin, _lib.ptr(xa), _lib.ptr(planes), _lib.stream()), "split")
-        wp = torch.empty(lib.gcl_pack_weights_bytes(K, cin, cout, 4), dtype=torch.uint8, device=DEV)
-        _lib.check(lib.gcl_pack_weights(_lib.ptr(W), K, cin, cout, 0, 4, _lib.ptr(wa), _lib.ptr(wp), _lib.stream()), "pack")
-        out = {}
-        for flags in (0, 2):
-            for fused in (False, True):
-                y = torch.full((n_out, cout), float("nan"), device=DEV)
-                stats = torch.full(((n_out + 127) // 128, 2, cout), float("nan"), device=DEV)
-                slot = ME.ops.amax_slot(x.device)
-                _lib.check(lib.gcl_conv_fwd_fused(_lib.ptr(planes), n_out, 1, _lib.ptr(wp), 4, _lib.ptr(xa), _lib.ptr(wa),
-                                                  _lib.ptr(tbl), _lib.ptr(order), _lib.ptr(mask), n_out, K, cin, cout, None,
-                                                  None, _lib.ptr(res) if fused else None, int(fused),
-                                                  _lib.ptr(slot) if fused else None, _lib.ptr(y), _lib.ptr(stats), flags,
-                                                  _lib.stream()), "gcl_conv_fwd_fused")
-                out[(flags, fused)] = (y, stats, ME.ops.amax_value(slot))
-        for fused in (False, True):
-            a, b = out[(0, fused)], out[(2, fused)]
-            assert torch.isfinite(a[0]).all() and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-            assert torch.equal(a[2], b[2])
-
-
 @pytest.mark.parametrize("cin,cout,stride,transpose", [(32, 32, 1, False), (64, 64, 1, False), (32, 64, 1, False),
                                                         (64, 32, 2, False), (64, 64, 2, True)])
 def test_weight_gradient_range_grouped_mode(cin, cout, stride, transpose):
@@ -694,120 +651,6 @@ def test_table_sort_is_a_stable_mask_sort(window):
                 assert np.array_equal(tmask.astype(np.int64), np.bitwise_or.reduce(mt, axis=1))
     finally:
         core.SORT_WINDOW = old
-
-
-@pytest.fixture
-def halo_tiles():
-    """Opt-in halo-tile path (gcl_table_sort_halo + gcl_conv_fwd_halo) switched on for every stride-1 3^3 map."""
-    from gcl_amd.MinkowskiEngine import core
-    old = core.HALO, core.HALO_MIN_ROWS
-    core.HALO, core.HALO_MIN_ROWS = True, 1
-    yield
-    core.HALO, core.HALO_MIN_ROWS = old
-
-
-@pytest.mark.parametrize("seed,n,t", [(9, 5000, 1), (10, 300, 1), (11, 20000, 2), (12, 1, 1)])
-def test_halo_tiles_are_consistent(halo_tiles, seed, n, t):
-    """gcl_table_sort_halo: order is a permutation, the permuted table and tile masks are consistent with it (so
-    gcl_conv_fwd can use them as they are), and per 128-row tile hrows lists exactly the distinct input rows of the
-    tile's entries in ascending order with hloc pointing every entry at its row (0xFFFF = no neighbour)."""
-    C = random_cloud(seed, n=n, batch=2)
-    mgr = make_mgr(C)
-    km = mgr.get_kernel_map(t, 3, 1)
-    tbl = km.nbr.cpu().numpy()
-    ts_t, order_t, tmask_t = km.sorted_table(False)
-    hcount, hrows, hloc = (x.cpu().numpy() for x in ts_t._gcl_halo)
-    ts, order, tmask = ts_t.cpu().numpy(), order_t.cpu().numpy(), tmask_t.cpu().numpy()
-    n_rows = tbl.shape[1]
-    assert np.array_equal(np.sort(order), np.arange(n_rows))
-    assert np.array_equal(ts, tbl[:, order])
-    mask = np.zeros(n_rows, dtype=np.int64)
-    for k in range(km.K):
-        mask |= (tbl[k] >= 0).astype(np.int64) << k
-    pad = (-n_rows) % 32
-    mt = np.concatenate([mask[order], np.zeros(pad, np.int64)]).reshape(-1, 32)
-    assert np.array_equal(tmask.astype(np.int64), np.bitwise_or.reduce(mt, axis=1))
-    hloc = hloc.view(np.uint16)
-    for tile in range((n_rows + 127) // 128):
-        ent = ts[:, tile * 128:(tile + 1) * 128]                       # [K, rows of the tile]
-        distinct = np.unique(ent[ent >= 0])
-        assert hcount[tile] == len(distinct)
-        assert np.array_equal(hrows[tile, :len(distinct)], distinct)
-        loc = hloc[tile, :, :ent.shape[1]]
-        assert np.array_equal(loc == 0xFFFF, ent < 0)
-        assert np.array_equal(hrows[tile][loc[ent >= 0]], ent[ent >= 0])
-        m = mask[order[tile * 128:(tile + 1) * 128]]
-        assert np.all(np.diff(m) >= 0)                                 # mask-sorted inside the tile
-
-
-@pytest.mark.parametrize("cin,cout", [(32, 32), (64, 64), (128, 128), (256, 256), (32, 64), (96, 32)])
-def test_halo_conv_fwd_bwd_vs_oracle(halo_tiles, cin, cout, precision):
-    """The halo-tile kernel behind the same layer: forward, input gradient (the same kernel with mirrored weights) and
-    weight gradient against the fp64 oracle, at the tolerance of the production kernel."""
-    if precision in ("f32", "bf16x6"):
-        pytest.skip("halo tiles carry two planes (fp16x3 / bf16x3); the other arithmetics take the production kernel")
-    r = _conv_case(cin, cout, 3, 1, False, seed=3, n=6000)
-    tol = PREC_TOL[precision]
-    assert rel_l2(*r["y"]) < tol, rel_l2(*r["y"])
-    assert rel_l2(*r["dx"]) < tol, rel_l2(*r["dx"])
-    assert rel_l2(*r["dW"]) < tol, rel_l2(*r["dW"])
-
-
-def test_halo_multi_pass_tiles_and_determinism(halo_tiles):
-    """A dense block: every 128-row tile names far more than the 224 halo rows one LDS window holds, so tiles run in
-    several passes over slot ranges; result equals the production kernel to rounding and is bitwise reproducible."""
-    import gcl_amd.MinkowskiEngine as ME
-    from gcl_amd.MinkowskiEngine import core
-    g = np.stack(np.meshgrid(np.arange(14), np.arange(14), np.arange(14), indexing="ij"), -1).reshape(-1, 3)
-    rng = np.random.default_rng(0)
-    g = g[rng.permutation(len(g))]                 # loader order is not spatial
-    C = np.concatenate([np.zeros((len(g), 1), np.int64), g], 1).astype(np.int32)
-    torch.manual_seed(0)
-    conv = ME.MinkowskiConvolution(64, 64, kernel_size=3, stride=1, dimension=3).to(DEV)
-    x = torch.randn(len(g), 64, device=DEV)
-    outs = []
-    for halo in (True, True, False):
-        core.HALO = halo
-        mgr = make_mgr(C)
-        if halo:
-            hc = mgr.get_kernel_map(1, 3, 1).sorted_table(False)[0]._gcl_halo[0]
-            assert int(hc.max()) > 224
-        with torch.no_grad():
-            outs.append(conv(ME.SparseTensor(x, coordinate_map_key=ME.CoordinateMapKey(1), coordinate_manager=mgr)).F)
-    assert torch.equal(outs[0], outs[1])
-    assert rel_l2(outs[0].cpu().double(), outs[2].cpu().double()) < 2e-6
-
-
-# ---------------------------------------------------------------------------------------------------------------
-# callers either side of the kernels: extract_features, find_corr / eval step, training step with DDP wrapper
-# ---------------------------------------------------------------------------------------------------------------
-def test_extract_features_and_eval_pair_vs_oracle():
-    """util/misc.extract_features (:58-130) and the eval-loop body (scripts/test_kitti.py:141-161): voxelise ->
-    SparseTensor -> model(eval) -> F; find_corr with seeded subsampling returns the oracle's correspondences."""
-    import gcl_amd.MinkowskiEngine as ME
-    from gcl_amd import synthetic
-    from gcl_amd.lib.eval import find_corr
-    from gcl_amd.util.misc import extract_features
-    m, st = _model_and_state(3, 5)
-    xyz = synthetic.raycast(synthetic.make_scene(2, n_boxes=15), np.zeros(3), 3)[::4]
-    ret_xyz, F = extract_features(m, xyz, voxel_size=0.3, device=torch.device(DEV), skip_check=True)
-    coords, inds = ME.utils.sparse_quantize(np.floor(xyz / 0.3), return_index=True)
-    assert np.array_equal(ret_xyz, xyz[inds]) and F.shape == (len(inds), 32)
-    C = ME.utils.batched_coordinates([coords]).numpy()
-    Fo = O.resunet_forward(st, C, torch.ones(len(C), 1, dtype=torch.float64), 5, True, False, 0.05)
-    assert rel_l2(F.detach().cpu(), Fo) < 1e-4
-    # a second, shifted view of the same scene: correspondences through feature 1-NN
-    xyz1 = synthetic.raycast(synthetic.make_scene(2, n_boxes=15), np.array([4.0, 0, 0]), 4)[::4]
-    ret1, F1 = extract_features(m, xyz1, voxel_size=0.3, device=torch.device(DEV), skip_check=True)
-    np.random.seed(5)
-    a0, a1 = find_corr(ret_xyz, ret1, F.detach(), F1.detach(), subsample_size=1500)
-    np.random.seed(5)
-    i0 = np.random.choice(len(F), 1500, replace=False)
-    i1 = np.random.choice(len(F1), 1500, replace=False)
-    nn = LO.find_nn(F.detach().cpu()[i0], F1.detach().cpu()[i1], nn_max_n=500)
-    assert np.array_equal(a0, ret_xyz[i0])
-    same = (a1 == ret1[i1[nn.numpy()]]).all(axis=1)
-    assert same.mean() > 0.995          # an index may differ only on fp32 near-ties of the distance
 
 
 def test_train_step_matches_oracle_and_flat_ddp_is_transparent():

@@ -1,5 +1,5 @@
 """DIAGNOSTIC: forward time of the network's convolution shapes on the benchmark batch (one line per layer shape).
-Usage on the GPU box:  [GCL_CONV_UNITS=1] python tools/micro/layer_bench.py"""
+Usage on the GPU box:  python tools/micro/layer_bench.py"""
 import os
 import sys
 
