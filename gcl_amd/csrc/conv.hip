@@ -494,12 +494,13 @@ __global__ void __launch_bounds__(256, GCL_FWD_MIN_WAVES(NB, PL)) k_conv_fwd_spl
     } else {                    // 3: every XCD owns a CONTIGUOUS range of row tiles (spatially ordered tables)
       const unsigned q = nrw >> 3, r = nrw & 7u, mine = q + (xcd < r ? 1u : 0u), j = slot / ncb;
       if (j >= mine) return;
-      bxx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+      // heavy first INSIDE the range: a region-sorted table (gcl_sort_regions) ends every region on its rare-offset rows
+      bxx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (heavy_first ? mine - 1u - j : j);
     }
   } else {
     bxx = xcd_tile(bxx, gridDim.x, swizzle);
   }
-  if (heavy_first) bxx = nrw - 1u - bxx;
+  if (heavy_first && swizzle != 3) bxx = nrw - 1u - bxx;
   const long long tile = (long long)bxx * 4 + w;
   const long long row0 = tile * 32;
   const bool active = row0 < n_out;
@@ -1963,9 +1964,12 @@ int gcl_conv_fwd_fused(const float* x, int64_t n_in, int32_t x_is_planes, const 
   static const int colgroup = [] { const char* e = getenv("GCL_FWD_COLGROUP"); return e ? atoi(e) : 1; }();
   const bool cg = colgroup && grid.y > 1 && !swz;
   dim3 sgrid = cg ? dim3((unsigned)(cdiv(gx, 8) * 8 * grid.y)) : grid;
-  const bool ranges = (flags & GCL_CONV_XCD_RANGES) != 0;     // spatially ordered table: contiguous tile range per XCD
+  // contiguous tile range per XCD: spatially ordered tables (flag) and region-sorted tables (gcl_sort_regions: the rows of
+  // one natural-order region = one XCD's range, so that its L2 only has to hold that region's slice of x)
+  const bool regions = tile_mask && gcl_sort_regions(n_out) != 0;
+  const bool ranges = (flags & GCL_CONV_XCD_RANGES) != 0 || regions;
   static const int heavy_first = [] { const char* e = getenv("GCL_CONV_HEAVY_FIRST"); return e ? atoi(e) : 1; }();
-  const int sswz = (cg ? (ranges ? 3 : 2) : (ranges ? 1 : swz)) | ((heavy_first && tile_mask && !ranges) ? 16 : 0);
+  const int sswz = (cg ? (ranges ? 3 : 2) : (ranges ? 1 : swz)) | ((heavy_first && tile_mask && (!ranges || regions)) ? 16 : 0);
 #define LAUNCH_F32(NBV)                                                                                          \
   hipLaunchKernelGGL(k_conv_fwd<NBV>, grid, dim3(256), 0, st, x, (const float4*)wp, tbl, order, tile_mask,       \
                      (long long)n_out, K, cin, cout, bias, y, swz)
