@@ -446,6 +446,81 @@ struct ConvEpi {
   int* y_amax;              // zero-initialised amax slot of y, NULL = not wanted
 };
 
+// Epilogue of the four-wave forward kernels (k_conv_fwd_split, k_conv_fwd_dma): un-scale, bias, optional fused inference
+// epilogue, scatter to the original row order, per-workgroup column sums for the BatchNorm that follows.  `tiles` = the
+// workgroup's four wave-private 32 x 32-float A tiles (idle by now: scratch for the column sums).
+template <int NB, bool EPI>
+__device__ __forceinline__ void conv_fwd_epilogue(f32x16 (&acc)[NB], float* tiles, const int* __restrict__ order,
+                                                  long long n_out, int cout, const float* __restrict__ bias,
+                                                  float* __restrict__ Y, float* __restrict__ stats, float out_scale,
+                                                  const ConvEpi& epi, long long tile, unsigned bxx, int nb0, bool active) {
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  const int i = l & 31, h = l >> 5;
+  const long long row0 = tile * 32;
+  if (!active && !stats) return;
+  int orow_l = -1;
+  if (active && (l < 32) && (row0 + l < n_out)) orow_l = order ? order[row0 + l] : (int)(row0 + l);
+  float ymax = 0.f;
+  // column sums of this wave's 32 rows go to its own (now idle) A tile; wave 0 adds the four waves in order and writes
+  // ONE partial per workgroup (128 rows) for the BatchNorm that follows (saves its statistics pass over Y)
+  float* const ssc = tiles + w * (32 * 32);   // wave w's tile; tiles are 32 x 32 floats apart
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int col = (nb0 + b) * 32 + i;
+    float bvv = bias ? bias[col] : 0.f;
+    float csc = (EPI && epi.col_scale) ? epi.col_scale[col] * out_scale : out_scale;
+    // consume the (conditional) loads HERE: otherwise every store below waits for all earlier stores (vmcnt(0))
+    asm volatile("v_mov_b32 %0, %1" : "=v"(bvv) : "v"(bvv));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(csc) : "v"(csc));
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int orow = __shfl(orow_l, (r & 3) + 8 * (r >> 2) + 4 * h);
+      if (orow >= 0) {
+        float v = acc[b][r] * csc + bvv;
+        if (EPI && epi.residual) v += epi.residual[(long long)orow * cout + col];
+        if (EPI && epi.relu) v = fmaxf(v, 0.f);
+        Y[(long long)orow * cout + col] = v;
+        s1 += v;
+        s2 += v * v;
+        if (EPI) ymax = fmaxf(ymax, fabsf(v));
+      }
+    }
+    if (stats) {
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (h == 0) {
+        ssc[b * 32 + i] = s1;
+        ssc[NB * 32 + b * 32 + i] = s2;
+      }
+    }
+  }
+  if (stats) {
+    __syncthreads();
+    if (w == 0 && h == 0) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int col = (nb0 + b) * 32 + i;
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {
+          const float* o = ssc + ww * (32 * 32);
+          t1 += o[b * 32 + i];
+          t2 += o[NB * 32 + b * 32 + i];
+        }
+        stats[((long long)bxx * 2 + 0) * cout + col] = t1;
+        stats[((long long)bxx * 2 + 1) * cout + col] = t2;
+      }
+    }
+    if (!active) return;
+  }
+  if (EPI && epi.y_amax) {   // one publish per wave (launches of this path are small: inference on single clouds)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o));
+    if (l == 0) amax_slot_publish(epi.y_amax, __float_as_int(ymax), (unsigned)tile);
+  }
+}
+
 // PRE: X is not the fp32 tensor but its fp16 plane image made by gcl_split_planes -- per row and 32-channel slice
 // 64 bytes of hi followed by 64 bytes of lo, i.e. the same 128 bytes per (row, slice) and the same addressing as the
 // fp32 rows.  The main loop then has no split at all (the kernels are instruction-issue-bound: the split was 48 of ~120
@@ -700,68 +775,236 @@ __global__ void __launch_bounds__(256, GCL_FWD_MIN_WAVES(NB, PL)) k_conv_fwd_spl
     o[0] = wg_t0; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = wg_steps; o[3] = __builtin_amdgcn_s_memtime() - wg_c0;
   }
 #endif
-  if (!active && !stats) return;
-  int orow_l = -1;
-  if (active && (l < 32) && (row0 + l < n_out)) orow_l = order ? order[row0 + l] : (int)(row0 + l);
-  float ymax = 0.f;
-  // column sums of this wave's 32 rows go to its own (now idle) A tile; wave 0 adds the four waves in order and writes
-  // ONE partial per workgroup (128 rows) for the BatchNorm that follows (saves its statistics pass over Y)
-  float* const ssc = &Asm[w][0][0];   // wave w's tile; tiles are 32 x 32 floats apart
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    const int col = (nb0 + b) * 32 + i;
-    float bvv = bias ? bias[col] : 0.f;
-    float csc = (EPI && epi.col_scale) ? epi.col_scale[col] * out_scale : out_scale;
-    // consume the (conditional) loads HERE: otherwise every store below waits for all earlier stores (vmcnt(0))
-    asm volatile("v_mov_b32 %0, %1" : "=v"(bvv) : "v"(bvv));
-    asm volatile("v_mov_b32 %0, %1" : "=v"(csc) : "v"(csc));
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int orow = __shfl(orow_l, (r & 3) + 8 * (r >> 2) + 4 * h);
-      if (orow >= 0) {
-        float v = acc[b][r] * csc + bvv;
-        if (EPI && epi.residual) v += epi.residual[(long long)orow * cout + col];
-        if (EPI && epi.relu) v = fmaxf(v, 0.f);
-        Y[(long long)orow * cout + col] = v;
-        s1 += v;
-        s2 += v * v;
-        if (EPI) ymax = fmaxf(ymax, fabsf(v));
-      }
+  conv_fwd_epilogue<NB, EPI>(acc, &Asm[0][0][0], order, n_out, cout, bias, Y, stats, out_scale, epi, tile, bxx, nb0, active);
+}
+
+// One LDS-DMA piece: every lane fetches 16 bytes at byte offset (voff + soff) of the buffer `rsrc` (beyond num_records: zeros)
+// and the wave's 64 pieces land at LDS bytes lds_base + 16 lane (lds_base, soff, rsrc wave-uniform, in SGPRs).  Inline asm
+// on purpose: hipcc makes every later LDS read wait (vmcnt(0)) for an LDS-DMA it knows about, which would put the DMA's
+// latency back into the step; written this way it does not count them -- the kernel waits itself (dma_wait_all) in front
+// of the barrier that precedes the reads.  M0 (the DMA's LDS base) is written in the same statement that uses it and
+// restored: the compiler does not expect an asm statement to change it.
+typedef unsigned rsrc_words __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ rsrc_words make_rsrc_words(const void* base, unsigned bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+  rsrc_words r;
+  r[0] = (unsigned)a;
+  r[1] = (unsigned)(a >> 32) & 0xffffu;       // stride 0, no swizzle
+  r[2] = bytes;                               // num_records (bytes, raw buffer)
+  r[3] = 0x00020000u;
+  return r;
+}
+template <int IMM>      // LDS destination = lds_base + IMM (bytes; the constant is added on the scalar unit inside the statement)
+__device__ __forceinline__ void dma16(const rsrc_words& rsrc, unsigned lds_base, unsigned voff, unsigned soff) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_add_u32 m0, %1, %5\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(lds_base), "v"(voff), "s"(rsrc), "s"(soff), "i"(IMM)
+      : "memory", "scc");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// ---- the same product with LDS-DMA staging (round 4; plane-image operands, fp16x3) -----------------------------------
+// k_conv_fwd_split moves every operand global -> VGPR -> ds_write -> LDS: per wave and step 6 loads into 24 staging
+// registers and 6 ds_write_b128 (13 issue cycles each on the VGPR -> LDS path, ~1200 of the ~5600 cycles a CU spends on a
+// round of 16 wave-steps).  With plane images the gathered bytes ARE the LDS image, so here they go straight to LDS
+// (`buffer_load_dwordx4 ... lds`: per-lane source offset, wave-uniform LDS base + 16 lane): no staging registers, no
+// ds_write, and the XOR swizzle of the A tile is applied to the SOURCE piece a lane fetches.  Missing neighbours (row -1)
+// wrap beyond the buffer resource and the DMA writes zeros (tools/micro/dma_probe.hip).  One workgroup barrier per step:
+//   top of step s:  __syncthreads() (waits for this wave's DMAs: A(s) in its own tile, its part of B(s)), then
+//                   B(s+1) -> the other weight buffer (last read in step s-1, before this barrier),
+//                   A fragments of step s -> registers, then A(s+1) -> the wave's tile, then B fragments + MFMAs.
+// Same products added in the same order as k_conv_fwd_split: bitwise the same y and column sums.
+template <int NB, bool EPI>
+__global__ void __launch_bounds__(256, (NB <= 2 ? 4 : 2)) k_conv_fwd_dma(const float* __restrict__ X, const u32x4* __restrict__ Wp,
+                                                        const int* __restrict__ tbl, const int* __restrict__ order,
+                                                        const int* __restrict__ tile_mask, long long n_out, int K,
+                                                        int cin, int cout, const float* __restrict__ bias,
+                                                        float* __restrict__ Y, int swizzle,
+                                                        float* __restrict__ stats, const int* __restrict__ x_amax,
+                                                        const int* __restrict__ w_amax, unsigned x_bytes, unsigned w_bytes,
+                                                        ConvEpi epi) {
+  constexpr int PL = 4, NPL = 2;
+  constexpr int BLK = NB * 2 * NPL * 64;                // uint4 per (k, cc) weight block of this workgroup = NB x 4 KB
+  constexpr int ISM_H = 15;
+  const float a_scale = amax_scale(x_amax);
+  const float out_scale = 1.f / (a_scale * amax_scale(w_amax));   // exact: powers of two
+  // ONE LDS object (a second one beside an LDS-DMA target makes hipcc wait for the DMA before unrelated reads)
+  constexpr int A_BYTES = 4 * 32 * 32 * 4, B_BYTES = 2 * BLK * 16, I_BYTES = 4 * ISM_H * 32 * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[A_BYTES + B_BYTES + I_BYTES + 16];
+  float (*Asm)[32][32] = reinterpret_cast<float (*)[32][32]>(smem);
+  u32x4* const Bsm = reinterpret_cast<u32x4*>(smem + A_BYTES);                       // [2][BLK]
+  int (*Ism)[ISM_H][32] = reinterpret_cast<int (*)[ISM_H][32]>(smem + A_BYTES + B_BYTES);
+  unsigned* const wmask = reinterpret_cast<unsigned*>(smem + A_BYTES + B_BYTES + I_BYTES);
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  const int i = l & 31, h = l >> 5;
+  unsigned bxx = blockIdx.x, byy = blockIdx.y;
+  const bool heavy_first = (swizzle & 16) != 0;
+  swizzle &= 15;
+  const unsigned nrw = (unsigned)((n_out + CONV_ROWS - 1) / CONV_ROWS);
+  if (swizzle >= 2) {
+    const unsigned ncb = (unsigned)(cout / (32 * NB));
+    const unsigned xcd = bxx & 7u, slot = bxx >> 3;
+    byy = slot % ncb;
+    if (swizzle == 2) {
+      bxx = (slot / ncb) * 8u + xcd;
+      if (bxx >= nrw) return;
+    } else {
+      const unsigned q = nrw >> 3, r = nrw & 7u, mine = q + (xcd < r ? 1u : 0u), j = slot / ncb;
+      if (j >= mine) return;
+      bxx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (heavy_first ? mine - 1u - j : j);
     }
-    if (stats) {
-      s1 += __shfl_xor(s1, 32);
-      s2 += __shfl_xor(s2, 32);
-      if (h == 0) {
-        ssc[b * 32 + i] = s1;
-        ssc[NB * 32 + b * 32 + i] = s2;
-      }
-    }
+  } else {
+    bxx = xcd_tile(bxx, gridDim.x, swizzle);
   }
-  if (stats) {
-    __syncthreads();
-    if (w == 0 && h == 0) {
+  if (heavy_first && swizzle != 3) bxx = nrw - 1u - bxx;
+  const long long tile = (long long)bxx * 4 + w;
+  const long long row0 = tile * 32;
+  const bool active = row0 < n_out;
+  const int nb0 = byy * NB;
+  const int TNB = cout >> 5, CC = cin >> 5;
+  const int p = l & 7, rsub = l >> 3;
+
+  f32x16 acc[NB];
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const int col = (nb0 + b) * 32 + i;
-        float t1 = 0.f, t2 = 0.f;
+  for (int b = 0; b < NB; ++b)
 #pragma unroll
-        for (int ww = 0; ww < 4; ++ww) {
-          const float* o = ssc + ww * (32 * 32);
-          t1 += o[b * 32 + i];
-          t2 += o[NB * 32 + b * 32 + i];
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+
+  unsigned mymask = 0u;
+  if (active) mymask = tile_mask ? (unsigned)tile_mask[tile] : ((K >= 32) ? ~0u : ((1u << K) - 1u));
+  mymask = __builtin_amdgcn_readfirstlane(mymask);
+  if (l == 0) wmask[w] = mymask;
+  for (int e = l; e < (K < ISM_H ? K : ISM_H) * 32; e += 64) {
+    const int k = e >> 5, r = e & 31;
+    int v = -1;
+    if (active && ((mymask >> k) & 1u) && row0 + r < n_out) v = tbl ? tbl[(long long)k * n_out + row0 + r] : (int)(row0 + r);
+    Ism[w][k][(r & 7) * 4 + (r >> 3)] = v;
+  }
+  int ib[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int e = 32 * ISM_H + l + 64 * j, k = e >> 5, r = e & 31;
+    int v = -1;
+    if (k < K && active && ((mymask >> k) & 1u) && row0 + r < n_out) v = tbl[(long long)k * n_out + row0 + r];
+    ib[j] = v;
+  }
+  bool second_half = false;
+  __syncthreads();
+  const unsigned wgmask = __builtin_amdgcn_readfirstlane(wmask[0] | wmask[1] | wmask[2] | wmask[3]);
+
+  const rsrc_words xrsrc = make_rsrc_words(X, x_bytes), wrsrc = make_rsrc_words(Wp, w_bytes);
+  const unsigned row_bytes = (unsigned)cin * 4u;
+  // wave-uniform LDS byte addresses (an LDS pointer is its byte offset in the workgroup's allocation)
+  const unsigned lds_a = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(&Asm[w][0][0]));
+  const unsigned lds_b = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(Bsm + w * 64));
+  // a lane's piece inside its four rows (rsub + 8 ps): LDS position p of row r holds source piece p ^ a_swz(r)
+  unsigned pc[4];
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) pc[ps] = (unsigned)((p ^ a_swz(rsub + 8 * ps)) << 4);
+#define GCL_DMA_A(KK, CCV)                                                                                     \
+  {                                                                                                            \
+    if ((KK) >= ISM_H && !second_half) {                                                                       \
+      second_half = true;                                                                                      \
+      WAVE_FENCE();                                                                                            \
+      _Pragma("unroll") for (int j_ = 0; j_ < 6; ++j_) {                                                       \
+        const int e_ = 32 * ISM_H + l + 64 * j_;                                                               \
+        if ((e_ >> 5) < K) Ism[w][(e_ >> 5) - ISM_H][((e_ & 31) & 7) * 4 + ((e_ & 31) >> 3)] = ib[j_];         \
+      }                                                                                                        \
+      WAVE_FENCE();                                                                                            \
+    }                                                                                                          \
+    const int4 ri_ = *reinterpret_cast<const int4*>(&Ism[w][(KK) >= ISM_H ? (KK) - ISM_H : (KK)][rsub * 4]);    \
+    const unsigned co_ = (unsigned)(CCV)*128u;                                                                 \
+    dma16<0>(xrsrc, lds_a, (unsigned)ri_.x * row_bytes + pc[0], co_);                                          \
+    dma16<1024>(xrsrc, lds_a, (unsigned)ri_.y * row_bytes + pc[1], co_);                                       \
+    dma16<2048>(xrsrc, lds_a, (unsigned)ri_.z * row_bytes + pc[2], co_);                                       \
+    dma16<3072>(xrsrc, lds_a, (unsigned)ri_.w * row_bytes + pc[3], co_);                                       \
+  }
+  // weight block (k, cc) of this workgroup's columns: BLK uint4, lane-linear; wave w moves pieces e * 256 + 64 w .. + 63
+#define GCL_DMA_B(KK, CCV, BUF)                                                                                \
+  {                                                                                                            \
+    const unsigned blk_ = (unsigned)((((KK)*CC + (CCV)) * TNB + nb0) * (2 * NPL * 64)) * 16u;                   \
+    const unsigned dst_ = lds_b + (unsigned)(BUF) * (unsigned)(BLK * 16);                                      \
+    dma16<0>(wrsrc, dst_, (unsigned)t * 16u, blk_);                                                            \
+    if (NB >= 2) dma16<4096>(wrsrc, dst_, (unsigned)t * 16u + 4096u, blk_);                                    \
+    if (NB >= 4) {                                                                                             \
+      dma16<8192>(wrsrc, dst_, (unsigned)t * 16u + 8192u, blk_);                                               \
+      dma16<12288>(wrsrc, dst_, (unsigned)t * 16u + 12288u, blk_);                                             \
+    }                                                                                                          \
+  }
+#define GCL_ADVANCE(KV, CV, HAS)             \
+  {                                          \
+    CV += 1;                                 \
+    if (CV == CC) {                          \
+      CV = 0;                                \
+      if (m_rest) {                          \
+        KV = __builtin_ctz(m_rest);          \
+        m_rest &= m_rest - 1;                \
+      } else {                               \
+        HAS = false;                         \
+      }                                      \
+    }                                        \
+  }
+  // every ordinary load of the prologue is consumed HERE: with loads of its own pending hipcc would put vmcnt waits into the
+  // loop (it counts the DMAs it cannot see as nothing and would wait in the middle of a DMA sequence)
+  asm volatile("" ::"v"(ib[0]), "v"(ib[1]), "v"(ib[2]), "v"(ib[3]), "v"(ib[4]), "v"(ib[5]) : "memory");
+  if (wgmask != 0u) {
+    unsigned m_rest = wgmask & (wgmask - 1);
+    int kc = __builtin_ctz(wgmask), cc = 0;
+    bool mine_cur = (mymask >> kc) & 1u;
+    if (mine_cur) GCL_DMA_A(kc, 0);
+    GCL_DMA_B(kc, 0, 0);
+    int buf = 0;
+    while (true) {
+      dma_wait_all();       // this wave's DMAs have landed: A(s) in its tile, its part of B(s)
+      __syncthreads();      // everybody's part of B(s) is in LDS; everybody's reads of step s-1 are done
+      int kn = kc, cn = cc;
+      bool hasn = true;
+      GCL_ADVANCE(kn, cn, hasn);
+      const bool mine_n = hasn && ((mymask >> kn) & 1u);
+      if (hasn) GCL_DMA_B(kn, cn, buf ^ 1);
+      if (mine_cur) {
+        u32x4 ap[2][2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {   // row image: dwords [0,16) = hi of channels 0..31, [16,32) = lo
+          ap[m][0] = *reinterpret_cast<const u32x4*>(&Asm[w][i][((2 * m + h) ^ a_swz(i)) << 2]);
+          ap[m][1] = *reinterpret_cast<const u32x4*>(&Asm[w][i][((4 + 2 * m + h) ^ a_swz(i)) << 2]);
         }
-        stats[((long long)bxx * 2 + 0) * cout + col] = t1;
-        stats[((long long)bxx * 2 + 1) * cout + col] = t2;
-      }
-    }
-    if (!active) return;
-  }
-  if (EPI && epi.y_amax) {   // one publish per wave (launches of this path are small: inference on single clouds)
+        if (mine_n) {
+          // the DMA overwrites the tile: this wave's fragment reads must have returned (the asm consumes them)
+          asm volatile("" : "+v"(ap[0][0]), "+v"(ap[0][1]), "+v"(ap[1][0]), "+v"(ap[1][1])::"memory");
+          GCL_DMA_A(kn, cn);
+        }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o));
-    if (l == 0) amax_slot_publish(epi.y_amax, __float_as_int(ymax), (unsigned)tile);
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            const u32x4* bb = &Bsm[buf * BLK + ((b * 2 + m) * NPL) * 64 + l];
+            u32x4 bp[2];
+            bp[0] = bb[0];
+            bp[1] = bb[64];
+            mfma_terms<PL>(ap[m], bp, acc[b]);
+          }
+        }
+      } else if (mine_n) {
+        GCL_DMA_A(kn, cn);
+      }
+      if (!hasn) break;
+      buf ^= 1;
+      kc = kn;
+      cc = cn;
+      mine_cur = mine_n;
+    }
   }
+#undef GCL_DMA_A
+#undef GCL_DMA_B
+#undef GCL_ADVANCE
+  conv_fwd_epilogue<NB, EPI>(acc, &Asm[0][0][0], order, n_out, cout, bias, Y, stats, out_scale, epi, tile, bxx, nb0, active);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2010,6 +2253,21 @@ int gcl_conv_fwd_fused(const float* x, int64_t n_in, int32_t x_is_planes, const 
     else
       hipLaunchKernelGGL((k_conv_fwd_tall<false>), tgrid, dim3(1024), 0, st, x, (const u32x4*)wp, tbl, order, tile_mask,
                          (long long)n_out, K, cin, cout, bias, y, tswz, x_amax, w_amax, x_bytes, epi);
+    GCL_CHECK_LAUNCH();
+    return GCL_OK;
+  }
+  // plane-image launches with LDS-DMA staging (k_conv_fwd_dma; knob GCL_FWD_DMA / flag GCL_CONV_DMA): bitwise the same
+  // results as k_conv_fwd_split
+  static const int dma = [] { const char* e = getenv("GCL_FWD_DMA"); return e ? atoi(e) : 0; }();
+  if ((dma || (flags & GCL_CONV_DMA)) && prec == 4 && x_is_planes) {
+    const unsigned w_bytes = (unsigned)((long long)K * cin * cout * 4);
+#define LAUNCH_DMA(NBV, EPIV)                                                                                     \
+  hipLaunchKernelGGL((k_conv_fwd_dma<NBV, EPIV>), sgrid, dim3(256), 0, st, x, (const u32x4*)wp, tbl, order, tile_mask, \
+                     (long long)n_out, K, cin, cout, bias, y, sswz, stats, x_amax, w_amax, x_bytes, w_bytes, epi)
+    if (nb == 4) { if (use_epi) LAUNCH_DMA(4, true); else LAUNCH_DMA(4, false); }
+    else if (nb == 2) { if (use_epi) LAUNCH_DMA(2, true); else LAUNCH_DMA(2, false); }
+    else { if (use_epi) LAUNCH_DMA(1, true); else LAUNCH_DMA(1, false); }
+#undef LAUNCH_DMA
     GCL_CHECK_LAUNCH();
     return GCL_OK;
   }

@@ -20,13 +20,15 @@ LAYERS = [(1, 32, 32, 1, False), (1, 64, 64, 1, False), (2, 64, 64, 1, False), (
 only = os.environ.get("LB_ONLY")
 if only:
     LAYERS = [l for l in LAYERS if str(l[0]) in only.split(",")]
-modes = [int(m) for m in os.environ.get("LB_MODES", "0,8").split(",")]
+# mode 0: global sort, interleaved tiles; 8: region sort, one contiguous tile range per XCD; 80: region-sorted TABLES run in
+# the interleaved tile order (separates what the sort costs from what the XCD assignment costs)
+modes = [int(m) for m in os.environ.get("LB_MODES", "0,8,80").split(",")]
 rounds = int(os.environ.get("LB_ROUNDS", "3"))
 reps = int(os.environ.get("LB_REPS", "10"))
 lib = _lib.load()
 mgrs = {}
 for m in modes:
-    _lib.check(lib.gcl_set_sort_regions(m, int(os.environ.get("LB_MIN_ROWS", "8192"))), "gcl_set_sort_regions")
+    _lib.check(lib.gcl_set_sort_regions(8 if m else 0, int(os.environ.get("LB_MIN_ROWS", "8192"))), "gcl_set_sort_regions")
     mgrs[m] = ME.CoordinateManager(C)
     for (t, cin, cout, stride, tr) in LAYERS:          # build the sorted tables under this mode
         km = mgrs[m].get_kernel_map(t // 2 if tr else t, 3, stride)
@@ -42,7 +44,7 @@ for (t, cin, cout, stride, tr) in LAYERS:
     best, ys = {m: [] for m in modes}, {}
     for r in range(rounds):
         for m in modes:
-            _lib.check(lib.gcl_set_sort_regions(m, 0), "gcl_set_sort_regions")
+            _lib.check(lib.gcl_set_sort_regions(8 if m == 8 else 0, 0), "gcl_set_sort_regions")
             x = ME.SparseTensor(F, coordinate_map_key=ME.CoordinateMapKey(t), coordinate_manager=mgrs[m])
             with torch.no_grad():
                 y = conv(x).F
