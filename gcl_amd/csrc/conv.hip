@@ -2256,10 +2256,11 @@ int gcl_conv_fwd_fused(const float* x, int64_t n_in, int32_t x_is_planes, const 
     GCL_CHECK_LAUNCH();
     return GCL_OK;
   }
-  // plane-image launches with LDS-DMA staging (k_conv_fwd_dma; knob GCL_FWD_DMA / flag GCL_CONV_DMA): bitwise the same
-  // results as k_conv_fwd_split
-  static const int dma = [] { const char* e = getenv("GCL_FWD_DMA"); return e ? atoi(e) : 0; }();
-  if ((dma || (flags & GCL_CONV_DMA)) && prec == 4 && x_is_planes) {
+  // plane-image launches with LDS-DMA staging (k_conv_fwd_dma; default, GCL_FWD_DMA=0 / flag GCL_CONV_NO_DMA select the
+  // register-staged k_conv_fwd_split): bitwise the same results, 15 - 21 % shorter launches on the C >= 128 layers of the
+  // KITTI batch (profiles/r04_conv_experiments.txt, 19)
+  static const int dma = [] { const char* e = getenv("GCL_FWD_DMA"); return e ? atoi(e) : 1; }();
+  if ((dma || (flags & GCL_CONV_DMA)) && !(flags & GCL_CONV_NO_DMA) && prec == 4 && x_is_planes) {
     const unsigned w_bytes = (unsigned)((long long)K * cin * cout * 4);
 #define LAUNCH_DMA(NBV, EPIV)                                                                                     \
   hipLaunchKernelGGL((k_conv_fwd_dma<NBV, EPIV>), sgrid, dim3(256), 0, st, x, (const u32x4*)wp, tbl, order, tile_mask, \

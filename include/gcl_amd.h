@@ -239,7 +239,9 @@ int gcl_split_planes(const float* x, int64_t n, int32_t c, const int32_t* amax, 
                                K Cin / 32 >= 108 (Cin >= 128 at K = 27), Cout a multiple of 64; ignored elsewhere.  Results differ from the launch
                                without the flag in the last bits (another summation order). */
 #define GCL_CONV_DMA 2      /* plane-image launches (fp16x3): operands staged by LDS-DMA (`buffer_load ... lds`: no staging
-                               registers, no ds_write); bitwise the same results (same as GCL_FWD_DMA=1) */
+                               registers, no ds_write); bitwise the same results.  The default (GCL_FWD_DMA=0 turns it off
+                               unless this flag is set) */
+#define GCL_CONV_NO_DMA 8   /* ... and this flag selects the register-staged kernel for a launch regardless */
 int gcl_conv_fwd(const float* x, int64_t n_in, int32_t x_is_planes, const void* wp, int32_t prec, const int32_t* x_amax,
                  const int32_t* w_amax, const int32_t* tbl, const int32_t* order, const int32_t* tile_mask,
                  int64_t n_out, int32_t K,

@@ -367,7 +367,7 @@ def test_lds_dma_forward_kernel_is_bitwise_the_register_staged_kernel(cin, cout,
         wp = torch.empty(lib.gcl_pack_weights_bytes(K, cin, cout, 4), dtype=torch.uint8, device=DEV)
         _lib.check(lib.gcl_pack_weights(_lib.ptr(W), K, cin, cout, 0, 4, _lib.ptr(wa), _lib.ptr(wp), _lib.stream()), "pack")
         out = {}
-        for flags in (0, 2):
+        for flags in (8, 2):
             for fused in (False, True):
                 y = torch.full((n_out, cout), float("nan"), device=DEV)
                 stats = torch.full(((n_out + 127) // 128, 2, cout), float("nan"), device=DEV)
@@ -379,7 +379,7 @@ def test_lds_dma_forward_kernel_is_bitwise_the_register_staged_kernel(cin, cout,
                                                   _lib.stream()), "gcl_conv_fwd_fused")
                 out[(flags, fused)] = (y, stats, ME.ops.amax_value(slot))
         for fused in (False, True):
-            a, b = out[(0, fused)], out[(2, fused)]
+            a, b = out[(8, fused)], out[(2, fused)]
             assert torch.isfinite(a[0]).all() and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
             assert torch.equal(a[2], b[2])
         # against the fp64 product as well (the two kernels could be wrong together)
