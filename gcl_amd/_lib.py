@@ -75,8 +75,6 @@ SIGNATURES = {
     "gcl_conv_fwd_nb": (_i32, [_i64, _i32, _i32]),
     "gcl_pack_weights": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "gcl_table_sort_scratch_len": (_i64, [_i64]),
-    "gcl_sort_regions": (_i32, [_i64]),
-    "gcl_set_sort_regions": (_i32, [_i32, _i64]),
     "gcl_table_sort": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "gcl_table_sort_multi": (_i32, [_vp, _i32, _vp]),
     "gcl_spatial_order": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),

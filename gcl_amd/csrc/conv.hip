@@ -569,13 +569,12 @@ __global__ void __launch_bounds__(256, GCL_FWD_MIN_WAVES(NB, PL)) k_conv_fwd_spl
     } else {                    // 3: every XCD owns a CONTIGUOUS range of row tiles (spatially ordered tables)
       const unsigned q = nrw >> 3, r = nrw & 7u, mine = q + (xcd < r ? 1u : 0u), j = slot / ncb;
       if (j >= mine) return;
-      // heavy first INSIDE the range: a region-sorted table (gcl_sort_regions) ends every region on its rare-offset rows
-      bxx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (heavy_first ? mine - 1u - j : j);
+      bxx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
     }
   } else {
     bxx = xcd_tile(bxx, gridDim.x, swizzle);
   }
-  if (heavy_first && swizzle != 3) bxx = nrw - 1u - bxx;
+  if (heavy_first) bxx = nrw - 1u - bxx;
   const long long tile = (long long)bxx * 4 + w;
   const long long row0 = tile * 32;
   const bool active = row0 < n_out;
@@ -845,6 +844,7 @@ __global__ void __launch_bounds__(256, (NB <= 2 ? 4 : 2)) k_conv_fwd_dma(const f
   const int i = l & 31, h = l >> 5;
   unsigned bxx = blockIdx.x, byy = blockIdx.y;
   const bool heavy_first = (swizzle & 16) != 0;
+  const bool prio = (swizzle & 32) != 0;      // experiment: s_setprio 1 around the MFMA block
   swizzle &= 15;
   const unsigned nrw = (unsigned)((n_out + CONV_ROWS - 1) / CONV_ROWS);
   if (swizzle >= 2) {
@@ -857,12 +857,12 @@ __global__ void __launch_bounds__(256, (NB <= 2 ? 4 : 2)) k_conv_fwd_dma(const f
     } else {
       const unsigned q = nrw >> 3, r = nrw & 7u, mine = q + (xcd < r ? 1u : 0u), j = slot / ncb;
       if (j >= mine) return;
-      bxx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (heavy_first ? mine - 1u - j : j);
+      bxx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
     }
   } else {
     bxx = xcd_tile(bxx, gridDim.x, swizzle);
   }
-  if (heavy_first && swizzle != 3) bxx = nrw - 1u - bxx;
+  if (heavy_first) bxx = nrw - 1u - bxx;
   const long long tile = (long long)bxx * 4 + w;
   const long long row0 = tile * 32;
   const bool active = row0 < n_out;
@@ -980,6 +980,7 @@ __global__ void __launch_bounds__(256, (NB <= 2 ? 4 : 2)) k_conv_fwd_dma(const f
           asm volatile("" : "+v"(ap[0][0]), "+v"(ap[0][1]), "+v"(ap[1][0]), "+v"(ap[1][1])::"memory");
           GCL_DMA_A(kn, cn);
         }
+        if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
 #pragma unroll
@@ -991,6 +992,7 @@ __global__ void __launch_bounds__(256, (NB <= 2 ? 4 : 2)) k_conv_fwd_dma(const f
             mfma_terms<PL>(ap[m], bp, acc[b]);
           }
         }
+        if (prio) __builtin_amdgcn_s_setprio(0);
       } else if (mine_n) {
         GCL_DMA_A(kn, cn);
       }
@@ -2207,12 +2209,10 @@ int gcl_conv_fwd_fused(const float* x, int64_t n_in, int32_t x_is_planes, const 
   static const int colgroup = [] { const char* e = getenv("GCL_FWD_COLGROUP"); return e ? atoi(e) : 1; }();
   const bool cg = colgroup && grid.y > 1 && !swz;
   dim3 sgrid = cg ? dim3((unsigned)(cdiv(gx, 8) * 8 * grid.y)) : grid;
-  // contiguous tile range per XCD: spatially ordered tables (flag) and region-sorted tables (gcl_sort_regions: the rows of
-  // one natural-order region = one XCD's range, so that its L2 only has to hold that region's slice of x)
-  const bool regions = tile_mask && gcl_sort_regions(n_out) != 0;
-  const bool ranges = (flags & GCL_CONV_XCD_RANGES) != 0 || regions;
+  const bool ranges = (flags & GCL_CONV_XCD_RANGES) != 0;     // spatially ordered table: contiguous tile range per XCD
   static const int heavy_first = [] { const char* e = getenv("GCL_CONV_HEAVY_FIRST"); return e ? atoi(e) : 1; }();
-  const int sswz = (cg ? (ranges ? 3 : 2) : (ranges ? 1 : swz)) | ((heavy_first && tile_mask && (!ranges || regions)) ? 16 : 0);
+  const int sswz = (cg ? (ranges ? 3 : 2) : (ranges ? 1 : swz)) | ((heavy_first && tile_mask && !ranges) ? 16 : 0);
+  const int sswz_ = sswz;
 #define LAUNCH_F32(NBV)                                                                                          \
   hipLaunchKernelGGL(k_conv_fwd<NBV>, grid, dim3(256), 0, st, x, (const float4*)wp, tbl, order, tile_mask,       \
                      (long long)n_out, K, cin, cout, bias, y, swz)
@@ -2262,6 +2262,8 @@ int gcl_conv_fwd_fused(const float* x, int64_t n_in, int32_t x_is_planes, const 
   static const int dma = [] { const char* e = getenv("GCL_FWD_DMA"); return e ? atoi(e) : 1; }();
   if ((dma || (flags & GCL_CONV_DMA)) && !(flags & GCL_CONV_NO_DMA) && prec == 4 && x_is_planes) {
     const unsigned w_bytes = (unsigned)((long long)K * cin * cout * 4);
+    static const int dma_prio = [] { const char* e = getenv("GCL_DMA_PRIO"); return e ? atoi(e) : 0; }();
+    const int sswz = sswz_ | (dma_prio ? 32 : 0);
 #define LAUNCH_DMA(NBV, EPIV)                                                                                     \
   hipLaunchKernelGGL((k_conv_fwd_dma<NBV, EPIV>), sgrid, dim3(256), 0, st, x, (const u32x4*)wp, tbl, order, tile_mask, \
                      (long long)n_out, K, cin, cout, bias, y, sswz, stats, x_amax, w_amax, x_bytes, w_bytes, epi)

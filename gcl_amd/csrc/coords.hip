@@ -470,7 +470,7 @@ __global__ void __launch_bounds__(256) k_mask_bit_count(const unsigned* __restri
 // 7.75 vs 8.26 units per 32-row tile at tensor stride 1, 9.88 vs 10.99 at stride 4, 11.41 vs 13.11 at stride 8
 // (exact sparse work: 6.3 / 7.3 / 7.7).  pos[k] = key bit of offset k, written for k_tile_masks.
 __device__ __forceinline__ void mask_keys_body(unsigned* keys, long long n, int K, const int* __restrict__ bit_count,
-                                               int* pos_out, unsigned bx, int regions = 0) {
+                                               int* pos_out, unsigned bx) {
   __shared__ int pos[32];
   if (threadIdx.x < 32) {
     const int k = threadIdx.x;
@@ -493,15 +493,11 @@ __device__ __forceinline__ void mask_keys_body(unsigned* keys, long long n, int 
   for (int k = 0; k < K; ++k) key |= ((m >> k) & 1u) << pos[k];
   // (taking the key's rank in the reflected Gray-code sequence would save another 2 - 3 % of the units -- measured --
   // but its pseudo-random low digits turn every radix scatter into 64 single-row writes per wave: +1 .. 2 ms per step)
-  // REGIONS (gcl_sort_regions() > 0): the row's eighth of the natural order (rows come cloud by cloud and a convolution
-  // never leaves its cloud) is the most significant part of the key: every region is mask-sorted on its own and its
-  // tiles are run by ONE XCD, whose L2 then only has to hold that eighth of the gathered tensor
-  if (regions) key |= (unsigned)((v * regions) / n) << K;
   keys[v] = key;
 }
 __global__ void __launch_bounds__(256) k_mask_keys(unsigned* keys, long long n, int K, const int* __restrict__ bit_count,
-                                                   int* pos_out, int regions) {
-  mask_keys_body(keys, n, K, bit_count, pos_out, blockIdx.x, regions);
+                                                   int* pos_out) {
+  mask_keys_body(keys, n, K, bit_count, pos_out, blockIdx.x);
 }
 
 __device__ __forceinline__ void radix_hist_body(const unsigned* __restrict__ keys, long long n, int shift, int nblk, int* hist,
@@ -709,8 +705,6 @@ __device__ __forceinline__ void tile_masks_body(const unsigned* __restrict__ key
     unsigned u = 0;
     for (int k = 0; k < K; ++k) u |= ((m >> pos[k]) & 1u) << k;
     m = u;
-  } else if (K < 32) {
-    m &= (1u << K) - 1u;      // region prefix of the sort key (mask_keys_body)
   }
   tile_mask[t] = (int)m;
 }
@@ -747,7 +741,7 @@ constexpr int SORT_MAX_JOBS = 16;
 struct SortJob {
   const int* tbl;
   long long n;
-  int K, nblk, shift, regions;
+  int K, nblk, shift;
   const unsigned* kin;
   unsigned* kout;
   const int* vin;
@@ -771,7 +765,7 @@ __global__ void __launch_bounds__(256) k_mask_bit_count_multi(SortJobs J) {
 __global__ void __launch_bounds__(256) k_mask_keys_multi(SortJobs J) {
   const SortJob& q = J.j[blockIdx.y];
   if ((long long)blockIdx.x * 256 >= q.n) return;
-  mask_keys_body(q.kout, q.n, q.K, q.bit_count, q.key_pos, blockIdx.x, q.regions);
+  mask_keys_body(q.kout, q.n, q.K, q.bit_count, q.key_pos, blockIdx.x);
 }
 __global__ void __launch_bounds__(64) k_radix_hist_multi(SortJobs J) {
   const SortJob& q = J.j[blockIdx.y];
@@ -984,19 +978,6 @@ int gcl_table_sort(const int32_t* tbl, int32_t K, int64_t n, int32_t window, int
   return gcl_table_sort_pre(tbl, K, n, window, nullptr, scratch, order, tbl_sorted, tile_mask, stream);
 }
 
-// Number of natural-order regions the mask sort keeps apart (0 = one global sort).  8 = one region per XCD: a table of
-// at least GCL_SORT_REGIONS_MIN_ROWS rows is sorted region by region and its convolution launches give every XCD the
-// contiguous tile range of one region (gcl_conv_fwd: tables with a region prefix run in XCD-range order).
-static int g_sort_regions = [] { const char* e = getenv("GCL_SORT_REGIONS"); int v = e ? atoi(e) : 0; return (v == 8) ? 8 : 0; }();
-static long long g_sort_regions_min = [] { const char* e = getenv("GCL_SORT_REGIONS_MIN_ROWS"); return e ? atoll(e) : 8192ll; }();
-int gcl_sort_regions(int64_t n_rows) { return (g_sort_regions && n_rows >= g_sort_regions_min) ? g_sort_regions : 0; }
-int gcl_set_sort_regions(int32_t regions, int64_t min_rows) {
-  GCL_CHECK_ARG(regions == 0 || regions == 8, "gcl_set_sort_regions: 0 (global sort) or 8 (one region per XCD)");
-  g_sort_regions = regions;
-  if (min_rows > 0) g_sort_regions_min = min_rows;
-  return GCL_OK;
-}
-
 int gcl_table_sort_pre(const int32_t* tbl, int32_t K, int64_t n, int32_t window, const int32_t* pre, int32_t* scratch,
                        int32_t* order, int32_t* tbl_sorted, int32_t* tile_mask, void* stream) {
   GCL_CHECK_ARG(tbl && scratch && order && tbl_sorted && tile_mask, "gcl_table_sort: null pointer");
@@ -1024,7 +1005,6 @@ int gcl_table_sort_pre(const int32_t* tbl, int32_t K, int64_t n, int32_t window,
     int* offs = hist + hist_len;
     int* bs = offs + hist_len;
     static const int freq_order = [] { const char* e = getenv("GCL_SORT_FREQ_ORDER"); return e ? atoi(e) : 1; }();
-    const int regions = freq_order ? gcl_sort_regions(n) : 0;
     if (freq_order) {
       bit_count = scratch + gcl_table_sort_scratch_len(n) - 64;
       key_pos = bit_count + 32;
@@ -1034,17 +1014,16 @@ int gcl_table_sort_pre(const int32_t* tbl, int32_t K, int64_t n, int32_t window,
     if (freq_order) {
       hipLaunchKernelGGL(k_mask_bit_count, dim3(512), dim3(256), 0, st, (const unsigned*)ka, (long long)n, K, bit_count);
       hipLaunchKernelGGL(k_mask_keys, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, ka, (long long)n, K,
-                         (const int*)bit_count, key_pos, regions);
+                         (const int*)bit_count, key_pos);
     }
-    const int Ks = K + (regions ? 3 : 0);      // key bits: the mask, the region above it
-    int passes = (Ks + 7) / 8;
+    int passes = (K + 7) / 8;
     // at most three 8-bit passes: a 27-offset mask is ordered by its 24 most significant bits (offsets 3..26); the
     // three dropped bits only permute rows inside runs that already share 24 bits (measured: MFMA work unchanged,
     // one pass of ~45 us per table saved)
     static const int max_passes = [] { const char* e = getenv("GCL_SORT_PASSES"); int v = e ? atoi(e) : 3; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
     int base = 0;
     if (passes > max_passes) {
-      base = Ks - 8 * max_passes;
+      base = K - 8 * max_passes;
       passes = max_passes;
     }
     for (int p = 0; p < passes; ++p) {
@@ -1095,7 +1074,6 @@ int gcl_table_sort_multi(const gcl_sort_job* jobs_host, int32_t n_jobs, void* st
     J.count = T;
     long long n_max = 0;
     int nblk_max = 0, K0 = jobs_host[j0].K;
-    bool any_regions = false;
     unsigned* ka[SORT_MAX_JOBS];
     unsigned* kb[SORT_MAX_JOBS];
     int* va[SORT_MAX_JOBS];
@@ -1113,8 +1091,6 @@ int gcl_table_sort_multi(const gcl_sort_job* jobs_host, int32_t n_jobs, void* st
       va[t] = g.scratch + 2 * n;
       vb[t] = g.scratch + 3 * n;
       q.tbl = g.tbl; q.n = n; q.K = g.K; q.nblk = nblk; q.shift = 0;
-      q.regions = gcl_sort_regions(n);
-      if (q.regions) any_regions = true;
       q.hist = g.scratch + 4 * n;
       q.offs = q.hist + hist_len;
       q.bs = q.offs + hist_len;
@@ -1129,19 +1105,15 @@ int gcl_table_sort_multi(const gcl_sort_job* jobs_host, int32_t n_jobs, void* st
     hipLaunchKernelGGL(k_row_masks_multi, dim3(gn, T), dim3(256), 0, st, J);            // masks -> ka, row ids -> va
     hipLaunchKernelGGL(k_mask_bit_count_multi, dim3(512, T), dim3(256), 0, st, J);
     hipLaunchKernelGGL(k_mask_keys_multi, dim3(gn, T), dim3(256), 0, st, J);             // ka: masks -> sort keys
-    // region prefix (gcl_sort_regions, per table): three more key bits.  The pass count is the call's, the first digit's
-    // shift the table's own (exactly what gcl_table_sort_pre does for that table alone)
-    int passes = (K0 + (any_regions ? 3 : 0) + 7) / 8;
-    if (passes > max_passes) passes = max_passes;
-    int base_of[SORT_MAX_JOBS];
-    for (int t = 0; t < T; ++t) {
-      const int Ks = K0 + (J.j[t].regions ? 3 : 0);
-      base_of[t] = Ks > 8 * passes ? Ks - 8 * passes : 0;
+    int passes = (K0 + 7) / 8, base = 0;
+    if (passes > max_passes) {
+      base = K0 - 8 * max_passes;
+      passes = max_passes;
     }
     for (int p = 0; p < passes; ++p) {
       for (int t = 0; t < T; ++t) {
         SortJob& q = J.j[t];
-        q.shift = base_of[t] + 8 * p;
+        q.shift = base + 8 * p;
         q.kin = ka[t]; q.vin = va[t];
         q.kout = kb[t];
         q.vout = (p == passes - 1) ? q.order : vb[t];

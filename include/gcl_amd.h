@@ -141,14 +141,6 @@ int gcl_kernel_map_pairs(const int32_t* nbr, int32_t K, int64_t n_out, const int
  * window = 0: one global sort.  window = 2048 | 4096: rows are sorted only inside windows of that many consecutive
  * rows (one LDS bitonic sort per window): keeps the loader's spatial coherence for the gathers. */
 int64_t gcl_table_sort_scratch_len(int64_t n);
-/* Region-sorted tables (knob GCL_SORT_REGIONS=8, tables of at least GCL_SORT_REGIONS_MIN_ROWS rows; returns 8 or 0 for a
- * table of n_rows rows): the eighth of the natural row order a row lies in -- rows arrive cloud by cloud and a
- * convolution never leaves its cloud -- is the most significant part of the sort key, i.e. each eighth is mask-sorted on
- * its own, and gcl_conv_fwd gives every XCD the contiguous tile range of one region (heaviest tiles first inside it), so
- * that an XCD's L2 only has to hold that region's slice of the gathered tensor.  Results: same sums in the same order per
- * row -- y is bitwise the same as with the global sort; only `order` differs. */
-int gcl_sort_regions(int64_t n_rows);
-int gcl_set_sort_regions(int32_t regions, int64_t min_rows);   /* process-wide; min_rows <= 0 keeps the current limit */
 int gcl_table_sort(const int32_t* tbl, int32_t K, int64_t n, int32_t window, int32_t* scratch, int32_t* order,
                    int32_t* tbl_sorted, int32_t* tile_mask, void* stream);
 /* gcl_table_sort (global mode, window 0) of SEVERAL tables in one sequence of 14 launches (a network has 12 such tables:

@@ -535,110 +535,6 @@ def test_resunet_forward_backward_vs_oracle(kind, precision):
     assert rel_l2(Fe.cpu(), Feo) < 1e-4
 
 
-@pytest.fixture
-def sort_regions():
-    """Region-sorted tables (gcl_set_sort_regions(8): each eighth of the natural row order is mask-sorted on its own and run
-    by one XCD) for every table of at least 64 rows; restored afterwards."""
-    from gcl_amd import _lib
-    lib = _lib.load()
-    _lib.check(lib.gcl_set_sort_regions(8, 64), "gcl_set_sort_regions")
-    yield lib
-    _lib.check(lib.gcl_set_sort_regions(8 if os.environ.get("GCL_SORT_REGIONS") == "8" else 0,
-                                        int(os.environ.get("GCL_SORT_REGIONS_MIN_ROWS", "8192"))), "gcl_set_sort_regions")
-
-
-@pytest.mark.parametrize("seed,n,batch,cin,cout,stride,tr", [(5, 3000, 3, 64, 64, 1, False), (6, 9000, 8, 128, 128, 1, False),
-                                                             (7, 700, 1, 256, 256, 1, False), (8, 4000, 4, 64, 128, 2, False),
-                                                             (9, 4000, 4, 128, 64, 2, True), (10, 150, 2, 32, 32, 1, False)])
-def test_region_sorted_tables(sort_regions, seed, n, batch, cin, cout, stride, tr):
-    """GCL_SORT_REGIONS: `order` is a permutation whose j-th eighth (by sorted position) holds exactly the rows of the j-th
-    eighth of the natural order, mask-sorted inside; the permuted table and the tile masks are consistent with it; and the
-    convolution over it (contiguous tile range per XCD, heaviest first inside) gives y BITWISE equal to the global sort's
-    (a row's sum never depends on the rows it shares a tile with) -- forward, fused residual epilogue, training statistics
-    equal to rounding."""
-    import gcl_amd.MinkowskiEngine as ME
-    from gcl_amd import _lib
-    lib = sort_regions
-    C = random_cloud(seed, n=n, extent=14, batch=batch)
-    def build(regions):
-        _lib.check(lib.gcl_set_sort_regions(regions, 64), "gcl_set_sort_regions")
-        mgr = make_mgr(C)
-        km = mgr.get_kernel_map(1, 3, stride)
-        return mgr, km, km.sorted_table(transposed=tr)
-
-    mgr0, km0, (tb0, or0, ms0) = build(0)
-    mgr8, km8, (tb8, or8, ms8) = build(8)
-    nrows = tb8.shape[1]
-    order = or8.cpu().numpy().astype(np.int64)
-    assert np.array_equal(np.sort(order), np.arange(nrows))
-    if nrows >= 64:
-        region_of = (order * 8) // nrows
-        assert np.all(np.diff(region_of) >= 0), "regions must be contiguous in the sorted order"
-        assert not np.array_equal(order, or0.cpu().numpy())
-    src = (km8.nbr_t if tr else km8.nbr).cpu().numpy()
-    tb = tb8.cpu().numpy()
-    masks = ms8.cpu().numpy().astype(np.uint32)
-    K = src.shape[0]
-    for k in range(K):
-        want = src[k][order]
-        live = ((masks[np.arange(nrows) // 32] >> np.uint32(k)) & 1).astype(bool)
-        assert np.array_equal(tb[k][live], want[live]) and np.all(tb[k][~live] == -1) and np.all(want[~live] == -1)
-    rowmask = np.zeros(nrows, np.uint32)
-    for k in range(K):
-        rowmask |= (tb[k] >= 0).astype(np.uint32) << np.uint32(k)
-    pad = np.zeros((-nrows) % 32, np.uint32)
-    assert np.array_equal(np.bitwise_or.reduce(np.concatenate([rowmask, pad]).reshape(-1, 32), axis=1), masks)
-    # the convolution over both tables
-    g = torch.Generator().manual_seed(seed)
-    cls = ME.MinkowskiConvolutionTranspose if tr else ME.MinkowskiConvolution
-    torch.manual_seed(seed)
-    conv = cls(cin, cout, kernel_size=3, stride=stride, dimension=3).to(DEV)
-    n_in = mgr0.num_rows(stride if tr else 1)
-    F = torch.randn(n_in, cin, generator=g).to(DEV)
-    ys = []
-    for regions, mgr in ((0, mgr0), (8, mgr8)):
-        _lib.check(lib.gcl_set_sort_regions(regions, 64), "gcl_set_sort_regions")
-        x = ME.SparseTensor(F, coordinate_map_key=ME.CoordinateMapKey(stride if tr else 1), coordinate_manager=mgr)
-        with torch.no_grad():
-            ys.append(conv(x).F.clone())
-    assert torch.isfinite(ys[0]).all() and torch.equal(ys[0], ys[1])
-
-
-def test_region_sorted_network_vs_oracle(sort_regions):
-    """The whole network (training forward + backward, plan path on the second pass) on region-sorted tables: features and
-    gradients against the fp64 oracle at the usual bounds, native maps == per-operator maps bit for bit in this mode."""
-    import gcl_amd.MinkowskiEngine as ME
-    C = torch.from_numpy(random_cloud(31, n=5000, extent=20, batch=4))
-    feats = torch.ones(len(C), 1)
-    m, st = _model_and_state(0, 5)
-    m.train()
-    specs = m.native_map_specs()
-    with torch.cuda.device(DEV):
-        ref = ME.CoordinateManager(C.to(DEV)).prefetch([s for s in specs if s[1] > 1])
-        nat = ME.CoordinateManager.build_native(C.to(DEV), specs)
-        for t_in, ks, stride, tables, pairs in (s[:5] for s in specs):
-            if ks == 3:
-                ka, kb = ref.get_kernel_map(t_in, ks, stride), nat.get_kernel_map(t_in, ks, stride)
-                for trn in tables:
-                    for u, v in zip(ka.sorted_table(transposed=trn), kb.sorted_table(transposed=trn)):
-                        assert torch.equal(u, v), (t_in, ks, stride, trn)
-        so = {k: v.clone().requires_grad_("running" not in k) for k, v in st.items()}
-        Fo = O.resunet_forward(so, C.numpy(), feats.double(), 5, True, True, 0.05)
-        gy = torch.randn(Fo.shape, generator=torch.Generator().manual_seed(1), dtype=torch.float64)
-        Fo.backward(gy)
-        for it in range(2):          # pass 0: Tape (records the plan), pass 1: the plan
-            for p in m.parameters():
-                p.grad = None
-            mgr = ME.CoordinateManager.build_native(C.to(DEV), specs)
-            F = m(ME.SparseTensor(feats.to(DEV), coordinates=C.to(DEV), coordinate_manager=mgr)).F
-            assert rel_l2(F.detach().cpu(), Fo.detach()) < 1e-4
-            F.backward(gy.float().to(DEV))
-            for name, p in m.named_parameters():
-                # (a random blob, not LiDAR geometry: the deep levels have few rows and the gradient noise of 21 BatchNorms
-                # reaches conv1 at 2.2e-3 -- the tight bounds live in test_resunet_forward_backward_vs_oracle)
-                assert rel_l2(p.grad.cpu(), so[name].grad) < (1e-2 if ".bn." in name else 5e-3), (it, name)
-
-
 # ---------------------------------------------------------------------------------------------------------------
 # loss / kNN against the golden vectors captured from the reference's own code
 # ---------------------------------------------------------------------------------------------------------------
