@@ -247,8 +247,9 @@ def _conv_launch(lib, x, Wk, mode, table, n_out, cin, cout, bias, pairs=0, want_
         name = "k_conv_generic" if generic else \
             (f"k_conv_fwd<{nb}>" if prec == 0 else
              f"k_conv_fwd_split<{nb},{prec},{pre},{'true' if add is not None else 'false'}>")
-        if x_planes is not None and prec == 4 and not generic and os.environ.get("GCL_FWD_DMA", "1") != "0":
-            name = f"k_conv_fwd_dma<{nb},{'true' if add is not None else 'false'}>"
+        if prec == 4 and not generic and os.environ.get("GCL_FWD_DMA", "1") != "0" and \
+                (x_planes is not None or os.environ.get("GCL_FWD_DMA_ROWS", "1") != "0"):
+            name = f"k_conv_fwd_dma<{nb},{pre},{'true' if add is not None else 'false'}>"
     with _Timed(name, pairs, cin, cout, x.shape[0], n_out, K):
         xin, is_planes = (x_planes, 1) if x_planes is not None else (x, 0)
         if add is not None:

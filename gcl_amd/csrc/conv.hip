@@ -819,7 +819,7 @@ __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0
 //                   B(s+1) -> the other weight buffer (last read in step s-1, before this barrier),
 //                   A fragments of step s -> registers, then A(s+1) -> the wave's tile, then B fragments + MFMAs.
 // Same products added in the same order as k_conv_fwd_split: bitwise the same y and column sums.
-template <int NB, bool EPI>
+template <int NB, bool PRE, bool EPI>
 __global__ void __launch_bounds__(256, (NB <= 2 ? 4 : 2)) k_conv_fwd_dma(const float* __restrict__ X, const u32x4* __restrict__ Wp,
                                                         const int* __restrict__ tbl, const int* __restrict__ order,
                                                         const int* __restrict__ tile_mask, long long n_out, int K,
@@ -844,7 +844,6 @@ __global__ void __launch_bounds__(256, (NB <= 2 ? 4 : 2)) k_conv_fwd_dma(const f
   const int i = l & 31, h = l >> 5;
   unsigned bxx = blockIdx.x, byy = blockIdx.y;
   const bool heavy_first = (swizzle & 16) != 0;
-  const bool prio = (swizzle & 32) != 0;      // experiment: s_setprio 1 around the MFMA block
   swizzle &= 15;
   const unsigned nrw = (unsigned)((n_out + CONV_ROWS - 1) / CONV_ROWS);
   if (swizzle >= 2) {
@@ -970,17 +969,34 @@ __global__ void __launch_bounds__(256, (NB <= 2 ? 4 : 2)) k_conv_fwd_dma(const f
       if (hasn) GCL_DMA_B(kn, cn, buf ^ 1);
       if (mine_cur) {
         u32x4 ap[2][2];
+        if (PRE) {   // row image: dwords [0,16) = hi of channels 0..31, [16,32) = lo
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {   // row image: dwords [0,16) = hi of channels 0..31, [16,32) = lo
-          ap[m][0] = *reinterpret_cast<const u32x4*>(&Asm[w][i][((2 * m + h) ^ a_swz(i)) << 2]);
-          ap[m][1] = *reinterpret_cast<const u32x4*>(&Asm[w][i][((4 + 2 * m + h) ^ a_swz(i)) << 2]);
+          for (int m = 0; m < 2; ++m) {
+            ap[m][0] = *reinterpret_cast<const u32x4*>(&Asm[w][i][((2 * m + h) ^ a_swz(i)) << 2]);
+            ap[m][1] = *reinterpret_cast<const u32x4*>(&Asm[w][i][((4 + 2 * m + h) ^ a_swz(i)) << 2]);
+          }
+          if (mine_n) {
+            // the DMA overwrites the tile: this wave's fragment reads must have returned (the asm consumes them)
+            asm volatile("" : "+v"(ap[0][0]), "+v"(ap[0][1]), "+v"(ap[1][0]), "+v"(ap[1][1])::"memory");
+            GCL_DMA_A(kn, cn);
+          }
+        } else {     // fp32 rows: the raw pieces come out of the tile and are split into the two fp16 planes here
+          typedef float f32x4 __attribute__((ext_vector_type(4)));
+          f32x4 f[2][2];
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            f[m][0] = *reinterpret_cast<const f32x4*>(&Asm[w][i][((4 * m + 2 * h) ^ a_swz(i)) << 2]);
+            f[m][1] = *reinterpret_cast<const f32x4*>(&Asm[w][i][((4 * m + 2 * h + 1) ^ a_swz(i)) << 2]);
+          }
+          if (mine_n) {
+            asm volatile("" : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1])::"memory");
+            GCL_DMA_A(kn, cn);
+          }
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+            split8<PL>(make_float4(f[m][0][0], f[m][0][1], f[m][0][2], f[m][0][3]),
+                       make_float4(f[m][1][0], f[m][1][1], f[m][1][2], f[m][1][3]), a_scale, ap[m]);
         }
-        if (mine_n) {
-          // the DMA overwrites the tile: this wave's fragment reads must have returned (the asm consumes them)
-          asm volatile("" : "+v"(ap[0][0]), "+v"(ap[0][1]), "+v"(ap[1][0]), "+v"(ap[1][1])::"memory");
-          GCL_DMA_A(kn, cn);
-        }
-        if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
 #pragma unroll
@@ -992,7 +1008,6 @@ __global__ void __launch_bounds__(256, (NB <= 2 ? 4 : 2)) k_conv_fwd_dma(const f
             mfma_terms<PL>(ap[m], bp, acc[b]);
           }
         }
-        if (prio) __builtin_amdgcn_s_setprio(0);
       } else if (mine_n) {
         GCL_DMA_A(kn, cn);
       }
@@ -2212,7 +2227,6 @@ int gcl_conv_fwd_fused(const float* x, int64_t n_in, int32_t x_is_planes, const 
   const bool ranges = (flags & GCL_CONV_XCD_RANGES) != 0;     // spatially ordered table: contiguous tile range per XCD
   static const int heavy_first = [] { const char* e = getenv("GCL_CONV_HEAVY_FIRST"); return e ? atoi(e) : 1; }();
   const int sswz = (cg ? (ranges ? 3 : 2) : (ranges ? 1 : swz)) | ((heavy_first && tile_mask && !ranges) ? 16 : 0);
-  const int sswz_ = sswz;
 #define LAUNCH_F32(NBV)                                                                                          \
   hipLaunchKernelGGL(k_conv_fwd<NBV>, grid, dim3(256), 0, st, x, (const float4*)wp, tbl, order, tile_mask,       \
                      (long long)n_out, K, cin, cout, bias, y, swz)
@@ -2260,16 +2274,20 @@ int gcl_conv_fwd_fused(const float* x, int64_t n_in, int32_t x_is_planes, const 
   // register-staged k_conv_fwd_split): bitwise the same results, 15 - 21 % shorter launches on the C >= 128 layers of the
   // KITTI batch (profiles/r04_conv_experiments.txt, 19)
   static const int dma = [] { const char* e = getenv("GCL_FWD_DMA"); return e ? atoi(e) : 1; }();
-  if ((dma || (flags & GCL_CONV_DMA)) && !(flags & GCL_CONV_NO_DMA) && prec == 4 && x_is_planes) {
+  // fp32-row launches too (the C = 32 / 64 layers; GCL_FWD_DMA_ROWS=0: plane images only)
+  static const int dma_rows = [] { const char* e = getenv("GCL_FWD_DMA_ROWS"); return e ? atoi(e) : 1; }();
+  if ((dma || (flags & GCL_CONV_DMA)) && !(flags & GCL_CONV_NO_DMA) && prec == 4 && (x_is_planes || dma_rows)) {
     const unsigned w_bytes = (unsigned)((long long)K * cin * cout * 4);
-    static const int dma_prio = [] { const char* e = getenv("GCL_DMA_PRIO"); return e ? atoi(e) : 0; }();
-    const int sswz = sswz_ | (dma_prio ? 32 : 0);
-#define LAUNCH_DMA(NBV, EPIV)                                                                                     \
-  hipLaunchKernelGGL((k_conv_fwd_dma<NBV, EPIV>), sgrid, dim3(256), 0, st, x, (const u32x4*)wp, tbl, order, tile_mask, \
-                     (long long)n_out, K, cin, cout, bias, y, sswz, stats, x_amax, w_amax, x_bytes, w_bytes, epi)
-    if (nb == 4) { if (use_epi) LAUNCH_DMA(4, true); else LAUNCH_DMA(4, false); }
-    else if (nb == 2) { if (use_epi) LAUNCH_DMA(2, true); else LAUNCH_DMA(2, false); }
-    else { if (use_epi) LAUNCH_DMA(1, true); else LAUNCH_DMA(1, false); }
+#define LAUNCH_DMA(NBV, PREV, EPIV)                                                                               \
+  hipLaunchKernelGGL((k_conv_fwd_dma<NBV, PREV, EPIV>), sgrid, dim3(256), 0, st, x, (const u32x4*)wp, tbl, order,  \
+                     tile_mask, (long long)n_out, K, cin, cout, bias, y, sswz, stats, x_amax, w_amax, x_bytes, w_bytes, epi)
+#define LAUNCH_DMA_P(NBV)                                                                                         \
+  do {                                                                                                            \
+    if (x_is_planes) { if (use_epi) LAUNCH_DMA(NBV, true, true); else LAUNCH_DMA(NBV, true, false); }             \
+    else { if (use_epi) LAUNCH_DMA(NBV, false, true); else LAUNCH_DMA(NBV, false, false); }                       \
+  } while (0)
+    if (nb == 4) LAUNCH_DMA_P(4); else if (nb == 2) LAUNCH_DMA_P(2); else LAUNCH_DMA_P(1);
+#undef LAUNCH_DMA_P
 #undef LAUNCH_DMA
     GCL_CHECK_LAUNCH();
     return GCL_OK;

@@ -339,13 +339,16 @@ def test_inference_launch_with_offset_groups(cin, cout):
         assert torch.equal(tall[:na], ya) and torch.equal(tall[na:], yb)
 
 
-@pytest.mark.parametrize("cin,cout,n", [(128, 128, 3000), (256, 256, 1500), (128, 256, 700), (256, 128, 129), (128, 128, 1),
-                                        (128, 64, 2500), (256, 64, 900), (128, 32, 600)])
-def test_lds_dma_forward_kernel_is_bitwise_the_register_staged_kernel(cin, cout, n):
-    """Flag GCL_CONV_DMA runs plane-image launches on k_conv_fwd_dma (operands staged by `buffer_load ... lds`: no staging
-    registers, no ds_write; missing neighbours read zero through the buffer resource) instead of k_conv_fwd_split.  Same
-    products added in the same order: y and the BatchNorm column-sum partials are equal bit for bit, with and without the
-    fused epilogue, for every column-block width (NB = 4, 2, 1) and for ragged / single-row launches."""
+@pytest.mark.parametrize("cin,cout,n,use_planes", [(128, 128, 3000, True), (256, 256, 1500, True), (128, 256, 700, True),
+                                                   (256, 128, 129, True), (128, 128, 1, True), (128, 64, 2500, True),
+                                                   (256, 64, 900, True), (128, 32, 600, True), (64, 64, 3000, False),
+                                                   (32, 32, 2000, False), (32, 64, 700, False), (64, 128, 1500, False),
+                                                   (96, 64, 300, False), (64, 32, 1, False), (128, 128, 500, False)])
+def test_lds_dma_forward_kernel_is_bitwise_the_register_staged_kernel(cin, cout, n, use_planes):
+    """k_conv_fwd_dma (operands staged by `buffer_load ... lds`: no staging registers, no ds_write; missing neighbours read
+    zero through the buffer resource; flag GCL_CONV_DMA) against k_conv_fwd_split (flag GCL_CONV_NO_DMA), on plane images and
+    on fp32 rows.  Same products added in the same order: y and the BatchNorm column-sum partials are equal bit for bit, with
+    and without the fused epilogue, for every column-block width (NB = 4, 2, 1) and for ragged / single-row launches."""
     from gcl_amd import _lib
     import gcl_amd.MinkowskiEngine as ME
     lib = _lib.load()
@@ -372,7 +375,8 @@ def test_lds_dma_forward_kernel_is_bitwise_the_register_staged_kernel(cin, cout,
                 y = torch.full((n_out, cout), float("nan"), device=DEV)
                 stats = torch.full(((n_out + 127) // 128, 2, cout), float("nan"), device=DEV)
                 slot = ME.ops.amax_slot(x.device)
-                _lib.check(lib.gcl_conv_fwd_fused(_lib.ptr(planes), n_out, 1, _lib.ptr(wp), 4, _lib.ptr(xa), _lib.ptr(wa),
+                _lib.check(lib.gcl_conv_fwd_fused(_lib.ptr(planes if use_planes else x), n_out, int(use_planes), _lib.ptr(wp), 4,
+                                                  _lib.ptr(xa), _lib.ptr(wa),
                                                   _lib.ptr(tbl), _lib.ptr(order), _lib.ptr(mask), n_out, K, cin, cout, None,
                                                   None, _lib.ptr(res) if fused else None, int(fused),
                                                   _lib.ptr(slot) if fused else None, _lib.ptr(y), _lib.ptr(stats), flags,

@@ -14,14 +14,16 @@ batch = synthetic.make_train_batch(100, batch_size=int(os.environ.get("LB_BATCH"
 dev = "cuda:0"
 C = batch["sinput_C"].to(dev)
 # (tensor stride of the kernel map's fine side, stride, transposed, cin, cout)
-LAYERS = [(4, 1, False, 128, 128), (8, 1, False, 256, 256), (4, 2, False, 128, 256), (4, 2, True, 256, 128),
-          (2, 2, True, 256, 64), (1, 2, True, 128, 64), (2, 1, False, 64, 64), (1, 1, False, 64, 64)]
+# last field: operand = plane image (what production feeds the C >= 128 layers) or fp32 rows
+LAYERS = [(4, 1, False, 128, 128, 1), (8, 1, False, 256, 256, 1), (4, 2, False, 128, 256, 1), (4, 2, True, 256, 128, 1),
+          (2, 2, True, 256, 64, 1), (1, 2, True, 128, 64, 1), (2, 1, False, 64, 64, 0), (1, 1, False, 64, 64, 0),
+          (1, 1, False, 32, 32, 0), (1, 2, False, 32, 64, 0), (2, 2, False, 64, 128, 0), (1, 2, True, 64, 32, 0)]
 rounds, reps = int(os.environ.get("LB_ROUNDS", "5")), int(os.environ.get("LB_REPS", "10"))
 lib = _lib.load()
 mgr = ME.CoordinateManager(C)
 tot = {8: 0.0, 2: 0.0}
 with torch.cuda.device(dev):
-    for (t_in, stride, tr, cin, cout) in LAYERS:
+    for (t_in, stride, tr, cin, cout, pre) in LAYERS:
         km = mgr.get_kernel_map(t_in, 3, stride)
         tbl, order, mask = km.sorted_table(transposed=tr)
         n_out = tbl.shape[1]
@@ -41,7 +43,7 @@ with torch.cuda.device(dev):
         stats = torch.empty(((n_out + 127) // 128, 2, cout), device=dev)
 
         def run(flags):
-            _lib.check(lib.gcl_conv_fwd(_lib.ptr(planes), n_in, 1, _lib.ptr(wp), 4, _lib.ptr(xa), _lib.ptr(wa), _lib.ptr(tbl),
+            _lib.check(lib.gcl_conv_fwd(_lib.ptr(planes if pre else x), n_in, pre, _lib.ptr(wp), 4, _lib.ptr(xa), _lib.ptr(wa), _lib.ptr(tbl),
                                         _lib.ptr(order), _lib.ptr(mask), n_out, K, cin, cout, None, _lib.ptr(y[flags]),
                                         _lib.ptr(stats), flags, _lib.stream()), "gcl_conv_fwd")
         times = {8: [], 2: []}
@@ -57,7 +59,7 @@ with torch.cuda.device(dev):
                 torch.cuda.synchronize()
                 times[f].append(e0.elapsed_time(e1) / reps * 1e3)
         same = torch.equal(y[8], y[2])
-        line = f"t={t_in} {cin:3d}->{cout:3d} s{stride}{' tr' if tr else '   '} n_out={n_out:7d} nb={lib.gcl_conv_fwd_nb(n_out, cout, 4)}:"
+        line = f"t={t_in} {cin:3d}->{cout:3d} s{stride}{' tr' if tr else '   '} n_out={n_out:7d} {'planes' if pre else 'rows  '} nb={lib.gcl_conv_fwd_nb(n_out, cout, 4)}:"
         for f, name in ((8, "regs"), (2, "dma ")):
             med = sorted(times[f])[len(times[f]) // 2]
             tot[f] += med
