@@ -720,7 +720,9 @@ class Tape:
             elif kind == "cat":
                 off = 0
                 for t in e[2]:
-                    give(t, g[:, off:off + t.shape[1]])
+                    # (contiguous, like the plan's k_split2 outputs: the reader's input-gradient launch can then take the
+                    # slice as its epilogue operand -- same sums, and the same BatchNorm-sum fusion decisions as the plan)
+                    give(t, g[:, off:off + t.shape[1]].contiguous())
                     off += t.shape[1]
             elif kind == "rownorm":
                 give(e[3], _RowNormalizeFn.backward(e[2], g))

@@ -486,41 +486,58 @@ __device__ __forceinline__ void conv_fwd_epilogue(f32x16 (&acc)[NB], float* tile
     asm volatile("v_mov_b32 %0, %1" : "=v"(bvv) : "v"(bvv));
     asm volatile("v_mov_b32 %0, %1" : "=v"(csc) : "v"(csc));
     float s1 = 0.f, s2 = 0.f;
-    if (EPI && bb.xc) {      // BatchNorm-backward sums of the record this gradient belongs to (see ConvBnBwd)
-      const float mu = bb.mean[col], rs = bb.rstd[col];
-      const int cq = cout >> 2;
+    // EPI: the epilogue operands of eight rows are loaded BEFORE the first of their stores (a load result waits for all
+    // earlier stores of the wave -- vmcnt is in order -- so loads between the stores made each row a full memory round trip)
+    const bool bnb = EPI && bb.xc != nullptr;
+    const float mu = bnb ? bb.mean[col] : 0.f, rs = bnb ? bb.rstd[col] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+    for (int r0 = 0; r0 < 16; r0 += 8) {
+      float rv[8], xv[8];
+      unsigned mw[8];
+      if (EPI && (epi.residual || bnb)) {
+        const int cq = cout >> 2;
+        const unsigned* const m32 = reinterpret_cast<const unsigned*>(bb.mask);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int r = r0 + j;
+          const int orow = __shfl(orow_l, (r & 3) + 8 * (r >> 2) + 4 * h);
+          rv[j] = 0.f;
+          xv[j] = 0.f;
+          mw[j] = ~0u;
+          if (orow >= 0) {
+            const long long e = (long long)orow * cout + col;
+            if (epi.residual) rv[j] = epi.residual[e];
+            if (bnb) {
+              xv[j] = bb.xc[e];
+              if (bb.relu) {      // sign bit of element (orow, col): norm.hip's layout, read as 32-bit halves
+                const long long q = (long long)orow * cq + (col >> 2);
+                mw[j] = m32[((q >> 6) * 4 + (col & 3)) * 2 + ((q >> 5) & 1)] >> (q & 31);
+              }
+            }
+          }
+        }
+        asm volatile("" ::: "memory");      // keep the stores below behind these loads
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = r0 + j;
         int orow = __shfl(orow_l, (r & 3) + 8 * (r >> 2) + 4 * h);
         if (orow >= 0) {
           float v = acc[b][r] * csc + bvv;
-          const long long e = (long long)orow * cout + col;
-          if (epi.residual) v += epi.residual[e];
-          Y[e] = v;
-          ymax = fmaxf(ymax, fabsf(v));
-          const float xh = (bb.xc[e] - mu) * rs;
-          if (bb.relu) {
-            const long long q = (long long)orow * cq + (col >> 2);
-            v = ((bb.mask[(q >> 6) * 4 + (col & 3)] >> (q & 63)) & 1ull) ? v : 0.f;
+          if (EPI && epi.residual) v += rv[j];
+          if (EPI && epi.relu) v = fmaxf(v, 0.f);
+          Y[(long long)orow * cout + col] = v;
+          if (EPI) ymax = fmaxf(ymax, fabsf(v));
+          if (bnb) {           // BatchNorm-backward sums of the record this gradient belongs to (see ConvBnBwd)
+            const float gm = (mw[j] & 1u) ? v : 0.f;
+            s1 += gm;
+            s2 += gm * ((xv[j] - mu) * rs);
+          } else {
+            s1 += v;
+            s2 += v * v;
           }
-          s1 += v;
-          s2 += v * xh;
         }
       }
-    } else {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int orow = __shfl(orow_l, (r & 3) + 8 * (r >> 2) + 4 * h);
-      if (orow >= 0) {
-        float v = acc[b][r] * csc + bvv;
-        if (EPI && epi.residual) v += epi.residual[(long long)orow * cout + col];
-        if (EPI && epi.relu) v = fmaxf(v, 0.f);
-        Y[(long long)orow * cout + col] = v;
-        s1 += v;
-        s2 += v * v;
-        if (EPI) ymax = fmaxf(ymax, fabsf(v));
-      }
-    }
     }
     if (stats) {
       s1 += __shfl_xor(s1, 32);
