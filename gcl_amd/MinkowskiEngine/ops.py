@@ -219,16 +219,13 @@ def ctypes_offset(t, elem):
 
 
 def _conv_launch(lib, x, Wk, mode, table, n_out, cin, cout, bias, pairs=0, want_stats=False, x_amax=None,
-                 w_amax=None, wp=None, x_planes=None, generic=False, add=None, bn_bwd=None):
+                 w_amax=None, wp=None, x_planes=None, generic=False, add=None):
     """One output-stationary convolution launch.  ``Wk`` [K, *, *] is packed for ``mode`` (0 forward, 1 transposed,
     2 transposed + mirrored offsets) in the current precision; ``table`` = (tbl, order, tile_mask) from
     KernelMap.sorted_table(), or None for a kernel_size-1 conv; (cin, cout) are the EFFECTIVE widths of the launch.
     ``want_stats``: also return the per-workgroup column sums [ceil(n_out/128), 2, cout] for a following BatchNorm.
     ``add`` [n_out, cout] (split-precision MFMA kernels only): added to the result in the epilogue (a gradient that
-    already reached the same tensor through another path: saves the separate accumulation pass).
-    ``bn_bwd`` = (conv_out, mask, mean, rstd, relu) of the conv + BatchNorm record whose OUTPUT GRADIENT this launch writes
-    (an input-gradient launch, fp16x3 MFMA shapes): returns (y, partials) with the per-workgroup BatchNorm-backward sums
-    (gcl_conv_fwd_bnbwd) in place of that record's gcl_bn_bwd_reduce pass."""
+    already reached the same tensor through another path: saves the separate accumulation pass)."""
     prec = _PREC_CODES[PRECISION]
     K, wc_in, wc_out = Wk.shape
     if prec == 4 and not generic:
@@ -253,20 +250,8 @@ def _conv_launch(lib, x, Wk, mode, table, n_out, cin, cout, bias, pairs=0, want_
         if prec == 4 and not generic and os.environ.get("GCL_FWD_DMA", "1") != "0" and \
                 (x_planes is not None or os.environ.get("GCL_FWD_DMA_ROWS", "1") != "0"):
             name = f"k_conv_fwd_dma<{nb},{pre},{'true' if add is not None else 'false'}>"
-    if bn_bwd is not None and PROFILE is not None:
-        name = name.replace(",false>", ",true>")
     with _Timed(name, pairs, cin, cout, x.shape[0], n_out, K):
         xin, is_planes = (x_planes, 1) if x_planes is not None else (x, 0)
-        if bn_bwd is not None:
-            bx, bmask, bmean, brstd, brelu = bn_bwd
-            partials = torch.empty(((n_out + 127) // 128, 2, cout), dtype=torch.float32, device=x.device)
-            _lib.check(lib.gcl_conv_fwd_bnbwd(_lib.ptr(xin), x.shape[0], is_planes, _lib.ptr(wp), _lib.ptr(x_amax),
-                                              _lib.ptr(w_amax), _lib.ptr(tbl), _lib.ptr(order), _lib.ptr(tile_mask), n_out, K,
-                                              cin, cout, _lib.ptr(add, torch.float32) if add is not None else None, None,
-                                              _lib.ptr(y), _lib.ptr(bx), _lib.ptr(bmask), _lib.ptr(bmean), _lib.ptr(brstd),
-                                              int(brelu), _lib.ptr(partials), getattr(tbl, "_gcl_flags", 0), _lib.stream()),
-                       "gcl_conv_fwd_bnbwd")
-            return y, partials
         if add is not None:
             _lib.check(lib.gcl_conv_fwd_fused(_lib.ptr(xin), x.shape[0], is_planes, _lib.ptr(wp), prec, _lib.ptr(x_amax),
                                               _lib.ptr(w_amax), _lib.ptr(tbl), _lib.ptr(order), _lib.ptr(tile_mask), n_out,
@@ -369,24 +354,13 @@ class _SparseConvFn(torch.autograd.Function):
             group = ctx.group
             wp = group.packed(lib, ctx.param, mode) if group is not None else None
             dyp = planes_of(lib, dy, dy_amax) if (fp16x3 and _want_planes(cout)) else None
-            acc = waiting = getattr(ctx, "dx_accumulate", None)   # Tape: a gradient that already reached x through another path
+            acc = getattr(ctx, "dx_accumulate", None)       # Tape: a gradient that already reached x through another path
             if acc is not None and (generic or prec == 0 or acc.shape != (x.shape[0], cin) or not acc.is_contiguous()
                                     or acc.dtype != torch.float32):
                 acc = None
             ctx.dx_accumulated = acc is not None
-            # Tape: dx is the output gradient of the conv + BatchNorm record that produced x and nothing is added to it
-            # later -> the launch also leaves that record's BatchNorm-backward sums (see Tape.backward)
-            bnctx = getattr(ctx, "bn_bwd", None)
-            ctx.bn_bwd = None
-            if bnctx is not None and fp16x3 and (acc is not None or waiting is None) and \
-                    (x.shape[0] + 127) // 128 <= lib.gcl_bn_bwd_partials_max():
-                bx, bmask, _bw, bmean, brstd = bnctx.saved_tensors
-                dx, bnctx.bwd_partials = _conv_launch(lib, dy, Wk, mode, tbl, x.shape[0], cout, cin, None, ctx.pairs,
-                                                      x_amax=dy_amax, w_amax=w_amax, wp=wp, x_planes=dyp, add=acc,
-                                                      bn_bwd=(bx, bmask, bmean, brstd, bnctx.relu))
-            else:
-                dx = _conv_launch(lib, dy, Wk, mode, tbl, x.shape[0], cout, cin, None, ctx.pairs, x_amax=dy_amax,
-                                  w_amax=w_amax, wp=wp, x_planes=dyp, generic=generic, add=acc)
+            dx = _conv_launch(lib, dy, Wk, mode, tbl, x.shape[0], cout, cin, None, ctx.pairs, x_amax=dy_amax,
+                              w_amax=w_amax, wp=wp, x_planes=dyp, generic=generic, add=acc)
         if ctx.needs_input_grad[1]:
             dW = torch.empty_like(Wk)
             if ctx.stem:
@@ -526,16 +500,10 @@ class _BatchNormFn(torch.autograd.Function):
         dy = dy.contiguous()
         sums = torch.empty((2, c), dtype=torch.float32, device=dev)           # one allocation: sum_g | sum_gx
         sum_g, sum_gx = sums[0], sums[1]
-        partials = getattr(ctx, "bwd_partials", None)
-        if partials is not None:      # left by the input-gradient launch that wrote dy (_SparseConvFn.backward, Tape only)
-            ctx.bwd_partials = None
-            _lib.check(lib.gcl_bn_bwd_from_partials(_lib.ptr(partials), partials.shape[0], c, _lib.ptr(sum_g), _lib.ptr(sum_gx),
-                                                    _lib.stream()), "gcl_bn_bwd_from_partials")
-        else:
-            scratch = torch.empty(lib.gcl_bn_scratch_len(n, c), dtype=torch.float64, device=dev)
-            _lib.check(lib.gcl_bn_bwd_reduce(_lib.ptr(x), _lib.ptr(dy), None, _lib.ptr(mask), n, c, _lib.ptr(mean),
-                                             _lib.ptr(rstd), int(ctx.relu), _lib.ptr(scratch), _lib.ptr(sum_g),
-                                             _lib.ptr(sum_gx), _lib.stream()), "gcl_bn_bwd_reduce")
+        scratch = torch.empty(lib.gcl_bn_scratch_len(n, c), dtype=torch.float64, device=dev)
+        _lib.check(lib.gcl_bn_bwd_reduce(_lib.ptr(x), _lib.ptr(dy), None, _lib.ptr(mask), n, c, _lib.ptr(mean), _lib.ptr(rstd),
+                                         int(ctx.relu), _lib.ptr(scratch), _lib.ptr(sum_g), _lib.ptr(sum_gx),
+                                         _lib.stream()), "gcl_bn_bwd_reduce")
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.has_res else None
         slot = amax_slot(dev) if PRECISION == "fp16x3" else None
@@ -664,26 +632,7 @@ class Tape:
                 k = id(p)
                 pgrads[k] = g if k not in pgrads else pgrads[k] + g
 
-        # BatchNorm-backward sums from the input-gradient launch (same rule as csrc/plan.hip conv_backward): the entry with
-        # the LOWEST index among the readers of a conv + BatchNorm output is visited last, so its input gradient (with the
-        # waiting gradients added in the epilogue) is that record's complete output gradient
-        producer, first_reader = {}, {}
-        if BN_BWD_FUSE and FUSE_GRAD_ADD:
-            for idx, e in enumerate(self.entries):
-                if e[0] == "convbn":
-                    producer[id(e[1])] = e[3]
-                reads = {"convbn": (e[4], e[5]) if e[0] == "convbn" else (), "conv": (e[3],) if e[0] == "conv" else (),
-                         "relu": (e[2],) if e[0] == "relu" else (), "cat": tuple(e[2]) if e[0] == "cat" else (),
-                         "rownorm": (e[3],) if e[0] == "rownorm" else ()}[e[0]]
-                for t in reads:
-                    if t is not None:
-                        first_reader.setdefault(id(t), idx)
-
-        def bn_of(x, idx):
-            return producer.get(id(x)) if first_reader.get(id(x)) == idx else None
-
-        for idx in range(len(self.entries) - 1, -1, -1):
-            e = self.entries[idx]
+        for e in reversed(self.entries):
             kind, y = e[0], e[1]
             g = grads.pop(id(y), None)
             if g is None:
@@ -693,7 +642,6 @@ class Tape:
                 r = _BatchNormFn.backward(c2, g.contiguous())
                 c1.needs_input_grad = (id(x) in self.made, True, False)
                 c1.dx_accumulate = grads.get(id(x)) if FUSE_GRAD_ADD else None
-                c1.bn_bwd = bn_of(x, idx)
                 dx, dW = _SparseConvFn.backward(c1, r[0], None)[:2]
                 if getattr(c1, "dx_accumulated", False):
                     grads[id(x)] = dx                    # the launch's epilogue added the gradient that was waiting
@@ -707,7 +655,6 @@ class Tape:
                 c1, x, (W, b) = e[2], e[3], e[4]
                 c1.needs_input_grad = (id(x) in self.made, True, b is not None)
                 c1.dx_accumulate = grads.get(id(x)) if FUSE_GRAD_ADD else None
-                c1.bn_bwd = bn_of(x, idx)
                 dx, dW, db = _SparseConvFn.backward(c1, g, None)[:3]
                 if getattr(c1, "dx_accumulated", False):
                     grads[id(x)] = dx
@@ -720,9 +667,7 @@ class Tape:
             elif kind == "cat":
                 off = 0
                 for t in e[2]:
-                    # (contiguous, like the plan's k_split2 outputs: the reader's input-gradient launch can then take the
-                    # slice as its epilogue operand -- same sums, and the same BatchNorm-sum fusion decisions as the plan)
-                    give(t, g[:, off:off + t.shape[1]].contiguous())
+                    give(t, g[:, off:off + t.shape[1]])
                     off += t.shape[1]
             elif kind == "rownorm":
                 give(e[3], _RowNormalizeFn.backward(e[2], g))
@@ -735,9 +680,6 @@ TAPE_ENABLED = os.environ.get("GCL_TAPE", "1") == "1"
 # Tape backward: a convolution's input gradient lands on a tensor that already holds a gradient from another path (the
 # residual branch of a block, a skip connection) -> the waiting gradient is added in the launch's epilogue
 FUSE_GRAD_ADD = os.environ.get("GCL_FUSE_GRAD_ADD", "1") == "1"
-# ... and when that tensor is the output of a conv + BatchNorm record whose other readers have all been visited, the launch
-# also accumulates the record's BatchNorm-backward sums (gcl_conv_fwd_bnbwd) instead of a gcl_bn_bwd_reduce pass
-BN_BWD_FUSE = os.environ.get("GCL_BN_BWD_FUSE", "1") == "1"
 
 
 class tape:

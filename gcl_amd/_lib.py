@@ -79,10 +79,6 @@ SIGNATURES = {
     "gcl_table_sort_multi": (_i32, [_vp, _i32, _vp]),
     "gcl_spatial_order": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
     "gcl_table_sort_pre": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "gcl_conv_fwd_bnbwd": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp,
-                                  _vp, _vp, _i32, _vp, _i32, _vp]),
-    "gcl_bn_bwd_partials_max": (_i64, []),
-    "gcl_bn_bwd_from_partials": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
     "gcl_conv_fwd_fused": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp,
                                   _i32, _vp, _vp, _vp, _i32, _vp]),
     "gcl_split_planes": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),

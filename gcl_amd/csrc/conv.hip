@@ -446,18 +446,6 @@ struct ConvEpi {
   int* y_amax;              // zero-initialised amax slot of y, NULL = not wanted
 };
 
-// Optional BatchNorm-backward sums in the epilogue of an INPUT-GRADIENT launch (EPI instantiations): the launch writes
-// g = dL/dy of a conv + BatchNorm (+ ReLU) record whose pre-normalisation output is xc; instead of the column sums of its own
-// output the per-workgroup partials then hold  sum g'  and  sum g' xhat  (g' = g where the record's ReLU let the value
-// through, xhat = (xc - mean) rstd) -- what k_bn_reduce<true> computes in a pass of its own over xc and g.
-struct ConvBnBwd {
-  const float* xc;                    // [n_out, cout] convolution output the BatchNorm normalised, NULL = off
-  const unsigned long long* mask;     // ReLU sign bits of the record's output (norm.hip layout), NULL when relu == 0
-  const float* mean;
-  const float* rstd;
-  int relu;
-};
-
 // Epilogue of the four-wave forward kernels (k_conv_fwd_split, k_conv_fwd_dma): un-scale, bias, optional fused inference
 // epilogue, scatter to the original row order, per-workgroup column sums for the BatchNorm that follows.  `tiles` = the
 // workgroup's four wave-private 32 x 32-float A tiles (idle by now: scratch for the column sums).
@@ -465,8 +453,7 @@ template <int NB, bool EPI>
 __device__ __forceinline__ void conv_fwd_epilogue(f32x16 (&acc)[NB], float* tiles, const int* __restrict__ order,
                                                   long long n_out, int cout, const float* __restrict__ bias,
                                                   float* __restrict__ Y, float* __restrict__ stats, float out_scale,
-                                                  const ConvEpi& epi, long long tile, unsigned bxx, int nb0, bool active,
-                                                  const ConvBnBwd& bb) {
+                                                  const ConvEpi& epi, long long tile, unsigned bxx, int nb0, bool active) {
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   const int i = l & 31, h = l >> 5;
   const long long row0 = tile * 32;
@@ -486,57 +473,17 @@ __device__ __forceinline__ void conv_fwd_epilogue(f32x16 (&acc)[NB], float* tile
     asm volatile("v_mov_b32 %0, %1" : "=v"(bvv) : "v"(bvv));
     asm volatile("v_mov_b32 %0, %1" : "=v"(csc) : "v"(csc));
     float s1 = 0.f, s2 = 0.f;
-    // EPI: the epilogue operands of eight rows are loaded BEFORE the first of their stores (a load result waits for all
-    // earlier stores of the wave -- vmcnt is in order -- so loads between the stores made each row a full memory round trip)
-    const bool bnb = EPI && bb.xc != nullptr;
-    const float mu = bnb ? bb.mean[col] : 0.f, rs = bnb ? bb.rstd[col] : 0.f;
 #pragma unroll
-    for (int r0 = 0; r0 < 16; r0 += 8) {
-      float rv[8], xv[8];
-      unsigned mw[8];
-      if (EPI && (epi.residual || bnb)) {
-        const int cq = cout >> 2;
-        const unsigned* const m32 = reinterpret_cast<const unsigned*>(bb.mask);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int r = r0 + j;
-          const int orow = __shfl(orow_l, (r & 3) + 8 * (r >> 2) + 4 * h);
-          rv[j] = 0.f;
-          xv[j] = 0.f;
-          mw[j] = ~0u;
-          if (orow >= 0) {
-            const long long e = (long long)orow * cout + col;
-            if (epi.residual) rv[j] = epi.residual[e];
-            if (bnb) {
-              xv[j] = bb.xc[e];
-              if (bb.relu) {      // sign bit of element (orow, col): norm.hip's layout, read as 32-bit halves
-                const long long q = (long long)orow * cq + (col >> 2);
-                mw[j] = m32[((q >> 6) * 4 + (col & 3)) * 2 + ((q >> 5) & 1)] >> (q & 31);
-              }
-            }
-          }
-        }
-        asm volatile("" ::: "memory");      // keep the stores below behind these loads
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int r = r0 + j;
-        int orow = __shfl(orow_l, (r & 3) + 8 * (r >> 2) + 4 * h);
-        if (orow >= 0) {
-          float v = acc[b][r] * csc + bvv;
-          if (EPI && epi.residual) v += rv[j];
-          if (EPI && epi.relu) v = fmaxf(v, 0.f);
-          Y[(long long)orow * cout + col] = v;
-          if (EPI) ymax = fmaxf(ymax, fabsf(v));
-          if (bnb) {           // BatchNorm-backward sums of the record this gradient belongs to (see ConvBnBwd)
-            const float gm = (mw[j] & 1u) ? v : 0.f;
-            s1 += gm;
-            s2 += gm * ((xv[j] - mu) * rs);
-          } else {
-            s1 += v;
-            s2 += v * v;
-          }
-        }
+    for (int r = 0; r < 16; ++r) {
+      int orow = __shfl(orow_l, (r & 3) + 8 * (r >> 2) + 4 * h);
+      if (orow >= 0) {
+        float v = acc[b][r] * csc + bvv;
+        if (EPI && epi.residual) v += epi.residual[(long long)orow * cout + col];
+        if (EPI && epi.relu) v = fmaxf(v, 0.f);
+        Y[(long long)orow * cout + col] = v;
+        s1 += v;
+        s2 += v * v;
+        if (EPI) ymax = fmaxf(ymax, fabsf(v));
       }
     }
     if (stats) {
@@ -585,8 +532,7 @@ __global__ void __launch_bounds__(256, GCL_FWD_MIN_WAVES(NB, PL)) k_conv_fwd_spl
                                                         int cin, int cout, const float* __restrict__ bias,
                                                         float* __restrict__ Y, int swizzle,
                                                         float* __restrict__ stats, const int* __restrict__ x_amax,
-                                                        const int* __restrict__ w_amax, unsigned x_bytes, ConvEpi epi,
-                                                        ConvBnBwd bb) {
+                                                        const int* __restrict__ w_amax, unsigned x_bytes, ConvEpi epi) {
   constexpr int NPL = Prec<PL>::planes;
   constexpr int BLK = NB * 2 * NPL * 64;                // uint4 per (k, cc) weight block of this workgroup
   constexpr int BREG = (BLK + 255) / 256;
@@ -828,7 +774,7 @@ __global__ void __launch_bounds__(256, GCL_FWD_MIN_WAVES(NB, PL)) k_conv_fwd_spl
     o[0] = wg_t0; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = wg_steps; o[3] = __builtin_amdgcn_s_memtime() - wg_c0;
   }
 #endif
-  conv_fwd_epilogue<NB, EPI>(acc, &Asm[0][0][0], order, n_out, cout, bias, Y, stats, out_scale, epi, tile, bxx, nb0, active, bb);
+  conv_fwd_epilogue<NB, EPI>(acc, &Asm[0][0][0], order, n_out, cout, bias, Y, stats, out_scale, epi, tile, bxx, nb0, active);
 }
 
 // One LDS-DMA piece: every lane fetches 16 bytes at byte offset (voff + soff) of the buffer `rsrc` (beyond num_records: zeros)
@@ -881,7 +827,7 @@ __global__ void __launch_bounds__(256, (NB <= 2 ? 4 : 2)) k_conv_fwd_dma(const f
                                                         float* __restrict__ Y, int swizzle,
                                                         float* __restrict__ stats, const int* __restrict__ x_amax,
                                                         const int* __restrict__ w_amax, unsigned x_bytes, unsigned w_bytes,
-                                                        ConvEpi epi, ConvBnBwd bb) {
+                                                        ConvEpi epi) {
   constexpr int PL = 4, NPL = 2;
   constexpr int BLK = NB * 2 * NPL * 64;                // uint4 per (k, cc) weight block of this workgroup = NB x 4 KB
   constexpr int ISM_H = 15;
@@ -1075,7 +1021,7 @@ __global__ void __launch_bounds__(256, (NB <= 2 ? 4 : 2)) k_conv_fwd_dma(const f
 #undef GCL_DMA_A
 #undef GCL_DMA_B
 #undef GCL_ADVANCE
-  conv_fwd_epilogue<NB, EPI>(acc, &Asm[0][0][0], order, n_out, cout, bias, Y, stats, out_scale, epi, tile, bxx, nb0, active, bb);
+  conv_fwd_epilogue<NB, EPI>(acc, &Asm[0][0][0], order, n_out, cout, bias, Y, stats, out_scale, epi, tile, bxx, nb0, active);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2229,41 +2175,13 @@ int gcl_conv_fwd(const float* x, int64_t n_in, int32_t x_is_planes, const void* 
                             bias, nullptr, nullptr, 0, nullptr, y, stats, flags, stream);
 }
 
-static int conv_fwd_impl(const float* x, int64_t n_in, int32_t x_is_planes, const void* wp, int32_t prec,
-                         const int32_t* x_amax, const int32_t* w_amax, const int32_t* tbl, const int32_t* order,
-                         const int32_t* tile_mask, int64_t n_out, int32_t K, int32_t cin, int32_t cout, const float* bias,
-                         const float* col_scale, const float* residual, int32_t relu, int32_t* y_amax, float* y,
-                         float* stats, int32_t flags, void* stream, const ConvBnBwd& bb);
-
 int gcl_conv_fwd_fused(const float* x, int64_t n_in, int32_t x_is_planes, const void* wp, int32_t prec,
                        const int32_t* x_amax, const int32_t* w_amax, const int32_t* tbl, const int32_t* order,
                        const int32_t* tile_mask, int64_t n_out, int32_t K, int32_t cin, int32_t cout, const float* bias,
                        const float* col_scale, const float* residual, int32_t relu, int32_t* y_amax, float* y,
                        float* stats, int32_t flags, void* stream) {
-  return conv_fwd_impl(x, n_in, x_is_planes, wp, prec, x_amax, w_amax, tbl, order, tile_mask, n_out, K, cin, cout, bias,
-                       col_scale, residual, relu, y_amax, y, stats, flags, stream, ConvBnBwd{nullptr, nullptr, nullptr, nullptr, 0});
-}
-
-int gcl_conv_fwd_bnbwd(const float* x, int64_t n_in, int32_t x_is_planes, const void* wp, const int32_t* x_amax,
-                       const int32_t* w_amax, const int32_t* tbl, const int32_t* order, const int32_t* tile_mask,
-                       int64_t n_out, int32_t K, int32_t cin, int32_t cout, const float* residual, int32_t* y_amax, float* y,
-                       const float* bn_x, const uint64_t* bn_mask, const float* bn_mean, const float* bn_rstd,
-                       int32_t bn_relu, float* partials, int32_t flags, void* stream) {
-  GCL_CHECK_ARG(bn_x && bn_mean && bn_rstd && partials && (!bn_relu || bn_mask), "gcl_conv_fwd_bnbwd: null pointer");
-  GCL_CHECK_ARG(!generic_shape(K, cin, cout) && cout % 4 == 0, "gcl_conv_fwd_bnbwd: MFMA-shaped launches only (Cin, Cout multiples of 32, K <= 27)");
-  GCL_CHECK_ARG(!(flags & GCL_CONV_TALL), "gcl_conv_fwd_bnbwd: not an inference launch");
-  return conv_fwd_impl(x, n_in, x_is_planes, wp, 4, x_amax, w_amax, tbl, order, tile_mask, n_out, K, cin, cout, nullptr,
-                       nullptr, residual, 0, y_amax, y, partials, flags, stream,
-                       ConvBnBwd{bn_x, (const unsigned long long*)bn_mask, bn_mean, bn_rstd, bn_relu});
-}
-
-static int conv_fwd_impl(const float* x, int64_t n_in, int32_t x_is_planes, const void* wp, int32_t prec,
-                         const int32_t* x_amax, const int32_t* w_amax, const int32_t* tbl, const int32_t* order,
-                         const int32_t* tile_mask, int64_t n_out, int32_t K, int32_t cin, int32_t cout, const float* bias,
-                         const float* col_scale, const float* residual, int32_t relu, int32_t* y_amax, float* y,
-                         float* stats, int32_t flags, void* stream, const ConvBnBwd& bb) {
   const ConvEpi epi{col_scale, residual, relu, y_amax};
-  const bool use_epi = col_scale || residual || relu || y_amax || bb.xc;
+  const bool use_epi = col_scale || residual || relu || y_amax;
   GCL_CHECK_ARG(prec != 0 || generic_shape(K, cin, cout) || (!col_scale && !residual && !relu && !y_amax),
                 "gcl_conv_fwd_fused: the fused epilogue needs a split-precision mode");
   GCL_CHECK_ARG(x && wp && y, "gcl_conv_fwd: null pointer");
@@ -2315,7 +2233,7 @@ static int conv_fwd_impl(const float* x, int64_t n_in, int32_t x_is_planes, cons
 #define LAUNCH_SPLIT_I(NBV, PLV, PREV, EPIV)                                                                     \
   hipLaunchKernelGGL((k_conv_fwd_split<NBV, PLV, PREV, EPIV>), sgrid, dim3(256), 0, st, x, (const u32x4*)wp, tbl, \
                      order, tile_mask, (long long)n_out, K, cin, cout, bias, y, sswz, stats, x_amax, w_amax,   \
-                     x_bytes, epi, bb)
+                     x_bytes, epi)
 #define LAUNCH_SPLIT(NBV, PLV)                                                                                   \
   do {                                                                                                           \
     if (PLV == 4 && x_is_planes) {                                                                               \
@@ -2339,7 +2257,7 @@ static int conv_fwd_impl(const float* x, int64_t n_in, int32_t x_is_planes, cons
   // eval_pairs 146 -> 160 - 165 pairs/s.
   static const int tall = [] { const char* e = getenv("GCL_FWD_TALL"); return e ? atoi(e) : 1; }();
   static const int tall_min = [] { const char* e = getenv("GCL_FWD_TALL_MIN_STEPS"); return e ? atoi(e) : 108; }();
-  if (tall && (flags & GCL_CONV_TALL) && !bb.xc && prec == 4 && !x_is_planes && !stats && tbl && tile_mask && K >= 8 &&
+  if (tall && (flags & GCL_CONV_TALL) && prec == 4 && !x_is_planes && !stats && tbl && tile_mask && K >= 8 &&
       K * (cin / 32) >= tall_min && cout % 64 == 0 && colgroup && !swz && !ranges) {
     const dim3 tgrid((unsigned)(cdiv(gx, 8) * 8 * (cout / 64)));
     const int tswz = 2 | (heavy_first ? 16 : 0);
@@ -2362,7 +2280,7 @@ static int conv_fwd_impl(const float* x, int64_t n_in, int32_t x_is_planes, cons
     const unsigned w_bytes = (unsigned)((long long)K * cin * cout * 4);
 #define LAUNCH_DMA(NBV, PREV, EPIV)                                                                               \
   hipLaunchKernelGGL((k_conv_fwd_dma<NBV, PREV, EPIV>), sgrid, dim3(256), 0, st, x, (const u32x4*)wp, tbl, order,  \
-                     tile_mask, (long long)n_out, K, cin, cout, bias, y, sswz, stats, x_amax, w_amax, x_bytes, w_bytes, epi, bb)
+                     tile_mask, (long long)n_out, K, cin, cout, bias, y, sswz, stats, x_amax, w_amax, x_bytes, w_bytes, epi)
 #define LAUNCH_DMA_P(NBV)                                                                                         \
   do {                                                                                                            \
     if (x_is_planes) { if (use_epi) LAUNCH_DMA(NBV, true, true); else LAUNCH_DMA(NBV, true, false); }             \

@@ -194,11 +194,9 @@ __global__ void __launch_bounds__(256) k_bn_stats_final(const double* __restrict
 // are then added in order (deterministic).  Used when there are at most BN_DIRECT_MAX partials (a 0.5 M-voxel level has
 // ~4 k); beyond that the two-stage path below keeps the per-thread chains short.
 constexpr int BN_DIRECT_MAX = 16384;
-// sums_only (gcl_bn_bwd_from_partials): the two ordered column sums are the result (sum g', sum g' xhat of the BatchNorm
-// backward pass, accumulated by the input-gradient launch that produced g) and go to mean[] / rstd[] as they are.
 __global__ void __launch_bounds__(1024) k_bn_stats_direct(const float* __restrict__ partial, int n_part, long long n, int c,
                                                           float eps, float momentum, float* running_mean,
-                                                          float* running_var, float* mean, float* rstd, int sums_only) {
+                                                          float* running_var, float* mean, float* rstd) {
   __shared__ double red[2][256][5];
   __shared__ double red2[2][16][5];
   const int cl = threadIdx.x & 3, sl = threadIdx.x >> 2;
@@ -241,11 +239,6 @@ __global__ void __launch_bounds__(1024) k_bn_stats_direct(const float* __restric
   for (int q = 0; q < 16; ++q) {
     s += red2[0][q][cl];
     ss += red2[1][q][cl];
-  }
-  if (sums_only) {
-    mean[ch] = (float)s;
-    rstd[ch] = (float)ss;
-    return;
   }
   double m = s / (double)n;
   double var = ss / (double)n - m * m;
@@ -567,7 +560,7 @@ int gcl_bn_stats_from_tiles(const float* partial, int64_t n_tiles, int64_t n, in
   hipStream_t st = (hipStream_t)stream;
   if (n_tiles <= BN_DIRECT_MAX) {
     hipLaunchKernelGGL(k_bn_stats_direct, dim3((unsigned)cdiv(c, 4)), dim3(1024), 0, st, partial, (int)n_tiles,
-                       (long long)n, c, eps, momentum, running_mean, running_var, mean, rstd, 0);
+                       (long long)n, c, eps, momentum, running_mean, running_var, mean, rstd);
     GCL_CHECK_LAUNCH();
     return GCL_OK;
   }
@@ -612,17 +605,6 @@ int gcl_bn_bwd_reduce(const float* x, const float* dy, const float* y, const uin
                      (const unsigned long long*)relu_mask, rows, scratch);
   hipLaunchKernelGGL(k_bn_bwd_final, dim3((unsigned)cdiv(c, 4)), dim3(256), 0, st, (const double*)scratch, nwg, c,
                      sum_g, sum_gx);
-  GCL_CHECK_LAUNCH();
-  return GCL_OK;
-}
-
-int64_t gcl_bn_bwd_partials_max(void) { return BN_DIRECT_MAX; }
-
-int gcl_bn_bwd_from_partials(const float* partials, int64_t n_part, int32_t c, float* sum_g, float* sum_gx, void* stream) {
-  GCL_CHECK_ARG(partials && sum_g && sum_gx, "gcl_bn_bwd_from_partials: null pointer");
-  GCL_CHECK_ARG(n_part > 0 && n_part <= BN_DIRECT_MAX && c > 0, "gcl_bn_bwd_from_partials: 1 .. %d partials", BN_DIRECT_MAX);
-  hipLaunchKernelGGL(k_bn_stats_direct, dim3((unsigned)cdiv(c, 4)), dim3(1024), 0, (hipStream_t)stream, partials, (int)n_part,
-                     1ll, c, 0.f, 0.f, (float*)nullptr, (float*)nullptr, sum_g, sum_gx, 1);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }

@@ -334,8 +334,6 @@ struct OpSaved {           // what the backward pass of a record needs from its 
   float *mean = nullptr, *rstd = nullptr;
   int32_t* x_amax = nullptr;
   float* norm = nullptr;                // ROWNORM
-  float* bwd_partials = nullptr;        // CONVBN, backward: per-workgroup sums of g' and g' xhat written by the input-gradient
-                                        // launch that produced this record's output gradient (gcl_conv_fwd_bnbwd)
 };
 
 struct ProfRec {
@@ -374,8 +372,6 @@ struct Plan : PassState {   // the base part is the pass being enqueued right no
   long long bytes_fwd = 0, bytes_bwd = 0, wgs_fwd = 0, wgs_bwd = 0;
   int n_bwd = 0;
   std::vector<char> made;           // tensor id -> produced by a record of the plan
-  std::vector<int> producer;        // tensor id -> record that writes it (-1: the input)
-  std::vector<int> first_consumer;  // tensor id -> lowest record that reads it (the LAST one the backward pass visits)
   // device tables (inside the caller's `state` buffer), re-uploaded when a parameter pointer changes
   std::vector<long long> host_tables, uploaded;
   // inference passes (gcl_plan_forward_eval): BatchNorm in eval mode folded into the convolution epilogue
@@ -798,24 +794,9 @@ static int conv_backward(Plan& P, int i, TState dy, void* const* grads, hipStrea
     const bool pl = pl_x;
     float* acc = P.g[op.x].ptr;       // a gradient that already reached x through another path: added in the epilogue
     float* dx = A.take_n<float>(n_in * op.cin);
-    // x is the output of a conv + BatchNorm record and this record is the last one the backward pass visits among its
-    // readers: dx (with `acc` added) IS that record's output gradient, and the launch leaves the BatchNorm-backward sums
-    // of it as per-workgroup partials -- the record's gcl_bn_bwd_reduce pass over (conv_out, g) is not needed
-    static const int bn_fuse = [] { const char* e = getenv("GCL_BN_BWD_FUSE"); return e ? atoi(e) : 1; }();
-    const int prod = P.producer[op.x];
-    const bool fuse_struct = bn_fuse && prod >= 0 && P.ops[prod].kind == GCL_OP_CONVBN && P.first_consumer[op.x] == i;
-    float* partials = fuse_struct ? A.take_n<float>(cdiv(n_in, 128) * 2 * op.cin) : nullptr;
-    const bool fuse = fuse_struct && cdiv(n_in, 128) <= gcl_bn_bwd_partials_max();
     {
-      ProfScope ps(P, st, (acc || fuse) ? 1 : 0, pairs, op.cout, op.cin, n_out, n_in, op.K);
-      if (fuse) {
-        const OpSaved& pv = P.saved[prod];
-        PLAN_CALL(gcl_conv_fwd_bnbwd(pl ? (const float*)dy.planes : dy.ptr, n_out, pl ? 1 : 0, P.pack_bwd + P.off_bwd[wi],
-                                     dy.amax, w_amax, tbl, order, mask, n_in, op.K, op.cout, op.cin, acc, nullptr, dx,
-                                     pv.conv_out, (const uint64_t*)pv.mask, pv.mean, pv.rstd, P.ops[prod].relu, partials, 0,
-                                     (void*)st));
-        P.saved[prod].bwd_partials = partials;
-      } else if (acc)
+      ProfScope ps(P, st, acc ? 1 : 0, pairs, op.cout, op.cin, n_out, n_in, op.K);
+      if (acc)
         PLAN_CALL(gcl_conv_fwd_fused(pl ? (const float*)dy.planes : dy.ptr, n_out, pl ? 1 : 0, P.pack_bwd + P.off_bwd[wi], 4,
                                      dy.amax, w_amax, tbl, order, mask, n_in, op.K, op.cout, op.cin, nullptr, nullptr, acc, 0,
                                      nullptr, dx, nullptr, 0, (void*)st));
@@ -881,11 +862,8 @@ static int plan_backward(Plan& P, const float* dy, void* const* grads, int first
         float* sum_g = (float*)grads[op.bn_b];
         float* sum_gx = (float*)grads[op.bn_w];
         double* scratch = A.take_n<double>(gcl_bn_scratch_len(n_out, c));
-        if (sv.bwd_partials)       // the input-gradient launch that wrote g left the sums (conv_backward)
-          PLAN_CALL(gcl_bn_bwd_from_partials(sv.bwd_partials, cdiv(n_out, 128), c, sum_g, sum_gx, (void*)st));
-        else
-          PLAN_CALL(gcl_bn_bwd_reduce(sv.conv_out, g.ptr, nullptr, (const uint64_t*)sv.mask, n_out, c, sv.mean, sv.rstd,
-                                      op.relu, scratch, sum_g, sum_gx, (void*)st));
+        PLAN_CALL(gcl_bn_bwd_reduce(sv.conv_out, g.ptr, nullptr, (const uint64_t*)sv.mask, n_out, c, sv.mean, sv.rstd, op.relu,
+                                    scratch, sum_g, sum_gx, (void*)st));
         TState d;
         d.ptr = A.take_n<float>(n_out * c);
         d.amax = new_slot(P);
@@ -1006,8 +984,6 @@ void* gcl_plan_create(const gcl_plan_op* ops_host, int32_t n_ops, int32_t n_tens
   P->worder.assign(weight_order_host, weight_order_host + n_weights);
   P->widx.assign(n_params, -1);
   P->made.assign(n_tensors, 0);
-  P->producer.assign(n_tensors, -1);
-  P->first_consumer.assign(n_tensors, -1);
   const size_t nw = (size_t)n_weights;
   P->wmode.assign(nw, 0);
   P->wK.assign(nw, 0);
@@ -1063,9 +1039,6 @@ void* gcl_plan_create(const gcl_plan_op* ops_host, int32_t n_ops, int32_t n_tens
       ok = false;
     }
     P->made[op.y] = 1;
-    P->producer[op.y] = i;
-    if (P->first_consumer[op.x] < 0) P->first_consumer[op.x] = i;
-    if (op.x2 >= 0 && P->first_consumer[op.x2] < 0) P->first_consumer[op.x2] = i;
   }
   if (!ok) {
     set_error("gcl_plan_create: malformed or unsupported operator records");

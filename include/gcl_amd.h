@@ -249,22 +249,6 @@ int gcl_conv_fwd_fused(const float* x, int64_t n_in, int32_t x_is_planes, const 
                        const float* col_scale, const float* residual, int32_t relu, int32_t* y_amax, float* y,
                        float* stats, int32_t flags, void* stream);
 
-/* gcl_conv_fwd_fused as the INPUT-GRADIENT launch that produces g = dL/dy of a conv + BatchNorm (+ ReLU) record (fp16x3,
- * MFMA shapes): y = conv (+ residual: a gradient that reached the tensor through another path), and -- instead of the
- * column sums of y -- partials[(n_out + 127) / 128][2][cout] receive the per-workgroup sums of g' and g' xhat, where
- * g' = g masked by the record's ReLU sign bits (bn_mask, gcl_bn_apply's layout; bn_relu = 0: g' = g) and
- * xhat = (bn_x - bn_mean) bn_rstd with bn_x the record's convolution output.  gcl_bn_bwd_from_partials adds them up in a
- * fixed order (deterministic) into sum_g / sum_gx, which replaces gcl_bn_bwd_reduce's pass over bn_x and g
- * (model/residual_block.py:37-53 backward: the BatchNorm-parameter gradients and the two batch terms of dL/dx).
- * At most gcl_bn_bwd_partials_max() partials (n_out <= 128 x that). */
-int gcl_conv_fwd_bnbwd(const float* x, int64_t n_in, int32_t x_is_planes, const void* wp, const int32_t* x_amax,
-                       const int32_t* w_amax, const int32_t* tbl, const int32_t* order, const int32_t* tile_mask,
-                       int64_t n_out, int32_t K, int32_t cin, int32_t cout, const float* residual, int32_t* y_amax, float* y,
-                       const float* bn_x, const uint64_t* bn_mask, const float* bn_mean, const float* bn_rstd,
-                       int32_t bn_relu, float* partials, int32_t flags, void* stream);
-int64_t gcl_bn_bwd_partials_max(void);
-int gcl_bn_bwd_from_partials(const float* partials, int64_t n_part, int32_t c, float* sum_g, float* sum_gx, void* stream);
-
 /* dW[k] = sum over pairs of offset k of  A[pair_a]^T . B[pair_b]   (A: [*, ca], B: [*, cb]) -> dw [K, ca, cb].
  * Forward conv: A = X, pair_a = pair_in, B = dY, pair_b = pair_out.  Transposed conv: roles swapped.
  * Deterministic: per-wave partial slabs + ordered reduction.  prec as in gcl_conv_fwd (both operands are split

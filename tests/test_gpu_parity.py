@@ -397,80 +397,6 @@ def test_lds_dma_forward_kernel_is_bitwise_the_register_staged_kernel(cin, cout,
         assert rel_l2(out[(2, False)][0].cpu(), yo) < 2e-6
 
 
-@pytest.mark.parametrize("cin,cout,n,relu,use_planes,with_acc", [(64, 64, 3000, 1, False, True), (128, 128, 2000, 1, True, False),
-                                                                 (32, 64, 900, 0, False, False), (256, 128, 700, 1, True, True),
-                                                                 (64, 32, 130, 1, False, True), (128, 256, 1, 1, True, False)])
-def test_input_gradient_launch_with_batchnorm_backward_sums(cin, cout, n, relu, use_planes, with_acc):
-    """gcl_conv_fwd_bnbwd: the input-gradient launch that writes g = dL/dy of a conv + BatchNorm (+ ReLU) record also leaves
-    the per-workgroup sums of g' and g' xhat.  y is bitwise the launch's ordinary result (with and without a waiting gradient
-    added in the epilogue); gcl_bn_bwd_from_partials gives the sums gcl_bn_bwd_reduce computes from (conv_out, g) in a pass
-    of its own -- against each other and against an fp64 evaluation; repeatable bit for bit."""
-    from gcl_amd import _lib
-    import gcl_amd.MinkowskiEngine as ME
-    lib = _lib.load()
-    C = random_cloud(cin + n, n=n, extent=14, batch=1) if n > 1 else np.zeros((1, 4), np.int32)
-    mgr = make_mgr(C)
-    km = mgr.get_kernel_map(1, 3, 1)
-    tbl, order, mask = km.sorted_table()
-    n_out, K = len(C), 27
-    g = torch.Generator().manual_seed(n)
-    with torch.cuda.device(DEV):
-        x = torch.randn(n_out, cin, generator=g).to(DEV)
-        W = (0.1 * torch.randn(K, cin, cout, generator=g)).to(DEV)
-        acc = torch.randn(n_out, cout, generator=g).to(DEV) if with_acc else None
-        conv_out = (2.0 * torch.randn(n_out, cout, generator=g) + 0.5).to(DEV)        # what the record's BatchNorm normalised
-        mean, var = conv_out.mean(0).contiguous(), conv_out.var(0, unbiased=False)
-        rstd = torch.rsqrt(var + 1e-5).contiguous()
-        yfwd = torch.randn(n_out, cout, generator=g).to(DEV)                           # the record's output: sign -> mask
-        bmask = torch.zeros(lib.gcl_bn_mask_len(n_out, cout), dtype=torch.int64, device=DEV)
-        ones = torch.ones(cout, device=DEV)
-        zeros = torch.zeros(cout, device=DEV)
-        tmp = torch.empty_like(yfwd)
-        # mask written by the kernel that writes it in production: y = relu(1 * (x - 0) * 1 + 0) with x = yfwd
-        _lib.check(lib.gcl_bn_apply(_lib.ptr(yfwd), n_out, cout, _lib.ptr(zeros), _lib.ptr(ones), _lib.ptr(ones), _lib.ptr(zeros),
-                                    None, 1, _lib.ptr(tmp), _lib.ptr(bmask), None, _lib.stream()), "gcl_bn_apply")
-        xa, wa = ME.ops.amax_slot(x.device), ME.ops.amax_slot(x.device)
-        _lib.check(lib.gcl_amax(_lib.ptr(x), x.numel(), _lib.ptr(xa), 1, _lib.stream()), "gcl_amax")
-        _lib.check(lib.gcl_amax(_lib.ptr(W), W.numel(), _lib.ptr(wa), 1, _lib.stream()), "gcl_amax")
-        planes = torch.empty((n_out, cin), dtype=torch.int32, device=DEV)
-        _lib.check(lib.gcl_split_planes(_lib.ptr(x), n_out, cin, _lib.ptr(xa), _lib.ptr(planes), _lib.stream()), "split")
-        wp = torch.empty(lib.gcl_pack_weights_bytes(K, cin, cout, 4), dtype=torch.uint8, device=DEV)
-        _lib.check(lib.gcl_pack_weights(_lib.ptr(W), K, cin, cout, 0, 4, _lib.ptr(wa), _lib.ptr(wp), _lib.stream()), "pack")
-        xin = planes if use_planes else x
-        y_ref = torch.full((n_out, cout), float("nan"), device=DEV)
-        _lib.check(lib.gcl_conv_fwd_fused(_lib.ptr(xin), n_out, int(use_planes), _lib.ptr(wp), 4, _lib.ptr(xa), _lib.ptr(wa),
-                                          _lib.ptr(tbl), _lib.ptr(order), _lib.ptr(mask), n_out, K, cin, cout, None, None,
-                                          _lib.ptr(acc), 0, None, _lib.ptr(y_ref), None, 0, _lib.stream()), "gcl_conv_fwd_fused")
-        runs = []
-        for _ in range(2):
-            y = torch.full((n_out, cout), float("nan"), device=DEV)
-            part = torch.full(((n_out + 127) // 128, 2, cout), float("nan"), device=DEV)
-            _lib.check(lib.gcl_conv_fwd_bnbwd(_lib.ptr(xin), n_out, int(use_planes), _lib.ptr(wp), _lib.ptr(xa), _lib.ptr(wa),
-                                              _lib.ptr(tbl), _lib.ptr(order), _lib.ptr(mask), n_out, K, cin, cout, _lib.ptr(acc),
-                                              None, _lib.ptr(y), _lib.ptr(conv_out), _lib.ptr(bmask) if relu else None,
-                                              _lib.ptr(mean), _lib.ptr(rstd), relu, _lib.ptr(part), 0, _lib.stream()),
-                       "gcl_conv_fwd_bnbwd")
-            sums = torch.empty(2, cout, device=DEV)
-            _lib.check(lib.gcl_bn_bwd_from_partials(_lib.ptr(part), part.shape[0], cout, _lib.ptr(sums[0]), _lib.ptr(sums[1]),
-                                                    _lib.stream()), "gcl_bn_bwd_from_partials")
-            runs.append((y, part, sums))
-        assert torch.equal(runs[0][0], y_ref) and torch.isfinite(runs[0][1]).all()
-        assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
-        ref = torch.empty(2, cout, device=DEV)
-        scratch = torch.empty(lib.gcl_bn_scratch_len(n_out, cout), dtype=torch.float64, device=DEV)
-        _lib.check(lib.gcl_bn_bwd_reduce(_lib.ptr(conv_out), _lib.ptr(y_ref), None, _lib.ptr(bmask) if relu else None, n_out,
-                                         cout, _lib.ptr(mean), _lib.ptr(rstd), relu, _lib.ptr(scratch), _lib.ptr(ref[0]),
-                                         _lib.ptr(ref[1]), _lib.stream()), "gcl_bn_bwd_reduce")
-        gd = y_ref.double().cpu()
-        if relu:
-            gd = gd * (yfwd.cpu() > 0)
-        xh = (conv_out.double().cpu() - mean.double().cpu()) * rstd.double().cpu()
-        want = torch.stack([gd.sum(0), (gd * xh).sum(0)])
-        scale = float(want.abs().max())
-        assert float((runs[0][2].double().cpu() - want).abs().max()) < 2e-5 * max(scale, 1.0) * max(1.0, n_out ** 0.5 / 16)
-        assert float((ref.double().cpu() - want).abs().max()) < 2e-5 * max(scale, 1.0) * max(1.0, n_out ** 0.5 / 16)
-
-
 @pytest.mark.parametrize("cin,cout,stride,transpose", [(32, 32, 1, False), (64, 64, 1, False), (32, 64, 1, False),
                                                         (64, 32, 2, False), (64, 64, 2, True)])
 def test_weight_gradient_range_grouped_mode(cin, cout, stride, transpose):
