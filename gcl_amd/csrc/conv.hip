@@ -1622,255 +1622,6 @@ __global__ void __launch_bounds__(256) k_conv_bwd_weight_split(const float* __re
 #undef GCL_GATHER
 }
 
-// ---- weight gradient with LDS-DMA staging (round 4; fp16x3: plane images or fp32 rows) -------------------------------
-// k_conv_bwd_weight_split stages a chunk of 32 pairs per wave through 64 registers (the compiler parks them in AGPRs: 63
-// v_accvgpr_write per chunk) and 16 ds_write_b128, ~230 instructions for 24 MFMAs -- the launches are bound by instruction
-// issue (SQ: wait_inst 0.48 + active 0.29), not by bytes.  Here every operand row goes global -> LDS by DMA (dma16), the
-// pair indices too (4-byte pieces into a four-chunk ring the row addresses are then read from: no index registers, no
-// ds_bpermute), and a wave's tile is filled and consumed in two 16-pair HALVES: while one half's fragments feed 12 MFMAs the
-// other half and the next chunk's first half are in flight.  Wave-private as before (no workgroup barrier in the loop); the
-// wave counts its own DMAs: per chunk  H0: [rows(c+1, half 0), indices(c+3)]  H1: [rows(c+1, half 1)]  and waits
-// `vmcnt(NPH + 2)` in front of each half (NPH = row pieces per half; the indices are two pieces).  A segment (offset) ends
-// drained (`vmcnt(0)`), because the flush re-uses the tiles.  Same products in the same order as k_conv_bwd_weight_split:
-// bitwise the same slabs.
-__device__ __forceinline__ void dma4(const rsrc_words& rsrc, unsigned lds_base, unsigned voff) {     // 4 bytes per lane
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %1\n\t"
-      "s_nop 0\n\t"
-      "buffer_load_dword %2, %3, 0 offen lds\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "s"(lds_base), "v"(voff), "s"(rsrc)
-      : "memory");
-}
-template <int N>
-__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-template <int TCA, int TCB, bool PRE, bool RG>
-__global__ void __launch_bounds__(256) k_conv_bwd_weight_dma(const float* __restrict__ A, const float* __restrict__ B,
-                                                             const int* __restrict__ pair_a,
-                                                             const int* __restrict__ pair_b, SegOffW seg, int K,
-                                                             int ca, int cb, long long n_chunks, int per,
-                                                             float* slabs, const int* __restrict__ a_amax,
-                                                             const int* __restrict__ b_amax, int n_wg_x, int n_tiles,
-                                                             unsigned a_bytes, unsigned b_bytes,
-                                                             const int* __restrict__ bounds, int n_ranges) {
-  constexpr int PL = 4;
-  constexpr int NBI = TCA / 32, NBJ = TCB / 32;
-  constexpr int PA = TCA / 4, PB = TCB / 4;         // 16-byte pieces per row
-  constexpr int RA = 64 / PA, RB = 64 / PB;          // rows per 1 KB piece
-  constexpr int HPA = 16 / RA, HPB = 16 / RB;        // pieces per 16-pair half
-  constexpr int NPH = HPA + HPB;
-  const float sa = amax_scale(a_amax), sb = amax_scale(b_amax);
-  const float out_scale = 1.f / (sa * sb);
-  constexpr int TILE_FLOATS = 4 * 32 * (TCA + TCB);
-  __shared__ __attribute__((aligned(16))) float lds_all[TILE_FLOATS + 4 * 4 * 64];      // tiles + index ring [wave][4][64]
-  float (*As)[32][TCA] = reinterpret_cast<float (*)[32][TCA]>(lds_all);
-  float (*Bs)[32][TCB] = reinterpret_cast<float (*)[32][TCB]>(lds_all + 4 * 32 * TCA);
-  int (*Ix)[4][64] = reinterpret_cast<int (*)[4][64]>(lds_all + TILE_FLOATS);
-  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int i = l & 31, h = l >> 5;
-  unsigned char* const imgA = reinterpret_cast<unsigned char*>(&As[w][0][0]);
-  unsigned char* const imgB = reinterpret_cast<unsigned char*>(&Bs[w][0][0]);
-  const unsigned ldsA = __builtin_amdgcn_readfirstlane((unsigned)(size_t)imgA);
-  const unsigned ldsB = __builtin_amdgcn_readfirstlane((unsigned)(size_t)imgB);
-  const unsigned ldsI = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(&Ix[w][0][0]));
-  unsigned trA[NBI][2], trB[NBJ][2];
-  if (PRE) {
-    const unsigned la = (unsigned)(unsigned long long)((__attribute__((address_space(3))) unsigned char*)imgA);
-    const unsigned lb = (unsigned)(unsigned long long)((__attribute__((address_space(3))) unsigned char*)imgB);
-    const int q = (l & 15) >> 2, pp = l & 3, c16 = (l >> 4) & 1, trow = 8 * (l >> 5) + q;
-#pragma unroll
-    for (int a = 0; a < NBI; ++a)
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl)
-        trA[a][pl] = la + trow * (TCA * 4) + (((a * 4 + pl * 2 + c16) ^ tr_swz<TCA>(q)) * 32) + pp * 8;
-#pragma unroll
-    for (int b = 0; b < NBJ; ++b)
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl)
-        trB[b][pl] = lb + trow * (TCB * 4) + (((b * 4 + pl * 2 + c16) ^ tr_swz<TCB>(q)) * 32) + pp * 8;
-  }
-  int bx, by;
-  long long rg_lo = 0, rg_hi = 0;
-  int rg_k = 0;
-  if (RG) {
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    rg_k = slot % K;
-    const int j = (slot / K) * 8 + xcd;
-    if (j >= n_ranges) return;
-    rg_lo = bounds[rg_k * (n_ranges + 1) + j];
-    rg_hi = bounds[rg_k * (n_ranges + 1) + j + 1];
-    bx = j * K;
-    by = 0;
-  } else if (n_tiles > 0) {
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    by = slot % n_tiles;
-    bx = (slot / n_tiles) * 8 + xcd;
-    if (bx >= n_wg_x) return;
-  } else {
-    bx = blockIdx.x;
-    by = blockIdx.y;
-  }
-  const int tiles_b = cb / TCB;
-  const int ca0 = (by / tiles_b) * TCA, cb0 = (by % tiles_b) * TCB;
-  const long long c0 = RG ? 0 : (long long)bx * per;
-  const long long c1 = RG ? (rg_hi - rg_lo + GCL_PAIR_CHUNK - 1) / GCL_PAIR_CHUNK
-                          : ((c0 + per < n_chunks) ? c0 + per : n_chunks);
-  if (!RG && c0 >= c1) return;   // uniform over the workgroup (an empty RG cell still writes its zero slab)
-
-  f32x16 acc[NBI][NBJ];
-#pragma unroll
-  for (int a = 0; a < NBI; ++a)
-#pragma unroll
-    for (int b = 0; b < NBJ; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-  auto flush = [&](int k) {
-#pragma unroll
-    for (int a = 0; a < NBI; ++a)
-#pragma unroll
-      for (int b = 0; b < NBJ; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][b][r] *= out_scale;
-    bwd_weight_flush<TCA, TCB>(acc, lds_all, slabs + (long long)(bx + k) * ((long long)ca * cb), ca0, cb0, cb);
-  };
-
-  const rsrc_words arsrc = make_rsrc_words(A, a_bytes), brsrc = make_rsrc_words(B, b_bytes);
-  const unsigned list_bytes = (unsigned)(seg.off[K] * 4);
-  const rsrc_words pars = make_rsrc_words(pair_a, list_bytes), pbrs = make_rsrc_words(pair_b, list_bytes);
-  const unsigned a_row = (unsigned)ca * 4u, b_row = (unsigned)cb * 4u;
-  const unsigned a_soff = (unsigned)ca0 * 4u, b_soff = (unsigned)cb0 * 4u;
-  // position l % P of the lane's row holds source piece (PRE: 32-byte blocks XOR-swizzled with the row, as the transposed
-  // reads expect them; fp32 rows: linear); the lane's rows are l / P + R * ps (+ 16 for the second half)
-  unsigned pieceA[HPA * 2], pieceB[HPB * 2];
-#pragma unroll
-  for (int e = 0; e < HPA * 2; ++e) {
-    const int row = l / PA + RA * e, q = l % PA;
-    pieceA[e] = (unsigned)((PRE ? ((((q >> 1) ^ tr_swz<TCA>(row)) << 1) | (q & 1)) : q) * 16);
-  }
-#pragma unroll
-  for (int e = 0; e < HPB * 2; ++e) {
-    const int row = l / PB + RB * e, q = l % PB;
-    pieceB[e] = (unsigned)((PRE ? ((((q >> 1) ^ tr_swz<TCB>(row)) << 1) | (q & 1)) : q) * 16);
-  }
-  const long long list_base = RG ? rg_lo : 0;
-  const long long list_lim = RG ? rg_hi : (long long)seg.off[K];
-  // indices of chunk c: lanes 0 .. 31 fetch pair_a, the same lanes pair_b (second 128 bytes of the slot)
-  auto issue_idx = [&](long long c) {
-    const long long p = list_base + c * GCL_PAIR_CHUNK + w * 32 + l;
-    const unsigned off = (p < (long long)seg.off[K]) ? (unsigned)(p * 4) : 0xfffffff0u;      // beyond the list: zeros, never used
-    const unsigned dst = ldsI + (unsigned)((c & 3) * 256);
-    if (l < 32) {
-      dma4(pars, dst, off);
-      dma4(pbrs, dst + 128u, off);
-    }
-  };
-  // rows of one 16-pair half of chunk c (its indices are in the ring)
-#define GCL_ROW_A(HALF, PS)                                                                                    \
-  if constexpr (HPA > (PS)) {                                                                                  \
-    const int r_ = l / PA + RA * (PS);                                                                         \
-    int ridx = ix_[16 * (HALF) + r_];                                                                          \
-    if (RG && pos0_ + r_ >= list_lim) ridx = -1;                                                               \
-    dma16<(HALF)*16 * TCA * 4 + (PS)*1024>(arsrc, ldsA, (unsigned)ridx * a_row + pieceA[(HALF)*HPA + (PS)], a_soff); \
-  }
-#define GCL_ROW_B(HALF, PS)                                                                                    \
-  if constexpr (HPB > (PS)) {                                                                                  \
-    const int r_ = l / PB + RB * (PS);                                                                         \
-    int ridx = ix_[32 + 16 * (HALF) + r_];                                                                     \
-    if (RG && pos0_ + r_ >= list_lim) ridx = -1;                                                               \
-    dma16<(HALF)*16 * TCB * 4 + (PS)*1024>(brsrc, ldsB, (unsigned)ridx * b_row + pieceB[(HALF)*HPB + (PS)], b_soff); \
-  }
-#define GCL_ISSUE_ROWS(C, HALF)                                                                                \
-  {                                                                                                            \
-    const int* ix_ = &Ix[w][(C)&3][0];                                                                         \
-    const long long pos0_ = list_base + (C)*GCL_PAIR_CHUNK + w * 32 + 16 * (HALF);                              \
-    GCL_ROW_A(HALF, 0) GCL_ROW_A(HALF, 1) GCL_ROW_A(HALF, 2) GCL_ROW_A(HALF, 3)                                \
-    GCL_ROW_B(HALF, 0) GCL_ROW_B(HALF, 1) GCL_ROW_B(HALF, 2) GCL_ROW_B(HALF, 3)                                \
-  }
-  // fragments of one half -> registers (all LDS reads of the half complete), then `ISSUE`, then the half's MFMAs
-#define GCL_HALF(HALFV, ISSUE)                                                                                 \
-  {                                                                                                            \
-    u32x4 fa[NBI][2], fb[NBJ][2];                                                                              \
-    if (PRE) {                                                                                                 \
-      _Pragma("unroll") for (int a = 0; a < NBI; ++a) tr_fragment<TCA, HALFV>(trA[a][0], trA[a][1], fa[a]);    \
-      _Pragma("unroll") for (int b = 0; b < NBJ; ++b) tr_fragment<TCB, HALFV>(trB[b][0], trB[b][1], fb[b]);    \
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                       \
-    } else {                                                                                                   \
-      _Pragma("unroll") for (int a = 0; a < NBI; ++a) {                                                        \
-        float v[8];                                                                                            \
-        _Pragma("unroll") for (int jj = 0; jj < 8; ++jj) v[jj] = As[w][16 * HALFV + 8 * h + jj][a * 32 + i];   \
-        split8<PL>(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), sa, fa[a]);       \
-      }                                                                                                        \
-      _Pragma("unroll") for (int b = 0; b < NBJ; ++b) {                                                        \
-        float v[8];                                                                                            \
-        _Pragma("unroll") for (int jj = 0; jj < 8; ++jj) v[jj] = Bs[w][16 * HALFV + 8 * h + jj][b * 32 + i];   \
-        split8<PL>(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), sb, fb[b]);       \
-      }                                                                                                        \
-    }                                                                                                          \
-    _Pragma("unroll") for (int a = 0; a < NBI; ++a) {                                                          \
-      asm volatile("" : "+v"(fa[a][0]));                                                                       \
-      asm volatile("" : "+v"(fa[a][1]));                                                                       \
-    }                                                                                                          \
-    _Pragma("unroll") for (int b = 0; b < NBJ; ++b) {                                                          \
-      asm volatile("" : "+v"(fb[b][0]));                                                                       \
-      asm volatile("" : "+v"(fb[b][1]));                                                                       \
-    }                                                                                                          \
-    ISSUE;                                                                                                     \
-    _Pragma("unroll") for (int b = 0; b < NBJ; ++b)                                                            \
-      _Pragma("unroll") for (int a = 0; a < NBI; ++a) mfma_terms<PL>(fa[a], fb[b], acc[a][b]);                 \
-  }
-
-  int kcur = RG ? rg_k : 0;
-  if (!RG)
-    while (seg.off[kcur + 1] <= c0 * GCL_PAIR_CHUNK) ++kcur;
-  // every ordinary load of the prologue is consumed here (hipcc would otherwise put its vmcnt waits into the loop, where
-  // they also wait for the DMAs it does not see)
-  asm volatile("" ::"v"(sa), "v"(sb), "v"(out_scale) : "memory");
-  // (re)start of the pipeline at chunk s: its rows and, in between, the indices of s + 2 -- the order of a steady chunk
-#define GCL_START(S)            \
-  {                             \
-    GCL_ISSUE_ROWS(S, 0);       \
-    issue_idx((S) + 2);         \
-    GCL_ISSUE_ROWS(S, 1);       \
-  }
-  if (c0 < c1) {
-    issue_idx(c0);
-    issue_idx(c0 + 1);
-    dma_wait<0>();
-    GCL_START(c0);
-  }
-  for (long long c = c0; c < c1; ++c) {
-    // the next chunk continues this segment: its rows are requested while this chunk computes; otherwise the segment ends
-    // drained, is flushed (the flush re-uses the tiles), and the pipeline restarts
-    const bool next = (c + 1 < c1) && (RG || (c + 1) * GCL_PAIR_CHUNK < seg.off[kcur + 1]);
-    dma_wait<NPH + 2>();
-    if (next) {
-      GCL_HALF(0, { GCL_ISSUE_ROWS(c + 1, 0); issue_idx(c + 3); });
-      dma_wait<NPH + 2>();
-      GCL_HALF(1, { GCL_ISSUE_ROWS(c + 1, 1); });
-    } else {
-      GCL_HALF(0, { issue_idx(c + 3); });
-      dma_wait<0>();
-      GCL_HALF(1, {});
-      if (c + 1 < c1) {
-        flush(kcur);
-        while (seg.off[kcur + 1] <= (c + 1) * GCL_PAIR_CHUNK) ++kcur;
-        GCL_START(c + 1);
-      }
-    }
-  }
-  flush(kcur);
-#undef GCL_START
-#undef GCL_HALF
-#undef GCL_ISSUE_ROWS
-#undef GCL_ROW_A
-#undef GCL_ROW_B
-}
-
 __global__ void __launch_bounds__(256) k_bwd_weight_reduce(const float* __restrict__ slabs, SegOffW seg, int per,
                                                            long long mat, float* dw) {
   const int k = blockIdx.y;
@@ -2575,10 +2326,6 @@ int gcl_conv_bwd_weight(const float* a, int64_t n_a, const float* b, int64_t n_b
                         int32_t ca, int32_t cb, int32_t prec,
                         const int32_t* a_amax, const int32_t* b_amax, float* scratch, float* dw, void* stream) {
   GCL_CHECK_ARG(a && b && pair_a && pair_b && seg_off_host && scratch && dw, "gcl_conv_bwd_weight: null pointer");
-  // bit 1 of `planes` (GCL_DW_NO_DMA): the register-staged kernel for this launch; GCL_DW_DMA=0: for every launch
-  static const int dw_dma_env = [] { const char* e = getenv("GCL_DW_DMA"); return e ? atoi(e) : 1; }();
-  const bool dw_dma = dw_dma_env && !(planes & 2) && prec == 4;
-  planes &= 1;
   GCL_CHECK_ARG(K >= 1 && K <= 125, "gcl_conv_bwd_weight: bad K");
   GCL_CHECK_ARG(ca > 0 && cb > 0, "gcl_conv_bwd_weight: channel counts (%d, %d) must be positive", ca, cb);
   GCL_CHECK_ARG(prec_ok(prec), "gcl_conv_bwd_weight: prec must be 0, 2, 3 or 4");
@@ -2627,9 +2374,6 @@ int gcl_conv_bwd_weight(const float* a, int64_t n_a, const float* b, int64_t n_b
   {                                                                    \
     if (prec == 2) LAUNCH_RG(TA, TB, 2);                               \
     else if (prec == 3) LAUNCH_RG(TA, TB, 3);                          \
-    else if (dw_dma)                                                   \
-      hipLaunchKernelGGL((k_conv_bwd_weight_dma<TA, TB, false, true>), rgrid, dim3(256), 0, st, a, b, pair_a, pair_b, seg, K, \
-                         ca, cb, nc, per, scratch, a_amax, b_amax, 0, 0, a_bytes, b_bytes, (const int*)bounds, nr);   \
     else LAUNCH_RG(TA, TB, 4);                                         \
   }
     if (ca == 64 && cb == 64) LAUNCH_RG_P(64, 64)
@@ -2659,14 +2403,6 @@ int gcl_conv_bwd_weight(const float* a, int64_t n_a, const float* b, int64_t n_b
                          nc, per, scratch);                                                                        \
     else if (prec == 2) LAUNCH_BWS(TA, TB, 2);                                                                     \
     else if (prec == 3) LAUNCH_BWS(TA, TB, 3);                                                                     \
-    else if (dw_dma && planes)                                                                                     \
-      hipLaunchKernelGGL((k_conv_bwd_weight_dma<TA, TB, true, false>), sgrid, dim3(256), 0, st, a, b, pair_a, pair_b, \
-                         seg, K, ca, cb, nc, per, scratch, a_amax, b_amax, W, stiles, a_bytes, b_bytes,            \
-                         (const int*)nullptr, 0);                                                                  \
-    else if (dw_dma)                                                                                               \
-      hipLaunchKernelGGL((k_conv_bwd_weight_dma<TA, TB, false, false>), sgrid, dim3(256), 0, st, a, b, pair_a, pair_b, \
-                         seg, K, ca, cb, nc, per, scratch, a_amax, b_amax, W, stiles, a_bytes, b_bytes,            \
-                         (const int*)nullptr, 0);                                                                  \
     else if (planes)                                                                                               \
       hipLaunchKernelGGL((k_conv_bwd_weight_split<TA, TB, 4, true>), sgrid, dim3(256), 0, st, a, b, pair_a, pair_b, \
                          seg, K, ca, cb, nc, per, scratch, a_amax, b_amax, W, stiles, a_bytes, b_bytes);           \

@@ -432,58 +432,6 @@ def test_weight_gradient_range_grouped_mode(cin, cout, stride, transpose):
     assert rel_l2(grads[0].cpu(), W.grad) < 2e-6
 
 
-@pytest.mark.parametrize("ca,cb,n,stride,use_planes", [(64, 64, 60000, 1, False), (32, 32, 50000, 1, False), (64, 64, 4000, 1, False),
-                                                       (128, 128, 3000, 1, True), (256, 128, 1500, 1, True), (32, 64, 5000, 2, False),
-                                                       (64, 32, 300, 1, False), (128, 64, 900, 2, True), (64, 64, 1, 1, False),
-                                                       (96, 64, 700, 1, False), (128, 256, 40, 1, True)])
-def test_lds_dma_weight_gradient_is_bitwise_the_register_staged_kernel(ca, cb, n, stride, use_planes):
-    """k_conv_bwd_weight_dma (rows and pair indices staged by LDS-DMA, a wave's tile filled and consumed in 16-pair halves;
-    the default for fp16x3) against k_conv_bwd_weight_split (bit 1 of `planes`): the same products in the same order --
-    dW bitwise equal for plane images and fp32 rows, the k-major and the range-grouped launch (>= 32768 sorted rows),
-    multi-tile channel counts, ragged / single-pair lists; and against the fp64 product."""
-    from gcl_amd import _lib
-    import gcl_amd.MinkowskiEngine as ME
-    lib = _lib.load()
-    C = random_cloud(ca + n, n=n, extent=40 if n > 20000 else 14, batch=1, sheet=n <= 20000) if n > 1 else np.zeros((1, 4), np.int32)
-    mgr = make_mgr(C)
-    km = mgr.get_kernel_map(1, 3, stride)
-    pin, pout, seg, seg_host = km.pairs()
-    n_a, n_b = len(C), mgr.num_rows(stride)
-    K = 27
-    g = torch.Generator().manual_seed(n + ca)
-    with torch.cuda.device(DEV):
-        a = torch.randn(n_a, ca, generator=g).to(DEV)
-        b = torch.randn(n_b, cb, generator=g).to(DEV)
-        aa, ba = ME.ops.amax_slot(a.device), ME.ops.amax_slot(a.device)
-        _lib.check(lib.gcl_amax(_lib.ptr(a), a.numel(), _lib.ptr(aa), 1, _lib.stream()), "gcl_amax")
-        _lib.check(lib.gcl_amax(_lib.ptr(b), b.numel(), _lib.ptr(ba), 1, _lib.stream()), "gcl_amax")
-        xa, xb = a, b
-        if use_planes:
-            xa = torch.empty((n_a, ca), dtype=torch.int32, device=DEV)
-            xb = torch.empty((n_b, cb), dtype=torch.int32, device=DEV)
-            _lib.check(lib.gcl_split_planes(_lib.ptr(a), n_a, ca, _lib.ptr(aa), _lib.ptr(xa), _lib.stream()), "split")
-            _lib.check(lib.gcl_split_planes(_lib.ptr(b), n_b, cb, _lib.ptr(ba), _lib.ptr(xb), _lib.stream()), "split")
-        out = {}
-        for no_dma in (1, 0, 0):
-            scratch = torch.full((lib.gcl_conv_bwd_weight_scratch_len(K, ca, cb, seg[-1], n_b),), float("nan"), device=DEV)
-            dw = torch.full((K, ca, cb), float("nan"), device=DEV)
-            _lib.check(lib.gcl_conv_bwd_weight(_lib.ptr(xa), n_a, _lib.ptr(xb), n_b, int(use_planes) | (2 * no_dma), 2, _lib.ptr(pin),
-                                               _lib.ptr(pout), seg_host, K, ca, cb, 4, _lib.ptr(aa), _lib.ptr(ba),
-                                               _lib.ptr(scratch), _lib.ptr(dw), _lib.stream()), "gcl_conv_bwd_weight")
-            out.setdefault(no_dma, []).append(dw)
-        assert torch.isfinite(out[1][0]).all()
-        assert torch.equal(out[0][0], out[0][1]), "deterministic"
-        assert torch.equal(out[1][0], out[0][0])
-        src = km.nbr.cpu().numpy()
-        ad, bd = a.double().cpu(), b.double().cpu()
-        want = torch.zeros(K, ca, cb, dtype=torch.float64)
-        for k in range(K):
-            rows = np.nonzero(src[k] >= 0)[0]
-            if len(rows):
-                want[k] = ad[src[k][rows]].T @ bd[rows]
-        assert rel_l2(out[0][0].cpu(), want) < 2e-6
-
-
 # ---------------------------------------------------------------------------------------------------------------
 # batch norm (+ residual, + relu)
 # ---------------------------------------------------------------------------------------------------------------
