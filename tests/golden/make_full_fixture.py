@@ -2,7 +2,8 @@
 configs[2]: seed 100, bs 4 x 7 clouds, 530 321 voxels, groups fixed16) -- 4096 sampled feature rows, per-column sums
 of the features, and the loss triple for fixed draws.  Run in the build container (minutes of CPU, ~20 GB):
 
-    python tests/golden/make_full_fixture.py
+    python tests/golden/make_full_fixture.py              (forward fixture)
+    python tests/golden/make_full_fixture.py --backward   (full_bs4_backward.npz: one oracle training step's gradients)
 
 Inputs are re-created on the GPU box from the same seeds (gcl_amd.synthetic is deterministic numpy; the parameters are
 oracle.me_oracle.random_state(0)); only the expected outputs travel in the fixture.
@@ -30,7 +31,44 @@ def fixed_draws(n_groups, n_rows, max_pos=1024, max_hn=1024):
             rng.choice(n_rows, min(n_rows, max_hn), replace=False))
 
 
+def backward_fixture():
+    """tests/golden/full_bs4_backward.npz: ONE fp64 oracle training step's gradients on the same batch / parameters /
+    draws (reference step: lib/colocation_trainer.py:875-887, loss = pos + finest + neg, weights 1): per-parameter norm,
+    256 sampled entries per parameter tensor (all of it when smaller), column sums of dL/dF_out.  ~30 GB, tens of minutes."""
+    torch.set_num_threads(8)
+    t0 = time.time()
+    batch = synthetic.make_train_batch(SEED, batch_size=BS, group_mode=MODE)
+    C, F = batch["sinput_C"].numpy(), batch["sinput_F"].double()
+    st = me_oracle.random_state(0, dtype=torch.float64)
+    leaves = {k: v.clone().requires_grad_("running" not in k) for k, v in st.items()}
+    out = me_oracle.resunet_forward(leaves, C, F, 5, True, True, 0.05)
+    out.retain_grad()
+    print(f"oracle forward (autograd) done ({time.time() - t0:.0f} s)", flush=True)
+    draws = fixed_draws(len(batch["group"]), len(C))
+    pos, fin, neg = loss_oracle.finest_contrastive_loss(out, batch["group"].numpy(), batch["index"].numpy(),
+                                                        batch["index_hash"], batch["finest_flag"].numpy(), draws=draws,
+                                                        max_pos_cluster=1024, max_hn_samples=1024)
+    (pos + fin + neg).backward()
+    print(f"oracle backward done ({time.time() - t0:.0f} s)", flush=True)
+    rec = {"loss": np.array([pos.item(), fin.item(), neg.item()]), "dF_col_sum": out.grad.sum(0).numpy(),
+           "dF_col_abs_sum": out.grad.abs().sum(0).numpy(), "n_voxels": len(C)}
+    rng = np.random.RandomState(11)
+    names = [k for k, v in leaves.items() if v.requires_grad]
+    rec["names"] = np.array(names)
+    for j, k in enumerate(names):
+        g = leaves[k].grad.reshape(-1).numpy()
+        idx = np.sort(rng.choice(g.size, min(g.size, 256), replace=False))
+        rec[f"norm_{j}"] = np.float64(np.linalg.norm(g))
+        rec[f"idx_{j}"] = idx.astype(np.int64)
+        rec[f"val_{j}"] = g[idx].astype(np.float64)
+    path = os.path.join(ROOT, "tests", "golden", "full_bs4_backward.npz")
+    np.savez_compressed(path, **rec)
+    print(f"wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB) in {time.time() - t0:.0f} s", flush=True)
+
+
 def main():
+    if "--backward" in sys.argv:
+        return backward_fixture()
     torch.set_num_threads(8)
     t0 = time.time()
     batch = synthetic.make_train_batch(SEED, batch_size=BS, group_mode=MODE)

@@ -476,6 +476,56 @@ def test_full_size_batch_against_oracle_fixture():
     assert rel_l2(m.block4.norm2.bn.running_var.cpu(), z["running_var_block4"]) < 1e-4
 
 
+def test_full_size_training_step_gradients_against_oracle_fixture():
+    """tests/golden/full_bs4_backward.npz (make_full_fixture.py --backward: ONE fp64 oracle training step on the 530 321-voxel
+    benchmark batch -- loss = pos + finest + neg, lib/colocation_trainer.py:875-887): the gradients the trainer's
+    ``train_step`` leaves in its seats on the SECOND step, i.e. through the native plan with the weight gradients on the aux
+    stream and the range-grouped launches (>= 32768 rows) -- per-parameter norm and 256 sampled entries per tensor, and the
+    loss triple.  lr = 0, so both steps see the fixture's parameters."""
+    import gcl_amd.MinkowskiEngine as ME  # noqa: F401
+    from gcl_amd import synthetic
+    from gcl_amd.MinkowskiEngine import native
+    from gcl_amd.lib.colocation_trainer import FinestContrastiveLossTrainer, make_config
+    path = os.path.join(os.path.dirname(__file__), "golden", "full_bs4_backward.npz")
+    z = np.load(path)
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_full_fixture import BS, MODE, SEED, fixed_draws
+    batch = synthetic.make_train_batch(SEED, batch_size=BS, group_mode=MODE)
+    assert len(batch["sinput_C"]) == int(z["n_voxels"])
+    cfg = make_config(batch_size=BS, lr=0.0, momentum=0.0, weight_decay=0.0)
+    with torch.cuda.device(DEV):
+        tr = FinestContrastiveLossTrainer(cfg, device=torch.device(DEV))
+        st = O.random_state(0, dtype=torch.float32)
+        missing = tr.model.load_state_dict(st, strict=False)
+        assert not missing.unexpected_keys and all("num_batches" in k for k in missing.missing_keys)
+        draws = fixed_draws(len(batch["group"]), len(batch["sinput_C"]))
+        keys = ("sinput_C", "sinput_F", "group", "index", "finest_flag")
+        dev_batch = {k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in batch.items() if k in keys}
+        for step in range(2):          # step 0 is recorded by the Tape, step 1 runs through the plan
+            b = dict(dev_batch)       # native maps in both steps: the Tape pass on them is what records the plan
+            b["_coordinate_manager"] = ME.CoordinateManager.build_native(dev_batch["sinput_C"], tr.model.native_map_specs())
+            loss, (pos, fin, neg), n = tr.train_step(b, draws=draws)
+            torch.cuda.synchronize()
+            got = np.array([pos.item(), fin.item(), neg.item()])
+            assert np.allclose(got, z["loss"], rtol=2e-4, atol=2e-5), (step, got, z["loss"])
+        assert isinstance(tr.model.__dict__.get("_plan"), native.NetworkPlan)
+        assert native.AUX_STREAM and tr.model._plan._aux is not None, "the plan's second pass must have used the aux stream"
+        params = dict(tr.model.named_parameters())
+        worst = {}
+        for j, name in enumerate(z["names"]):
+            g = params[str(name)].grad.detach().double().cpu().reshape(-1).numpy()
+            ref_norm, idx, val = float(z[f"norm_{j}"]), z[f"idx_{j}"], z[f"val_{j}"]
+            e_norm = abs(np.linalg.norm(g) - ref_norm) / max(ref_norm, 1e-30)
+            e_val = np.linalg.norm(g[idx] - val) / max(np.linalg.norm(val), 1e-30)
+            worst[str(name)] = (e_norm, e_val)
+            # BatchNorm-parameter gradients are sums over all rows with heavy cancellation (tests/test_gpu_parity.py uses
+            # 1e-2 for them on small clouds); convolution kernels 2e-3 there -- at this size both are far tighter
+            bound = 2e-3 if ".bn." in str(name) else 5e-4
+            assert e_norm < bound and e_val < bound, (str(name), e_norm, e_val)
+        top = sorted(worst.items(), key=lambda kv: -max(kv[1]))[:3]
+        print("full-size backward: worst parameters (norm err, sampled-entry err):", top)
+
+
 def test_prefetch_staging_slots_are_reused_only_after_release():
     """prefetch_to_device: device staging slots are handed out again only after release_batch (an event on the compute
     stream the copy stream waits for); a consumer that never releases gets one slot per batch (the pool grows, a pending

@@ -39,6 +39,9 @@ with torch.cuda.device(dev):
         _lib.check(lib.gcl_split_planes(_lib.ptr(x), n_in, cin, _lib.ptr(xa), _lib.ptr(planes), _lib.stream()), "split")
         wp = torch.empty(lib.gcl_pack_weights_bytes(K, cin, cout, 4), dtype=torch.uint8, device=dev)
         _lib.check(lib.gcl_pack_weights(_lib.ptr(W), K, cin, cout, 0, 4, _lib.ptr(wa), _lib.ptr(wp), _lib.stream()), "pack")
+        if os.environ.get("LB_HOT_ROWS"):      # diagnostic: every gather hits the same few rows (L1 / L2 hot) -- same
+            hot = int(os.environ["LB_HOT_ROWS"])   # instruction stream, no fabric traffic for the A operand
+            tbl = torch.where(tbl >= 0, tbl % hot, tbl).contiguous()
         y = {f: torch.empty((n_out, cout), device=dev) for f in (8, 2)}
         stats = torch.empty(((n_out + 127) // 128, 2, cout), device=dev)
 
