@@ -453,9 +453,8 @@ template <int NB, bool EPI>
 __device__ __forceinline__ void conv_fwd_epilogue(f32x16 (&acc)[NB], float* tiles, const int* __restrict__ order,
                                                   long long n_out, int cout, const float* __restrict__ bias,
                                                   float* __restrict__ Y, float* __restrict__ stats, float out_scale,
-                                                  const ConvEpi& epi, long long tile, unsigned bxx, int nb0, bool active,
-                                                  int w) {      // w: the wave's row-tile slot 0 .. 3 among the four it adds up with
-  const int t = threadIdx.x, l = t & 63;
+                                                  const ConvEpi& epi, long long tile, unsigned bxx, int nb0, bool active) {
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
   const int i = l & 31, h = l >> 5;
   const long long row0 = tile * 32;
   if (!active && !stats) return;
@@ -775,7 +774,7 @@ __global__ void __launch_bounds__(256, GCL_FWD_MIN_WAVES(NB, PL)) k_conv_fwd_spl
     o[0] = wg_t0; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = wg_steps; o[3] = __builtin_amdgcn_s_memtime() - wg_c0;
   }
 #endif
-  conv_fwd_epilogue<NB, EPI>(acc, &Asm[0][0][0], order, n_out, cout, bias, Y, stats, out_scale, epi, tile, bxx, nb0, active, w);
+  conv_fwd_epilogue<NB, EPI>(acc, &Asm[0][0][0], order, n_out, cout, bias, Y, stats, out_scale, epi, tile, bxx, nb0, active);
 }
 
 // One LDS-DMA piece: every lane fetches 16 bytes at byte offset (voff + soff) of the buffer `rsrc` (beyond num_records: zeros)
@@ -1022,166 +1021,7 @@ __global__ void __launch_bounds__(256, (NB <= 2 ? 4 : 2)) k_conv_fwd_dma(const f
 #undef GCL_DMA_A
 #undef GCL_DMA_B
 #undef GCL_ADVANCE
-  conv_fwd_epilogue<NB, EPI>(acc, &Asm[0][0][0], order, n_out, cout, bias, Y, stats, out_scale, epi, tile, bxx, nb0, active, w);
-}
-
-// ---- EIGHT waves per workgroup on LDS-DMA staging: 128 rows x 128 output columns (Cout a multiple of 128) ---------------
-// k_conv_fwd_dma moves 24 KB per workgroup-step (four 4 KB A tiles + an 8 KB weight block) for 48 MFMAs, and with 16 waves
-// per CU that is what bounds it: 96 KB per ~1800 cycles = 53 of the 64 bytes per clock a CU's vector memory path takes in
-// -- the launches take the same time when every gather hits the same 64 L2-hot rows (profiles/r04_conv_experiments.txt, 25).
-// So the lever is bytes per MFMA THROUGH L1: here the four row tiles are shared by two waves each (wave = tile wt x column
-// half ch, 32 rows x 64 columns, the same registers as a k_conv_fwd_dma<2> wave) and the weight block is 128 columns wide:
-// 32 KB per step for 96 MFMAs (4 instead of 6 KB per wave-step), every wave issues two A pieces of its tile and two weight
-// pieces.  A tiles are double-buffered like the weight block (the partner wave may still be reading), so ALL DMAs of step
-// s+1 are issued right behind the barrier that opens step s.  71.5 + KB of LDS: two workgroups = 16 waves per CU as before.
-// Same products in the same order as k_conv_fwd_dma / k_conv_fwd_split: bitwise the same y and column sums.
-template <bool PRE, bool EPI>
-__global__ void __launch_bounds__(512, 4) k_conv_fwd_dma8(const float* __restrict__ X, const u32x4* __restrict__ Wp,
-                                                         const int* __restrict__ tbl, const int* __restrict__ order,
-                                                         const int* __restrict__ tile_mask, long long n_out, int K, int cin,
-                                                         int cout, const float* __restrict__ bias, float* __restrict__ Y,
-                                                         int swizzle, float* __restrict__ stats,
-                                                         const int* __restrict__ x_amax, const int* __restrict__ w_amax,
-                                                         unsigned x_bytes, unsigned w_bytes, ConvEpi epi) {
-  constexpr int PL = 4, NPL = 2, NB = 2, NBT = 4;
-  constexpr int BLK = NBT * 2 * NPL * 64;               // 1024 uint4 = 16 KB per (k, cc) weight block of the workgroup
-  const float a_scale = amax_scale(x_amax);
-  const float out_scale = 1.f / (a_scale * amax_scale(w_amax));
-  constexpr int A_BYTES = 2 * 4 * 32 * 32 * 4, B_BYTES = 2 * BLK * 16, I_BYTES = 4 * 27 * 32 * 4;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[A_BYTES + B_BYTES + I_BYTES + 16];
-  float (*Asm)[4][32][32] = reinterpret_cast<float (*)[4][32][32]>(smem);            // [buffer][tile][row][32 floats]
-  u32x4* const Bsm = reinterpret_cast<u32x4*>(smem + A_BYTES);                       // [2][BLK]
-  int (*Ism)[27][32] = reinterpret_cast<int (*)[27][32]>(smem + A_BYTES + B_BYTES);
-  unsigned* const wmask = reinterpret_cast<unsigned*>(smem + A_BYTES + B_BYTES + I_BYTES);
-  const int t = threadIdx.x, l = t & 63, w8 = t >> 6, wt = w8 & 3, ch = w8 >> 2;
-  const int i = l & 31, h = l >> 5;
-  unsigned bxx = blockIdx.x, byy;
-  const bool heavy_first = (swizzle & 16) != 0;
-  const unsigned nrw = (unsigned)((n_out + CONV_ROWS - 1) / CONV_ROWS);
-  {
-    const unsigned ncb = (unsigned)(cout / (32 * NBT));
-    const unsigned xcd = bxx & 7u, slot = bxx >> 3;
-    byy = slot % ncb;
-    bxx = (slot / ncb) * 8u + xcd;
-    if (bxx >= nrw) return;      // whole workgroup, before any barrier
-  }
-  if (heavy_first) bxx = nrw - 1u - bxx;
-  const long long tile = (long long)bxx * 4 + wt;
-  const long long row0 = tile * 32;
-  const bool active = row0 < n_out;
-  const int nbw = byy * NBT;                 // first 32-column block of the workgroup
-  const int nb0 = nbw + ch * NB;             // ... of this wave
-  const int TNB = cout >> 5, CC = cin >> 5;
-  const int p = l & 7, rsub = l >> 3;
-
-  f32x16 acc[NB];
-#pragma unroll
-  for (int b = 0; b < NB; ++b)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
-
-  unsigned mymask = 0u;
-  if (active) mymask = tile_mask ? (unsigned)tile_mask[tile] : ((K >= 32) ? ~0u : ((1u << K) - 1u));
-  mymask = __builtin_amdgcn_readfirstlane(mymask);
-  if (l == 0 && ch == 0) wmask[wt] = mymask;
-  for (int e = l + 64 * ch; e < K * 32; e += 128) {       // the tile's neighbour rows, the two waves of a tile half each
-    const int k = e >> 5, r = e & 31;
-    int v = -1;
-    if (active && ((mymask >> k) & 1u) && row0 + r < n_out) v = tbl ? tbl[(long long)k * n_out + row0 + r] : (int)(row0 + r);
-    Ism[wt][k][(r & 7) * 4 + (r >> 3)] = v;
-  }
-  __syncthreads();
-  const unsigned wgmask = __builtin_amdgcn_readfirstlane(wmask[0] | wmask[1] | wmask[2] | wmask[3]);
-
-  const rsrc_words xrsrc = make_rsrc_words(X, x_bytes), wrsrc = make_rsrc_words(Wp, w_bytes);
-  const unsigned row_bytes = (unsigned)cin * 4u;
-  const unsigned lds_a = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(&Asm[0][wt][16 * ch][0]));   // this wave's half of its tile
-  const unsigned lds_b = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(Bsm + w8 * 64));
-  const unsigned pc0 = (unsigned)((p ^ a_swz(rsub + 16 * ch)) << 4), pc1 = (unsigned)((p ^ a_swz(rsub + 16 * ch + 8)) << 4);
-  // wave (wt, ch) fetches rows 16 ch .. 16 ch + 15 of tile wt: two 1 KB pieces of 8 rows
-#define GCL8_DMA_A(KK, CCV, BUF)                                                                               \
-  {                                                                                                            \
-    const int4 ri_ = *reinterpret_cast<const int4*>(&Ism[wt][(KK)][rsub * 4]);                                 \
-    const unsigned co_ = (unsigned)(CCV)*128u;                                                                 \
-    const unsigned dst_ = lds_a + (unsigned)(BUF) * (unsigned)(4 * 32 * 32 * 4);                               \
-    dma16<0>(xrsrc, dst_, (unsigned)(ch ? ri_.z : ri_.x) * row_bytes + pc0, co_);                              \
-    dma16<1024>(xrsrc, dst_, (unsigned)(ch ? ri_.w : ri_.y) * row_bytes + pc1, co_);                           \
-  }
-#define GCL8_DMA_B(KK, CCV, BUF)                                                                               \
-  {                                                                                                            \
-    const unsigned blk_ = (unsigned)((((KK)*CC + (CCV)) * TNB + nbw) * (2 * NPL * 64)) * 16u;                   \
-    const unsigned dst_ = lds_b + (unsigned)(BUF) * (unsigned)(BLK * 16);                                      \
-    dma16<0>(wrsrc, dst_, (unsigned)t * 16u, blk_);                                                            \
-    dma16<8192>(wrsrc, dst_, (unsigned)t * 16u + 8192u, blk_);                                                 \
-  }
-  if (wgmask != 0u) {
-    unsigned m_rest = wgmask & (wgmask - 1);
-    int kc = __builtin_ctz(wgmask), cc = 0;
-    bool mine_cur = (mymask >> kc) & 1u;
-    if (mine_cur) GCL8_DMA_A(kc, 0, 0);
-    GCL8_DMA_B(kc, 0, 0);
-    int buf = 0;
-    while (true) {
-      dma_wait_all();       // this wave's DMAs have landed
-      __syncthreads();      // everybody's pieces of step s are in LDS; everybody's reads of step s-1 are done
-      int kn = kc, cn = cc;
-      bool hasn = true;
-      cn += 1;
-      if (cn == CC) {
-        cn = 0;
-        if (m_rest) {
-          kn = __builtin_ctz(m_rest);
-          m_rest &= m_rest - 1;
-        } else {
-          hasn = false;
-        }
-      }
-      const bool mine_n = hasn && ((mymask >> kn) & 1u);
-      if (hasn) {           // step s+1 -> the buffers step s-1 used
-        GCL8_DMA_B(kn, cn, buf ^ 1);
-        if (mine_n) GCL8_DMA_A(kn, cn, buf ^ 1);
-      }
-      if (mine_cur) {
-        u32x4 ap[2][2];
-        if (PRE) {
-#pragma unroll
-          for (int m = 0; m < 2; ++m) {
-            ap[m][0] = *reinterpret_cast<const u32x4*>(&Asm[buf][wt][i][((2 * m + h) ^ a_swz(i)) << 2]);
-            ap[m][1] = *reinterpret_cast<const u32x4*>(&Asm[buf][wt][i][((4 + 2 * m + h) ^ a_swz(i)) << 2]);
-          }
-        } else {
-#pragma unroll
-          for (int m = 0; m < 2; ++m) {
-            const float4 f0 = *reinterpret_cast<const float4*>(&Asm[buf][wt][i][((4 * m + 2 * h) ^ a_swz(i)) << 2]);
-            const float4 f1 = *reinterpret_cast<const float4*>(&Asm[buf][wt][i][((4 * m + 2 * h + 1) ^ a_swz(i)) << 2]);
-            split8<PL>(f0, f1, a_scale, ap[m]);
-          }
-        }
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-#pragma unroll
-          for (int b = 0; b < NB; ++b) {
-            const u32x4* bb = &Bsm[buf * BLK + (((ch * NB + b) * 2 + m) * NPL) * 64 + l];
-            u32x4 bp[2];
-            bp[0] = bb[0];
-            bp[1] = bb[64];
-            mfma_terms<PL>(ap[m], bp, acc[b]);
-          }
-        }
-      }
-      if (!hasn) break;
-      buf ^= 1;
-      kc = kn;
-      cc = cn;
-      mine_cur = mine_n;
-    }
-  }
-#undef GCL8_DMA_A
-#undef GCL8_DMA_B
-  __syncthreads();      // the A buffers become the epilogue's scratch: every wave is done reading them
-  // column sums: each column half adds its four row tiles in its own 16 KB of the (idle) A buffers
-  conv_fwd_epilogue<NB, EPI>(acc, &Asm[ch][0][0][0], order, n_out, cout, bias, Y, stats, out_scale, epi, tile, bxx, nb0, active,
-                             wt);
+  conv_fwd_epilogue<NB, EPI>(acc, &Asm[0][0][0], order, n_out, cout, bias, Y, stats, out_scale, epi, tile, bxx, nb0, active);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2438,21 +2278,6 @@ int gcl_conv_fwd_fused(const float* x, int64_t n_in, int32_t x_is_planes, const 
   static const int dma_rows = [] { const char* e = getenv("GCL_FWD_DMA_ROWS"); return e ? atoi(e) : 1; }();
   if ((dma || (flags & GCL_CONV_DMA)) && !(flags & GCL_CONV_NO_DMA) && prec == 4 && (x_is_planes || dma_rows)) {
     const unsigned w_bytes = (unsigned)((long long)K * cin * cout * 4);
-    // Cout a multiple of 128: eight-wave workgroups (128 rows x 128 columns, k_conv_fwd_dma8): a third fewer bytes through L1
-    // per MFMA; bitwise the same results (GCL_FWD_WIDE8=0 / flag GCL_CONV_NO_WIDE8: the four-wave kernel)
-    static const int wide8 = [] { const char* e = getenv("GCL_FWD_WIDE8"); return e ? atoi(e) : 1; }();
-    if (wide8 && !(flags & GCL_CONV_NO_WIDE8) && cout % 128 == 0 && colgroup && !swz && !ranges) {
-      const dim3 wgrid((unsigned)(cdiv(gx, 8) * 8 * (cout / 128)));
-      const int wswz = 2 | ((heavy_first && tile_mask) ? 16 : 0);
-#define LAUNCH_DMA8(PREV, EPIV)                                                                                    \
-  hipLaunchKernelGGL((k_conv_fwd_dma8<PREV, EPIV>), wgrid, dim3(512), 0, st, x, (const u32x4*)wp, tbl, order, tile_mask, \
-                     (long long)n_out, K, cin, cout, bias, y, wswz, stats, x_amax, w_amax, x_bytes, w_bytes, epi)
-      if (x_is_planes) { if (use_epi) LAUNCH_DMA8(true, true); else LAUNCH_DMA8(true, false); }
-      else { if (use_epi) LAUNCH_DMA8(false, true); else LAUNCH_DMA8(false, false); }
-#undef LAUNCH_DMA8
-      GCL_CHECK_LAUNCH();
-      return GCL_OK;
-    }
 #define LAUNCH_DMA(NBV, PREV, EPIV)                                                                               \
   hipLaunchKernelGGL((k_conv_fwd_dma<NBV, PREV, EPIV>), sgrid, dim3(256), 0, st, x, (const u32x4*)wp, tbl, order,  \
                      tile_mask, (long long)n_out, K, cin, cout, bias, y, sswz, stats, x_amax, w_amax, x_bytes, w_bytes, epi)

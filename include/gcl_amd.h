@@ -234,9 +234,6 @@ int gcl_split_planes(const float* x, int64_t n, int32_t c, const int32_t* amax, 
                                registers, no ds_write); bitwise the same results.  The default (GCL_FWD_DMA=0 turns it off
                                unless this flag is set) */
 #define GCL_CONV_NO_DMA 8   /* ... and this flag selects the register-staged kernel for a launch regardless */
-#define GCL_CONV_NO_WIDE8 16 /* Cout a multiple of 128 runs on eight-wave workgroups (128 rows x 128 columns: a third fewer bytes
-                               per MFMA through the CU's memory path; GCL_FWD_WIDE8=0 turns that off); this flag keeps the
-                               four-wave kernel for a launch.  Bitwise the same results either way */
 int gcl_conv_fwd(const float* x, int64_t n_in, int32_t x_is_planes, const void* wp, int32_t prec, const int32_t* x_amax,
                  const int32_t* w_amax, const int32_t* tbl, const int32_t* order, const int32_t* tile_mask,
                  int64_t n_out, int32_t K,

@@ -21,7 +21,7 @@ LAYERS = [(4, 1, False, 128, 128, 1), (8, 1, False, 256, 256, 1), (4, 2, False, 
 rounds, reps = int(os.environ.get("LB_ROUNDS", "5")), int(os.environ.get("LB_REPS", "10"))
 lib = _lib.load()
 mgr = ME.CoordinateManager(C)
-tot = {8: 0.0, 18: 0.0, 2: 0.0}
+tot = {8: 0.0, 2: 0.0}
 with torch.cuda.device(dev):
     for (t_in, stride, tr, cin, cout, pre) in LAYERS:
         km = mgr.get_kernel_map(t_in, 3, stride)
@@ -42,16 +42,16 @@ with torch.cuda.device(dev):
         if os.environ.get("LB_HOT_ROWS"):      # diagnostic: every gather hits the same few rows (L1 / L2 hot) -- same
             hot = int(os.environ["LB_HOT_ROWS"])   # instruction stream, no fabric traffic for the A operand
             tbl = torch.where(tbl >= 0, tbl % hot, tbl).contiguous()
-        y = {f: torch.empty((n_out, cout), device=dev) for f in (8, 18, 2)}
+        y = {f: torch.empty((n_out, cout), device=dev) for f in (8, 2)}
         stats = torch.empty(((n_out + 127) // 128, 2, cout), device=dev)
 
         def run(flags):
             _lib.check(lib.gcl_conv_fwd(_lib.ptr(planes if pre else x), n_in, pre, _lib.ptr(wp), 4, _lib.ptr(xa), _lib.ptr(wa), _lib.ptr(tbl),
                                         _lib.ptr(order), _lib.ptr(mask), n_out, K, cin, cout, None, _lib.ptr(y[flags]),
                                         _lib.ptr(stats), flags, _lib.stream()), "gcl_conv_fwd")
-        times = {8: [], 18: [], 2: []}
+        times = {8: [], 2: []}
         for r in range(rounds):
-            for f in (8, 18, 2):
+            for f in (8, 2):
                 run(f)
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -61,11 +61,11 @@ with torch.cuda.device(dev):
                 e1.record()
                 torch.cuda.synchronize()
                 times[f].append(e0.elapsed_time(e1) / reps * 1e3)
-        same = torch.equal(y[8], y[2]) and torch.equal(y[8], y[18])
+        same = torch.equal(y[8], y[2])
         line = f"t={t_in} {cin:3d}->{cout:3d} s{stride}{' tr' if tr else '   '} n_out={n_out:7d} {'planes' if pre else 'rows  '} nb={lib.gcl_conv_fwd_nb(n_out, cout, 4)}:"
-        for f, name in ((8, "regs"), (18, "dma4"), (2, "dma8" if cout % 128 == 0 else "dma4")):
+        for f, name in ((8, "regs"), (2, "dma ")):
             med = sorted(times[f])[len(times[f]) // 2]
             tot[f] += med
             line += f"  {name} {med:6.1f} ({min(times[f]):6.1f})"
         print(line + f"  bitwise_equal={same}", flush=True)
-print(f"sum regs {tot[8]:.1f} us  dma four waves {tot[18]:.1f} us  dma (eight waves where Cout % 128 == 0) {tot[2]:.1f} us")
+print(f"sum regs {tot[8]:.1f} us  dma {tot[2]:.1f} us")
