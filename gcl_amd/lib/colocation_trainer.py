@@ -224,28 +224,77 @@ def finest_contrastive_loss(F_out, group, index, index_hash, finest_flag, max_po
     return pos.sum() / len(pos_sel), fin.sum() / len(pos_sel), neg
 
 
+class _RandomNegFn(torch.autograd.Function):
+    """mean over the kept (i, j) of relu(neg_thresh - sqrt(sum_c (F[rows_i[i]] - F[rows_j[j]])^2 + 1e-7))^2, evaluated in
+    blocks of rows_i so that the [block, M, C] difference tensor -- never the [M, M, C] one (8.6 GB at M = 8192, C = 32,
+    plus autograd's copies: ADVICE round 3) -- is what lives at a time; backward recomputes block by block."""
+    BLOCK_BYTES = 256 << 20
+
+    @staticmethod
+    def _blocks(m_i, m_j, c):
+        rows = max(1, min(m_i, _RandomNegFn.BLOCK_BYTES // max(1, m_j * c * 4)))
+        return [(a, min(m_i, a + rows)) for a in range(0, m_i, rows)]
+
+    @staticmethod
+    def _block_terms(Fi, Fj, rows_i, rows_j, n_out, pos_keys, neg_thresh):
+        D = torch.sqrt(((Fi.unsqueeze(1) - Fj.unsqueeze(0)) ** 2).sum(2) + 1e-7)       # lib/metrics.py:22-29, exact form
+        a, b = rows_j.unsqueeze(0), rows_i.unsqueeze(1)
+        keys = torch.minimum(a * n_out + b, a + b * n_out)                            # _neg_hash (util/misc.py:39-40)
+        keep = (a != b) & ~torch.isin(keys, pos_keys)
+        return torch.relu(neg_thresh - D[keep]).pow(2), keep
+
+    @staticmethod
+    def forward(ctx, F_out, rows_i, rows_j, pos_keys, neg_thresh):
+        n_out, c = F_out.shape
+        Fj = F_out[rows_j]
+        tot = torch.zeros((), dtype=torch.float64, device=F_out.device)
+        cnt = 0
+        for a, b in _RandomNegFn._blocks(len(rows_i), len(rows_j), c):
+            t, keep = _RandomNegFn._block_terms(F_out[rows_i[a:b]], Fj, rows_i[a:b], rows_j, n_out, pos_keys, neg_thresh)
+            tot += t.double().sum()
+            cnt += int(keep.sum())
+        ctx.save_for_backward(F_out, rows_i, rows_j, pos_keys)
+        ctx.neg_thresh, ctx.cnt = neg_thresh, cnt
+        return (tot / max(cnt, 1)).float() if cnt else torch.full((), float("nan"), device=F_out.device)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        F_out, rows_i, rows_j, pos_keys = ctx.saved_tensors
+        n_out, c = F_out.shape
+        gF = torch.zeros_like(F_out)
+        if not ctx.cnt:
+            return gF, None, None, None, None
+        scale = gout / ctx.cnt
+        for a, b in _RandomNegFn._blocks(len(rows_i), len(rows_j), c):
+            with torch.enable_grad():
+                Fi = F_out[rows_i[a:b]].detach().requires_grad_(True)
+                Fj = F_out[rows_j].detach().requires_grad_(True)
+                t, _ = _RandomNegFn._block_terms(Fi, Fj, rows_i[a:b], rows_j, n_out, pos_keys, ctx.neg_thresh)
+                gi, gj = torch.autograd.grad(t.sum(), (Fi, Fj))
+            gF.index_add_(0, rows_i[a:b], gi * scale)
+            gF.index_add_(0, rows_j, gj * scale)
+        return gF, None, None, None, None
+
+
 def random_negative_term(F_out, sel1, sel2, cols, group, index, index_hash, neg_thresh):
     """The negative term with ``use_hard_negative == False`` exactly as the reference's code evaluates it
     (lib/colocation_trainer.py:513-530): ``D_fs[torch.arange(M), D_fs_ind]`` with ``D_fs_ind`` of shape [M, 1]
     broadcasts to ``out[i, j] = D_fs[j, c_i]``, and ``sel_hn2[D_fs_ind]`` / ``_neg_hash`` / ``np.isin`` broadcast
     alike: the loss is the mean over ALL (i, j) of relu(neg_thresh - D_fs[j, c_i])^2 whose pair (sel1[j], sel2[c_i]) is
     neither the same row nor inside one positive group.  Distances in the exact (a - b)^2 form of lib/metrics.py:22-29
-    (torch on the device, differentiable); the positive-pair keys are ``index_hash`` when the loader supplies it, else
-    ``_exhaustive_hash(group, index)`` (util/misc.py:29-36).  A debug path: [M, M, C] temporaries, no HIP kernel."""
+    (torch on the device, differentiable, evaluated in row blocks: _RandomNegFn); the positive-pair keys are ``index_hash``
+    when the loader supplies it, else ``_exhaustive_hash(group, index)`` (util/misc.py:29-36).  A debug path, no HIP kernel."""
     from gcl_amd.util.misc import _exhaustive_hash
     dev = F_out.device
     n_out = F_out.shape[0]
     cols_d = torch.as_tensor(np.asarray(cols, dtype=np.int64)).to(dev)
     rows_j, rows_i = sel1, sel2[cols_d]                                          # sel1[j], sel2[c_i]
-    D = torch.sqrt(((F_out[rows_i].unsqueeze(1) - F_out[rows_j].unsqueeze(0)) ** 2).sum(2) + 1e-7)    # [i, j] = D_fs[j, c_i]
-    a, b = rows_j.unsqueeze(0), rows_i.unsqueeze(1)
-    keys = torch.minimum(a * n_out + b, a + b * n_out)                          # _neg_hash (util/misc.py:39-40)
     if index_hash is None:
         split = torch.split(torch.as_tensor(index).cpu(), tuple(int(g) for g in torch.as_tensor(group).tolist()))
         index_hash = _exhaustive_hash(split, n_out)
     pos_keys = torch.as_tensor(np.asarray(index_hash, dtype=np.int64)).to(dev)
-    keep = (a != b) & ~torch.isin(keys, pos_keys)
-    return torch.relu(neg_thresh - D[keep]).pow(2).mean()
+    return _RandomNegFn.apply(F_out, rows_i, rows_j, pos_keys, float(neg_thresh))
 
 
 def location_contrastive_loss(F_out, group, index, index_hash, finest_flag, max_pos_cluster=256, max_hn_samples=2048,
