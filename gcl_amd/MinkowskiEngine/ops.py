@@ -386,6 +386,8 @@ class _SparseConvFn(torch.autograd.Function):
                 name = "k_conv_bwd_weight_generic" if (cin % 32 or cout % 32) else \
                     (f"k_conv_bwd_weight<{tile}>" if prec == 0 else
                      f"k_conv_bwd_weight_split<{tile},{prec},{'true' if use_pl else 'false'}>")
+                if use_pl and cin % 128 == 0 and cout % 128 == 0 and os.environ.get("GCL_DW_WG128", "1") != "0":
+                    name = "k_conv_bwd_weight_wg128"
                 if prec == 4 and not fp16x3 and not (cin % 32 or cout % 32):     # K > 27 with MFMA-shaped channels
                     x_amax, dy_amax = tensor_amax(lib, x), tensor_amax(lib, dy)
                 with _Timed(name, ctx.pairs, cin, cout, x.shape[0], dy.shape[0], K):

@@ -1388,23 +1388,23 @@ __device__ __forceinline__ u32x2 lds_read_tr16(unsigned base) {      // one base
 template <int TC>
 __device__ __forceinline__ int tr_swz(int row) { return (TC == 64) ? ((row & 3) << 1) : (((row >> 1) & 1) << 1); }
 // both planes of the fragment of 32-channel slice (base addresses precomputed per lane) for the 16-pair half HALF
-template <int TC, int HALF>
+template <int TC, int HALF, int EXTRA = 0>      // EXTRA: constant byte offset added to every read (a second tile buffer)
 __device__ __forceinline__ void tr_fragment(unsigned base_hi, unsigned base_lo, u32x4* f) {
   constexpr int ROWB = TC * 4;
-  u32x2 h0 = lds_read_tr16<(16 * HALF) * ROWB>(base_hi), h1 = lds_read_tr16<(16 * HALF + 4) * ROWB>(base_hi);
-  u32x2 l0 = lds_read_tr16<(16 * HALF) * ROWB>(base_lo), l1 = lds_read_tr16<(16 * HALF + 4) * ROWB>(base_lo);
+  u32x2 h0 = lds_read_tr16<(16 * HALF) * ROWB + EXTRA>(base_hi), h1 = lds_read_tr16<(16 * HALF + 4) * ROWB + EXTRA>(base_hi);
+  u32x2 l0 = lds_read_tr16<(16 * HALF) * ROWB + EXTRA>(base_lo), l1 = lds_read_tr16<(16 * HALF + 4) * ROWB + EXTRA>(base_lo);
   f[0] = u32x4{h0.x, h0.y, h1.x, h1.y};
   f[1] = u32x4{l0.x, l0.y, l1.x, l1.y};
 }
-template <int TCA, int TCB, int HALF>
+template <int TCA, int TCB, int HALF, int EXTRA = 0>
 __device__ __forceinline__ void tr_mma_half(const unsigned (*baseA)[2], const unsigned (*baseB)[2],
                                             f32x16 (&acc)[TCA / 32][TCB / 32]) {
   constexpr int NBI = TCA / 32, NBJ = TCB / 32;
   u32x4 fa[NBI][2], fb[NBJ][2];
 #pragma unroll
-  for (int a = 0; a < NBI; ++a) tr_fragment<TCA, HALF>(baseA[a][0], baseA[a][1], fa[a]);
+  for (int a = 0; a < NBI; ++a) tr_fragment<TCA, HALF, EXTRA>(baseA[a][0], baseA[a][1], fa[a]);
 #pragma unroll
-  for (int b = 0; b < NBJ; ++b) tr_fragment<TCB, HALF>(baseB[b][0], baseB[b][1], fb[b]);
+  for (int b = 0; b < NBJ; ++b) tr_fragment<TCB, HALF, EXTRA>(baseB[b][0], baseB[b][1], fb[b]);
   // the asm reads complete asynchronously and the compiler does not know: wait, then pin every fragment behind the
   // wait with an empty asm (volatile asms keep their order) so that no MFMA is scheduled above it
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1620,6 +1620,178 @@ __global__ void __launch_bounds__(256) k_conv_bwd_weight_split(const float* __re
   }
   flush(kcur);
 #undef GCL_GATHER
+}
+
+// ---- weight gradient on plane images, 128 x 128 output block per workgroup (round 4) ---------------------------------
+// k_conv_bwd_weight_split gives every wave its own 32 pairs and a 64 x 64 block, so a layer with Ca = Cb = 128 gathers every
+// row twice (once per channel tile of the OTHER operand), 256 x 256 four times; per CU the launches have 8 waves x 16 KB of
+// gathers in flight and deliver what that buys at ~2.5 us per round trip (profiles/r04_conv_experiments.txt, 23 / 27) --
+// bytes per MFMA are the lever.  Here the four waves of a workgroup share the SAME 32 pairs: the rows (128 channels of each
+// operand) are gathered once into a double-buffered workgroup tile, wave (wi, wj) multiplies channel half wi of A with half
+// wj of B (its 64 x 64 block, the same registers as before), and every wave stages a quarter of each sub-chunk two
+// sub-chunks ahead: the same 16 KB in flight per wave for twice the MFMAs.  No cross-wave sums: a wave flushes its own
+// block.  One workgroup barrier per sub-chunk of 32 pairs.  Deterministic (fixed order); NOT bitwise equal to the
+// 64 x 64 kernel (one accumulator per block walks the pairs in order instead of four interleaved ones).
+template <bool DUMMY = false>
+__global__ void __launch_bounds__(256, 2) k_conv_bwd_weight_wg128(const float* __restrict__ A, const float* __restrict__ B,
+                                                               const int* __restrict__ pair_a,
+                                                               const int* __restrict__ pair_b, SegOffW seg, int K,
+                                                               int ca, int cb, long long n_chunks, int per,
+                                                               float* slabs, const int* __restrict__ a_amax,
+                                                               const int* __restrict__ b_amax, int n_wg_x, int n_tiles,
+                                                               unsigned a_bytes, unsigned b_bytes) {
+  constexpr int TC = 64;                   // a wave's channel half of each operand
+  constexpr int SUB = GCL_PAIR_CHUNK / 32; // sub-chunks of 32 pairs per 128-pair chunk
+  const float out_scale = 1.f / (amax_scale(a_amax) * amax_scale(b_amax));
+  // [buffer][operand A | B][channel half][32 rows][256 B]: each [32][256 B] piece is the row image of the 64-channel kernels
+  __shared__ __attribute__((aligned(16))) unsigned char tiles[2][2][2][32 * TC * 4];
+  const int t = threadIdx.x, l = t & 63, w = t >> 6, wi = w >> 1, wj = w & 1;
+  constexpr int BUF_BYTES = 2 * 2 * 32 * TC * 4;      // one buffer: both operands, both halves (32 KB)
+  unsigned trA[2][2], trB[2][2];           // buffer 0: [32-channel slice of the half][plane]; buffer 1 = + BUF_BYTES (immediate)
+  {
+    const int q = (l & 15) >> 2, pp = l & 3, c16 = (l >> 4) & 1, trow = 8 * (l >> 5) + q;
+    const unsigned la = (unsigned)(unsigned long long)((__attribute__((address_space(3))) unsigned char*)&tiles[0][0][wi][0]);
+    const unsigned lb = (unsigned)(unsigned long long)((__attribute__((address_space(3))) unsigned char*)&tiles[0][1][wj][0]);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        const unsigned off = trow * (TC * 4) + (((a * 4 + pl * 2 + c16) ^ tr_swz<TC>(q)) * 32) + pp * 8;
+        trA[a][pl] = la + off;
+        trB[a][pl] = lb + off;
+      }
+  }
+  int bx, by;
+  if (n_tiles > 0) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    by = slot % n_tiles;
+    bx = (slot / n_tiles) * 8 + xcd;
+    if (bx >= n_wg_x) return;
+  } else {
+    bx = blockIdx.x;
+    by = blockIdx.y;
+  }
+  const int tiles_b = cb / 128;
+  const int ca0 = (by / tiles_b) * 128, cb0 = (by % tiles_b) * 128;
+  const long long c0 = (long long)bx * per;
+  const long long c1 = (c0 + per < n_chunks) ? c0 + per : n_chunks;
+  if (c0 >= c1) return;
+  const long long s0 = c0 * SUB, s1 = c1 * SUB;      // sub-chunk range of this workgroup
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)b_bytes, 0x00020000);
+  const unsigned a_row = (unsigned)ca * 4u, b_row = (unsigned)cb * 4u;
+  // a lane's share of a sub-chunk: rows 8 w + 2 ps + (l >> 5), ps = 0 .. 3, 16-byte piece l & 31 of the 512-byte row
+  const int pc = l & 31, rsub = l >> 5;
+  const unsigned a_col = (unsigned)ca0 * 4u + (unsigned)pc * 16u, b_col = (unsigned)cb0 * 4u + (unsigned)pc * 16u;
+  // where piece pc of row r goes: half pc / 16, then the 64-channel row image (32-byte blocks XOR-swizzled with the row)
+  unsigned dst[4];
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    const int row = 8 * w + 2 * ps + rsub, p16 = pc & 15;
+    dst[ps] = (unsigned)((pc >> 4) * (32 * TC * 4) + row * (TC * 4) + (((p16 >> 1) ^ tr_swz<TC>(row)) * 32) + (p16 & 1) * 16);
+  }
+  auto load_pairs = [&](long long sc, int& ia, int& ib) {      // lanes 0 .. 31: the pair of row `lane` of sub-chunk sc
+    ia = -1;
+    ib = -1;
+    if (sc < s1 && l < 32) {
+      const long long p0 = sc * 32 + l;
+      ia = pair_a[p0];
+      ib = pair_b[p0];
+    }
+  };
+#define GCLW_GATHER(IA, IB, GA, GB)                                                                            \
+  {                                                                                                            \
+    _Pragma("unroll") for (int ps = 0; ps < 4; ++ps) {                                                         \
+      const int row_ = 8 * w + 2 * ps + rsub;                                                                  \
+      const unsigned ra_ = (unsigned)__shfl(IA, row_), rb_ = (unsigned)__shfl(IB, row_);                       \
+      GA[ps] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, (int)(ra_ * a_row + a_col), 0, 0)); \
+      GB[ps] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(brsrc, (int)(rb_ * b_row + b_col), 0, 0)); \
+    }                                                                                                          \
+  }
+#define GCLW_STORE(BUF, GA, GB)                                                                                \
+  {                                                                                                            \
+    _Pragma("unroll") for (int ps = 0; ps < 4; ++ps) {                                                         \
+      *reinterpret_cast<float4*>(&tiles[BUF][0][0][0] + dst[ps]) = GA[ps];                                     \
+      *reinterpret_cast<float4*>(&tiles[BUF][1][0][0] + dst[ps]) = GB[ps];                                     \
+    }                                                                                                          \
+  }
+  auto flush = [&](int k) {      // this wave's 64 x 64 block of the slab of (workgroup, offset k)
+    int cbv = cb;
+    asm volatile("" : "+s"(cbv));      // opaque here: keeps the 64 element offsets out of the loop's live registers (they spilled)
+    float* base = slabs + (long long)(bx + k) * ((long long)ca * cb) +
+                  (long long)(ca0 + wi * 64 + 4 * (l >> 5)) * cb + cb0 + wj * 64 + (l & 31);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          base[(unsigned)((a * 32 + (r & 3) + 8 * (r >> 2)) * cbv + b * 32)] = acc[a][b][r] * out_scale;
+          acc[a][b][r] = 0.f;
+        }
+  };
+
+  int kcur = 0;
+  while (seg.off[kcur + 1] <= c0 * GCL_PAIR_CHUNK) ++kcur;
+  float4 ga0[4], gb0[4], ga1[4], gb1[4];
+  int ia, ib, ian, ibn;
+  // sub-chunks s0 and s0 + 1 -> registers, s0 -> buffer 0, then s0 + 2 -> the freed registers; indices two ahead
+  load_pairs(s0, ia, ib);
+  load_pairs(s0 + 1, ian, ibn);
+  GCLW_GATHER(ia, ib, ga0, gb0);
+  GCLW_GATHER(ian, ibn, ga1, gb1);
+  load_pairs(s0 + 2, ia, ib);
+  load_pairs(s0 + 3, ian, ibn);
+  GCLW_STORE(0, ga0, gb0);
+  GCLW_GATHER(ia, ib, ga0, gb0);          // rows of s0 + 2 (out of range: row -1 reads zeros, never used)
+  load_pairs(s0 + 4, ia, ib);
+  __syncthreads();
+  // steady state, two sub-chunks per trip (static register sets): at the top of the trip for sub-chunk s, buffer s & 1 holds
+  // s, set 1 holds s + 1, set 0 holds s + 2 (in flight), `ian/ibn` = pairs of s + 3, `ia/ib` = pairs of s + 4
+#define GCLW_COMPUTE(BUF)                                                                                      \
+  {                                                                                                            \
+    tr_mma_half<TC, TC, 0, (BUF)*BUF_BYTES>(trA, trB, acc);                                                    \
+    tr_mma_half<TC, TC, 1, (BUF)*BUF_BYTES>(trA, trB, acc);                                                    \
+  }
+#define GCLW_SEGMENT(S)                                                                                        \
+  if (((S) + 1) % SUB == 0) {        /* last sub-chunk of a 128-pair chunk: does the next chunk start a new offset? */ \
+    const long long nb_ = ((S) + 1) / SUB * GCL_PAIR_CHUNK;                                                    \
+    if ((S) + 1 < s1 && nb_ >= seg.off[kcur + 1]) {                                                            \
+      flush(kcur);                                                                                             \
+      while (seg.off[kcur + 1] <= nb_) ++kcur;                                                                 \
+    }                                                                                                          \
+  }
+  for (long long s = s0; s < s1; s += 2) {
+    // ---- sub-chunk s (buffer 0 of this trip's pair = (s - s0) & 1 == 0 -> buffer index alternates with s - s0)
+    GCLW_COMPUTE(0);
+    GCLW_SEGMENT(s);
+    GCLW_STORE(1, ga1, gb1);              // s + 1 -> buffer 1 (last read one sub-chunk ago, before the previous barrier)
+    GCLW_GATHER(ian, ibn, ga1, gb1);      // s + 3
+    load_pairs(s + 5, ian, ibn);
+    __syncthreads();
+    if (s + 1 >= s1) break;
+    // ---- sub-chunk s + 1
+    GCLW_COMPUTE(1);
+    GCLW_SEGMENT(s + 1);
+    GCLW_STORE(0, ga0, gb0);              // s + 2 -> buffer 0
+    GCLW_GATHER(ia, ib, ga0, gb0);        // s + 4
+    load_pairs(s + 6, ia, ib);
+    __syncthreads();
+  }
+  flush(kcur);
+#undef GCLW_SEGMENT
+#undef GCLW_COMPUTE
+#undef GCLW_STORE
+#undef GCLW_GATHER
 }
 
 __global__ void __launch_bounds__(256) k_bwd_weight_reduce(const float* __restrict__ slabs, SegOffW seg, int per,
@@ -2326,6 +2498,8 @@ int gcl_conv_bwd_weight(const float* a, int64_t n_a, const float* b, int64_t n_b
                         int32_t ca, int32_t cb, int32_t prec,
                         const int32_t* a_amax, const int32_t* b_amax, float* scratch, float* dw, void* stream) {
   GCL_CHECK_ARG(a && b && pair_a && pair_b && seg_off_host && scratch && dw, "gcl_conv_bwd_weight: null pointer");
+  const bool legacy_dw = (planes & 2) != 0;      // bit 1 of `planes`: the 64 x 64-block kernel for this launch (tests)
+  planes &= 1;
   GCL_CHECK_ARG(K >= 1 && K <= 125, "gcl_conv_bwd_weight: bad K");
   GCL_CHECK_ARG(ca > 0 && cb > 0, "gcl_conv_bwd_weight: channel counts (%d, %d) must be positive", ca, cb);
   GCL_CHECK_ARG(prec_ok(prec), "gcl_conv_bwd_weight: prec must be 0, 2, 3 or 4");
@@ -2384,6 +2558,21 @@ int gcl_conv_bwd_weight(const float* a, int64_t n_a, const float* b, int64_t n_b
 #undef LAUNCH_RG
     hipLaunchKernelGGL(k_bwd_weight_reduce_rg, dim3((unsigned)cdiv(mat, 256), K), dim3(256), 0, st, (const float*)scratch,
                        nr, K, mat, dw);
+    GCL_CHECK_LAUNCH();
+    return GCL_OK;
+  }
+  // plane images with Ca, Cb multiples of 128: one 128 x 128 block per workgroup, rows gathered once and shared by its four
+  // waves (k_conv_bwd_weight_wg128; GCL_DW_WG128=0 / bit 1 of `planes`: the 64 x 64 kernel)
+  static const int wg128 = [] { const char* e = getenv("GCL_DW_WG128"); return e ? atoi(e) : 1; }();
+  if (nc > 0 && prec == 4 && planes && wg128 && !legacy_dw && ca % 128 == 0 && cb % 128 == 0) {
+    const int tiles = (ca / 128) * (cb / 128);
+    static const int dwswz2 = [] { const char* s = getenv("GCL_DW_SWIZZLE"); return s ? atoi(s) : 1; }();
+    const int stiles = (dwswz2 && tiles > 1) ? tiles : 0;
+    const dim3 g2 = stiles ? dim3((unsigned)(cdiv(W, 8) * 8 * stiles)) : dim3(W, tiles);
+    hipLaunchKernelGGL((k_conv_bwd_weight_wg128<false>), g2, dim3(256), 0, st, a, b, pair_a, pair_b, seg, K, ca, cb, nc, per,
+                       scratch, a_amax, b_amax, W, stiles, a_bytes, b_bytes);
+    hipLaunchKernelGGL(k_bwd_weight_reduce, dim3((unsigned)cdiv(mat, 256), K), dim3(256), 0, st, (const float*)scratch,
+                       seg, per, mat, dw);
     GCL_CHECK_LAUNCH();
     return GCL_OK;
   }

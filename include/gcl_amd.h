@@ -260,7 +260,10 @@ int gcl_conv_fwd_fused(const float* x, int64_t n_in, int32_t x_is_planes, const 
  *   in {32, 64}, 1 < K <= 27, no plane images and >= 32768 rows on that side, the launch is "range-grouped": a workgroup
  *   takes the pairs of ONE offset whose sorted-side row lies in one row range, the K workgroups of a range share an XCD,
  *   and the sorted side's rows are fetched from the fabric once per range instead of once per offset (same sums, other
- *   fixed order).  scratch: float[gcl_conv_bwd_weight_scratch_len(K, ca, cb, n_pairs_padded, rows of the sorted side or 0)]. */
+ *   fixed order).  scratch: float[gcl_conv_bwd_weight_scratch_len(K, ca, cb, n_pairs_padded, rows of the sorted side or 0)].
+ * planes: bit 0 = a and b are plane images (gcl_split_planes); with Ca and Cb multiples of 128 the launch then gives every
+ *   workgroup a 128 x 128 block of dW[k] whose rows are gathered once and shared by its four waves (half the gathered bytes
+ *   per MFMA).  Bit 1 = keep the 64 x 64-block kernel for this launch (same result to rounding: another fixed order). */
 int64_t gcl_conv_bwd_weight_scratch_len(int32_t K, int32_t ca, int32_t cb, int64_t n_pairs_padded, int64_t n_sorted_rows);
 int gcl_conv_bwd_weight(const float* a, int64_t n_a, const float* b, int64_t n_b, int32_t planes, int32_t sorted_side,
                         const int32_t* pair_a, const int32_t* pair_b, const int64_t* seg_off_host, int32_t K,

@@ -432,6 +432,53 @@ def test_weight_gradient_range_grouped_mode(cin, cout, stride, transpose):
     assert rel_l2(grads[0].cpu(), W.grad) < 2e-6
 
 
+@pytest.mark.parametrize("ca,cb,n,stride", [(128, 128, 3000, 1), (256, 128, 1500, 1), (128, 256, 40, 1), (256, 256, 700, 2),
+                                            (128, 128, 1, 1), (128, 128, 9000, 1)])
+def test_weight_gradient_128_block_kernel(ca, cb, n, stride):
+    """k_conv_bwd_weight_wg128 (plane images, Ca and Cb multiples of 128: a 128 x 128 block of dW[k] per workgroup, the rows
+    gathered once into a shared double-buffered tile, every wave a 64 x 64 block; the default there) against the 64 x 64-block
+    kernel (bit 1 of `planes`) and the fp64 product: equal to rounding (one accumulator per block walks the pairs in order
+    instead of four interleaved ones), bitwise reproducible; ragged / single-pair lists and several offsets per workgroup."""
+    from gcl_amd import _lib
+    import gcl_amd.MinkowskiEngine as ME
+    lib = _lib.load()
+    C = random_cloud(ca + n, n=n, extent=14, batch=1) if n > 1 else np.zeros((1, 4), np.int32)
+    mgr = make_mgr(C)
+    km = mgr.get_kernel_map(1, 3, stride)
+    pin, pout, seg, seg_host = km.pairs()
+    n_a, n_b = len(C), mgr.num_rows(stride)
+    K = 27
+    g = torch.Generator().manual_seed(n + ca)
+    with torch.cuda.device(DEV):
+        a = torch.randn(n_a, ca, generator=g).to(DEV)
+        b = torch.randn(n_b, cb, generator=g).to(DEV)
+        aa, ba = ME.ops.amax_slot(a.device), ME.ops.amax_slot(a.device)
+        _lib.check(lib.gcl_amax(_lib.ptr(a), a.numel(), _lib.ptr(aa), 1, _lib.stream()), "gcl_amax")
+        _lib.check(lib.gcl_amax(_lib.ptr(b), b.numel(), _lib.ptr(ba), 1, _lib.stream()), "gcl_amax")
+        xa = torch.empty((n_a, ca), dtype=torch.int32, device=DEV)
+        xb = torch.empty((n_b, cb), dtype=torch.int32, device=DEV)
+        _lib.check(lib.gcl_split_planes(_lib.ptr(a), n_a, ca, _lib.ptr(aa), _lib.ptr(xa), _lib.stream()), "split")
+        _lib.check(lib.gcl_split_planes(_lib.ptr(b), n_b, cb, _lib.ptr(ba), _lib.ptr(xb), _lib.stream()), "split")
+        out = {}
+        for legacy in (1, 0, 0):
+            scratch = torch.full((lib.gcl_conv_bwd_weight_scratch_len(K, ca, cb, seg[-1], n_b),), float("nan"), device=DEV)
+            dw = torch.full((K, ca, cb), float("nan"), device=DEV)
+            _lib.check(lib.gcl_conv_bwd_weight(_lib.ptr(xa), n_a, _lib.ptr(xb), n_b, 1 | (2 * legacy), 2, _lib.ptr(pin),
+                                               _lib.ptr(pout), seg_host, K, ca, cb, 4, _lib.ptr(aa), _lib.ptr(ba),
+                                               _lib.ptr(scratch), _lib.ptr(dw), _lib.stream()), "gcl_conv_bwd_weight")
+            out.setdefault(legacy, []).append(dw)
+        assert torch.isfinite(out[0][0]).all() and torch.equal(out[0][0], out[0][1]), "deterministic"
+        src = km.nbr.cpu().numpy()
+        ad, bd = a.double().cpu(), b.double().cpu()
+        want = torch.zeros(K, ca, cb, dtype=torch.float64)
+        for k in range(K):
+            rows = np.nonzero(src[k] >= 0)[0]
+            if len(rows):
+                want[k] = ad[src[k][rows]].T @ bd[rows]
+        assert rel_l2(out[0][0].cpu(), want) < 2e-6 and rel_l2(out[1][0].cpu(), want) < 2e-6
+        assert rel_l2(out[0][0].cpu(), out[1][0].cpu()) < 2e-6
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # batch norm (+ residual, + relu)
 # ---------------------------------------------------------------------------------------------------------------
