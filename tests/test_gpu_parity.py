@@ -397,6 +397,52 @@ def test_lds_dma_forward_kernel_is_bitwise_the_register_staged_kernel(cin, cout,
         assert rel_l2(out[(2, False)][0].cpu(), yo) < 2e-6
 
 
+@pytest.mark.parametrize("cin,cout,use_planes", [(128, 128, True), (64, 64, False)])
+def test_lds_dma_forward_kernel_race_screen(cin, cout, use_planes):
+    """The LDS-DMA kernel orders its reads behind its DMAs by its own `s_waitcnt vmcnt(0)` + the workgroup barrier, and its
+    DMAs behind its reads by program order + `lgkmcnt` -- nothing the compiler checks.  A wrong placement shows as RARE wrong
+    tiles that come and go with timing, so: 40 launches of a 60 k-row layer, half of them while a second stream keeps the
+    memory system busy, every one compared bit for bit with the register-staged kernel's result."""
+    from gcl_amd import _lib
+    import gcl_amd.MinkowskiEngine as ME
+    lib = _lib.load()
+    C = random_cloud(5, n=60000, extent=40, batch=1, sheet=False)
+    mgr = make_mgr(C)
+    km = mgr.get_kernel_map(1, 3, 1)
+    tbl, order, mask = km.sorted_table()
+    n_out, K = len(C), 27
+    g = torch.Generator().manual_seed(3)
+    with torch.cuda.device(DEV):
+        x = torch.randn(n_out, cin, generator=g).to(DEV)
+        W = (0.1 * torch.randn(K, cin, cout, generator=g)).to(DEV)
+        xa, wa = ME.ops.amax_slot(x.device), ME.ops.amax_slot(x.device)
+        _lib.check(lib.gcl_amax(_lib.ptr(x), x.numel(), _lib.ptr(xa), 1, _lib.stream()), "gcl_amax")
+        _lib.check(lib.gcl_amax(_lib.ptr(W), W.numel(), _lib.ptr(wa), 1, _lib.stream()), "gcl_amax")
+        planes = torch.empty((n_out, cin), dtype=torch.int32, device=DEV)
+        _lib.check(lib.gcl_split_planes(_lib.ptr(x), n_out, cin, _lib.ptr(xa), _lib.ptr(planes), _lib.stream()), "split")
+        wp = torch.empty(lib.gcl_pack_weights_bytes(K, cin, cout, 4), dtype=torch.uint8, device=DEV)
+        _lib.check(lib.gcl_pack_weights(_lib.ptr(W), K, cin, cout, 0, 4, _lib.ptr(wa), _lib.ptr(wp), _lib.stream()), "pack")
+        xin = planes if use_planes else x
+
+        def run(flags):
+            y = torch.full((n_out, cout), float("nan"), device=DEV)
+            stats = torch.full(((n_out + 127) // 128, 2, cout), float("nan"), device=DEV)
+            _lib.check(lib.gcl_conv_fwd(_lib.ptr(xin), n_out, int(use_planes), _lib.ptr(wp), 4, _lib.ptr(xa), _lib.ptr(wa),
+                                        _lib.ptr(tbl), _lib.ptr(order), _lib.ptr(mask), n_out, K, cin, cout, None, _lib.ptr(y),
+                                        _lib.ptr(stats), flags, _lib.stream()), "gcl_conv_fwd")
+            return y, stats
+        ref = run(8)
+        side = torch.cuda.Stream()
+        junk = torch.randn(64 << 20, device=DEV)
+        for it in range(40):
+            if it % 2:
+                with torch.cuda.stream(side):           # streaming traffic beside the launch: other timing, other latencies
+                    junk.mul_(1.0001)
+            got = run(2)
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), it
+        torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("cin,cout,stride,transpose", [(32, 32, 1, False), (64, 64, 1, False), (32, 64, 1, False),
                                                         (64, 32, 2, False), (64, 64, 2, True)])
 def test_weight_gradient_range_grouped_mode(cin, cout, stride, transpose):
