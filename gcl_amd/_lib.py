@@ -81,6 +81,8 @@ SIGNATURES = {
     "gcl_table_sort_pre": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gcl_conv_fwd_fused": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp,
                                   _i32, _vp, _vp, _vp, _i32, _vp]),
+    "gcl_conv_fwd_fused_ld": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp,
+                                     _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "gcl_split_planes": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
     "gcl_conv_fwd": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i32,
                             _vp]),
@@ -100,6 +102,8 @@ SIGNATURES = {
     "gcl_bn_mask_len": (_i64, [_i64, _i32]),
     "gcl_bn_bwd_reduce": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "gcl_bn_bwd_apply": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "gcl_bn_bwd_reduce_ld": (_i32, [_vp, _vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "gcl_bn_bwd_apply_ld": (_i32, [_vp, _vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "gcl_row_normalize_fwd": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
     "gcl_row_normalize_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     "gcl_sgd_multi": (_i32, [_vp, _vp, _i32, _f32, _f32, _f32, _i32, _vp]),

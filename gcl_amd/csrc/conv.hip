@@ -444,6 +444,7 @@ struct ConvEpi {
   const float* residual;    // [n_out, cout] added before the ReLU, NULL = none
   int relu;
   int* y_amax;              // zero-initialised amax slot of y, NULL = not wanted
+  int residual_ld;          // row pitch of `residual` in floats (a column slice of a wider tensor), 0 = cout
 };
 
 // Epilogue of the four-wave forward kernels (k_conv_fwd_split, k_conv_fwd_dma): un-scale, bias, optional fused inference
@@ -478,7 +479,7 @@ __device__ __forceinline__ void conv_fwd_epilogue(f32x16 (&acc)[NB], float* tile
       int orow = __shfl(orow_l, (r & 3) + 8 * (r >> 2) + 4 * h);
       if (orow >= 0) {
         float v = acc[b][r] * csc + bvv;
-        if (EPI && epi.residual) v += epi.residual[(long long)orow * cout + col];
+        if (EPI && epi.residual) v += epi.residual[(long long)orow * (epi.residual_ld ? epi.residual_ld : cout) + col];
         if (EPI && epi.relu) v = fmaxf(v, 0.f);
         Y[(long long)orow * cout + col] = v;
         s1 += v;
@@ -1242,7 +1243,7 @@ __global__ void __launch_bounds__(1024, 1) k_conv_fwd_tall(const float* __restri
       int orow = __shfl(orow_l, (r & 3) + 8 * (r >> 2) + 4 * h);
       if (orow >= 0) {
         float v = acc[b][r] * csc + bvv;
-        if (EPI && epi.residual) v += epi.residual[(long long)orow * cout + col];
+        if (EPI && epi.residual) v += epi.residual[(long long)orow * (epi.residual_ld ? epi.residual_ld : cout) + col];
         if (EPI && epi.relu) v = fmaxf(v, 0.f);
         Y[(long long)orow * cout + col] = v;
         if (EPI) ymax = fmaxf(ymax, fabsf(v));
@@ -2352,7 +2353,18 @@ int gcl_conv_fwd_fused(const float* x, int64_t n_in, int32_t x_is_planes, const 
                        const int32_t* tile_mask, int64_t n_out, int32_t K, int32_t cin, int32_t cout, const float* bias,
                        const float* col_scale, const float* residual, int32_t relu, int32_t* y_amax, float* y,
                        float* stats, int32_t flags, void* stream) {
-  const ConvEpi epi{col_scale, residual, relu, y_amax};
+  return gcl_conv_fwd_fused_ld(x, n_in, x_is_planes, wp, prec, x_amax, w_amax, tbl, order, tile_mask, n_out, K, cin, cout, bias,
+                               col_scale, residual, 0, relu, y_amax, y, stats, flags, stream);
+}
+
+int gcl_conv_fwd_fused_ld(const float* x, int64_t n_in, int32_t x_is_planes, const void* wp, int32_t prec,
+                          const int32_t* x_amax, const int32_t* w_amax, const int32_t* tbl, const int32_t* order,
+                          const int32_t* tile_mask, int64_t n_out, int32_t K, int32_t cin, int32_t cout, const float* bias,
+                          const float* col_scale, const float* residual, int32_t residual_ld, int32_t relu,
+                          int32_t* y_amax, float* y, float* stats, int32_t flags, void* stream) {
+  GCL_CHECK_ARG(residual_ld == 0 || (residual && residual_ld >= cout && !generic_shape(K, cin, cout)),
+                "gcl_conv_fwd_fused_ld: residual_ld needs a residual, >= Cout, MFMA-shaped launches");
+  const ConvEpi epi{col_scale, residual, relu, y_amax, residual_ld};
   const bool use_epi = col_scale || residual || relu || y_amax;
   GCL_CHECK_ARG(prec != 0 || generic_shape(K, cin, cout) || (!col_scale && !residual && !relu && !y_amax),
                 "gcl_conv_fwd_fused: the fused epilogue needs a split-precision mode");

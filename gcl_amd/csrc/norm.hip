@@ -33,7 +33,9 @@ __global__ void __launch_bounds__(256) k_bn_reduce(const float* __restrict__ x, 
                                                    const float* __restrict__ y, long long n, int c,
                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
                                                    int relu, const unsigned long long* __restrict__ mask,
-                                                   int rows_per_wg, double* partial) {
+                                                   int rows_per_wg, double* partial, int dy_ld = 0) {
+  // dy_ld: row pitch of dy in floats (0 = c): dy may be a column slice of a wider tensor (the gradient of an ME.cat input)
+  const long long gld = dy_ld ? dy_ld : c;
   __shared__ double red[2][256][4];
   const int cq_n = c >> 2;
   const int cq = threadIdx.x % cq_n, rl = threadIdx.x / cq_n, rstep = 256 / cq_n;
@@ -68,8 +70,8 @@ __global__ void __launch_bounds__(256) k_bn_reduce(const float* __restrict__ x, 
     float4 xa = reinterpret_cast<const float4*>(x + r * c)[cq], xb = reinterpret_cast<const float4*>(x + q * c)[cq];
     float4 ga = z4, gb = z4, ya = z4, yb = z4;
     if (BWD) {
-      ga = reinterpret_cast<const float4*>(dy + r * c)[cq];
-      gb = reinterpret_cast<const float4*>(dy + q * c)[cq];
+      ga = reinterpret_cast<const float4*>(dy + r * gld)[cq];
+      gb = reinterpret_cast<const float4*>(dy + q * gld)[cq];
       if (relu) {
         if (mask) {
           ya = mask_as_y(mask, r * cq_n + cq);
@@ -87,7 +89,7 @@ __global__ void __launch_bounds__(256) k_bn_reduce(const float* __restrict__ x, 
     float4 xa = reinterpret_cast<const float4*>(x + r * c)[cq];
     float4 ga = z4, ya = z4;
     if (BWD) {
-      ga = reinterpret_cast<const float4*>(dy + r * c)[cq];
+      ga = reinterpret_cast<const float4*>(dy + r * gld)[cq];
       if (relu) ya = mask ? mask_as_y(mask, r * cq_n + cq) : reinterpret_cast<const float4*>(y + r * c)[cq];
     }
     BN_ACC(xa, ga, ya)
@@ -398,10 +400,19 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const float* __restrict__ 
                                                       const float* __restrict__ sum_gx, int relu,
                                                       const unsigned long long* __restrict__ mask,
                                                       float* __restrict__ dx, float* __restrict__ dres,
-                                                      int* amax_bits) {
+                                                      int* amax_bits, int dy_ld = 0) {
   const int cq_n = c >> 2;
   const long long S = (long long)gridDim.x * blockDim.x;
   const long long e0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  // dy_ld != 0: dy is a column slice (row pitch dy_ld floats) of a wider tensor; element quad e = (row e / cq_n, quad e % cq_n)
+  const long long gld4 = (dy_ld ? dy_ld : c) >> 2;
+  // HOIST: the thread's quad column never changes and its row advances by S / cq_n per stride -- no division in the loop
+  const long long rstep = HOIST ? S / cq_n : 0;
+  long long row_e = e0 / cq_n;
+  const int q0 = (int)(e0 % cq_n);
+#define BN_DY(E, ROW) (dy_ld ? (HOIST ? reinterpret_cast<const float4*>(dy)[(ROW)*gld4 + q0]                       \
+                                      : reinterpret_cast<const float4*>(dy)[((E) / cq_n) * gld4 + ((E) % cq_n)])  \
+                             : reinterpret_cast<const float4*>(dy)[E])
   const float4 z4 = make_float4(0, 0, 0, 0);
   float am = 0.f;
   BnBwdC ka, kb;
@@ -413,12 +424,13 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const float* __restrict__ 
       ka = bn_bwd_c(mean, rstd, weight, sum_g, sum_gx, (int)(e % cq_n));
       kb = bn_bwd_c(mean, rstd, weight, sum_g, sum_gx, (int)((okb ? f : 0) % cq_n));
     }
-    float4 xa = reinterpret_cast<const float4*>(x)[e], ga = reinterpret_cast<const float4*>(dy)[e];
+    float4 xa = reinterpret_cast<const float4*>(x)[e], ga = BN_DY(e, row_e);
     float4 xb = z4, gb = z4, ya = z4, yb = z4;
     if (okb) {
       xb = reinterpret_cast<const float4*>(x)[f];
-      gb = reinterpret_cast<const float4*>(dy)[f];
+      gb = BN_DY(f, row_e + rstep);
     }
+    row_e += 2 * rstep;
     if (relu) {
       ya = mask ? mask_as_y(mask, e) : reinterpret_cast<const float4*>(y)[e];
       if (okb) yb = mask ? mask_as_y(mask, f) : reinterpret_cast<const float4*>(y)[f];
@@ -436,6 +448,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const float* __restrict__ 
       if (dres) reinterpret_cast<float4*>(dres)[f] = gb;
     }
   }
+#undef BN_DY
   if (amax_bits) publish_amax(am, amax_bits);
 }
 
@@ -595,6 +608,13 @@ int64_t gcl_bn_mask_len(int64_t n, int32_t c) { return cdiv(n * (c / 4), 64) * 4
 int gcl_bn_bwd_reduce(const float* x, const float* dy, const float* y, const uint64_t* relu_mask, int64_t n,
                       int32_t c, const float* mean, const float* rstd, int32_t relu, double* scratch, float* sum_g,
                       float* sum_gx, void* stream) {
+  return gcl_bn_bwd_reduce_ld(x, dy, 0, y, relu_mask, n, c, mean, rstd, relu, scratch, sum_g, sum_gx, stream);
+}
+
+int gcl_bn_bwd_reduce_ld(const float* x, const float* dy, int32_t dy_ld, const float* y, const uint64_t* relu_mask, int64_t n,
+                         int32_t c, const float* mean, const float* rstd, int32_t relu, double* scratch, float* sum_g,
+                         float* sum_gx, void* stream) {
+  GCL_CHECK_ARG(dy_ld == 0 || (dy_ld >= c && dy_ld % 4 == 0), "gcl_bn_bwd_reduce: dy_ld must be 0 or a multiple of 4 >= c");
   GCL_CHECK_ARG(x && dy && mean && rstd && scratch && sum_g && sum_gx, "gcl_bn_bwd_reduce: null pointer");
   GCL_CHECK_ARG(!relu || y || relu_mask, "gcl_bn_bwd_reduce: y or relu_mask is required when relu is set");
   GCL_CHECK_ARG(n > 0 && bn_c_ok(c), "gcl_bn_bwd_reduce: unsupported shape n=%lld c=%d", (long long)n, c);
@@ -602,7 +622,7 @@ int gcl_bn_bwd_reduce(const float* x, const float* dy, const float* y, const uin
   const int rows = bn_rows_per_wg(n, c);
   int nwg = (int)cdiv(n, rows);
   hipLaunchKernelGGL(k_bn_reduce<true>, dim3(nwg), dim3(256), 0, st, x, dy, y, (long long)n, c, mean, rstd, relu,
-                     (const unsigned long long*)relu_mask, rows, scratch);
+                     (const unsigned long long*)relu_mask, rows, scratch, dy_ld);
   hipLaunchKernelGGL(k_bn_bwd_final, dim3((unsigned)cdiv(c, 4)), dim3(256), 0, st, (const double*)scratch, nwg, c,
                      sum_g, sum_gx);
   GCL_CHECK_LAUNCH();
@@ -612,6 +632,13 @@ int gcl_bn_bwd_reduce(const float* x, const float* dy, const float* y, const uin
 int gcl_bn_bwd_apply(const float* x, const float* dy, const float* y, const uint64_t* relu_mask, int64_t n, int32_t c,
                      const float* mean, const float* rstd, const float* weight, const float* sum_g,
                      const float* sum_gx, int32_t relu, float* dx, float* dres, int32_t* dx_amax, void* stream) {
+  return gcl_bn_bwd_apply_ld(x, dy, 0, y, relu_mask, n, c, mean, rstd, weight, sum_g, sum_gx, relu, dx, dres, dx_amax, stream);
+}
+
+int gcl_bn_bwd_apply_ld(const float* x, const float* dy, int32_t dy_ld, const float* y, const uint64_t* relu_mask, int64_t n,
+                        int32_t c, const float* mean, const float* rstd, const float* weight, const float* sum_g,
+                        const float* sum_gx, int32_t relu, float* dx, float* dres, int32_t* dx_amax, void* stream) {
+  GCL_CHECK_ARG(dy_ld == 0 || (dy_ld >= c && dy_ld % 4 == 0), "gcl_bn_bwd_apply: dy_ld must be 0 or a multiple of 4 >= c");
   GCL_CHECK_ARG(x && dy && mean && rstd && weight && sum_g && sum_gx && dx, "gcl_bn_bwd_apply: null pointer");
   GCL_CHECK_ARG(!relu || y || relu_mask, "gcl_bn_bwd_apply: y or relu_mask is required when relu is set");
   GCL_CHECK_ARG(n > 0 && c >= 4 && c % 4 == 0, "gcl_bn_bwd_apply: unsupported shape");
@@ -621,11 +648,11 @@ int gcl_bn_bwd_apply(const float* x, const float* dy, const float* y, const uint
   if ((g * 256) % (c / 4) == 0)
     hipLaunchKernelGGL(k_bn_bwd_apply<true>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, dy, y, total4, c,
                        1.0f / (float)n, mean, rstd, weight, sum_g, sum_gx, relu, (const unsigned long long*)relu_mask, dx,
-                       dres, dx_amax);
+                       dres, dx_amax, dy_ld);
   else
     hipLaunchKernelGGL(k_bn_bwd_apply<false>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, dy, y, total4, c,
                        1.0f / (float)n, mean, rstd, weight, sum_g, sum_gx, relu, (const unsigned long long*)relu_mask, dx,
-                       dres, dx_amax);
+                       dres, dx_amax, dy_ld);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }

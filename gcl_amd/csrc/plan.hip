@@ -95,6 +95,22 @@ __global__ void __launch_bounds__(256) k_split2(const float4* __restrict__ g, in
     if (q < ca4) ga[r * ca4 + q] = v; else gb[r * cb4 + (q - ca4)] = v;
   }
 }
+// y = a + b for row-major [n, c] operands with row pitches (floats; a column slice of a wider tensor has pitch > c);
+// b == NULL: y = a (materialises a slice)
+__global__ void __launch_bounds__(256) k_add2_ld(const float* __restrict__ a, int a_ld, const float* __restrict__ b, int b_ld,
+                                                 long long n, int c4, float4* __restrict__ y) {
+  const long long total = n * c4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / c4;
+    const int q = (int)(i - r * c4);
+    float4 u = reinterpret_cast<const float4*>(a + r * a_ld)[q];
+    if (b) {
+      const float4 v = reinterpret_cast<const float4*>(b + r * b_ld)[q];
+      u = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+    }
+    y[i] = u;
+  }
+}
 __global__ void __launch_bounds__(256) k_add2(const float4* __restrict__ a, const float4* __restrict__ b, long long n4,
                                               float4* __restrict__ y) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
@@ -326,6 +342,8 @@ struct TState {            // a tensor of the pass (forward value or gradient)
   float* ptr = nullptr;
   int32_t* amax = nullptr;   // amax slot that holds max|tensor|, or NULL = not measured yet
   void* planes = nullptr;    // gcl_split_planes image, or NULL = not made yet
+  int ld = 0;                // row pitch in floats when the tensor is a column slice of a wider one (gradients of ME.cat
+                             // inputs: slices of the gradient of the cat's output), 0 = its own channel count
 };
 
 struct OpSaved {           // what the backward pass of a record needs from its forward pass
@@ -730,24 +748,49 @@ static int plan_forward(Plan& P, const float* x_in, void* const* bn_stats, float
 }
 
 // Tape.backward's give(): the first gradient of a tensor is kept, later ones are added in arrival order
-static int give(Plan& P, int tensor, float* gptr, long long numel, hipStream_t st, int32_t* amax = nullptr) {
+// gptr: [rows, c] with row pitch ld floats (0 = c: contiguous; numel = rows * c)
+static int give(Plan& P, int tensor, float* gptr, long long numel, hipStream_t st, int32_t* amax = nullptr, int ld = 0,
+                int c = 0) {
   Arena& A = P.A;
   if (tensor < 0 || !P.made[tensor] || !gptr) return GCL_OK;
   TState& g = P.g[tensor];
   if (!g.ptr) {
     g = TState();
     g.ptr = gptr;
+    g.ld = ld;
     g.amax = amax;        // published by the producing kernel (valid while the gradient stays this one tensor)
     return GCL_OK;
   }
   float* sum = A.take_n<float>(numel);
   if (!A.dry) {
-    hipLaunchKernelGGL(k_add2, dim3(grid_for(numel / 4)), dim3(256), 0, st, (const float4*)g.ptr, (const float4*)gptr, numel / 4,
-                       (float4*)sum);
+    if (g.ld || ld) {
+      GCL_CHECK_ARG(c > 0 && c % 4 == 0, "gcl_plan_backward: a sliced gradient needs its channel count");
+      hipLaunchKernelGGL(k_add2_ld, dim3(grid_for(numel / 4)), dim3(256), 0, st, (const float*)g.ptr, g.ld ? g.ld : c,
+                         (const float*)gptr, ld ? ld : c, numel / c, c / 4, (float4*)sum);
+    } else {
+      hipLaunchKernelGGL(k_add2, dim3(grid_for(numel / 4)), dim3(256), 0, st, (const float4*)g.ptr, (const float4*)gptr,
+                         numel / 4, (float4*)sum);
+    }
     GCL_CHECK_LAUNCH();
   }
   g = TState();
   g.ptr = sum;
+  return GCL_OK;
+}
+
+// a gradient that is a column slice, for consumers that want contiguous rows: copied once (rare paths only -- the
+// BatchNorm backward kernels and the convolution epilogue read slices as they are)
+static int contiguous(Plan& P, TState& g, long long rows, int c, hipStream_t st) {
+  if (!g.ld || !g.ptr) return GCL_OK;
+  Arena& A = P.A;
+  float* out = A.take_n<float>(rows * c);
+  if (!A.dry) {
+    hipLaunchKernelGGL(k_add2_ld, dim3(grid_for(rows * c / 4)), dim3(256), 0, st, (const float*)g.ptr, g.ld, (const float*)nullptr,
+                       0, rows, c / 4, (float4*)out);
+    GCL_CHECK_LAUNCH();
+  }
+  g = TState();
+  g.ptr = out;
   return GCL_OK;
 }
 
@@ -793,13 +836,14 @@ static int conv_backward(Plan& P, int i, TState dy, void* const* grads, hipStrea
     GCL_CHECK_ARG(A.dry || m.kernel_size == 1 || tbl, "gcl_plan_backward: record %d needs a sorted table the maps do not carry", i);
     const bool pl = pl_x;
     float* acc = P.g[op.x].ptr;       // a gradient that already reached x through another path: added in the epilogue
+    const int acc_ld = P.g[op.x].ld;  // ... possibly a column slice of a cat's gradient
     float* dx = A.take_n<float>(n_in * op.cin);
     {
       ProfScope ps(P, st, acc ? 1 : 0, pairs, op.cout, op.cin, n_out, n_in, op.K);
       if (acc)
-        PLAN_CALL(gcl_conv_fwd_fused(pl ? (const float*)dy.planes : dy.ptr, n_out, pl ? 1 : 0, P.pack_bwd + P.off_bwd[wi], 4,
-                                     dy.amax, w_amax, tbl, order, mask, n_in, op.K, op.cout, op.cin, nullptr, nullptr, acc, 0,
-                                     nullptr, dx, nullptr, 0, (void*)st));
+        PLAN_CALL(gcl_conv_fwd_fused_ld(pl ? (const float*)dy.planes : dy.ptr, n_out, pl ? 1 : 0, P.pack_bwd + P.off_bwd[wi], 4,
+                                        dy.amax, w_amax, tbl, order, mask, n_in, op.K, op.cout, op.cin, nullptr, nullptr, acc,
+                                        acc_ld, 0, nullptr, dx, nullptr, 0, (void*)st));
       else
         PLAN_CALL(gcl_conv_fwd(pl ? (const float*)dy.planes : dy.ptr, n_out, pl ? 1 : 0, P.pack_bwd + P.off_bwd[wi], 4, dy.amax,
                                w_amax, tbl, order, mask, n_in, op.K, op.cout, op.cin, nullptr, dx, nullptr, 0, (void*)st));
@@ -862,22 +906,25 @@ static int plan_backward(Plan& P, const float* dy, void* const* grads, int first
         float* sum_g = (float*)grads[op.bn_b];
         float* sum_gx = (float*)grads[op.bn_w];
         double* scratch = A.take_n<double>(gcl_bn_scratch_len(n_out, c));
-        PLAN_CALL(gcl_bn_bwd_reduce(sv.conv_out, g.ptr, nullptr, (const uint64_t*)sv.mask, n_out, c, sv.mean, sv.rstd, op.relu,
-                                    scratch, sum_g, sum_gx, (void*)st));
+        PLAN_CALL(gcl_bn_bwd_reduce_ld(sv.conv_out, g.ptr, g.ld, nullptr, (const uint64_t*)sv.mask, n_out, c, sv.mean, sv.rstd,
+                                       op.relu, scratch, sum_g, sum_gx, (void*)st));
         TState d;
         d.ptr = A.take_n<float>(n_out * c);
         d.amax = new_slot(P);
         float* dres = op.x2 >= 0 ? A.take_n<float>(n_out * c) : nullptr;
-        PLAN_CALL(gcl_bn_bwd_apply(sv.conv_out, g.ptr, nullptr, (const uint64_t*)sv.mask, n_out, c, sv.mean, sv.rstd,
-                                   (const float*)P.params[op.bn_w], sum_g, sum_gx, op.relu, d.ptr, dres, d.amax, (void*)st));
+        PLAN_CALL(gcl_bn_bwd_apply_ld(sv.conv_out, g.ptr, g.ld, nullptr, (const uint64_t*)sv.mask, n_out, c, sv.mean, sv.rstd,
+                                      (const float*)P.params[op.bn_w], sum_g, sum_gx, op.relu, d.ptr, dres, d.amax,
+                                      (void*)st));
         if ((rc = conv_backward(P, i, d, grads, st))) return rc;
-        if ((rc = give(P, op.x2, dres, n_out * c, st))) return rc;
+        if ((rc = give(P, op.x2, dres, n_out * c, st, nullptr, 0, c))) return rc;
         break;
       }
       case GCL_OP_CONV:
+        if ((rc = contiguous(P, g, n_out, op.cout, st))) return rc;
         if ((rc = conv_backward(P, i, g, grads, st))) return rc;
         break;
       case GCL_OP_RELU: {
+        if ((rc = contiguous(P, g, n_out, op.cout, st))) return rc;
         const long long numel = n_out * op.cout;
         float* gx = A.take_n<float>(numel);
         int32_t* slot = new_slot(P);
@@ -886,11 +933,20 @@ static int plan_backward(Plan& P, const float* dy, void* const* grads, int first
                              (const float4*)P.t[op.y].ptr, numel / 4, (float4*)gx, slot);
           GCL_CHECK_LAUNCH();
         }
-        if ((rc = give(P, op.x, gx, numel, st, slot))) return rc;
+        if ((rc = give(P, op.x, gx, numel, st, slot, 0, op.cout))) return rc;
         break;
       }
       case GCL_OP_CAT: {
+        // the gradients of the two inputs ARE the column slices of g: handed on as views (row pitch = the cat's width); their
+        // readers -- the BatchNorm backward kernels, a convolution epilogue that adds a waiting gradient -- take the pitch
         const int ca = op.cin, cb = op.cout - op.cin;
+        static const int cat_views = [] { const char* e = getenv("GCL_CAT_VIEWS"); return e ? atoi(e) : 1; }();
+        if ((rc = contiguous(P, g, n_out, op.cout, st))) return rc;
+        if (cat_views) {
+          if ((rc = give(P, op.x, g.ptr, n_out * ca, st, nullptr, op.cout, ca))) return rc;
+          if ((rc = give(P, op.x2, g.ptr + ca, n_out * cb, st, nullptr, op.cout, cb))) return rc;
+          break;
+        }
         float* ga = A.take_n<float>(n_out * ca);
         float* gb = A.take_n<float>(n_out * cb);
         if (!A.dry) {
@@ -903,10 +959,11 @@ static int plan_backward(Plan& P, const float* dy, void* const* grads, int first
         break;
       }
       case GCL_OP_ROWNORM: {
+        if ((rc = contiguous(P, g, n_out, op.cout, st))) return rc;
         float* dx = A.take_n<float>(n_in * op.cin);
         int32_t* slot = new_slot(P);
         PLAN_CALL(gcl_row_normalize_bwd(P.t[op.y].ptr, g.ptr, P.saved[i].norm, n_out, op.cout, dx, slot, (void*)st));
-        if ((rc = give(P, op.x, dx, n_in * op.cin, st, slot))) return rc;
+        if ((rc = give(P, op.x, dx, n_in * op.cin, st, slot, 0, op.cin))) return rc;
         break;
       }
       default:

@@ -248,6 +248,13 @@ int gcl_conv_fwd_fused(const float* x, int64_t n_in, int32_t x_is_planes, const 
                        const int32_t* tile_mask, int64_t n_out, int32_t K, int32_t cin, int32_t cout, const float* bias,
                        const float* col_scale, const float* residual, int32_t relu, int32_t* y_amax, float* y,
                        float* stats, int32_t flags, void* stream);
+/* the same with `residual` a column slice of a wider row-major tensor: row pitch residual_ld floats (0 = cout).  Used by the
+ * backward pass for the gradient of an ME.cat input, which is a slice of the gradient of the cat's output (no split copy). */
+int gcl_conv_fwd_fused_ld(const float* x, int64_t n_in, int32_t x_is_planes, const void* wp, int32_t prec,
+                          const int32_t* x_amax, const int32_t* w_amax, const int32_t* tbl, const int32_t* order,
+                          const int32_t* tile_mask, int64_t n_out, int32_t K, int32_t cin, int32_t cout, const float* bias,
+                          const float* col_scale, const float* residual, int32_t residual_ld, int32_t relu,
+                          int32_t* y_amax, float* y, float* stats, int32_t flags, void* stream);
 
 /* dW[k] = sum over pairs of offset k of  A[pair_a]^T . B[pair_b]   (A: [*, ca], B: [*, cb]) -> dw [K, ca, cb].
  * Forward conv: A = X, pair_a = pair_in, B = dY, pair_b = pair_out.  Transposed conv: roles swapped.
@@ -317,10 +324,17 @@ int64_t gcl_bn_mask_len(int64_t n, int32_t c);                  /* uint64 words 
 int gcl_bn_bwd_reduce(const float* x, const float* dy, const float* y, const uint64_t* relu_mask, int64_t n,
                       int32_t c, const float* mean, const float* rstd, int32_t relu, double* scratch,
                       float* sum_g, float* sum_gx, void* stream);
+/* ... with dy a column slice of a wider tensor: row pitch dy_ld floats (0 = c) */
+int gcl_bn_bwd_reduce_ld(const float* x, const float* dy, int32_t dy_ld, const float* y, const uint64_t* relu_mask, int64_t n,
+                         int32_t c, const float* mean, const float* rstd, int32_t relu, double* scratch, float* sum_g,
+                         float* sum_gx, void* stream);
 int gcl_bn_bwd_apply(const float* x, const float* dy, const float* y, const uint64_t* relu_mask, int64_t n, int32_t c,
                      const float* mean, const float* rstd, const float* weight,
                      const float* sum_g, const float* sum_gx, int32_t relu,
                      float* dx, float* dres, int32_t* dx_amax, void* stream);
+int gcl_bn_bwd_apply_ld(const float* x, const float* dy, int32_t dy_ld, const float* y, const uint64_t* relu_mask, int64_t n,
+                        int32_t c, const float* mean, const float* rstd, const float* weight, const float* sum_g,
+                        const float* sum_gx, int32_t relu, float* dx, float* dres, int32_t* dx_amax, void* stream);
 
 /* Row-wise L2 normalisation of the output features, y = x / ||x||_2 (model/resunet.py:226-230; no epsilon, as there).
  * norm[n] keeps the row norms for the backward pass: dx = (dy - y (y . dy)) / norm.  c: power of two in [4, 256].
