@@ -1892,13 +1892,15 @@ static int bwd_weight_wgs(long long n_chunks) {
 // ---------------------------------------------------------------------------------------------------
 // first layer (Cin <= 4 -> 32): VALU kernels over the neighbour table
 // ---------------------------------------------------------------------------------------------------
-// OCCUPANCY INPUT (presence != NULL, *not_ones == 0, cin == 1): every feature is exactly 1.0f -- what the reference's
-// test loaders and scripts feed (torch.ones((n, 1)), no transform; its training loaders add lib/transforms.py:18 Jitter to
-// the centre cloud, so training takes the table path).  x[nbr[k][v]] is then bit k of the row's presence words: the
-// forward adds W[k] over the set bits (k_stem_fwd_occ; this kernel returns at once), the weight gradient fills its 0/1
-// tile from the words.  Same values in the same order: bitwise identical to the table path, which any other input takes
-// (device-side flag, no host decision).  Measured at 0.53 M rows, K = 125: forward 150 -> 48 us, weight gradient
-// 195 -> 157 us (tools/micro/stem_time.py).
+// OCCUPANCY ROWS (presence != NULL, cin == 1, not_ones[v] == 0): every feature row v gathers is exactly 1.0f -- what the
+// reference's loaders feed (torch.ones((n, 1))): its test loaders and scripts for every cloud, its training loaders for
+// the six neighbour clouds of a sample; only the centre cloud carries lib/transforms.py:18 Jitter (prob. 0.95;
+// lib/colocation_data_loader.py:401-415).  A row's neighbours lie in its own cloud (the batch index is part of the key),
+// so the flag is per cloud, spread to rows by gcl_not_ones_rows.  x[nbr[k][v]] is then bit k of the row's presence
+// words: the forward adds W[k] over the set bits (k_stem_fwd_occ; this kernel skips the row), the weight gradient fills
+// its 0/1 tile from the words.  Same values in the same order: bitwise identical to the table path, which every other
+// row takes (device-side flags, no host decision).  Measured at 0.53 M rows, K = 125, all rows occupancy: forward
+// 150 -> 48 us, weight gradient 195 -> 157 us (tools/micro/stem_time.py).
 __global__ void __launch_bounds__(256) k_stem_fwd(const float* __restrict__ x, const float* __restrict__ w,
                                                   const int* __restrict__ nbr, long long n_out, int K, int cin,
                                                   int cout, float* __restrict__ y, const unsigned* __restrict__ presence,
@@ -1911,7 +1913,7 @@ __global__ void __launch_bounds__(256) k_stem_fwd(const float* __restrict__ x, c
 #pragma unroll
   for (int c = 0; c < 32; ++c) acc[c] = 0.f;
   constexpr int STEM_B = 25;
-  if (presence && cin == 1 && *not_ones == 0) return;      // k_stem_fwd_occ, enqueued right behind, produces y
+  if (presence && cin == 1 && not_ones[v] == 0) return;    // k_stem_fwd_occ, enqueued right behind, writes this row
   {
   // offsets in batches of STEM_B: all table reads of a batch are issued first, then all feature gathers, then the FMAs --
   // the walk is bound by the latency of these two dependent loads (one table entry per offset and row, 265 MB at K = 125
@@ -1951,7 +1953,6 @@ __global__ void __launch_bounds__(256) k_stem_fwd_occ(const float* __restrict__ 
                                                       const int* __restrict__ not_ones, long long n_out, int K, int cout,
                                                       float* __restrict__ y) {
   __shared__ __attribute__((aligned(16))) float Ws[128 * 32];
-  if (*not_ones != 0) return;
   const int cb0 = blockIdx.y * 32;
   for (int e = threadIdx.x; e < K * 8; e += 256) {
     const int k = e >> 3, q = e & 7;
@@ -1962,7 +1963,7 @@ __global__ void __launch_bounds__(256) k_stem_fwd_occ(const float* __restrict__ 
   const int sub = threadIdx.x & 7;
   for (int pass = 0; pass < STEM_OCC_ROWS / 32; ++pass) {
     const long long v = (long long)blockIdx.x * STEM_OCC_ROWS + pass * 32 + (threadIdx.x >> 3);
-    if (v >= n_out) continue;
+    if (v >= n_out || not_ones[v] != 0) continue;      // flagged rows: k_stem_fwd's table walk
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int q = 0; q < words; ++q) {
       unsigned bits = presence[v * words + q];
@@ -1994,7 +1995,7 @@ __global__ void __launch_bounds__(256) k_stem_bwd_weight(const float* __restrict
                                                          int cin, int cout, float* slabs,
                                                          const unsigned* __restrict__ presence,
                                                          const int* __restrict__ not_ones) {
-  const bool occupancy = presence && cin == 1 && *not_ones == 0;      // see k_stem_fwd
+  const bool occ_rows = presence && cin == 1;      // see k_stem_fwd: per row, not_ones[row] == 0
   __shared__ float As[128 * STEM_LD];
   const int cb0 = blockIdx.y * 32;             // 32-column block of dY / dW          // 66 KB; reused as the cross-wave reduction buffer [4][4*16*64]
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -2014,6 +2015,7 @@ __global__ void __launch_bounds__(256) k_stem_bwd_weight(const float* __restrict
         const int r = threadIdx.x & (STEM_TILE - 1), kq = threadIdx.x >> 7;
         const long long row = r0 + r;
         const bool rv = row < r_end;
+        const bool occupancy = occ_rows && (!rv || not_ones[row] == 0);
         if (occupancy) {      // A[k][row] = bit k of the row's presence words (1.0 / 0.0), no table read, no gather
           const int words = (K + 31) >> 5;
           unsigned bits[4] = {0u, 0u, 0u, 0u};

@@ -725,12 +725,24 @@ __global__ void __launch_bounds__(256) k_presence_bits(const int* __restrict__ n
     bits[v * words + q] = m;
   }
 }
-// *flag = 1 when some element differs from 1.0f (flag zero-initialised by the caller)
-__global__ void __launch_bounds__(256) k_not_all_ones(const float* __restrict__ x, long long n, int* flag) {
-  bool bad = false;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-    bad = bad || (x[i] != 1.0f);
-  if (__any(bad) && (threadIdx.x & 63) == 0) atomicExch(flag, 1);
+// per-cloud flags: cloud[b] = 1 when some feature of a row with batch index b differs from 1.0f (cloud[] zeroed by the
+// entry; rows whose batch index does not fit the array are flagged themselves in the second pass)
+__global__ void __launch_bounds__(256) k_not_ones_clouds(const float* __restrict__ x, int cin, const int* __restrict__ coords,
+                                                         long long n, int* cloud, int n_cloud) {
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long long)gridDim.x * blockDim.x) {
+    bool bad = false;
+    for (int c = 0; c < cin; ++c) bad = bad || (x[v * cin + c] != 1.0f);
+    const int b = coords[v * 4];
+    if (bad && b >= 0 && b < n_cloud) cloud[b] = 1;      // same value from every writer
+  }
+}
+// rows[v] = 0 when every feature of v's cloud is 1.0f -- a row's kernel-map neighbours share its batch index
+__global__ void __launch_bounds__(256) k_not_ones_rows(const int* __restrict__ coords, long long n,
+                                                       const int* __restrict__ cloud, int n_cloud, int* rows) {
+  const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n) return;
+  const int b = coords[v * 4];
+  rows[v] = (b >= 0 && b < n_cloud) ? cloud[b] : 1;
 }
 
 // ---- the same mask sort for SEVERAL tables per launch (gcl_table_sort_multi) --------------------------------------
@@ -1054,12 +1066,18 @@ int gcl_presence_bits(const int32_t* nbr, int32_t K, int64_t n, uint32_t* bits, 
   return GCL_OK;
 }
 
-int gcl_not_all_ones(const float* x, int64_t n, int32_t* flag, void* stream) {
-  GCL_CHECK_ARG(x && flag && n > 0, "gcl_not_all_ones: bad argument");
-  long long g = cdiv(n, 256 * 8);
-  if (g > 256) g = 256;
-  if (g < 1) g = 1;
-  hipLaunchKernelGGL(k_not_all_ones, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, (long long)n, flag);
+int gcl_not_ones_rows(const float* x, int32_t cin, const int32_t* coords, int64_t n, int32_t* cloud_flags,
+                      int32_t n_cloud_flags, int32_t* row_flags, void* stream) {
+  GCL_CHECK_ARG(x && coords && cloud_flags && row_flags && n > 0 && cin >= 1 && n_cloud_flags >= 1,
+                "gcl_not_ones_rows: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  GCL_CHECK_HIP(hipMemsetAsync(cloud_flags, 0, sizeof(int32_t) * (size_t)n_cloud_flags, st));
+  long long g = cdiv(n, 256 * 4);
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(k_not_ones_clouds, dim3((unsigned)g), dim3(256), 0, st, x, cin, (const int*)coords, (long long)n,
+                     (int*)cloud_flags, n_cloud_flags);
+  hipLaunchKernelGGL(k_not_ones_rows, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, (const int*)coords, (long long)n,
+                     (const int*)cloud_flags, n_cloud_flags, (int*)row_flags);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }

@@ -375,7 +375,7 @@ struct PassState {        // everything one forward pass leaves behind for its b
   bool forward_done = false, bwd_packed = false;
   hipEvent_t fwd_packs = nullptr;      // recorded on the aux stream behind the forward packs of the pass
   bool fwd_packs_pending = false;
-  int32_t* not_ones = nullptr;      // device flag of the pass: some input feature differs from 1.0f (occupancy path off)
+  int32_t* not_ones = nullptr;      // per input row of the pass: its cloud has a feature that differs from 1.0f (table path)
   void* key = nullptr;              // the pass's arena: how gcl_plan_backward / gcl_plan_release find it
 };
 
@@ -486,12 +486,15 @@ static bool is_stem(const gcl_plan_op& op, const gcl_map_desc& m) {
   return op.cin <= 4 && (op.cout % 32) == 0 && !op.transpose && m.kernel_size > 1 && op.bias < 0;
 }
 
-// occupancy path of the first layer: measure once per pass whether every input feature is exactly 1.0f (device flag)
+// occupancy rows of the first layer: measured once per pass, per cloud (the reference's training loaders jitter the centre
+// cloud of a sample only), spread to rows -- device flags, no host decision
 static int stem_flag(Plan& P, const gcl_plan_op& op, const gcl_map_desc& m, const TState& x, long long n_in, hipStream_t st) {
   Arena& A = P.A;
   if (!m.presence || P.not_ones) return GCL_OK;
-  P.not_ones = new_slot(P);        // a zeroed word of the slot pool
-  PLAN_CALL(gcl_not_all_ones(x.ptr, n_in * op.cin, P.not_ones, (void*)st));
+  constexpr int CLOUD_FLAGS = 4096;      // batch indices beyond this take the table path
+  int32_t* cloud = A.take_n<int32_t>(CLOUD_FLAGS);
+  P.not_ones = A.take_n<int32_t>(n_in);
+  PLAN_CALL(gcl_not_ones_rows(x.ptr, op.cin, P.maps->coords[op.level_in], n_in, cloud, CLOUD_FLAGS, P.not_ones, (void*)st));
   return GCL_OK;
 }
 

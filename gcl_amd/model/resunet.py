@@ -86,11 +86,12 @@ class ResUNet2(ME.MinkowskiNetwork):
             old = merged.get(key, ((), False))
             merged[key] = (tuple(sorted(set(old[0]) | set(bool(t) for t in tables))), (old[1] or bool(pairs)) and training)
         out = [k + v for k, v in merged.items()]
-        if self.conv1.in_channels == 1 and not training and os.environ.get("GCL_STEM_OCC", "1") != "0":
-            # inference feeds occupancy features (lib/data_loaders.py test sets / scripts/test_kitti.py: torch.ones((n, 1)),
-            # no transform): presence words of the first layer's table, its kernels then add W[k] over the set bits.
-            # Training batches carry lib/transforms.py:18 Jitter on the centre cloud, so they would pay for the words and
-            # take the table path anyway.
+        if self.conv1.in_channels == 1 and os.environ.get("GCL_STEM_OCC", "1") != "0":
+            # the reference's loaders feed occupancy features, torch.ones((n, 1)): every cloud at inference
+            # (lib/data_loaders.py test sets / scripts/test_kitti.py), the neighbour clouds of a sample in training -- only
+            # the centre cloud carries lib/transforms.py:18 Jitter (lib/colocation_data_loader.py:401-415).  With the
+            # presence words of the first layer's table its kernels add W[k] over the set bits for the rows of all-ones
+            # clouds and walk the table for the others (per-row device flags, bitwise the same results).
             k1 = (1, self.conv1.kernel_size, 1)
             out = [(s + ("presence",)) if s[:3] == k1 else s for s in out]
         return out

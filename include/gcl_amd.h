@@ -279,15 +279,20 @@ int gcl_conv_bwd_weight(const float* a, int64_t n_a, const float* b, int64_t n_b
 
 /* First layer (Cin <= 4, Cout a multiple of 32, any ks <= 5): VALU kernels over the nbr table (one 32-column block per
  * workgroup column).  Other first-layer widths go through gcl_conv_fwd / gcl_conv_bwd_weight (generic shapes). */
-/* Occupancy input: `presence` (uint32 [n_out][ceil(K / 32)], gcl_presence_bits of `nbr`) and `not_ones` (device int32,
- * 0 = every input feature equals 1.0f; gcl_not_all_ones) are optional and go together.  When given, cin == 1 and the flag
- * is 0 -- the input of the reference's test loaders and scripts (torch.ones((n, 1)), no transform; its training loaders
- * add lib/transforms.py:18 Jitter to the centre cloud) -- x[nbr[k][v]] is bit k of the row's presence words:
- * gcl_stem_fwd adds W[k] over the SET bits, k ascending (k_stem_fwd_occ; the table kernel is enqueued too and returns at
- * once), gcl_stem_bwd_weight fills its 0/1 tile from the words.  Same values added in the same order: bitwise identical
- * to the table path, which any other input takes (the flag is read on the device, no host decision). */
+/* Occupancy rows: `presence` (uint32 [n_out][ceil(K / 32)], gcl_presence_bits of `nbr`) and `not_ones` (device int32
+ * [n_out], 0 = every feature row v gathers equals 1.0f; gcl_not_ones_rows) are optional and go together; cin must be 1.
+ * The reference's loaders feed torch.ones((n, 1)): its test loaders and scripts for every cloud, its training loaders for
+ * the neighbour clouds of a sample -- only the centre cloud carries lib/transforms.py:18 Jitter
+ * (lib/colocation_data_loader.py:401-415).  For a row with flag 0, x[nbr[k][v]] is bit k of the row's presence words:
+ * gcl_stem_fwd adds W[k] over the SET bits, k ascending (k_stem_fwd_occ; the table kernel is enqueued too and skips
+ * those rows), gcl_stem_bwd_weight fills its 0/1 tile from the words.  Same values added in the same order: bitwise
+ * identical to the table path, which every flagged row takes (flags are read on the device, no host decision).
+ * gcl_not_ones_rows: a row's kernel-map neighbours share its batch index (coords[v][0], part of the key), so the flag is
+ * per cloud: cloud_flags (int32 [n_cloud_flags] scratch, zeroed here) gets 1 for a batch index with a feature != 1.0f,
+ * row_flags[v] = cloud_flags[batch index of v] (1 when the index does not fit the scratch). */
 int gcl_presence_bits(const int32_t* nbr, int32_t K, int64_t n, uint32_t* bits, void* stream);
-int gcl_not_all_ones(const float* x, int64_t n, int32_t* flag, void* stream);      /* flag must be zero on entry */
+int gcl_not_ones_rows(const float* x, int32_t cin, const int32_t* coords, int64_t n, int32_t* cloud_flags,
+                      int32_t n_cloud_flags, int32_t* row_flags, void* stream);
 int gcl_stem_fwd(const float* x, const float* w, const int32_t* nbr, int64_t n_out, int32_t K,
                  int32_t cin, int32_t cout, float* y, const uint32_t* presence, const int32_t* not_ones, void* stream);
 int64_t gcl_stem_bwd_weight_scratch_len(int32_t K, int32_t cin, int32_t cout, int64_t n_out);

@@ -221,17 +221,20 @@ def test_stem_conv_vs_oracle(cin, ks):
 
 @pytest.mark.parametrize("ks,n", [(5, 3000), (3, 700), (5, 1)])
 def test_stem_occupancy_path_is_bitwise_the_general_path(ks, n):
-    """Occupancy input (all features exactly 1.0, what the reference's loaders feed): gcl_stem_fwd / gcl_stem_bwd_weight
-    given presence words + the device flag produce bit for bit what they produce from the neighbour table; an input
-    that is not all ones raises the flag and takes the general path (same bits as without presence)."""
+    """Occupancy rows (features exactly 1.0: what the reference's loaders feed for every cloud but a training sample's
+    jittered centre cloud, lib/colocation_data_loader.py:401-415): gcl_stem_fwd / gcl_stem_bwd_weight given presence words
+    + per-row flags produce bit for bit what they produce from the neighbour table -- with every cloud all ones, with one
+    cloud of the batch carrying other values (its rows walk the table, the other clouds' rows use the words), with all."""
     from gcl_amd import _lib
     lib = _lib.load()
-    C = random_cloud(5, n=n, extent=12, batch=2) if n > 1 else np.zeros((1, 4), np.int32)
+    C = random_cloud(5, n=n, extent=12, batch=3) if n > 1 else np.zeros((1, 4), np.int32)
     mgr = make_mgr(C)
     kmap = mgr.get_kernel_map(1, ks, 1)
     K, n_out = kmap.nbr.shape[0], len(C)
     words = (K + 31) // 32
+    batch_idx = torch.from_numpy(C[:, 0].astype(np.int64)).to(DEV)
     with torch.cuda.device(DEV):
+        Cd = torch.from_numpy(np.ascontiguousarray(C, dtype=np.int32)).to(DEV)
         bits = torch.empty(n_out * words, dtype=torch.int32, device=DEV)
         _lib.check(lib.gcl_presence_bits(_lib.ptr(kmap.nbr), K, n_out, _lib.ptr(bits), _lib.stream()), "gcl_presence_bits")
         nb = kmap.nbr.cpu().numpy()
@@ -242,28 +245,34 @@ def test_stem_occupancy_path_is_bitwise_the_general_path(ks, n):
         g = torch.Generator().manual_seed(ks)
         W = torch.randn(K, 1, 32, generator=g).to(DEV)
         dy = torch.randn(n_out, 32, generator=g).to(DEV)
-        for ones in (True, False):
+        noise = 1.0 + 0.01 * torch.randn(n_out, 1, generator=g).to(DEV)
+        n_clouds = int(C[:, 0].max()) + 1
+        for jittered in ((), (n_clouds - 1,), tuple(range(n_clouds))):
             x = torch.ones(n_out, 1, device=DEV)
-            if not ones:
-                x[n_out // 2] = 1.0000001
-            flag = torch.zeros(1, dtype=torch.int32, device=DEV)
-            _lib.check(lib.gcl_not_all_ones(_lib.ptr(x), n_out, _lib.ptr(flag), _lib.stream()), "gcl_not_all_ones")
-            assert int(flag.item()) == (0 if ones else 1)
-            ys, dws = [], []
-            for pres in (None, bits):
-                y = torch.full((n_out, 32), float("nan"), device=DEV)
-                _lib.check(lib.gcl_stem_fwd(_lib.ptr(x), _lib.ptr(W), _lib.ptr(kmap.nbr), n_out, K, 1, 32, _lib.ptr(y),
-                                            _lib.ptr(pres) if pres is not None else None,
-                                            _lib.ptr(flag) if pres is not None else None, _lib.stream()), "gcl_stem_fwd")
-                scratch = torch.empty(lib.gcl_stem_bwd_weight_scratch_len(K, 1, 32, n_out), dtype=torch.float32, device=DEV)
-                dw = torch.empty(K, 1, 32, device=DEV)
-                _lib.check(lib.gcl_stem_bwd_weight(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(kmap.nbr), n_out, K, 1, 32,
-                                                   _lib.ptr(scratch), _lib.ptr(dw),
-                                                   _lib.ptr(pres) if pres is not None else None,
-                                                   _lib.ptr(flag) if pres is not None else None, _lib.stream()),
-                           "gcl_stem_bwd_weight")
-                ys.append(y), dws.append(dw)
-            assert torch.equal(ys[0], ys[1]) and torch.equal(dws[0], dws[1]), ones
+            for b in jittered:
+                x = torch.where((batch_idx == b)[:, None], noise, x)
+            for n_flags in (4096, 1):          # 1: batch indices beyond the scratch are flagged (table path), same bits
+                cloud = torch.full((n_flags,), -1, dtype=torch.int32, device=DEV)
+                rows = torch.full((n_out,), -1, dtype=torch.int32, device=DEV)
+                _lib.check(lib.gcl_not_ones_rows(_lib.ptr(x), 1, _lib.ptr(Cd), n_out, _lib.ptr(cloud), n_flags, _lib.ptr(rows),
+                                                 _lib.stream()), "gcl_not_ones_rows")
+                want_rows = np.isin(C[:, 0], [b for b in jittered if (x[batch_idx == b] != 1).any()]) | (C[:, 0] >= n_flags)
+                assert np.array_equal(rows.cpu().numpy(), want_rows.astype(np.int32)), (jittered, n_flags)
+                ys, dws = [], []
+                for pres in (None, bits):
+                    y = torch.full((n_out, 32), float("nan"), device=DEV)
+                    _lib.check(lib.gcl_stem_fwd(_lib.ptr(x), _lib.ptr(W), _lib.ptr(kmap.nbr), n_out, K, 1, 32, _lib.ptr(y),
+                                                _lib.ptr(pres) if pres is not None else None,
+                                                _lib.ptr(rows) if pres is not None else None, _lib.stream()), "gcl_stem_fwd")
+                    scratch = torch.empty(lib.gcl_stem_bwd_weight_scratch_len(K, 1, 32, n_out), dtype=torch.float32, device=DEV)
+                    dw = torch.empty(K, 1, 32, device=DEV)
+                    _lib.check(lib.gcl_stem_bwd_weight(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(kmap.nbr), n_out, K, 1, 32,
+                                                       _lib.ptr(scratch), _lib.ptr(dw),
+                                                       _lib.ptr(pres) if pres is not None else None,
+                                                       _lib.ptr(rows) if pres is not None else None, _lib.stream()),
+                               "gcl_stem_bwd_weight")
+                    ys.append(y), dws.append(dw)
+                assert torch.equal(ys[0], ys[1]) and torch.equal(dws[0], dws[1]), (jittered, n_flags)
 
 
 @pytest.mark.parametrize("n", [1, 31, 33, 127, 129, 1000])

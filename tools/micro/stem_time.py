@@ -19,7 +19,10 @@ dy = torch.randn(n, 32, device=dev)
 y = torch.empty(n, 32, device=dev)
 dw = torch.empty(K, 1, 32, device=dev)
 bits = torch.empty(n * words, dtype=torch.int32, device=dev)
-flag = torch.zeros(1, dtype=torch.int32, device=dev)
+cloud = torch.zeros(4096, dtype=torch.int32, device=dev)
+rows = torch.zeros(n, dtype=torch.int32, device=dev)
+xb = batch["sinput_F"].to(dev).float().contiguous()      # the batch's own features: centre clouds jittered, the others ones
+Ci = C.int().contiguous()
 scratch = torch.empty(lib.gcl_stem_bwd_weight_scratch_len(K, 1, 32, n), dtype=torch.float32, device=dev)
 s = _lib.stream()
 p = _lib.ptr
@@ -36,7 +39,10 @@ def timed(name, fn):
 
 
 timed("presence_bits", lambda: lib.gcl_presence_bits(p(km.nbr), K, n, p(bits), s))
-timed("not_all_ones", lambda: lib.gcl_not_all_ones(p(x), n, p(flag), s))
-for name, pb, pf in (("table", None, None), ("occupancy", p(bits), p(flag))):
-    timed("fwd " + name, lambda: lib.gcl_stem_fwd(p(x), p(W), p(km.nbr), n, K, 1, 32, p(y), pb, pf, s))
-    timed("bwd_weight " + name, lambda: lib.gcl_stem_bwd_weight(p(x), p(dy), p(km.nbr), n, K, 1, 32, p(scratch), p(dw), pb, pf, s))
+for label, feats in (("all ones", x), ("batch features", xb)):
+    timed("not_ones_rows " + label, lambda: lib.gcl_not_ones_rows(p(feats), 1, p(Ci), n, p(cloud), 4096, p(rows), s))
+    print(f"  rows on the table path: {int(rows.sum().item())} of {n}")
+    for name, pb, pf in (("table", None, None), ("occupancy rows", p(bits), p(rows))):
+        timed(f"fwd {name} ({label})", lambda: lib.gcl_stem_fwd(p(feats), p(W), p(km.nbr), n, K, 1, 32, p(y), pb, pf, s))
+        timed(f"bwd_weight {name} ({label})",
+              lambda: lib.gcl_stem_bwd_weight(p(feats), p(dy), p(km.nbr), n, K, 1, 32, p(scratch), p(dw), pb, pf, s))
