@@ -1901,13 +1901,13 @@ static int bwd_weight_wgs(long long n_chunks) {
 // its 0/1 tile from the words.  Same values in the same order: bitwise identical to the table path, which every other
 // row takes (device-side flags, no host decision).  Measured at 0.53 M rows, K = 125, all rows occupancy: forward
 // 150 -> 48 us, weight gradient 195 -> 157 us (tools/micro/stem_time.py).
-__global__ void __launch_bounds__(256) k_stem_fwd(const float* __restrict__ x, const float* __restrict__ w,
-                                                  const int* __restrict__ nbr, long long n_out, int K, int cin,
-                                                  int cout, float* __restrict__ y, const unsigned* __restrict__ presence,
-                                                  const int* __restrict__ not_ones) {
+static __device__ __forceinline__ void stem_fwd_table(const float* __restrict__ x, const float* __restrict__ w,
+                                                      const int* __restrict__ nbr, long long n_out, int K, int cin,
+                                                      int cout, float* __restrict__ y, const unsigned* __restrict__ presence,
+                                                      const int* __restrict__ not_ones, const long long bx) {
   // thread = output row; the weights W[k][ci][0..31] are wave-uniform and come through the scalar cache (s_load),
   // so the inner product costs one v_fmac with an SGPR operand per (offset, channel) and no LDS traffic
-  long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long v = bx * blockDim.x + threadIdx.x;
   if (v >= n_out) v = n_out - 1;   // keep the wave uniform; the duplicate rows are not stored
   float acc[32];
 #pragma unroll
@@ -1938,7 +1938,7 @@ __global__ void __launch_bounds__(256) k_stem_fwd(const float* __restrict__ x, c
     }
   }
   }
-  if ((long long)blockIdx.x * blockDim.x + threadIdx.x >= n_out) return;
+  if (bx * blockDim.x + threadIdx.x >= n_out) return;
   float4* yo = reinterpret_cast<float4*>(y + v * cout + blockIdx.y * 32);
 #pragma unroll
   for (int c4 = 0; c4 < 8; ++c4) yo[c4] = make_float4(acc[4 * c4], acc[4 * c4 + 1], acc[4 * c4 + 2], acc[4 * c4 + 3]);
@@ -1949,9 +1949,9 @@ __global__ void __launch_bounds__(256) k_stem_fwd(const float* __restrict__ x, c
 // bitwise identical.  8 lanes per row (4 columns each), the 32-column slice of W in LDS (one ds_read_b128 per set bit
 // and lane): ~20 adds per row instead of 125 table reads + gathers + 4000 FMAs.
 constexpr int STEM_OCC_ROWS = 256;      // rows per workgroup (8 passes of 32)
-__global__ void __launch_bounds__(256) k_stem_fwd_occ(const float* __restrict__ w, const unsigned* __restrict__ presence,
-                                                      const int* __restrict__ not_ones, long long n_out, int K, int cout,
-                                                      float* __restrict__ y) {
+static __device__ __forceinline__ void stem_fwd_occ(const float* __restrict__ w, const unsigned* __restrict__ presence,
+                                                    const int* __restrict__ not_ones, long long n_out, int K, int cout,
+                                                    float* __restrict__ y, const long long bx) {
   __shared__ __attribute__((aligned(16))) float Ws[128 * 32];
   const int cb0 = blockIdx.y * 32;
   for (int e = threadIdx.x; e < K * 8; e += 256) {
@@ -1962,8 +1962,8 @@ __global__ void __launch_bounds__(256) k_stem_fwd_occ(const float* __restrict__ 
   const int words = (K + 31) >> 5;
   const int sub = threadIdx.x & 7;
   for (int pass = 0; pass < STEM_OCC_ROWS / 32; ++pass) {
-    const long long v = (long long)blockIdx.x * STEM_OCC_ROWS + pass * 32 + (threadIdx.x >> 3);
-    if (v >= n_out || not_ones[v] != 0) continue;      // flagged rows: k_stem_fwd's table walk
+    const long long v = bx * STEM_OCC_ROWS + pass * 32 + (threadIdx.x >> 3);
+    if (v >= n_out || not_ones[v] != 0) continue;      // flagged rows: stem_fwd_table's walk
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int q = 0; q < words; ++q) {
       unsigned bits = presence[v * words + q];
@@ -1981,7 +1981,21 @@ __global__ void __launch_bounds__(256) k_stem_fwd_occ(const float* __restrict__ 
   }
 }
 
-constexpr int STEM_ROWS_PER_WG = 1024;
+__global__ void __launch_bounds__(256) k_stem_fwd(const float* __restrict__ x, const float* __restrict__ w,
+                                                  const int* __restrict__ nbr, long long n_out, int K, int cin, int cout,
+                                                  float* __restrict__ y, const unsigned* __restrict__ presence,
+                                                  const int* __restrict__ not_ones) {
+  stem_fwd_table(x, w, nbr, n_out, K, cin, cout, y, presence, not_ones, (long long)blockIdx.x);
+}
+// Two launches, not one: merged (table workgroups first, occupancy workgroups behind them in the same grid) the
+// occupancy rows inherit the table walk's registers and lose the occupancy that hides their LDS reads -- all-ones input
+// (every inference pass) 49 -> 72 us, the bench's training batch 97 -> 85 us.
+__global__ void __launch_bounds__(256) k_stem_fwd_occ(const float* __restrict__ w, const unsigned* __restrict__ presence,
+                                                      const int* __restrict__ not_ones, long long n_out, int K, int cout,
+                                                      float* __restrict__ y) {
+  stem_fwd_occ(w, presence, not_ones, n_out, K, cout, y, (long long)blockIdx.x);
+}
+
 constexpr int STEM_KMAX = 125;
 
 // dW[k][ci][c] = sum_v x[nbr[k][v]][ci] * dY[v][c]  as an exact-f32 MFMA GEMM: M = K offsets (4 blocks of 32),
@@ -1989,19 +2003,26 @@ constexpr int STEM_KMAX = 125;
 // with coalesced reads of the k-major neighbour table (lanes along rows) into an LDS tile A[k][row]; the MFMA phase
 // then reads A[i = offset][kk = row] from LDS (row pitch 129: conflict-free) and B[kk = row][j = channel] as a
 // coalesced row of dY.  Per-workgroup slabs + ordered reduction (k_stem_reduce).
-constexpr int STEM_TILE = 128, STEM_LD = STEM_TILE + 1;
-__global__ void __launch_bounds__(256) k_stem_bwd_weight(const float* __restrict__ x, const float* __restrict__ dy,
-                                                         const int* __restrict__ nbr, long long n_out, int K,
-                                                         int cin, int cout, float* slabs,
-                                                         const unsigned* __restrict__ presence,
-                                                         const int* __restrict__ not_ones) {
+// TILE = rows per tile.  64 (default): 33 KB of LDS and <= 128 registers, FOUR workgroups per CU -- the kernel is a chain
+// of dependent phases per tile (flags / words or table -> LDS tile -> barrier -> dY values -> 32 MFMAs per wave) and what
+// hides their latencies is other workgroups; at 128 rows (66 KB, two per CU) the launch at the end of the backward pass,
+// alone on the chip with the optimizer waiting, took 155 us at 0.53 M rows (table path 197), 92 us now (118).
+constexpr int STEM_TILE = 64;
+template <int TILE>
+__global__ void __launch_bounds__(256, TILE == 64 ? 4 : 2)
+    k_stem_bwd_weight(const float* __restrict__ x, const float* __restrict__ dy, const int* __restrict__ nbr, long long n_out,
+                      int K, int cin, int cout, float* slabs, const unsigned* __restrict__ presence,
+                      const int* __restrict__ not_ones, long long rows_per_wg) {
+  constexpr int LD = TILE + 1;            // A[k][row] pitch: conflict-free column reads
+  constexpr int G = 256 / TILE;           // fill: thread -> row t & (TILE - 1), offsets k = t / TILE + G j
+  constexpr int RW = TILE / 4;            // rows of a tile per wave in the MFMA phase
   const bool occ_rows = presence && cin == 1;      // see k_stem_fwd: per row, not_ones[row] == 0
-  __shared__ float As[128 * STEM_LD];
-  const int cb0 = blockIdx.y * 32;             // 32-column block of dY / dW          // 66 KB; reused as the cross-wave reduction buffer [4][4*16*64]
+  __shared__ float As[128 * LD > 4096 ? 128 * LD : 4096];      // also the 16 KB buffer of the cross-wave sum
+  const int cb0 = blockIdx.y * 32;             // 32-column block of dY / dW
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = l & 31, h = l >> 5;
-  const long long r_begin = (long long)blockIdx.x * STEM_ROWS_PER_WG;
-  long long r_end = r_begin + STEM_ROWS_PER_WG;
+  const long long r_begin = (long long)blockIdx.x * rows_per_wg;
+  long long r_end = r_begin + rows_per_wg;
   if (r_end > n_out) r_end = n_out;
   for (int ci = 0; ci < cin; ++ci) {
     f32x16 acc[4];
@@ -2009,10 +2030,13 @@ __global__ void __launch_bounds__(256) k_stem_bwd_weight(const float* __restrict
     for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[kb][r] = 0.f;
-    for (long long r0 = r_begin; r0 < r_end; r0 += STEM_TILE) {
+    for (long long r0 = r_begin; r0 < r_end; r0 += TILE) {
       __syncthreads();
-      {   // thread -> row r = t & 127, offsets k = (t >> 7) + 2 j; 16 table reads, then 16 gathers, in flight at a time
-        const int r = threadIdx.x & (STEM_TILE - 1), kq = threadIdx.x >> 7;
+      {
+        const int r = threadIdx.x & (TILE - 1);
+        int kq = threadIdx.x / TILE;
+        asm volatile("" : "+v"(kq));      // opaque per tile: the 128 / G products k * n_out of the table path were hoisted
+                                          // out of the tile loop and spilled (652 bytes of scratch)
         const long long row = r0 + r;
         const bool rv = row < r_end;
         const bool occupancy = occ_rows && (!rv || not_ones[row] == 0);
@@ -2021,77 +2045,101 @@ __global__ void __launch_bounds__(256) k_stem_bwd_weight(const float* __restrict
           unsigned bits[4] = {0u, 0u, 0u, 0u};
           if (rv)
             for (int q = 0; q < words && q < 4; ++q) bits[q] = presence[row * words + q];
-          for (int j = 0; j < 64; ++j) {
-            const int k = kq + 2 * j;
-            As[k * STEM_LD + r] = (k < K && ((bits[k >> 5] >> (k & 31)) & 1u)) ? 1.f : 0.f;
+          for (int j = 0; j < 128 / G; ++j) {
+            const int k = kq + G * j;
+            As[k * LD + r] = (k < K && ((bits[k >> 5] >> (k & 31)) & 1u)) ? 1.f : 0.f;
           }
         } else
-        for (int j0 = 0; j0 < 64; j0 += 16) {
-          int idx[16];
+        for (int j0 = 0; j0 < 128 / G; j0 += 8) {      // 8 table reads, then 8 gathers, in flight at a time
+          int idx[8];
 #pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            const int k = kq + 2 * (j0 + j);
+          for (int j = 0; j < 8; ++j) {
+            const int k = kq + G * (j0 + j);
             idx[j] = (rv && k < K) ? nbr[(long long)k * n_out + row] : -1;
           }
-          float a[16];
+          float a[8];
 #pragma unroll
-          for (int j = 0; j < 16; ++j) a[j] = idx[j] >= 0 ? x[(long long)idx[j] * cin + ci] : 0.f;
+          for (int j = 0; j < 8; ++j) a[j] = idx[j] >= 0 ? x[(long long)idx[j] * cin + ci] : 0.f;
 #pragma unroll
-          for (int j = 0; j < 16; ++j) As[(kq + 2 * (j0 + j)) * STEM_LD + r] = a[j];
+          for (int j = 0; j < 8; ++j) As[(kq + G * (j0 + j)) * LD + r] = a[j];
         }
       }
       __syncthreads();
-      float bv[16];      // the lane's 16 dY values of the tile: all loads in flight before the first MFMA (they were one
-#pragma unroll          // dependent load per MFMA step: 16 round trips per tile and wave)
-      for (int s = 0; s < 16; ++s) {
-        const long long row = r0 + w * 32 + 2 * s + h;
+      float bv[RW / 2];      // the lane's dY values of the tile: all loads in flight before the first MFMA
+#pragma unroll
+      for (int s = 0; s < RW / 2; ++s) {
+        const long long row = r0 + w * RW + 2 * s + h;
         bv[s] = (row < r_end) ? dy[row * cout + cb0 + i] : 0.f;
       }
-#pragma unroll 4
-      for (int s = 0; s < 16; ++s) {
-        const int rl = w * 32 + 2 * s + h;
+#pragma unroll
+      for (int s = 0; s < RW / 2; ++s) {
+        const int rl = w * RW + 2 * s + h;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
-          acc[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(kb * 32 + i) * STEM_LD + rl], bv[s], acc[kb], 0, 0, 0);
+          acc[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(kb * 32 + i) * LD + rl], bv[s], acc[kb], 0, 0, 0);
       }
     }
-    __syncthreads();
+    // cross-wave sum ((w0 + w1) + w2) + w3 through one 16 KB buffer, then wave 3 writes the workgroup's slab
     float* red = As;
+    for (int src = 0; src < 3; ++src) {
+      __syncthreads();
+      if (w == src) {
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb)
+        for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) red[w * 4096 + (kb * 16 + r) * 64 + l] = acc[kb][r];
-    __syncthreads();
-    for (int e = threadIdx.x; e < 4 * 16 * 64; e += 256) {
-      float v = red[e] + red[4096 + e] + red[8192 + e] + red[12288 + e];
-      int ll = e & 63, r = (e >> 6) & 15, kb = e >> 10;
-      int k = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ll >> 5);
-      if (k < K) slabs[((long long)blockIdx.x * K * cin + (long long)k * cin + ci) * cout + cb0 + (ll & 31)] = v;
+          for (int r = 0; r < 16; ++r) red[(kb * 16 + r) * 64 + l] = acc[kb][r];
+      }
+      __syncthreads();
+      if (w == src + 1) {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[kb][r] = red[(kb * 16 + r) * 64 + l] + acc[kb][r];
+      }
+    }
+    if (w == 3) {
+      int h_o = h;      // opaque: keeps the 64 store offsets out of the kernel's prologue (they were hoisted and spilled)
+      asm volatile("" : "+v"(h_o));
+      float* slab = slabs + ((long long)blockIdx.x * K * cin + ci) * cout + cb0 + i;
+      const int kstep = cin * cout;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int k = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h_o;
+          if (k < K) slab[k * kstep] = acc[kb][r];
+        }
     }
   }
 }
 
-// ordered sum of the per-workgroup slabs: thread = (element e = t & 63, part = t >> 6) adds slabs part, part + 4, ...
-// (4 loads in flight), the four parts are then added in order
+// ordered sum of the per-workgroup slabs: thread = (element e = t & 15, part = t >> 4) adds slabs part, part + 16, ...
+// (4 loads in flight), the sixteen parts are then added as a fixed tree.  16 elements per workgroup: 250 workgroups for the
+// 4000 elements of the 5^3 x 1 x 32 kernel (64 elements x 4 parts was 63 workgroups walking ~230 slabs each in series).
 __global__ void __launch_bounds__(256) k_stem_reduce(const float* __restrict__ slabs, int n_slabs, long long mat,
                                                      float* dw) {
-  __shared__ float red[4][64];
-  const int el = threadIdx.x & 63, part = threadIdx.x >> 6;
-  const long long e = (long long)blockIdx.x * 64 + el;
+  __shared__ float red[16][17];
+  const int el = threadIdx.x & 15, part = threadIdx.x >> 4;
+  const long long e = (long long)blockIdx.x * 16 + el;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (e < mat) {
     int b = part;
-    for (; b + 12 < n_slabs; b += 16) {
+    for (; b + 48 < n_slabs; b += 64) {
       s0 += slabs[(long long)b * mat + e];
-      s1 += slabs[(long long)(b + 4) * mat + e];
-      s2 += slabs[(long long)(b + 8) * mat + e];
-      s3 += slabs[(long long)(b + 12) * mat + e];
+      s1 += slabs[(long long)(b + 16) * mat + e];
+      s2 += slabs[(long long)(b + 32) * mat + e];
+      s3 += slabs[(long long)(b + 48) * mat + e];
     }
-    for (; b < n_slabs; b += 4) s0 += slabs[(long long)b * mat + e];
+    for (; b < n_slabs; b += 16) s0 += slabs[(long long)b * mat + e];
   }
   red[part][el] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (part == 0 && e < mat) dw[e] = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+  if (part == 0 && e < mat) {
+    float q[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) q[g] = (red[4 * g][el] + red[4 * g + 1][el]) + (red[4 * g + 2][el] + red[4 * g + 3][el]);
+    dw[e] = (q[0] + q[1]) + (q[2] + q[3]);
+  }
 }
 
 
@@ -2634,8 +2682,7 @@ int gcl_stem_fwd(const float* x, const float* w, const int32_t* nbr, int64_t n_o
                      x, w, nbr, (long long)n_out, K, cin, cout, y, (const unsigned*)presence, (const int*)not_ones);
   GCL_CHECK_LAUNCH();
   if (presence && cin == 1) {
-    // both kernels are enqueued and the device flag picks the one that works: the general kernel returns at once when
-    // the input is all ones, the occupancy kernel when it is not (no host read of the flag)
+    // both kernels are enqueued and the per-row device flags pick the rows each one writes (no host read of the flags)
     hipLaunchKernelGGL(k_stem_fwd_occ, dim3((unsigned)cdiv(n_out, STEM_OCC_ROWS), (unsigned)(cout / 32)), dim3(256), 0,
                        (hipStream_t)stream, w, (const unsigned*)presence, (const int*)not_ones, (long long)n_out, K, cout, y);
     GCL_CHECK_LAUNCH();
@@ -2643,8 +2690,21 @@ int gcl_stem_fwd(const float* x, const float* w, const int32_t* nbr, int64_t n_o
   return GCL_OK;
 }
 
+// Rows per workgroup of k_stem_bwd_weight: the tiles are dealt evenly to at most `slots` workgroups -- four per CU of an
+// MI355X, one round (a fixed 1024 rows per workgroup ran 518 workgroups on 512 places at 0.53 M rows: a second round of
+// six).  A constant, not the device's CU count: the slab count fixes the summation order of the result.
+static long long stem_rows_per_wg(long long n_out, int cout) {
+  static const int slots = [] { const char* e = getenv("GCL_STEM_DW_WGS"); int v = e ? atoi(e) : 1024; return v < 1 ? 1 : v; }();
+  int col_blocks = cout / 32;
+  long long s = slots / (col_blocks > 0 ? col_blocks : 1);
+  if (s < 1) s = 1;
+  long long per = cdiv(cdiv(n_out, STEM_TILE), s);
+  if (per < 8) per = 8;      // small inputs: few slabs rather than many workgroups
+  return per * STEM_TILE;
+}
+
 int64_t gcl_stem_bwd_weight_scratch_len(int32_t K, int32_t cin, int32_t cout, int64_t n_out) {
-  return cdiv(n_out, STEM_ROWS_PER_WG) * (long long)K * cin * cout;
+  return cdiv(n_out, stem_rows_per_wg(n_out, cout)) * (long long)K * cin * cout;
 }
 
 int gcl_stem_bwd_weight(const float* x, const float* dy, const int32_t* nbr, int64_t n_out, int32_t K, int32_t cin,
@@ -2655,11 +2715,12 @@ int gcl_stem_bwd_weight(const float* x, const float* dy, const int32_t* nbr, int
   GCL_CHECK_ARG(cin >= 1 && cin <= 4 && cout > 0 && cout % 32 == 0 && K >= 1 && K <= STEM_KMAX && n_out > 0,
                 "gcl_stem_bwd_weight: supports Cin <= 4, Cout a multiple of 32, K <= 125 (got %d, %d, %d)", cin, cout, K);
   hipStream_t st = (hipStream_t)stream;
-  int nwg = (int)cdiv(n_out, STEM_ROWS_PER_WG);
+  const long long rows_per_wg = stem_rows_per_wg(n_out, cout);
+  int nwg = (int)cdiv(n_out, rows_per_wg);
   long long mat = (long long)K * cin * cout;
-  hipLaunchKernelGGL(k_stem_bwd_weight, dim3(nwg, (unsigned)(cout / 32)), dim3(256), 0, st, x, dy, nbr, (long long)n_out, K,
-                     cin, cout, scratch, (const unsigned*)presence, (const int*)not_ones);
-  hipLaunchKernelGGL(k_stem_reduce, dim3((unsigned)cdiv(mat, 64)), dim3(256), 0, st, (const float*)scratch, nwg, mat,
+  hipLaunchKernelGGL(k_stem_bwd_weight<STEM_TILE>, dim3(nwg, (unsigned)(cout / 32)), dim3(256), 0, st, x, dy, nbr,
+                     (long long)n_out, K, cin, cout, scratch, (const unsigned*)presence, (const int*)not_ones, rows_per_wg);
+  hipLaunchKernelGGL(k_stem_reduce, dim3((unsigned)cdiv(mat, 16)), dim3(256), 0, st, (const float*)scratch, nwg, mat,
                      dw);
   GCL_CHECK_LAUNCH();
   return GCL_OK;

@@ -629,11 +629,29 @@ class FinestContrastiveLossTrainer:
             a[2] += 1
             return out
 
+        # GCL_TRACE_HELPERS=2 (diagnostic): host time stamps of every helper call / wait / enqueue and a GPU event behind
+        # every step, for tools/host_gpu_timeline.py (who waits for whom at a step boundary)
+        tl = self._timeline = [] if os.environ.get("GCL_TRACE_HELPERS") == "2" else None
+        if tl is not None:
+            torch.cuda.synchronize()
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            torch.cuda.synchronize()
+            tl.append(("anchor", 0, time.perf_counter(), e0))
+
+        def stamped(name, fn, grp):
+            if tl is None:
+                return fn(grp)
+            t0 = time.perf_counter()
+            out = fn(grp)
+            tl.append((name, 0, t0, time.perf_counter()))
+            return out
+
         def draw(grp):
-            return timed("draw", lambda g: [self._draw_for(b) for b in g], grp)
+            return timed("draw", lambda g: stamped("draw", lambda g2: [self._draw_for(b) for b in g2], g), grp)
 
         def maps(grp):
-            return timed("maps", lambda g: [self._prefetch_maps(b) for b in g], grp)
+            return timed("maps", lambda g: stamped("maps", lambda g2: [self._prefetch_maps(b) for b in g2], g), grp)
 
         depth = max(1, int(os.environ.get("GCL_PREFETCH_DEPTH", "2")))      # steps the helpers work ahead
         from collections import deque
@@ -657,7 +675,15 @@ class FinestContrastiveLossTrainer:
                     wt[0] += time.perf_counter() - w0
                     wt[2] += 1
                 refill()
-                yield self.train_step(cur if k > 1 else cur[0], draws if k > 1 else draws[0])
+                if tl is None:
+                    yield self.train_step(cur if k > 1 else cur[0], draws if k > 1 else draws[0])
+                    continue
+                w1 = time.perf_counter()
+                out = self.train_step(cur if k > 1 else cur[0], draws if k > 1 else draws[0])
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                tl.append(("step", 0, w0, w1, time.perf_counter(), ev))
+                yield out
 
     # ---- validation step (``_valid_epoch`` :306-379) -----------------------------------------------------------
     @staticmethod
