@@ -239,7 +239,7 @@ def _conv_launch(lib, x, Wk, mode, table, n_out, cin, cout, bias, pairs=0, want_
     y = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
     stats = None
     if want_stats and prec != 0:
-        stats = torch.empty(((n_out + 127) // 128, 2, cout), dtype=torch.float32, device=x.device)
+        stats = torch.empty((2, cout, (n_out + 127) // 128), dtype=torch.float32, device=x.device)     # channel-major partials
     name = None
     if PROFILE is not None:
         nb = lib.gcl_conv_fwd_nb(n_out, cout, prec)
@@ -465,7 +465,7 @@ class _BatchNormFn(torch.autograd.Function):
             mr = torch.empty((2, c), dtype=torch.float32, device=dev)          # one allocation: mean | rstd
             mean, rstd = mr[0], mr[1]
             if tile_stats is not None:      # column sums already produced by the convolution epilogue
-                nt = tile_stats.shape[0]
+                nt = tile_stats.shape[2]
                 scratch = torch.empty(lib.gcl_bn_tiles_scratch_len(nt, c), dtype=torch.float64, device=dev)
                 _lib.check(lib.gcl_bn_stats_from_tiles(_lib.ptr(tile_stats, torch.float32), nt, n, c, float(eps),
                                                        float(momentum), _lib.ptr(running_mean), _lib.ptr(running_var),

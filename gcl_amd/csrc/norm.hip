@@ -191,56 +191,54 @@ __global__ void __launch_bounds__(256) k_bn_stats_final(const double* __restrict
   }
 }
 
-// One-launch finalisation straight from the convolution epilogue's fp32 partials [n_part][2][c] (one per 128-row
-// workgroup): 1024 threads = (channel t & 3, slice t >> 2); slice s adds partials s, s + 256, ... in fp64, the 256 slices
-// are then added in order (deterministic).  Used when there are at most BN_DIRECT_MAX partials (a 0.5 M-voxel level has
-// ~4 k); beyond that the two-stage path below keeps the per-thread chains short.
-constexpr int BN_DIRECT_MAX = 16384;
-__global__ void __launch_bounds__(1024) k_bn_stats_direct(const float* __restrict__ partial, int n_part, long long n, int c,
-                                                          float eps, float momentum, float* running_mean,
-                                                          float* running_var, float* mean, float* rstd) {
-  __shared__ double red[2][256][5];
-  __shared__ double red2[2][16][5];
-  const int cl = threadIdx.x & 3, sl = threadIdx.x >> 2;
-  const int ch = blockIdx.x * 4 + cl;
-  double a = 0, b = 0;
-  if (ch < c) {
-    double a1 = 0, b1 = 0;        // two independent chains per thread
-    int w = sl;
-    for (; w + 256 < n_part; w += 512) {
-      a += (double)partial[(long long)w * 2 * c + ch];
-      b += (double)partial[(long long)w * 2 * c + c + ch];
-      a1 += (double)partial[(long long)(w + 256) * 2 * c + ch];
-      b1 += (double)partial[(long long)(w + 256) * 2 * c + c + ch];
-    }
-    for (; w < n_part; w += 256) {
-      a += (double)partial[(long long)w * 2 * c + ch];
-      b += (double)partial[(long long)w * 2 * c + c + ch];
-    }
-    a += a1;
-    b += b1;
+// One-launch finalisation straight from the convolution epilogue's fp32 partials, CHANNEL-MAJOR [2][c][n_part] (one
+// partial per 128-row workgroup): one workgroup per channel, thread t adds partials t, t + 256, ... of the channel's two
+// contiguous runs in fp64 (four independent chains, every load coalesced), the 256 thread sums are then added as a fixed
+// tree (16 groups of 16, then the 16 group sums in order) -- deterministic.  The [n_part][2][c] layout of rounds 2 - 3 was
+// read by c / 4 workgroups as 16-byte pieces 2 c floats apart: 55 us per 0.5 M-row layer (4143 partials), on the training
+// stream between every convolution and its BatchNorm apply pass.
+constexpr int BN_DIRECT_MAX = 1 << 20;
+__global__ void __launch_bounds__(256) k_bn_stats_direct(const float* __restrict__ partial, int n_part, long long n, int c,
+                                                         float eps, float momentum, float* running_mean,
+                                                         float* running_var, float* mean, float* rstd) {
+  __shared__ double red[2][256];
+  __shared__ double red2[2][16];
+  const int ch = blockIdx.x, t = threadIdx.x;
+  const float* p1 = partial + (long long)ch * n_part;
+  const float* p2 = partial + ((long long)c + ch) * n_part;
+  double a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+  int w = t;
+  for (; w + 768 < n_part; w += 1024) {
+    a0 += (double)p1[w];
+    a1 += (double)p1[w + 256];
+    a2 += (double)p1[w + 512];
+    a3 += (double)p1[w + 768];
+    b0 += (double)p2[w];
+    b1 += (double)p2[w + 256];
+    b2 += (double)p2[w + 512];
+    b3 += (double)p2[w + 768];
   }
-  red[0][sl][cl] = a;
-  red[1][sl][cl] = b;
+  for (; w < n_part; w += 256) {
+    a0 += (double)p1[w];
+    b0 += (double)p2[w];
+  }
+  red[0][t] = (a0 + a1) + (a2 + a3);
+  red[1][t] = (b0 + b1) + (b2 + b3);
   __syncthreads();
-  // fixed tree: 16 groups of 16 consecutive slices, then the 16 group sums in order (was one 256-step serial chain)
-  if (sl < 16) {
-    double u = 0, v = 0;
+  if (t < 32) {      // fixed tree: 16 groups of 16 consecutive thread sums (lanes 0..15: sums, 16..31: squares)
+    const int which = t >> 4, g = t & 15;
+    double u = 0;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      u += red[0][sl * 16 + q][cl];
-      v += red[1][sl * 16 + q][cl];
-    }
-    red2[0][sl][cl] = u;
-    red2[1][sl][cl] = v;
+    for (int q = 0; q < 16; ++q) u += red[which][g * 16 + q];
+    red2[which][g] = u;
   }
   __syncthreads();
-  if (sl != 0 || ch >= c) return;
+  if (t != 0) return;
   double s = 0, ss = 0;
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
-    s += red2[0][q][cl];
-    ss += red2[1][q][cl];
+    s += red2[0][q];
+    ss += red2[1][q];
   }
   double m = s / (double)n;
   double var = ss / (double)n - m * m;
@@ -251,23 +249,6 @@ __global__ void __launch_bounds__(1024) k_bn_stats_direct(const float* __restric
     double unb = (n > 1) ? var * (double)n / (double)(n - 1) : var;
     running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * m);
     running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unb);
-  }
-}
-
-// statistics from the per-tile column sums written by the convolution epilogue: partial [n_tiles][2][c] (fp32 sums of
-// <= 32 rows each).  Stage 1 adds 32 tiles per workgroup in fp64 (coalesced: thread = column), stage 2 is the
-// ordinary ordered finalisation over the per-workgroup partials.
-constexpr int BN_TILES_PER_WG = 32;
-
-__global__ void __launch_bounds__(256) k_bn_tiles_reduce(const float* __restrict__ partial, long long n_tiles, int c,
-                                                         double* out) {
-  const long long t0 = (long long)blockIdx.x * BN_TILES_PER_WG;
-  long long t1 = t0 + BN_TILES_PER_WG;
-  if (t1 > n_tiles) t1 = n_tiles;
-  for (int j = threadIdx.x; j < 2 * c; j += 256) {
-    double s = 0;
-    for (long long t = t0; t < t1; ++t) s += (double)partial[t * 2 * c + j];
-    out[(long long)blockIdx.x * 2 * c + j] = s;
   }
 }
 
@@ -563,23 +544,15 @@ int gcl_bn_stats(const float* x, int64_t n, int32_t c, float eps, float momentum
   return GCL_OK;
 }
 
-int64_t gcl_bn_tiles_scratch_len(int64_t n_tiles, int32_t c) { return cdiv(n_tiles, BN_TILES_PER_WG) * 2 * c; }
+int64_t gcl_bn_tiles_scratch_len(int64_t n_tiles, int32_t c) { (void)n_tiles; return 2 * (int64_t)c; }      // unused since round 4
 
 int gcl_bn_stats_from_tiles(const float* partial, int64_t n_tiles, int64_t n, int32_t c, float eps, float momentum,
                             float* running_mean, float* running_var, double* scratch, float* mean, float* rstd,
                             void* stream) {
-  GCL_CHECK_ARG(partial && scratch && mean && rstd, "gcl_bn_stats_from_tiles: null pointer");
-  GCL_CHECK_ARG(n > 0 && n_tiles > 0 && c > 0, "gcl_bn_stats_from_tiles: bad sizes");
-  hipStream_t st = (hipStream_t)stream;
-  if (n_tiles <= BN_DIRECT_MAX) {
-    hipLaunchKernelGGL(k_bn_stats_direct, dim3((unsigned)cdiv(c, 4)), dim3(1024), 0, st, partial, (int)n_tiles,
-                       (long long)n, c, eps, momentum, running_mean, running_var, mean, rstd);
-    GCL_CHECK_LAUNCH();
-    return GCL_OK;
-  }
-  int nwg = (int)cdiv(n_tiles, BN_TILES_PER_WG);
-  hipLaunchKernelGGL(k_bn_tiles_reduce, dim3(nwg), dim3(256), 0, st, partial, (long long)n_tiles, c, scratch);
-  hipLaunchKernelGGL(k_bn_stats_final, dim3((unsigned)cdiv(c, 4)), dim3(256), 0, st, (const double*)scratch, nwg,
+  (void)scratch;
+  GCL_CHECK_ARG(partial && mean && rstd, "gcl_bn_stats_from_tiles: null pointer");
+  GCL_CHECK_ARG(n > 0 && n_tiles > 0 && n_tiles <= BN_DIRECT_MAX && c > 0, "gcl_bn_stats_from_tiles: bad sizes");
+  hipLaunchKernelGGL(k_bn_stats_direct, dim3((unsigned)c), dim3(256), 0, (hipStream_t)stream, partial, (int)n_tiles,
                      (long long)n, c, eps, momentum, running_mean, running_var, mean, rstd);
   GCL_CHECK_LAUNCH();
   return GCL_OK;

@@ -190,9 +190,9 @@ int gcl_table_sort_pre(const int32_t* tbl, int32_t K, int64_t n, int32_t window,
  *   wave tile visits only the offsets of tile_mask; with NULLs, row(j) = j and every offset is visited.
  *   Output-stationary (no atomics, deterministic).  The same entry computes the input gradient when given
  *   the opposite table and mode-1/2 weights.  K <= 27.
- *   stats (optional, split precisions): float[ceil(n_out/128)][2][cout] -- column sums of y and y^2 per 128-row
- *   workgroup tile (its four waves added in order), consumed by gcl_bn_stats_from_tiles (the BatchNorm that follows
- *   then needs no statistics pass over y). */
+ *   stats (optional, split precisions): float[2][cout][ceil(n_out/128)] (channel-major) -- column sums of y and y^2
+ *   per 128-row workgroup tile (its four waves added in order), consumed by gcl_bn_stats_from_tiles (the BatchNorm
+ *   that follows then needs no statistics pass over y; n_tiles = ceil(n_out/128), its `scratch` is unused). */
 int64_t gcl_pack_weights_bytes(int32_t K, int32_t cin, int32_t cout, int32_t prec);
 /* max |x| of a tensor in an "amax slot": GCL_AMAX_WORDS device int32, 16 entries on separate 128-byte lines (entry i
  * at word 32 i), value = max over the entries, each the bit pattern of a non-negative float.  (Workgroups publish to

@@ -382,7 +382,7 @@ def test_lds_dma_forward_kernel_is_bitwise_the_register_staged_kernel(cin, cout,
         for flags in (8, 2):
             for fused in (False, True):
                 y = torch.full((n_out, cout), float("nan"), device=DEV)
-                stats = torch.full(((n_out + 127) // 128, 2, cout), float("nan"), device=DEV)
+                stats = torch.full((2, cout, (n_out + 127) // 128), float("nan"), device=DEV)
                 slot = ME.ops.amax_slot(x.device)
                 _lib.check(lib.gcl_conv_fwd_fused(_lib.ptr(planes if use_planes else x), n_out, int(use_planes), _lib.ptr(wp), 4,
                                                   _lib.ptr(xa), _lib.ptr(wa),
@@ -435,7 +435,7 @@ def test_lds_dma_forward_kernel_race_screen(cin, cout, use_planes):
 
         def run(flags):
             y = torch.full((n_out, cout), float("nan"), device=DEV)
-            stats = torch.full(((n_out + 127) // 128, 2, cout), float("nan"), device=DEV)
+            stats = torch.full((2, cout, (n_out + 127) // 128), float("nan"), device=DEV)
             _lib.check(lib.gcl_conv_fwd(_lib.ptr(xin), n_out, int(use_planes), _lib.ptr(wp), 4, _lib.ptr(xa), _lib.ptr(wa),
                                         _lib.ptr(tbl), _lib.ptr(order), _lib.ptr(mask), n_out, K, cin, cout, None, _lib.ptr(y),
                                         _lib.ptr(stats), flags, _lib.stream()), "gcl_conv_fwd")
