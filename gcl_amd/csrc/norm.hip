@@ -101,8 +101,8 @@ __global__ void __launch_bounds__(256) k_bn_reduce(const float* __restrict__ x, 
     red[1][threadIdx.x][j] = s1[j];
   }
   __syncthreads();
-  if (rl == 0) {
-    double* out = partial + (long long)blockIdx.x * 2 * c;
+  if (rl == 0) {      // channel-major partials [2][c][gridDim.x]: a channel's run is contiguous for reduce_runs
+    const long long nwg = gridDim.x;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       double a = 0, b = 0;
@@ -110,64 +110,58 @@ __global__ void __launch_bounds__(256) k_bn_reduce(const float* __restrict__ x, 
         a += red[0][q * cq_n + cq][j];
         b += red[1][q * cq_n + cq][j];
       }
-      out[cq * 4 + j] = a;
-      out[c + cq * 4 + j] = b;
+      partial[(long long)(cq * 4 + j) * nwg + blockIdx.x] = a;
+      partial[(long long)(c + cq * 4 + j) * nwg + blockIdx.x] = b;
     }
   }
 }
 
-// ordered (deterministic) sum of the per-workgroup partials of 4 channels by one 256-thread workgroup:
-// thread = (channel ch = t & 3, slice sl = t >> 2) sums partials sl, sl+64, ... (all loads of a thread are independent
-// and issued together); the 64 slice sums are then added as 8 groups of 8 consecutive slices (threads sl < 8), and the 8
-// group sums in order by the thread with sl == 0 -- a fixed tree, so the result does not depend on timing.  (The former
-// single 64-step serial chain of LDS reads was most of these kernels' ~11 us.)
-__device__ __forceinline__ void reduce_partials4(const double* __restrict__ partial, int nwg, int c, int ch,
-                                                 double& s, double& ss) {
-  __shared__ double red[2][64][5];
-  __shared__ double red2[2][8][5];
-  const int sl = threadIdx.x >> 2, cl = threadIdx.x & 3;
-  double a = 0, b = 0;
-  if (ch < c) {
-    double a1 = 0, b1 = 0, a2 = 0, b2 = 0, a3 = 0, b3 = 0;       // four independent chains: loads in flight together
-    int w = sl;
-    for (; w + 192 < nwg; w += 256) {
-      a += partial[(long long)w * 2 * c + ch];
-      b += partial[(long long)w * 2 * c + c + ch];
-      a1 += partial[(long long)(w + 64) * 2 * c + ch];
-      b1 += partial[(long long)(w + 64) * 2 * c + c + ch];
-      a2 += partial[(long long)(w + 128) * 2 * c + ch];
-      b2 += partial[(long long)(w + 128) * 2 * c + c + ch];
-      a3 += partial[(long long)(w + 192) * 2 * c + ch];
-      b3 += partial[(long long)(w + 192) * 2 * c + c + ch];
-    }
-    for (; w < nwg; w += 64) {
-      a += partial[(long long)w * 2 * c + ch];
-      b += partial[(long long)w * 2 * c + c + ch];
-    }
-    a = (a + a1) + (a2 + a3);
-    b = (b + b1) + (b2 + b3);
+// ordered (deterministic) sum of ONE channel's two runs of per-workgroup partials (channel-major layout) by a 256-thread
+// workgroup: thread t adds elements t, t + 256, ... in fp64 (four independent chains, every load coalesced), the 256
+// thread sums are then added as a fixed tree -- 16 groups of 16 consecutive threads, then the 16 group sums in order -- so
+// the result does not depend on timing.  Valid in thread 0.  (Rounds 2 - 3 kept the partials workgroup-major and read
+// them with c / 4 workgroups as 16 / 32-byte pieces a row apart: 11 us per BatchNorm backward, 55 us per 0.5 M-row
+// forward layer, all on the training stream.)
+template <typename T>
+__device__ __forceinline__ void reduce_runs(const T* __restrict__ p1, const T* __restrict__ p2, int n_part, double& s,
+                                            double& ss) {
+  __shared__ double red[2][256];
+  __shared__ double red2[2][16];
+  const int t = threadIdx.x;
+  double a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+  int w = t;
+  for (; w + 768 < n_part; w += 1024) {
+    a0 += (double)p1[w];
+    a1 += (double)p1[w + 256];
+    a2 += (double)p1[w + 512];
+    a3 += (double)p1[w + 768];
+    b0 += (double)p2[w];
+    b1 += (double)p2[w + 256];
+    b2 += (double)p2[w + 512];
+    b3 += (double)p2[w + 768];
   }
-  red[0][sl][cl] = a;
-  red[1][sl][cl] = b;
+  for (; w < n_part; w += 256) {
+    a0 += (double)p1[w];
+    b0 += (double)p2[w];
+  }
+  red[0][t] = (a0 + a1) + (a2 + a3);
+  red[1][t] = (b0 + b1) + (b2 + b3);
   __syncthreads();
-  if (sl < 8) {
-    double u = 0, v = 0;
+  if (t < 32) {      // lanes 0..15: the sums' 16 groups, lanes 16..31: the squares'
+    const int which = t >> 4, g = t & 15;
+    double u = 0;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      u += red[0][sl * 8 + q][cl];
-      v += red[1][sl * 8 + q][cl];
-    }
-    red2[0][sl][cl] = u;
-    red2[1][sl][cl] = v;
+    for (int q = 0; q < 16; ++q) u += red[which][g * 16 + q];
+    red2[which][g] = u;
   }
   __syncthreads();
   s = 0;
   ss = 0;
-  if (sl == 0) {
+  if (t == 0) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      s += red2[0][q][cl];
-      ss += red2[1][q][cl];
+    for (int q = 0; q < 16; ++q) {
+      s += red2[0][q];
+      ss += red2[1][q];
     }
   }
 }
@@ -175,10 +169,10 @@ __device__ __forceinline__ void reduce_partials4(const double* __restrict__ part
 __global__ void __launch_bounds__(256) k_bn_stats_final(const double* __restrict__ partial, int nwg, long long n,
                                                         int c, float eps, float momentum, float* running_mean,
                                                         float* running_var, float* mean, float* rstd) {
-  int ch = blockIdx.x * 4 + (threadIdx.x & 3);
+  const int ch = blockIdx.x;      // one workgroup per channel
   double s, ss;
-  reduce_partials4(partial, nwg, c, ch, s, ss);
-  if ((threadIdx.x >> 2) != 0 || ch >= c) return;
+  reduce_runs(partial + (long long)ch * nwg, partial + ((long long)c + ch) * nwg, nwg, s, ss);
+  if (threadIdx.x != 0) return;
   double m = s / (double)n;
   double var = ss / (double)n - m * m;
   if (var < 0) var = 0;
@@ -201,45 +195,10 @@ constexpr int BN_DIRECT_MAX = 1 << 20;
 __global__ void __launch_bounds__(256) k_bn_stats_direct(const float* __restrict__ partial, int n_part, long long n, int c,
                                                          float eps, float momentum, float* running_mean,
                                                          float* running_var, float* mean, float* rstd) {
-  __shared__ double red[2][256];
-  __shared__ double red2[2][16];
-  const int ch = blockIdx.x, t = threadIdx.x;
-  const float* p1 = partial + (long long)ch * n_part;
-  const float* p2 = partial + ((long long)c + ch) * n_part;
-  double a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
-  int w = t;
-  for (; w + 768 < n_part; w += 1024) {
-    a0 += (double)p1[w];
-    a1 += (double)p1[w + 256];
-    a2 += (double)p1[w + 512];
-    a3 += (double)p1[w + 768];
-    b0 += (double)p2[w];
-    b1 += (double)p2[w + 256];
-    b2 += (double)p2[w + 512];
-    b3 += (double)p2[w + 768];
-  }
-  for (; w < n_part; w += 256) {
-    a0 += (double)p1[w];
-    b0 += (double)p2[w];
-  }
-  red[0][t] = (a0 + a1) + (a2 + a3);
-  red[1][t] = (b0 + b1) + (b2 + b3);
-  __syncthreads();
-  if (t < 32) {      // fixed tree: 16 groups of 16 consecutive thread sums (lanes 0..15: sums, 16..31: squares)
-    const int which = t >> 4, g = t & 15;
-    double u = 0;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) u += red[which][g * 16 + q];
-    red2[which][g] = u;
-  }
-  __syncthreads();
-  if (t != 0) return;
-  double s = 0, ss = 0;
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    s += red2[0][q];
-    ss += red2[1][q];
-  }
+  const int ch = blockIdx.x;
+  double s, ss;
+  reduce_runs(partial + (long long)ch * n_part, partial + ((long long)c + ch) * n_part, n_part, s, ss);
+  if (threadIdx.x != 0) return;
   double m = s / (double)n;
   double var = ss / (double)n - m * m;
   if (var < 0) var = 0;
@@ -254,10 +213,10 @@ __global__ void __launch_bounds__(256) k_bn_stats_direct(const float* __restrict
 
 __global__ void __launch_bounds__(256) k_bn_bwd_final(const double* __restrict__ partial, int nwg, int c,
                                                       float* sum_g, float* sum_gx) {
-  int ch = blockIdx.x * 4 + (threadIdx.x & 3);
+  const int ch = blockIdx.x;
   double s, ss;
-  reduce_partials4(partial, nwg, c, ch, s, ss);
-  if ((threadIdx.x >> 2) != 0 || ch >= c) return;
+  reduce_runs(partial + (long long)ch * nwg, partial + ((long long)c + ch) * nwg, nwg, s, ss);
+  if (threadIdx.x != 0) return;
   sum_g[ch] = (float)s;
   sum_gx[ch] = (float)ss;
 }
@@ -513,10 +472,10 @@ static bool bn_c_ok(int c) { return c >= 4 && c % 4 == 0 && (256 % (c / 4)) == 0
 
 // column sums of a matrix from k_bn_reduce<false>'s per-workgroup fp64 partials (ordered => deterministic)
 __global__ void __launch_bounds__(256) k_col_sum_final(const double* __restrict__ partial, int nwg, int c, float* out) {
-  int ch = blockIdx.x * 4 + (threadIdx.x & 3);
+  const int ch = blockIdx.x;
   double s, ss;
-  reduce_partials4(partial, nwg, c, ch, s, ss);
-  if ((threadIdx.x >> 2) != 0 || ch >= c) return;
+  reduce_runs(partial + (long long)ch * nwg, partial + ((long long)c + ch) * nwg, nwg, s, ss);
+  if (threadIdx.x != 0) return;
   out[ch] = (float)s;
 }
 
@@ -538,7 +497,7 @@ int gcl_bn_stats(const float* x, int64_t n, int32_t c, float eps, float momentum
   hipLaunchKernelGGL(k_bn_reduce<false>, dim3(nwg), dim3(256), 0, st, x, (const float*)nullptr,
                      (const float*)nullptr, (long long)n, c, (const float*)nullptr, (const float*)nullptr, 0,
                      (const unsigned long long*)nullptr, rows, scratch);
-  hipLaunchKernelGGL(k_bn_stats_final, dim3((unsigned)cdiv(c, 4)), dim3(256), 0, st, (const double*)scratch, nwg,
+  hipLaunchKernelGGL(k_bn_stats_final, dim3((unsigned)c), dim3(256), 0, st, (const double*)scratch, nwg,
                      (long long)n, c, eps, momentum, running_mean, running_var, mean, rstd);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
@@ -596,7 +555,7 @@ int gcl_bn_bwd_reduce_ld(const float* x, const float* dy, int32_t dy_ld, const f
   int nwg = (int)cdiv(n, rows);
   hipLaunchKernelGGL(k_bn_reduce<true>, dim3(nwg), dim3(256), 0, st, x, dy, y, (long long)n, c, mean, rstd, relu,
                      (const unsigned long long*)relu_mask, rows, scratch, dy_ld);
-  hipLaunchKernelGGL(k_bn_bwd_final, dim3((unsigned)cdiv(c, 4)), dim3(256), 0, st, (const double*)scratch, nwg, c,
+  hipLaunchKernelGGL(k_bn_bwd_final, dim3((unsigned)c), dim3(256), 0, st, (const double*)scratch, nwg, c,
                      sum_g, sum_gx);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
@@ -662,7 +621,7 @@ int gcl_col_sum(const float* x, int64_t n, int32_t c, double* scratch, float* ou
   hipLaunchKernelGGL(k_bn_reduce<false>, dim3(nwg), dim3(256), 0, st, x, (const float*)nullptr,
                      (const float*)nullptr, (long long)n, c, (const float*)nullptr, (const float*)nullptr, 0,
                      (const unsigned long long*)nullptr, rows, scratch);
-  hipLaunchKernelGGL(k_col_sum_final, dim3((unsigned)cdiv(c, 4)), dim3(256), 0, st, (const double*)scratch, nwg, c, out);
+  hipLaunchKernelGGL(k_col_sum_final, dim3((unsigned)c), dim3(256), 0, st, (const double*)scratch, nwg, c, out);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }
