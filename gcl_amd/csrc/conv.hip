@@ -479,8 +479,11 @@ __device__ __forceinline__ void conv_fwd_epilogue(f32x16 (&acc)[NB], float* tile
       int orow = __shfl(orow_l, (r & 3) + 8 * (r >> 2) + 4 * h);
       if (orow >= 0) {
         float v = acc[b][r] * csc + bvv;
-        if (EPI && epi.residual) v += epi.residual[(long long)orow * (epi.residual_ld ? epi.residual_ld : cout) + col];
-        if (EPI && epi.relu) v = fmaxf(v, 0.f);
+        if (EPI && epi.residual) {
+          const float rsd = epi.residual[(long long)orow * (epi.residual_ld ? epi.residual_ld : cout) + col];
+          v = epi.relu == 2 ? (rsd > 0.f ? v : 0.f) : v + rsd;      // relu == 2: threshold_backward, pass v where residual > 0
+        }
+        if (EPI && epi.relu == 1) v = fmaxf(v, 0.f);
         Y[(long long)orow * cout + col] = v;
         s1 += v;
         s2 += v * v;
@@ -1246,8 +1249,11 @@ __global__ void __launch_bounds__(1024, 1) k_conv_fwd_tall(const float* __restri
       int orow = __shfl(orow_l, (r & 3) + 8 * (r >> 2) + 4 * h);
       if (orow >= 0) {
         float v = acc[b][r] * csc + bvv;
-        if (EPI && epi.residual) v += epi.residual[(long long)orow * (epi.residual_ld ? epi.residual_ld : cout) + col];
-        if (EPI && epi.relu) v = fmaxf(v, 0.f);
+        if (EPI && epi.residual) {
+          const float rsd = epi.residual[(long long)orow * (epi.residual_ld ? epi.residual_ld : cout) + col];
+          v = epi.relu == 2 ? (rsd > 0.f ? v : 0.f) : v + rsd;      // relu == 2: threshold_backward, pass v where residual > 0
+        }
+        if (EPI && epi.relu == 1) v = fmaxf(v, 0.f);
         Y[(long long)orow * cout + col] = v;
         if (EPI) ymax = fmaxf(ymax, fabsf(v));
       }
@@ -2212,8 +2218,11 @@ __global__ void __launch_bounds__(256) k_conv_generic(const float* __restrict__ 
       if (j < ncol) {
         const int col = n0 + j;
         float v = acc[j] * (epi.col_scale ? epi.col_scale[col] : 1.f) + (bias ? bias[col] : 0.f);
-        if (epi.residual) v += epi.residual[orow * cout + col];
-        if (epi.relu) v = fmaxf(v, 0.f);
+        if (epi.residual) {
+          const float rsd = epi.residual[orow * cout + col];
+          v = epi.relu == 2 ? (rsd > 0.f ? v : 0.f) : v + rsd;
+        }
+        if (epi.relu == 1) v = fmaxf(v, 0.f);
         Y[orow * cout + col] = v;
         ymax = fmaxf(ymax, fabsf(v));
       }
@@ -2417,6 +2426,7 @@ int gcl_conv_fwd_fused_ld(const float* x, int64_t n_in, int32_t x_is_planes, con
                           int32_t* y_amax, float* y, float* stats, int32_t flags, void* stream) {
   GCL_CHECK_ARG(residual_ld == 0 || (residual && residual_ld >= cout && !generic_shape(K, cin, cout)),
                 "gcl_conv_fwd_fused_ld: residual_ld needs a residual, >= Cout, MFMA-shaped launches");
+  GCL_CHECK_ARG(relu == 0 || relu == 1 || (relu == 2 && residual), "gcl_conv_fwd_fused: relu must be 0, 1, or 2 with a residual");
   const ConvEpi epi{col_scale, residual, relu, y_amax, residual_ld};
   const bool use_epi = col_scale || residual || relu || y_amax;
   GCL_CHECK_ARG(prec != 0 || generic_shape(K, cin, cout) || (!col_scale && !residual && !relu && !y_amax),

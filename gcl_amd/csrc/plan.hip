@@ -373,6 +373,7 @@ struct PassState {        // everything one forward pass leaves behind for its b
   unsigned char *pack_fwd = nullptr, *pack_bwd = nullptr;
   void* state = nullptr;
   bool forward_done = false, bwd_packed = false;
+  std::vector<char> relu_masked;    // backward pass: RELU record whose backward the consumer's epilogue has already applied
   hipEvent_t fwd_packs = nullptr;      // recorded on the aux stream behind the forward packs of the pass
   bool fwd_packs_pending = false;
   int32_t* not_ones = nullptr;      // per input row of the pass: its cloud has a feature that differs from 1.0f (table path)
@@ -390,6 +391,9 @@ struct Plan : PassState {   // the base part is the pass being enqueued right no
   long long bytes_fwd = 0, bytes_bwd = 0, wgs_fwd = 0, wgs_bwd = 0;
   int n_bwd = 0;
   std::vector<char> made;           // tensor id -> produced by a record of the plan
+  std::vector<char> fuse_relu;      // record i is a CONV whose only consumer is the RELU record i + 1: one launch writes relu(y)
+  std::vector<int> mask_from;       // record i is a convolution whose input is the output of RELU record mask_from[i] and that
+                                    // ReLU's only consumer: its input-gradient epilogue applies the ReLU's backward (-1: no)
   // device tables (inside the caller's `state` buffer), re-uploaded when a parameter pointer changes
   std::vector<long long> host_tables, uploaded;
   // inference passes (gcl_plan_forward_eval): BatchNorm in eval mode folded into the convolution epilogue
@@ -499,7 +503,7 @@ static int stem_flag(Plan& P, const gcl_plan_op& op, const gcl_map_desc& m, cons
 }
 
 // the convolution of a CONVBN / CONV record (ops._SparseConvFn.forward); returns its output in *y_out
-static int conv_forward(Plan& P, int i, float** y_out, float** stats_out, hipStream_t st) {
+static int conv_forward(Plan& P, int i, float** y_out, float** stats_out, hipStream_t st, int32_t** relu_amax_out) {
   Arena& A = P.A;
   const gcl_plan_op& op = P.ops[i];
   const gcl_maps_desc& M = *P.maps;
@@ -509,6 +513,7 @@ static int conv_forward(Plan& P, int i, float** y_out, float** stats_out, hipStr
   float* y = A.take_n<float>(n_out * op.cout);
   *y_out = y;
   *stats_out = nullptr;
+  *relu_amax_out = nullptr;
   const float* W = (const float*)P.params[op.w];
   if (is_stem(op, m)) {
     int rcs = stem_flag(P, op, m, x, n_in, st);
@@ -539,9 +544,11 @@ static int conv_forward(Plan& P, int i, float** y_out, float** stats_out, hipStr
   }
   const float* bias = op.bias >= 0 ? (const float*)P.params[op.bias] : nullptr;
   ProfScope ps(P, st, 0, (double)(m.kernel_size > 1 ? m.n_pairs : n_out), op.cin, op.cout, n_in, n_out, op.K);
-  PLAN_CALL(gcl_conv_fwd(pl ? (const float*)x.planes : x.ptr, n_in, pl ? 1 : 0, P.pack_fwd + P.off_fwd[wi], 4, x.amax,
-                         P.w_amax + (long long)wi * GCL_AMAX_WORDS, tbl, order, mask, n_out, op.K, op.cin, op.cout, bias,
-                         y, stats, 0, (void*)st));
+  int32_t* relu_amax = (op.kind == GCL_OP_CONV && P.fuse_relu[i]) ? new_slot(P) : nullptr;
+  *relu_amax_out = relu_amax;
+  PLAN_CALL(gcl_conv_fwd_fused(pl ? (const float*)x.planes : x.ptr, n_in, pl ? 1 : 0, P.pack_fwd + P.off_fwd[wi], 4, x.amax,
+                               P.w_amax + (long long)wi * GCL_AMAX_WORDS, tbl, order, mask, n_out, op.K, op.cin, op.cout, bias,
+                               nullptr, nullptr, relu_amax ? 1 : 0, relu_amax, y, stats, 0, (void*)st));
   return GCL_OK;
 }
 
@@ -682,7 +689,8 @@ static int plan_forward(Plan& P, const float* x_in, void* const* bn_stats, float
           break;
         }
         float *cy, *stats;
-        if ((rc = conv_forward(P, (int)i, &cy, &stats, st))) return rc;
+        int32_t* unused_slot;
+        if ((rc = conv_forward(P, (int)i, &cy, &stats, st, &unused_slot))) return rc;
         OpSaved& sv = P.saved[i];
         sv.conv_out = cy;
         const int c = op.cout;
@@ -709,11 +717,17 @@ static int plan_forward(Plan& P, const float* x_in, void* const* bn_stats, float
       }
       case GCL_OP_CONV: {
         float *cy, *stats;
-        if ((rc = conv_forward(P, (int)i, &cy, &stats, st))) return rc;
+        int32_t* relu_amax;
+        if ((rc = conv_forward(P, (int)i, &cy, &stats, st, &relu_amax))) return rc;
         y.ptr = cy;
+        if (relu_amax) {      // the epilogue applied the ReLU record that follows: both tensor ids name relu(conv(x))
+          y.amax = relu_amax;
+          P.t[P.ops[i + 1].y] = y;
+        }
         break;
       }
       case GCL_OP_RELU: {
+        if (i > 0 && P.fuse_relu[i - 1]) break;      // written by the convolution in front of it
         const long long n4 = n_out * op.cout / 4;
         y.ptr = A.take_n<float>(n_out * op.cout);
         y.amax = new_slot(P);        // published by the kernel itself: the consumer needs no gcl_amax pass
@@ -841,18 +855,28 @@ static int conv_backward(Plan& P, int i, TState dy, void* const* grads, hipStrea
     float* acc = P.g[op.x].ptr;       // a gradient that already reached x through another path: added in the epilogue
     const int acc_ld = P.g[op.x].ld;  // ... possibly a column slice of a cat's gradient
     float* dx = A.take_n<float>(n_in * op.cin);
+    int32_t* dx_amax = nullptr;
     {
       ProfScope ps(P, st, acc ? 1 : 0, pairs, op.cout, op.cin, n_out, n_in, op.K);
       if (acc)
         PLAN_CALL(gcl_conv_fwd_fused_ld(pl ? (const float*)dy.planes : dy.ptr, n_out, pl ? 1 : 0, P.pack_bwd + P.off_bwd[wi], 4,
                                         dy.amax, w_amax, tbl, order, mask, n_in, op.K, op.cout, op.cin, nullptr, nullptr, acc,
                                         acc_ld, 0, nullptr, dx, nullptr, 0, (void*)st));
-      else
+      else if (P.mask_from[i] >= 0) {
+        // x came out of a ReLU that nothing else reads: its backward (g where y > 0) in this epilogue, max|g| published
+        dx_amax = new_slot(P);
+        PLAN_CALL(gcl_conv_fwd_fused(pl ? (const float*)dy.planes : dy.ptr, n_out, pl ? 1 : 0, P.pack_bwd + P.off_bwd[wi], 4,
+                                     dy.amax, w_amax, tbl, order, mask, n_in, op.K, op.cout, op.cin, nullptr, nullptr, x.ptr, 2,
+                                     dx_amax, dx, nullptr, 0, (void*)st));
+        if (P.relu_masked.size() != P.ops.size()) P.relu_masked.assign(P.ops.size(), 0);
+        P.relu_masked[P.mask_from[i]] = 1;
+      } else
         PLAN_CALL(gcl_conv_fwd(pl ? (const float*)dy.planes : dy.ptr, n_out, pl ? 1 : 0, P.pack_bwd + P.off_bwd[wi], 4, dy.amax,
                                w_amax, tbl, order, mask, n_in, op.K, op.cout, op.cin, nullptr, dx, nullptr, 0, (void*)st));
     }
     P.g[op.x] = TState();
     P.g[op.x].ptr = dx;
+    P.g[op.x].amax = dx_amax;
   }
   {      // weight gradient over the compacted pair lists
     const int32_t *pa = m.pair_in, *pb = m.pair_out;
@@ -927,6 +951,11 @@ static int plan_backward(Plan& P, const float* dy, void* const* grads, int first
         if ((rc = conv_backward(P, i, g, grads, st))) return rc;
         break;
       case GCL_OP_RELU: {
+        if ((size_t)i < P.relu_masked.size() && P.relu_masked[i]) {      // applied by the consumer's input-gradient epilogue
+          P.relu_masked[i] = 0;
+          if ((rc = give(P, op.x, g.ptr, n_out * op.cout, st, g.amax, g.ld, op.cout))) return rc;
+          break;
+        }
         if ((rc = contiguous(P, g, n_out, op.cout, st))) return rc;
         const long long numel = n_out * op.cout;
         float* gx = A.take_n<float>(numel);
@@ -1099,6 +1128,29 @@ void* gcl_plan_create(const gcl_plan_op* ops_host, int32_t n_ops, int32_t n_tens
       ok = false;
     }
     P->made[op.y] = 1;
+  }
+  // CONV directly followed by the RELU that is its only consumer (model/resunet.py:222-224: conv1_tr, MEF.relu, final): the
+  // convolution's epilogue applies the ReLU and publishes max|y| (GCL_PLAN_FUSE_RELU=0: two launches, same values)
+  P->fuse_relu.assign(P->ops.size(), 0);
+  static const bool fuse_relu_on = [] { const char* e = getenv("GCL_PLAN_FUSE_RELU"); return !(e && e[0] == '0'); }();
+  for (size_t i = 0; ok && fuse_relu_on && i + 1 < P->ops.size(); ++i) {
+    const gcl_plan_op &a = P->ops[i], &b = P->ops[i + 1];
+    if (a.kind != GCL_OP_CONV || b.kind != GCL_OP_RELU || b.x != a.y || a.cin <= 4) continue;
+    bool other = a.y == P->ops.back().y;       // the plan's output keeps its own tensor
+    for (size_t j = 0; j < P->ops.size(); ++j)
+      if (j != i + 1 && (P->ops[j].x == a.y || P->ops[j].x2 == a.y)) other = true;
+    if (!other) P->fuse_relu[i] = 1;
+  }
+  P->mask_from.assign(P->ops.size(), -1);
+  for (size_t i = 0; ok && fuse_relu_on && i < P->ops.size(); ++i) {
+    const gcl_plan_op& a = P->ops[i];
+    if ((a.kind != GCL_OP_CONV && a.kind != GCL_OP_CONVBN) || a.cin <= 4 || a.x == 0) continue;
+    int r = -1, consumers = 0;
+    for (size_t j = 0; j < P->ops.size(); ++j) {
+      if (P->ops[j].kind == GCL_OP_RELU && P->ops[j].y == a.x) r = (int)j;
+      consumers += (P->ops[j].x == a.x) + (P->ops[j].x2 == a.x);
+    }
+    if (r >= 0 && consumers == 1 && a.x != P->ops.back().y) P->mask_from[i] = r;
   }
   if (!ok) {
     set_error("gcl_plan_create: malformed or unsupported operator records");

@@ -242,7 +242,10 @@ int gcl_conv_fwd(const float* x, int64_t n_in, int32_t x_is_planes, const void* 
 /* gcl_conv_fwd with a fused inference epilogue: y = relu?(conv * col_scale + bias (+ residual)), i.e. convolution +
  * BatchNorm in eval mode (col_scale = gamma * rsqrt(var + eps), bias = beta - mean * col_scale) + BasicBlock's residual
  * add + ReLU in ONE launch (model/residual_block.py:37-53 with running statistics); y_amax (optional, zero-initialised
- * amax slot) receives max|y| for the next fp16x3 convolution.  Split-precision modes only. */
+ * amax slot) receives max|y| for the next fp16x3 convolution.  Split-precision modes only.
+ * relu == 2 (needs `residual`): aten::threshold_backward instead of the add -- y = conv where residual > 0, else 0: the
+ * input gradient of a convolution whose input came out of a ReLU, with that ReLU's backward in the epilogue (`residual` =
+ * the ReLU's output). */
 int gcl_conv_fwd_fused(const float* x, int64_t n_in, int32_t x_is_planes, const void* wp, int32_t prec,
                        const int32_t* x_amax, const int32_t* w_amax, const int32_t* tbl, const int32_t* order,
                        const int32_t* tile_mask, int64_t n_out, int32_t K, int32_t cin, int32_t cout, const float* bias,
