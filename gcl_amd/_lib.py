@@ -99,6 +99,7 @@ SIGNATURES = {
     "gcl_bn_tiles_scratch_len": (_i64, [_i64, _i32]),
     "gcl_bn_stats_from_tiles": (_i32, [_vp, _i64, _i64, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gcl_bn_apply": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "gcl_bn_apply_ld": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp]),
     "gcl_bn_mask_len": (_i64, [_i64, _i32]),
     "gcl_bn_bwd_reduce": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "gcl_bn_bwd_apply": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),

@@ -273,10 +273,19 @@ __global__ void __launch_bounds__(256) k_bn_apply(const float* __restrict__ x, l
                                                   const float* __restrict__ weight, const float* __restrict__ bias,
                                                   const float* __restrict__ residual, int relu,
                                                   float* __restrict__ y, unsigned long long* __restrict__ mask,
-                                                  int* amax_bits) {
+                                                  int* amax_bits, int y_ld = 0) {
   const int cq_n = c >> 2;
   const long long S = (long long)gridDim.x * blockDim.x;
   const long long e0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  // y_ld != 0: y is a column slice (row pitch y_ld floats) of a wider tensor -- the left columns of an ME.cat's output,
+  // written in place (no cat copy of this input).  HOIST: the thread's quad column is fixed, its row advances by S / cq_n.
+  const long long yld4 = (y_ld ? y_ld : c) >> 2;
+  const long long rstep = HOIST ? S / cq_n : 0;
+  long long row_e = e0 / cq_n;
+  const int q0 = (int)(e0 % cq_n);
+#define BN_Y(E, ROW) (y_ld ? (HOIST ? reinterpret_cast<float4*>(y)[(ROW)*yld4 + q0]                        \
+                                    : reinterpret_cast<float4*>(y)[((E) / cq_n) * yld4 + ((E) % cq_n)])   \
+                           : reinterpret_cast<float4*>(y)[E])
   const float4 z4 = make_float4(0, 0, 0, 0);
   float am = 0.f;
   BnFwdC ka, kb;
@@ -298,13 +307,15 @@ __global__ void __launch_bounds__(256) k_bn_apply(const float* __restrict__ x, l
     }
     const float4 oa = bn_fwd_one(xa, ra, residual != nullptr, relu, ka);
     const float4 ob = bn_fwd_one(xb, rb, residual != nullptr, relu, kb);
-    if (oka) { reinterpret_cast<float4*>(y)[e] = oa; am = amax4(am, oa); }
-    if (okb) { reinterpret_cast<float4*>(y)[f] = ob; am = amax4(am, ob); }
+    if (oka) { BN_Y(e, row_e) = oa; am = amax4(am, oa); }
+    if (okb) { BN_Y(f, row_e + rstep) = ob; am = amax4(am, ob); }
+    row_e += 2 * rstep;
     if (mask) {
       bn_mask_store(mask, e, oa, oka);
       if (f - (threadIdx.x & 63) < total4) bn_mask_store(mask, f, ob, okb);
     }
   }
+#undef BN_Y
   if (amax_bits) publish_amax(am, amax_bits);
 }
 
@@ -520,17 +531,24 @@ int gcl_bn_stats_from_tiles(const float* partial, int64_t n_tiles, int64_t n, in
 int gcl_bn_apply(const float* x, int64_t n, int32_t c, const float* mean, const float* rstd, const float* weight,
                  const float* bias, const float* residual, int32_t relu, float* y, uint64_t* relu_mask,
                  int32_t* y_amax, void* stream) {
+  return gcl_bn_apply_ld(x, n, c, mean, rstd, weight, bias, residual, relu, y, 0, relu_mask, y_amax, stream);
+}
+
+int gcl_bn_apply_ld(const float* x, int64_t n, int32_t c, const float* mean, const float* rstd, const float* weight,
+                    const float* bias, const float* residual, int32_t relu, float* y, int32_t y_ld, uint64_t* relu_mask,
+                    int32_t* y_amax, void* stream) {
   GCL_CHECK_ARG(x && mean && rstd && weight && bias && y, "gcl_bn_apply: null pointer");
   GCL_CHECK_ARG(n > 0 && c >= 4 && c % 4 == 0, "gcl_bn_apply: unsupported shape");
+  GCL_CHECK_ARG(y_ld == 0 || (y_ld >= c && y_ld % 4 == 0), "gcl_bn_apply_ld: y_ld must be 0 or a multiple of 4 >= c");
   long long total4 = n * (c / 4);
   long long g = cdiv(total4, 256);
   if (g > 4096) g = 4096;
   if ((g * 256) % (c / 4) == 0)
     hipLaunchKernelGGL(k_bn_apply<true>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, total4, c, mean, rstd,
-                       weight, bias, residual, relu, y, (unsigned long long*)(relu ? relu_mask : nullptr), y_amax);
+                       weight, bias, residual, relu, y, (unsigned long long*)(relu ? relu_mask : nullptr), y_amax, y_ld);
   else
     hipLaunchKernelGGL(k_bn_apply<false>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, total4, c, mean, rstd,
-                       weight, bias, residual, relu, y, (unsigned long long*)(relu ? relu_mask : nullptr), y_amax);
+                       weight, bias, residual, relu, y, (unsigned long long*)(relu ? relu_mask : nullptr), y_amax, y_ld);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }

@@ -84,6 +84,21 @@ __global__ void __launch_bounds__(256) k_cat2(const float4* __restrict__ a, int 
   }
   if (amax) publish_amax_wg(m, amax);
 }
+// ME.cat whose left input was written in place by its producer: copy the right input's columns, y[r][ca..] = b[r]
+__global__ void __launch_bounds__(256) k_cat_right(const float4* __restrict__ b, int cb4, long long n, int ca4,
+                                                   float4* __restrict__ y, int* amax) {
+  const int c4 = ca4 + cb4;
+  const long long total = n * cb4;
+  float m = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / cb4;
+    const int q = (int)(i - r * cb4);
+    const float4 v = b[i];
+    y[r * c4 + ca4 + q] = v;
+    m = amax4p(m, v);
+  }
+  if (amax) publish_amax_wg(m, amax);
+}
 __global__ void __launch_bounds__(256) k_split2(const float4* __restrict__ g, int ca4, int cb4, long long n,
                                                 float4* __restrict__ ga, float4* __restrict__ gb) {
   const int c4 = ca4 + cb4;
@@ -392,6 +407,8 @@ struct Plan : PassState {   // the base part is the pass being enqueued right no
   int n_bwd = 0;
   std::vector<char> made;           // tensor id -> produced by a record of the plan
   std::vector<char> fuse_relu;      // record i is a CONV whose only consumer is the RELU record i + 1: one launch writes relu(y)
+  std::vector<int> cat_left;        // record i is a CONVBN whose output is only the LEFT input of CAT record cat_left[i]: its
+                                    // BatchNorm apply pass writes into the cat's output (row pitch = the cat's width)
   std::vector<int> mask_from;       // record i is a convolution whose input is the output of RELU record mask_from[i] and that
                                     // ReLU's only consumer: its input-gradient epilogue applies the ReLU's backward (-1: no)
   // device tables (inside the caller's `state` buffer), re-uploaded when a parameter pointer changes
@@ -707,12 +724,27 @@ static int plan_forward(Plan& P, const float* x_in, void* const* bn_stats, float
           double* scratch = A.take_n<double>(gcl_bn_scratch_len(n_out, c));
           PLAN_CALL(gcl_bn_stats(cy, n_out, c, op.eps, op.momentum, rm, rv, scratch, sv.mean, sv.rstd, (void*)st));
         }
-        y.ptr = A.take_n<float>(n_out * c);
-        y.amax = new_slot(P);
+        if (P.cat_left[i] >= 0) {
+          // y is only the left input of an ME.cat: written straight into the cat's output (row pitch = its width); the
+          // cat record then copies the other input's columns only.  max|y| goes to the cat's slot (the right half adds its own)
+          const gcl_plan_op& cat = P.ops[P.cat_left[i]];
+          TState& cty = P.t[cat.y];
+          cty = TState();
+          cty.ptr = A.take_n<float>(n_out * cat.cout);
+          cty.amax = new_slot(P);
+          y.ptr = cty.ptr;
+          y.ld = cat.cout;
+          y.amax = cty.amax;
+        } else {
+          y.ptr = A.take_n<float>(n_out * c);
+          y.ld = 0;
+          y.amax = new_slot(P);
+        }
         if (op.relu) sv.mask = A.take_n<unsigned long long>(gcl_bn_mask_len(n_out, c));
         const float* res = op.x2 >= 0 ? P.t[op.x2].ptr : nullptr;
-        PLAN_CALL(gcl_bn_apply(cy, n_out, c, sv.mean, sv.rstd, (const float*)P.params[op.bn_w], (const float*)P.params[op.bn_b],
-                               res, op.relu, y.ptr, (uint64_t*)sv.mask, y.amax, (void*)st));
+        PLAN_CALL(gcl_bn_apply_ld(cy, n_out, c, sv.mean, sv.rstd, (const float*)P.params[op.bn_w],
+                                  (const float*)P.params[op.bn_b], res, op.relu, y.ptr, y.ld, (uint64_t*)sv.mask, y.amax,
+                                  (void*)st));
         break;
       }
       case GCL_OP_CONV: {
@@ -740,6 +772,14 @@ static int plan_forward(Plan& P, const float* x_in, void* const* bn_stats, float
       }
       case GCL_OP_CAT: {
         const int ca = op.cin, cb = op.cout - op.cin;
+        if (P.t[op.x].ld == op.cout && P.t[op.x].ptr == y.ptr && y.ptr) {      // left input already in place (cat_left)
+          if (!A.dry) {
+            hipLaunchKernelGGL(k_cat_right, dim3(grid_for(n_out * cb / 4)), dim3(256), 0, st, (const float4*)P.t[op.x2].ptr,
+                               cb / 4, n_out, ca / 4, (float4*)y.ptr, y.amax);
+            GCL_CHECK_LAUNCH();
+          }
+          break;
+        }
         y.ptr = A.take_n<float>(n_out * op.cout);
         y.amax = new_slot(P);
         if (!A.dry) {
@@ -1140,6 +1180,18 @@ void* gcl_plan_create(const gcl_plan_op* ops_host, int32_t n_ops, int32_t n_tens
     for (size_t j = 0; j < P->ops.size(); ++j)
       if (j != i + 1 && (P->ops[j].x == a.y || P->ops[j].x2 == a.y)) other = true;
     if (!other) P->fuse_relu[i] = 1;
+  }
+  P->cat_left.assign(P->ops.size(), -1);
+  static const bool cat_inplace = [] { const char* e = getenv("GCL_CAT_INPLACE"); return !(e && e[0] == '0'); }();
+  for (size_t i = 0; ok && cat_inplace && i < P->ops.size(); ++i) {
+    const gcl_plan_op& a = P->ops[i];
+    if (a.kind != GCL_OP_CONVBN || a.cin <= 4 || a.y == P->ops.back().y) continue;
+    int cat = -1, consumers = 0;
+    for (size_t j = 0; j < P->ops.size(); ++j) {
+      if (P->ops[j].kind == GCL_OP_CAT && P->ops[j].x == a.y && P->ops[j].x2 != a.y && j > i) cat = (int)j;
+      consumers += (P->ops[j].x == a.y) + (P->ops[j].x2 == a.y);
+    }
+    if (cat >= 0 && consumers == 1) P->cat_left[i] = cat;
   }
   P->mask_from.assign(P->ops.size(), -1);
   for (size_t i = 0; ok && fuse_relu_on && i < P->ops.size(); ++i) {

@@ -328,6 +328,11 @@ int gcl_bn_stats_from_tiles(const float* partial, int64_t n_tiles, int64_t n, in
 int gcl_bn_apply(const float* x, int64_t n, int32_t c, const float* mean, const float* rstd,
                  const float* weight, const float* bias, const float* residual, int32_t relu,
                  float* y, uint64_t* relu_mask, int32_t* y_amax, void* stream);
+/* the same with y a column slice of a wider row-major tensor (row pitch y_ld floats, 0 = c): the plan writes the decoder
+ * input of an ME.cat (model/resunet.py:206,213,220) straight into the cat's output */
+int gcl_bn_apply_ld(const float* x, int64_t n, int32_t c, const float* mean, const float* rstd,
+                    const float* weight, const float* bias, const float* residual, int32_t relu,
+                    float* y, int32_t y_ld, uint64_t* relu_mask, int32_t* y_amax, void* stream);
 int64_t gcl_bn_mask_len(int64_t n, int32_t c);                  /* uint64 words */
 int gcl_bn_bwd_reduce(const float* x, const float* dy, const float* y, const uint64_t* relu_mask, int64_t n,
                       int32_t c, const float* mean, const float* rstd, int32_t relu, double* scratch,
