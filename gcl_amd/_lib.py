@@ -141,6 +141,8 @@ SIGNATURES = {
     "gcl_neg_mask": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp]),
     "gcl_neg_loss_fwd": (_i32, [_vp, _vp, _i32, _f32, _vp, _vp]),
     "gcl_neg_loss_bwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _vp, _vp, _vp, _vp]),
+    "gcl_loss_combine": (_i32, [_vp, _vp, _i32, _vp, _f32, _f32, _f32, _vp, _vp]),
+    "gcl_loss_seed": (_i32, [_vp, _f32, _f32, _f32, _i32, _vp, _vp, _vp, _vp]),
 }
 
 PAIR_CHUNK = 128   # GCL_PAIR_CHUNK

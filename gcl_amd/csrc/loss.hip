@@ -514,6 +514,51 @@ __global__ void __launch_bounds__(64) k_neg_loss_bwd(const float* __restrict__ f
   atomicAdd(&df[rb * c + lane], -coef * diff);
 }
 
+
+// The step's scalar arithmetic in one launch: pos_mean = sum(pos) / n_sel, fin_mean = sum(fin) / n_sel (lib/colocation_
+// trainer.py:533-535), total = w_pos * pos_mean + w_fin * fin_mean + w_neg * neg (:865-868).  One workgroup, fp64 thread
+// sums in a fixed tree (deterministic).  out = {total, pos_mean, fin_mean, neg}.
+__global__ void __launch_bounds__(256) k_loss_combine(const float* __restrict__ pos, const float* __restrict__ fin, int n_sel,
+                                                      const float* __restrict__ neg, float w_pos, float w_fin, float w_neg,
+                                                      float* __restrict__ out) {
+  __shared__ double red[2][256];
+  const int t = threadIdx.x;
+  double a = 0, b = 0;
+  for (int i = t; i < n_sel; i += 256) {
+    a += (double)pos[i];
+    b += (double)fin[i];
+  }
+  red[0][t] = a;
+  red[1][t] = b;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) {
+      red[0][t] += red[0][t + o];
+      red[1][t] += red[1][t + o];
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    const float pm = (float)red[0][0] / (float)n_sel, fm = (float)red[1][0] / (float)n_sel, ng = neg[0];
+    out[0] = (w_pos * pm + w_fin * fm) + w_neg * ng;
+    out[1] = pm;
+    out[2] = fm;
+    out[3] = ng;
+  }
+}
+// ... and its backward: the upstream gradients of the three terms from the gradient of the total
+__global__ void __launch_bounds__(256) k_loss_seed(const float* __restrict__ g_total, float w_pos, float w_fin, float w_neg,
+                                                   int n_sel, float* __restrict__ gpos, float* __restrict__ gfin,
+                                                   float* __restrict__ gneg) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const float g = g_total[0];
+  if (i < n_sel) {
+    gpos[i] = (g * w_pos) / (float)n_sel;
+    gfin[i] = (g * w_fin) / (float)n_sel;
+  }
+  if (i == 0) gneg[0] = g * w_neg;
+}
+
 }  // namespace gcl
 
 using namespace gcl;
@@ -650,6 +695,23 @@ int gcl_neg_loss_bwd(const float* f, int32_t c, const int64_t* sel1, const int64
   GCL_CHECK_ARG(c >= 1 && c <= 64, "gcl_neg_loss_bwd: feature width must be <= 64");
   hipLaunchKernelGGL(k_neg_loss_bwd, dim3(m), dim3(64), 0, (hipStream_t)stream, f, c, (const long long*)sel1,
                      (const long long*)sel2, arg, dmin, keep, thresh, out, gneg, df);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int gcl_loss_combine(const float* pos, const float* fin, int32_t n_sel, const float* neg, float w_pos, float w_fin,
+                     float w_neg, float* out, void* stream) {
+  GCL_CHECK_ARG(pos && fin && neg && out && n_sel > 0, "gcl_loss_combine: bad argument");
+  hipLaunchKernelGGL(k_loss_combine, dim3(1), dim3(256), 0, (hipStream_t)stream, pos, fin, n_sel, neg, w_pos, w_fin, w_neg, out);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int gcl_loss_seed(const float* g_total, float w_pos, float w_fin, float w_neg, int32_t n_sel, float* gpos, float* gfin,
+                  float* gneg, void* stream) {
+  GCL_CHECK_ARG(g_total && gpos && gfin && gneg && n_sel > 0, "gcl_loss_seed: bad argument");
+  hipLaunchKernelGGL(k_loss_seed, dim3((unsigned)cdiv(n_sel, 256)), dim3(256), 0, (hipStream_t)stream, g_total, w_pos, w_fin,
+                     w_neg, n_sel, gpos, gfin, gneg);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }

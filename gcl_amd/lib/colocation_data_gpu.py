@@ -75,7 +75,9 @@ def colocation_groups_gpu(xyz_own, xyz_cf, coords, n_center, n_clouds, list_M, v
     cap = _cap(ntot)
     table = torch.empty((cap, 2), dtype=torch.int64, device=dev)
     status = torch.empty(4, dtype=torch.int32, device=dev)
-    _lib.check(lib.gcl_coords_insert(_lib.ptr(coords.contiguous(), torch.int32), ntot, _lib.ptr(table), cap,
+    coords = coords.contiguous()          # named, not temporaries inside the call: a temporary's block is reused at once
+    xyz_own, xyz_cf = xyz_own.contiguous(), xyz_cf.contiguous()
+    _lib.check(lib.gcl_coords_insert(_lib.ptr(coords, torch.int32), ntot, _lib.ptr(table), cap,
                                      _lib.ptr(status), _lib.stream()), "gcl_coords_insert")
     to_cloud = np.zeros((n_clouds, 12), dtype=np.float64)
     to_cloud[0] = np.eye(4)[:3].reshape(-1)
@@ -84,8 +86,8 @@ def colocation_groups_gpu(xyz_own, xyz_cf, coords, n_center, n_clouds, list_M, v
     hits = torch.empty((n_center, n_clouds, K), dtype=torch.int32, device=dev)
     cnt = torch.empty((n_center, n_clouds), dtype=torch.int32, device=dev)
     rng = torch.empty((n_center, n_clouds), dtype=torch.float64, device=dev)
-    _lib.check(lib.gcl_colocation_hits(_lib.ptr(xyz_own.contiguous(), torch.float32),
-                                       _lib.ptr(xyz_cf.contiguous(), torch.float32), n_center, n_clouds,
+    _lib.check(lib.gcl_colocation_hits(_lib.ptr(xyz_own, torch.float32),
+                                       _lib.ptr(xyz_cf, torch.float32), n_center, n_clouds,
                                        to_cloud.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), _lib.ptr(table), cap,
                                        float(1.0 / voxel_size), float(radius), K, _lib.ptr(hits), _lib.ptr(cnt),
                                        _lib.ptr(rng), _lib.stream()), "gcl_colocation_hits")

@@ -85,22 +85,64 @@ class _GCLLossFn(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, gpos, gfin, gneg):
+        return (_GCLLossFn.backward_terms(ctx, gpos, gfin, gneg),) + (None,) * 11
+
+    @staticmethod
+    def backward_terms(ctx, gpos, gfin, gneg):
         lib = _lib.load()
         F, index, goff, flag, sel, sel1, sel2, dmin, arg, keep, out, pairpos = ctx.saved_tensors
         pos_thresh, fin_thresh, neg_thresh, flags = ctx.th
         n, c = F.shape
         st = _lib.stream()
         dF = torch.zeros_like(F)
+        # the contiguous copies are NAMED: a temporary handed to _lib.ptr dies with that call and the caching allocator
+        # gave its block to the next temporary -- gpos and gfin (expanded tensors out of sum()'s backward) then shared one
+        # address and the kernel read gfin for both, unnoticed while pos_weight == finest_weight (every test, the defaults)
+        gpos_c, gfin_c = gpos.contiguous(), gfin.contiguous()
         _lib.check(lib.gcl_group_loss_bwd(_lib.ptr(F), c, _lib.ptr(index), _lib.ptr(goff), _lib.ptr(flag),
                                           _lib.ptr(sel), sel.shape[0], pos_thresh, fin_thresh, flags,
-                                          _lib.ptr(pairpos), _lib.ptr(gpos.contiguous()),
-                                          _lib.ptr(gfin.contiguous()), _lib.ptr(dF), st),
+                                          _lib.ptr(pairpos), _lib.ptr(gpos_c), _lib.ptr(gfin_c), _lib.ptr(dF), st),
                    "gcl_group_loss_bwd")
         g = gneg.reshape(1).contiguous()
         _lib.check(lib.gcl_neg_loss_bwd(_lib.ptr(F), c, _lib.ptr(sel1), _lib.ptr(sel2), _lib.ptr(arg), _lib.ptr(dmin),
                                         _lib.ptr(keep), sel1.shape[0], neg_thresh, _lib.ptr(out), _lib.ptr(g),
                                         _lib.ptr(dF), st), "gcl_neg_loss_bwd")
-        return (dF,) + (None,) * 11
+        return dF
+
+
+class _GCLTotalLossFn(torch.autograd.Function):
+    """(total, pos_mean, fin_mean, neg) with total = w_pos * pos.sum() / n + w_fin * fin.sum() / n + w_neg * neg
+    (lib/colocation_trainer.py:533-535, :865-868) as ONE autograd node: the two sums, two divisions and the weighted
+    sum are one launch (gcl_loss_combine), their backward another (gcl_loss_seed) -- the same values, without the ~20
+    one-element torch kernels (and their launch gaps) that sat between the network's forward and backward pass of every
+    training step.  Only ``total`` carries a gradient; the three terms are returned for the meters."""
+
+    @staticmethod
+    def forward(ctx, F, index, goff, flag, sel, sel1, sel2, pos_thresh, fin_thresh, neg_thresh, flags, pairpos,
+                w_pos, w_fin, w_neg):
+        lib = _lib.require_gpu()
+        pos, fin, neg = _GCLLossFn.forward(ctx, F, index, goff, flag, sel, sel1, sel2, pos_thresh, fin_thresh, neg_thresh,
+                                           flags, pairpos)
+        out = torch.empty(4, dtype=torch.float32, device=F.device)
+        _lib.check(lib.gcl_loss_combine(_lib.ptr(pos), _lib.ptr(fin), pos.shape[0], _lib.ptr(neg), float(w_pos),
+                                        float(w_fin), float(w_neg), _lib.ptr(out), _lib.stream()), "gcl_loss_combine")
+        ctx.w = (float(w_pos), float(w_fin), float(w_neg))
+        total, pm, fm, ng = out[0], out[1], out[2], out[3]
+        ctx.mark_non_differentiable(pm, fm, ng)
+        return total, pm, fm, ng
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gtotal, _gp, _gf, _gn):
+        lib = _lib.load()
+        n_sel = ctx.saved_tensors[4].shape[0]
+        dev = gtotal.device
+        seeds = torch.empty(2 * n_sel + 1, dtype=torch.float32, device=dev)
+        g = gtotal.reshape(1).contiguous().float()
+        _lib.check(lib.gcl_loss_seed(_lib.ptr(g), ctx.w[0], ctx.w[1], ctx.w[2], n_sel, _lib.ptr(seeds),
+                                     _lib.ptr(seeds[n_sel:]), _lib.ptr(seeds[2 * n_sel:]), _lib.stream()), "gcl_loss_seed")
+        dF = _GCLLossFn.backward_terms(ctx, seeds[:n_sel], seeds[n_sel:2 * n_sel], seeds[2 * n_sel:])
+        return (dF,) + (None,) * 14
 
 
 LOSS_SQRT, LOSS_BLOCK, LOSS_PAIR, LOSS_NOFIN = 1, 2, 4, 8      # GCL_LOSS_* of include/gcl_amd.h
@@ -175,7 +217,7 @@ def finest_contrastive_loss(F_out, group, index, index_hash, finest_flag, max_po
                             points=None, batch_lengths=None, pos_thresh=0.1, neg_thresh=1.4, finest_thresh=0.2,
                             draws=None, square_loss=True, block_finest_gradient=False,
                             use_pair_group_positive_loss=False, use_hard_negative=True, finest_term=True,
-                            prepared=None):
+                            prepared=None, total_weights=None):
     """(pos_loss, finest_loss, neg_loss) of lib/colocation_trainer.py:430-535 with its four config switches
     (defaults = scripts/train_gcl_kitti.sh:96-105).  ``finest_term=False`` gives ``location_contrastive_loss``
     (:734-809) when combined with ``square_loss=False``.
@@ -186,7 +228,9 @@ def finest_contrastive_loss(F_out, group, index, index_hash, finest_flag, max_po
     (:514-515), which BROADCASTS -- every row j is paired with every drawn column c_i, the masks (:521-529) broadcast
     the same way, and the loss is the mean of relu(neg_thresh - D[j, c_i])^2 over the kept (i, j) cells
     (``random_negative_term``; pinned by a golden captured from the reference).  ``index_hash``, ``points`` and
-    ``batch_lengths`` are unused (see module docstring).
+    ``batch_lengths`` are unused (see module docstring).  ``total_weights=(w_pos, w_fin, w_neg)`` (the trainer's step, with
+    hard negatives): returns ``(total, pos, fin, neg)`` from one autograd node instead -- same values, the scalar arithmetic
+    in one launch each way; only ``total`` carries a gradient.
     """
     dev = F_out.device
     n_out = F_out.shape[0]
@@ -215,6 +259,12 @@ def finest_contrastive_loss(F_out, group, index, index_hash, finest_flag, max_po
     np.concatenate([np.asarray(pos_sel, dtype=np.int64), np.asarray(sel_hn1, dtype=np.int64),
                     np.asarray(sel_hn2, dtype=np.int64)], out=sel_host.numpy())
     sel_all = sel_host.to(dev, non_blocking=True)
+    if total_weights is not None and use_hard_negative:
+        # the trainer's step: (total, pos, fin, neg) from one autograd node (``_GCLTotalLossFn``); only total has a gradient
+        return _GCLTotalLossFn.apply(F_out, index, goff, flag, sel_all[:n_pos], sel_all[n_pos:n_pos + n_hn],
+                                     sel_all[n_pos + n_hn:], float(pos_thresh), float(finest_thresh), float(neg_thresh),
+                                     flags, to_dev32(pair_pos) if use_pair_group_positive_loss else None,
+                                     *[float(w) for w in total_weights])
     pos, fin, neg = _GCLLossFn.apply(F_out, index, goff, flag, sel_all[:n_pos], sel_all[n_pos:n_pos + n_hn],
                                      sel_all[n_pos + n_hn:], float(pos_thresh), float(finest_thresh), float(neg_thresh),
                                      flags, to_dev32(pair_pos) if use_pair_group_positive_loss else None)
@@ -338,11 +388,11 @@ class _CircleGroupFn(torch.autograd.Function):
         F, index, goff, flag, sel, pairpos = ctx.saved_tensors
         pos_thresh, fin_thresh, log_scale, flags = ctx.cfg
         dF = torch.zeros_like(F)
+        gpos_c, gfin_c, gmean_c = gpos.contiguous(), gfin.contiguous(), gmean.contiguous()     # named: see _GCLLossFn
         _lib.check(lib.gcl_circle_group_bwd(_lib.ptr(F), F.shape[1], _lib.ptr(index), _lib.ptr(goff), _lib.ptr(flag),
                                             _lib.ptr(sel), sel.shape[0], pos_thresh, fin_thresh, log_scale, flags,
-                                            _lib.ptr(pairpos), _lib.ptr(gpos.contiguous()),
-                                            _lib.ptr(gfin.contiguous()), _lib.ptr(gmean.contiguous()), _lib.ptr(dF),
-                                            _lib.stream()), "gcl_circle_group_bwd")
+                                            _lib.ptr(pairpos), _lib.ptr(gpos_c), _lib.ptr(gfin_c), _lib.ptr(gmean_c),
+                                            _lib.ptr(dF), _lib.stream()), "gcl_circle_group_bwd")
         return (dF,) + (None,) * 9
 
 
@@ -488,7 +538,7 @@ class FinestContrastiveLossTrainer:
         return self._bucket_map
 
     def location_loss(self, F_out, group, index, index_hash, finest_flag, max_pos_cluster, max_hn_samples,
-                      points=None, batch_lengths=None, draws=None, prepared=None):
+                      points=None, batch_lengths=None, draws=None, prepared=None, total_weights=None):
         cfg = self.config
         if cfg.use_group_circle_loss:         # lib/colocation_trainer.py:423-424
             return location_circle_loss(F_out, group, index, index_hash, finest_flag, max_pos_cluster, max_hn_samples,
@@ -502,20 +552,28 @@ class FinestContrastiveLossTrainer:
         return finest_contrastive_loss(F_out, group, index, index_hash, finest_flag, max_pos_cluster, max_hn_samples,
                                        points, batch_lengths, cfg.pos_thresh, cfg.neg_thresh, cfg.finest_thresh, draws,
                                        cfg.square_loss, cfg.block_finest_gradient, cfg.use_pair_group_positive_loss,
-                                       cfg.use_hard_negative, prepared=prepared)
+                                       cfg.use_hard_negative, prepared=prepared, total_weights=total_weights)
 
-    def forward_loss(self, input_dict, draws=None):
+    def forward_loss(self, input_dict, draws=None, fused_total=False):
+        """``fused_total``: the weighted total comes out of the loss node itself (one optimizer step on one batch; with
+        gradient accumulation the terms are rescaled first, :875-877, and the sum stays in torch)."""
         cfg = self.config
         sinput = ME.SparseTensor(input_dict["sinput_F"].to(self.device, non_blocking=True),
                                  coordinates=input_dict["sinput_C"].to(self.device, non_blocking=True),
                                  coordinate_manager=input_dict.get("_coordinate_manager"))
         F_out = self.model(sinput).F
-        pos, fin, neg = self.location_loss(
+        fuse = (fused_total and not cfg.use_group_circle_loss and cfg.finest_weight != 0 and cfg.use_hard_negative
+                and os.environ.get("GCL_FUSED_LOSS_TOTAL", "1") == "1")
+        terms = self.location_loss(
             F_out, input_dict["group"], input_dict["index"], input_dict.get("index_hash"), input_dict["finest_flag"],
             max_pos_cluster=cfg.num_pos_per_batch * cfg.batch_size,
             max_hn_samples=cfg.num_hn_samples_per_batch * cfg.batch_size,
             points=input_dict["sinput_C"][:, 1:] if cfg.use_group_circle_loss else None,
-            batch_lengths=input_dict.get("batch_lengths"), draws=draws, prepared=input_dict.get("_loss_inputs"))
+            batch_lengths=input_dict.get("batch_lengths"), draws=draws, prepared=input_dict.get("_loss_inputs"),
+            total_weights=(self.pos_weight, self.finest_weight, self.neg_weight) if fuse else None)
+        if len(terms) == 4:
+            return terms[0], tuple(terms[1:]), F_out
+        pos, fin, neg = terms
         loss = self.pos_weight * pos + self.finest_weight * fin + self.neg_weight * neg
         return loss, (pos, fin, neg), F_out
 
@@ -779,7 +837,7 @@ class FinestContrastiveLossTrainer:
                 plan.on_bucket = self.ddp.bucket_ready if overlap else None
             wait_for_batch(b)
             try:
-                loss, parts, F_out = self.forward_loss(b, d)
+                loss, parts, F_out = self.forward_loss(b, d, fused_total=(n_micro == 1))
                 if n_micro > 1:
                     parts = tuple(p / n_micro for p in parts)         # :875-877
                     loss = self.pos_weight * parts[0] + self.finest_weight * parts[1] + self.neg_weight * parts[2]

@@ -427,6 +427,15 @@ int gcl_neg_loss_fwd(const float* dmin, const uint8_t* keep, int32_t m, float th
 int gcl_neg_loss_bwd(const float* f, int32_t c, const int64_t* sel1, const int64_t* sel2, const int32_t* arg,
                      const float* dmin, const uint8_t* keep, int32_t m, float thresh, const float* out,
                      const float* gneg, float* df, void* stream);
+/* The step's scalar arithmetic in one launch each way (lib/colocation_trainer.py:533-535, :865-868):
+ * out = {total, pos_mean, fin_mean, neg} with pos_mean = sum(pos) / n_sel, fin_mean = sum(fin) / n_sel,
+ * total = w_pos * pos_mean + w_fin * fin_mean + w_neg * neg[0]; gcl_loss_seed writes the upstream gradients of the
+ * terms for gcl_group_loss_bwd / gcl_neg_loss_bwd from the gradient of the total: gpos[i] = gfin-alike
+ * (g * w) / n_sel, gneg[0] = g * w_neg. */
+int gcl_loss_combine(const float* pos, const float* fin, int32_t n_sel, const float* neg, float w_pos, float w_fin,
+                     float w_neg, float* out, void* stream);
+int gcl_loss_seed(const float* g_total, float w_pos, float w_fin, float w_neg, int32_t n_sel, float* gpos, float* gfin,
+                  float* gneg, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * SC2-PCR registration back-end (scripts/SC2_PCR/SC2_PCR.py, Matcher.SC2_PCR :304-381) for ONE pair:

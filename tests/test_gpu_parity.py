@@ -674,6 +674,29 @@ def test_finest_contrastive_loss_golden(path):
         assert abs(neg.item() - float(z["neg"])) < 2e-6
         (pos + fin + neg).backward()
         assert rel_l2(F.grad.cpu(), z["grad"]) < 1e-5
+    # the trainer's one-node total (``total_weights``): same terms, total = the weighted sum, dL/dF = that of the sum
+    if sw.get("use_hard_negative", True) and not np.isnan(float(z["neg"])):
+        w = (0.7, 1.3, 0.9)
+        F2 = torch.from_numpy(z["F_out"]).to(DEV).requires_grad_(True)
+        tot, p1, f1, n1 = finest_contrastive_loss(F2, torch.from_numpy(z["group"]), torch.from_numpy(z["index"]),
+                                                  z["index_hash"], torch.from_numpy(z["finest_flag"]), draws=draws,
+                                                  total_weights=w, **kw)
+        assert not (p1.requires_grad or f1.requires_grad or n1.requires_grad) and tot.requires_grad
+        assert abs(p1.item() - pos.item()) < 1e-6 and abs(f1.item() - fin.item()) < 1e-6 and n1.item() == neg.item()
+        assert abs(tot.item() - (w[0] * pos.item() + w[1] * fin.item() + w[2] * neg.item())) < 2e-6
+        (2.0 * tot).backward()
+        F3 = torch.from_numpy(z["F_out"]).to(DEV).requires_grad_(True)
+        p3, f3, n3 = finest_contrastive_loss(F3, torch.from_numpy(z["group"]), torch.from_numpy(z["index"]),
+                                             z["index_hash"], torch.from_numpy(z["finest_flag"]), draws=draws, **kw)
+        (2.0 * (w[0] * p3 + w[1] * f3 + w[2] * n3)).backward()
+        assert rel_l2(F2.grad.cpu(), F3.grad.cpu()) < 1e-6
+        # ... and both equal the oracle's autograd with UNEQUAL weights (pos_weight != finest_weight used to read the
+        # finest term's upstream gradient for both terms: two temporaries shared one address)
+        Fo = torch.from_numpy(z["F_out"]).double().requires_grad_(True)
+        po, fo, no = LO.finest_contrastive_loss(Fo, z["group"], z["index"], z["index_hash"], z["finest_flag"],
+                                                draws=draws, **kw)
+        (2.0 * (w[0] * po + w[1] * fo + w[2] * no)).backward()
+        assert rel_l2(F3.grad.cpu(), Fo.grad) < 1e-5 and rel_l2(F2.grad.cpu(), Fo.grad) < 1e-5
     # drawing on the host from a seeded np.random reproduces the reference's selections
     np.random.seed(int(z["np_seed"]))
     p2, f2, n2 = finest_contrastive_loss(F.detach(), torch.from_numpy(z["group"]), torch.from_numpy(z["index"]),
