@@ -90,6 +90,7 @@ SIGNATURES = {
     "gcl_conv_bwd_weight": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, ctypes.POINTER(_i64), _i32, _i32, _i32, _i32, _vp,
                                    _vp, _vp, _vp, _vp]),
     "gcl_presence_bits": (_i32, [_vp, _i32, _i64, _vp, _vp]),
+    "gcl_kernel_map_3_from_5": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "gcl_not_ones_rows": (_i32, [_vp, _i32, _vp, _i64, _vp, _i32, _vp, _vp]),
     "gcl_stem_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "gcl_stem_bwd_weight_scratch_len": (_i64, [_i32, _i32, _i32, _i64]),

@@ -713,6 +713,18 @@ __global__ void __launch_bounds__(256) k_tile_masks(const unsigned* __restrict__
   tile_masks_body(keys_sorted, n, n_tiles, tile_mask, pos, K, blockIdx.x);
 }
 
+// The 3^3 stride-1 map of a level from its 5^3 stride-1 map: offset (dx, dy, dz) in {-1, 0, 1}^3 is row
+// (dx + 2) + 5 (dy + 2) + 25 (dz + 2) of the 5^3 table and row (dx + 1) + 3 (dy + 1) + 9 (dz + 1) of the 3^3 one -- the same
+// lookups, already answered (a copy of 27 rows instead of 13 hash probes per voxel).  blockIdx.y = 3^3 offset.
+__global__ void __launch_bounds__(256) k_map3_from_map5(const int* __restrict__ nbr5, const int* __restrict__ counts5,
+                                                        long long n, int* __restrict__ nbr3, int* __restrict__ counts3) {
+  const int k3 = blockIdx.y;
+  const int k5 = (k3 % 3 + 1) + 5 * ((k3 / 3) % 3 + 1) + 25 * (k3 / 9 + 1);
+  const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < n) nbr3[(long long)k3 * n + v] = nbr5[(long long)k5 * n + v];
+  if (blockIdx.x == 0 && threadIdx.x == 0) counts3[k3] = counts5[k5];
+}
+
 // presence words of a neighbour table: bit (k & 31) of bits[v][k >> 5] = nbr[k][v] >= 0 (the first layer's occupancy path)
 __global__ void __launch_bounds__(256) k_presence_bits(const int* __restrict__ nbr, int K, long long n, unsigned* bits) {
   const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1054,6 +1066,15 @@ int gcl_table_sort_pre(const int32_t* tbl, int32_t K, int64_t n, int32_t window,
                      (long long)n, n_tiles, tile_mask, (const int*)key_pos, K);
   hipLaunchKernelGGL(k_permute_table, dim3((unsigned)cdiv(n, 256), K), dim3(256), 0, st, tbl, (const int*)order,
                      (long long)n, tbl_sorted, (const int*)tile_mask);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int gcl_kernel_map_3_from_5(const int32_t* nbr5, const int32_t* counts5, int64_t n, int32_t* nbr3, int32_t* counts3,
+                            void* stream) {
+  GCL_CHECK_ARG(nbr5 && counts5 && nbr3 && counts3 && n > 0, "gcl_kernel_map_3_from_5: bad argument");
+  hipLaunchKernelGGL(k_map3_from_map5, dim3((unsigned)cdiv(n, 256), 27), dim3(256), 0, (hipStream_t)stream, nbr5, counts5,
+                     (long long)n, nbr3, counts3);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }

@@ -258,6 +258,17 @@ static int maps_build(const int32_t* coords, long long n, const gcl_map_spec* sp
     const bool same = sp.stride == 1;
     d.nbr_t = same ? nullptr : A.take_n<int32_t>((long long)d.K * d.n_in);
     d.counts = A.take_n<int32_t>(d.K);
+    // a 3^3 stride-1 map of a table whose 5^3 stride-1 map is already built: 27 of its rows (GCL_MAP3_FROM5=0: probe again)
+    static const bool from5 = [] { const char* e = getenv("GCL_MAP3_FROM5"); return !(e && e[0] == '0'); }();
+    int src5 = -1;
+    for (int q = 0; q < s && from5 && same && sp.kernel_size == 3; ++q)
+      if (specs[q].t_in == sp.t_in && specs[q].kernel_size == 5 && specs[q].stride == 1 && out->maps[q].nbr) src5 = q;
+    if (src5 >= 0) {
+      PLAN_CALL(gcl_kernel_map_3_from_5(out->maps[src5].nbr, out->maps[src5].counts, d.n_out, d.nbr, d.counts, stream));
+      if (!A.dry && any_pairs)
+        GCL_CHECK_HIP(hipMemcpyAsync(pinned + 128 * (s + 1), d.counts, sizeof(int32_t) * d.K, hipMemcpyDeviceToHost, st));
+      continue;
+    }
     const bool bitmap_valid = bitmap[d.level_in] != nullptr;
     if (!bitmap_valid) bitmap[d.level_in] = A.take_n<int32_t>(gcl_kernel_map_bitmap_len());
     int32_t* scratch = A.take_n<int32_t>(gcl_kernel_map_scratch_len(sp.kernel_size, d.n_out));

@@ -293,6 +293,11 @@ int gcl_conv_bwd_weight(const float* a, int64_t n_a, const float* b, int64_t n_b
  * gcl_not_ones_rows: a row's kernel-map neighbours share its batch index (coords[v][0], part of the key), so the flag is
  * per cloud: cloud_flags (int32 [n_cloud_flags] scratch, zeroed here) gets 1 for a batch index with a feature != 1.0f,
  * row_flags[v] = cloud_flags[batch index of v] (1 when the index does not fit the scratch). */
+/* the 3^3 stride-1 kernel map of a coordinate table from its 5^3 stride-1 map (the same neighbour lookups, already
+ * answered: nbr3 = 27 rows of nbr5, counts3 = their counts) -- gcl_maps_build uses it when a network asks for both
+ * (conv1 5^3 + block1 3^3 on the input table, model/resunet.py:38-46, :59-60); bit-exact the direct build */
+int gcl_kernel_map_3_from_5(const int32_t* nbr5, const int32_t* counts5, int64_t n, int32_t* nbr3, int32_t* counts3,
+                            void* stream);
 int gcl_presence_bits(const int32_t* nbr, int32_t K, int64_t n, uint32_t* bits, void* stream);
 int gcl_not_ones_rows(const float* x, int32_t cin, const int32_t* coords, int64_t n, int32_t* cloud_flags,
                       int32_t n_cloud_flags, int32_t* row_flags, void* stream);
