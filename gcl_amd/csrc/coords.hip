@@ -399,7 +399,8 @@ __global__ void __launch_bounds__(256) k_pairs_emit(const int* __restrict__ nbr,
     s += (u[j] >= 0);
   }
   int tot;
-  long long p = seg.off[k] + bc[(long long)k * nb + blockIdx.x] + block_excl_scan(s, lds, &tot);
+  const long long blk0 = seg.off[k] + bc[(long long)k * nb + blockIdx.x];
+  long long p = blk0 + block_excl_scan(s, lds, &tot);
 #pragma unroll
   for (int j = 0; j < 4; ++j)
     if (u[j] >= 0) {
@@ -407,6 +408,10 @@ __global__ void __launch_bounds__(256) k_pairs_emit(const int* __restrict__ nbr,
       pair_out[p] = (int)(base + j);
       ++p;
     }
+  // the segment's padding (< GCL_PAIR_CHUNK entries behind its last pair) is written here, by the offset's last block --
+  // the lists used to be filled with -1 as a whole first (two passes over every list, ~15 fills per batch)
+  if ((int)blockIdx.x == nb - 1)
+    for (long long q = blk0 + tot + threadIdx.x; q < seg.off[k + 1]; q += blockDim.x) pair_in[q] = pair_out[q] = -1;
 }
 
 
@@ -946,14 +951,6 @@ int gcl_kernel_map_pairs(const int32_t* nbr, int32_t K, int64_t n_out, const int
                   GCL_PAIR_CHUNK);
   }
   int nb = (int)cdiv(n_out, PAIR_B);
-  if (seg.off[K] > 0) {
-    if (pair_out == pair_in + seg.off[K]) {   // adjacent lists: one fill
-      GCL_CHECK_HIP(hipMemsetAsync(pair_in, 0xFF, (size_t)seg.off[K] * 2 * sizeof(int32_t), st));
-    } else {
-      GCL_CHECK_HIP(hipMemsetAsync(pair_in, 0xFF, (size_t)seg.off[K] * sizeof(int32_t), st));
-      GCL_CHECK_HIP(hipMemsetAsync(pair_out, 0xFF, (size_t)seg.off[K] * sizeof(int32_t), st));
-    }
-  }
   hipLaunchKernelGGL(k_pairs_count, dim3(nb, K), dim3(256), 0, st, nbr, (long long)n_out, nb, scratch);
   hipLaunchKernelGGL(k_pairs_scan, dim3(K), dim3(256), 0, st, scratch, nb);
   hipLaunchKernelGGL(k_pairs_emit, dim3(nb, K), dim3(256), 0, st, nbr, (long long)n_out, nb, (const int*)scratch, seg,
