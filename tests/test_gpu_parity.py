@@ -406,6 +406,50 @@ def test_lds_dma_forward_kernel_is_bitwise_the_register_staged_kernel(cin, cout,
         assert rel_l2(out[(2, False)][0].cpu(), yo) < 2e-6
 
 
+@pytest.mark.parametrize("cin,cout,K", [(32, 64, 1), (64, 64, 27)])
+def test_fused_epilogue_relu_forward_and_threshold_backward(cin, cout, K):
+    """gcl_conv_fwd_fused's two ReLU modes against the plain launch: relu = 1 is max(conv, 0) with max|y| published (conv1_tr ->
+    MEF.relu, model/resunet.py:222-223), relu = 2 passes conv where `residual` > 0 and writes 0 elsewhere -- the backward of a
+    ReLU applied in the consumer's input-gradient epilogue (aten::threshold_backward(g, y, 0))."""
+    from gcl_amd import _lib
+    import gcl_amd.MinkowskiEngine as ME
+    lib = _lib.load()
+    C = random_cloud(9, n=5000, extent=20, batch=2)
+    mgr = make_mgr(C)
+    n_out = len(C)
+    g = torch.Generator().manual_seed(cin + K)
+    with torch.cuda.device(DEV):
+        tbl = order = mask = None
+        if K > 1:
+            tbl, order, mask = mgr.get_kernel_map(1, 3, 1).sorted_table()
+        x = torch.randn(n_out, cin, generator=g).to(DEV)
+        W = (0.1 * torch.randn(K, cin, cout, generator=g)).to(DEV)
+        gate = torch.randn(n_out, cout, generator=g).to(DEV)          # the "ReLU output" whose sign gates mode 2
+        xa, wa = ME.ops.amax_slot(x.device), ME.ops.amax_slot(x.device)
+        _lib.check(lib.gcl_amax(_lib.ptr(x), x.numel(), _lib.ptr(xa), 1, _lib.stream()), "gcl_amax")
+        _lib.check(lib.gcl_amax(_lib.ptr(W), W.numel(), _lib.ptr(wa), 1, _lib.stream()), "gcl_amax")
+        wp = torch.empty(lib.gcl_pack_weights_bytes(K, cin, cout, 4), dtype=torch.uint8, device=DEV)
+        _lib.check(lib.gcl_pack_weights(_lib.ptr(W), K, cin, cout, 0, 4, _lib.ptr(wa), _lib.ptr(wp), _lib.stream()), "pack")
+
+        def run(relu, residual):
+            y = torch.full((n_out, cout), float("nan"), device=DEV)
+            slot = ME.ops.amax_slot(x.device)
+            _lib.check(lib.gcl_conv_fwd_fused(_lib.ptr(x), n_out, 0, _lib.ptr(wp), 4, _lib.ptr(xa), _lib.ptr(wa), _lib.ptr(tbl),
+                                              _lib.ptr(order), _lib.ptr(mask), n_out, K, cin, cout, None, None,
+                                              _lib.ptr(residual), relu, _lib.ptr(slot), _lib.ptr(y), None, 0, _lib.stream()),
+                       "gcl_conv_fwd_fused")
+            return y, ME.ops.amax_value(slot)
+        plain, _ = run(0, None)
+        y1, a1 = run(1, None)
+        assert torch.equal(y1, torch.clamp_min(plain, 0.0)) and float(a1) == float(y1.abs().max())
+        y2, a2 = run(2, gate)
+        want = torch.where(gate > 0, plain, torch.zeros_like(plain))
+        assert torch.equal(y2, want) and float(a2) == float(want.abs().max())
+        assert lib.gcl_conv_fwd_fused(_lib.ptr(x), n_out, 0, _lib.ptr(wp), 4, _lib.ptr(xa), _lib.ptr(wa), _lib.ptr(tbl),
+                                      _lib.ptr(order), _lib.ptr(mask), n_out, K, cin, cout, None, None, None, 2, None,
+                                      _lib.ptr(y2), None, 0, _lib.stream()) != 0          # mode 2 without its gate tensor
+
+
 @pytest.mark.parametrize("cin,cout,use_planes", [(128, 128, True), (64, 64, False)])
 def test_lds_dma_forward_kernel_race_screen(cin, cout, use_planes):
     """The LDS-DMA kernel orders its reads behind its DMAs by its own `s_waitcnt vmcnt(0)` + the workgroup barrier, and its
@@ -572,6 +616,33 @@ def test_batch_norm_vs_torch(c, n, res, relu, training):
         assert rel_l2(rg.grad.cpu(), ro.grad) < 2e-6
     if training and n > 1:
         assert rel_l2(rmg.cpu(), rmo) < 1e-6 and rel_l2(rvg.cpu(), rvo) < 1e-6
+
+
+@pytest.mark.parametrize("c,n,ld,relu", [(64, 1000, 96, True), (32, 257, 160, False), (128, 70000, 256, True)])
+def test_batch_norm_apply_into_a_column_slice(c, n, ld, relu):
+    """gcl_bn_apply_ld (the decoder input of an ME.cat written straight into the cat's output): the slice holds bit for bit
+    what gcl_bn_apply writes to a tensor of its own, the other columns are untouched, mask and max|y| are the same."""
+    from gcl_amd import _lib
+    import gcl_amd.MinkowskiEngine as ME
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(c + n)
+    x = (torch.randn(n, c, generator=g) * 2 + 1).to(DEV)
+    mean, rstd = torch.randn(c, generator=g).to(DEV), (torch.rand(c, generator=g) + 0.5).to(DEV)
+    w, b = (torch.rand(c, generator=g) + 0.5).to(DEV), torch.randn(c, generator=g).to(DEV)
+    res = torch.randn(n, c, generator=g).to(DEV)
+    with torch.cuda.device(DEV):
+        outs = []
+        for y_ld in (0, ld):
+            y = torch.full((n, y_ld if y_ld else c), 7.0, device=DEV)
+            mask = torch.zeros(lib.gcl_bn_mask_len(n, c), dtype=torch.int64, device=DEV)
+            slot = ME.ops.amax_slot(x.device)
+            _lib.check(lib.gcl_bn_apply_ld(_lib.ptr(x), n, c, _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(w), _lib.ptr(b),
+                                           _lib.ptr(res), int(relu), _lib.ptr(y), y_ld, _lib.ptr(mask) if relu else None,
+                                           _lib.ptr(slot), _lib.stream()), "gcl_bn_apply_ld")
+            outs.append((y, mask, ME.ops.amax_value(slot)))
+        (y0, m0, a0), (y1, m1, a1) = outs
+        assert torch.equal(y1[:, :c], y0) and bool((y1[:, c:] == 7.0).all())
+        assert torch.equal(m0, m1) and torch.equal(a0, a1)
 
 
 # ---------------------------------------------------------------------------------------------------------------
