@@ -23,7 +23,7 @@ from .. import _lib
 PLAN_ENABLED = os.environ.get("GCL_PLAN", "1") == "1"
 # weight gradients of the plan's backward pass on a second stream ("0" off, "1" same priority [default], "low" lowest
 # priority): measured 14.48 -> 13.72 ms per step (same box, alternating runs; the optimizer is their only consumer)
-AUX_STREAM = {"0": "", "1": "1", "low": "low"}[os.environ.get("GCL_PLAN_AUX", "1")]
+AUX_STREAM = {"0": "", "1": "1", "low": "low", "high": "high"}[os.environ.get("GCL_PLAN_AUX", "1")]
 
 
 def _addr(t):
@@ -311,7 +311,7 @@ class NetworkPlan:
         if AUX_STREAM and self._aux is None:
             # weight gradients run on a second (lower-priority) stream beside the input-gradient chain
             lo, _hi = torch.cuda.Stream.priority_range()
-            self._aux = torch.cuda.Stream(device=dev, priority=lo if AUX_STREAM == "low" else 0)
+            self._aux = torch.cuda.Stream(device=dev, priority={"low": lo, "high": _hi}.get(AUX_STREAM, 0))
             lib.gcl_plan_set_aux_stream(self.handle, ctypes.c_void_p(self._aux.cuda_stream))
         if self.profile_next:
             lib.gcl_plan_profile(self.handle, 1)
