@@ -30,7 +30,7 @@ class MapDesc(ctypes.Structure):      # gcl_map_desc
                 ("level_out", _i32), ("n_in", _i64), ("n_out", _i64), ("n_pairs", _i64),
                 ("nbr", _vp), ("nbr_t", _vp), ("counts", _vp),
                 ("tbl_n", _vp), ("order_n", _vp), ("mask_n", _vp), ("tbl_t", _vp), ("order_t", _vp), ("mask_t", _vp),
-                ("pair_in", _vp), ("pair_out", _vp), ("presence", _vp), ("seg_off", _i64 * 128),
+                ("pair_in", _vp), ("pair_out", _vp), ("presence", _vp), ("dw_bounds", _vp), ("seg_off", _i64 * 128),
                 ("counts_host", _i32 * 128)]
 
 
@@ -89,6 +89,10 @@ SIGNATURES = {
     "gcl_conv_bwd_weight_scratch_len": (_i64, [_i32, _i32, _i32, _i64, _i64]),
     "gcl_conv_bwd_weight": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, ctypes.POINTER(_i64), _i32, _i32, _i32, _i32, _vp,
                                    _vp, _vp, _vp, _vp]),
+    "gcl_conv_bwd_weight_bounds_len": (_i64, [_i32, _i64]),
+    "gcl_conv_bwd_weight_bounds": (_i32, [_vp, ctypes.POINTER(_i64), _i32, _i64, _vp, _vp]),
+    "gcl_conv_bwd_weight_rg": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, ctypes.POINTER(_i64), _i32, _i32, _i32, _i32, _vp,
+                                      _vp, _vp, _vp, _vp, _vp]),
     "gcl_presence_bits": (_i32, [_vp, _i32, _i64, _vp, _vp]),
     "gcl_kernel_map_3_from_5": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "gcl_not_ones_rows": (_i32, [_vp, _i32, _vp, _i64, _vp, _i32, _vp, _vp]),

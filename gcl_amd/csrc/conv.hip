@@ -2568,10 +2568,37 @@ int64_t gcl_conv_bwd_weight_scratch_len(int32_t K, int32_t ca, int32_t cb, int64
   return len;
 }
 
+int64_t gcl_conv_bwd_weight_bounds_len(int32_t K, int64_t n_sorted_rows) {
+  if (n_sorted_rows < 32768 || K <= 1 || K > 27) return 0;
+  return (long long)K * (cdiv(n_sorted_rows, dw_range_rows(n_sorted_rows, K)) + 1);
+}
+
+int gcl_conv_bwd_weight_bounds(const int32_t* sorted_rows, const int64_t* seg_off_host, int32_t K, int64_t n_sorted_rows,
+                               int32_t* bounds, void* stream) {
+  GCL_CHECK_ARG(sorted_rows && seg_off_host && bounds && gcl_conv_bwd_weight_bounds_len(K, n_sorted_rows) > 0,
+                "gcl_conv_bwd_weight_bounds: bad argument (the range-grouped mode needs 1 < K <= 27 and >= 32768 rows)");
+  SegOffW seg;
+  for (int k = 0; k <= K; ++k) seg.off[k] = seg_off_host[k];
+  const int rr = dw_range_rows(n_sorted_rows, K);
+  const int nr = (int)cdiv(n_sorted_rows, rr);
+  hipLaunchKernelGGL(k_pair_bounds, dim3((unsigned)cdiv((long long)K * (nr + 1), 256)), dim3(256), 0, (hipStream_t)stream,
+                     sorted_rows, seg, K, rr, nr, bounds);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
 int gcl_conv_bwd_weight(const float* a, int64_t n_a, const float* b, int64_t n_b, int32_t planes, int32_t sorted_side,
                         const int32_t* pair_a, const int32_t* pair_b, const int64_t* seg_off_host, int32_t K,
                         int32_t ca, int32_t cb, int32_t prec,
                         const int32_t* a_amax, const int32_t* b_amax, float* scratch, float* dw, void* stream) {
+  return gcl_conv_bwd_weight_rg(a, n_a, b, n_b, planes, sorted_side, pair_a, pair_b, seg_off_host, K, ca, cb, prec, a_amax,
+                                b_amax, scratch, dw, nullptr, stream);
+}
+
+int gcl_conv_bwd_weight_rg(const float* a, int64_t n_a, const float* b, int64_t n_b, int32_t planes, int32_t sorted_side,
+                           const int32_t* pair_a, const int32_t* pair_b, const int64_t* seg_off_host, int32_t K,
+                           int32_t ca, int32_t cb, int32_t prec, const int32_t* a_amax, const int32_t* b_amax,
+                           float* scratch, float* dw, const int32_t* rg_bounds, void* stream) {
   GCL_CHECK_ARG(a && b && pair_a && pair_b && seg_off_host && scratch && dw, "gcl_conv_bwd_weight: null pointer");
   const bool legacy_dw = (planes & 2) != 0;      // bit 1 of `planes`: the 64 x 64-block kernel for this launch (tests)
   planes &= 1;
@@ -2612,9 +2639,13 @@ int gcl_conv_bwd_weight(const float* a, int64_t n_a, const float* b, int64_t n_b
   if (nc > 0 && dw_rg_shape(K, ca, cb, prec, planes, sorted_side, n_sorted)) {
     const int rr = dw_range_rows(n_sorted, K);
     const int nr = (int)cdiv(n_sorted, rr);
-    int* bounds = (int*)(scratch + (long long)nr * K * mat);
-    hipLaunchKernelGGL(k_pair_bounds, dim3((unsigned)cdiv((long long)K * (nr + 1), 256)), dim3(256), 0, st,
-                       sorted_side == 1 ? pair_a : pair_b, seg, K, rr, nr, bounds);
+    const int* bounds = (const int*)rg_bounds;      // gcl_conv_bwd_weight_bounds of the sorted list, made once per map ...
+    if (!bounds) {                                  // ... or here, per launch
+      int* own = (int*)(scratch + (long long)nr * K * mat);
+      hipLaunchKernelGGL(k_pair_bounds, dim3((unsigned)cdiv((long long)K * (nr + 1), 256)), dim3(256), 0, st,
+                         sorted_side == 1 ? pair_a : pair_b, seg, K, rr, nr, own);
+      bounds = own;
+    }
     dim3 rgrid((unsigned)(cdiv(nr, 8) * 8 * K));
 #define LAUNCH_RG(TA, TB, PLV)                                                                                      \
   hipLaunchKernelGGL((k_conv_bwd_weight_split<TA, TB, PLV, false, true>), rgrid, dim3(256), 0, st, a, b, pair_a, pair_b, \

@@ -352,6 +352,13 @@ static int maps_build(const int32_t* coords, long long n, const gcl_map_spec* sp
     d.pair_out = both + len;
     int32_t* scratch = A.take_n<int32_t>((long long)d.K * cdiv(d.n_out, 1024) + d.K + 1);
     PLAN_CALL(gcl_kernel_map_pairs(d.nbr, d.K, d.n_out, d.seg_off, scratch, d.pair_in, d.pair_out, stream));
+    // cell limits of the weight gradient's range-grouped launches: a function of the map, made here once (side stream)
+    // instead of by every convolution that uses the map (k_pair_bounds: 9 launches per step on the weight-gradient stream)
+    const long long nb = gcl_conv_bwd_weight_bounds_len(d.K, d.n_out);
+    if (nb > 0 && total > 0) {
+      d.dw_bounds = A.take_n<int32_t>(nb);
+      PLAN_CALL(gcl_conv_bwd_weight_bounds(d.pair_out, d.seg_off, d.K, d.n_out, d.dw_bounds, stream));
+    }
   }
   out->arena_used = A.off;
   if (!A.fits()) {
@@ -938,9 +945,12 @@ static int conv_backward(Plan& P, int i, TState dy, void* const* grads, hipStrea
     float* scratch = A.take_n<float>(gcl_conv_bwd_weight_scratch_len(op.K, op.cin, op.cout, m.seg_off[op.K], n_sorted));
     const bool pl = pl_w;
     ProfScope ps(P, ws, 2, pairs, op.cin, op.cout, n_in, n_out, op.K);
-    PLAN_CALL(gcl_conv_bwd_weight(pl ? (const float*)x.planes : x.ptr, n_in, pl ? (const float*)dy.planes : dy.ptr, n_out,
-                                  pl ? 1 : 0, sorted_side, pa, pb, m.seg_off, op.K, op.cin, op.cout, 4, P.saved[i].x_amax, dy.amax,
-                                  scratch, dW, (void*)ws));
+    static const bool map_bounds = [] { const char* e = getenv("GCL_DW_MAP_BOUNDS"); return !(e && e[0] == '0'); }();
+    // m.dw_bounds: over the map's pair_out with n_out(map) rows -- the sorted list of this launch on either side
+    const int32_t* rgb = (map_bounds && sorted_side != 0 && n_sorted == m.n_out) ? m.dw_bounds : nullptr;
+    PLAN_CALL(gcl_conv_bwd_weight_rg(pl ? (const float*)x.planes : x.ptr, n_in, pl ? (const float*)dy.planes : dy.ptr, n_out,
+                                     pl ? 1 : 0, sorted_side, pa, pb, m.seg_off, op.K, op.cin, op.cout, 4, P.saved[i].x_amax,
+                                     dy.amax, scratch, dW, rgb, (void*)ws));
   }
   if (op.bias >= 0) {
     double* scratch = A.take_n<double>(gcl_bn_scratch_len(n_out, op.cout));

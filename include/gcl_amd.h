@@ -279,6 +279,18 @@ int gcl_conv_bwd_weight(const float* a, int64_t n_a, const float* b, int64_t n_b
                         const int32_t* pair_a, const int32_t* pair_b, const int64_t* seg_off_host, int32_t K,
                         int32_t ca, int32_t cb, int32_t prec, const int32_t* a_amax, const int32_t* b_amax, float* scratch, float* dw,
                         void* stream);
+/* The range-grouped mode's cell limits (first position of every (offset, row range) cell in the sorted pair list) depend
+ * on the map alone: gcl_conv_bwd_weight_bounds makes them once (int32[gcl_conv_bwd_weight_bounds_len(K, rows of the sorted
+ * side)], 0 = the mode does not apply), gcl_conv_bwd_weight_rg takes them (`rg_bounds`, NULL = computed per launch as
+ * gcl_conv_bwd_weight does).  gcl_maps_build makes them for every map with pair lists (gcl_map_desc.dw_bounds: over
+ * pair_out, the sorted list of the convolution and of its transpose alike). */
+int64_t gcl_conv_bwd_weight_bounds_len(int32_t K, int64_t n_sorted_rows);
+int gcl_conv_bwd_weight_bounds(const int32_t* sorted_rows, const int64_t* seg_off_host, int32_t K, int64_t n_sorted_rows,
+                               int32_t* bounds, void* stream);
+int gcl_conv_bwd_weight_rg(const float* a, int64_t n_a, const float* b, int64_t n_b, int32_t planes, int32_t sorted_side,
+                           const int32_t* pair_a, const int32_t* pair_b, const int64_t* seg_off_host, int32_t K,
+                           int32_t ca, int32_t cb, int32_t prec, const int32_t* a_amax, const int32_t* b_amax,
+                           float* scratch, float* dw, const int32_t* rg_bounds, void* stream);
 
 /* First layer (Cin <= 4, Cout a multiple of 32, any ks <= 5): VALU kernels over the nbr table (one 32-column block per
  * workgroup column).  Other first-layer widths go through gcl_conv_fwd / gcl_conv_bwd_weight (generic shapes). */
@@ -511,6 +523,7 @@ typedef struct gcl_map_desc {
   int32_t *tbl_t, *order_t, *mask_t;    /* gcl_table_sort(nbr_t) */
   int32_t *pair_in, *pair_out;
   uint32_t* presence;                   /* gcl_presence_bits(nbr) when the spec asks for it (tables bit 2), else NULL */
+  int32_t* dw_bounds;                   /* gcl_conv_bwd_weight_bounds over pair_out (maps with pair lists and >= 32768 out rows), else NULL */
   int64_t seg_off[128];                 /* padded prefix sums of the per-offset pair counts, K + 1 used */
   int32_t counts_host[128];
 } gcl_map_desc;
