@@ -354,7 +354,10 @@ static int maps_build(const int32_t* coords, long long n, const gcl_map_spec* sp
     PLAN_CALL(gcl_kernel_map_pairs(d.nbr, d.K, d.n_out, d.seg_off, scratch, d.pair_in, d.pair_out, stream));
     // cell limits of the weight gradient's range-grouped launches: a function of the map, made here once (side stream)
     // instead of by every convolution that uses the map (k_pair_bounds: 9 launches per step on the weight-gradient stream)
-    const long long nb = gcl_conv_bwd_weight_bounds_len(d.K, d.n_out);
+    // (dry run: n_out is an upper bound of the level's rows and gcl_conv_bwd_weight_bounds_len is not monotone in the row
+    // count -- the range length doubles as the level grows -- so the bound reserves for the SHORTEST range, 512 rows)
+    const long long nb = !A.dry ? gcl_conv_bwd_weight_bounds_len(d.K, d.n_out)
+                                : (d.n_out >= 32768 && d.K > 1 && d.K <= 27 ? (long long)d.K * (cdiv(d.n_out, 512) + 1) : 0);
     if (nb > 0 && total > 0) {
       d.dw_bounds = A.take_n<int32_t>(nb);
       PLAN_CALL(gcl_conv_bwd_weight_bounds(d.pair_out, d.seg_off, d.K, d.n_out, d.dw_bounds, stream));

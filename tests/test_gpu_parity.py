@@ -685,7 +685,8 @@ def test_resunet_forward_backward_vs_oracle(kind, precision):
     Fo = O.resunet_forward(so, C.numpy(), feats.double(), k1, True, True, 0.05)
     err = rel_l2(F.detach().cpu(), Fo.detach())
     print(f"[{kind}/{precision}] N={len(C)} feature rel-L2 vs fp64 oracle: {err:.3e}")
-    with open(os.path.join(os.path.dirname(__file__), "..", "gpurun_out", "precision_errors.log"), "a") as fh:
+    from conftest import precision_log_path
+    with open(precision_log_path(), "a") as fh:
         fh.write(f"{kind} {precision} N={len(C)} feature_rel_l2={err:.4e}\n")
     assert err < 1e-4            # north-star tolerance
     g = torch.Generator().manual_seed(1)
@@ -905,6 +906,35 @@ def test_table_sort_is_a_stable_mask_sort(window):
                 assert np.array_equal(tmask.astype(np.int64), np.bitwise_or.reduce(mt, axis=1))
     finally:
         core.SORT_WINDOW = old
+
+
+def test_extract_features_and_eval_pair_vs_oracle():
+    """util/misc.extract_features (:58-130) and the eval-loop body (scripts/test_kitti.py:141-161): voxelise ->
+    SparseTensor -> model(eval) -> F; find_corr with seeded subsampling returns the oracle's correspondences."""
+    import gcl_amd.MinkowskiEngine as ME
+    from gcl_amd import synthetic
+    from gcl_amd.lib.eval import find_corr
+    from gcl_amd.util.misc import extract_features
+    m, st = _model_and_state(3, 5)
+    xyz = synthetic.raycast(synthetic.make_scene(2, n_boxes=15), np.zeros(3), 3)[::4]
+    ret_xyz, F = extract_features(m, xyz, voxel_size=0.3, device=torch.device(DEV), skip_check=True)
+    coords, inds = ME.utils.sparse_quantize(np.floor(xyz / 0.3), return_index=True)
+    assert np.array_equal(ret_xyz, xyz[inds]) and F.shape == (len(inds), 32)
+    C = ME.utils.batched_coordinates([coords]).numpy()
+    Fo = O.resunet_forward(st, C, torch.ones(len(C), 1, dtype=torch.float64), 5, True, False, 0.05)
+    assert rel_l2(F.detach().cpu(), Fo) < 1e-4
+    # a second, shifted view of the same scene: correspondences through feature 1-NN
+    xyz1 = synthetic.raycast(synthetic.make_scene(2, n_boxes=15), np.array([4.0, 0, 0]), 4)[::4]
+    ret1, F1 = extract_features(m, xyz1, voxel_size=0.3, device=torch.device(DEV), skip_check=True)
+    np.random.seed(5)
+    a0, a1 = find_corr(ret_xyz, ret1, F.detach(), F1.detach(), subsample_size=1500)
+    np.random.seed(5)
+    i0 = np.random.choice(len(F), 1500, replace=False)
+    i1 = np.random.choice(len(F1), 1500, replace=False)
+    nn = LO.find_nn(F.detach().cpu()[i0], F1.detach().cpu()[i1], nn_max_n=500)
+    assert np.array_equal(a0, ret_xyz[i0])
+    same = (a1 == ret1[i1[nn.numpy()]]).all(axis=1)
+    assert same.mean() > 0.995          # an index may differ only on fp32 near-ties of the distance
 
 
 def test_train_step_matches_oracle_and_flat_ddp_is_transparent():

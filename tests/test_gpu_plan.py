@@ -4,7 +4,6 @@ the Tape (bitwise-equal features, gradients, losses and parameters over several 
 ADVICE round 2, and the two-rank data-parallel step with the bucket all-reduce started between backward segments."""
 import json
 import os
-import socket
 import subprocess
 import sys
 
@@ -82,6 +81,26 @@ def test_native_maps_equal_the_per_operator_maps(seed, n, batch):
                 for k in range(K):
                     want[:, k // 32] |= (nb[k] >= 0).astype(np.uint32) << np.uint32(k % 32)
                 assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("seed,n,batch", [(0, 4000, 2), (1, 300, 1), (2, 20000, 3)])
+def test_kernel_map_3_from_5_equals_the_probed_map(seed, n, batch):
+    """gcl_kernel_map_3_from_5 (the GCL_MAP3_FROM5 shortcut of gcl_maps_build: the 3^3 stride-1 map of the input table as
+    27 rows of its 5^3 map) == the map the probing pass builds (GCL_MAP3_FROM5=0): neighbour table and pair counts, bit
+    for bit."""
+    import gcl_amd.MinkowskiEngine as ME
+    from gcl_amd import _lib
+    lib = _lib.load()
+    C = torch.from_numpy(_cloud(seed, n, batch)).to(DEV)
+    with torch.cuda.device(DEV):
+        mgr = ME.CoordinateManager(C)
+        k5, k3 = mgr.get_kernel_map(1, 5, 1), mgr.get_kernel_map(1, 3, 1)
+        nbr3 = torch.full_like(k3.nbr, -7)
+        counts3 = torch.full((27,), -7, dtype=torch.int32, device=DEV)
+        _lib.check(lib.gcl_kernel_map_3_from_5(_lib.ptr(k5.nbr), _lib.ptr(k5._counts_dev), len(C), _lib.ptr(nbr3),
+                                               _lib.ptr(counts3), _lib.stream()), "gcl_kernel_map_3_from_5")
+        assert torch.equal(nbr3, k3.nbr)
+        assert counts3.tolist() == list(k3.counts)
 
 
 def test_native_maps_reject_bad_coordinates():
@@ -375,11 +394,10 @@ def test_two_ranks_on_one_device_overlap_the_decoder_bucket(tmp_path):
     env["GCL_DDP_SELFTEST_DIR"] = out
     r = None
     for attempt in (0, 1):      # the run takes 10 - 15 s; ONE retry if the two-process rendezvous on a shared device stalls
-        with socket.socket() as sk:      # (seen once in ~40 runs of this round: 900 s of silence, five clean repeats after it)
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-               "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tools", "ddp_selftest.py")]
+        # (seen once in ~40 runs of round 4: 900 s of silence, five clean repeats after it); --standalone: the launcher binds
+        # its own free rendezvous port
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+               "--nproc-per-node", "2", os.path.join(ROOT, "tools", "ddp_selftest.py")]
         try:
             r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240, cwd=ROOT)
             break
