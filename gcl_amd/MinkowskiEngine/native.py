@@ -311,7 +311,13 @@ class NetworkPlan:
         if AUX_STREAM and self._aux is None:
             # weight gradients run on a second (lower-priority) stream beside the input-gradient chain
             lo, _hi = torch.cuda.Stream.priority_range()
-            self._aux = torch.cuda.Stream(device=dev, priority={"low": lo, "high": _hi}.get(AUX_STREAM, 0))
+            pct = int(os.environ.get("GCL_AUX_CU_PCT", "0"))
+            if 0 < pct < 100:      # measurement: the weight gradients on a share of the CUs
+                h = ctypes.c_void_p()
+                _lib.check(lib.gcl_stream_create_cu_share(pct, 1, ctypes.byref(h)), "gcl_stream_create_cu_share")
+                self._aux = torch.cuda.ExternalStream(h.value, device=dev)
+            else:
+                self._aux = torch.cuda.Stream(device=dev, priority={"low": lo, "high": _hi}.get(AUX_STREAM, 0))
             lib.gcl_plan_set_aux_stream(self.handle, ctypes.c_void_p(self._aux.cuda_stream))
         if self.profile_next:
             lib.gcl_plan_profile(self.handle, 1)
@@ -442,7 +448,7 @@ class NetworkPlan:
     def profile_records(self):
         """Per-launch records of the profiled pass (call after synchronising the stream): list of
         (kind, ms, pairs, cin, cout, n_in, n_out, K); kind 0 = forward / input gradient, 1 = input gradient with the fused
-        gradient add, 2 = weight gradient."""
+        gradient add, 2 = weight gradient over pair lists, 3 = weight gradient of a kernel_size-1 convolution (row stream)."""
         lib = _lib.load()
         buf = (ctypes.c_double * (8 * 1024))()
         n = lib.gcl_plan_profile_read(self.handle, buf, 1024)

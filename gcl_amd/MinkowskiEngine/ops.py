@@ -111,6 +111,7 @@ def tensor_amax(lib, t):
 
 
 PRESPLIT_MIN_C = int(os.environ.get("GCL_PRESPLIT_MIN_C", "128"))     # operands at least this wide are pre-split
+BN_PLANES = os.environ.get("GCL_BN_PLANES", "1") != "0"                  # BatchNorm bound mode (csrc/plan.hip bound_mode)
 
 
 def planes_of(lib, t, amax):
@@ -239,7 +240,7 @@ def _conv_launch(lib, x, Wk, mode, table, n_out, cin, cout, bias, pairs=0, want_
     y = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
     stats = None
     if want_stats and prec != 0:
-        stats = torch.empty((2, cout, (n_out + 127) // 128), dtype=torch.float32, device=x.device)     # channel-major partials
+        stats = torch.empty((4, cout, (n_out + 127) // 128), dtype=torch.float32, device=x.device)     # channel-major partials: sum, squares, min, max
     name = None
     if PROFILE is not None:
         nb = lib.gcl_conv_fwd_nb(n_out, cout, prec)
@@ -370,6 +371,14 @@ class _SparseConvFn(torch.autograd.Function):
                 _lib.check(lib.gcl_stem_bwd_weight(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(kmap.nbr), n_out, K, cin, cout,
                                                    _lib.ptr(scratch), _lib.ptr(dW), None, None, _lib.stream()),
                            "gcl_stem_bwd_weight")
+            elif kmap is None and fp16x3 and lib.gcl_conv_bwd_weight_rows_scratch_len(cin, cout, prec, x.shape[0]) > 0:
+                # kernel_size 1: every row is its own pair -- both operands streamed once, no pair list (k_bwd_weight_rows)
+                scratch = torch.empty(lib.gcl_conv_bwd_weight_rows_scratch_len(cin, cout, prec, x.shape[0]),
+                                      dtype=torch.float32, device=x.device)
+                with _Timed(f"k_bwd_weight_rows<{cin // 32},{cout // 32}>", ctx.pairs, cin, cout, x.shape[0], dy.shape[0], K):
+                    _lib.check(lib.gcl_conv_bwd_weight_rows(_lib.ptr(x), _lib.ptr(dy), x.shape[0], cin, cout, prec,
+                                                            _lib.ptr(x_amax), _lib.ptr(dy_amax), _lib.ptr(scratch),
+                                                            _lib.ptr(dW), _lib.stream()), "gcl_conv_bwd_weight_rows")
             else:
                 if kmap is None:
                     pa, pb, seg, seg_host = ctx.mgr.identity_pairs(x.shape[0])
@@ -461,16 +470,26 @@ class _BatchNormFn(torch.autograd.Function):
         x = x.contiguous()
         n, c = x.shape
         dev = x.device
+        bound, bound_slot, xrange = False, None, None
         if training:
             mr = torch.empty((2, c), dtype=torch.float32, device=dev)          # one allocation: mean | rstd
             mean, rstd = mr[0], mr[1]
-            if tile_stats is not None:      # column sums already produced by the convolution epilogue
+            if tile_stats is not None:      # column sums (and ranges) already produced by the convolution epilogue
                 nt = tile_stats.shape[2]
-                scratch = torch.empty(lib.gcl_bn_tiles_scratch_len(nt, c), dtype=torch.float64, device=dev)
-                _lib.check(lib.gcl_bn_stats_from_tiles(_lib.ptr(tile_stats, torch.float32), nt, n, c, float(eps),
-                                                       float(momentum), _lib.ptr(running_mean), _lib.ptr(running_var),
-                                                       _lib.ptr(scratch), _lib.ptr(mean), _lib.ptr(rstd),
-                                                       _lib.stream()), "gcl_bn_stats_from_tiles")
+                # bound mode (csrc/plan.hip GCL_OP_CONVBN): an output at least PRESPLIT_MIN_C channels wide is consumed as a
+                # plane image, whose scale the native plan fixes BEFORE the apply pass from a bound of max|y| -- the same
+                # launch with the same arguments here, so that both paths hand their consumers the same slot value
+                res_amax = known_amax(residual) if residual is not None else None
+                bound = (BN_PLANES and PRECISION == "fp16x3" and c >= PRESPLIT_MIN_C and c % 32 == 0
+                         and (residual is None or res_amax is not None))
+                if bound:
+                    bound_slot = amax_slot(dev)
+                    xrange = torch.empty((2, c), dtype=torch.float32, device=dev)
+                _lib.check(lib.gcl_bn_stats_from_tiles_range(
+                    _lib.ptr(tile_stats, torch.float32), nt, n, c, float(eps), float(momentum), _lib.ptr(running_mean),
+                    _lib.ptr(running_var), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(xrange), _lib.ptr(weight.detach()),
+                    _lib.ptr(bias.detach()), int(relu), _lib.ptr(res_amax) if bound else None, None, _lib.ptr(bound_slot),
+                    _lib.stream()), "gcl_bn_stats_from_tiles_range")
             else:
                 scratch = torch.empty(lib.gcl_bn_scratch_len(n, c), dtype=torch.float64, device=dev)
                 _lib.check(lib.gcl_bn_stats(_lib.ptr(x, torch.float32), n, c, float(eps), float(momentum),
@@ -482,7 +501,8 @@ class _BatchNormFn(torch.autograd.Function):
         res = residual.contiguous() if residual is not None else None
         y = torch.empty_like(x)
         global _LAST_BN_AMAX
-        _LAST_BN_AMAX = slot = amax_slot(dev) if PRECISION == "fp16x3" else None
+        # bound mode: the slot already holds the bound (the apply pass's own, smaller maximum changes nothing in it)
+        _LAST_BN_AMAX = slot = bound_slot if bound else (amax_slot(dev) if PRECISION == "fp16x3" else None)
         # with relu the sign bits of y (1 bit / element) are kept for the backward pass instead of y itself
         mask = torch.empty(lib.gcl_bn_mask_len(n, c), dtype=torch.int64, device=dev) if relu else None
         _lib.check(lib.gcl_bn_apply(_lib.ptr(x), n, c, _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(weight.detach()),
@@ -490,6 +510,7 @@ class _BatchNormFn(torch.autograd.Function):
                                     _lib.ptr(slot), _lib.stream()), "gcl_bn_apply")
         ctx.save_for_backward(x, mask, weight, mean, rstd)
         ctx.relu, ctx.training, ctx.has_res = bool(relu), bool(training), residual is not None
+        ctx.xrange = xrange
         return y
 
     @staticmethod
@@ -503,12 +524,16 @@ class _BatchNormFn(torch.autograd.Function):
         sums = torch.empty((2, c), dtype=torch.float32, device=dev)           # one allocation: sum_g | sum_gx
         sum_g, sum_gx = sums[0], sums[1]
         scratch = torch.empty(lib.gcl_bn_scratch_len(n, c), dtype=torch.float64, device=dev)
-        _lib.check(lib.gcl_bn_bwd_reduce(_lib.ptr(x), _lib.ptr(dy), None, _lib.ptr(mask), n, c, _lib.ptr(mean), _lib.ptr(rstd),
-                                         int(ctx.relu), _lib.ptr(scratch), _lib.ptr(sum_g), _lib.ptr(sum_gx),
-                                         _lib.stream()), "gcl_bn_bwd_reduce")
+        slot = amax_slot(dev) if PRECISION == "fp16x3" else None
+        # bound mode (as csrc/plan.hip): max|dx| bounded by the reduce launch; the apply pass publishes nothing larger
+        xrange = getattr(ctx, "xrange", None)
+        bound = xrange is not None and slot is not None and ctx.training and c >= PRESPLIT_MIN_C
+        _lib.check(lib.gcl_bn_bwd_reduce_range(_lib.ptr(x), _lib.ptr(dy), 0, None, _lib.ptr(mask), n, c, _lib.ptr(mean),
+                                               _lib.ptr(rstd), int(ctx.relu), _lib.ptr(scratch), _lib.ptr(sum_g),
+                                               _lib.ptr(sum_gx), _lib.ptr(xrange), _lib.ptr(weight.detach()),
+                                               _lib.ptr(slot) if bound else None, _lib.stream()), "gcl_bn_bwd_reduce_range")
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.has_res else None
-        slot = amax_slot(dev) if PRECISION == "fp16x3" else None
         if ctx.training:
             sg, sx = sum_g, sum_gx
         else:                       # running statistics are constants: no batch-statistics terms
@@ -749,6 +774,14 @@ def cat_features(tensors):
     if _TAPE is not None and any(id(t) in _TAPE.made for t in tensors):
         with torch.no_grad():
             y = torch.cat(tensors, dim=1)
+            tags = [known_amax(t) for t in tensors]
+            if PRECISION == "fp16x3" and all(t is not None for t in tags):
+                # max|cat| = max over the inputs' slots -- what the native plan's in-place cat holds in the shared slot
+                # (a slot of a BatchNorm in bound mode carries its bound, not the measured maximum: csrc/plan.hip)
+                slot = tags[0]
+                for t in tags[1:]:
+                    slot = torch.maximum(slot, t)
+                tag_amax(y, slot)
         return _TAPE.add("cat", y, tuple(tensors), ())
     return torch.cat(tensors, dim=1)
 

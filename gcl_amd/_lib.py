@@ -93,6 +93,8 @@ SIGNATURES = {
     "gcl_conv_bwd_weight_bounds": (_i32, [_vp, ctypes.POINTER(_i64), _i32, _i64, _vp, _vp]),
     "gcl_conv_bwd_weight_rg": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, ctypes.POINTER(_i64), _i32, _i32, _i32, _i32, _vp,
                                       _vp, _vp, _vp, _vp, _vp]),
+    "gcl_conv_bwd_weight_rows_scratch_len": (_i64, [_i32, _i32, _i32, _i64]),
+    "gcl_conv_bwd_weight_rows": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "gcl_presence_bits": (_i32, [_vp, _i32, _i64, _vp, _vp]),
     "gcl_kernel_map_3_from_5": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "gcl_not_ones_rows": (_i32, [_vp, _i32, _vp, _i64, _vp, _i32, _vp, _vp]),
@@ -102,6 +104,11 @@ SIGNATURES = {
     "gcl_bn_scratch_len": (_i64, [_i64, _i32]),
     "gcl_bn_stats": (_i32, [_vp, _i64, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gcl_bn_tiles_scratch_len": (_i64, [_i64, _i32]),
+    "gcl_bn_stats_from_tiles_range": (_i32, [_vp, _i64, _i64, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp,
+                                             _vp]),
+    "gcl_bn_apply_planes": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "gcl_bn_bwd_reduce_range": (_i32, [_vp, _vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gcl_bn_bwd_apply_planes": (_i32, [_vp, _vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "gcl_bn_stats_from_tiles": (_i32, [_vp, _i64, _i64, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gcl_bn_apply": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "gcl_bn_apply_ld": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp]),
@@ -127,6 +134,8 @@ SIGNATURES = {
     "gcl_plan_backward": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "gcl_plan_release": (_i32, [_vp, _vp]),
     "gcl_plan_set_aux_stream": (_i32, [_vp, _vp]),
+    "gcl_stream_create_cu_share": (_i32, [_i32, _i32, ctypes.POINTER(ctypes.c_void_p)]),
+    "gcl_stream_destroy": (_i32, [_vp]),
     "gcl_plan_profile": (_i32, [_vp, _i32]),
     "gcl_plan_profile_read": (_i32, [_vp, _vp, _i32]),
     "gcl_sc2_chunks": (_i32, []),
@@ -153,6 +162,17 @@ SIGNATURES = {
 PAIR_CHUNK = 128   # GCL_PAIR_CHUNK
 
 _lib = None
+
+
+def source_hash():
+    """sha256 (16 hex digits) over the kernel sources + headers the library is built from: stamps profiles/pmc_summary.json,
+    so that bench.py can tell whether the counter figures it quotes were collected on the kernels it is timing."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"), HEADER]:
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def build(force=False, verbose=False):

@@ -107,4 +107,44 @@ __device__ __forceinline__ void amax_slot_publish(int* slot, int bits, unsigned 
   if (bits > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, bits);
 }
 
+
+// ---- fp16x3 operand format (csrc/conv.hip "fp16x3, range-extended") ----------------------------------------------------
+// power-of-two scale that maps amax into [2^13, 2^14)
+__device__ __forceinline__ float amax_scale(const int* __restrict__ amax_bits) {
+  float amax = __int_as_float(amax_slot_bits(amax_bits));
+  if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.f;
+  int e;
+  frexpf(amax, &e);   // amax = m * 2^e, m in [0.5, 1)
+  int sh = 14 - e;
+  sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);   // keep scale and 1/scale finite for degenerate tensors
+  return ldexpf(1.f, sh);
+}
+
+
+constexpr float F16_LO_UP = 2048.f, F16_LO_DOWN = 1.f / 2048.f;
+__device__ __forceinline__ void split_f16(float sv, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)sv;
+  lo = (_Float16)((sv - (float)hi) * F16_LO_UP);
+}
+
+
+// plane image of an [n, ldc] fp32 tensor: per row and 32-channel slice 64 bytes of hi followed by 64 bytes of lo' (16-bit
+// units: row * ldc * 2 + slice * 64 + plane * 32 + channel % 32).  Four consecutive channels col .. col + 3 of one row:
+__device__ __forceinline__ void store_planes4(unsigned short* __restrict__ planes, long long row, long long ldc, int col,
+                                              const float4& v, float s) {
+  typedef _Float16 f16x4_ __attribute__((ext_vector_type(4)));
+  const float sv[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
+  f16x4_ h, lo;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    _Float16 hh, ll;
+    split_f16(sv[j], hh, ll);
+    h[j] = hh;
+    lo[j] = ll;
+  }
+  unsigned short* base = planes + (row * ldc + (long long)(col >> 5) * 32) * 2 + (col & 31);
+  *reinterpret_cast<f16x4_*>(base) = h;
+  *reinterpret_cast<f16x4_*>(base + 32) = lo;
+}
+
 }  // namespace gcl

@@ -225,17 +225,16 @@ struct Prec {
   static constexpr int planes = (PL == 3) ? 3 : 2;
 };
 
-// power-of-two scale that maps amax into [2^13, 2^14)
-__device__ __forceinline__ float amax_scale(const int* __restrict__ amax_bits) {
-  float amax = __int_as_float(amax_slot_bits(amax_bits));
-  if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.f;
-  int e;
-  frexpf(amax, &e);   // amax = m * 2^e, m in [0.5, 1)
-  int sh = 14 - e;
-  sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);   // keep scale and 1/scale finite for degenerate tensors
-  return ldexpf(1.f, sh);
-}
-
+// fp16x3, range-extended (round 5): the lo plane holds the remainder TIMES 2^11, i.e. lo' = fp16((x s - hi) 2^11).  The
+// remainder of an fp16-rounded value is <= 2^-11 |x s|, so lo' lies in the same binade range as hi and is a NORMAL fp16
+// number whenever hi is -- every element down to 2^-27 of the tensor's max-abs keeps its 22 significand bits.  (Rounds 1 - 4
+// stored the remainder itself: it went subnormal for |x| < 2^-17 amax.  Forward activations never get there; the gradient
+// tensors do -- a BatchNorm backward leaves a dense background ~ 1 / n below the few rows the loss touches, and the
+// reductions downstream cancel the two against each other: the full-size gradient check showed the exact-f32 kernels 8 -
+// 20 x closer to the fp64 oracle on the encoder's weight gradients.)  The cross terms hi lo' + lo' hi then carry a factor
+// 2^11 and are summed in an accumulator of their own (`accx`), folded in once at the end: acc + accx 2^-11.  Same MFMA
+// count; NB x 16 more accumulator registers.
+// (F16_LO_UP / F16_LO_DOWN, split_f16 and amax_scale live in common.h: the BatchNorm passes write plane images too)
 template <int PL>
 __device__ __forceinline__ void split8(const float4& f0, const float4& f1, float scale, u32x4* pl) {
   float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
@@ -243,10 +242,10 @@ __device__ __forceinline__ void split8(const float4& f0, const float4& f1, float
     f16x8 hi, lo;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float sv = v[j] * scale;
-      _Float16 hh = (_Float16)sv;
+      _Float16 hh, ll;
+      split_f16(v[j] * scale, hh, ll);
       hi[j] = hh;
-      lo[j] = (_Float16)(sv - (float)hh);
+      lo[j] = ll;
     }
     pl[0] = __builtin_bit_cast(u32x4, hi);
     pl[1] = __builtin_bit_cast(u32x4, lo);
@@ -274,9 +273,16 @@ __device__ __forceinline__ f32x16 mfma16(const u32x4& a, const u32x4& b, const f
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// all product terms of one (A planes, B planes) pair, small terms first
+// all product terms of one (A planes, B planes) pair, small terms first.  PL == 4: the two cross terms go to `accx` (they
+// carry the lo planes' factor 2^11), hi hi to `acc`; fold_cross adds them up.  The bf16 modes use `acc` only.
 template <int PL>
-__device__ __forceinline__ void mfma_terms(const u32x4* a, const u32x4* b, f32x16& acc) {
+__device__ __forceinline__ void mfma_terms(const u32x4* a, const u32x4* b, f32x16& acc, f32x16& accx) {
+  if (PL == 4) {
+    accx = mfma16<PL>(a[1], b[0], accx);
+    accx = mfma16<PL>(a[0], b[1], accx);
+    acc = mfma16<PL>(a[0], b[0], acc);
+    return;
+  }
   if (PL == 3) {
     acc = mfma16<PL>(a[2], b[0], acc);
     acc = mfma16<PL>(a[0], b[2], acc);
@@ -285,6 +291,43 @@ __device__ __forceinline__ void mfma_terms(const u32x4* a, const u32x4* b, f32x1
   acc = mfma16<PL>(a[1], b[0], acc);
   acc = mfma16<PL>(a[0], b[1], acc);
   acc = mfma16<PL>(a[0], b[0], acc);
+}
+// The weight-gradient kernels hold 64 - 96 accumulator registers per wave and have no room for a second set.  They do not
+// need one: of their two operands only the output gradient (B) spans many binades; the layer input x (A) is an activation,
+// where the round 1 - 4 format was adequate.  So A's two planes are re-scaled on the fly (packed fp16 multiplies by 2^-11,
+// exact unless the value drops below fp16's normal range, i.e. for |x| < 2^-17 max|x|):
+//   a[0] = hi_x,  a[1] = lo_x = lo'_x 2^-11 (the plain remainder),  a[2] = hi_x 2^-11
+// and all three terms have the same scale:  hi_x hi_g + lo_x hi_g + (hi_x 2^-11) lo'_g  -> ONE accumulator.
+__device__ __forceinline__ u32x4 f16x8_down(const u32x4& v) {
+  f16x8 h = __builtin_bit_cast(f16x8, v);
+  h = h * (_Float16)F16_LO_DOWN;
+  return __builtin_bit_cast(u32x4, h);
+}
+// a: {hi, lo'} as stored -> {hi, lo, hi 2^-11}
+__device__ __forceinline__ void dw_a_planes(u32x4* a) {
+  a[2] = f16x8_down(a[0]);
+  a[1] = f16x8_down(a[1]);
+}
+template <int PL>
+__device__ __forceinline__ void mfma_terms_dw(const u32x4* a, const u32x4* b, f32x16& acc) {
+  if (PL == 4) {
+    acc = mfma16<PL>(a[1], b[0], acc);
+    acc = mfma16<PL>(a[2], b[1], acc);
+    acc = mfma16<PL>(a[0], b[0], acc);
+    return;
+  }
+  f32x16 unused;
+  mfma_terms<PL>(a, b, acc, unused);
+}
+template <int PL>
+__device__ __forceinline__ void fold_cross(f32x16& acc, f32x16& accx) {
+  if (PL == 4) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc[r] += accx[r] * F16_LO_DOWN;
+      accx[r] = 0.f;
+    }
+  }
 }
 
 // max |x| of a tensor as the bit pattern of a non-negative float (integer atomicMax is order-independent)
@@ -332,7 +375,7 @@ __global__ void __launch_bounds__(256) k_amax_multi(const float* const* __restri
                       __float_as_int(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))), blockIdx.x);
 }
 
-// fp32 [n, c] -> fp16 plane image [n][c / 32][2][32]: hi = fp16(x s), lo = fp16(x s - hi), s from the tensor's amax
+// fp32 [n, c] -> fp16 plane image [n][c / 32][2][32]: hi = fp16(x s), lo = fp16((x s - hi) 2^11) (split_f16), s from the tensor's amax
 // slot.  One thread per 4 channels (16-byte read, two 8-byte writes).
 __global__ void __launch_bounds__(256) k_split_planes(const float4* __restrict__ x, long long total4, int c,
                                                       const int* __restrict__ amax, unsigned short* __restrict__ planes) {
@@ -343,17 +386,7 @@ __global__ void __launch_bounds__(256) k_split_planes(const float4* __restrict__
     const float4 v = x[e];
     const long long row = e / q_per_row;
     const int col = (int)(e % q_per_row) * 4;            // first channel of this quad
-    typedef _Float16 f16x4_ __attribute__((ext_vector_type(4)));
-    const float sv[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
-    f16x4_ h, lo;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      h[j] = (_Float16)sv[j];
-      lo[j] = (_Float16)(sv[j] - (float)h[j]);
-    }
-    unsigned short* base = planes + (row * c + (long long)(col >> 5) * 32) * 2 + (col & 31);   // hi of this slice
-    *reinterpret_cast<f16x4_*>(base) = h;
-    *reinterpret_cast<f16x4_*>(base + 32) = lo;
+    store_planes4(planes, row, c, col, v, s);
   }
 }
 
@@ -386,9 +419,8 @@ __device__ __forceinline__ void pack_split_one(const float* __restrict__ w, int 
   }
   long long blk = ((((long long)k * CC + cc) * TNB + nb) * 2 + m) * NPL;
   if (PL == 4) {
-    float sv = v * amax_scale(w_amax);
-    _Float16 hi = (_Float16)sv;
-    _Float16 lo = (_Float16)(sv - (float)hi);
+    _Float16 hi, lo;
+    split_f16(v * amax_scale(w_amax), hi, lo);
     wp[((blk + 0) * 64 + l) * 8 + jj] = __builtin_bit_cast(unsigned short, hi);
     wp[((blk + 1) * 64 + l) * 8 + jj] = __builtin_bit_cast(unsigned short, lo);
   } else {
@@ -473,7 +505,7 @@ __device__ __forceinline__ void conv_fwd_epilogue(f32x16 (&acc)[NB], float* tile
     // consume the (conditional) loads HERE: otherwise every store below waits for all earlier stores (vmcnt(0))
     asm volatile("v_mov_b32 %0, %1" : "=v"(bvv) : "v"(bvv));
     asm volatile("v_mov_b32 %0, %1" : "=v"(csc) : "v"(csc));
-    float s1 = 0.f, s2 = 0.f;
+    float s1 = 0.f, s2 = 0.f, lo = 3.0e38f, hi = -3.0e38f;      // column sum, sum of squares, minimum, maximum
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       int orow = __shfl(orow_l, (r & 3) + 8 * (r >> 2) + 4 * h);
@@ -487,15 +519,21 @@ __device__ __forceinline__ void conv_fwd_epilogue(f32x16 (&acc)[NB], float* tile
         Y[(long long)orow * cout + col] = v;
         s1 += v;
         s2 += v * v;
+        lo = fminf(lo, v);
+        hi = fmaxf(hi, v);
         if (EPI) ymax = fmaxf(ymax, fabsf(v));
       }
     }
     if (stats) {
       s1 += __shfl_xor(s1, 32);
       s2 += __shfl_xor(s2, 32);
+      lo = fminf(lo, __shfl_xor(lo, 32));
+      hi = fmaxf(hi, __shfl_xor(hi, 32));
       if (h == 0) {
         ssc[b * 32 + i] = s1;
         ssc[NB * 32 + b * 32 + i] = s2;
+        ssc[2 * NB * 32 + b * 32 + i] = lo;
+        ssc[3 * NB * 32 + b * 32 + i] = hi;
       }
     }
   }
@@ -505,18 +543,24 @@ __device__ __forceinline__ void conv_fwd_epilogue(f32x16 (&acc)[NB], float* tile
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         const int col = (nb0 + b) * 32 + i;
-        float t1 = 0.f, t2 = 0.f;
+        float t1 = 0.f, t2 = 0.f, tlo = 3.0e38f, thi = -3.0e38f;
 #pragma unroll
         for (int ww = 0; ww < 4; ++ww) {
           const float* o = ssc + ww * (32 * 32);
           t1 += o[b * 32 + i];
           t2 += o[NB * 32 + b * 32 + i];
+          tlo = fminf(tlo, o[2 * NB * 32 + b * 32 + i]);
+          thi = fmaxf(thi, o[3 * NB * 32 + b * 32 + i]);
         }
-        // channel-major [2][cout][n_part]: the finalisation reads a channel's partials as one contiguous run
-        // ([n_part][2][cout] made it a walk of 16-byte pieces 256 bytes apart: 55 us per 0.5 M-row layer)
+        // channel-major [4][cout][n_part] (sum, sum of squares, minimum, maximum): the finalisation reads a channel's
+        // partials as contiguous runs ([n_part][2][cout] made it a walk of 16-byte pieces 256 bytes apart: 55 us per 0.5 M-row
+        // layer).  Minimum / maximum (round 5): the exact range of the BatchNorm's output follows from them BEFORE its apply
+        // pass runs (an affine map per channel is monotone), which is what lets that pass write fp16 plane images itself.
         const long long n_part = (n_out + 127) >> 7;
         stats[(long long)col * n_part + bxx] = t1;
         stats[((long long)cout + col) * n_part + bxx] = t2;
+        stats[((long long)2 * cout + col) * n_part + bxx] = tlo;
+        stats[((long long)3 * cout + col) * n_part + bxx] = thi;
       }
     }
     if (!active) return;
@@ -589,11 +633,15 @@ __global__ void __launch_bounds__(256, GCL_FWD_MIN_WAVES(NB, PL)) k_conv_fwd_spl
   const int TNB = cout >> 5, CC = cin >> 5;
   const int p = l & 7, rsub = l >> 3;
 
-  f32x16 acc[NB];
+  f32x16 acc[NB], accx[(PL == 4) ? NB : 1];      // accx: the fp16x3 cross terms (mfma_terms)
 #pragma unroll
   for (int b = 0; b < NB; ++b)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+#pragma unroll
+  for (int b = 0; b < (int)(sizeof(accx) / sizeof(accx[0])); ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accx[b][r] = 0.f;
 
   unsigned mymask = 0u;
   if (active) mymask = tile_mask ? (unsigned)tile_mask[tile] : ((K >= 32) ? ~0u : ((1u << K) - 1u));
@@ -729,7 +777,7 @@ __global__ void __launch_bounds__(256, GCL_FWD_MIN_WAVES(NB, PL)) k_conv_fwd_spl
             bp[0] = bb[0];
             bp[1] = bb[64];
             if (NPL == 3) bp[2] = bb[128];
-            mfma_terms<PL>(ap, bp, acc[b]);
+            mfma_terms<PL>(ap, bp, acc[b], accx[(PL == 4) ? b : 0]);
           }
         }
       }
@@ -781,6 +829,8 @@ __global__ void __launch_bounds__(256, GCL_FWD_MIN_WAVES(NB, PL)) k_conv_fwd_spl
     o[0] = wg_t0; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = wg_steps; o[3] = __builtin_amdgcn_s_memtime() - wg_c0;
   }
 #endif
+#pragma unroll
+  for (int b = 0; b < NB; ++b) fold_cross<PL>(acc[b], accx[(PL == 4) ? b : 0]);
   conv_fwd_epilogue<NB, EPI>(acc, &Asm[0][0][0], order, n_out, cout, bias, Y, stats, out_scale, epi, tile, bxx, nb0, active);
 }
 
@@ -876,11 +926,15 @@ __global__ void __launch_bounds__(256, (NB <= 2 ? 4 : 2)) k_conv_fwd_dma(const f
   const int TNB = cout >> 5, CC = cin >> 5;
   const int p = l & 7, rsub = l >> 3;
 
-  f32x16 acc[NB];
+  f32x16 acc[NB], accx[NB];      // accx: the fp16x3 cross terms (mfma_terms)
 #pragma unroll
   for (int b = 0; b < NB; ++b)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+#pragma unroll
+  for (int b = 0; b < (int)(sizeof(accx) / sizeof(accx[0])); ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accx[b][r] = 0.f;
 
   unsigned mymask = 0u;
   if (active) mymask = tile_mask ? (unsigned)tile_mask[tile] : ((K >= 32) ? ~0u : ((1u << K) - 1u));
@@ -1012,7 +1066,7 @@ __global__ void __launch_bounds__(256, (NB <= 2 ? 4 : 2)) k_conv_fwd_dma(const f
             u32x4 bp[2];
             bp[0] = bb[0];
             bp[1] = bb[64];
-            mfma_terms<PL>(ap[m], bp, acc[b]);
+            mfma_terms<PL>(ap[m], bp, acc[b], accx[b]);
           }
         }
       } else if (mine_n) {
@@ -1028,6 +1082,8 @@ __global__ void __launch_bounds__(256, (NB <= 2 ? 4 : 2)) k_conv_fwd_dma(const f
 #undef GCL_DMA_A
 #undef GCL_DMA_B
 #undef GCL_ADVANCE
+#pragma unroll
+  for (int b = 0; b < NB; ++b) fold_cross<PL>(acc[b], accx[(PL == 4) ? b : 0]);
   conv_fwd_epilogue<NB, EPI>(acc, &Asm[0][0][0], order, n_out, cout, bias, Y, stats, out_scale, epi, tile, bxx, nb0, active);
 }
 
@@ -1086,11 +1142,15 @@ __global__ void __launch_bounds__(1024, 1) k_conv_fwd_tall(const float* __restri
   for (int k = 0; k < K; ++k)
     if ((k & 3) == g) gsel |= 1u << k;
 
-  f32x16 acc[NB];
+  f32x16 acc[NB], accx[(PL == 4) ? NB : 1];      // accx: the fp16x3 cross terms (mfma_terms)
 #pragma unroll
   for (int b = 0; b < NB; ++b)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+#pragma unroll
+  for (int b = 0; b < (int)(sizeof(accx) / sizeof(accx[0])); ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accx[b][r] = 0.f;
 
   unsigned tmask = 0u;
   if (active) tmask = tile_mask ? (unsigned)tile_mask[tile] : ((1u << K) - 1u);
@@ -1189,7 +1249,7 @@ __global__ void __launch_bounds__(1024, 1) k_conv_fwd_tall(const float* __restri
             u32x4 bp[3];
             bp[0] = bb[0];
             bp[1] = bb[64];
-            mfma_terms<PL>(ap, bp, acc[b]);
+            mfma_terms<PL>(ap, bp, acc[b], accx[(PL == 4) ? b : 0]);
           }
         }
       }
@@ -1218,6 +1278,8 @@ __global__ void __launch_bounds__(1024, 1) k_conv_fwd_tall(const float* __restri
 #undef GCLT_LOAD_B
 #undef GCLT_STORE_LDS
 #undef GCLT_ADVANCE
+#pragma unroll
+  for (int b = 0; b < NB; ++b) fold_cross<PL>(acc[b], accx[(PL == 4) ? b : 0]);
   // partial accumulators of groups 1 - 3 through LDS (the loop's last barrier has passed: tiles and weight blocks are free)
   float* const red = lds;      // [g - 1][wt][b * 16 + r][64 lanes]
   if (g > 0) {
@@ -1410,7 +1472,7 @@ template <int TCA, int TCB, int HALF, int EXTRA = 0>
 __device__ __forceinline__ void tr_mma_half(const unsigned (*baseA)[2], const unsigned (*baseB)[2],
                                             f32x16 (&acc)[TCA / 32][TCB / 32]) {
   constexpr int NBI = TCA / 32, NBJ = TCB / 32;
-  u32x4 fa[NBI][2], fb[NBJ][2];
+  u32x4 fa[NBI][3], fb[NBJ][2];
 #pragma unroll
   for (int a = 0; a < NBI; ++a) tr_fragment<TCA, HALF, EXTRA>(baseA[a][0], baseA[a][1], fa[a]);
 #pragma unroll
@@ -1428,10 +1490,13 @@ __device__ __forceinline__ void tr_mma_half(const unsigned (*baseA)[2], const un
     asm volatile("" : "+v"(fb[b][0]));
     asm volatile("" : "+v"(fb[b][1]));
   }
+  // a outermost: one slice's re-scaled planes are live at a time (the 128 x 128 kernel has no registers to spare)
 #pragma unroll
-  for (int b = 0; b < NBJ; ++b)
+  for (int a = 0; a < NBI; ++a) {
+    dw_a_planes(fa[a]);
 #pragma unroll
-    for (int a = 0; a < NBI; ++a) mfma_terms<4>(fa[a], fb[b], acc[a][b]);
+    for (int b = 0; b < NBJ; ++b) mfma_terms_dw<4>(fa[a], fb[b], acc[a][b]);
+  }
 }
 
 // split-precision weight gradient: both operands are gathered activations, split on the fly into PL bf16 planes.
@@ -1615,6 +1680,7 @@ __global__ void __launch_bounds__(256) k_conv_bwd_weight_split(const float* __re
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) v[jj] = As[w][16 * half + 8 * h + jj][a * 32 + i];
         split8<PL>(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), sa, pa[a]);
+        if (PL == 4) dw_a_planes(pa[a]);
       }
 #pragma unroll
       for (int b = 0; b < NBJ; ++b) {
@@ -1624,7 +1690,7 @@ __global__ void __launch_bounds__(256) k_conv_bwd_weight_split(const float* __re
         u32x4 pb[3];
         split8<PL>(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), sb, pb);
 #pragma unroll
-        for (int a = 0; a < NBI; ++a) mfma_terms<PL>(pa[a], pb, acc[a][b]);
+        for (int a = 0; a < NBI; ++a) mfma_terms_dw<PL>(pa[a], pb, acc[a][b]);
       }
     }
   }
@@ -1843,6 +1909,127 @@ __global__ void __launch_bounds__(256) k_bwd_weight_reduce_rg(const float* __res
   }
   for (; j < n_ranges; ++j) s0 += slabs[((long long)j * K + k) * mat + e];
   dw[(long long)k * mat + e] = (s0 + s1) + (s2 + s3);
+}
+
+// ---- weight gradient of a kernel_size-1 convolution (identity map): dW = A^T B as a row STREAM (round 5) -----------------
+// conv1_tr 96 -> 64 and final 64 -> 32 (model/resunet.py:153-171) own one "pair" per row, (i, i): nothing to gather.  The
+// pair-list kernels still walked an index list and staged 32-row tiles through LDS for them (144 / 211 us at 0.53 M rows,
+// 0.18 - 0.22 of HBM for bytes that are compulsory).  Here a wave takes 16 consecutive rows per step straight from global
+// memory into MFMA fragment order: lane (i, h) loads rows r0 + 8 h + j (j = 0..7), channel 32 t + i -- every load instruction
+// covers two full 128-byte row segments -- one step ahead of the step it multiplies; no LDS, no index reads, no barrier in the
+// loop.  Rows beyond n read zero through the buffer resource.  fp16x3 split on the fly (the tensors are C < 128: no plane
+// images).  Deterministic: a wave sums its steps in order, the four waves are added in wave order through LDS, one
+// slab per workgroup, slabs summed in order by k_rows_slab_sum.
+template <int NBI, int NBJ>
+__global__ void __launch_bounds__(256, 2) k_bwd_weight_rows(const float* __restrict__ A, const float* __restrict__ B,
+                                                            long long n_rows, int steps_per_wg, float* slabs,
+                                                            const int* __restrict__ a_amax, const int* __restrict__ b_amax,
+                                                            unsigned a_bytes, unsigned b_bytes) {
+  constexpr int CA = NBI * 32, CB = NBJ * 32;
+  __shared__ __attribute__((aligned(16))) float lds_sum[CA * CB];
+  const float sa = amax_scale(a_amax), sb = amax_scale(b_amax);
+  const float out_scale = 1.f / (sa * sb);
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = l & 31, h = l >> 5;
+  const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)b_bytes, 0x00020000);
+  const long long n_steps = (n_rows + 15) / 16;
+  const long long s0 = (long long)blockIdx.x * steps_per_wg;
+  const long long s1 = (s0 + steps_per_wg < n_steps) ? s0 + steps_per_wg : n_steps;
+  f32x16 acc[NBI][NBJ];
+#pragma unroll
+  for (int a = 0; a < NBI; ++a)
+#pragma unroll
+    for (int b = 0; b < NBJ; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  float ra[2][NBI][8], rb[2][NBJ][8];
+  // One base offset per operand and step (byte offsets fit 32 bits: operands < 4 GiB, checked by the entry), the (row j,
+  // slice) part is an instruction immediate.  A step beyond the wave's share is redirected past the tensor: the buffer
+  // resource returns zeros, and a product of zeros leaves the sums unchanged -- no branch anywhere in the loop.
+  const int wv = __builtin_amdgcn_readfirstlane(w);
+  constexpr unsigned BEYOND = 0xFFFF0000u;      // + the largest immediate (< 4096) still does not wrap
+  auto load = [&](long long st, float (&xa)[NBI][8], float (&xb)[NBJ][8]) {
+    const unsigned r0 = (unsigned)(st * 16) + 8u * h;
+    const int va = (int)(st < s1 ? (r0 * CA + i) * 4u : BEYOND), vb = (int)(st < s1 ? (r0 * CB + i) * 4u : BEYOND);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int a = 0; a < NBI; ++a)
+        xa[a][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(arsrc, va + (j * CA + a * 32) * 4, 0, 0));
+#pragma unroll
+      for (int b = 0; b < NBJ; ++b)
+        xb[b][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brsrc, vb + (j * CB + b * 32) * 4, 0, 0));
+    }
+  };
+  auto mma = [&](float (&xa)[NBI][8], float (&xb)[NBJ][8]) {
+    u32x4 pa[NBI][3];
+#pragma unroll
+    for (int a = 0; a < NBI; ++a)
+    {
+      split8<4>(make_float4(xa[a][0], xa[a][1], xa[a][2], xa[a][3]), make_float4(xa[a][4], xa[a][5], xa[a][6], xa[a][7]), sa, pa[a]);
+      dw_a_planes(pa[a]);
+    }
+#pragma unroll
+    for (int b = 0; b < NBJ; ++b) {
+      u32x4 pb[3];
+      split8<4>(make_float4(xb[b][0], xb[b][1], xb[b][2], xb[b][3]), make_float4(xb[b][4], xb[b][5], xb[b][6], xb[b][7]), sb, pb);
+#pragma unroll
+      for (int a = 0; a < NBI; ++a) mfma_terms_dw<4>(pa[a], pb, acc[a][b]);
+    }
+  };
+  // the four waves interleave over the workgroup's steps (the workgroup streams one contiguous row range); two steps per
+  // iteration so that the register buffers alternate without copies; loads run one step ahead of their products
+  long long st = s0 + wv;
+  load(st, ra[0], rb[0]);
+  for (; st < s1; st += 8) {
+    load(st + 4, ra[1], rb[1]);
+    mma(ra[0], rb[0]);
+    load(st + 8, ra[0], rb[0]);
+    mma(ra[1], rb[1]);
+  }
+  // the four waves' sums are added in wave order through ONE slab image in LDS (lane-owned cells: ((w0 + w1) + w2) + w3)
+#pragma unroll 1
+  for (int ww = 0; ww < 4; ++ww) {
+    if (w == ww) {
+#pragma unroll
+      for (int a = 0; a < NBI; ++a)
+#pragma unroll
+        for (int b = 0; b < NBJ; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float* cell = &lds_sum[((a * NBJ + b) * 16 + r) * 64 + l];
+            *cell = (ww == 0) ? acc[a][b][r] : *cell + acc[a][b][r];
+          }
+    }
+    __syncthreads();
+  }
+  float* slab = slabs + (long long)blockIdx.x * (CA * CB);
+  for (int e = threadIdx.x; e < CA * CB; e += 256) {
+    const int ll = e & 63, r = (e >> 6) & 15, blk = e >> 10;
+    const int a = blk / NBJ, b = blk % NBJ;
+    const int row = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ll >> 5);
+    slab[row * CB + b * 32 + (ll & 31)] = lds_sum[e] * out_scale;
+  }
+}
+
+// dw[e] = sum of n_slabs slabs in a FIXED order: thread (e, q) sums the slabs congruent q mod 4 in ascending order on two
+// chains, the four q are added in order through LDS.  64 elements per workgroup: mat / 64 workgroups share the read
+__global__ void __launch_bounds__(256) k_rows_slab_sum(const float* __restrict__ slabs, int n_slabs, int mat, float* dw) {
+  __shared__ float part[4][64];
+  const int e = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+  float c0 = 0.f, c1 = 0.f;
+  if (e < mat) {
+    int j = q;
+    for (; j + 4 < n_slabs; j += 8) {
+      c0 += slabs[(long long)j * mat + e];
+      c1 += slabs[(long long)(j + 4) * mat + e];
+    }
+    if (j < n_slabs) c0 += slabs[(long long)j * mat + e];
+  }
+  part[q][threadIdx.x & 63] = c0 + c1;
+  __syncthreads();
+  if (q == 0 && e < mat) dw[e] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
 // cell limits of the RG mode: bounds[k (n_ranges + 1) + j] = first position p of offset k's segment whose sorted-side row
@@ -2712,6 +2899,52 @@ int gcl_conv_bwd_weight_rg(const float* a, int64_t n_a, const float* b, int64_t 
   }
   hipLaunchKernelGGL(k_bwd_weight_reduce, dim3((unsigned)cdiv(mat, 256), K), dim3(256), 0, st, (const float*)scratch,
                      seg, per, mat, dw);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+// kernel_size-1 convolutions: dW = A^T B over ALL rows (pair (i, i) for every i), streamed (k_bwd_weight_rows)
+static bool dw_rows_shape(int ca, int cb, int prec) {
+  static const int on = [] { const char* e = getenv("GCL_DW_ROWS"); return e ? atoi(e) : 1; }();
+  return on && prec == 4 && ca % 32 == 0 && cb % 32 == 0 && ca >= 32 && cb >= 32 && ca <= 128 && cb <= 64 &&
+         (ca / 32) * (cb / 32) <= 6;
+}
+static int dw_rows_steps_per_wg(long long n_rows) {
+  const long long n_steps = cdiv(n_rows, 16);
+  long long per = cdiv(n_steps, 512);        // <= 512 workgroups (two per CU), every wave of a workgroup the same number of steps
+  per = cdiv(per, 4) * 4;
+  return (int)(per < 4 ? 4 : per);
+}
+
+int64_t gcl_conv_bwd_weight_rows_scratch_len(int32_t ca, int32_t cb, int32_t prec, int64_t n_rows) {
+  if (n_rows <= 0 || !dw_rows_shape(ca, cb, prec)) return 0;
+  return cdiv(cdiv(n_rows, 16), dw_rows_steps_per_wg(n_rows)) * (long long)ca * cb;
+}
+
+int gcl_conv_bwd_weight_rows(const float* a, const float* b, int64_t n_rows, int32_t ca, int32_t cb, int32_t prec,
+                             const int32_t* a_amax, const int32_t* b_amax, float* scratch, float* dw, void* stream) {
+  GCL_CHECK_ARG(a && b && scratch && dw && a_amax && b_amax, "gcl_conv_bwd_weight_rows: null pointer");
+  GCL_CHECK_ARG(gcl_conv_bwd_weight_rows_scratch_len(ca, cb, prec, n_rows) > 0,
+                "gcl_conv_bwd_weight_rows: shape (%d, %d) / arithmetic %d not taken by the row stream (scratch_len == 0: use "
+                "gcl_conv_bwd_weight with identity pairs)", ca, cb, prec);
+  GCL_CHECK_ARG((long long)n_rows * ca * 4 < (1ll << 32) - (1ll << 20) && (long long)n_rows * cb * 4 < (1ll << 32) - (1ll << 20),
+                "gcl_conv_bwd_weight_rows: operands must be smaller than 4 GiB (buffer addressing)");
+  const unsigned a_bytes = (unsigned)((long long)n_rows * ca * 4), b_bytes = (unsigned)((long long)n_rows * cb * 4);
+  const int per = dw_rows_steps_per_wg(n_rows);
+  const int W = (int)cdiv(cdiv(n_rows, 16), per);
+  const int mat = ca * cb;
+  hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_ROWS(NI, NJ)                                                                                           \
+  hipLaunchKernelGGL((k_bwd_weight_rows<NI, NJ>), dim3(W), dim3(256), 0, st, a, b, (long long)n_rows, per, scratch, a_amax, \
+                     b_amax, a_bytes, b_bytes)
+  const int ni = ca / 32, nj = cb / 32;
+  if (nj == 1) {
+    if (ni == 1) LAUNCH_ROWS(1, 1); else if (ni == 2) LAUNCH_ROWS(2, 1); else if (ni == 3) LAUNCH_ROWS(3, 1); else LAUNCH_ROWS(4, 1);
+  } else {
+    if (ni == 1) LAUNCH_ROWS(1, 2); else if (ni == 2) LAUNCH_ROWS(2, 2); else LAUNCH_ROWS(3, 2);
+  }
+#undef LAUNCH_ROWS
+  hipLaunchKernelGGL(k_rows_slab_sum, dim3((unsigned)cdiv(mat, 64)), dim3(256), 0, st, (const float*)scratch, W, mat, dw);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }

@@ -33,7 +33,8 @@ __global__ void __launch_bounds__(256) k_bn_reduce(const float* __restrict__ x, 
                                                    const float* __restrict__ y, long long n, int c,
                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
                                                    int relu, const unsigned long long* __restrict__ mask,
-                                                   int rows_per_wg, double* partial, int dy_ld = 0) {
+                                                   int rows_per_wg, double* partial, int dy_ld = 0, int want_gmax = 0) {
+  // want_gmax (BWD): a third run of partials, the workgroup's max|g| per channel after the ReLU gate (k_bn_bwd_final's bound)
   // dy_ld: row pitch of dy in floats (0 = c): dy may be a column slice of a wider tensor (the gradient of an ME.cat input)
   const long long gld = dy_ld ? dy_ld : c;
   __shared__ double red[2][256][4];
@@ -43,6 +44,7 @@ __global__ void __launch_bounds__(256) k_bn_reduce(const float* __restrict__ x, 
   long long r_end = r_begin + rows_per_wg;
   if (r_end > n) r_end = n;
   double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+  float gm[4] = {0.f, 0.f, 0.f, 0.f};
   float4 mu = make_float4(0, 0, 0, 0), rs = make_float4(1, 1, 1, 1);
   if (BWD) {
     mu = reinterpret_cast<const float4*>(mean)[cq];
@@ -59,6 +61,8 @@ __global__ void __launch_bounds__(256) k_bn_reduce(const float* __restrict__ x, 
       g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;                                             \
     }                                                                                                         \
     s0[0] += g.x; s0[1] += g.y; s0[2] += g.z; s0[3] += g.w;                                                   \
+    gm[0] = fmaxf(gm[0], fabsf(g.x)); gm[1] = fmaxf(gm[1], fabsf(g.y));                                       \
+    gm[2] = fmaxf(gm[2], fabsf(g.z)); gm[3] = fmaxf(gm[3], fabsf(g.w));                                       \
     s1[0] += (double)g.x * ((xv.x - mu.x) * rs.x); s1[1] += (double)g.y * ((xv.y - mu.y) * rs.y);             \
     s1[2] += (double)g.z * ((xv.z - mu.z) * rs.z); s1[3] += (double)g.w * ((xv.w - mu.w) * rs.w);             \
   }
@@ -112,6 +116,21 @@ __global__ void __launch_bounds__(256) k_bn_reduce(const float* __restrict__ x, 
       }
       partial[(long long)(cq * 4 + j) * nwg + blockIdx.x] = a;
       partial[(long long)(c + cq * 4 + j) * nwg + blockIdx.x] = b;
+    }
+  }
+  if (BWD && want_gmax) {      // uniform over the workgroup
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[0][threadIdx.x][j] = (double)gm[j];
+    __syncthreads();
+    if (rl == 0) {
+      const long long nwg = gridDim.x;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        double a = 0;
+        for (int q = 0; q < rstep; ++q) a = fmax(a, red[0][q * cq_n + cq][j]);
+        partial[(long long)(2 * c + cq * 4 + j) * nwg + blockIdx.x] = a;
+      }
     }
   }
 }
@@ -192,33 +211,121 @@ __global__ void __launch_bounds__(256) k_bn_stats_final(const double* __restrict
 // read by c / 4 workgroups as 16-byte pieces 2 c floats apart: 55 us per 0.5 M-row layer (4143 partials), on the training
 // stream between every convolution and its BatchNorm apply pass.
 constexpr int BN_DIRECT_MAX = 1 << 20;
+// minimum of run p1 and maximum of run p2 (n_part floats each) over a 256-thread workgroup; order-independent by nature.
+// Valid in thread 0.  (Its own LDS: may follow reduce_runs without a barrier in between.)
+__device__ __forceinline__ void reduce_min_max(const float* __restrict__ p1, const float* __restrict__ p2, int n_part,
+                                               float& lo, float& hi) {
+  __shared__ float mm[2][256];
+  const int t = threadIdx.x;
+  float a = 3.0e38f, b = -3.0e38f;
+  for (int w = t; w < n_part; w += 256) {
+    a = fminf(a, p1[w]);
+    b = fmaxf(b, p2[w]);
+  }
+  mm[0][t] = a;
+  mm[1][t] = b;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) {
+      mm[0][t] = fminf(mm[0][t], mm[0][t + o]);
+      mm[1][t] = fmaxf(mm[1][t], mm[1][t + o]);
+    }
+    __syncthreads();
+  }
+  lo = mm[0][0];
+  hi = mm[1][0];
+}
+
+// What the BatchNorm apply pass of channel `ch` will write, bounded BEFORE it runs (round 5): y = (x - mu) rs w + b is a
+// monotone function of x in fp32 arithmetic too (every step rounds monotonically), so max|y| over the channel is attained
+// at the channel's minimum or maximum of x -- both known from the convolution epilogue's partials -- and is EXACT without
+// a residual.  With a residual: + max|residual| (an upper bound); with ReLU only the positive side counts.  `max_with`:
+// another tensor that shares the slot (the other input of an ME.cat whose output this BatchNorm writes in place).
+struct BnRange {
+  float* xrange;           // out [2][c]: channel minimum, maximum of x (kept for the backward pass's bound), or NULL
+  const float* weight;     // BatchNorm weight / bias [c]
+  const float* bias;
+  int relu;
+  const int* add_amax;     // amax slot of the residual, or NULL
+  const int* max_with;     // amax slot of a tensor that shares y's slot, or NULL
+  int* y_amax;             // zero-initialised slot that receives the bound, or NULL: nothing of the above is computed
+};
 __global__ void __launch_bounds__(256) k_bn_stats_direct(const float* __restrict__ partial, int n_part, long long n, int c,
                                                          float eps, float momentum, float* running_mean,
-                                                         float* running_var, float* mean, float* rstd) {
+                                                         float* running_var, float* mean, float* rstd, BnRange rg) {
   const int ch = blockIdx.x;
   double s, ss;
   reduce_runs(partial + (long long)ch * n_part, partial + ((long long)c + ch) * n_part, n_part, s, ss);
+  float xlo = 0.f, xhi = 0.f;
+  if (rg.y_amax)
+    reduce_min_max(partial + ((long long)2 * c + ch) * n_part, partial + ((long long)3 * c + ch) * n_part, n_part, xlo, xhi);
   if (threadIdx.x != 0) return;
   double m = s / (double)n;
   double var = ss / (double)n - m * m;
   if (var < 0) var = 0;
-  mean[ch] = (float)m;
-  rstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
+  const float mu = (float)m, rs = (float)(1.0 / sqrt(var + (double)eps));
+  mean[ch] = mu;
+  rstd[ch] = rs;
   if (running_mean) {
     double unb = (n > 1) ? var * (double)n / (double)(n - 1) : var;
     running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * m);
     running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unb);
   }
+  if (rg.y_amax) {
+    if (rg.xrange) {
+      rg.xrange[ch] = xlo;
+      rg.xrange[c + ch] = xhi;
+    }
+    const float w = rg.weight[ch], b = rg.bias[ch];
+    const float f_lo = (xlo - mu) * rs * w + b, f_hi = (xhi - mu) * rs * w + b;      // bn_fwd_one's expression
+    float bound = rg.relu ? fmaxf(fmaxf(f_lo, f_hi), 0.f) : fmaxf(fabsf(f_lo), fabsf(f_hi));
+    if (rg.add_amax) bound += __int_as_float(amax_slot_bits(rg.add_amax));
+    if (rg.max_with) bound = fmaxf(bound, __int_as_float(amax_slot_bits(rg.max_with)));
+    amax_slot_publish(rg.y_amax, __float_as_int(bound), (unsigned)ch);
+  }
 }
 
+// Bound of the BatchNorm backward's dx = w rs (g - sum_g / n - xhat sum_gx / n) per channel, before its apply pass runs:
+// |dx| <= |w rs| (max|g| + |sum_g| / n + max|xhat| |sum_gx| / n), max|g| of the channel from k_bn_reduce's third run (after
+// the ReLU gate), max|xhat| from the forward pass's channel range of x.  Tight to within the triangle inequality.
+struct BnBwdRange {
+  const float* xrange;     // [2][c] from the forward pass (BnRange.xrange)
+  const float* mean;
+  const float* rstd;
+  const float* weight;
+  long long n;
+  int* dx_amax;            // zero-initialised slot that receives the bound, or NULL (then the partials have two runs)
+};
 __global__ void __launch_bounds__(256) k_bn_bwd_final(const double* __restrict__ partial, int nwg, int c,
-                                                      float* sum_g, float* sum_gx) {
+                                                      float* sum_g, float* sum_gx, BnBwdRange rg) {
   const int ch = blockIdx.x;
   double s, ss;
   reduce_runs(partial + (long long)ch * nwg, partial + ((long long)c + ch) * nwg, nwg, s, ss);
+  double gmax = 0;
+  if (rg.dx_amax) {      // third run: per-workgroup max|g| of the channel
+    __shared__ double gm[256];
+    double a = 0;
+    const double* p3 = partial + ((long long)2 * c + ch) * nwg;
+    for (int w = threadIdx.x; w < nwg; w += 256) a = fmax(a, p3[w]);
+    gm[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) gm[threadIdx.x] = fmax(gm[threadIdx.x], gm[threadIdx.x + o]);
+      __syncthreads();
+    }
+    gmax = gm[0];
+  }
   if (threadIdx.x != 0) return;
   sum_g[ch] = (float)s;
   sum_gx[ch] = (float)ss;
+  if (rg.dx_amax) {
+    const float mu = rg.mean[ch], rs = rg.rstd[ch], inv_n = 1.0f / (float)rg.n;
+    const float xh = fmaxf(fabsf(rg.xrange[ch] - mu), fabsf(rg.xrange[c + ch] - mu)) * rs;
+    const float bound = fabsf(rg.weight[ch] * rs) * ((float)gmax + fabsf((float)s) * inv_n + xh * fabsf((float)ss) * inv_n);
+    // one part in 2^16 of slack: the apply pass rounds its own way (a bound that is low by an ulp would only matter at a
+    // power of two, where the fp16 planes still have 4 x headroom)
+    amax_slot_publish(rg.dx_amax, __float_as_int(bound * 1.0000153f), (unsigned)ch);
+  }
 }
 
 // max |v| of the values a workgroup produced -> the gcl_amax slot (common.h)
@@ -273,7 +380,11 @@ __global__ void __launch_bounds__(256) k_bn_apply(const float* __restrict__ x, l
                                                   const float* __restrict__ weight, const float* __restrict__ bias,
                                                   const float* __restrict__ residual, int relu,
                                                   float* __restrict__ y, unsigned long long* __restrict__ mask,
-                                                  int* amax_bits, int y_ld = 0) {
+                                                  int* amax_bits, int y_ld = 0, unsigned short* __restrict__ planes = nullptr,
+                                                  const int* __restrict__ planes_amax = nullptr) {
+  // planes (round 5): the fp16 plane image of y is written in the same pass (row pitch = y's, y_ld or c channels), scaled
+  // by the slot `planes_amax` -- k_bn_stats_direct's bound of max|y|, final before this launch starts; no publication then
+  const float pscale = planes ? amax_scale(planes_amax) : 1.f;
   const int cq_n = c >> 2;
   const long long S = (long long)gridDim.x * blockDim.x;
   const long long e0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -309,6 +420,11 @@ __global__ void __launch_bounds__(256) k_bn_apply(const float* __restrict__ x, l
     const float4 ob = bn_fwd_one(xb, rb, residual != nullptr, relu, kb);
     if (oka) { BN_Y(e, row_e) = oa; am = amax4(am, oa); }
     if (okb) { BN_Y(f, row_e + rstep) = ob; am = amax4(am, ob); }
+    if (planes) {
+      const long long pld = yld4 * 4;
+      if (oka) store_planes4(planes, HOIST ? row_e : e / cq_n, pld, HOIST ? q0 * 4 : (int)(e % cq_n) * 4, oa, pscale);
+      if (okb) store_planes4(planes, HOIST ? row_e + rstep : f / cq_n, pld, HOIST ? q0 * 4 : (int)(f % cq_n) * 4, ob, pscale);
+    }
     row_e += 2 * rstep;
     if (mask) {
       bn_mask_store(mask, e, oa, oka);
@@ -316,7 +432,7 @@ __global__ void __launch_bounds__(256) k_bn_apply(const float* __restrict__ x, l
     }
   }
 #undef BN_Y
-  if (amax_bits) publish_amax(am, amax_bits);
+  if (amax_bits && !planes) publish_amax(am, amax_bits);
 }
 
 struct BnBwdC { float4 mu, rs, wv, sg, sx; };
@@ -351,7 +467,11 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const float* __restrict__ 
                                                       const float* __restrict__ sum_gx, int relu,
                                                       const unsigned long long* __restrict__ mask,
                                                       float* __restrict__ dx, float* __restrict__ dres,
-                                                      int* amax_bits, int dy_ld = 0) {
+                                                      int* amax_bits, int dy_ld = 0,
+                                                      unsigned short* __restrict__ planes = nullptr,
+                                                      const int* __restrict__ planes_amax = nullptr) {
+  // planes: the fp16 plane image of dx in the same pass, scaled by k_bn_bwd_final's bound (slot `planes_amax`)
+  const float pscale = planes ? amax_scale(planes_amax) : 1.f;
   const int cq_n = c >> 2;
   const long long S = (long long)gridDim.x * blockDim.x;
   const long long e0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -391,16 +511,18 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const float* __restrict__ 
     const float4 oa = bn_bwd_one(xa, ga, inv_n, ka);
     reinterpret_cast<float4*>(dx)[e] = oa;
     am = amax4(am, oa);
+    if (planes) store_planes4(planes, e / cq_n, c, (int)(e % cq_n) * 4, oa, pscale);
     if (dres) reinterpret_cast<float4*>(dres)[e] = ga;
     if (okb) {
       const float4 ob = bn_bwd_one(xb, gb, inv_n, kb);
       reinterpret_cast<float4*>(dx)[f] = ob;
       am = amax4(am, ob);
+      if (planes) store_planes4(planes, f / cq_n, c, (int)(f % cq_n) * 4, ob, pscale);
       if (dres) reinterpret_cast<float4*>(dres)[f] = gb;
     }
   }
 #undef BN_DY
-  if (amax_bits) publish_amax(am, amax_bits);
+  if (amax_bits && !planes) publish_amax(am, amax_bits);
 }
 
 // ---- row-wise L2 normalisation  y = x / ||x||_2  (model/resunet.py:226-230) -------------------------------------
@@ -496,7 +618,7 @@ using namespace gcl;
 
 extern "C" {
 
-int64_t gcl_bn_scratch_len(int64_t n, int32_t c) { return cdiv(n, bn_rows_per_wg(n, c)) * 2 * c; }
+int64_t gcl_bn_scratch_len(int64_t n, int32_t c) { return cdiv(n, bn_rows_per_wg(n, c)) * 3 * c; }      // sum, xhat-weighted sum, max|g|
 
 int gcl_bn_stats(const float* x, int64_t n, int32_t c, float eps, float momentum, float* running_mean,
                  float* running_var, double* scratch, float* mean, float* rstd, void* stream) {
@@ -520,10 +642,20 @@ int gcl_bn_stats_from_tiles(const float* partial, int64_t n_tiles, int64_t n, in
                             float* running_mean, float* running_var, double* scratch, float* mean, float* rstd,
                             void* stream) {
   (void)scratch;
+  return gcl_bn_stats_from_tiles_range(partial, n_tiles, n, c, eps, momentum, running_mean, running_var, mean, rstd, nullptr,
+                                       nullptr, nullptr, 0, nullptr, nullptr, nullptr, stream);
+}
+
+int gcl_bn_stats_from_tiles_range(const float* partial, int64_t n_tiles, int64_t n, int32_t c, float eps, float momentum,
+                                  float* running_mean, float* running_var, float* mean, float* rstd, float* xrange,
+                                  const float* weight, const float* bias, int32_t relu, const int32_t* add_amax,
+                                  const int32_t* max_with, int32_t* y_amax, void* stream) {
   GCL_CHECK_ARG(partial && mean && rstd, "gcl_bn_stats_from_tiles: null pointer");
   GCL_CHECK_ARG(n > 0 && n_tiles > 0 && n_tiles <= BN_DIRECT_MAX && c > 0, "gcl_bn_stats_from_tiles: bad sizes");
+  GCL_CHECK_ARG(!y_amax || (weight && bias), "gcl_bn_stats_from_tiles_range: the bound of max|y| needs the BatchNorm's weight and bias");
+  const BnRange rg{xrange, weight, bias, relu, (const int*)add_amax, (const int*)max_with, (int*)y_amax};
   hipLaunchKernelGGL(k_bn_stats_direct, dim3((unsigned)c), dim3(256), 0, (hipStream_t)stream, partial, (int)n_tiles,
-                     (long long)n, c, eps, momentum, running_mean, running_var, mean, rstd);
+                     (long long)n, c, eps, momentum, running_mean, running_var, mean, rstd, rg);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }
@@ -537,18 +669,28 @@ int gcl_bn_apply(const float* x, int64_t n, int32_t c, const float* mean, const 
 int gcl_bn_apply_ld(const float* x, int64_t n, int32_t c, const float* mean, const float* rstd, const float* weight,
                     const float* bias, const float* residual, int32_t relu, float* y, int32_t y_ld, uint64_t* relu_mask,
                     int32_t* y_amax, void* stream) {
+  return gcl_bn_apply_planes(x, n, c, mean, rstd, weight, bias, residual, relu, y, y_ld, relu_mask, y_amax, nullptr, stream);
+}
+
+int gcl_bn_apply_planes(const float* x, int64_t n, int32_t c, const float* mean, const float* rstd, const float* weight,
+                        const float* bias, const float* residual, int32_t relu, float* y, int32_t y_ld, uint64_t* relu_mask,
+                        int32_t* y_amax, void* planes, void* stream) {
   GCL_CHECK_ARG(x && mean && rstd && weight && bias && y, "gcl_bn_apply: null pointer");
   GCL_CHECK_ARG(n > 0 && c >= 4 && c % 4 == 0, "gcl_bn_apply: unsupported shape");
   GCL_CHECK_ARG(y_ld == 0 || (y_ld >= c && y_ld % 4 == 0), "gcl_bn_apply_ld: y_ld must be 0 or a multiple of 4 >= c");
+  GCL_CHECK_ARG(!planes || (y_amax && c % 32 == 0 && (y_ld % 32) == 0),
+                "gcl_bn_apply_planes: a plane image needs the slot that holds the bound of max|y| and widths that are multiples of 32");
   long long total4 = n * (c / 4);
   long long g = cdiv(total4, 256);
   if (g > 4096) g = 4096;
   if ((g * 256) % (c / 4) == 0)
     hipLaunchKernelGGL(k_bn_apply<true>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, total4, c, mean, rstd,
-                       weight, bias, residual, relu, y, (unsigned long long*)(relu ? relu_mask : nullptr), y_amax, y_ld);
+                       weight, bias, residual, relu, y, (unsigned long long*)(relu ? relu_mask : nullptr), y_amax, y_ld,
+                       (unsigned short*)planes, (const int*)y_amax);
   else
     hipLaunchKernelGGL(k_bn_apply<false>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, total4, c, mean, rstd,
-                       weight, bias, residual, relu, y, (unsigned long long*)(relu ? relu_mask : nullptr), y_amax, y_ld);
+                       weight, bias, residual, relu, y, (unsigned long long*)(relu ? relu_mask : nullptr), y_amax, y_ld,
+                       (unsigned short*)planes, (const int*)y_amax);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }
@@ -564,17 +706,27 @@ int gcl_bn_bwd_reduce(const float* x, const float* dy, const float* y, const uin
 int gcl_bn_bwd_reduce_ld(const float* x, const float* dy, int32_t dy_ld, const float* y, const uint64_t* relu_mask, int64_t n,
                          int32_t c, const float* mean, const float* rstd, int32_t relu, double* scratch, float* sum_g,
                          float* sum_gx, void* stream) {
+  return gcl_bn_bwd_reduce_range(x, dy, dy_ld, y, relu_mask, n, c, mean, rstd, relu, scratch, sum_g, sum_gx, nullptr, nullptr,
+                                 nullptr, stream);
+}
+
+int gcl_bn_bwd_reduce_range(const float* x, const float* dy, int32_t dy_ld, const float* y, const uint64_t* relu_mask,
+                            int64_t n, int32_t c, const float* mean, const float* rstd, int32_t relu, double* scratch,
+                            float* sum_g, float* sum_gx, const float* xrange, const float* weight, int32_t* dx_amax,
+                            void* stream) {
   GCL_CHECK_ARG(dy_ld == 0 || (dy_ld >= c && dy_ld % 4 == 0), "gcl_bn_bwd_reduce: dy_ld must be 0 or a multiple of 4 >= c");
   GCL_CHECK_ARG(x && dy && mean && rstd && scratch && sum_g && sum_gx, "gcl_bn_bwd_reduce: null pointer");
   GCL_CHECK_ARG(!relu || y || relu_mask, "gcl_bn_bwd_reduce: y or relu_mask is required when relu is set");
   GCL_CHECK_ARG(n > 0 && bn_c_ok(c), "gcl_bn_bwd_reduce: unsupported shape n=%lld c=%d", (long long)n, c);
+  GCL_CHECK_ARG(!dx_amax || (xrange && weight), "gcl_bn_bwd_reduce_range: the bound of max|dx| needs xrange (forward pass) and the weight");
   hipStream_t st = (hipStream_t)stream;
   const int rows = bn_rows_per_wg(n, c);
   int nwg = (int)cdiv(n, rows);
   hipLaunchKernelGGL(k_bn_reduce<true>, dim3(nwg), dim3(256), 0, st, x, dy, y, (long long)n, c, mean, rstd, relu,
-                     (const unsigned long long*)relu_mask, rows, scratch, dy_ld);
+                     (const unsigned long long*)relu_mask, rows, scratch, dy_ld, dx_amax ? 1 : 0);
+  const BnBwdRange rg{xrange, mean, rstd, weight, (long long)n, (int*)dx_amax};
   hipLaunchKernelGGL(k_bn_bwd_final, dim3((unsigned)c), dim3(256), 0, st, (const double*)scratch, nwg, c,
-                     sum_g, sum_gx);
+                     sum_g, sum_gx, rg);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }
@@ -588,21 +740,31 @@ int gcl_bn_bwd_apply(const float* x, const float* dy, const float* y, const uint
 int gcl_bn_bwd_apply_ld(const float* x, const float* dy, int32_t dy_ld, const float* y, const uint64_t* relu_mask, int64_t n,
                         int32_t c, const float* mean, const float* rstd, const float* weight, const float* sum_g,
                         const float* sum_gx, int32_t relu, float* dx, float* dres, int32_t* dx_amax, void* stream) {
+  return gcl_bn_bwd_apply_planes(x, dy, dy_ld, y, relu_mask, n, c, mean, rstd, weight, sum_g, sum_gx, relu, dx, dres, dx_amax,
+                                 nullptr, stream);
+}
+
+int gcl_bn_bwd_apply_planes(const float* x, const float* dy, int32_t dy_ld, const float* y, const uint64_t* relu_mask, int64_t n,
+                            int32_t c, const float* mean, const float* rstd, const float* weight, const float* sum_g,
+                            const float* sum_gx, int32_t relu, float* dx, float* dres, int32_t* dx_amax, void* planes,
+                            void* stream) {
   GCL_CHECK_ARG(dy_ld == 0 || (dy_ld >= c && dy_ld % 4 == 0), "gcl_bn_bwd_apply: dy_ld must be 0 or a multiple of 4 >= c");
   GCL_CHECK_ARG(x && dy && mean && rstd && weight && sum_g && sum_gx && dx, "gcl_bn_bwd_apply: null pointer");
   GCL_CHECK_ARG(!relu || y || relu_mask, "gcl_bn_bwd_apply: y or relu_mask is required when relu is set");
   GCL_CHECK_ARG(n > 0 && c >= 4 && c % 4 == 0, "gcl_bn_bwd_apply: unsupported shape");
+  GCL_CHECK_ARG(!planes || (dx_amax && c % 32 == 0),
+                "gcl_bn_bwd_apply_planes: a plane image needs the slot that holds the bound of max|dx| and c a multiple of 32");
   long long total4 = n * (c / 4);
   long long g = cdiv(total4, 256);
   if (g > 4096) g = 4096;
   if ((g * 256) % (c / 4) == 0)
     hipLaunchKernelGGL(k_bn_bwd_apply<true>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, dy, y, total4, c,
                        1.0f / (float)n, mean, rstd, weight, sum_g, sum_gx, relu, (const unsigned long long*)relu_mask, dx,
-                       dres, dx_amax, dy_ld);
+                       dres, dx_amax, dy_ld, (unsigned short*)planes, (const int*)dx_amax);
   else
     hipLaunchKernelGGL(k_bn_bwd_apply<false>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, dy, y, total4, c,
                        1.0f / (float)n, mean, rstd, weight, sum_g, sum_gx, relu, (const unsigned long long*)relu_mask, dx,
-                       dres, dx_amax, dy_ld);
+                       dres, dx_amax, dy_ld, (unsigned short*)planes, (const int*)dx_amax);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }

@@ -84,20 +84,28 @@ __global__ void __launch_bounds__(256) k_cat2(const float4* __restrict__ a, int 
   }
   if (amax) publish_amax_wg(m, amax);
 }
+// out = elementwise maximum of two amax slots (a valid slot of max(value a, value b))
+__global__ void k_slot_max(const int* __restrict__ a, const int* __restrict__ b, int* __restrict__ out) {
+  out[threadIdx.x] = max(a[threadIdx.x], b[threadIdx.x]);
+}
 // ME.cat whose left input was written in place by its producer: copy the right input's columns, y[r][ca..] = b[r]
+// planes (round 5): the cat's plane image gets these columns too, at the scale of `amax` -- then a slot that already holds a
+// bound of the WHOLE cat (the left input's BatchNorm statistics launch folded this input's maximum in): nothing is published
 __global__ void __launch_bounds__(256) k_cat_right(const float4* __restrict__ b, int cb4, long long n, int ca4,
-                                                   float4* __restrict__ y, int* amax) {
+                                                   float4* __restrict__ y, int* amax, unsigned short* __restrict__ planes) {
   const int c4 = ca4 + cb4;
   const long long total = n * cb4;
+  const float pscale = planes ? amax_scale(amax) : 1.f;
   float m = 0.f;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long r = i / cb4;
     const int q = (int)(i - r * cb4);
     const float4 v = b[i];
     y[r * c4 + ca4 + q] = v;
+    if (planes) store_planes4(planes, r, (long long)c4 * 4, (ca4 + q) * 4, v, pscale);
     m = amax4p(m, v);
   }
-  if (amax) publish_amax_wg(m, amax);
+  if (amax && !planes) publish_amax_wg(m, amax);
 }
 __global__ void __launch_bounds__(256) k_split2(const float4* __restrict__ g, int ca4, int cb4, long long n,
                                                 float4* __restrict__ ga, float4* __restrict__ gb) {
@@ -386,6 +394,7 @@ struct OpSaved {           // what the backward pass of a record needs from its 
   float* conv_out = nullptr;            // CONVBN: the convolution output (the BatchNorm input)
   unsigned long long* mask = nullptr;   // CONVBN with relu: sign bits of the output
   float *mean = nullptr, *rstd = nullptr;
+  float* xrange = nullptr;              // CONVBN in bound mode: per-channel minimum / maximum of conv_out ([2][c])
   int32_t* x_amax = nullptr;
   float* norm = nullptr;                // ROWNORM
 };
@@ -450,6 +459,13 @@ struct Plan : PassState {   // the base part is the pass being enqueued right no
 };
 
 static long long state_words(const Plan& P) { return (long long)P.worder.size() * (2 + 8 + 8); }
+
+// GCL_BN_PLANES=0: the BatchNorm passes publish the measured max-abs and every plane image is a gcl_split_planes pass of
+// its own (rounds 1 - 4); ops.py reads the same variable
+static bool bound_mode() {
+  static const bool on = [] { const char* e = getenv("GCL_BN_PLANES"); return !(e && e[0] == '0'); }();
+  return on;
+}
 
 static int32_t* new_slot(Plan& P) {      // slots are used once per pass (they start zeroed); the pool is sized for the worst case
   if (P.next_slot >= P.n_slots) {
@@ -571,7 +587,7 @@ static int conv_forward(Plan& P, int i, float** y_out, float** stats_out, hipStr
   const bool pl = op.cin >= P.presplit;
   if (pl && (rc = ensure_planes(P, x, n_in, op.cin, st))) return rc;
   float* stats = nullptr;
-  if (op.kind == GCL_OP_CONVBN) stats = A.take_n<float>(cdiv(n_out, 128) * 2 * op.cout);
+  if (op.kind == GCL_OP_CONVBN) stats = A.take_n<float>(cdiv(n_out, 128) * 4 * op.cout);      // sum, squares, min, max per column and 128-row tile
   *stats_out = stats;
   const int32_t *tbl = nullptr, *order = nullptr, *mask = nullptr;
   if (m.kernel_size > 1) {
@@ -737,10 +753,22 @@ static int plan_forward(Plan& P, const float* x_in, void* const* bn_stats, float
         sv.rstd = mr + c;
         float* rm = (float*)bn_stats[2 * op.bn];
         float* rv = (float*)bn_stats[2 * op.bn + 1];
-        if (stats) {       // column sums from the convolution epilogue
+        // Bound mode (round 5): this BatchNorm's output is at least `presplit` channels wide, i.e. its consumers read a
+        // plane image: the statistics launch bounds max|y| from the epilogue's column ranges and the apply pass writes the
+        // image itself -- into the image of the ME.cat it writes in place, if so (no gcl_split_planes pass; ops.py mirrors the
+        // slot values: _BatchNormFn, cat_features).  Needs the residual's / the cat partner's max-abs slots, which their
+        // producers have published.
+        const int32_t* res_amax = op.x2 >= 0 ? P.t[op.x2].amax : nullptr;
+        const int32_t* cat_amax = P.cat_left[i] >= 0 ? P.t[P.ops[P.cat_left[i]].x2].amax : nullptr;
+        const bool bound = stats && bound_mode() && c >= P.presplit && (c % 32) == 0 && (op.x2 < 0 || res_amax) &&
+                           (P.cat_left[i] < 0 || (cat_amax && (P.ops[P.cat_left[i]].cout % 32) == 0));
+        int32_t* bound_slot = bound ? new_slot(P) : nullptr;
+        if (stats) {       // column sums (and ranges) from the convolution epilogue
           const long long nt = cdiv(n_out, 128);
-          double* scratch = A.take_n<double>(gcl_bn_tiles_scratch_len(nt, c));
-          PLAN_CALL(gcl_bn_stats_from_tiles(stats, nt, n_out, c, op.eps, op.momentum, rm, rv, scratch, sv.mean, sv.rstd, (void*)st));
+          if (bound) sv.xrange = A.take_n<float>(2 * c);
+          PLAN_CALL(gcl_bn_stats_from_tiles_range(stats, nt, n_out, c, op.eps, op.momentum, rm, rv, sv.mean, sv.rstd, sv.xrange,
+                                                  (const float*)P.params[op.bn_w], (const float*)P.params[op.bn_b], op.relu,
+                                                  res_amax, cat_amax, bound_slot, (void*)st));
         } else {
           double* scratch = A.take_n<double>(gcl_bn_scratch_len(n_out, c));
           PLAN_CALL(gcl_bn_stats(cy, n_out, c, op.eps, op.momentum, rm, rv, scratch, sv.mean, sv.rstd, (void*)st));
@@ -752,20 +780,24 @@ static int plan_forward(Plan& P, const float* x_in, void* const* bn_stats, float
           TState& cty = P.t[cat.y];
           cty = TState();
           cty.ptr = A.take_n<float>(n_out * cat.cout);
-          cty.amax = new_slot(P);
+          cty.amax = bound ? bound_slot : new_slot(P);
+          if (bound) cty.planes = A.take(n_out * cat.cout * 4);
           y.ptr = cty.ptr;
           y.ld = cat.cout;
           y.amax = cty.amax;
+          y.planes = nullptr;      // the image belongs to the cat (this tensor's only consumer)
         } else {
           y.ptr = A.take_n<float>(n_out * c);
           y.ld = 0;
-          y.amax = new_slot(P);
+          y.amax = bound ? bound_slot : new_slot(P);
+          if (bound) y.planes = A.take(n_out * c * 4);
         }
         if (op.relu) sv.mask = A.take_n<unsigned long long>(gcl_bn_mask_len(n_out, c));
         const float* res = op.x2 >= 0 ? P.t[op.x2].ptr : nullptr;
-        PLAN_CALL(gcl_bn_apply_ld(cy, n_out, c, sv.mean, sv.rstd, (const float*)P.params[op.bn_w],
-                                  (const float*)P.params[op.bn_b], res, op.relu, y.ptr, y.ld, (uint64_t*)sv.mask, y.amax,
-                                  (void*)st));
+        void* img = !bound ? nullptr : (P.cat_left[i] >= 0 ? P.t[P.ops[P.cat_left[i]].y].planes : y.planes);
+        PLAN_CALL(gcl_bn_apply_planes(cy, n_out, c, sv.mean, sv.rstd, (const float*)P.params[op.bn_w],
+                                      (const float*)P.params[op.bn_b], res, op.relu, y.ptr, y.ld, (uint64_t*)sv.mask, y.amax,
+                                      img, (void*)st));
         break;
       }
       case GCL_OP_CONV: {
@@ -796,16 +828,20 @@ static int plan_forward(Plan& P, const float* x_in, void* const* bn_stats, float
         if (P.t[op.x].ld == op.cout && P.t[op.x].ptr == y.ptr && y.ptr) {      // left input already in place (cat_left)
           if (!A.dry) {
             hipLaunchKernelGGL(k_cat_right, dim3(grid_for(n_out * cb / 4)), dim3(256), 0, st, (const float4*)P.t[op.x2].ptr,
-                               cb / 4, n_out, ca / 4, (float4*)y.ptr, y.amax);
+                               cb / 4, n_out, ca / 4, (float4*)y.ptr, y.amax, (unsigned short*)y.planes);
             GCL_CHECK_LAUNCH();
           }
           break;
         }
         y.ptr = A.take_n<float>(n_out * op.cout);
         y.amax = new_slot(P);
+        // max|cat| = the larger of the inputs' slots when both are known (ops.cat_features: a slot may hold a BatchNorm's
+        // bound instead of the measured maximum, and both paths must hand the consumers the same value); else measured
+        const int32_t *sa = P.t[op.x].amax, *sb = P.t[op.x2].amax;
         if (!A.dry) {
+          if (sa && sb) hipLaunchKernelGGL(k_slot_max, dim3(1), dim3(AMAX_WORDS), 0, st, (const int*)sa, (const int*)sb, (int*)y.amax);
           hipLaunchKernelGGL(k_cat2, dim3(grid_for(n_out * op.cout / 4)), dim3(256), 0, st, (const float4*)P.t[op.x].ptr, ca / 4,
-                             (const float4*)P.t[op.x2].ptr, cb / 4, n_out, (float4*)y.ptr, y.amax);
+                             (const float4*)P.t[op.x2].ptr, cb / 4, n_out, (float4*)y.ptr, (sa && sb) ? nullptr : y.amax);
           GCL_CHECK_LAUNCH();
         }
         break;
@@ -939,7 +975,13 @@ static int conv_backward(Plan& P, int i, TState dy, void* const* grads, hipStrea
     P.g[op.x].ptr = dx;
     P.g[op.x].amax = dx_amax;
   }
-  {      // weight gradient over the compacted pair lists
+  const long long rows_len = m.kernel_size == 1 ? gcl_conv_bwd_weight_rows_scratch_len(op.cin, op.cout, 4, n_in) : 0;
+  if (rows_len > 0) {      // kernel_size 1: both operands streamed once, no pair list (as ops._ConvFn.backward decides)
+    float* scratch = A.take_n<float>(rows_len);
+    ProfScope ps(P, ws, 3, pairs, op.cin, op.cout, n_in, n_out, op.K);
+    PLAN_CALL(gcl_conv_bwd_weight_rows(x.ptr, dy.ptr, n_in, op.cin, op.cout, 4, P.saved[i].x_amax, dy.amax, scratch, dW,
+                                       (void*)ws));
+  } else {      // weight gradient over the compacted pair lists
     const int32_t *pa = m.pair_in, *pb = m.pair_out;
     if (op.transpose) { pa = m.pair_out; pb = m.pair_in; }
     GCL_CHECK_ARG(A.dry || (pa && pb), "gcl_plan_backward: record %d needs pair lists the maps do not carry", i);
@@ -997,15 +1039,19 @@ static int plan_backward(Plan& P, const float* dy, void* const* grads, int first
         float* sum_g = (float*)grads[op.bn_b];
         float* sum_gx = (float*)grads[op.bn_w];
         double* scratch = A.take_n<double>(gcl_bn_scratch_len(n_out, c));
-        PLAN_CALL(gcl_bn_bwd_reduce_ld(sv.conv_out, g.ptr, g.ld, nullptr, (const uint64_t*)sv.mask, n_out, c, sv.mean, sv.rstd,
-                                       op.relu, scratch, sum_g, sum_gx, (void*)st));
+        // bound mode: dx is read as a plane image by the input gradient (and by the weight gradient when both widths allow)
+        const bool bound = sv.xrange && c >= P.presplit && !is_stem(op, M.maps[op.map]);
         TState d;
         d.ptr = A.take_n<float>(n_out * c);
         d.amax = new_slot(P);
+        PLAN_CALL(gcl_bn_bwd_reduce_range(sv.conv_out, g.ptr, g.ld, nullptr, (const uint64_t*)sv.mask, n_out, c, sv.mean, sv.rstd,
+                                          op.relu, scratch, sum_g, sum_gx, sv.xrange, (const float*)P.params[op.bn_w],
+                                          bound ? d.amax : nullptr, (void*)st));
+        if (bound) d.planes = A.take(n_out * c * 4);
         float* dres = op.x2 >= 0 ? A.take_n<float>(n_out * c) : nullptr;
-        PLAN_CALL(gcl_bn_bwd_apply_ld(sv.conv_out, g.ptr, g.ld, nullptr, (const uint64_t*)sv.mask, n_out, c, sv.mean, sv.rstd,
-                                      (const float*)P.params[op.bn_w], sum_g, sum_gx, op.relu, d.ptr, dres, d.amax,
-                                      (void*)st));
+        PLAN_CALL(gcl_bn_bwd_apply_planes(sv.conv_out, g.ptr, g.ld, nullptr, (const uint64_t*)sv.mask, n_out, c, sv.mean,
+                                          sv.rstd, (const float*)P.params[op.bn_w], sum_g, sum_gx, op.relu, d.ptr, dres,
+                                          d.amax, d.planes, (void*)st));
         if ((rc = conv_backward(P, i, d, grads, st))) return rc;
         if ((rc = give(P, op.x2, dres, n_out * c, st, nullptr, 0, c))) return rc;
         break;
@@ -1455,6 +1501,32 @@ int gcl_plan_set_aux_stream(void* plan, void* stream) {
   Plan* P = (Plan*)plan;
   GCL_CHECK_ARG(P, "gcl_plan_set_aux_stream: null plan");
   P->aux = (hipStream_t)stream;
+  return GCL_OK;
+}
+
+// A HIP stream restricted to a share of the chip's CUs (hipExtStreamCreateWithCUMask): the lowest `percent` % of the mask
+// bits.  Experiment hook for the weight-gradient stream (GCL_AUX_CU_PCT, native.py): how much of the main chain's slowdown
+// beside the weight gradients is bought back by giving them fewer CUs.
+int gcl_stream_create_cu_share(int32_t percent, int32_t low_priority, void** stream_out) {
+  GCL_CHECK_ARG(stream_out && percent >= 1 && percent <= 100, "gcl_stream_create_cu_share: percent must be 1..100");
+  int dev = 0;
+  hipDeviceProp_t prop;
+  GCL_CHECK_HIP(hipGetDevice(&dev));
+  GCL_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+  const int n_cu = prop.multiProcessorCount, words = (n_cu + 31) / 32;
+  int on = (int)((long long)n_cu * percent / 100);
+  if (on < 8) on = 8;
+  std::vector<uint32_t> mask((size_t)words, 0u);
+  for (int i = 0; i < on && i < n_cu; ++i) mask[(size_t)i >> 5] |= 1u << (i & 31);
+  hipStream_t st = nullptr;
+  GCL_CHECK_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask.data()));
+  (void)low_priority;      // hipExtStreamCreateWithCUMask has no priority argument
+  *stream_out = (void*)st;
+  return GCL_OK;
+}
+
+int gcl_stream_destroy(void* stream) {
+  if (stream) GCL_CHECK_HIP(hipStreamDestroy((hipStream_t)stream));
   return GCL_OK;
 }
 

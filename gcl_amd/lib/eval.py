@@ -17,18 +17,33 @@ def find_nn_gpu(F0, F1, nn_max_n=-1, return_distance=False, dist_type="SquareL2"
     return inds
 
 
+class DeferredCorr:
+    """``find_corr`` with the host half postponed: the random draws are made and the feature 1-NN is ENQUEUED when the
+    object is built (same numpy call order as scripts/test_kitti.py:29-43), the nearest-neighbour indices stay on the
+    device until ``resolve()`` -- so a loop over pairs need not stop the GPU once per pair to read 5000 indices it only
+    needs for the optional distance statistics (scripts/test_kitti.py:155)."""
+
+    def __init__(self, xyz0, xyz1, F0, F1, subsample_size=-1, nn_max_n=500):
+        self.xyz0, self.xyz1 = xyz0, xyz1
+        self.subsampled = subsample_size > 0 and len(F0) > subsample_size
+        if self.subsampled:
+            N0, N1 = min(len(F0), subsample_size), min(len(F1), subsample_size)
+            self.inds0 = np.random.choice(len(F0), N0, replace=False)
+            self.inds1 = np.random.choice(len(F1), N1, replace=False)
+            F0, F1 = F0[torch.from_numpy(self.inds0).to(F0.device)], F1[torch.from_numpy(self.inds1).to(F1.device)]
+        _, arg = pdist_min(F0, F1, "SquareL2")
+        self.nn_dev = arg              # int32 on the device; ties -> lowest index
+
+    def resolve(self):
+        nn_inds = self.nn_dev.long().cpu()
+        if self.subsampled:
+            return self.xyz0[self.inds0], self.xyz1[self.inds1[nn_inds.numpy()]]
+        return self.xyz0, self.xyz1[nn_inds]
+
+
 def find_corr(xyz0, xyz1, F0, F1, subsample_size=-1, nn_max_n=500):
     """scripts/test_kitti.py:29-43: random subsample (np.random.choice, same call order), kNN, matched points."""
-    subsample = len(F0) > subsample_size
-    if subsample_size > 0 and subsample:
-        N0, N1 = min(len(F0), subsample_size), min(len(F1), subsample_size)
-        inds0 = np.random.choice(len(F0), N0, replace=False)
-        inds1 = np.random.choice(len(F1), N1, replace=False)
-        F0, F1 = F0[torch.from_numpy(inds0).to(F0.device)], F1[torch.from_numpy(inds1).to(F1.device)]
-    nn_inds = find_nn_gpu(F0, F1, nn_max_n=nn_max_n)
-    if subsample_size > 0 and subsample:
-        return xyz0[inds0], xyz1[inds1[nn_inds.numpy()]]
-    return xyz0, xyz1[nn_inds]
+    return DeferredCorr(xyz0, xyz1, F0, F1, subsample_size, nn_max_n).resolve()
 
 
 def forward_pair(model, F0, C0, F1, C1):

@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 import gcl_amd.MinkowskiEngine as ME
-from gcl_amd.lib.eval import find_corr
+from gcl_amd.lib.eval import DeferredCorr
 
 
 class AverageMeter:
@@ -101,7 +101,31 @@ def eval_pairs(model, pairs, matcher, device=None, batch_pairs=1, subsample_size
     out = dict(T_est=[], rte=[], rre=[], success=[], dists_nn=[], n_voxels=0)
     t_feat = t_reg = 0.0
     pairs = list(pairs)
+
+    def finish(pending):
+        """Host half of a chunk whose device work was enqueued one chunk ago: ONE wait for its transformations (a pinned
+        copy behind an event), then the reference's per-pair bookkeeping (scripts/test_kitti.py:180-217)."""
+        chunk, corrs, T_host, ev = pending
+        ev.synchronize()
+        for j, d in enumerate(chunk):
+            T_est, T_gth = T_host[j].clone(), d["T_gt"]
+            if collect:
+                xyz0_corr, xyz1_corr = corrs[j].resolve()
+                out["dists_nn"].append(evaluate_nn_dist(xyz0_corr, xyz1_corr, T_gth))
+            rte, rre = rotation_translation_error(T_est, T_gth)
+            if rte < rte_thresh:
+                rte_meter.update(rte)
+            if not np.isnan(rre) and rre < np.pi / 180 * rre_thresh:
+                rre_meter.update(rre * 180 / np.pi)
+            ok = rte < rte_thresh and not np.isnan(rre) and rre < np.pi / 180 * rre_thresh
+            success_meter.update(1 if ok else 0)
+            out["T_est"].append(T_est)
+            out["rte"].append(rte)
+            out["rre"].append(rre)
+            out["success"].append(bool(ok))
+
     with torch.cuda.device(dev), torch.no_grad():
+        pending = None
         for b0 in range(0, len(pairs), max(1, batch_pairs)):
             chunk = pairs[b0:b0 + max(1, batch_pairs)]
             t0 = time.perf_counter()
@@ -112,32 +136,32 @@ def eval_pairs(model, pairs, matcher, device=None, batch_pairs=1, subsample_size
                                    d[f"sinput{k}_C"].to(dev, non_blocking=True)))
             feats = forward_clouds(model, clouds)
             t_feat += time.perf_counter() - t0
+            corrs, Ts = [], []
             for j, d in enumerate(chunk):
                 F0, F1 = feats[2 * j].detach(), feats[2 * j + 1].detach()
                 out["n_voxels"] += len(F0) + len(F1)
-                xyz0, xyz1, T_gth = d["pcd0"][0], d["pcd1"][0], d["T_gt"]
+                xyz0, xyz1 = d["pcd0"][0], d["pcd1"][0]
                 xyz0np, xyz1np = xyz0.numpy(), xyz1.numpy()
-                xyz0_corr, xyz1_corr = find_corr(xyz0, xyz1, F0, F1, subsample_size=subsample_size)
-                if collect:
-                    out["dists_nn"].append(evaluate_nn_dist(xyz0_corr, xyz1_corr, T_gth))
+                # draws + feature 1-NN now (the reference's order); its 5000 indices are read back only when ``collect``
+                corrs.append(DeferredCorr(xyz0, xyz1, F0, F1, subsample_size=subsample_size))
                 xyz0s, F0s = random_sample(xyz0np, F0, n_points)
                 xyz1s, F1s = random_sample(xyz1np, F1, n_points)
                 t0 = time.perf_counter()
                 x0, x1 = torch.from_numpy(xyz0s).to(dev), torch.from_numpy(xyz1s).to(dev)
                 T_est, _, _, _ = matcher.estimator(x0[None], x1[None], F0s[None], F1s[None])
-                T_est = T_est[0].to("cpu")                      # the reference reads T on the host here (:180)
+                Ts.append(T_est[0])
                 t_reg += time.perf_counter() - t0
-                rte, rre = rotation_translation_error(T_est, T_gth)
-                if rte < rte_thresh:
-                    rte_meter.update(rte)
-                if not np.isnan(rre) and rre < np.pi / 180 * rre_thresh:
-                    rre_meter.update(rre * 180 / np.pi)
-                ok = rte < rte_thresh and not np.isnan(rre) and rre < np.pi / 180 * rre_thresh
-                success_meter.update(1 if ok else 0)
-                out["T_est"].append(T_est)
-                out["rte"].append(rte)
-                out["rre"].append(rre)
-                out["success"].append(bool(ok))
+            # the reference reads T on the host after every pair (:180); here the chunk's transformations leave the device
+            # in ONE copy, and the host half of a chunk runs while the next chunk's kernels execute
+            T_host = torch.empty((len(chunk), 4, 4), dtype=torch.float32, pin_memory=True)
+            T_host.copy_(torch.stack(Ts), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            if pending is not None:
+                finish(pending)
+            pending = (chunk, corrs, T_host, ev)
+        if pending is not None:
+            finish(pending)
     out.update(rte_avg=rte_meter.avg, rte_var=rte_meter.var, rre_avg=rre_meter.avg, rre_var=rre_meter.var,
                success_rate=success_meter.avg, n_pairs=success_meter.count, feat_time=t_feat, reg_time=t_reg)
     return out

@@ -190,9 +190,10 @@ int gcl_table_sort_pre(const int32_t* tbl, int32_t K, int64_t n, int32_t window,
  *   wave tile visits only the offsets of tile_mask; with NULLs, row(j) = j and every offset is visited.
  *   Output-stationary (no atomics, deterministic).  The same entry computes the input gradient when given
  *   the opposite table and mode-1/2 weights.  K <= 27.
- *   stats (optional, split precisions): float[2][cout][ceil(n_out/128)] (channel-major) -- column sums of y and y^2
- *   per 128-row workgroup tile (its four waves added in order), consumed by gcl_bn_stats_from_tiles (the BatchNorm
- *   that follows then needs no statistics pass over y; n_tiles = ceil(n_out/128), its `scratch` is unused). */
+ *   stats (optional, split precisions): float[4][cout][ceil(n_out/128)] (channel-major) -- column sums of y and y^2,
+ *   column minimum and maximum per 128-row workgroup tile (its four waves combined in order), consumed by
+ *   gcl_bn_stats_from_tiles(_range) (the BatchNorm that follows then needs no statistics pass over y; n_tiles =
+ *   ceil(n_out/128), its `scratch` is unused). */
 int64_t gcl_pack_weights_bytes(int32_t K, int32_t cin, int32_t cout, int32_t prec);
 /* max |x| of a tensor in an "amax slot": GCL_AMAX_WORDS device int32, 16 entries on separate 128-byte lines (entry i
  * at word 32 i), value = max over the entries, each the bit pattern of a non-negative float.  (Workgroups publish to
@@ -279,6 +280,14 @@ int gcl_conv_bwd_weight(const float* a, int64_t n_a, const float* b, int64_t n_b
                         const int32_t* pair_a, const int32_t* pair_b, const int64_t* seg_off_host, int32_t K,
                         int32_t ca, int32_t cb, int32_t prec, const int32_t* a_amax, const int32_t* b_amax, float* scratch, float* dw,
                         void* stream);
+/* kernel_size-1 convolutions (conv1_tr, final: model/resunet.py:153-171; ME binds them to the same GEMM path with an
+ * identity kernel map): dW[ca][cb] = sum over ALL n_rows rows of a[i][:]^T b[i][:] -- pair (i, i) for every row, so no pair
+ * list is read and nothing is gathered: both operands are streamed once (k_bwd_weight_rows, fp16x3 split on the fly,
+ * per-workgroup slabs summed in a fixed order: deterministic).  gcl_conv_bwd_weight_rows_scratch_len returns the scratch
+ * floats, or 0 when the shape / arithmetic is not taken (then use gcl_conv_bwd_weight with identity pairs). */
+int64_t gcl_conv_bwd_weight_rows_scratch_len(int32_t ca, int32_t cb, int32_t prec, int64_t n_rows);
+int gcl_conv_bwd_weight_rows(const float* a, const float* b, int64_t n_rows, int32_t ca, int32_t cb, int32_t prec,
+                             const int32_t* a_amax, const int32_t* b_amax, float* scratch, float* dw, void* stream);
 /* The range-grouped mode's cell limits (first position of every (offset, row range) cell in the sorted pair list) depend
  * on the map alone: gcl_conv_bwd_weight_bounds makes them once (int32[gcl_conv_bwd_weight_bounds_len(K, rows of the sorted
  * side)], 0 = the mode does not apply), gcl_conv_bwd_weight_rg takes them (`rg_bounds`, NULL = computed per launch as
@@ -365,6 +374,37 @@ int gcl_bn_bwd_apply(const float* x, const float* dy, const float* y, const uint
 int gcl_bn_bwd_apply_ld(const float* x, const float* dy, int32_t dy_ld, const float* y, const uint64_t* relu_mask, int64_t n,
                         int32_t c, const float* mean, const float* rstd, const float* weight, const float* sum_g,
                         const float* sum_gx, int32_t relu, float* dx, float* dres, int32_t* dx_amax, void* stream);
+
+/* Round 5: plane images from the producer.  A tensor at least 128 channels wide is consumed by the fp16x3 convolutions as a
+ * plane image (gcl_split_planes); the BatchNorm passes that write such a tensor write the image in the same pass, which
+ * needs the tensor's power-of-two scale BEFORE the pass -- i.e. max|tensor| bounded from what is known by then:
+ *   forward   gcl_bn_stats_from_tiles_range: the convolution epilogue's partials carry per-column minimum / maximum
+ *             (float[4][c][n_tiles]: sum, squares, min, max); y = (x - mean) rstd w + b is monotone in x, so max|y| of a
+ *             channel is attained at its minimum or maximum of x: EXACT without residual; + max|residual| (add_amax: its
+ *             slot) with one; max'ed with `max_with` (the slot of the other input of an ME.cat written in place).  The
+ *             bound goes to the zeroed slot y_amax, the channel ranges to xrange[2][c] (kept for the backward pass).
+ *             gcl_bn_apply_planes: as gcl_bn_apply_ld; with planes != NULL it also writes the image (row pitch = y's) at
+ *             the scale of y_amax's value and publishes nothing.
+ *   backward  gcl_bn_bwd_reduce_range: k_bn_reduce also keeps max|g| per channel; with it, xrange and the sums,
+ *             |dx| <= |w rstd| (max|g| + |sum_g| / n + max|xhat| |sum_gx| / n) goes to the zeroed slot dx_amax;
+ *             gcl_bn_bwd_apply_planes writes dx's image at that scale.
+ * A bound above the true maximum costs range at the bottom of the lo plane (which the range-extended format has to spare),
+ * never correctness; consumers derive their scale from the same slot. */
+int gcl_bn_stats_from_tiles_range(const float* partial, int64_t n_tiles, int64_t n, int32_t c, float eps, float momentum,
+                                  float* running_mean, float* running_var, float* mean, float* rstd, float* xrange,
+                                  const float* weight, const float* bias, int32_t relu, const int32_t* add_amax,
+                                  const int32_t* max_with, int32_t* y_amax, void* stream);
+int gcl_bn_apply_planes(const float* x, int64_t n, int32_t c, const float* mean, const float* rstd, const float* weight,
+                        const float* bias, const float* residual, int32_t relu, float* y, int32_t y_ld, uint64_t* relu_mask,
+                        int32_t* y_amax, void* planes, void* stream);
+int gcl_bn_bwd_reduce_range(const float* x, const float* dy, int32_t dy_ld, const float* y, const uint64_t* relu_mask,
+                            int64_t n, int32_t c, const float* mean, const float* rstd, int32_t relu, double* scratch,
+                            float* sum_g, float* sum_gx, const float* xrange, const float* weight, int32_t* dx_amax,
+                            void* stream);
+int gcl_bn_bwd_apply_planes(const float* x, const float* dy, int32_t dy_ld, const float* y, const uint64_t* relu_mask, int64_t n,
+                            int32_t c, const float* mean, const float* rstd, const float* weight, const float* sum_g,
+                            const float* sum_gx, int32_t relu, float* dx, float* dres, int32_t* dx_amax, void* planes,
+                            void* stream);
 
 /* Row-wise L2 normalisation of the output features, y = x / ||x||_2 (model/resunet.py:226-230; no epsilon, as there).
  * norm[n] keeps the row norms for the backward pass: dx = (dy - y (y . dy)) / norm.  c: power of two in [4, 256].
@@ -608,6 +648,10 @@ int gcl_plan_release(void* plan, void* arena);
  * operands by events, while `stream` continues with the input-gradient chain; every gcl_plan_backward call ends with
  * `stream` waiting for them.  NULL (default) = everything on one stream.  Results do not depend on it. */
 int gcl_plan_set_aux_stream(void* plan, void* stream);
+/* a stream whose kernels run on the lowest `percent` % of the device's CUs (hipExtStreamCreateWithCUMask) -- measurement hook
+ * for the weight-gradient stream (GCL_AUX_CU_PCT); gcl_stream_destroy frees it */
+int gcl_stream_create_cu_share(int32_t percent, int32_t low_priority, void** stream_out);
+int gcl_stream_destroy(void* stream);
 /* Per-launch timing of the convolution launches of the NEXT forward + backward pass (events on `stream`):
  * gcl_plan_profile(plan, 1) arms it; after the stream has been synchronised gcl_plan_profile_read copies up to
  * max_records records of 8 doubles {kind (0 fwd/dx, 1 dW), ms, pairs, cin, cout, n_in, n_out, K | flags} and returns

@@ -476,12 +476,15 @@ def test_full_size_batch_against_oracle_fixture():
     assert rel_l2(m.block4.norm2.bn.running_var.cpu(), z["running_var_block4"]) < 1e-4
 
 
-# Bounds of the full-size gradient test = 2 x the larger of the two arithmetics' measured worst (norm error, sampled-entry
-# error), per parameter class; the measured values of the last GPU run are in $GCL_PRECISION_LOG / profiles/r05_precision_errors.log
-FULL_BWD_BOUNDS = {"kernel": (2e-3, 8e-3), "bn": (1e-2, 4e-2)}
+# Bounds of the full-size gradient test = 2 x the larger of the two default arithmetics' measured worst (norm error,
+# sampled-entry error) per parameter class -- profiles/r05_precision_errors_full_bs4.log: kernels 1.8e-5 / 1.5e-3 (exact f32;
+# fp16x3 1.8e-5 / 1.1e-3), BatchNorm parameters 2.3e-4 / 2.0e-3 (fp16x3; f32 1.4e-4 / 1.0e-3).  bf16x6 (GCL_FULL_BWD_PRECISIONS)
+# measured 2.7e-5 / 5.0e-3 and 2.0e-4 / 2.4e-3 and needs the wider pair.
+FULL_BWD_BOUNDS = {"kernel": (4e-5, 3e-3), "bn": (5e-4, 4e-3)}
+FULL_BWD_BOUNDS_BF16 = {"kernel": (6e-5, 1e-2), "bn": (5e-4, 5e-3)}
 
 
-@pytest.mark.parametrize("precision", ["fp16x3", "f32"])
+@pytest.mark.parametrize("precision", os.environ.get("GCL_FULL_BWD_PRECISIONS", "fp16x3,f32").split(","))
 def test_full_size_training_step_gradients_against_oracle_fixture(precision):
     """tests/golden/full_bs4_backward.npz (make_full_fixture.py --backward: ONE fp64 oracle training step on the 530 321-voxel
     benchmark batch -- loss = pos + finest + neg, lib/colocation_trainer.py:875-887): the gradients the trainer's
@@ -540,7 +543,7 @@ def test_full_size_training_step_gradients_against_oracle_fixture(precision):
     top = sorted(worst.items(), key=lambda kv: -max(kv[1]))[:5]
     print(f"full-size backward [{precision}]: worst parameters (norm err, sampled-entry err):", top)
     for name, (e_norm, e_val) in worst.items():
-        b_norm, b_val = FULL_BWD_BOUNDS["bn" if ".bn." in name else "kernel"]
+        b_norm, b_val = (FULL_BWD_BOUNDS_BF16 if precision.startswith("bf16") else FULL_BWD_BOUNDS)["bn" if ".bn." in name else "kernel"]
         assert e_norm < b_norm and e_val < b_val, (precision, name, e_norm, e_val, f"all parameters: {log}")
 
 

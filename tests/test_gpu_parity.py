@@ -382,7 +382,7 @@ def test_lds_dma_forward_kernel_is_bitwise_the_register_staged_kernel(cin, cout,
         for flags in (8, 2):
             for fused in (False, True):
                 y = torch.full((n_out, cout), float("nan"), device=DEV)
-                stats = torch.full((2, cout, (n_out + 127) // 128), float("nan"), device=DEV)
+                stats = torch.full((4, cout, (n_out + 127) // 128), float("nan"), device=DEV)
                 slot = ME.ops.amax_slot(x.device)
                 _lib.check(lib.gcl_conv_fwd_fused(_lib.ptr(planes if use_planes else x), n_out, int(use_planes), _lib.ptr(wp), 4,
                                                   _lib.ptr(xa), _lib.ptr(wa),
@@ -479,7 +479,7 @@ def test_lds_dma_forward_kernel_race_screen(cin, cout, use_planes):
 
         def run(flags):
             y = torch.full((n_out, cout), float("nan"), device=DEV)
-            stats = torch.full((2, cout, (n_out + 127) // 128), float("nan"), device=DEV)
+            stats = torch.full((4, cout, (n_out + 127) // 128), float("nan"), device=DEV)
             _lib.check(lib.gcl_conv_fwd(_lib.ptr(xin), n_out, int(use_planes), _lib.ptr(wp), 4, _lib.ptr(xa), _lib.ptr(wa),
                                         _lib.ptr(tbl), _lib.ptr(order), _lib.ptr(mask), n_out, K, cin, cout, None, _lib.ptr(y),
                                         _lib.ptr(stats), flags, _lib.stream()), "gcl_conv_fwd")
@@ -529,6 +529,46 @@ def test_weight_gradient_range_grouped_mode(cin, cout, stride, transpose):
         grads.append(conv.kernel.grad.clone())
     assert torch.equal(grads[0], grads[1]), "deterministic"
     assert rel_l2(grads[0].cpu(), W.grad) < 2e-6
+
+
+@pytest.mark.parametrize("ca,cb,n", [(96, 64, 70001), (64, 32, 70001), (96, 64, 1), (64, 32, 15), (32, 32, 16), (128, 32, 4099),
+                                     (64, 64, 263), (96, 32, 8193), (32, 64, 530321)])
+def test_weight_gradient_row_stream_kernel_size_1(ca, cb, n):
+    """gcl_conv_bwd_weight_rows (kernel_size-1 convolutions -- conv1_tr 96 -> 64, final 64 -> 32, model/resunet.py:153-171:
+    dW = x^T dy over ALL rows, both operands streamed once, no pair list): against the fp64 product at the per-operator
+    bound, equal to the pair-list kernel on identity pairs to rounding, bitwise reproducible; single rows, row counts that
+    are no multiple of the 16-row step, more workgroups than full steps, and the benchmark's row count."""
+    from gcl_amd import _lib
+    import gcl_amd.MinkowskiEngine as ME
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(n + ca)
+    with torch.cuda.device(DEV):
+        a = torch.randn(n, ca, generator=g).to(DEV)
+        b = (torch.randn(n, cb, generator=g) * 3e-3).to(DEV)          # gradients are small: a second scale
+        aa, ba = ME.ops.amax_slot(a.device), ME.ops.amax_slot(a.device)
+        _lib.check(lib.gcl_amax(_lib.ptr(a), a.numel(), _lib.ptr(aa), 1, _lib.stream()), "gcl_amax")
+        _lib.check(lib.gcl_amax(_lib.ptr(b), b.numel(), _lib.ptr(ba), 1, _lib.stream()), "gcl_amax")
+        ln = lib.gcl_conv_bwd_weight_rows_scratch_len(ca, cb, 4, n)
+        assert ln > 0 and lib.gcl_conv_bwd_weight_rows_scratch_len(ca, cb, 0, n) == 0      # exact-f32: the pair-list path
+        assert lib.gcl_conv_bwd_weight_rows_scratch_len(160, 64, 4, n) == 0                  # shapes the stream does not take
+        outs = []
+        for _ in range(2):
+            scratch = torch.full((ln,), float("nan"), device=DEV)
+            dw = torch.full((ca, cb), float("nan"), device=DEV)
+            _lib.check(lib.gcl_conv_bwd_weight_rows(_lib.ptr(a), _lib.ptr(b), n, ca, cb, 4, _lib.ptr(aa), _lib.ptr(ba),
+                                                    _lib.ptr(scratch), _lib.ptr(dw), _lib.stream()), "gcl_conv_bwd_weight_rows")
+            outs.append(dw)
+        assert torch.equal(outs[0], outs[1]), "deterministic"
+        ref = a.double().T @ b.double()
+        assert rel_l2(outs[0].double().cpu(), ref.cpu()) < 2e-6
+        # the pair-list kernel on identity pairs (what kernel_size-1 convolutions ran until round 4)
+        pa, pb, seg, seg_host = ME.CoordinateManager(torch.zeros((1, 4), dtype=torch.int32, device=DEV)).identity_pairs(n)
+        scratch = torch.empty(lib.gcl_conv_bwd_weight_scratch_len(1, ca, cb, seg[-1], 0), device=DEV)
+        dw2 = torch.empty((ca, cb), device=DEV)
+        _lib.check(lib.gcl_conv_bwd_weight(_lib.ptr(a), n, _lib.ptr(b), n, 0, 0, _lib.ptr(pa), _lib.ptr(pb), seg_host, 1, ca, cb,
+                                           4, _lib.ptr(aa), _lib.ptr(ba), _lib.ptr(scratch), _lib.ptr(dw2), _lib.stream()),
+                   "gcl_conv_bwd_weight")
+        assert rel_l2(outs[0].double().cpu(), dw2.double().cpu()) < 2e-6
 
 
 @pytest.mark.parametrize("ca,cb,n,stride", [(128, 128, 3000, 1), (256, 128, 1500, 1), (128, 256, 40, 1), (256, 256, 700, 2),
@@ -616,6 +656,106 @@ def test_batch_norm_vs_torch(c, n, res, relu, training):
         assert rel_l2(rg.grad.cpu(), ro.grad) < 2e-6
     if training and n > 1:
         assert rel_l2(rmg.cpu(), rmo) < 1e-6 and rel_l2(rvg.cpu(), rvo) < 1e-6
+
+
+@pytest.mark.parametrize("c,n,res,relu,ld", [(128, 3000, False, False, 0), (128, 70001, True, True, 0), (256, 777, False, True, 0),
+                                             (128, 5000, True, True, 256), (256, 129, True, False, 0)])
+def test_batch_norm_plane_images_from_the_producer(c, n, res, relu, ld):
+    """Bound mode (round 5, gcl_bn_stats_from_tiles_range / gcl_bn_apply_planes / gcl_bn_bwd_reduce_range /
+    gcl_bn_bwd_apply_planes): from the convolution epilogue's column ranges the statistics launch bounds max|y| BEFORE the
+    apply pass -- exactly the measured maximum without a residual, an upper bound (< 2 x + max|residual|) with one -- and
+    the apply passes write the plane image themselves: bit for bit what gcl_split_planes makes of the same tensor at the
+    same slot; y, mask, dx, dres unchanged by it.  ``ld``: the image of an ME.cat written in place (row pitch ld)."""
+    from gcl_amd import _lib
+    import gcl_amd.MinkowskiEngine as ME
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(c + n)
+    x = (torch.randn(n, c, generator=g) * torch.rand(c, generator=g) * 3 + torch.randn(c, generator=g)).to(DEV)
+    w, b = (torch.rand(c, generator=g) - 0.3).to(DEV), torch.randn(c, generator=g).to(DEV)      # some negative weights
+    r = (torch.randn(n, c, generator=g) * 2).to(DEV) if res else None
+    gy = (torch.randn(n, c, generator=g) * torch.rand(c, generator=g) * 1e-3).to(DEV)
+    nt = (n + 127) // 128
+    with torch.cuda.device(DEV):
+        # the epilogue's partials, made here: per 128-row tile column sum, sum of squares, minimum, maximum
+        pad = nt * 128 - n
+        xp = torch.cat([x, torch.zeros(pad, c, device=DEV)]).view(nt, 128, c)
+        big = torch.full((pad, c), 3.0e38, device=DEV)
+        xmin = torch.cat([x, big]).view(nt, 128, c).amin(1)
+        xmax = torch.cat([x, -big]).view(nt, 128, c).amax(1)
+        part = torch.stack([xp.sum(1), (xp * xp).sum(1), xmin, xmax]).permute(0, 2, 1).contiguous()      # [4][c][nt]
+        mean, rstd = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+        xrange = torch.empty((2, c), device=DEV)
+        slot, rslot = ME.ops.amax_slot(x.device), ME.ops.amax_slot(x.device)
+        if res:
+            _lib.check(lib.gcl_amax(_lib.ptr(r), r.numel(), _lib.ptr(rslot), 1, _lib.stream()), "gcl_amax")
+        _lib.check(lib.gcl_bn_stats_from_tiles_range(_lib.ptr(part), nt, n, c, 1e-5, 0.05, None, None, _lib.ptr(mean), _lib.ptr(rstd),
+                                                     _lib.ptr(xrange), _lib.ptr(w), _lib.ptr(b), int(relu),
+                                                     _lib.ptr(rslot) if res else None, None, _lib.ptr(slot), _lib.stream()),
+                   "gcl_bn_stats_from_tiles_range")
+        assert torch.equal(xrange[0], x.amin(0)) and torch.equal(xrange[1], x.amax(0))
+        bound = float(ME.ops.amax_value(slot))
+        width = ld if ld else c
+        outs = []
+        for with_planes in (False, True):
+            y = torch.full((n, width), 7.0, device=DEV)
+            mask = torch.zeros(lib.gcl_bn_mask_len(n, c), dtype=torch.int64, device=DEV)
+            s2 = slot.clone() if with_planes else ME.ops.amax_slot(x.device)
+            img = torch.full((n, width), 0x7B7B7B7B, dtype=torch.int32, device=DEV) if with_planes else None
+            _lib.check(lib.gcl_bn_apply_planes(_lib.ptr(x), n, c, _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(w), _lib.ptr(b),
+                                               _lib.ptr(r), int(relu), _lib.ptr(y), ld, _lib.ptr(mask) if relu else None,
+                                               _lib.ptr(s2), _lib.ptr(img), _lib.stream()), "gcl_bn_apply_planes")
+            outs.append((y, mask, s2, img))
+        (y0, m0, s0, _), (y1, m1, s1, img) = outs
+        assert torch.equal(y0, y1) and torch.equal(m0, m1) and torch.equal(s1, slot), "the image changes nothing else"
+        measured = float(y0[:, :c].abs().max())
+        assert float(ME.ops.amax_value(s0)) == measured
+        if res:
+            assert measured <= bound <= 2.0 * measured + float(r.abs().max())
+        else:
+            assert bound == measured, "exact without a residual: max|y| is attained at a channel's extreme x"
+        # the image == gcl_split_planes of y at the same slot (columns beyond c of a wider image are not touched)
+        ref = torch.full((n, width), 0x7B7B7B7B, dtype=torch.int32, device=DEV)
+        if ld:
+            full = y1.clone()
+            full[:, c:] = 0.0
+            _lib.check(lib.gcl_split_planes(_lib.ptr(full), n, width, _lib.ptr(slot), _lib.ptr(ref), _lib.stream()), "split")
+            sl = c // 32 * 32           # 32-column slices written by the pass: compare those
+            assert torch.equal(img.view(n, width // 32, 32)[:, :c // 32], ref.view(n, width // 32, 32)[:, :c // 32])
+            assert bool((img.view(n, width // 32, 32)[:, c // 32:] == 0x7B7B7B7B).all())
+        else:
+            _lib.check(lib.gcl_split_planes(_lib.ptr(y1), n, c, _lib.ptr(slot), _lib.ptr(ref), _lib.stream()), "split")
+            assert torch.equal(img, ref)
+        # backward: bound of max|dx| from the reduce launch, image from the apply pass
+        sums = torch.empty((2, c), device=DEV)
+        scratch = torch.empty(lib.gcl_bn_scratch_len(n, c), dtype=torch.float64, device=DEV)
+        dslot = ME.ops.amax_slot(x.device)
+        _lib.check(lib.gcl_bn_bwd_reduce_range(_lib.ptr(x), _lib.ptr(gy), 0, None, _lib.ptr(m0) if relu else None, n, c,
+                                               _lib.ptr(mean), _lib.ptr(rstd), int(relu), _lib.ptr(scratch), _lib.ptr(sums[0]),
+                                               _lib.ptr(sums[1]), _lib.ptr(xrange), _lib.ptr(w), _lib.ptr(dslot), _lib.stream()),
+                   "gcl_bn_bwd_reduce_range")
+        sums0 = torch.empty((2, c), device=DEV)
+        _lib.check(lib.gcl_bn_bwd_reduce(_lib.ptr(x), _lib.ptr(gy), None, _lib.ptr(m0) if relu else None, n, c, _lib.ptr(mean),
+                                         _lib.ptr(rstd), int(relu), _lib.ptr(scratch), _lib.ptr(sums0[0]), _lib.ptr(sums0[1]),
+                                         _lib.stream()), "gcl_bn_bwd_reduce")
+        assert torch.equal(sums, sums0)
+        bouts = []
+        for with_planes in (False, True):
+            dx, dres = torch.empty_like(x), (torch.empty_like(x) if res else None)
+            s2 = dslot.clone() if with_planes else ME.ops.amax_slot(x.device)
+            img = torch.empty((n, c), dtype=torch.int32, device=DEV) if with_planes else None
+            _lib.check(lib.gcl_bn_bwd_apply_planes(_lib.ptr(x), _lib.ptr(gy), 0, None, _lib.ptr(m0) if relu else None, n, c,
+                                                   _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(w), _lib.ptr(sums[0]),
+                                                   _lib.ptr(sums[1]), int(relu), _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(s2),
+                                                   _lib.ptr(img), _lib.stream()), "gcl_bn_bwd_apply_planes")
+            bouts.append((dx, dres, s2, img))
+        (dx0, dr0, t0, _), (dx1, dr1, t1, dimg) = bouts
+        assert torch.equal(dx0, dx1) and (not res or torch.equal(dr0, dr1)) and torch.equal(t1, dslot)
+        dmeasured, dbound = float(dx0.abs().max()), float(ME.ops.amax_value(dslot))
+        assert float(ME.ops.amax_value(t0)) == dmeasured
+        assert dmeasured <= dbound <= 4.0 * dmeasured, (dmeasured, dbound)
+        dref = torch.empty((n, c), dtype=torch.int32, device=DEV)
+        _lib.check(lib.gcl_split_planes(_lib.ptr(dx1), n, c, _lib.ptr(dslot), _lib.ptr(dref), _lib.stream()), "split")
+        assert torch.equal(dimg, dref)
 
 
 @pytest.mark.parametrize("c,n,ld,relu", [(64, 1000, 96, True), (32, 257, 160, False), (128, 70000, 256, True)])

@@ -43,7 +43,7 @@ with torch.cuda.device(dev):
             hot = int(os.environ["LB_HOT_ROWS"])   # instruction stream, no fabric traffic for the A operand
             tbl = torch.where(tbl >= 0, tbl % hot, tbl).contiguous()
         y = {f: torch.empty((n_out, cout), device=dev) for f in (8, 2)}
-        stats = torch.empty(((n_out + 127) // 128, 2, cout), device=dev)
+        stats = torch.empty((4, cout, (n_out + 127) // 128), device=dev)
 
         def run(flags):
             _lib.check(lib.gcl_conv_fwd(_lib.ptr(planes if pre else x), n_in, pre, _lib.ptr(wp), 4, _lib.ptr(xa), _lib.ptr(wa), _lib.ptr(tbl),

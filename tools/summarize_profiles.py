@@ -74,6 +74,13 @@ for n in fe:
             # MFMA pipe busy share: busy cycles per dispatch and SIMD (1024 SIMDs) over the launch duration at 2.4 GHz
             per = sum(sq[n]["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(sq[n]["SQ_VALU_MFMA_BUSY_CYCLES"]) / 1024.0
             out[n]["mfma_busy"] = round(per / (avg_ns * 2.4), 4)
+# stamp: the kernel sources the counters were collected on (tools/collect_profiles.sh writes it ON the GPU box, from the
+# snapshot that ran); bench.py quotes traffic / mfma_busy only when its own sources have the same hash
+stamp = os.path.join(G, "csrc_sha16.txt")
+sys.path.insert(0, ROOT)
+from gcl_amd import _lib  # noqa: E402
+out["_csrc_sha16"] = open(stamp).read().strip() if os.path.exists(stamp) else _lib.source_hash()
+out["_tag"] = tag
 json.dump(out, open(os.path.join(P, "pmc_summary.json"), "w"), indent=1)
 print(open(os.path.join(P, f"{tag}_kernel_stats_summary.txt")).read())
 print(open(os.path.join(P, f"{tag}_pmc_sq.txt")).read()[:2500])
