@@ -124,7 +124,9 @@ __device__ __forceinline__ float amax_scale(const int* __restrict__ amax_bits) {
 constexpr float F16_LO_UP = 2048.f, F16_LO_DOWN = 1.f / 2048.f;
 __device__ __forceinline__ void split_f16(float sv, _Float16& hi, _Float16& lo) {
   hi = (_Float16)sv;
-  lo = (_Float16)((sv - (float)hi) * F16_LO_UP);
+  // (sv - hi) 2^11, exactly (the difference of a value and its fp16 rounding is exact in fp32, so is every scaling by 2^11):
+  // written as one fused multiply-add with the fp16 value as a source (v_fma_mix_f32: no conversion back to fp32)
+  lo = (_Float16)__builtin_fmaf((float)hi, -F16_LO_UP, sv * F16_LO_UP);
 }
 
 

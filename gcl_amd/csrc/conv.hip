@@ -239,16 +239,27 @@ template <int PL>
 __device__ __forceinline__ void split8(const float4& f0, const float4& f1, float scale, u32x4* pl) {
   float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
   if (PL == 4) {
-    f16x8 hi, lo;
+    // two elements at a time: sv = v s and t = v (2^11 s) are both exact (s is a power of two); hi = fp16(sv) packed;
+    // lo' = fp16(t - 2^11 hi) with the fp16 value as a source of ONE mixed-precision FMA (v_fma_mix_f32: no conversion of
+    // hi back to fp32) -- six instructions per pair of elements, what the un-scaled lo plane of rounds 1 - 4 cost (the
+    // compiler's own packed form needs seven).  Same values as split_f16.
+    typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+    const float scale_up = scale * F16_LO_UP, neg_up = -F16_LO_UP;
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    unsigned hw[4], lw[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      _Float16 hh, ll;
-      split_f16(v[j] * scale, hh, ll);
-      hi[j] = hh;
-      lo[j] = ll;
+    for (int j = 0; j < 4; ++j) {
+      const f32x2_ vv = {v[2 * j], v[2 * j + 1]};
+      const f32x2_ sv = vv * scale, tv = vv * scale_up;               // packed multiplies
+      const f16x2_ h2 = __builtin_convertvector(sv, f16x2_);           // one packed conversion
+      hw[j] = __builtin_bit_cast(unsigned, h2);
+      f32x2_ r;
+      asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r[0]) : "v"(hw[j]), "s"(neg_up), "v"(tv[0]));
+      asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r[1]) : "v"(hw[j]), "s"(neg_up), "v"(tv[1]));
+      lw[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2_));
     }
-    pl[0] = __builtin_bit_cast(u32x4, hi);
-    pl[1] = __builtin_bit_cast(u32x4, lo);
+    pl[0] = u32x4{hw[0], hw[1], hw[2], hw[3]};
+    pl[1] = u32x4{lw[0], lw[1], lw[2], lw[3]};
   } else {
     bf16x8 p0, p1, p2;
 #pragma unroll
@@ -1142,15 +1153,14 @@ __global__ void __launch_bounds__(1024, 1) k_conv_fwd_tall(const float* __restri
   for (int k = 0; k < K; ++k)
     if ((k & 3) == g) gsel |= 1u << k;
 
-  f32x16 acc[NB], accx[(PL == 4) ? NB : 1];      // accx: the fp16x3 cross terms (mfma_terms)
+  // ONE accumulator set (1024 threads per workgroup leave 128 registers per wave): both operands of an inference launch
+  // are narrow-range (activations, weights), so the activation planes are re-scaled on the fly as in the weight-gradient
+  // kernels (mfma_terms_dw) instead of summing the cross terms apart
+  f32x16 acc[NB];
 #pragma unroll
   for (int b = 0; b < NB; ++b)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
-#pragma unroll
-  for (int b = 0; b < (int)(sizeof(accx) / sizeof(accx[0])); ++b)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accx[b][r] = 0.f;
 
   unsigned tmask = 0u;
   if (active) tmask = tile_mask ? (unsigned)tile_mask[tile] : ((1u << K) - 1u);
@@ -1243,13 +1253,14 @@ __global__ void __launch_bounds__(1024, 1) k_conv_fwd_tall(const float* __restri
           float4 f0 = *reinterpret_cast<const float4*>(&Asm[w16][i][((4 * m + 2 * h) ^ a_swz(i)) << 2]);
           float4 f1 = *reinterpret_cast<const float4*>(&Asm[w16][i][((4 * m + 2 * h + 1) ^ a_swz(i)) << 2]);
           split8<PL>(f0, f1, a_scale, ap);
+          dw_a_planes(ap);
 #pragma unroll
           for (int b = 0; b < NB; ++b) {
             const u32x4* bb = &Bg[buf * BLK + ((b * 2 + m) * NPL) * 64 + l];
             u32x4 bp[3];
             bp[0] = bb[0];
             bp[1] = bb[64];
-            mfma_terms<PL>(ap, bp, acc[b], accx[(PL == 4) ? b : 0]);
+            mfma_terms_dw<PL>(ap, bp, acc[b]);
           }
         }
       }
@@ -1278,8 +1289,6 @@ __global__ void __launch_bounds__(1024, 1) k_conv_fwd_tall(const float* __restri
 #undef GCLT_LOAD_B
 #undef GCLT_STORE_LDS
 #undef GCLT_ADVANCE
-#pragma unroll
-  for (int b = 0; b < NB; ++b) fold_cross<PL>(acc[b], accx[(PL == 4) ? b : 0]);
   // partial accumulators of groups 1 - 3 through LDS (the loop's last barrier has passed: tiles and weight blocks are free)
   float* const red = lds;      // [g - 1][wt][b * 16 + r][64 lanes]
   if (g > 0) {

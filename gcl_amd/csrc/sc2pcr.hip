@@ -14,6 +14,8 @@
 
 #include <math.h>
 
+#include <algorithm>
+
 namespace gcl {
 
 constexpr int SC_TILE = 256;      // correspondences per LDS tile
@@ -53,6 +55,127 @@ __global__ void __launch_bounds__(SC_TILE) k_sc_matvec(const float* __restrict__
       const float cd = fabsf(dist3(si, P3{ts[q][0], ts[q][1], ts[q][2]}) - dist3(ti, P3{ts[q][3], ts[q][4], ts[q][5]}));
       acc += fmaxf(1.f - cd * cd / d2_thre, 0.f) * ts[q][6];
     }
+  }
+  if (ok) partial[(size_t)blockIdx.y * n + i] = acc;
+}
+
+// ---- the same matvec over the NON-ZERO entries of the compatibility matrix, kept from one build (round 5) ---------------------
+// The power iteration multiplies the same n x n matrix 20 times and k_sc_matvec re-derives every entry each time from six
+// coordinates and two correctly rounded square roots (64 M entries at n = 8000: 74 us per product, 1.5 ms per registration).
+// Most entries are zero -- a pair of correspondences is compatible only when its two lengths agree to d_thre.  Build once:
+// count[chunk][i] non-zeros of row i in column chunk `chunk` (same eight chunks), an exclusive scan, the entries (column,
+// value) in ascending column order.  A product then walks a row's entries of a chunk in that order: the same non-zero terms
+// in the same order as k_sc_matvec -- the skipped terms are exact zeros -- so partial[][] is BITWISE what k_sc_matvec writes.
+// When the entries do not fit `cap` the flag `overflow` makes the product fall back to the dense loop.
+struct ScEntry { int j; float m; };
+__device__ __forceinline__ float sc_first_order(const P3& si, const P3& ti, const float* ts_row, float d2_thre) {
+  const float cd = fabsf(dist3(si, P3{ts_row[0], ts_row[1], ts_row[2]}) - dist3(ti, P3{ts_row[3], ts_row[4], ts_row[5]}));
+  return fmaxf(1.f - cd * cd / d2_thre, 0.f);
+}
+// PASS 0: count, PASS 1: fill (offsets from the scan)
+template <int PASS>
+__global__ void __launch_bounds__(SC_TILE) k_sc_sparse_build(const float* __restrict__ src, const float* __restrict__ tgt, int n,
+                                                             float d2_thre, int* count, const int* __restrict__ offset,
+                                                             ScEntry* entries, long long cap, int* overflow) {
+  __shared__ float ts[SC_TILE][6];
+  const int i = blockIdx.x * SC_TILE + threadIdx.x;
+  const bool ok = i < n;
+  const P3 si = ok ? ld3(src, i) : P3{0, 0, 0}, ti = ok ? ld3(tgt, i) : P3{0, 0, 0};
+  const int per = (n + SC_CHUNKS - 1) / SC_CHUNKS;
+  const int j0 = blockIdx.y * per, j1 = min(n, j0 + per);
+  if (PASS == 1 && *overflow) return;      // uniform
+  long long pos = (PASS == 1 && ok) ? offset[(size_t)blockIdx.y * n + i] : 0;
+  const int room = (PASS == 1 && ok) ? count[(size_t)blockIdx.y * n + i] : 0;      // never write outside the own segment
+  int cnt = 0;
+  for (int jb = j0; jb < j1; jb += SC_TILE) {
+    __syncthreads();
+    const int j = jb + threadIdx.x;
+    if (j < j1) {
+      ts[threadIdx.x][0] = src[3 * j]; ts[threadIdx.x][1] = src[3 * j + 1]; ts[threadIdx.x][2] = src[3 * j + 2];
+      ts[threadIdx.x][3] = tgt[3 * j]; ts[threadIdx.x][4] = tgt[3 * j + 1]; ts[threadIdx.x][5] = tgt[3 * j + 2];
+    }
+    __syncthreads();
+    const int m = min(SC_TILE, j1 - jb);
+    for (int q = 0; q < m; ++q) {
+      float v = sc_first_order(si, ti, ts[q], d2_thre);
+      // The ROUNDED value decides, in both passes alike.  Without this barrier the compiler derives the predicate from
+      // intermediates (q < 1 instead of max(1 - q, 0) != 0) where the value itself is not needed, the two instantiations
+      // disagreed on borderline pairs (22 of 64000 segments at n = 8000), and a fill pass that finds one entry more than
+      // was counted writes into its neighbour's segment.
+      asm volatile("" : "+v"(v));
+      if (v != 0.f) {      // (a NaN entry counts as non-zero: it must reach the sum as it does in the dense loop)
+        if (PASS == 1 && cnt < room) entries[pos + cnt] = ScEntry{jb + q, v};
+        ++cnt;
+      }
+    }
+  }
+  if (PASS == 0 && ok) count[(size_t)blockIdx.y * n + i] = cnt;
+  if (PASS == 1) {      // (cannot happen with the barrier above; a short segment is padded with exact zeros all the same)
+    for (int q = cnt; q < room; ++q) entries[pos + q] = ScEntry{0, 0.f};
+  }
+}
+// exclusive scan of count[SC_CHUNKS * n] by ONE workgroup (<= 64 K values); total > cap sets the overflow flag
+__global__ void __launch_bounds__(1024) k_sc_sparse_scan(const int* __restrict__ count, int total_n, int* offset, long long cap,
+                                                         int* overflow) {
+  __shared__ long long part[1024];
+  const int per = (total_n + 1023) / 1024;
+  const int b = threadIdx.x * per, e = min(total_n, b + per);
+  long long s = 0;
+  for (int q = b; q < e; ++q) s += count[q];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    long long run = 0;
+    for (int t = 0; t < 1024; ++t) {
+      const long long v = part[t];
+      part[t] = run;
+      run += v;
+    }
+    *overflow = (run > cap || run > 0x7fffffffll) ? 1 : 0;
+  }
+  __syncthreads();
+  long long run = part[threadIdx.x];
+  for (int q = b; q < e; ++q) {
+    offset[q] = (int)run;
+    run += count[q];
+  }
+}
+__global__ void __launch_bounds__(SC_TILE) k_sc_matvec_sparse(const float* __restrict__ src, const float* __restrict__ tgt,
+                                                              int n, float d2_thre, const float* __restrict__ x,
+                                                              const int* __restrict__ done, float* partial,
+                                                              const int* __restrict__ count, const int* __restrict__ offset,
+                                                              const ScEntry* __restrict__ entries,
+                                                              const int* __restrict__ overflow) {
+  if (*done) return;
+  const int i = blockIdx.x * SC_TILE + threadIdx.x;
+  if (!*overflow) {
+    if (i >= n) return;
+    const size_t seg = (size_t)blockIdx.y * n + i;
+    const ScEntry* e = entries + offset[seg];
+    const int cnt = count[seg];
+    float acc = 0.f;
+    for (int q = 0; q < cnt; ++q) acc += e[q].m * x[e[q].j];
+    partial[seg] = acc;
+    return;
+  }
+  // the entries did not fit: the dense loop of k_sc_matvec
+  __shared__ float ts[SC_TILE][7];
+  const bool ok = i < n;
+  const P3 si = ok ? ld3(src, i) : P3{0, 0, 0}, ti = ok ? ld3(tgt, i) : P3{0, 0, 0};
+  const int per = (n + SC_CHUNKS - 1) / SC_CHUNKS;
+  const int j0 = blockIdx.y * per, j1 = min(n, j0 + per);
+  float acc = 0.f;
+  for (int jb = j0; jb < j1; jb += SC_TILE) {
+    __syncthreads();
+    const int j = jb + threadIdx.x;
+    if (j < j1) {
+      ts[threadIdx.x][0] = src[3 * j]; ts[threadIdx.x][1] = src[3 * j + 1]; ts[threadIdx.x][2] = src[3 * j + 2];
+      ts[threadIdx.x][3] = tgt[3 * j]; ts[threadIdx.x][4] = tgt[3 * j + 1]; ts[threadIdx.x][5] = tgt[3 * j + 2];
+      ts[threadIdx.x][6] = x[j];
+    }
+    __syncthreads();
+    const int m = min(SC_TILE, j1 - jb);
+    for (int q = 0; q < m; ++q) acc += sc_first_order(si, ti, ts[q], d2_thre) * ts[q][6];
   }
   if (ok) partial[(size_t)blockIdx.y * n + i] = acc;
 }
@@ -411,6 +534,90 @@ __global__ void k_sc_refine_solve(const double* __restrict__ partial, int* state
   kabsch_from_H(H, ca, cb, T);
 }
 
+// The whole refinement in ONE launch (round 5): a single 1024-thread workgroup runs the iterations and stops at convergence
+// (the two-kernel form launched 2 x 20 kernels per registration, 35 of them typically no-ops behind the `done` flag: 0.3 ms of
+// dependent launches per pair).  Same arithmetic in the same order: the RF_BLOCKS x 256 "virtual" threads of k_sc_refine_accum
+// own at most one point each for n <= 16384 (j = b 256 + t), their 17 terms are tree-reduced per 256-point block exactly as
+// there, the block sums are added in block order exactly as k_sc_refine_solve does -- T is bitwise the two-kernel result.
+__global__ void __launch_bounds__(1024) k_sc_refine_all(const float* __restrict__ src, const float* __restrict__ tgt, int n,
+                                                        float thr, int iterations, int* state, float* T) {
+  constexpr int RT = 6;                        // terms reduced per round (LDS: 6 x 1024 doubles)
+  __shared__ double red[RT][1024];
+  __shared__ double s[RF_TERMS];
+  __shared__ float Ts[12];
+  __shared__ int done, prev;
+  const int t = threadIdx.x;
+  if (t < 12) Ts[t] = T[t];
+  if (t == 0) { done = 0; prev = 0; }
+  __syncthreads();
+  for (int it = 0; it < iterations; ++it) {
+    if (t < RF_TERMS) s[t] = 0;
+    __syncthreads();
+    for (int g = 0; g < RF_BLOCKS / 4; ++g) {            // four 256-point blocks at a time, in block order
+      const int j = g * 1024 + t;
+      double term[RF_TERMS];
+      for (int k = 0; k < RF_TERMS; ++k) term[k] = 0;
+      if (j < n) {
+        const P3 p = ld3(src, j), q = ld3(tgt, j);
+        const float x = Ts[0] * p.x + Ts[1] * p.y + Ts[2] * p.z + Ts[3] - q.x;
+        const float y = Ts[4] * p.x + Ts[5] * p.y + Ts[6] * p.z + Ts[7] - q.y;
+        const float z = Ts[8] * p.x + Ts[9] * p.y + Ts[10] * p.z + Ts[11] - q.z;
+        const float d = sqrtf(x * x + y * y + z * z);
+        if (d < thr) {
+          const float r = d / thr;
+          const double w = 1.f / (1.f + r * r);
+          const double a[3] = {p.x, p.y, p.z}, b[3] = {q.x, q.y, q.z};
+          term[0] = w;
+          for (int c = 0; c < 3; ++c) { term[1 + c] = w * a[c]; term[4 + c] = w * b[c]; }
+          for (int i = 0; i < 3; ++i)
+            for (int k = 0; k < 3; ++k) term[7 + 3 * i + k] = w * a[i] * b[k];
+          term[16] = 1.0;
+        }
+      }
+      if (g * 1024 >= n) break;                          // uniform: the remaining blocks hold no point (their sums are +0)
+      for (int k0 = 0; k0 < RF_TERMS; k0 += RT) {
+#pragma unroll
+        for (int k = 0; k < RT; ++k) red[k][t] = (k0 + k < RF_TERMS) ? term[k0 + k] : 0.0;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+          if ((t & 255) < o) {
+#pragma unroll
+            for (int k = 0; k < RT; ++k) red[k][t] += red[k][t + o];
+          }
+          __syncthreads();
+        }
+        if (t < RT && k0 + t < RF_TERMS) {               // the four block sums of this term, in block order
+          double v = s[k0 + t];
+          for (int b = 0; b < 4; ++b) v += red[t][256 * b];
+          s[k0 + t] = v;
+        }
+        __syncthreads();
+      }
+    }
+    if (t == 0) {
+      const int cnt = (int)s[16];
+      if (abs(cnt - prev) < 1) {      // :266-267
+        done = 1;
+      } else {
+        prev = cnt;
+        const double sw = s[0] + 1e-6;      // common.py:22-23
+        double ca[3], cb[3], H[9];
+        for (int c = 0; c < 3; ++c) { ca[c] = s[1 + c] / sw; cb[c] = s[4 + c] / sw; }
+        for (int i = 0; i < 3; ++i)
+          for (int k = 0; k < 3; ++k)
+            H[3 * i + k] = s[7 + 3 * i + k] - ca[i] * s[4 + k] - s[1 + i] * cb[k] + s[0] * ca[i] * cb[k];
+        float Tn[12];
+        kabsch_from_H(H, ca, cb, Tn);
+        for (int k = 0; k < 12; ++k) Ts[k] = Tn[k];
+      }
+    }
+    __syncthreads();
+    if (done) break;
+  }
+  if (t < 12) T[t] = Ts[t];
+  if (t == 0) { state[0] = done; state[1] = prev; }
+}
+
 }  // namespace gcl
 
 using namespace gcl;
@@ -429,6 +636,42 @@ int gcl_sc2_confidence(const float* src, const float* tgt, int32_t n, float d_th
   for (int it = 0; it < num_iterations; ++it) {
     hipLaunchKernelGGL(k_sc_matvec, grid, dim3(SC_TILE), 0, st, src, tgt, n, d_thre * d_thre, (const float*)x,
                        (const int*)done, partial);
+    hipLaunchKernelGGL(k_sc_normalize, dim3(1), dim3(1024), 0, st, (const float*)partial, n, x, done);
+  }
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+// entries kept per registration: 16 M (128 MB) or n^2, whichever is smaller; beyond that the products run dense
+static long long sc_sparse_cap(int n) { return std::min<long long>((long long)n * n, 16ll << 20); }
+
+int64_t gcl_sc2_confidence_scratch_bytes(int32_t n) {
+  if (n <= 0 || n > SC_MAXN) return 0;
+  return (long long)(2 * SC_CHUNKS * n + 64) * 4 + sc_sparse_cap(n) * (long long)sizeof(ScEntry);
+}
+
+int gcl_sc2_confidence_sparse(const float* src, const float* tgt, int32_t n, float d_thre, int32_t num_iterations,
+                              float* partial, float* x, int32_t* done, void* scratch, void* stream) {
+  GCL_CHECK_ARG(src && tgt && partial && x && done && scratch, "gcl_sc2_confidence_sparse: null pointer");
+  GCL_CHECK_ARG(n > 0 && n <= SC_MAXN && d_thre > 0 && num_iterations >= 0, "gcl_sc2_confidence: 0 < n <= %d", SC_MAXN);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)cdiv(n, SC_TILE), SC_CHUNKS);
+  int* count = (int*)scratch;
+  int* offset = count + SC_CHUNKS * n;
+  int* overflow = offset + SC_CHUNKS * n;
+  ScEntry* entries = (ScEntry*)(overflow + 64);
+  const long long cap = sc_sparse_cap(n);
+  const float d2 = d_thre * d_thre;
+  if (num_iterations > 0) {
+    hipLaunchKernelGGL(k_sc_sparse_build<0>, grid, dim3(SC_TILE), 0, st, src, tgt, n, d2, count, (const int*)offset, entries, cap,
+                       overflow);
+    hipLaunchKernelGGL(k_sc_sparse_scan, dim3(1), dim3(1024), 0, st, (const int*)count, SC_CHUNKS * n, offset, cap, overflow);
+    hipLaunchKernelGGL(k_sc_sparse_build<1>, grid, dim3(SC_TILE), 0, st, src, tgt, n, d2, count, (const int*)offset, entries, cap,
+                       overflow);
+  }
+  for (int it = 0; it < num_iterations; ++it) {
+    hipLaunchKernelGGL(k_sc_matvec_sparse, grid, dim3(SC_TILE), 0, st, src, tgt, n, d2, (const float*)x, (const int*)done,
+                       partial, (const int*)count, (const int*)offset, (const ScEntry*)entries, (const int*)overflow);
     hipLaunchKernelGGL(k_sc_normalize, dim3(1), dim3(1024), 0, st, (const float*)partial, n, x, done);
   }
   GCL_CHECK_LAUNCH();
@@ -476,6 +719,12 @@ int gcl_sc2_refine(const float* src, const float* tgt, int32_t n, float thr, int
                    int32_t* state, float* T, void* stream) {
   GCL_CHECK_ARG(src && tgt && partial && state && T && n > 0 && iterations >= 0, "gcl_sc2_refine: bad argument");
   hipStream_t st = (hipStream_t)stream;
+  static const int one_launch = [] { const char* e = getenv("GCL_SC2_REFINE_ONE_LAUNCH"); return e ? atoi(e) : 1; }();
+  if (one_launch && n <= RF_BLOCKS * 256) {      // every virtual thread of the two-kernel form owns at most one point
+    hipLaunchKernelGGL(k_sc_refine_all, dim3(1), dim3(1024), 0, st, src, tgt, n, thr, iterations, state, T);
+    GCL_CHECK_LAUNCH();
+    return GCL_OK;
+  }
   GCL_CHECK_HIP(hipMemsetAsync(state, 0, 2 * sizeof(int32_t), st));
   for (int it = 0; it < iterations; ++it) {
     hipLaunchKernelGGL(k_sc_refine_accum, dim3(RF_BLOCKS), dim3(256), 0, st, src, tgt, n, (const float*)T, thr,

@@ -13,6 +13,10 @@ import torch
 from gcl_amd import _lib
 from gcl_amd.lib.metrics import pdist_min
 
+import os
+
+SPARSE_CONFIDENCE = os.environ.get("GCL_SC2_SPARSE", "1") != "0"      # gcl_sc2_confidence_sparse (round 5)
+
 
 class Matcher:
     def __init__(self, inlier_threshold=0.10, num_node="all", use_mutual=True, d_thre=0.1, num_iterations=10,
@@ -50,9 +54,15 @@ class Matcher:
         conf = torch.ones(n, dtype=torch.float32, device=dev)
         partial = torch.empty(lib.gcl_sc2_chunks() * n, dtype=torch.float32, device=dev)
         done = torch.zeros(1, dtype=torch.int32, device=dev)
-        _lib.check(lib.gcl_sc2_confidence(_lib.ptr(src), _lib.ptr(tgt), n, float(self.d_thre),
-                                          int(self.num_iterations), _lib.ptr(partial), _lib.ptr(conf), _lib.ptr(done),
-                                          st), "gcl_sc2_confidence")
+        if SPARSE_CONFIDENCE:      # the matrix's non-zero entries kept from one build: bitwise the dense products' result
+            scratch = torch.empty(lib.gcl_sc2_confidence_scratch_bytes(n), dtype=torch.uint8, device=dev)
+            _lib.check(lib.gcl_sc2_confidence_sparse(_lib.ptr(src), _lib.ptr(tgt), n, float(self.d_thre),
+                                                     int(self.num_iterations), _lib.ptr(partial), _lib.ptr(conf),
+                                                     _lib.ptr(done), _lib.ptr(scratch), st), "gcl_sc2_confidence_sparse")
+        else:
+            _lib.check(lib.gcl_sc2_confidence(_lib.ptr(src), _lib.ptr(tgt), n, float(self.d_thre),
+                                              int(self.num_iterations), _lib.ptr(partial), _lib.ptr(conf), _lib.ptr(done),
+                                              st), "gcl_sc2_confidence")
         # seeds: local maxima first, by confidence (:32-58); ties -> lowest index
         is_max = torch.ones(n, dtype=torch.int32, device=dev)
         _lib.check(lib.gcl_sc2_local_max(_lib.ptr(src), _lib.ptr(conf), n, float(self.nms_radius), _lib.ptr(is_max),

@@ -77,6 +77,71 @@ def forward_clouds(model, clouds):
     return list(torch.split(out, [len(f) for f, _ in clouds]))
 
 
+def forward_clouds_stream(model, cloud_sets, device=None, depth=2):
+    """Features of successive cloud sets (an iterable of lists of (F, coords) as ``forward_clouds`` takes them), one forward
+    pass per set, with the COORDINATE MAPS of the next sets built ahead: a helper thread copies set i + 1 to the device and
+    makes its ``gcl_maps_build`` call on a side stream (the call carries the pass's host syncs -- level sizes -- and runs
+    with the interpreter lock released) while the main thread enqueues the forward pass of set i.  A pass over one pair of
+    35 k voxels is bound by exactly that chain (scripts/test_kitti.py:141-152 runs pair after pair); the features are those
+    of ``forward_clouds`` bit for bit (same maps, same launches).  Yields one list of per-cloud feature tensors per set."""
+    import concurrent.futures
+    if model.training:
+        raise RuntimeError("forward_clouds_stream needs model.eval(): batch statistics would mix the clouds")
+    dev = torch.device(device) if device is not None else next(model.parameters()).device
+    specs = model.native_map_specs(training=False) if hasattr(model, "native_map_specs") else None
+    sets = iter(cloud_sets)
+    if specs is None or dev.type != "cuda":
+        for clouds in sets:
+            yield forward_clouds(model, [(f.to(dev), c.to(dev)) for f, c in clouds])
+        return
+    side = torch.cuda.Stream(device=dev)
+    ring = [{"arena": None, "free": None} for _ in range(depth + 1)]
+
+    def build(clouds, slot):
+        with torch.cuda.device(dev), torch.cuda.stream(side):
+            if slot["free"] is not None:
+                side.wait_event(slot["free"])           # the pass that read this arena last has been enqueued and has run
+            Fs, Cs = [], []
+            for b, (f, c) in enumerate(clouds):
+                cb = c.to(dev, non_blocking=True)
+                if len(clouds) > 1:
+                    cb = cb.clone() if cb is c else cb
+                    cb[:, 0] = b
+                Fs.append(f.to(dev, non_blocking=True))
+                Cs.append(cb)
+            F = Fs[0] if len(Fs) == 1 else torch.cat(Fs)
+            C = Cs[0] if len(Cs) == 1 else torch.cat(Cs)
+            mgr = ME.CoordinateManager.build_native(C, specs, arena=slot["arena"])
+            slot["arena"] = mgr.native.arena
+            ev = torch.cuda.Event()
+            ev.record(side)
+        return F, mgr, ev, [len(f) for f in Fs], slot
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=1) as pool, torch.cuda.device(dev):
+        pending, k = [], 0
+        for clouds in sets:
+            pending.append(pool.submit(build, clouds, ring[k % len(ring)]))
+            k += 1
+            if len(pending) > depth:
+                yield _run_built(model, pending.pop(0).result())
+        while pending:
+            yield _run_built(model, pending.pop(0).result())
+
+
+def _run_built(model, built):
+    F, mgr, ev, sizes, slot = built
+    main = torch.cuda.current_stream()
+    main.wait_event(ev)
+    out = model(ME.SparseTensor(F, coordinate_map_key=ME.CoordinateMapKey(1), coordinate_manager=mgr)).F
+    slot["free"] = torch.cuda.Event()
+    slot["free"].record(main)
+    # allocated on the side stream, read by the pass just enqueued on this one: the allocator must not hand their blocks to
+    # the helper's next allocations before that pass has run (the maps' arena is the ring's own, guarded by slot["free"])
+    F.record_stream(main)
+    mgr.native.coords.record_stream(main)
+    return list(torch.split(out, sizes)) if len(sizes) > 1 else [out]
+
+
 def rotation_translation_error(T_est, T_gth):
     """(rte, rre in radians) with the reference's clamp of the trace diagonal (scripts/test_kitti.py:189-192)."""
     T_est, T_gth = torch.as_tensor(T_est).float().cpu(), torch.as_tensor(T_gth).float().cpu()
@@ -124,17 +189,15 @@ def eval_pairs(model, pairs, matcher, device=None, batch_pairs=1, subsample_size
             out["rre"].append(rre)
             out["success"].append(bool(ok))
 
+    chunks = [pairs[b0:b0 + max(1, batch_pairs)] for b0 in range(0, len(pairs), max(1, batch_pairs))]
     with torch.cuda.device(dev), torch.no_grad():
         pending = None
-        for b0 in range(0, len(pairs), max(1, batch_pairs)):
-            chunk = pairs[b0:b0 + max(1, batch_pairs)]
+        # the maps of the coming chunks are built on a side stream while this chunk's kernels are enqueued
+        feat_stream = forward_clouds_stream(model, ([(d[f"sinput{k}_F"], d[f"sinput{k}_C"]) for d in chunk for k in (0, 1)]
+                                                    for chunk in chunks), device=dev)
+        for chunk in chunks:
             t0 = time.perf_counter()
-            clouds = []
-            for d in chunk:
-                for k in (0, 1):
-                    clouds.append((d[f"sinput{k}_F"].to(dev, non_blocking=True),
-                                   d[f"sinput{k}_C"].to(dev, non_blocking=True)))
-            feats = forward_clouds(model, clouds)
+            feats = next(feat_stream)
             t_feat += time.perf_counter() - t0
             corrs, Ts = [], []
             for j, d in enumerate(chunk):

@@ -517,6 +517,13 @@ int32_t gcl_sc2_chunks(void);
 int32_t gcl_sc2_refine_partial_len(void);
 int gcl_sc2_confidence(const float* src, const float* tgt, int32_t n, float d_thre, int32_t num_iterations,
                        float* partial, float* x, int32_t* done, void* stream);
+/* the same power iteration over the NON-ZERO entries of the compatibility matrix, built once per registration (count, scan,
+ * fill; scratch: gcl_sc2_confidence_scratch_bytes(n) bytes): the same non-zero terms in the same order, i.e. bitwise the
+ * result of gcl_sc2_confidence, without re-deriving 64 M entries (two square roots each) in every one of the 20 products;
+ * falls back to the dense products on the device when the entries exceed the scratch */
+int64_t gcl_sc2_confidence_scratch_bytes(int32_t n);
+int gcl_sc2_confidence_sparse(const float* src, const float* tgt, int32_t n, float d_thre, int32_t num_iterations,
+                              float* partial, float* x, int32_t* done, void* scratch, void* stream);
 int gcl_sc2_local_max(const float* src, const float* conf, int32_t n, float radius, int32_t* is_max, void* stream);
 int gcl_sc2_seed_knn(const float* src, const float* tgt, int32_t n, const int64_t* seeds, int32_t n_seeds,
                      float d_thre, int32_t k1, uint64_t* bits, int32_t* knn, void* stream);

@@ -6,6 +6,7 @@ Bar: bit-exact for coordinate maps / kernel maps / indices; for fp32 features th
 """
 import glob
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -17,6 +18,7 @@ from oracle import loss_oracle as LO          # noqa: E402
 from oracle import me_oracle as O             # noqa: E402
 
 G = os.path.join(os.path.dirname(__file__), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEV = "cuda:0"
 
 
@@ -1474,6 +1476,72 @@ def test_sc2pcr_matches_reference_output_and_oracle_stages(path):
         assert good.sum() >= 5 and d[good].max() < 5e-3
     else:
         assert set(m.last["seeds"].cpu().numpy()[:50]) == set(st["seeds"].numpy()[:50])
+
+
+@pytest.mark.parametrize("n,inlier,noise", [(8000, 0.3, 0.03), (8000, 1.0, 0.0), (3000, 0.6, 0.02), (257, 0.5, 0.02), (1, 1.0, 0.0)])
+def test_sc2pcr_confidence_sparse_equals_dense_bitwise(n, inlier, noise):
+    """gcl_sc2_confidence_sparse (the compatibility matrix's non-zero entries kept from ONE build; 20 products over them)
+    == gcl_sc2_confidence (every entry re-derived in every product), bit for bit: the same non-zero terms in the same order,
+    the skipped ones exact zeros.  (8000, all inliers, no noise): 64 M non-zeros exceed the 16 M kept -- the products fall
+    back to the dense loop on the device."""
+    from gcl_amd import _lib
+    lib = _lib.load()
+    rng = np.random.RandomState(n)
+    src = rng.uniform(-40, 40, (n, 3)).astype(np.float32)
+    src[:, 2] *= 0.1
+    ang = np.deg2rad(9.0)
+    R = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]])
+    tgt = (src @ R.T + np.array([3.0, 1.0, 0.1]) + rng.normal(0, noise, (n, 3))).astype(np.float32)
+    out = rng.rand(n) > inlier
+    tgt[out] = rng.uniform(-40, 40, (int(out.sum()), 3)).astype(np.float32)
+    with torch.cuda.device(DEV):
+        s, t = torch.from_numpy(src).to(DEV), torch.from_numpy(tgt).to(DEV)
+        res = []
+        for sparse in (False, True):
+            conf = torch.ones(n, device=DEV)
+            partial = torch.full((lib.gcl_sc2_chunks() * n,), float("nan"), device=DEV)
+            done = torch.zeros(1, dtype=torch.int32, device=DEV)
+            if sparse:
+                scratch = torch.empty(lib.gcl_sc2_confidence_scratch_bytes(n), dtype=torch.uint8, device=DEV)
+                _lib.check(lib.gcl_sc2_confidence_sparse(_lib.ptr(s), _lib.ptr(t), n, 0.1, 20, _lib.ptr(partial), _lib.ptr(conf),
+                                                         _lib.ptr(done), _lib.ptr(scratch), _lib.stream()), "sparse")
+            else:
+                _lib.check(lib.gcl_sc2_confidence(_lib.ptr(s), _lib.ptr(t), n, 0.1, 20, _lib.ptr(partial), _lib.ptr(conf),
+                                                  _lib.ptr(done), _lib.stream()), "dense")
+            res.append((conf, partial, done))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][2], res[1][2])
+        assert torch.equal(res[0][1], res[1][1]) and bool(torch.isfinite(res[0][0]).all())
+
+
+def test_sc2pcr_one_launch_refinement_and_sparse_confidence_change_no_bit(tmp_path):
+    """The round-5 forms of two SC2-PCR stages -- the refinement as ONE persistent launch (k_sc_refine_all) and the
+    confidence's products over kept non-zero entries -- against the round-1 forms (GCL_SC2_REFINE_ONE_LAUNCH=0,
+    GCL_SC2_SPARSE=0, selected in a fresh process: the switches are read once): the transformation of every golden problem is
+    bitwise the same."""
+    import subprocess
+    script = (
+        "import sys, glob, os, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from gcl_amd.scripts.SC2_PCR import Matcher\n"
+        "out = {}\n"
+        "for path in sorted(glob.glob(os.path.join(%r, 'sc2pcr_*.npz'))):\n"
+        "    z = np.load(path)\n"
+        "    cfg = {k: (int(z[k]) if k in ('num_iterations', 'max_points', 'k1', 'k2') else float(z[k])) for k in %r}\n"
+        "    m = Matcher(num_node='all', use_mutual=False, **cfg)\n"
+        "    with torch.cuda.device(%r):\n"
+        "        T = m.SC2_PCR(torch.from_numpy(z['src']).to(%r)[None], torch.from_numpy(z['tgt']).to(%r)[None])\n"
+        "    out[os.path.basename(path)] = T[0].cpu().numpy()\n"
+        "np.savez(sys.argv[1], **out)\n") % (ROOT, G, SC2_KEYS, DEV, DEV, DEV)
+    res = {}
+    for tag, env in (("new", {}), ("old", {"GCL_SC2_REFINE_ONE_LAUNCH": "0", "GCL_SC2_SPARSE": "0"})):
+        f = str(tmp_path / f"{tag}.npz")
+        r = subprocess.run([sys.executable, "-c", script, f], env=dict(os.environ, **env), capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = np.load(f)
+    assert len(res["new"].files) >= 3
+    for k in res["new"].files:
+        assert np.array_equal(res["new"][k], res["old"][k]), k
 
 
 def test_sc2pcr_estimator_end_to_end_at_kitti_size():

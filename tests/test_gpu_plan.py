@@ -222,6 +222,17 @@ def test_inference_plan_equals_the_per_operator_eval_path(k1):
             batched = forward_clouds(m, [(f, c) for f, c in zip(feats, clouds)])
             for got, r in zip(batched, refs):
                 assert torch.equal(got, r)
+            # the same sets through forward_clouds_stream (maps of the coming sets built on a side stream by a helper
+            # thread): single clouds from host memory, then mixed set sizes -- bit for bit the same features, in order
+            from gcl_amd.scripts.test_kitti import forward_clouds_stream
+            host = [(f.cpu(), c.cpu()) for f, c in zip(feats, clouds)]
+            for rep in range(2):
+                got = list(forward_clouds_stream(m, ([fc] for fc in host), device=DEV))
+                assert len(got) == len(refs) and all(len(g) == 1 and torch.equal(g[0], r) for g, r in zip(got, refs))
+            sets = [[(feats[0], clouds[0]), (feats[1], clouds[1])], [(feats[2], clouds[2])], [(feats[1], clouds[1]), (feats[0], clouds[0])]]
+            got = list(forward_clouds_stream(m, sets, device=DEV, depth=1))
+            want = [[refs[0], refs[1]], [refs[2]], [refs[1], refs[0]]]
+            assert all(len(g) == len(w) and all(torch.equal(a, b) for a, b in zip(g, w)) for g, w in zip(got, want))
         # parameters change behind the persistent packed kernels: one optimizer step through the fused SGD kernel
         from gcl_amd.lib.optim import FusedSGD
         m.train()
