@@ -96,48 +96,59 @@ __global__ void __launch_bounds__(SC_TILE) k_sc_sparse_build(const float* __rest
     }
     __syncthreads();
     const int m = min(SC_TILE, j1 - jb);
-    for (int q = 0; q < m; ++q) {
-      float v = sc_first_order(si, ti, ts[q], d2_thre);
-      // The ROUNDED value decides, in both passes alike.  Without this barrier the compiler derives the predicate from
-      // intermediates (q < 1 instead of max(1 - q, 0) != 0) where the value itself is not needed, the two instantiations
-      // disagreed on borderline pairs (22 of 64000 segments at n = 8000), and a fill pass that finds one entry more than
-      // was counted writes into its neighbour's segment.
-      asm volatile("" : "+v"(v));
+    // The ROUNDED value decides, in both passes alike: the empty asm makes it opaque.  Without it the compiler derives the
+    // predicate from intermediates (q < 1 instead of max(1 - q, 0) != 0) where the value itself is not needed, the two
+    // instantiations disagreed on borderline pairs (22 of 64000 segments at n = 8000), and a fill pass that finds one entry
+    // more than was counted writes into its neighbour's segment.  Four entries per trip, written out: the asm keeps the
+    // compiler from unrolling, and one entry is a dependent chain of two square roots and a division.
+    auto take = [&](int q, float v) {
       if (v != 0.f) {      // (a NaN entry counts as non-zero: it must reach the sum as it does in the dense loop)
         if (PASS == 1 && cnt < room) entries[pos + cnt] = ScEntry{jb + q, v};
         ++cnt;
       }
+    };
+    int q = 0;
+    for (; q + 4 <= m; q += 4) {
+      float v0 = sc_first_order(si, ti, ts[q], d2_thre), v1 = sc_first_order(si, ti, ts[q + 1], d2_thre);
+      float v2 = sc_first_order(si, ti, ts[q + 2], d2_thre), v3 = sc_first_order(si, ti, ts[q + 3], d2_thre);
+      asm("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));
+      take(q, v0);
+      take(q + 1, v1);
+      take(q + 2, v2);
+      take(q + 3, v3);
+    }
+    for (; q < m; ++q) {
+      float v = sc_first_order(si, ti, ts[q], d2_thre);
+      asm("" : "+v"(v));
+      take(q, v);
     }
   }
-  if (PASS == 0 && ok) count[(size_t)blockIdx.y * n + i] = cnt;
+  if (PASS == 0) {
+    // where this workgroup's segments live: an exclusive scan of its 256 counts + ONE atomic reservation of their total.
+    // (Which range a workgroup gets depends on timing; nothing else does -- a segment's entries and their order are fixed.)
+    __shared__ int sc[SC_TILE];
+    __shared__ unsigned base;
+    __syncthreads();
+    sc[threadIdx.x] = ok ? cnt : 0;
+    __syncthreads();
+    for (int o = 1; o < SC_TILE; o <<= 1) {
+      const int add = (int)threadIdx.x >= o ? sc[threadIdx.x - o] : 0;
+      __syncthreads();
+      sc[threadIdx.x] += add;
+      __syncthreads();
+    }
+    if (threadIdx.x == SC_TILE - 1) {
+      base = atomicAdd((unsigned*)(overflow + 1), (unsigned)sc[SC_TILE - 1]);
+      if ((long long)base + sc[SC_TILE - 1] > cap) atomicExch(overflow, 1);
+    }
+    __syncthreads();
+    if (ok) {
+      count[(size_t)blockIdx.y * n + i] = cnt;
+      ((int*)offset)[(size_t)blockIdx.y * n + i] = (int)(base + (unsigned)(sc[threadIdx.x] - cnt));
+    }
+  }
   if (PASS == 1) {      // (cannot happen with the barrier above; a short segment is padded with exact zeros all the same)
     for (int q = cnt; q < room; ++q) entries[pos + q] = ScEntry{0, 0.f};
-  }
-}
-// exclusive scan of count[SC_CHUNKS * n] by ONE workgroup (<= 64 K values); total > cap sets the overflow flag
-__global__ void __launch_bounds__(1024) k_sc_sparse_scan(const int* __restrict__ count, int total_n, int* offset, long long cap,
-                                                         int* overflow) {
-  __shared__ long long part[1024];
-  const int per = (total_n + 1023) / 1024;
-  const int b = threadIdx.x * per, e = min(total_n, b + per);
-  long long s = 0;
-  for (int q = b; q < e; ++q) s += count[q];
-  part[threadIdx.x] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    long long run = 0;
-    for (int t = 0; t < 1024; ++t) {
-      const long long v = part[t];
-      part[t] = run;
-      run += v;
-    }
-    *overflow = (run > cap || run > 0x7fffffffll) ? 1 : 0;
-  }
-  __syncthreads();
-  long long run = part[threadIdx.x];
-  for (int q = b; q < e; ++q) {
-    offset[q] = (int)run;
-    run += count[q];
   }
 }
 __global__ void __launch_bounds__(SC_TILE) k_sc_matvec_sparse(const float* __restrict__ src, const float* __restrict__ tgt,
@@ -257,51 +268,93 @@ __global__ void __launch_bounds__(256) k_sc_tight_bits(const float* __restrict__
 }
 
 // ---- per seed: second-order measure row and its k1 largest entries (:353-361, :85-86) -------------------------
-// one workgroup per seed; vals in LDS; selection by (value desc, index asc)
+// one workgroup per seed; selection by (value desc, index asc).
+// Round 5: (1) the AND + popcount of a compatible column j is done by a WAVE -- lanes read the 125 words of bit row j as two
+// coalesced pieces (lane, lane + 64) against the seed's words held in registers, and four columns share one packed
+// reduction -- instead of one lane walking the row word by word (64 lanes, 64 different 1 KB rows: every load instruction
+// touched 64 cache lines; a seed that is an inlier has thousands of compatible columns); (2) the k1 selection rounds keep
+// every thread's 32 values in registers and reduce with shuffles + one exchange through LDS (two barriers per round, not
+// nine).  Same integers, same tie rule: the k1 lists are those of the round-1 kernel.
 constexpr int SC_MAXN = 8192;
 __global__ void __launch_bounds__(256) k_sc_seed_knn(const float* __restrict__ src, const float* __restrict__ tgt,
                                                      const unsigned long long* __restrict__ bits, int n, int words,
                                                      const long long* __restrict__ seeds, float d_thre, int k1,
                                                      int* knn) {
   __shared__ int vals[SC_MAXN];
-  __shared__ unsigned long long rowb[SC_MAXN / 64];
-  __shared__ int bv[256], bi[256];
+  __shared__ int wv[4], wi[4];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int r = (int)seeds[blockIdx.x];
-  for (int w = threadIdx.x; w < words; w += 256) rowb[w] = bits[(size_t)r * words + w];
-  __syncthreads();
+  // the seed's bit row: words lane and lane + 64 (words <= 128)
+  const unsigned long long* br = bits + (size_t)r * words;
+  const unsigned long long r0 = lane < words ? br[lane] : 0ull, r1 = lane + 64 < words ? br[lane + 64] : 0ull;
   const P3 sr = ld3(src, r), tr = ld3(tgt, r);
-  for (int j = threadIdx.x; j < n; j += 256) {
-    const float cd = fabsf(dist3(sr, ld3(src, j)) - dist3(tr, ld3(tgt, j)));
-    int v = 0;
-    if (cd < d_thre) {                       // hard[seed][j]: rows outside it score 0 and need no bit row
-      const unsigned long long* bj = bits + (size_t)j * words;
-      for (int w = 0; w < words; ++w) v += __popcll(rowb[w] & bj[w]);
+  for (int jb = 0; jb < n; jb += 256) {
+    const int j = jb + t;
+    bool hard = false;
+    if (j < n) {
+      hard = fabsf(dist3(sr, ld3(src, j)) - dist3(tr, ld3(tgt, j))) < d_thre;      // hard[seed][j]: others score 0
+      vals[j] = 0;
     }
-    vals[j] = v;
-  }
-  __syncthreads();
-  for (int round = 0; round < k1; ++round) {
-    int best = -1, besti = 0x7fffffff;
-    for (int j = threadIdx.x; j < n; j += 256) {
-      const int v = vals[j];
-      if (v > best) { best = v; besti = j; }      // ascending j per thread: the first maximum is the lowest index
-    }
-    bv[threadIdx.x] = best;
-    bi[threadIdx.x] = besti;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if ((int)threadIdx.x < o) {
-        const int v2 = bv[threadIdx.x + o], i2 = bi[threadIdx.x + o];
-        if (v2 > bv[threadIdx.x] || (v2 == bv[threadIdx.x] && i2 < bi[threadIdx.x])) {
-          bv[threadIdx.x] = v2;
-          bi[threadIdx.x] = i2;
+    unsigned long long m = __ballot(hard);      // this wave's 64 columns jb + 64 w + bit
+    const int j0 = jb + 64 * w;
+    while (m) {      // four compatible columns per trip: eight coalesced loads in flight, one packed reduction
+      int jj[4];
+      unsigned long long pk = 0;      // 4 x 16-bit lane counts (each <= 128; their wave sums <= 8192)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        jj[u] = -1;
+        if (m) {
+          jj[u] = j0 + __builtin_ctzll(m);
+          m &= m - 1;
         }
       }
-      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (jj[u] >= 0) {      // uniform over the wave
+          const unsigned long long* bj = bits + (size_t)jj[u] * words;
+          const unsigned long long a0 = lane < words ? bj[lane] : 0ull, a1 = lane + 64 < words ? bj[lane + 64] : 0ull;
+          pk |= (unsigned long long)(__popcll(r0 & a0) + __popcll(r1 & a1)) << (16 * u);
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) pk += __shfl_xor(pk, o);      // four 16-bit sums at once (no carry: <= 8192 each)
+      if (lane == 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (jj[u] >= 0) vals[jj[u]] = (int)((pk >> (16 * u)) & 0xffffull);
+      }
     }
-    if (threadIdx.x == 0) {
-      knn[blockIdx.x * k1 + round] = bi[0];
-      vals[bi[0]] = -1;
+  }
+  __syncthreads();
+  // selection: thread t owns columns t, t + 256, ... (ascending), its values in registers
+  int v[SC_MAXN / 256];
+#pragma unroll
+  for (int q = 0; q < SC_MAXN / 256; ++q) {
+    const int j = t + 256 * q;
+    v[q] = j < n ? vals[j] : -2;      // -2: no such column; -1: taken
+  }
+  for (int round = 0; round < k1; ++round) {
+    int best = -2, besti = 0x7fffffff;
+#pragma unroll
+    for (int q = 0; q < SC_MAXN / 256; ++q)
+      if (v[q] > best) { best = v[q]; besti = t + 256 * q; }      // ascending column per thread: first maximum = lowest index
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const int v2 = __shfl_xor(best, o), i2 = __shfl_xor(besti, o);
+      if (v2 > best || (v2 == best && i2 < besti)) { best = v2; besti = i2; }
+    }
+    if (lane == 0) { wv[w] = best; wi[w] = besti; }
+    __syncthreads();
+    best = wv[0];
+    besti = wi[0];
+#pragma unroll
+    for (int u = 1; u < 4; ++u)
+      if (wv[u] > best || (wv[u] == best && wi[u] < besti)) { best = wv[u]; besti = wi[u]; }
+    if (t == 0) knn[blockIdx.x * k1 + round] = besti;
+    if ((besti & 255) == t) {      // the owner takes it out
+#pragma unroll
+      for (int q = 0; q < SC_MAXN / 256; ++q)
+        if (q == (besti >> 8)) v[q] = -1;
     }
     __syncthreads();
   }
@@ -535,66 +588,61 @@ __global__ void k_sc_refine_solve(const double* __restrict__ partial, int* state
 }
 
 // The whole refinement in ONE launch (round 5): a single 1024-thread workgroup runs the iterations and stops at convergence
-// (the two-kernel form launched 2 x 20 kernels per registration, 35 of them typically no-ops behind the `done` flag: 0.3 ms of
-// dependent launches per pair).  Same arithmetic in the same order: the RF_BLOCKS x 256 "virtual" threads of k_sc_refine_accum
-// own at most one point each for n <= 16384 (j = b 256 + t), their 17 terms are tree-reduced per 256-point block exactly as
-// there, the block sums are added in block order exactly as k_sc_refine_solve does -- T is bitwise the two-kernel result.
+// (the two-kernel form launched 2 x 20 kernels per registration, most of them no-ops behind the `done` flag once the inlier
+// count stands still: 0.3 ms of dependent launches per pair).  A thread owns points t, t + 1024, ... and sums their 17
+// weighted-Kabsch terms in fp64 in that order; the 64 lanes of a wave are combined by a butterfly of shuffles, the 16 waves
+// in wave order by thread 0 -- a fixed order, so the result is reproducible; it is NOT the summation order of the two-kernel
+// form (64 blocks of 256, a halving tree each): the fp64 sums may differ in their last bits, the fp32 transformation
+// practically never (tests/test_gpu_parity.py compares the two forms on the golden problems).
 __global__ void __launch_bounds__(1024) k_sc_refine_all(const float* __restrict__ src, const float* __restrict__ tgt, int n,
                                                         float thr, int iterations, int* state, float* T) {
-  constexpr int RT = 6;                        // terms reduced per round (LDS: 6 x 1024 doubles)
-  __shared__ double red[RT][1024];
-  __shared__ double s[RF_TERMS];
+  __shared__ double ws[16][RF_TERMS];
   __shared__ float Ts[12];
-  __shared__ int done, prev;
-  const int t = threadIdx.x;
+  __shared__ int done;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   if (t < 12) Ts[t] = T[t];
-  if (t == 0) { done = 0; prev = 0; }
+  if (t == 0) done = 0;
+  int prev = 0;      // thread 0's
   __syncthreads();
   for (int it = 0; it < iterations; ++it) {
-    if (t < RF_TERMS) s[t] = 0;
-    __syncthreads();
-    for (int g = 0; g < RF_BLOCKS / 4; ++g) {            // four 256-point blocks at a time, in block order
-      const int j = g * 1024 + t;
-      double term[RF_TERMS];
-      for (int k = 0; k < RF_TERMS; ++k) term[k] = 0;
-      if (j < n) {
-        const P3 p = ld3(src, j), q = ld3(tgt, j);
-        const float x = Ts[0] * p.x + Ts[1] * p.y + Ts[2] * p.z + Ts[3] - q.x;
-        const float y = Ts[4] * p.x + Ts[5] * p.y + Ts[6] * p.z + Ts[7] - q.y;
-        const float z = Ts[8] * p.x + Ts[9] * p.y + Ts[10] * p.z + Ts[11] - q.z;
-        const float d = sqrtf(x * x + y * y + z * z);
-        if (d < thr) {
-          const float r = d / thr;
-          const double w = 1.f / (1.f + r * r);
-          const double a[3] = {p.x, p.y, p.z}, b[3] = {q.x, q.y, q.z};
-          term[0] = w;
-          for (int c = 0; c < 3; ++c) { term[1 + c] = w * a[c]; term[4 + c] = w * b[c]; }
-          for (int i = 0; i < 3; ++i)
-            for (int k = 0; k < 3; ++k) term[7 + 3 * i + k] = w * a[i] * b[k];
-          term[16] = 1.0;
-        }
-      }
-      if (g * 1024 >= n) break;                          // uniform: the remaining blocks hold no point (their sums are +0)
-      for (int k0 = 0; k0 < RF_TERMS; k0 += RT) {
+    double acc[RF_TERMS];
 #pragma unroll
-        for (int k = 0; k < RT; ++k) red[k][t] = (k0 + k < RF_TERMS) ? term[k0 + k] : 0.0;
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-          if ((t & 255) < o) {
+    for (int k = 0; k < RF_TERMS; ++k) acc[k] = 0;
+    for (int j = t; j < n; j += 1024) {
+      const P3 p = ld3(src, j), q = ld3(tgt, j);
+      const float x = Ts[0] * p.x + Ts[1] * p.y + Ts[2] * p.z + Ts[3] - q.x;
+      const float y = Ts[4] * p.x + Ts[5] * p.y + Ts[6] * p.z + Ts[7] - q.y;
+      const float z = Ts[8] * p.x + Ts[9] * p.y + Ts[10] * p.z + Ts[11] - q.z;
+      const float d = sqrtf(x * x + y * y + z * z);
+      if (d < thr) {
+        const float r = d / thr;
+        const double wgt = 1.f / (1.f + r * r);
+        const double a[3] = {p.x, p.y, p.z}, b[3] = {q.x, q.y, q.z};
+        acc[0] += wgt;
 #pragma unroll
-            for (int k = 0; k < RT; ++k) red[k][t] += red[k][t + o];
-          }
-          __syncthreads();
-        }
-        if (t < RT && k0 + t < RF_TERMS) {               // the four block sums of this term, in block order
-          double v = s[k0 + t];
-          for (int b = 0; b < 4; ++b) v += red[t][256 * b];
-          s[k0 + t] = v;
-        }
-        __syncthreads();
+        for (int c = 0; c < 3; ++c) { acc[1 + c] += wgt * a[c]; acc[4 + c] += wgt * b[c]; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) acc[7 + 3 * i + k] += wgt * a[i] * b[k];
+        acc[16] += 1.0;
       }
     }
+#pragma unroll
+    for (int k = 0; k < RF_TERMS; ++k) {
+      double v = acc[k];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      if (lane == 0) ws[w][k] = v;
+    }
+    __syncthreads();
     if (t == 0) {
+      double s[RF_TERMS];
+      for (int k = 0; k < RF_TERMS; ++k) {
+        double v = 0;
+        for (int u = 0; u < 16; ++u) v += ws[u][k];
+        s[k] = v;
+      }
       const int cnt = (int)s[16];
       if (abs(cnt - prev) < 1) {      // :266-267
         done = 1;
@@ -663,9 +711,9 @@ int gcl_sc2_confidence_sparse(const float* src, const float* tgt, int32_t n, flo
   const long long cap = sc_sparse_cap(n);
   const float d2 = d_thre * d_thre;
   if (num_iterations > 0) {
+    GCL_CHECK_HIP(hipMemsetAsync(overflow, 0, 2 * sizeof(int), st));      // [0] overflow flag, [1] entries reserved so far
     hipLaunchKernelGGL(k_sc_sparse_build<0>, grid, dim3(SC_TILE), 0, st, src, tgt, n, d2, count, (const int*)offset, entries, cap,
                        overflow);
-    hipLaunchKernelGGL(k_sc_sparse_scan, dim3(1), dim3(1024), 0, st, (const int*)count, SC_CHUNKS * n, offset, cap, overflow);
     hipLaunchKernelGGL(k_sc_sparse_build<1>, grid, dim3(SC_TILE), 0, st, src, tgt, n, d2, count, (const int*)offset, entries, cap,
                        overflow);
   }
@@ -720,7 +768,7 @@ int gcl_sc2_refine(const float* src, const float* tgt, int32_t n, float thr, int
   GCL_CHECK_ARG(src && tgt && partial && state && T && n > 0 && iterations >= 0, "gcl_sc2_refine: bad argument");
   hipStream_t st = (hipStream_t)stream;
   static const int one_launch = [] { const char* e = getenv("GCL_SC2_REFINE_ONE_LAUNCH"); return e ? atoi(e) : 1; }();
-  if (one_launch && n <= RF_BLOCKS * 256) {      // every virtual thread of the two-kernel form owns at most one point
+  if (one_launch) {
     hipLaunchKernelGGL(k_sc_refine_all, dim3(1), dim3(1024), 0, st, src, tgt, n, thr, iterations, state, T);
     GCL_CHECK_LAUNCH();
     return GCL_OK;

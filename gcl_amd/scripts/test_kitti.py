@@ -12,6 +12,7 @@ and every output row is accumulated in a fixed offset order, so the features equ
 a fraction of the launches of this launch-bound case.  All host random draws are made per pair in the reference's
 order, so a seeded run selects the same rows whatever ``batch_pairs`` is.
 """
+import os
 import time
 
 import numpy as np
@@ -77,13 +78,16 @@ def forward_clouds(model, clouds):
     return list(torch.split(out, [len(f) for f, _ in clouds]))
 
 
-def forward_clouds_stream(model, cloud_sets, device=None, depth=2):
+def forward_clouds_stream(model, cloud_sets, device=None, depth=2, exec_streams=None):
     """Features of successive cloud sets (an iterable of lists of (F, coords) as ``forward_clouds`` takes them), one forward
     pass per set, with the COORDINATE MAPS of the next sets built ahead: a helper thread copies set i + 1 to the device and
     makes its ``gcl_maps_build`` call on a side stream (the call carries the pass's host syncs -- level sizes -- and runs
     with the interpreter lock released) while the main thread enqueues the forward pass of set i.  A pass over one pair of
     35 k voxels is bound by exactly that chain (scripts/test_kitti.py:141-152 runs pair after pair); the features are those
-    of ``forward_clouds`` bit for bit (same maps, same launches).  Yields one list of per-cloud feature tensors per set."""
+    of ``forward_clouds`` bit for bit (same maps, same launches).  Yields one list of per-cloud feature tensors per set.
+    ``exec_streams`` (default ``GCL_FWD_STREAMS`` = 2): the passes themselves alternate over that many streams -- a pass over
+    one pair is a chain of ~25 dependent launches that leaves most of the chip idle, and the passes of different sets are
+    independent; the caller's stream is made to wait for a set's pass before the set is yielded."""
     import concurrent.futures
     if model.training:
         raise RuntimeError("forward_clouds_stream needs model.eval(): batch statistics would mix the clouds")
@@ -95,7 +99,9 @@ def forward_clouds_stream(model, cloud_sets, device=None, depth=2):
             yield forward_clouds(model, [(f.to(dev), c.to(dev)) for f, c in clouds])
         return
     side = torch.cuda.Stream(device=dev)
-    ring = [{"arena": None, "free": None} for _ in range(depth + 1)]
+    n_exec = int(os.environ.get("GCL_FWD_STREAMS", "2")) if exec_streams is None else int(exec_streams)
+    execs = [torch.cuda.Stream(device=dev) for _ in range(n_exec)] if n_exec > 1 else [None]
+    ring = [{"arena": None, "free": None} for _ in range(depth + max(1, n_exec) + 1)]
 
     def build(clouds, slot):
         with torch.cuda.device(dev), torch.cuda.stream(side):
@@ -117,28 +123,45 @@ def forward_clouds_stream(model, cloud_sets, device=None, depth=2):
             ev.record(side)
         return F, mgr, ev, [len(f) for f in Fs], slot
 
+    ran = [0]
+
+    def run(built):
+        feats = _run_built(model, built, execs[ran[0] % len(execs)])
+        if ran[0] == 0 and execs[0] is not None:
+            # what a model's FIRST inference pass leaves behind for the later ones (packed kernels in the plan's state buffer,
+            # the BatchNorm modules' folded scale / shift) is written on the first stream: the others start after it
+            for e in execs[1:]:
+                e.wait_event(built[4]["free"])
+        ran[0] += 1
+        return feats
+
     with concurrent.futures.ThreadPoolExecutor(max_workers=1) as pool, torch.cuda.device(dev):
         pending, k = [], 0
         for clouds in sets:
             pending.append(pool.submit(build, clouds, ring[k % len(ring)]))
             k += 1
             if len(pending) > depth:
-                yield _run_built(model, pending.pop(0).result())
+                yield run(pending.pop(0).result())
         while pending:
-            yield _run_built(model, pending.pop(0).result())
+            yield run(pending.pop(0).result())
 
 
-def _run_built(model, built):
+def _run_built(model, built, exec_stream=None):
     F, mgr, ev, sizes, slot = built
-    main = torch.cuda.current_stream()
-    main.wait_event(ev)
-    out = model(ME.SparseTensor(F, coordinate_map_key=ME.CoordinateMapKey(1), coordinate_manager=mgr)).F
-    slot["free"] = torch.cuda.Event()
-    slot["free"].record(main)
-    # allocated on the side stream, read by the pass just enqueued on this one: the allocator must not hand their blocks to
-    # the helper's next allocations before that pass has run (the maps' arena is the ring's own, guarded by slot["free"])
-    F.record_stream(main)
-    mgr.native.coords.record_stream(main)
+    caller = torch.cuda.current_stream()
+    st = exec_stream if exec_stream is not None else caller
+    with torch.cuda.stream(st):
+        st.wait_event(ev)
+        out = model(ME.SparseTensor(F, coordinate_map_key=ME.CoordinateMapKey(1), coordinate_manager=mgr)).F
+        slot["free"] = torch.cuda.Event()
+        slot["free"].record(st)
+        # allocated on the side stream, read by the pass just enqueued on this one: the allocator must not hand their blocks
+        # to the helper's next allocations before that pass has run (the maps' arena is the ring's own, guarded by slot["free"])
+        F.record_stream(st)
+        mgr.native.coords.record_stream(st)
+    if st is not caller:
+        caller.wait_event(slot["free"])        # the caller's later work (and only that) is ordered behind this pass
+        out.record_stream(caller)
     return list(torch.split(out, sizes)) if len(sizes) > 1 else [out]
 
 
@@ -190,41 +213,72 @@ def eval_pairs(model, pairs, matcher, device=None, batch_pairs=1, subsample_size
             out["success"].append(bool(ok))
 
     chunks = [pairs[b0:b0 + max(1, batch_pairs)] for b0 in range(0, len(pairs), max(1, batch_pairs))]
+    n_streams = max(1, int(os.environ.get("GCL_EVAL_STREAMS", "1")))
     with torch.cuda.device(dev), torch.no_grad():
         pending = None
+        main = torch.cuda.current_stream()
+        # GCL_EVAL_STREAMS > 1 (measured, not the default): pair j's registration on stream j mod n_streams beside the others
+        # and beside the next chunk's forward pass, a collector stream gathering the chunk's transformations -- 276 pairs/s on
+        # one stream vs 259 - 261 on 2 - 4 at batch_pairs = 8 (216 vs 210 - 222 at 1): the registrations are bound by the
+        # enqueuing thread and by kernels that fill the chip (the matrix build, the 1-NN), not by idle gaps between launches.
+        # The host draws stay in the reference's per-pair order (they are made while enqueuing, serially).
+        streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else [main]
+        collector = torch.cuda.Stream(device=dev) if n_streams > 1 else main
         # the maps of the coming chunks are built on a side stream while this chunk's kernels are enqueued
         feat_stream = forward_clouds_stream(model, ([(d[f"sinput{k}_F"], d[f"sinput{k}_C"]) for d in chunk for k in (0, 1)]
                                                     for chunk in chunks), device=dev)
+        pair_no = 0
         for chunk in chunks:
             t0 = time.perf_counter()
             feats = next(feat_stream)
+            feats_ready = torch.cuda.Event()
+            feats_ready.record(main)
             t_feat += time.perf_counter() - t0
-            corrs, Ts = [], []
+            corrs, Ts, dones = [], [], []
             for j, d in enumerate(chunk):
-                F0, F1 = feats[2 * j].detach(), feats[2 * j + 1].detach()
-                out["n_voxels"] += len(F0) + len(F1)
-                xyz0, xyz1 = d["pcd0"][0], d["pcd1"][0]
-                xyz0np, xyz1np = xyz0.numpy(), xyz1.numpy()
-                # draws + feature 1-NN now (the reference's order); its 5000 indices are read back only when ``collect``
-                corrs.append(DeferredCorr(xyz0, xyz1, F0, F1, subsample_size=subsample_size))
-                xyz0s, F0s = random_sample(xyz0np, F0, n_points)
-                xyz1s, F1s = random_sample(xyz1np, F1, n_points)
-                t0 = time.perf_counter()
-                x0, x1 = torch.from_numpy(xyz0s).to(dev), torch.from_numpy(xyz1s).to(dev)
-                T_est, _, _, _ = matcher.estimator(x0[None], x1[None], F0s[None], F1s[None])
-                Ts.append(T_est[0])
-                t_reg += time.perf_counter() - t0
+                st = streams[pair_no % len(streams)]
+                pair_no += 1
+                with torch.cuda.stream(st):
+                    st.wait_event(feats_ready)
+                    F0, F1 = feats[2 * j].detach(), feats[2 * j + 1].detach()
+                    if st is not main:               # allocated on the main stream, read on this one
+                        F0.record_stream(st)
+                        F1.record_stream(st)
+                    out["n_voxels"] += len(F0) + len(F1)
+                    xyz0, xyz1 = d["pcd0"][0], d["pcd1"][0]
+                    xyz0np, xyz1np = xyz0.numpy(), xyz1.numpy()
+                    # draws + feature 1-NN now (the reference's order); its 5000 indices are read back only when ``collect``
+                    corrs.append(DeferredCorr(xyz0, xyz1, F0, F1, subsample_size=subsample_size))
+                    xyz0s, F0s = random_sample(xyz0np, F0, n_points)
+                    xyz1s, F1s = random_sample(xyz1np, F1, n_points)
+                    t0 = time.perf_counter()
+                    x0, x1 = torch.from_numpy(xyz0s).to(dev), torch.from_numpy(xyz1s).to(dev)
+                    T_est, _, _, _ = matcher.estimator(x0[None], x1[None], F0s[None], F1s[None])
+                    Ts.append(T_est[0])
+                    done = torch.cuda.Event()
+                    done.record(st)
+                    dones.append(done)
+                    t_reg += time.perf_counter() - t0
             # the reference reads T on the host after every pair (:180); here the chunk's transformations leave the device
             # in ONE copy, and the host half of a chunk runs while the next chunk's kernels execute
             T_host = torch.empty((len(chunk), 4, 4), dtype=torch.float32, pin_memory=True)
-            T_host.copy_(torch.stack(Ts), non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
+            with torch.cuda.stream(collector):
+                for done, T in zip(dones, Ts):
+                    collector.wait_event(done)
+                    if collector is not main:
+                        T.record_stream(collector)
+                T_host.copy_(torch.stack(Ts), non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(collector)
             if pending is not None:
                 finish(pending)
             pending = (chunk, corrs, T_host, ev)
         if pending is not None:
             finish(pending)
+        if n_streams > 1:      # leave nothing of this loop in flight on streams the caller does not know
+            for st in streams:
+                main.wait_stream(st)
+            main.wait_stream(collector)
     out.update(rte_avg=rte_meter.avg, rte_var=rte_meter.var, rre_avg=rre_meter.avg, rre_var=rre_meter.var,
                success_rate=success_meter.avg, n_pairs=success_meter.count, feat_time=t_feat, reg_time=t_reg)
     return out
