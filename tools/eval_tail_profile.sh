@@ -1,3 +1,4 @@
+# kernel stats + host profile of the packaged eval loop (configs[4]) on the GPU box:  gpurun -- "bash tools/eval_tail_profile.sh"
 python3 tools/micro/eval_tail_probe.py > gpurun_out/r05_eval_probe.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof_eval

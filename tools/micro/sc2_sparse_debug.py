@@ -1,4 +1,5 @@
-"""Debug: gcl_sc2_confidence_sparse vs gcl_sc2_confidence after 1 and 20 products; scratch contents vs a torch rebuild."""
+"""Debug: gcl_sc2_confidence_sparse vs gcl_sc2_confidence after 1 and 20 products; scratch contents vs a torch rebuild.
+(This is how the count / fill predicate mismatch of the first version was found: profiles/r05_conv_experiments.txt 52.)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -37,7 +38,7 @@ for n in (1500, 8000):
             ints = scratch[: (16 * n + 64) * 4].view(torch.int32)
             count, offset, ovf = ints[:8 * n], ints[8 * n:16 * n], ints[16 * n]
             total = int(count.sum())
-            print(f"   overflow {int(ovf)} total nnz {total} ({total / n / n:.4f} of n^2) offset ok {bool(torch.equal(offset.long(), torch.cumsum(count.long(), 0) - count.long()))}")
+            print(f"   overflow {int(ovf)} total nnz {total} ({total / n / n:.4f} of n^2) segments disjoint {bool(((torch.sort(offset.long())[0][1:] - (torch.sort(offset.long())[0] + count.long()[torch.sort(offset.long())[1]])[:-1]) >= 0).all())}")
             # torch rebuild of the counts (fp32 arithmetic as the kernel's)
             ds = torch.cdist(s.double(), s.double()).float(); dt = torch.cdist(t.double(), t.double()).float()
             ds = (s[:, None, :] - s[None, :, :]).pow(2).sum(-1).sqrt(); dt = (t[:, None, :] - t[None, :, :]).pow(2).sum(-1).sqrt()
@@ -49,7 +50,9 @@ for n in (1500, 8000):
             ent = scratch[(16 * n + 64) * 4:(16 * n + 64) * 4 + total * 8].view(torch.int32).view(-1, 2)
             print(f"   entry column range {int(ent[:, 0].min())} .. {int(ent[:, 0].max())}")
             vals = ent[:, 1].contiguous().view(torch.float32)
-            segid = torch.repeat_interleave(torch.arange(8 * n, device=dev), count.long())
+            # (a workgroup's range of the entry buffer is reserved atomically: walk the segments in offset order)
+            perm = torch.sort(offset.long())[1]
+            segid = torch.repeat_interleave(perm, count.long()[perm])
             part_from_entries = torch.zeros(8 * n, device=dev, dtype=torch.float64).index_add_(0, segid, vals.double())
             print(f"   sum of entries per segment vs dense partial {(part_from_entries - res[0][1].double()).abs().max().item():.3e}; vs sparse partial {(part_from_entries - res[1][1].double()).abs().max().item():.3e}")
             rows = segid % n

@@ -1,5 +1,5 @@
 # eval-tail probe + presplit-threshold experiment (bound mode writes the planes of every BatchNorm output >= the threshold)
-bash tools/r05_run4.sh > gpurun_out/r05_run4_out.txt 2>&1
+bash tools/eval_tail_profile.sh > gpurun_out/r05_run4_out.txt 2>&1
 tail -70 gpurun_out/r05_run4_out.txt
 B="bench.py --no-cpu-baseline --no-secondary"
 for i in 1 2; do
