@@ -64,7 +64,7 @@ out = {"_source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate pas
                   "hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 averaged over launches (gfx950: FETCH_SIZE "
                   "counts half of a 16-B/lane stream -- MI355X_MICROARCH.md 'HBM'; Infinity-Cache hits are included)"}
 for n in fe:
-    if n.startswith(("k_conv", "k_bn", "k_stem", "k_amax")):
+    if n.startswith(("k_conv", "k_bn", "k_stem", "k_amax", "k_bwd_weight", "k_split", "k_kernel_map", "k_permute")):
         f = sum(fe[n]["FETCH_SIZE"]) / len(fe[n]["FETCH_SIZE"])
         w = sum(wr[n]["WRITE_SIZE"]) / len(wr[n]["WRITE_SIZE"]) if n in wr else 0.0
         out[n] = {"launches": len(fe[n]["FETCH_SIZE"]), "fetch_size_kb_avg": round(f, 1), "write_size_kb_avg": round(w, 1),
