@@ -23,7 +23,7 @@ from .. import _lib
 PLAN_ENABLED = os.environ.get("GCL_PLAN", "1") == "1"
 # weight gradients of the plan's backward pass on a second stream ("0" off, "1" same priority [default], "low" lowest
 # priority): measured 14.48 -> 13.72 ms per step (same box, alternating runs; the optimizer is their only consumer)
-AUX_STREAM = {"0": "", "1": "1", "low": "low", "high": "high"}[os.environ.get("GCL_PLAN_AUX", "1")]
+AUX_STREAM = {"0": "", "1": "1", "low": "low", "high": "high"}[os.environ.get("GCL_PLAN_AUX", "low")]      # "1": normal priority
 
 
 def _addr(t):
