@@ -78,16 +78,18 @@ def forward_clouds(model, clouds):
     return list(torch.split(out, [len(f) for f, _ in clouds]))
 
 
-def forward_clouds_stream(model, cloud_sets, device=None, depth=2, exec_streams=None):
+def forward_clouds_stream(model, cloud_sets, device=None, depth=3, exec_streams=None):
     """Features of successive cloud sets (an iterable of lists of (F, coords) as ``forward_clouds`` takes them), one forward
     pass per set, with the COORDINATE MAPS of the next sets built ahead: a helper thread copies set i + 1 to the device and
     makes its ``gcl_maps_build`` call on a side stream (the call carries the pass's host syncs -- level sizes -- and runs
     with the interpreter lock released) while the main thread enqueues the forward pass of set i.  A pass over one pair of
     35 k voxels is bound by exactly that chain (scripts/test_kitti.py:141-152 runs pair after pair); the features are those
     of ``forward_clouds`` bit for bit (same maps, same launches).  Yields one list of per-cloud feature tensors per set.
-    ``exec_streams`` (default ``GCL_FWD_STREAMS`` = 2): the passes themselves alternate over that many streams -- a pass over
+    ``exec_streams`` (default ``GCL_FWD_STREAMS`` = 3): the passes themselves alternate over that many streams -- a pass over
     one pair is a chain of ~25 dependent launches that leaves most of the chip idle, and the passes of different sets are
-    independent; the caller's stream is made to wait for a set's pass before the set is yielded."""
+    independent; the caller's stream is made to wait for a set's pass before the set is yielded.  One pair per pass, M
+    voxels/s (tools/micro/fwd_stream_probe.py): one call per pair 21.3; 1 / 2 / 3 / 4 streams at depth 3: 24.4 / 33.9 / 40.7 /
+    26.9 (depth 2: 24.4 / 33.4 / 38.3 / 27.8)."""
     import concurrent.futures
     if model.training:
         raise RuntimeError("forward_clouds_stream needs model.eval(): batch statistics would mix the clouds")
@@ -99,7 +101,7 @@ def forward_clouds_stream(model, cloud_sets, device=None, depth=2, exec_streams=
             yield forward_clouds(model, [(f.to(dev), c.to(dev)) for f, c in clouds])
         return
     side = torch.cuda.Stream(device=dev)
-    n_exec = int(os.environ.get("GCL_FWD_STREAMS", "2")) if exec_streams is None else int(exec_streams)
+    n_exec = int(os.environ.get("GCL_FWD_STREAMS", "3")) if exec_streams is None else int(exec_streams)
     execs = [torch.cuda.Stream(device=dev) for _ in range(n_exec)] if n_exec > 1 else [None]
     ring = [{"arena": None, "free": None} for _ in range(depth + max(1, n_exec) + 1)]
 
