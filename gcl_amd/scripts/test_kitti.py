@@ -104,6 +104,15 @@ def forward_clouds_stream(model, cloud_sets, device=None, depth=3, exec_streams=
     n_exec = int(os.environ.get("GCL_FWD_STREAMS", "3")) if exec_streams is None else int(exec_streams)
     execs = [torch.cuda.Stream(device=dev) for _ in range(n_exec)] if n_exec > 1 else [None]
     ring = [{"arena": None, "free": None} for _ in range(depth + max(1, n_exec) + 1)]
+    # everything the caller has enqueued so far (parameter updates, the inputs themselves when they are device tensors) comes
+    # first on the helper's stream and on the execution streams too
+    with torch.cuda.device(dev):
+        started = torch.cuda.Event()
+        started.record(torch.cuda.current_stream())
+        side.wait_event(started)
+        for e in execs:
+            if e is not None:
+                e.wait_event(started)
 
     def build(clouds, slot):
         with torch.cuda.device(dev), torch.cuda.stream(side):
