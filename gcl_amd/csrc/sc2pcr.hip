@@ -62,30 +62,26 @@ __global__ void __launch_bounds__(SC_TILE) k_sc_matvec(const float* __restrict__
 // ---- the same matvec over the NON-ZERO entries of the compatibility matrix, kept from one build (round 5) ---------------------
 // The power iteration multiplies the same n x n matrix 20 times and k_sc_matvec re-derives every entry each time from six
 // coordinates and two correctly rounded square roots (64 M entries at n = 8000: 74 us per product, 1.5 ms per registration).
-// Most entries are zero -- a pair of correspondences is compatible only when its two lengths agree to d_thre.  Build once:
-// count[chunk][i] non-zeros of row i in column chunk `chunk` (same eight chunks), an exclusive scan, the entries (column,
-// value) in ascending column order.  A product then walks a row's entries of a chunk in that order: the same non-zero terms
-// in the same order as k_sc_matvec -- the skipped terms are exact zeros -- so partial[][] is BITWISE what k_sc_matvec writes.
-// When the entries do not fit `cap` the flag `overflow` makes the product fall back to the dense loop.
+// Most entries are zero -- a pair of correspondences is compatible only when its two lengths agree to d_thre.  ONE build pass
+// keeps the non-zero entries (column, value) of row i in column chunk c (the same eight chunks) in ascending column order, in
+// that segment's own fixed place of `per` = chunk-length entries (an ELL layout: n^2 entries of address space, 512 MB at n =
+// 8000, of which only the non-zero ones are ever touched), and count[c][i].  A product then walks a segment in that order:
+// the same non-zero terms in the same order as k_sc_matvec -- the skipped terms are exact zeros -- so partial[][] is BITWISE
+// what k_sc_matvec writes.
 struct ScEntry { int j; float m; };
 __device__ __forceinline__ float sc_first_order(const P3& si, const P3& ti, const float* ts_row, float d2_thre) {
   const float cd = fabsf(dist3(si, P3{ts_row[0], ts_row[1], ts_row[2]}) - dist3(ti, P3{ts_row[3], ts_row[4], ts_row[5]}));
   return fmaxf(1.f - cd * cd / d2_thre, 0.f);
 }
-// PASS 0: count, PASS 1: fill (offsets from the scan)
-template <int PASS>
 __global__ void __launch_bounds__(SC_TILE) k_sc_sparse_build(const float* __restrict__ src, const float* __restrict__ tgt, int n,
-                                                             float d2_thre, int* count, const int* __restrict__ offset,
-                                                             ScEntry* entries, long long cap, int* overflow) {
+                                                             float d2_thre, int* count, ScEntry* entries) {
   __shared__ float ts[SC_TILE][6];
   const int i = blockIdx.x * SC_TILE + threadIdx.x;
   const bool ok = i < n;
   const P3 si = ok ? ld3(src, i) : P3{0, 0, 0}, ti = ok ? ld3(tgt, i) : P3{0, 0, 0};
   const int per = (n + SC_CHUNKS - 1) / SC_CHUNKS;
   const int j0 = blockIdx.y * per, j1 = min(n, j0 + per);
-  if (PASS == 1 && *overflow) return;      // uniform
-  long long pos = (PASS == 1 && ok) ? offset[(size_t)blockIdx.y * n + i] : 0;
-  const int room = (PASS == 1 && ok) ? count[(size_t)blockIdx.y * n + i] : 0;      // never write outside the own segment
+  ScEntry* const seg = entries + ((size_t)blockIdx.y * n + (ok ? i : 0)) * per;
   int cnt = 0;
   for (int jb = j0; jb < j1; jb += SC_TILE) {
     __syncthreads();
@@ -96,14 +92,15 @@ __global__ void __launch_bounds__(SC_TILE) k_sc_sparse_build(const float* __rest
     }
     __syncthreads();
     const int m = min(SC_TILE, j1 - jb);
-    // The ROUNDED value decides, in both passes alike: the empty asm makes it opaque.  Without it the compiler derives the
-    // predicate from intermediates (q < 1 instead of max(1 - q, 0) != 0) where the value itself is not needed, the two
-    // instantiations disagreed on borderline pairs (22 of 64000 segments at n = 8000), and a fill pass that finds one entry
-    // more than was counted writes into its neighbour's segment.  Four entries per trip, written out: the asm keeps the
+    // The ROUNDED value decides what is kept: the empty asm makes it opaque.  Without it the compiler derives the predicate
+    // from intermediates (q < 1 instead of max(1 - q, 0) != 0): an entry whose rounded value is not zero could be dropped, and
+    // the sums would differ from the dense kernel's in their last bits.  (The first, two-pass version of this build -- count,
+    // scan, fill -- failed on exactly that: its two instantiations disagreed on borderline pairs and the fill pass wrote into
+    // neighbouring segments; profiles/r05_conv_experiments.txt 52.)  Four entries per trip, written out: the asm keeps the
     // compiler from unrolling, and one entry is a dependent chain of two square roots and a division.
     auto take = [&](int q, float v) {
       if (v != 0.f) {      // (a NaN entry counts as non-zero: it must reach the sum as it does in the dense loop)
-        if (PASS == 1 && cnt < room) entries[pos + cnt] = ScEntry{jb + q, v};
+        if (ok) seg[cnt] = ScEntry{jb + q, v};
         ++cnt;
       }
     };
@@ -123,72 +120,21 @@ __global__ void __launch_bounds__(SC_TILE) k_sc_sparse_build(const float* __rest
       take(q, v);
     }
   }
-  if (PASS == 0) {
-    // where this workgroup's segments live: an exclusive scan of its 256 counts + ONE atomic reservation of their total.
-    // (Which range a workgroup gets depends on timing; nothing else does -- a segment's entries and their order are fixed.)
-    __shared__ int sc[SC_TILE];
-    __shared__ unsigned base;
-    __syncthreads();
-    sc[threadIdx.x] = ok ? cnt : 0;
-    __syncthreads();
-    for (int o = 1; o < SC_TILE; o <<= 1) {
-      const int add = (int)threadIdx.x >= o ? sc[threadIdx.x - o] : 0;
-      __syncthreads();
-      sc[threadIdx.x] += add;
-      __syncthreads();
-    }
-    if (threadIdx.x == SC_TILE - 1) {
-      base = atomicAdd((unsigned*)(overflow + 1), (unsigned)sc[SC_TILE - 1]);
-      if ((long long)base + sc[SC_TILE - 1] > cap) atomicExch(overflow, 1);
-    }
-    __syncthreads();
-    if (ok) {
-      count[(size_t)blockIdx.y * n + i] = cnt;
-      ((int*)offset)[(size_t)blockIdx.y * n + i] = (int)(base + (unsigned)(sc[threadIdx.x] - cnt));
-    }
-  }
-  if (PASS == 1) {      // (cannot happen with the barrier above; a short segment is padded with exact zeros all the same)
-    for (int q = cnt; q < room; ++q) entries[pos + q] = ScEntry{0, 0.f};
-  }
+  if (ok) count[(size_t)blockIdx.y * n + i] = cnt;
 }
-__global__ void __launch_bounds__(SC_TILE) k_sc_matvec_sparse(const float* __restrict__ src, const float* __restrict__ tgt,
-                                                              int n, float d2_thre, const float* __restrict__ x,
-                                                              const int* __restrict__ done, float* partial,
-                                                              const int* __restrict__ count, const int* __restrict__ offset,
-                                                              const ScEntry* __restrict__ entries,
-                                                              const int* __restrict__ overflow) {
+__global__ void __launch_bounds__(SC_TILE) k_sc_matvec_sparse(int n, const float* __restrict__ x, const int* __restrict__ done,
+                                                              float* partial, const int* __restrict__ count,
+                                                              const ScEntry* __restrict__ entries) {
   if (*done) return;
   const int i = blockIdx.x * SC_TILE + threadIdx.x;
-  if (!*overflow) {
-    if (i >= n) return;
-    const size_t seg = (size_t)blockIdx.y * n + i;
-    const ScEntry* e = entries + offset[seg];
-    const int cnt = count[seg];
-    float acc = 0.f;
-    for (int q = 0; q < cnt; ++q) acc += e[q].m * x[e[q].j];
-    partial[seg] = acc;
-    return;
-  }
-  // the entries did not fit: the dense loop of k_sc_matvec
-  __shared__ float ts[SC_TILE][7];
-  const bool ok = i < n;
-  const P3 si = ok ? ld3(src, i) : P3{0, 0, 0}, ti = ok ? ld3(tgt, i) : P3{0, 0, 0};
+  if (i >= n) return;
   const int per = (n + SC_CHUNKS - 1) / SC_CHUNKS;
-  const int j0 = blockIdx.y * per, j1 = min(n, j0 + per);
+  const size_t seg = (size_t)blockIdx.y * n + i;
+  const ScEntry* e = entries + seg * per;
+  const int cnt = count[seg];
   float acc = 0.f;
-  for (int jb = j0; jb < j1; jb += SC_TILE) {
-    __syncthreads();
-    const int j = jb + threadIdx.x;
-    if (j < j1) {
-      ts[threadIdx.x][0] = src[3 * j]; ts[threadIdx.x][1] = src[3 * j + 1]; ts[threadIdx.x][2] = src[3 * j + 2];
-      ts[threadIdx.x][3] = tgt[3 * j]; ts[threadIdx.x][4] = tgt[3 * j + 1]; ts[threadIdx.x][5] = tgt[3 * j + 2];
-      ts[threadIdx.x][6] = x[j];
-    }
-    __syncthreads();
-    const int m = min(SC_TILE, j1 - jb);
-    for (int q = 0; q < m; ++q) acc += sc_first_order(si, ti, ts[q], d2_thre) * ts[q][6];
-  }
-  if (ok) partial[(size_t)blockIdx.y * n + i] = acc;
+  for (int q = 0; q < cnt; ++q) acc += e[q].m * x[e[q].j];
+  partial[seg] = acc;
 }
 
 // one workgroup: y = sum of the partials, x_new = y / (|y| + 1e-6), done = allclose(x_new, x_old) (:176-181)
@@ -690,12 +636,10 @@ int gcl_sc2_confidence(const float* src, const float* tgt, int32_t n, float d_th
   return GCL_OK;
 }
 
-// entries kept per registration: 16 M (128 MB) or n^2, whichever is smaller; beyond that the products run dense
-static long long sc_sparse_cap(int n) { return std::min<long long>((long long)n * n, 16ll << 20); }
-
 int64_t gcl_sc2_confidence_scratch_bytes(int32_t n) {
   if (n <= 0 || n > SC_MAXN) return 0;
-  return (long long)(2 * SC_CHUNKS * n + 64) * 4 + sc_sparse_cap(n) * (long long)sizeof(ScEntry);
+  const long long per = cdiv(n, SC_CHUNKS);
+  return (long long)SC_CHUNKS * n * 4 + 256 + (long long)SC_CHUNKS * n * per * (long long)sizeof(ScEntry);
 }
 
 int gcl_sc2_confidence_sparse(const float* src, const float* tgt, int32_t n, float d_thre, int32_t num_iterations,
@@ -705,21 +649,13 @@ int gcl_sc2_confidence_sparse(const float* src, const float* tgt, int32_t n, flo
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)cdiv(n, SC_TILE), SC_CHUNKS);
   int* count = (int*)scratch;
-  int* offset = count + SC_CHUNKS * n;
-  int* overflow = offset + SC_CHUNKS * n;
-  ScEntry* entries = (ScEntry*)(overflow + 64);
-  const long long cap = sc_sparse_cap(n);
+  ScEntry* entries = (ScEntry*)((char*)scratch + (((size_t)SC_CHUNKS * n * 4 + 255) & ~(size_t)255));
   const float d2 = d_thre * d_thre;
-  if (num_iterations > 0) {
-    GCL_CHECK_HIP(hipMemsetAsync(overflow, 0, 2 * sizeof(int), st));      // [0] overflow flag, [1] entries reserved so far
-    hipLaunchKernelGGL(k_sc_sparse_build<0>, grid, dim3(SC_TILE), 0, st, src, tgt, n, d2, count, (const int*)offset, entries, cap,
-                       overflow);
-    hipLaunchKernelGGL(k_sc_sparse_build<1>, grid, dim3(SC_TILE), 0, st, src, tgt, n, d2, count, (const int*)offset, entries, cap,
-                       overflow);
-  }
+  if (num_iterations > 0)
+    hipLaunchKernelGGL(k_sc_sparse_build, grid, dim3(SC_TILE), 0, st, src, tgt, n, d2, count, entries);
   for (int it = 0; it < num_iterations; ++it) {
-    hipLaunchKernelGGL(k_sc_matvec_sparse, grid, dim3(SC_TILE), 0, st, src, tgt, n, d2, (const float*)x, (const int*)done,
-                       partial, (const int*)count, (const int*)offset, (const ScEntry*)entries, (const int*)overflow);
+    hipLaunchKernelGGL(k_sc_matvec_sparse, grid, dim3(SC_TILE), 0, st, n, (const float*)x, (const int*)done, partial,
+                       (const int*)count, (const ScEntry*)entries);
     hipLaunchKernelGGL(k_sc_normalize, dim3(1), dim3(1024), 0, st, (const float*)partial, n, x, done);
   }
   GCL_CHECK_LAUNCH();

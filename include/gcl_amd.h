@@ -517,10 +517,11 @@ int32_t gcl_sc2_chunks(void);
 int32_t gcl_sc2_refine_partial_len(void);
 int gcl_sc2_confidence(const float* src, const float* tgt, int32_t n, float d_thre, int32_t num_iterations,
                        float* partial, float* x, int32_t* done, void* stream);
-/* the same power iteration over the NON-ZERO entries of the compatibility matrix, built once per registration (count, scan,
- * fill; scratch: gcl_sc2_confidence_scratch_bytes(n) bytes): the same non-zero terms in the same order, i.e. bitwise the
- * result of gcl_sc2_confidence, without re-deriving 64 M entries (two square roots each) in every one of the 20 products;
- * falls back to the dense products on the device when the entries exceed the scratch */
+/* the same power iteration over the NON-ZERO entries of the compatibility matrix, kept from ONE build pass per registration
+ * in an ELL layout (every (row, column chunk) segment has its own place of chunk-length entries; scratch:
+ * gcl_sc2_confidence_scratch_bytes(n) bytes = n^2 entries of address space, 512 MB at n = 8000, of which only the non-zero
+ * ones are touched): the same non-zero terms in the same order, i.e. bitwise the result of gcl_sc2_confidence, without
+ * re-deriving 64 M entries (two square roots each) in every one of the 20 products */
 int64_t gcl_sc2_confidence_scratch_bytes(int32_t n);
 int gcl_sc2_confidence_sparse(const float* src, const float* tgt, int32_t n, float d_thre, int32_t num_iterations,
                               float* partial, float* x, int32_t* done, void* scratch, void* stream);

@@ -1482,8 +1482,8 @@ def test_sc2pcr_matches_reference_output_and_oracle_stages(path):
 def test_sc2pcr_confidence_sparse_equals_dense_bitwise(n, inlier, noise):
     """gcl_sc2_confidence_sparse (the compatibility matrix's non-zero entries kept from ONE build; 20 products over them)
     == gcl_sc2_confidence (every entry re-derived in every product), bit for bit: the same non-zero terms in the same order,
-    the skipped ones exact zeros.  (8000, all inliers, no noise): 64 M non-zeros exceed the 16 M kept -- the products fall
-    back to the dense loop on the device."""
+    the skipped ones exact zeros.  (8000, all inliers, no noise): every one of the 64 M entries is non-zero -- each segment
+    of the ELL layout is full."""
     from gcl_amd import _lib
     lib = _lib.load()
     rng = np.random.RandomState(n)
