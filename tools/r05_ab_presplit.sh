@@ -1,6 +1,5 @@
-# eval-tail probe + presplit-threshold experiment (bound mode writes the planes of every BatchNorm output >= the threshold)
-bash tools/eval_tail_profile.sh > gpurun_out/r05_run4_out.txt 2>&1
-tail -70 gpurun_out/r05_run4_out.txt
+# experiment 49: presplit threshold with producer-written planes (bound mode writes the planes of every BatchNorm output >= the
+# threshold), alternating with the default and with the round's first commit (.ab_prev/, tools/ab_prev.sh export)
 B="bench.py --no-cpu-baseline --no-secondary"
 for i in 1 2; do
   python3 $B > gpurun_out/r05_b3_c128_$i.json 2> gpurun_out/r05_b3_c128_$i.err
