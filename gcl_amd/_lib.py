@@ -171,11 +171,12 @@ TRAINING_STEP_SOURCES = ("coords.hip", "conv.hip", "norm.hip", "plan.hip")      
 
 def source_hash():
     """sha256 (16 hex digits) over the sources of the TRAINING step's kernels (maps, convolutions, BatchNorm, the plan) + the
-    shared headers: stamps profiles/pmc_summary.json, so that bench.py can tell whether the counter figures it quotes were
-    collected on the kernels it is timing.  (loss.hip / data.hip / sc2pcr.hip hold no kernel the summary lists.)"""
+    shared device header: stamps profiles/pmc_summary.json, so that bench.py can tell whether the counter figures it quotes
+    were collected on the kernels it is timing.  (loss.hip / data.hip / sc2pcr.hip hold no kernel the summary lists; the public
+    header declares entry points, it holds no kernel code.)"""
     import hashlib
     h = hashlib.sha256()
-    for path in [os.path.join(CSRC, s) for s in TRAINING_STEP_SOURCES] + [os.path.join(CSRC, "common.h"), HEADER]:
+    for path in [os.path.join(CSRC, s) for s in TRAINING_STEP_SOURCES] + [os.path.join(CSRC, "common.h")]:
         with open(path, "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
