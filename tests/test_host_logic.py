@@ -186,3 +186,29 @@ def test_bench_secondary_figures_cannot_take_the_headline_down():
                        timeout=240)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1 and "error" in json.loads(lines[0])
+
+
+def test_counter_figures_are_quoted_only_for_the_sources_they_were_collected_on(tmp_path, monkeypatch):
+    """profiles/pmc_summary.json is stamped with a hash of the training step's kernel sources (_lib.source_hash); bench.py's
+    roofline quotes `traffic` / `mfma_busy` from it only when its own sources carry the same hash (VERDICT round 4, weak #9:
+    a pasted number must not outlive the kernels it was measured on)."""
+    import importlib.util
+    import json
+    from gcl_amd import _lib
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    h = _lib.source_hash()
+    assert len(h) == 16 and h == _lib.source_hash()
+    committed = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))
+    assert "_csrc_sha16" in committed
+    prof = [("k_conv_fwd_dma<2,true,false>", 0.15, None, 1000000, 128, 128, 70000, 70000, 27)]
+    for stamp, quoted in ((h, True), ("0" * 16, False)):
+        root = tmp_path / stamp
+        (root / "profiles").mkdir(parents=True)
+        json.dump({"_csrc_sha16": stamp, "k_conv_fwd_dma<2,true,false>": {"hbm_bytes_per_launch": 123456, "mfma_busy": 0.25}},
+                  open(root / "profiles" / "pmc_summary.json", "w"))
+        monkeypatch.setattr(bench, "ROOT", str(root))
+        r = bench.roofline_of(prof, "fp16x3")
+        assert (r["traffic"], r["mfma_busy"]) == ((123456, 0.25) if quoted else (None, None)), (stamp, r["traffic"])
+        assert ("collected on these kernel sources" in r["note"]) == quoted
