@@ -310,66 +310,103 @@ __global__ void __launch_bounds__(64) k_circle_group_bwd(const float* __restrict
 }
 
 // ---- pairwise squared distance + row minimum ----------------------------------------------------------
+// Round 5 form.  A thread owns ONE A row, held as (a_c, a_c) register pairs; the B rows come two at a time from a copy
+// of B[rows_b] interleaved as [row pair][channel][2] (k_nn_interleave), read with SCALAR loads (the address is the same
+// for the whole wave), so that one v_pk_add_f32 / v_pk_fma_f32 with an SGPR-pair operand serves two B rows and the loop
+// touches no LDS: 38 us for 5000 x 5000 x 32 against 66 us of the LDS-broadcast form (tools/micro/nn_variants.hip, which
+// also holds the five other forms tried).  The distance keeps the exact (a - b)^2 form of lib/metrics.py:22-25 (no
+// |a|^2 + |b|^2 - 2ab) as ONE chain per pair, written out (nn_chain8) so that the compiler has no choice in it:
+// d2 = (a_0 - b_0)^2 rounded, then d2 = fma(a_c - b_c, a_c - b_c, d2) for c = 1 .. C - 1.
+// Grid = (64-row A tiles) x (B chunks, an even number of rows each); the four waves of a workgroup take every fourth row
+// pair of the chunk.  A chunk's (minimum, lowest index) goes to part_v / part_i [chunk][row]; k_nn_merge folds the chunks
+// in ascending order (strict <: the lowest index wins ties, as torch.min over the reference's distance matrix does).
 constexpr int NN_TA = 64;    // A rows per workgroup
-constexpr int NN_TB = 128;   // B rows per LDS tile
+constexpr int NN_GRAN = 8;   // B rows per chunk: a multiple of (4 waves x 2 rows)
+typedef float nn_f2 __attribute__((ext_vector_type(2)));
 
-// Grid = (A tiles of 64 rows) x (B chunks): every workgroup scans ONE chunk of B (a multiple of NN_TB rows) for its 64 A
-// rows, so that a 1024 x 1024 search is 128 workgroups instead of 16 and a 5000 x 5000 one ~800 (256 CUs).  A chunk's
-// (minimum, lowest index) goes to part_v / part_i [chunk][row]; k_nn_merge folds the chunks in ascending order (strict <:
-// the lowest index wins ties, as torch.min over the reference's distance matrix does).  With one chunk the result is
-// written directly.  The distance keeps the exact (a - b)^2 form of lib/metrics.py:22-25 (no |a|^2 + |b|^2 - 2ab).
+// eight channels of the chain  acc = fma(a_c - b_c, a_c - b_c, acc)  for two B rows at once; every dependent pair of packed
+// operations has one independent instruction between them (the packed-fp32 forwarding hazard of gfx950 needs one wait
+// state: the compiler writes s_nop 0 there, and does not look inside an asm block).
+#define NN_SUB(D, A, B) "v_pk_add_f32 " D ", " A ", " B " neg_lo:[0,1] neg_hi:[0,1]\n"
+#define NN_FMA(D) "v_pk_fma_f32 %[acc], " D ", " D ", %[acc]\n"
+template <bool FIRST>
+__device__ __forceinline__ void nn_chain8(nn_f2& acc, const nn_f2* a, const nn_f2* b) {
+  nn_f2 d0, d1;
+  if (FIRST)
+    asm volatile(NN_SUB("%[d0]", "%[a0]", "%[b0]") NN_SUB("%[d1]", "%[a1]", "%[b1]")
+                 "v_pk_mul_f32 %[acc], %[d0], %[d0]\n"
+                 NN_SUB("%[d0]", "%[a2]", "%[b2]") NN_FMA("%[d1]") NN_SUB("%[d1]", "%[a3]", "%[b3]") NN_FMA("%[d0]")
+                 NN_SUB("%[d0]", "%[a4]", "%[b4]") NN_FMA("%[d1]") NN_SUB("%[d1]", "%[a5]", "%[b5]") NN_FMA("%[d0]")
+                 NN_SUB("%[d0]", "%[a6]", "%[b6]") NN_FMA("%[d1]") NN_SUB("%[d1]", "%[a7]", "%[b7]") NN_FMA("%[d0]")
+                 "s_nop 0\n" NN_FMA("%[d1]")
+                 : [acc] "=&v"(acc), [d0] "=&v"(d0), [d1] "=&v"(d1)
+                 : [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]), [a4] "v"(a[4]), [a5] "v"(a[5]),
+                   [a6] "v"(a[6]), [a7] "v"(a[7]), [b0] "s"(b[0]), [b1] "s"(b[1]), [b2] "s"(b[2]), [b3] "s"(b[3]),
+                   [b4] "s"(b[4]), [b5] "s"(b[5]), [b6] "s"(b[6]), [b7] "s"(b[7]));
+  else
+    asm volatile(NN_SUB("%[d0]", "%[a0]", "%[b0]") NN_SUB("%[d1]", "%[a1]", "%[b1]") NN_FMA("%[d0]")
+                 NN_SUB("%[d0]", "%[a2]", "%[b2]") NN_FMA("%[d1]") NN_SUB("%[d1]", "%[a3]", "%[b3]") NN_FMA("%[d0]")
+                 NN_SUB("%[d0]", "%[a4]", "%[b4]") NN_FMA("%[d1]") NN_SUB("%[d1]", "%[a5]", "%[b5]") NN_FMA("%[d0]")
+                 NN_SUB("%[d0]", "%[a6]", "%[b6]") NN_FMA("%[d1]") NN_SUB("%[d1]", "%[a7]", "%[b7]") NN_FMA("%[d0]")
+                 "s_nop 0\n" NN_FMA("%[d1]")
+                 : [acc] "+v"(acc), [d0] "=&v"(d0), [d1] "=&v"(d1)
+                 : [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]), [a4] "v"(a[4]), [a5] "v"(a[5]),
+                   [a6] "v"(a[6]), [a7] "v"(a[7]), [b0] "s"(b[0]), [b1] "s"(b[1]), [b2] "s"(b[2]), [b3] "s"(b[3]),
+                   [b4] "s"(b[4]), [b5] "s"(b[5]), [b6] "s"(b[6]), [b7] "s"(b[7]));
+}
+template <int C>
+__global__ void __launch_bounds__(256) k_nn_interleave(const float* __restrict__ b, const long long* __restrict__ rows_b,
+                                                       int mb, float* __restrict__ bi) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;       // one (row pair, channel)
+  const int p = (int)(e / C), c = (int)(e % C);
+  if (2 * p >= mb) return;
+  const long long r0 = rows_b ? rows_b[2 * p] : (long long)(2 * p);
+  float v1 = 0.f;                                                        // an odd count's last partner: never compared
+  if (2 * p + 1 < mb) v1 = b[(rows_b ? rows_b[2 * p + 1] : (long long)(2 * p + 1)) * C + c];
+  *reinterpret_cast<nn_f2*>(bi + 2 * e) = nn_f2{b[r0 * C + c], v1};
+}
+
 template <int C>
 __global__ void __launch_bounds__(256) k_nn_rowmin(const float* __restrict__ a, const long long* __restrict__ rows_a,
-                                                   int ma, const float* __restrict__ b,
-                                                   const long long* __restrict__ rows_b, int mb, int chunk, int l2,
+                                                   int ma, const float* __restrict__ bi_, int mb, int chunk, int l2,
                                                    float* __restrict__ out_v, int* __restrict__ out_i) {
-  __shared__ __attribute__((aligned(16))) float bt[NN_TB][C];
   __shared__ float rv[4][NN_TA];
   __shared__ int ri[4][NN_TA];
-  const int t = threadIdx.x, ar = t & 63, cg = t >> 6;
+  const nn_f2* __restrict__ bi = reinterpret_cast<const nn_f2*>(bi_);
+  const int t = threadIdx.x, ar = t & 63, cg = __builtin_amdgcn_readfirstlane(t >> 6);
   const int arow = blockIdx.x * NN_TA + ar;
-  float av[C];
+  nn_f2 av[C];
   {
     long long src = (arow < ma) ? (rows_a ? rows_a[arow] : (long long)arow) : -1;
 #pragma unroll
     for (int q = 0; q < C / 4; ++q) {
       float4 v = make_float4(0, 0, 0, 0);
       if (src >= 0) v = reinterpret_cast<const float4*>(a + src * C)[q];
-      av[4 * q] = v.x; av[4 * q + 1] = v.y; av[4 * q + 2] = v.z; av[4 * q + 3] = v.w;
+      av[4 * q] = nn_f2{v.x, v.x}; av[4 * q + 1] = nn_f2{v.y, v.y};
+      av[4 * q + 2] = nn_f2{v.z, v.z}; av[4 * q + 3] = nn_f2{v.w, v.w};
     }
   }
   float best = INFINITY;
   int besti = 0;
   const int jb = blockIdx.y * chunk;
   const int je = (jb + chunk < mb) ? jb + chunk : mb;
-  for (int j0 = jb; j0 < je; j0 += NN_TB) {
-    __syncthreads();
-    for (int e = t; e < NN_TB * (C / 4); e += 256) {
-      int r = e / (C / 4), q = e % (C / 4);
-      float4 v = make_float4(0, 0, 0, 0);
-      if (j0 + r < je) {
-        long long src = rows_b ? rows_b[j0 + r] : (long long)(j0 + r);
-        v = reinterpret_cast<const float4*>(b + src * C)[q];
-      }
-      reinterpret_cast<float4*>(&bt[r][0])[q] = v;
-    }
-    __syncthreads();
-    int jn = (je - j0 < NN_TB) ? je - j0 : NN_TB;
-    for (int r = cg; r < jn; r += 4) {
-      float d2 = 0.f;
+  for (int p = jb / 2 + cg; 2 * p < je; p += 4) {       // ascending within a thread: strict < keeps the lowest index
+    const nn_f2* __restrict__ row = bi + (long long)p * C;
+    nn_f2 bv[C];
 #pragma unroll
-      for (int q = 0; q < C / 4; ++q) {
-        float4 v = reinterpret_cast<const float4*>(&bt[r][0])[q];
-        float d0 = av[4 * q] - v.x, d1 = av[4 * q + 1] - v.y, d2a = av[4 * q + 2] - v.z, d3 = av[4 * q + 3] - v.w;
-        d2 += d0 * d0;
-        d2 += d1 * d1;
-        d2 += d2a * d2a;
-        d2 += d3 * d3;
-      }
-      if (d2 < best) {   // strict: ascending j within a thread keeps the lowest index on ties
-        best = d2;
-        besti = j0 + r;
-      }
+    for (int c = 0; c < C; ++c) bv[c] = row[c];
+    nn_f2 acc;
+    nn_chain8<true>(acc, av, bv);
+#pragma unroll
+    for (int c = 8; c < C; c += 8) nn_chain8<false>(acc, av + c, bv + c);
+    asm volatile("s_nop 0" : "+v"(acc));      // the last packed write before the compiler's own reads of acc
+    if (acc.x < best) {
+      best = acc.x;
+      besti = 2 * p;
+    }
+    if (2 * p + 1 < je && acc.y < best) {
+      best = acc.y;
+      besti = 2 * p + 1;
     }
   }
   rv[cg][ar] = best;
@@ -377,22 +414,22 @@ __global__ void __launch_bounds__(256) k_nn_rowmin(const float* __restrict__ a, 
   __syncthreads();
   if (cg == 0 && arow < ma) {
     float bv = rv[0][ar];
-    int bi = ri[0][ar];
+    int bix = ri[0][ar];
 #pragma unroll
     for (int w = 1; w < 4; ++w) {
       float v = rv[w][ar];
       int i2 = ri[w][ar];
-      if (v < bv || (v == bv && i2 < bi)) {
+      if (v < bv || (v == bv && i2 < bix)) {
         bv = v;
-        bi = i2;
+        bix = i2;
       }
     }
     if (gridDim.y == 1) {
       out_v[arow] = l2 ? sqrtf(bv + 1e-7f) : bv;
-      out_i[arow] = bi;
+      out_i[arow] = bix;
     } else {
       out_v[(long long)blockIdx.y * ma + arow] = bv;
-      out_i[(long long)blockIdx.y * ma + arow] = bi;
+      out_i[(long long)blockIdx.y * ma + arow] = bix;
     }
   }
 }
@@ -414,15 +451,17 @@ __global__ void __launch_bounds__(256) k_nn_merge(const float* __restrict__ part
   argmin[r] = bi;
 }
 
-// B rows per chunk: as many chunks as it takes to put ~1024 workgroups on the chip, each a multiple of NN_TB rows
+// B rows per chunk: as many chunks as it takes to put ~1536 workgroups on the chip, each a multiple of NN_GRAN rows
 static int nn_chunk_rows(int ma, int mb) {
   const long long a_tiles = cdiv(ma, NN_TA);
-  long long want = cdiv(1024, a_tiles);                 // chunks wanted
-  const long long tiles_b = cdiv(mb, NN_TB);
-  if (want > tiles_b) want = tiles_b;
+  long long want = cdiv(1536, a_tiles);                 // chunks wanted
+  const long long grans = cdiv(mb, NN_GRAN);
+  if (want > grans) want = grans;
   if (want < 1) want = 1;
-  return (int)(cdiv(tiles_b, want) * NN_TB);
+  return (int)(cdiv(grans, want) * NN_GRAN);
 }
+// scratch (32-bit words): the interleaved copy of B, then the chunks' partial (minimum, index) pairs
+static long long nn_interleaved_words(int mb, int c) { return (long long)cdiv(mb, 2) * 2 * c; }
 
 // ---- negative-pair mask ---------------------------------------------------------------------------------
 __global__ void k_table_fill2(Slot* t, long long cap) {
@@ -633,7 +672,7 @@ int64_t gcl_nn_rowmin_scratch_len(int32_t ma, int32_t mb) {
   if (ma <= 0 || mb <= 0) return 0;
   const int chunk = nn_chunk_rows(ma, mb);
   const long long n_chunks = cdiv(mb, chunk);
-  return n_chunks > 1 ? 2 * n_chunks * (long long)ma : 0;
+  return nn_interleaved_words(mb, 64) + (n_chunks > 1 ? 2 * n_chunks * (long long)ma : 0);   // sized for the widest rows
 }
 
 int gcl_nn_rowmin(const float* a, const int64_t* rows_a, int32_t ma, const float* b, const int64_t* rows_b,
@@ -641,16 +680,22 @@ int gcl_nn_rowmin(const float* a, const int64_t* rows_a, int32_t ma, const float
   GCL_CHECK_ARG(a && b && dmin && argmin, "gcl_nn_rowmin: null pointer");
   GCL_CHECK_ARG(ma > 0 && mb > 0, "gcl_nn_rowmin: empty input");
   GCL_CHECK_ARG(c == 16 || c == 32 || c == 64, "gcl_nn_rowmin: feature width must be 16, 32 or 64 (got %d)", c);
+  GCL_CHECK_ARG(scratch, "gcl_nn_rowmin: scratch (int32[gcl_nn_rowmin_scratch_len]) is required");
   hipStream_t st = (hipStream_t)stream;
   const int chunk = nn_chunk_rows(ma, mb);
   const int n_chunks = (int)cdiv(mb, chunk);
-  GCL_CHECK_ARG(n_chunks == 1 || scratch, "gcl_nn_rowmin: scratch (int32[gcl_nn_rowmin_scratch_len]) is required");
   dim3 grid((unsigned)cdiv(ma, NN_TA), (unsigned)n_chunks);
-  float* pv = n_chunks > 1 ? (float*)scratch : dmin;
-  int* pi = n_chunks > 1 ? scratch + (long long)n_chunks * ma : argmin;
-#define LAUNCH_NN(CC)                                                                                     \
-  hipLaunchKernelGGL(k_nn_rowmin<CC>, grid, dim3(256), 0, st, a, (const long long*)rows_a, ma, b,         \
-                     (const long long*)rows_b, mb, chunk, l2, pv, pi)
+  float* bi = (float*)scratch;
+  int32_t* part = scratch + nn_interleaved_words(mb, 64);
+  float* pv = n_chunks > 1 ? (float*)part : dmin;
+  int* pi = n_chunks > 1 ? part + (long long)n_chunks * ma : argmin;
+  const unsigned il_grid = (unsigned)cdiv(cdiv(mb, 2) * c, 256);
+#define LAUNCH_NN(CC)                                                                                              \
+  do {                                                                                                             \
+    hipLaunchKernelGGL(k_nn_interleave<CC>, dim3(il_grid), dim3(256), 0, st, b, (const long long*)rows_b, mb, bi); \
+    hipLaunchKernelGGL(k_nn_rowmin<CC>, grid, dim3(256), 0, st, a, (const long long*)rows_a, ma, (const float*)bi, \
+                       mb, chunk, l2, pv, pi);                                                                     \
+  } while (0)
   if (c == 16) LAUNCH_NN(16);
   else if (c == 32) LAUNCH_NN(32);
   else LAUNCH_NN(64);

@@ -13,6 +13,7 @@
 #include "common.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -20,6 +21,7 @@ namespace gcl {
 
 constexpr int SC_TILE = 256;      // correspondences per LDS tile
 constexpr int SC_CHUNKS = 8;      // column chunks of the matvec (partials added in fixed order)
+constexpr int SC_MAXN = 8192;     // correspondences per registration (max_points = 8000 in the reference's configs)
 
 struct P3 { float x, y, z; };
 __device__ __forceinline__ float dist3(const P3& a, const P3& b) {
@@ -73,54 +75,113 @@ __device__ __forceinline__ float sc_first_order(const P3& si, const P3& ti, cons
   const float cd = fabsf(dist3(si, P3{ts_row[0], ts_row[1], ts_row[2]}) - dist3(ti, P3{ts_row[3], ts_row[4], ts_row[5]}));
   return fmaxf(1.f - cd * cd / d2_thre, 0.f);
 }
-__global__ void __launch_bounds__(SC_TILE) k_sc_sparse_build(const float* __restrict__ src, const float* __restrict__ tgt, int n,
-                                                             float d2_thre, int* count, ScEntry* entries) {
-  __shared__ float ts[SC_TILE][6];
-  const int i = blockIdx.x * SC_TILE + threadIdx.x;
-  const bool ok = i < n;
-  const P3 si = ok ? ld3(src, i) : P3{0, 0, 0}, ti = ok ? ld3(tgt, i) : P3{0, 0, 0};
+// One WAVE per row: lane = column, 64 columns per trip, the non-zero ones written in column order behind a ballot's prefix
+// count -- n x 8 waves (40 000 at n = 5000) instead of n x 8 threads (625 waves on 1024 SIMDs, every one of them a serial
+// chain of square roots and divisions): 191 -> 60 us.  A workgroup takes SB_ROWS rows of one column chunk and holds the
+// chunk's coordinates in LDS.
+constexpr int SB_ROWS = 16;
+constexpr int SB_PER_MAX = SC_MAXN / SC_CHUNKS;
+__global__ void __launch_bounds__(256) k_sc_sparse_build(const float* __restrict__ src, const float* __restrict__ tgt, int n,
+                                                         float d2_thre, int* count, ScEntry* entries) {
+  __shared__ float cs[6][SB_PER_MAX];
   const int per = (n + SC_CHUNKS - 1) / SC_CHUNKS;
-  const int j0 = blockIdx.y * per, j1 = min(n, j0 + per);
-  ScEntry* const seg = entries + ((size_t)blockIdx.y * n + (ok ? i : 0)) * per;
-  int cnt = 0;
-  for (int jb = j0; jb < j1; jb += SC_TILE) {
-    __syncthreads();
-    const int j = jb + threadIdx.x;
-    if (j < j1) {
-      ts[threadIdx.x][0] = src[3 * j]; ts[threadIdx.x][1] = src[3 * j + 1]; ts[threadIdx.x][2] = src[3 * j + 2];
-      ts[threadIdx.x][3] = tgt[3 * j]; ts[threadIdx.x][4] = tgt[3 * j + 1]; ts[threadIdx.x][5] = tgt[3 * j + 2];
-    }
-    __syncthreads();
-    const int m = min(SC_TILE, j1 - jb);
-    // The ROUNDED value decides what is kept: the empty asm makes it opaque.  Without it the compiler derives the predicate
-    // from intermediates (q < 1 instead of max(1 - q, 0) != 0): an entry whose rounded value is not zero could be dropped, and
-    // the sums would differ from the dense kernel's in their last bits.  (The first, two-pass version of this build -- count,
-    // scan, fill -- failed on exactly that: its two instantiations disagreed on borderline pairs and the fill pass wrote into
-    // neighbouring segments; profiles/r05_conv_experiments.txt 52.)  Four entries per trip, written out: the asm keeps the
-    // compiler from unrolling, and one entry is a dependent chain of two square roots and a division.
-    auto take = [&](int q, float v) {
-      if (v != 0.f) {      // (a NaN entry counts as non-zero: it must reach the sum as it does in the dense loop)
-        if (ok) seg[cnt] = ScEntry{jb + q, v};
-        ++cnt;
-      }
-    };
-    int q = 0;
-    for (; q + 4 <= m; q += 4) {
-      float v0 = sc_first_order(si, ti, ts[q], d2_thre), v1 = sc_first_order(si, ti, ts[q + 1], d2_thre);
-      float v2 = sc_first_order(si, ti, ts[q + 2], d2_thre), v3 = sc_first_order(si, ti, ts[q + 3], d2_thre);
-      asm("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));
-      take(q, v0);
-      take(q + 1, v1);
-      take(q + 2, v2);
-      take(q + 3, v3);
-    }
-    for (; q < m; ++q) {
-      float v = sc_first_order(si, ti, ts[q], d2_thre);
+  const int j0 = blockIdx.y * per, m = min(n, j0 + per) - j0;
+  for (int q = threadIdx.x; q < m; q += 256) {
+    const int j = j0 + q;
+    cs[0][q] = src[3 * j]; cs[1][q] = src[3 * j + 1]; cs[2][q] = src[3 * j + 2];
+    cs[3][q] = tgt[3 * j]; cs[4][q] = tgt[3 * j + 1]; cs[5][q] = tgt[3 * j + 2];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (int r = 0; r < SB_ROWS / 4; ++r) {
+    const int i = blockIdx.x * SB_ROWS + wave * (SB_ROWS / 4) + r;
+    if (i >= n) break;
+    const P3 si = ld3(src, i), ti = ld3(tgt, i);
+    ScEntry* const seg = entries + ((size_t)blockIdx.y * n + i) * per;
+    int cnt = 0;
+    for (int q0 = 0; q0 < m; q0 += 64) {
+      const int q = q0 + lane;
+      const bool in = q < m;
+      const int qq = in ? q : 0;
+      const float col[6] = {cs[0][qq], cs[1][qq], cs[2][qq], cs[3][qq], cs[4][qq], cs[5][qq]};
+      // The ROUNDED value decides what is kept: the empty asm makes it opaque.  Without it the compiler derives the predicate
+      // from intermediates (q < 1 instead of max(1 - q, 0) != 0): an entry whose rounded value is not zero could be dropped,
+      // and the sums would differ from the dense kernel's in their last bits (profiles/r05_conv_experiments.txt 52).
+      float v = sc_first_order(si, ti, col, d2_thre);
       asm("" : "+v"(v));
-      take(q, v);
+      const bool nz = in && v != 0.f;      // (a NaN entry counts as non-zero: it must reach the sum as in the dense loop)
+      const unsigned long long mask = __ballot(nz);
+      if (nz) seg[cnt + __popcll(mask & below)] = ScEntry{j0 + q, v};
+      cnt += __popcll(mask);
+    }
+    if (lane == 0) count[(size_t)blockIdx.y * n + i] = cnt;
+  }
+}
+// FOLDED form (the default): product k does the normalisation of product k - 1 ITSELF -- every workgroup sums the previous
+// launch's partials (8 n floats from L2), reduces |y| exactly as k_sc_normalize does (256 threads standing for its 1024: the
+// same per-thread sums, the same tree) and keeps x = y / (|y| + 1e-6) in LDS, where the product then gathers it from;
+// workgroup (0, 0) also writes x and makes the allclose test against the x before it.  20 + 1 launches per registration
+// instead of 40 and no cross-workgroup synchronisation inside a launch (a last-workgroup ticket was tried first: the
+// device-scope fences it needs cost 40 us per launch); partials alternate between two buffers.  x is bitwise what the
+// two-kernel form writes.  When the test sets `done` the other workgroups of that launch may still write a (never read)
+// partial; x then stays at the converged vector as in the reference's `break` (:181).
+template <bool FIRST>
+__global__ void __launch_bounds__(SC_TILE) k_sc_matvec_folded(int n, float* x, int* done, const float* __restrict__ prev,
+                                                              float* __restrict__ partial, const int* __restrict__ count,
+                                                              const ScEntry* __restrict__ entries) {
+  if (*done) return;
+  __shared__ float xs[SC_MAXN];
+  __shared__ float red[1024];
+  __shared__ int allc;
+  const int t = threadIdx.x;
+  if (FIRST) {
+    for (int i = t; i < n; i += SC_TILE) xs[i] = x[i];
+  } else {
+    for (int v = t; v < 1024; v += SC_TILE) {
+      float ss = 0.f;
+      for (int i = v; i < n; i += 1024) {
+        float y = 0.f;
+        for (int c = 0; c < SC_CHUNKS; ++c) y += prev[(size_t)c * n + i];
+        xs[i] = y;
+        ss += y * y;
+      }
+      red[v] = ss;
+    }
+    if (t == 0) allc = 1;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+      for (int v = t; v < o; v += SC_TILE) red[v] += red[v + o];
+      __syncthreads();
+    }
+    const float inv = 1.f / (sqrtf(red[0]) + 1e-6f);
+    const bool writer = blockIdx.x == 0 && blockIdx.y == 0;
+    bool close = true;
+    for (int i = t; i < n; i += SC_TILE) {
+      const float xn = xs[i] * inv;
+      xs[i] = xn;
+      if (writer) {
+        const float xo = x[i];
+        close = close && (fabsf(xn - xo) <= 1e-8f + 1e-5f * fabsf(xo));
+        x[i] = xn;
+      }
+    }
+    if (writer) {
+      if (!close) allc = 0;      // benign race: every writer stores 0
+      __syncthreads();
+      if (t == 0 && allc) *done = 1;
     }
   }
-  if (ok) count[(size_t)blockIdx.y * n + i] = cnt;
+  __syncthreads();
+  const int i = blockIdx.x * SC_TILE + t;
+  if (i >= n) return;
+  const int per = (n + SC_CHUNKS - 1) / SC_CHUNKS;
+  const size_t seg = (size_t)blockIdx.y * n + i;
+  const ScEntry* e = entries + seg * per;
+  const int cnt = count[seg];
+  float acc = 0.f;
+  for (int q = 0; q < cnt; ++q) acc += e[q].m * xs[e[q].j];
+  partial[seg] = acc;
 }
 __global__ void __launch_bounds__(SC_TILE) k_sc_matvec_sparse(int n, const float* __restrict__ x, const int* __restrict__ done,
                                                               float* partial, const int* __restrict__ count,
@@ -137,63 +198,83 @@ __global__ void __launch_bounds__(SC_TILE) k_sc_matvec_sparse(int n, const float
   partial[seg] = acc;
 }
 
-// one workgroup: y = sum of the partials, x_new = y / (|y| + 1e-6), done = allclose(x_new, x_old) (:176-181)
-__global__ void __launch_bounds__(1024) k_sc_normalize(const float* __restrict__ partial, int n, float* x, int* done) {
-  if (*done) return;
-  __shared__ float red[1024];
-  __shared__ int allc;
-  float ss = 0.f;
-  for (int i = threadIdx.x; i < n; i += 1024) {
-    float y = 0.f;
-    for (int c = 0; c < SC_CHUNKS; ++c) y += partial[(size_t)c * n + i];
-    ss += y * y;
+// one workgroup: y = sum of the partials, x_new = y / (|y| + 1e-6), done = allclose(x_new, x_old) (:176-181).
+// `nt` threads stand for 1024: thread t for the rows of t, t + nt, ... < 1024, each with its own sum (red[1024]).
+__device__ void sc_normalize_by(int t, int nt, const float* partial, int n, float* x, int* done, float* red, int* allc) {
+  const float* pv = partial;
+  for (int v = t; v < 1024; v += nt) {
+    float ss = 0.f;
+    for (int i = v; i < n; i += 1024) {
+      float y = 0.f;
+      for (int c = 0; c < SC_CHUNKS; ++c) y += pv[(size_t)c * n + i];
+      ss += y * y;
+    }
+    red[v] = ss;
   }
-  red[threadIdx.x] = ss;
-  if (threadIdx.x == 0) allc = 1;
+  if (t == 0) *allc = 1;
   __syncthreads();
   for (int o = 512; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    for (int v = t; v < o; v += nt) red[v] += red[v + o];
     __syncthreads();
   }
   const float inv = 1.f / (sqrtf(red[0]) + 1e-6f);
   bool close = true;
-  for (int i = threadIdx.x; i < n; i += 1024) {
+  for (int i = t; i < n; i += nt) {
     float y = 0.f;
-    for (int c = 0; c < SC_CHUNKS; ++c) y += partial[(size_t)c * n + i];
+    for (int c = 0; c < SC_CHUNKS; ++c) y += pv[(size_t)c * n + i];
     const float xn = y * inv, xo = x[i];
     close = close && (fabsf(xn - xo) <= 1e-8f + 1e-5f * fabsf(xo));
     x[i] = xn;
   }
-  if (!close) allc = 0;      // benign race: every writer stores 0
+  if (!close) *allc = 0;      // benign race: every writer stores 0
   __syncthreads();
-  if (threadIdx.x == 0 && allc) *done = 1;
+  if (t == 0 && *allc) *done = 1;
+}
+__global__ void __launch_bounds__(1024) k_sc_normalize(const float* __restrict__ partial, int n, float* x, int* done) {
+  if (*done) return;
+  __shared__ float red[1024];
+  __shared__ int allc;
+  sc_normalize_by(threadIdx.x, 1024, partial, n, x, done, red, &allc);
 }
 
 // ---- seeds: non-maximum suppression (:32-58) -----------------------------------------------------------------
-// is_max[i] = all_j (conf_i >= conf_j  or  |s_i s_j| >= R);   is_max pre-set to 1
+// is_max[i] = all_j (conf_i >= conf_j  or  |s_i s_j| >= R);   is_max pre-set to 1.
+// Round 5: every pair is looked at ONCE: within the radius the one of lower confidence loses, whichever side it is on (equal
+// confidences: neither) -- the same flags from half the distance evaluations.  A loser is cleared by a plain store (every
+// writer stores 0).  Workgroup (bx, y) takes row tile bx against column tile (bx + y) mod tiles, y = 0 .. tiles / 2: every
+// unordered pair of tiles exactly once (y = 0: the columns behind the row only; y = tiles / 2 of an even count: the lower
+// half of bx only), one tile pair per workgroup so that the launch balances.
 __global__ void __launch_bounds__(SC_TILE) k_sc_local_max(const float* __restrict__ src, const float* __restrict__ conf,
                                                           int n, float radius, int* is_max) {
   __shared__ float ts[SC_TILE][4];
+  const int n_tiles = (n + SC_TILE - 1) / SC_TILE;
+  const int y = blockIdx.y;
+  if (2 * y == n_tiles && (int)blockIdx.x >= y) return;
+  const int jt = ((int)blockIdx.x + y) % n_tiles;
+  const int jb = jt * SC_TILE;
   const int i = blockIdx.x * SC_TILE + threadIdx.x;
   const bool ok = i < n;
   const P3 si = ok ? ld3(src, i) : P3{0, 0, 0};
   const float ci = ok ? conf[i] : 0.f;
-  const int per = (n + SC_CHUNKS - 1) / SC_CHUNKS;
-  const int j0 = blockIdx.y * per, j1 = min(n, j0 + per);
-  bool good = true;
-  for (int jb = j0; jb < j1; jb += SC_TILE) {
-    __syncthreads();
+  {
     const int j = jb + threadIdx.x;
-    if (j < j1) {
+    if (j < n) {
       ts[threadIdx.x][0] = src[3 * j]; ts[threadIdx.x][1] = src[3 * j + 1]; ts[threadIdx.x][2] = src[3 * j + 2];
       ts[threadIdx.x][3] = conf[j];
     }
-    __syncthreads();
-    const int m = min(SC_TILE, j1 - jb);
-    for (int q = 0; q < m; ++q)
-      good = good && ((ci >= ts[q][3]) || (dist3(si, P3{ts[q][0], ts[q][1], ts[q][2]}) >= radius));
   }
-  if (ok && !good) is_max[i] = 0;
+  __syncthreads();
+  if (!ok) return;
+  const int m = min(SC_TILE, n - jb);
+  bool good = true;
+  for (int q = (y == 0) ? (int)threadIdx.x + 1 : 0; q < m; ++q) {
+    if (dist3(si, P3{ts[q][0], ts[q][1], ts[q][2]}) < radius) {
+      const float cj = ts[q][3];
+      if (ci < cj) good = false;
+      else if (cj < ci) is_max[jb + q] = 0;
+    }
+  }
+  if (!good) is_max[i] = 0;
 }
 
 // ---- tight compatibility as a bit matrix: bit j of row i = (cross_ij < thr)  (:354) ---------------------------
@@ -221,7 +302,6 @@ __global__ void __launch_bounds__(256) k_sc_tight_bits(const float* __restrict__
 // touched 64 cache lines; a seed that is an inlier has thousands of compatible columns); (2) the k1 selection rounds keep
 // every thread's 32 values in registers and reduce with shuffles + one exchange through LDS (two barriers per round, not
 // nine).  Same integers, same tie rule: the k1 lists are those of the round-1 kernel.
-constexpr int SC_MAXN = 8192;
 __global__ void __launch_bounds__(256) k_sc_seed_knn(const float* __restrict__ src, const float* __restrict__ tgt,
                                                      const unsigned long long* __restrict__ bits, int n, int words,
                                                      const long long* __restrict__ seeds, float d_thre, int k1,
@@ -639,7 +719,15 @@ int gcl_sc2_confidence(const float* src, const float* tgt, int32_t n, float d_th
 int64_t gcl_sc2_confidence_scratch_bytes(int32_t n) {
   if (n <= 0 || n > SC_MAXN) return 0;
   const long long per = cdiv(n, SC_CHUNKS);
-  return (long long)SC_CHUNKS * n * 4 + 256 + (long long)SC_CHUNKS * n * per * (long long)sizeof(ScEntry);
+  return (long long)SC_CHUNKS * n * 4 + 256 + (long long)SC_CHUNKS * n * per * (long long)sizeof(ScEntry) + (long long)SC_CHUNKS * n * 4;
+}
+
+static bool sc_folded_normalize() {      // GCL_SC2_FOLDED_NORMALIZE=0: every product followed by its own k_sc_normalize launch
+  static const bool on = [] {
+    const char* e = getenv("GCL_SC2_FOLDED_NORMALIZE");
+    return !(e && e[0] == '0');
+  }();
+  return on;
 }
 
 int gcl_sc2_confidence_sparse(const float* src, const float* tgt, int32_t n, float d_thre, int32_t num_iterations,
@@ -649,14 +737,27 @@ int gcl_sc2_confidence_sparse(const float* src, const float* tgt, int32_t n, flo
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)cdiv(n, SC_TILE), SC_CHUNKS);
   int* count = (int*)scratch;
-  ScEntry* entries = (ScEntry*)((char*)scratch + (((size_t)SC_CHUNKS * n * 4 + 255) & ~(size_t)255));
+  const size_t entries_off = ((size_t)SC_CHUNKS * n * 4 + 255) & ~(size_t)255;
+  ScEntry* entries = (ScEntry*)((char*)scratch + entries_off);
+  float* partial2 = (float*)((char*)scratch + entries_off + (size_t)SC_CHUNKS * n * cdiv(n, SC_CHUNKS) * sizeof(ScEntry));
   const float d2 = d_thre * d_thre;
   if (num_iterations > 0)
-    hipLaunchKernelGGL(k_sc_sparse_build, grid, dim3(SC_TILE), 0, st, src, tgt, n, d2, count, entries);
-  for (int it = 0; it < num_iterations; ++it) {
-    hipLaunchKernelGGL(k_sc_matvec_sparse, grid, dim3(SC_TILE), 0, st, n, (const float*)x, (const int*)done, partial,
+    hipLaunchKernelGGL(k_sc_sparse_build, dim3((unsigned)cdiv(n, SB_ROWS), SC_CHUNKS), dim3(256), 0, st, src, tgt, n, d2, count,
+                       entries);
+  if (sc_folded_normalize() && num_iterations > 0) {
+    float* buf[2] = {partial, partial2};
+    hipLaunchKernelGGL(k_sc_matvec_folded<true>, grid, dim3(SC_TILE), 0, st, n, x, done, (const float*)nullptr, buf[0],
                        (const int*)count, (const ScEntry*)entries);
-    hipLaunchKernelGGL(k_sc_normalize, dim3(1), dim3(1024), 0, st, (const float*)partial, n, x, done);
+    for (int it = 1; it < num_iterations; ++it)
+      hipLaunchKernelGGL(k_sc_matvec_folded<false>, grid, dim3(SC_TILE), 0, st, n, x, done, (const float*)buf[(it - 1) & 1],
+                         buf[it & 1], (const int*)count, (const ScEntry*)entries);
+    hipLaunchKernelGGL(k_sc_normalize, dim3(1), dim3(1024), 0, st, (const float*)buf[(num_iterations - 1) & 1], n, x, done);
+  } else {
+    for (int it = 0; it < num_iterations; ++it) {
+      hipLaunchKernelGGL(k_sc_matvec_sparse, grid, dim3(SC_TILE), 0, st, n, (const float*)x, (const int*)done, partial,
+                         (const int*)count, (const ScEntry*)entries);
+      hipLaunchKernelGGL(k_sc_normalize, dim3(1), dim3(1024), 0, st, (const float*)partial, n, x, done);
+    }
   }
   GCL_CHECK_LAUNCH();
   return GCL_OK;
@@ -664,7 +765,7 @@ int gcl_sc2_confidence_sparse(const float* src, const float* tgt, int32_t n, flo
 
 int gcl_sc2_local_max(const float* src, const float* conf, int32_t n, float radius, int32_t* is_max, void* stream) {
   GCL_CHECK_ARG(src && conf && is_max && n > 0, "gcl_sc2_local_max: bad argument");
-  hipLaunchKernelGGL(k_sc_local_max, dim3((unsigned)cdiv(n, SC_TILE), SC_CHUNKS), dim3(SC_TILE), 0,
+  hipLaunchKernelGGL(k_sc_local_max, dim3((unsigned)cdiv(n, SC_TILE), (unsigned)(cdiv(n, SC_TILE) / 2 + 1)), dim3(SC_TILE), 0,
                      (hipStream_t)stream, src, conf, n, radius, is_max);
   GCL_CHECK_LAUNCH();
   return GCL_OK;

@@ -467,7 +467,8 @@ int gcl_circle_group_bwd(const float* f, int32_t c, const int64_t* index, const 
 /* Row-wise nearest neighbour: for every row i of A[rows_a[i]] (rows_a may be NULL = identity) the column j
  * minimising sum_c (a - b)^2 over B[rows_b[j]]; ties -> lowest j.  dmin = that squared distance, or
  * sqrt(d2 + 1e-7) when l2 != 0 (lib/metrics.py:24-25).  The search runs as (64-row A tiles) x (chunks of B) workgroups
- * followed by a merge over the chunks; scratch: int32[gcl_nn_rowmin_scratch_len(ma, mb)] (0 = none needed, NULL ok). */
+ * over a pair-interleaved copy of B[rows_b] made in scratch, followed by a merge over the chunks;
+ * scratch: int32[gcl_nn_rowmin_scratch_len(ma, mb)], always required. */
 int64_t gcl_nn_rowmin_scratch_len(int32_t ma, int32_t mb);
 int gcl_nn_rowmin(const float* a, const int64_t* rows_a, int32_t ma, const float* b, const int64_t* rows_b,
                   int32_t mb, int32_t c, int32_t l2, int32_t* scratch, float* dmin, int32_t* argmin, void* stream);
@@ -520,8 +521,10 @@ int gcl_sc2_confidence(const float* src, const float* tgt, int32_t n, float d_th
 /* the same power iteration over the NON-ZERO entries of the compatibility matrix, kept from ONE build pass per registration
  * in an ELL layout (every (row, column chunk) segment has its own place of chunk-length entries; scratch:
  * gcl_sc2_confidence_scratch_bytes(n) bytes = n^2 entries of address space, 512 MB at n = 8000, of which only the non-zero
- * ones are touched): the same non-zero terms in the same order, i.e. bitwise the result of gcl_sc2_confidence, without
- * re-deriving 64 M entries (two square roots each) in every one of the 20 products */
+ * ones are touched): the same non-zero terms in the same order, i.e. bitwise the result x of gcl_sc2_confidence, without
+ * re-deriving 64 M entries (two square roots each) in every one of the 20 products.  `partial` is working space here (the
+ * products alternate between it and a second buffer in scratch: product k normalises product k - 1 itself, 21 launches
+ * instead of 40; GCL_SC2_FOLDED_NORMALIZE=0 restores one normalisation launch per product) */
 int64_t gcl_sc2_confidence_scratch_bytes(int32_t n);
 int gcl_sc2_confidence_sparse(const float* src, const float* tgt, int32_t n, float d_thre, int32_t num_iterations,
                               float* partial, float* x, int32_t* done, void* scratch, void* stream);

@@ -1510,7 +1510,9 @@ def test_sc2pcr_confidence_sparse_equals_dense_bitwise(n, inlier, noise):
                                                   _lib.ptr(done), _lib.stream()), "dense")
             res.append((conf, partial, done))
         assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][2], res[1][2])
-        assert torch.equal(res[0][1], res[1][1]) and bool(torch.isfinite(res[0][0]).all())
+        assert bool(torch.isfinite(res[0][0]).all())
+        if os.environ.get("GCL_SC2_FOLDED_NORMALIZE") == "0":      # every product followed by its own normalisation launch:
+            assert torch.equal(res[0][1], res[1][1])              # then the last product's partial sums are the same buffer too
 
 
 def test_sc2pcr_one_launch_refinement_and_sparse_confidence_vs_round_1_forms(tmp_path):
