@@ -143,6 +143,9 @@ SIGNATURES = {
     "gcl_sc2_confidence": (_i32, [_vp, _vp, _i32, _f32, _i32, _vp, _vp, _vp, _vp]),
     "gcl_sc2_confidence_scratch_bytes": (_i64, [_i32]),
     "gcl_sc2_confidence_sparse": (_i32, [_vp, _vp, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "gcl_sc2_register_scratch_bytes": (_i64, [_i32]),
+    "gcl_sc2_register": (_i32, [_vp, _vp, _i32, _f32, _i32, _f32, _i32, _i32, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _vp, _vp,
+                                _vp, _vp, _vp, _vp, _vp]),
     "gcl_sc2_local_max": (_i32, [_vp, _vp, _i32, _f32, _vp, _vp]),
     "gcl_sc2_seed_knn": (_i32, [_vp, _vp, _i32, _vp, _i32, _f32, _i32, _vp, _vp, _vp]),
     "gcl_sc2_seed_trans": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _f32, _i32, _f32, _vp, _vp, _vp]),

@@ -696,6 +696,99 @@ __global__ void __launch_bounds__(1024) k_sc_refine_all(const float* __restrict_
 
 using namespace gcl;
 
+// ---- one call per registration (round 5): what scripts/SC2_PCR.py did between the stages, on the device ------------------------
+__global__ void k_sc_reg_init(float* conf, int* is_max, int* done, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    conf[i] = 1.f;
+    is_max[i] = 1;
+  }
+  if (i == 0) *done = 0;
+}
+
+// seeds = the n_seeds first of argsort(-(conf * is_max), stable) (:56-58): value descending, index ascending -- a bitonic sort of
+// 64-bit keys (order-reversed value bits, index) in LDS by one workgroup.  NaN last, as torch.sort places it.
+__global__ void __launch_bounds__(1024) k_sc_seed_sort(const float* __restrict__ conf, const int* __restrict__ is_max, int n,
+                                                       int n_seeds, long long* __restrict__ seeds) {
+  __shared__ unsigned long long keys[SC_MAXN];
+  const int t = threadIdx.x;
+  int np2 = 1;
+  while (np2 < n) np2 <<= 1;
+  for (int i = t; i < np2; i += 1024) {
+    unsigned long long k = ~0ull;
+    if (i < n) {
+      float v = conf[i] * (float)is_max[i];
+      if (v == 0.f) v = 0.f;                                            // -0 and +0 are one value to the reference's sort
+      const unsigned b = __float_as_uint(v);
+      const unsigned asc = b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);   // ascending in v
+      const unsigned hi = (v != v) ? 0xFFFFFFFFu : ~asc;
+      k = ((unsigned long long)hi << 32) | (unsigned)i;
+    }
+    keys[i] = k;
+  }
+  __syncthreads();
+  for (int k = 2; k <= np2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = t; i < np2; i += 1024) {
+        const int p = i ^ j;
+        if (p > i) {
+          const unsigned long long a = keys[i], b = keys[p];
+          if ((a > b) == ((i & k) == 0)) {
+            keys[i] = b;
+            keys[p] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = t; i < n_seeds; i += 1024) seeds[i] = (long long)(keys[i] & 0xFFFFFFFFull);
+}
+
+// best = lowest index of the maximum fitness (torch.sort(-fitness, stable)[1][0]); T = that seed's [R | t]
+__global__ void __launch_bounds__(256) k_sc_best(const float* __restrict__ fitness, const float* __restrict__ trans, int n_seeds,
+                                                 int* best_out, float* T) {
+  __shared__ float bv[256];
+  __shared__ int bi[256];
+  float v = -INFINITY;
+  int ix = 0x7fffffff;
+  for (int i = threadIdx.x; i < n_seeds; i += 256) {      // ascending i per thread: the first maximum is the lowest index
+    const float f = fitness[i];
+    if (ix == 0x7fffffff || f > v) { v = f; ix = i; }
+  }
+  bv[threadIdx.x] = v;
+  bi[threadIdx.x] = ix;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      const float v2 = bv[threadIdx.x + o];
+      const int i2 = bi[threadIdx.x + o];
+      if (i2 != 0x7fffffff && (bi[threadIdx.x] == 0x7fffffff || v2 > bv[threadIdx.x] ||
+                               (v2 == bv[threadIdx.x] && i2 < bi[threadIdx.x]))) {
+        bv[threadIdx.x] = v2;
+        bi[threadIdx.x] = i2;
+      }
+    }
+    __syncthreads();
+  }
+  const int best = bi[0];
+  if (threadIdx.x == 0) *best_out = best;
+  if (threadIdx.x < 12) T[threadIdx.x] = trans[(size_t)best * 12 + threadIdx.x];
+}
+
+// the [4, 4] transformation and the inlier labels |R s + t - t'| < thr of Matcher.estimator (:404-409)
+__global__ void k_sc_finish(const float* __restrict__ src, const float* __restrict__ tgt, int n, const float* __restrict__ T,
+                            float thr, float* out16, float* labels) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 16) out16[i] = i < 12 ? T[i] : (i == 15 ? 1.f : 0.f);
+  if (i >= n) return;
+  const P3 s = ld3(src, i), g = ld3(tgt, i);
+  const float wx = T[0] * s.x + T[1] * s.y + T[2] * s.z + T[3] - g.x;
+  const float wy = T[4] * s.x + T[5] * s.y + T[6] * s.z + T[7] - g.y;
+  const float wz = T[8] * s.x + T[9] * s.y + T[10] * s.z + T[11] - g.z;
+  labels[i] = sqrtf(wx * wx + wy * wy + wz * wz) < thr ? 1.f : 0.f;
+}
+
 extern "C" {
 
 int32_t gcl_sc2_chunks(void) { return SC_CHUNKS; }
@@ -816,6 +909,65 @@ int gcl_sc2_refine(const float* src, const float* tgt, int32_t n, float thr, int
                        (const int*)state, partial);
     hipLaunchKernelGGL(k_sc_refine_solve, dim3(1), dim3(1), 0, st, (const double*)partial, state, T);
   }
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+
+static size_t sc_up256(size_t b) { return (b + 255) & ~(size_t)255; }
+struct ScRegLayout { size_t partial, done, sparse, is_max, bits, T, rpart, state, total; };
+static ScRegLayout sc_reg_layout(int n) {
+  ScRegLayout L;
+  size_t o = 0;
+  L.partial = o; o += sc_up256((size_t)SC_CHUNKS * n * 4);
+  L.done = o;    o += 256;
+  L.sparse = o;  o += sc_up256((size_t)gcl_sc2_confidence_scratch_bytes(n));
+  L.is_max = o;  o += sc_up256((size_t)n * 4);
+  L.bits = o;    o += sc_up256((size_t)n * ((n + 63) / 64) * 8);
+  L.T = o;       o += 256;
+  L.rpart = o;   o += sc_up256((size_t)RF_BLOCKS * RF_TERMS * 8);
+  L.state = o;   o += 256;
+  L.total = o;
+  return L;
+}
+
+int64_t gcl_sc2_register_scratch_bytes(int32_t n) {
+  if (n <= 0 || n > SC_MAXN) return 0;
+  return (int64_t)sc_reg_layout(n).total;
+}
+
+int gcl_sc2_register(const float* src, const float* tgt, int32_t n, float d_thre, int32_t num_iterations, float nms_radius,
+                     int32_t n_seeds, int32_t k1, int32_t k2, float inlier_thresh, float refine_thr, int32_t refine_iters,
+                     void* scratch, float* conf, int64_t* seeds, int32_t* knn, float* seed_trans, float* fitness,
+                     int32_t* best, float* trans16, float* labels, void* stream) {
+  GCL_CHECK_ARG(src && tgt && scratch && conf && seeds && knn && seed_trans && fitness && best && trans16 && labels,
+                "gcl_sc2_register: null pointer");
+  GCL_CHECK_ARG(n > 0 && n <= SC_MAXN && n_seeds >= 1 && n_seeds <= n, "gcl_sc2_register: need 1 <= n_seeds <= n <= %d",
+                SC_MAXN);
+  hipStream_t st = (hipStream_t)stream;
+  const ScRegLayout L = sc_reg_layout(n);
+  char* base = (char*)scratch;
+  float* partial = (float*)(base + L.partial);
+  int* done = (int*)(base + L.done);
+  int* is_max = (int*)(base + L.is_max);
+  float* T = (float*)(base + L.T);
+  hipLaunchKernelGGL(k_sc_reg_init, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, conf, is_max, done, n);
+  int rc = gcl_sc2_confidence_sparse(src, tgt, n, d_thre, num_iterations, partial, conf, done, base + L.sparse, stream);
+  if (rc != GCL_OK) return rc;
+  rc = gcl_sc2_local_max(src, conf, n, nms_radius, is_max, stream);
+  if (rc != GCL_OK) return rc;
+  hipLaunchKernelGGL(k_sc_seed_sort, dim3(1), dim3(1024), 0, st, (const float*)conf, (const int*)is_max, n, n_seeds,
+                     (long long*)seeds);
+  rc = gcl_sc2_seed_knn(src, tgt, n, seeds, n_seeds, d_thre, k1, (uint64_t*)(base + L.bits), knn, stream);
+  if (rc != GCL_OK) return rc;
+  rc = gcl_sc2_seed_trans(src, tgt, n, knn, n_seeds, k1, k2, d_thre, num_iterations, inlier_thresh, seed_trans, fitness,
+                          stream);
+  if (rc != GCL_OK) return rc;
+  hipLaunchKernelGGL(k_sc_best, dim3(1), dim3(256), 0, st, (const float*)fitness, (const float*)seed_trans, n_seeds, best, T);
+  rc = gcl_sc2_refine(src, tgt, n, refine_thr, refine_iters, (double*)(base + L.rpart), (int32_t*)(base + L.state), T, stream);
+  if (rc != GCL_OK) return rc;
+  hipLaunchKernelGGL(k_sc_finish, dim3((unsigned)cdiv(std::max(n, 16), 256)), dim3(256), 0, st, src, tgt, n, (const float*)T,
+                     inlier_thresh, trans16, labels);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 import gcl_amd.MinkowskiEngine as ME
-from gcl_amd.lib.eval import DeferredCorr
+from gcl_amd.lib.eval import DeferredCorr, host_to_device
 
 
 class AverageMeter:
@@ -58,7 +58,7 @@ def random_sample(pcd, feats, N):
     if n1 == N:
         return pcd, feats
     choice = np.random.permutation(n1)[:N] if n1 > N else np.random.choice(n1, N)
-    sel = torch.from_numpy(choice).to(feats.device) if isinstance(feats, torch.Tensor) else choice
+    sel = host_to_device(choice, feats.device) if isinstance(feats, torch.Tensor) else choice
     return pcd[choice], feats[sel]
 
 
@@ -263,7 +263,7 @@ def eval_pairs(model, pairs, matcher, device=None, batch_pairs=1, subsample_size
                     xyz0s, F0s = random_sample(xyz0np, F0, n_points)
                     xyz1s, F1s = random_sample(xyz1np, F1, n_points)
                     t0 = time.perf_counter()
-                    x0, x1 = torch.from_numpy(xyz0s).to(dev), torch.from_numpy(xyz1s).to(dev)
+                    x0, x1 = host_to_device(xyz0s, dev), host_to_device(xyz1s, dev)
                     T_est, _, _, _ = matcher.estimator(x0[None], x1[None], F0s[None], F1s[None])
                     Ts.append(T_est[0])
                     done = torch.cuda.Event()

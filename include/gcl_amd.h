@@ -528,6 +528,19 @@ int gcl_sc2_confidence(const float* src, const float* tgt, int32_t n, float d_th
 int64_t gcl_sc2_confidence_scratch_bytes(int32_t n);
 int gcl_sc2_confidence_sparse(const float* src, const float* tgt, int32_t n, float d_thre, int32_t num_iterations,
                               float* partial, float* x, int32_t* done, void* scratch, void* stream);
+/* One call per registration (round 5): Matcher.SC2_PCR + the labels of Matcher.estimator (:304-381, :404-409) as ONE launch
+ * sequence -- gcl_sc2_confidence_sparse, gcl_sc2_local_max, the seed order (stable argsort of -(conf * is_max): value
+ * descending, index ascending), gcl_sc2_seed_knn, gcl_sc2_seed_trans, the best seed (lowest index of the maximum fitness),
+ * gcl_sc2_refine, and the [4, 4] result with labels[i] = |R s_i + t - t'_i| < inlier_thresh -- without the host in between
+ * (the Python Matcher issued ~25 torch operations and 7 calls per pair: 1 ms of host time in a loop that is host-bound).
+ * Outputs: conf float[n], seeds int64[n_seeds], knn int32[n_seeds * k1], seed_trans float[n_seeds * 12],
+ * fitness float[n_seeds], best int32[1], trans16 float[16] (row-major [4, 4]), labels float[n] (0 / 1).
+ * scratch: gcl_sc2_register_scratch_bytes(n) bytes.  Same kernels, same results as the staged calls. */
+int64_t gcl_sc2_register_scratch_bytes(int32_t n);
+int gcl_sc2_register(const float* src, const float* tgt, int32_t n, float d_thre, int32_t num_iterations, float nms_radius,
+                     int32_t n_seeds, int32_t k1, int32_t k2, float inlier_thresh, float refine_thr, int32_t refine_iters,
+                     void* scratch, float* conf, int64_t* seeds, int32_t* knn, float* seed_trans, float* fitness,
+                     int32_t* best, float* trans16, float* labels, void* stream);
 int gcl_sc2_local_max(const float* src, const float* conf, int32_t n, float radius, int32_t* is_max, void* stream);
 int gcl_sc2_seed_knn(const float* src, const float* tgt, int32_t n, const int64_t* seeds, int32_t n_seeds,
                      float d_thre, int32_t k1, uint64_t* bits, int32_t* knn, void* stream);

@@ -1478,6 +1478,57 @@ def test_sc2pcr_matches_reference_output_and_oracle_stages(path):
         assert set(m.last["seeds"].cpu().numpy()[:50]) == set(st["seeds"].numpy()[:50])
 
 
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "sc2pcr_*.npz"))))
+def test_sc2pcr_one_call_equals_the_staged_calls(path, monkeypatch):
+    """gcl_sc2_register (every stage of Matcher.SC2_PCR + the estimator's labels behind ONE C-ABI call, the seed order by a
+    device sort) == the five staged calls with torch's stable sort / argmax between them: every stage and the transformation
+    bit for bit, the labels equal to torch's expression except where a residual sits within rounding of the threshold."""
+    import gcl_amd.scripts.SC2_PCR as S
+    z = np.load(path)
+    cfg = _sc2_cfg(z)
+    src, tgt = torch.from_numpy(z["src"]).to(DEV), torch.from_numpy(z["tgt"]).to(DEV)
+    res = []
+    for one_call in (False, True):
+        monkeypatch.setattr(S, "ONE_CALL", one_call)
+        m = S.Matcher(num_node="all", use_mutual=False, **cfg)
+        T = m.SC2_PCR(src[None], tgt[None]).clone()
+        res.append((T, {k: m.last[k].clone() for k in ("conf", "seeds", "knn", "seed_trans", "fitness", "best")}, m._labels))
+    assert res[0][2] is None and res[1][2] is not None
+    assert torch.equal(res[0][0], res[1][0]) and res[1][0].shape == (1, 4, 4)
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k].to(res[1][1][k].dtype), res[1][1][k]), k
+    T = res[1][0]
+    n = min(src.shape[0], cfg["max_points"])
+    warped = src[None, :n] @ T[:, :3, :3].transpose(1, 2) + T[:, None, :3, 3]
+    dist = torch.sum((warped - tgt[None, :n]) ** 2, dim=-1) ** 0.5
+    ref = (dist < cfg["inlier_threshold"]).float()
+    differ = ref != res[1][2]
+    assert res[1][2].shape == ref.shape
+    assert not bool(differ.any()) or float((dist[differ] - cfg["inlier_threshold"]).abs().max()) < 1e-5
+
+
+def test_sc2pcr_seed_order_of_the_one_call_form_with_ties():
+    """The device sort behind gcl_sc2_register's seeds: (value descending, index ascending) = torch.sort(-(conf * is_max),
+    stable=True) -- on a problem whose confidences are massively tied (a regular grid: many equal entries, most of them
+    suppressed to exactly zero)."""
+    import gcl_amd.scripts.SC2_PCR as S
+    g = np.stack(np.meshgrid(np.arange(12), np.arange(12), np.arange(4), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    src = torch.from_numpy(g * 0.5).to(DEV)
+    tgt = src + torch.tensor([1.0, 2.0, 0.5], device=DEV)
+    cfg = dict(inlier_threshold=0.6, d_thre=0.1, num_iterations=10, ratio=0.5, nms_radius=0.6, max_points=8000, k1=30, k2=20)
+    out = []
+    for one_call in (False, True):
+        S.ONE_CALL = one_call
+        try:
+            m = S.Matcher(num_node="all", use_mutual=False, **cfg)
+            m.SC2_PCR(src[None], tgt[None])
+            out.append((m.last["conf"].clone(), m.last["seeds"].clone()))
+        finally:
+            S.ONE_CALL = True
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    assert len(torch.unique(out[1][0])) < len(out[1][0]) // 2          # the ties are there
+
+
 @pytest.mark.parametrize("n,inlier,noise", [(8000, 0.3, 0.03), (8000, 1.0, 0.0), (3000, 0.6, 0.02), (257, 0.5, 0.02), (1, 1.0, 0.0)])
 def test_sc2pcr_confidence_sparse_equals_dense_bitwise(n, inlier, noise):
     """gcl_sc2_confidence_sparse (the compatibility matrix's non-zero entries kept from ONE build; 20 products over them)
