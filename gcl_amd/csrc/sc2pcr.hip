@@ -26,7 +26,10 @@ constexpr int SC_MAXN = 8192;     // correspondences per registration (max_point
 struct P3 { float x, y, z; };
 __device__ __forceinline__ float dist3(const P3& a, const P3& b) {
   float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
-  return sqrtf(dx * dx + dy * dy + dz * dz);   // torch.norm(a - b): no epsilon
+  // torch.norm(a - b): no epsilon.  The sum of squares is written out as ONE chain: left to the compiler, kernels that compare
+  // the same length difference against a threshold (k_sc_tight_bits, k_sc_sparse_build, k_sc_seed_knn) got different
+  // contractions (packed multiplies + one fma + add in one, multiply + two fmas in another) and disagreed on borderline pairs.
+  return sqrtf(__builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy)));
 }
 __device__ __forceinline__ P3 ld3(const float* __restrict__ p, int i) { return P3{p[3 * i], p[3 * i + 1], p[3 * i + 2]}; }
 
@@ -77,47 +80,58 @@ __device__ __forceinline__ float sc_first_order(const P3& si, const P3& ti, cons
 }
 // One WAVE per row: lane = column, 64 columns per trip, the non-zero ones written in column order behind a ballot's prefix
 // count -- n x 8 waves (40 000 at n = 5000) instead of n x 8 threads (625 waves on 1024 SIMDs, every one of them a serial
-// chain of square roots and divisions): 191 -> 60 us.  A workgroup takes SB_ROWS rows of one column chunk and holds the
+// chain of square roots and divisions): 191 -> 116 us.  A workgroup takes SB_ROWS rows of one column chunk and holds the
 // chunk's coordinates in LDS.
+// The trips are aligned to 64 columns of the whole row, and with `bits` the same pass also writes the TIGHT compatibility
+// bit matrix k_sc_tight_bits makes (bit j of row i = |.| < tight_thr, the same |.| the entry's value comes from): a chunk
+// owns the words that START in it, and holds the up to 63 columns beyond its end that such a word needs.
 constexpr int SB_ROWS = 16;
 constexpr int SB_PER_MAX = SC_MAXN / SC_CHUNKS;
 __global__ void __launch_bounds__(256) k_sc_sparse_build(const float* __restrict__ src, const float* __restrict__ tgt, int n,
-                                                         float d2_thre, int* count, ScEntry* entries) {
-  __shared__ float cs[6][SB_PER_MAX];
+                                                         float d2_thre, int* count, ScEntry* entries, float tight_thr,
+                                                         unsigned long long* bits) {
+  __shared__ float cs[6][SB_PER_MAX + 128];
   const int per = (n + SC_CHUNKS - 1) / SC_CHUNKS;
-  const int j0 = blockIdx.y * per, m = min(n, j0 + per) - j0;
-  for (int q = threadIdx.x; q < m; q += 256) {
-    const int j = j0 + q;
+  const int j0 = blockIdx.y * per, j1 = min(n, j0 + per);
+  const int g0 = j0 & ~63, g1 = min(n, (j1 + 63) & ~63);       // the columns held: the chunk widened to whole words
+  for (int q = threadIdx.x; q < g1 - g0; q += 256) {
+    const int j = g0 + q;
     cs[0][q] = src[3 * j]; cs[1][q] = src[3 * j + 1]; cs[2][q] = src[3 * j + 2];
     cs[3][q] = tgt[3 * j]; cs[4][q] = tgt[3 * j + 1]; cs[5][q] = tgt[3 * j + 2];
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned long long below = (1ull << lane) - 1ull;
+  const int words = (n + 63) >> 6;
   for (int r = 0; r < SB_ROWS / 4; ++r) {
     const int i = blockIdx.x * SB_ROWS + wave * (SB_ROWS / 4) + r;
     if (i >= n) break;
     const P3 si = ld3(src, i), ti = ld3(tgt, i);
     ScEntry* const seg = entries + ((size_t)blockIdx.y * n + i) * per;
     int cnt = 0;
-    for (int q0 = 0; q0 < m; q0 += 64) {
-      const int q = q0 + lane;
-      const bool in = q < m;
-      const int qq = in ? q : 0;
-      const float col[6] = {cs[0][qq], cs[1][qq], cs[2][qq], cs[3][qq], cs[4][qq], cs[5][qq]};
+    for (int g = g0; g < j1; g += 64) {
+      const int j = g + lane;
+      const bool held = j < g1;
+      const int q = held ? j - g0 : 0;
+      const float cd = fabsf(dist3(si, P3{cs[0][q], cs[1][q], cs[2][q]}) - dist3(ti, P3{cs[3][q], cs[4][q], cs[5][q]}));
+      if (bits && g >= j0) {                                   // uniform over the wave: this chunk owns the word
+        const unsigned long long w = __ballot(held && cd < tight_thr);
+        if (lane == 0) bits[(size_t)i * words + (g >> 6)] = w;
+      }
       // The ROUNDED value decides what is kept: the empty asm makes it opaque.  Without it the compiler derives the predicate
       // from intermediates (q < 1 instead of max(1 - q, 0) != 0): an entry whose rounded value is not zero could be dropped,
       // and the sums would differ from the dense kernel's in their last bits (profiles/r05_conv_experiments.txt 52).
-      float v = sc_first_order(si, ti, col, d2_thre);
+      float v = fmaxf(1.f - cd * cd / d2_thre, 0.f);
       asm("" : "+v"(v));
-      const bool nz = in && v != 0.f;      // (a NaN entry counts as non-zero: it must reach the sum as in the dense loop)
+      const bool nz = j >= j0 && j < j1 && v != 0.f;      // (a NaN entry counts as non-zero: it must reach the sum as in the dense loop)
       const unsigned long long mask = __ballot(nz);
-      if (nz) seg[cnt + __popcll(mask & below)] = ScEntry{j0 + q, v};
+      if (nz) seg[cnt + __popcll(mask & below)] = ScEntry{j, v};
       cnt += __popcll(mask);
     }
     if (lane == 0) count[(size_t)blockIdx.y * n + i] = cnt;
   }
 }
+
 // FOLDED form (the default): product k does the normalisation of product k - 1 ITSELF -- every workgroup sums the previous
 // launch's partials (8 n floats from L2), reduces |y| exactly as k_sc_normalize does (256 threads standing for its 1024: the
 // same per-thread sums, the same tree) and keeps x = y / (|y| + 1e-6) in LDS, where the product then gathers it from;
@@ -697,52 +711,52 @@ __global__ void __launch_bounds__(1024) k_sc_refine_all(const float* __restrict_
 using namespace gcl;
 
 // ---- one call per registration (round 5): what scripts/SC2_PCR.py did between the stages, on the device ------------------------
-__global__ void k_sc_reg_init(float* conf, int* is_max, int* done, int n) {
+__global__ void k_sc_reg_init(float* conf, int* is_max, int* rank, int* done, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
     conf[i] = 1.f;
     is_max[i] = 1;
+    rank[i] = 0;
   }
   if (i == 0) *done = 0;
 }
 
-// seeds = the n_seeds first of argsort(-(conf * is_max), stable) (:56-58): value descending, index ascending -- a bitonic sort of
-// 64-bit keys (order-reversed value bits, index) in LDS by one workgroup.  NaN last, as torch.sort places it.
-__global__ void __launch_bounds__(1024) k_sc_seed_sort(const float* __restrict__ conf, const int* __restrict__ is_max, int n,
-                                                       int n_seeds, long long* __restrict__ seeds) {
-  __shared__ unsigned long long keys[SC_MAXN];
-  const int t = threadIdx.x;
-  int np2 = 1;
-  while (np2 < n) np2 <<= 1;
-  for (int i = t; i < np2; i += 1024) {
-    unsigned long long k = ~0ull;
-    if (i < n) {
-      float v = conf[i] * (float)is_max[i];
-      if (v == 0.f) v = 0.f;                                            // -0 and +0 are one value to the reference's sort
-      const unsigned b = __float_as_uint(v);
-      const unsigned asc = b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);   // ascending in v
-      const unsigned hi = (v != v) ? 0xFFFFFFFFu : ~asc;
-      k = ((unsigned long long)hi << 32) | (unsigned)i;
-    }
-    keys[i] = k;
-  }
-  __syncthreads();
-  for (int k = 2; k <= np2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = t; i < np2; i += 1024) {
-        const int p = i ^ j;
-        if (p > i) {
-          const unsigned long long a = keys[i], b = keys[p];
-          if ((a > b) == ((i & k) == 0)) {
-            keys[i] = b;
-            keys[p] = a;
-          }
-        }
-      }
-      __syncthreads();
+// seeds = the n_seeds first of argsort(-(conf * is_max), stable) (:56-58): value descending, index ascending.  By RANK: the
+// place of correspondence i is the number of correspondences ordered before it -- n^2 comparisons spread over the chip
+// (row tiles x SC_CHUNKS column chunks, integer atomics: any order gives the same count) -- then seeds[rank[i]] = i.  (A
+// bitonic sort in LDS by one workgroup was the first form: 111 us; torch's sort took 45 us in four launches.)  NaN last, as
+// torch.sort places it.
+__device__ __forceinline__ unsigned sc_seed_key(const float* __restrict__ conf, const int* __restrict__ is_max, int i) {
+  float v = conf[i] * (float)is_max[i];
+  if (v == 0.f) v = 0.f;                                                // -0 and +0 are one value to the reference's sort
+  const unsigned b = __float_as_uint(v);
+  const unsigned asc = b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);     // ascending in v
+  return (v != v) ? 0xFFFFFFFFu : ~asc;                                 // ascending key = descending value
+}
+__global__ void __launch_bounds__(SC_TILE) k_sc_seed_rank(const float* __restrict__ conf, const int* __restrict__ is_max, int n,
+                                                          int* rank) {
+  __shared__ unsigned tk[SC_TILE];
+  const int i = blockIdx.x * SC_TILE + threadIdx.x;
+  const bool ok = i < n;
+  const unsigned ki = ok ? sc_seed_key(conf, is_max, i) : 0u;
+  const int per = (n + SC_CHUNKS - 1) / SC_CHUNKS;
+  const int j0 = blockIdx.y * per, j1 = min(n, j0 + per);
+  int before = 0;
+  for (int jb = j0; jb < j1; jb += SC_TILE) {
+    __syncthreads();
+    if (jb + (int)threadIdx.x < j1) tk[threadIdx.x] = sc_seed_key(conf, is_max, jb + threadIdx.x);
+    __syncthreads();
+    const int m = min(SC_TILE, j1 - jb);
+    for (int q = 0; q < m; ++q) {
+      const unsigned kj = tk[q];
+      before += (kj < ki || (kj == ki && jb + q < i)) ? 1 : 0;
     }
   }
-  for (int i = t; i < n_seeds; i += 1024) seeds[i] = (long long)(keys[i] & 0xFFFFFFFFull);
+  if (ok && before) atomicAdd(&rank[i], before);
+}
+__global__ void k_sc_seed_place(const int* __restrict__ rank, int n, int n_seeds, long long* __restrict__ seeds) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && rank[i] < n_seeds) seeds[rank[i]] = i;
 }
 
 // best = lowest index of the maximum fitness (torch.sort(-fitness, stable)[1][0]); T = that seed's [R | t]
@@ -823,8 +837,9 @@ static bool sc_folded_normalize() {      // GCL_SC2_FOLDED_NORMALIZE=0: every pr
   return on;
 }
 
-int gcl_sc2_confidence_sparse(const float* src, const float* tgt, int32_t n, float d_thre, int32_t num_iterations,
-                              float* partial, float* x, int32_t* done, void* scratch, void* stream) {
+static int sc_confidence_sparse(const float* src, const float* tgt, int32_t n, float d_thre, int32_t num_iterations,
+                                float* partial, float* x, int32_t* done, void* scratch, float tight_thr,
+                                unsigned long long* bits, void* stream) {
   GCL_CHECK_ARG(src && tgt && partial && x && done && scratch, "gcl_sc2_confidence_sparse: null pointer");
   GCL_CHECK_ARG(n > 0 && n <= SC_MAXN && d_thre > 0 && num_iterations >= 0, "gcl_sc2_confidence: 0 < n <= %d", SC_MAXN);
   hipStream_t st = (hipStream_t)stream;
@@ -836,7 +851,7 @@ int gcl_sc2_confidence_sparse(const float* src, const float* tgt, int32_t n, flo
   const float d2 = d_thre * d_thre;
   if (num_iterations > 0)
     hipLaunchKernelGGL(k_sc_sparse_build, dim3((unsigned)cdiv(n, SB_ROWS), SC_CHUNKS), dim3(256), 0, st, src, tgt, n, d2, count,
-                       entries);
+                       entries, tight_thr, bits);
   if (sc_folded_normalize() && num_iterations > 0) {
     float* buf[2] = {partial, partial2};
     hipLaunchKernelGGL(k_sc_matvec_folded<true>, grid, dim3(SC_TILE), 0, st, n, x, done, (const float*)nullptr, buf[0],
@@ -856,6 +871,11 @@ int gcl_sc2_confidence_sparse(const float* src, const float* tgt, int32_t n, flo
   return GCL_OK;
 }
 
+int gcl_sc2_confidence_sparse(const float* src, const float* tgt, int32_t n, float d_thre, int32_t num_iterations,
+                              float* partial, float* x, int32_t* done, void* scratch, void* stream) {
+  return sc_confidence_sparse(src, tgt, n, d_thre, num_iterations, partial, x, done, scratch, 0.f, nullptr, stream);
+}
+
 int gcl_sc2_local_max(const float* src, const float* conf, int32_t n, float radius, int32_t* is_max, void* stream) {
   GCL_CHECK_ARG(src && conf && is_max && n > 0, "gcl_sc2_local_max: bad argument");
   hipLaunchKernelGGL(k_sc_local_max, dim3((unsigned)cdiv(n, SC_TILE), (unsigned)(cdiv(n, SC_TILE) / 2 + 1)), dim3(SC_TILE), 0,
@@ -864,19 +884,25 @@ int gcl_sc2_local_max(const float* src, const float* conf, int32_t n, float radi
   return GCL_OK;
 }
 
-int gcl_sc2_seed_knn(const float* src, const float* tgt, int32_t n, const int64_t* seeds, int32_t n_seeds,
-                     float d_thre, int32_t k1, uint64_t* bits, int32_t* knn, void* stream) {
+static int sc_seed_knn(const float* src, const float* tgt, int32_t n, const int64_t* seeds, int32_t n_seeds,
+                       float d_thre, int32_t k1, uint64_t* bits, bool make_bits, int32_t* knn, void* stream) {
   GCL_CHECK_ARG(src && tgt && seeds && bits && knn, "gcl_sc2_seed_knn: null pointer");
   GCL_CHECK_ARG(n > 0 && n <= SC_MAXN && n_seeds > 0 && k1 >= 1 && k1 <= 32 && k1 <= n,
                 "gcl_sc2_seed_knn: need n <= %d, 1 <= k1 <= min(32, n)", SC_MAXN);
   hipStream_t st = (hipStream_t)stream;
   const int words = (n + 63) / 64;
-  hipLaunchKernelGGL(k_sc_tight_bits, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, st, src, tgt, n, words, d_thre * 0.5f,
-                     (unsigned long long*)bits);
+  if (make_bits)
+    hipLaunchKernelGGL(k_sc_tight_bits, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, st, src, tgt, n, words, d_thre * 0.5f,
+                       (unsigned long long*)bits);
   hipLaunchKernelGGL(k_sc_seed_knn, dim3(n_seeds), dim3(256), 0, st, src, tgt, (const unsigned long long*)bits, n,
                      words, (const long long*)seeds, d_thre, k1, knn);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
+}
+
+int gcl_sc2_seed_knn(const float* src, const float* tgt, int32_t n, const int64_t* seeds, int32_t n_seeds,
+                     float d_thre, int32_t k1, uint64_t* bits, int32_t* knn, void* stream) {
+  return sc_seed_knn(src, tgt, n, seeds, n_seeds, d_thre, k1, bits, true, knn, stream);
 }
 
 int gcl_sc2_seed_trans(const float* src, const float* tgt, int32_t n, const int32_t* knn, int32_t n_seeds, int32_t k1,
@@ -915,7 +941,7 @@ int gcl_sc2_refine(const float* src, const float* tgt, int32_t n, float thr, int
 
 
 static size_t sc_up256(size_t b) { return (b + 255) & ~(size_t)255; }
-struct ScRegLayout { size_t partial, done, sparse, is_max, bits, T, rpart, state, total; };
+struct ScRegLayout { size_t partial, done, sparse, is_max, rank, bits, T, rpart, state, total; };
 static ScRegLayout sc_reg_layout(int n) {
   ScRegLayout L;
   size_t o = 0;
@@ -923,6 +949,7 @@ static ScRegLayout sc_reg_layout(int n) {
   L.done = o;    o += 256;
   L.sparse = o;  o += sc_up256((size_t)gcl_sc2_confidence_scratch_bytes(n));
   L.is_max = o;  o += sc_up256((size_t)n * 4);
+  L.rank = o;    o += sc_up256((size_t)n * 4);
   L.bits = o;    o += sc_up256((size_t)n * ((n + 63) / 64) * 8);
   L.T = o;       o += 256;
   L.rpart = o;   o += sc_up256((size_t)RF_BLOCKS * RF_TERMS * 8);
@@ -951,14 +978,20 @@ int gcl_sc2_register(const float* src, const float* tgt, int32_t n, float d_thre
   int* done = (int*)(base + L.done);
   int* is_max = (int*)(base + L.is_max);
   float* T = (float*)(base + L.T);
-  hipLaunchKernelGGL(k_sc_reg_init, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, conf, is_max, done, n);
-  int rc = gcl_sc2_confidence_sparse(src, tgt, n, d_thre, num_iterations, partial, conf, done, base + L.sparse, stream);
+  int* rank = (int*)(base + L.rank);
+  hipLaunchKernelGGL(k_sc_reg_init, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, conf, is_max, rank, done, n);
+  // the tight compatibility bits come out of the confidence's build pass (one evaluation of the n^2 length differences, not two)
+  const bool bits_from_build = num_iterations > 0;
+  int rc = sc_confidence_sparse(src, tgt, n, d_thre, num_iterations, partial, conf, done, base + L.sparse, d_thre * 0.5f,
+                                bits_from_build ? (unsigned long long*)(base + L.bits) : nullptr, stream);
   if (rc != GCL_OK) return rc;
   rc = gcl_sc2_local_max(src, conf, n, nms_radius, is_max, stream);
   if (rc != GCL_OK) return rc;
-  hipLaunchKernelGGL(k_sc_seed_sort, dim3(1), dim3(1024), 0, st, (const float*)conf, (const int*)is_max, n, n_seeds,
+  hipLaunchKernelGGL(k_sc_seed_rank, dim3((unsigned)cdiv(n, SC_TILE), SC_CHUNKS), dim3(SC_TILE), 0, st, (const float*)conf,
+                     (const int*)is_max, n, rank);
+  hipLaunchKernelGGL(k_sc_seed_place, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, (const int*)rank, n, n_seeds,
                      (long long*)seeds);
-  rc = gcl_sc2_seed_knn(src, tgt, n, seeds, n_seeds, d_thre, k1, (uint64_t*)(base + L.bits), knn, stream);
+  rc = sc_seed_knn(src, tgt, n, seeds, n_seeds, d_thre, k1, (uint64_t*)(base + L.bits), !bits_from_build, knn, stream);
   if (rc != GCL_OK) return rc;
   rc = gcl_sc2_seed_trans(src, tgt, n, knn, n_seeds, k1, k2, d_thre, num_iterations, inlier_thresh, seed_trans, fitness,
                           stream);
