@@ -10,6 +10,7 @@
 #include "common.h"
 
 #include <limits.h>
+#include <stdlib.h>
 
 namespace gcl {
 
@@ -265,71 +266,117 @@ __global__ void k_bitmap_fill(const Slot* __restrict__ t, long long cap, unsigne
   atomicOr(&bitmap[b >> 5], 1u << (b & 31));
 }
 
-__device__ __forceinline__ int lookup_row(const Slot* __restrict__ t, long long cap, const unsigned* __restrict__ bitmap,
-                                          int b, int x, int y, int z) {
-  if (!pack_ok(b, x, y, z)) return -1;
-  unsigned long long key = pack_key(b, x, y, z);
-  if (bitmap) {
-    unsigned p = bitmap_pos(key);
-    if (!((bitmap[p >> 5] >> (p & 31)) & 1u)) return -1;
+// A thread answers KPT offsets of its voxel (round 5; it was one: 63 x 2070 workgroups of one dependent chain -- coordinate,
+// presence word, table slot, row -- each at the 5^3 stem map of 0.5 M voxels, wait_any 0.81): the coordinate is read once, the KPT
+// presence words are independent loads in flight together, and only then the (rare: 17 %) table probes follow.  Same entries,
+// same per-(offset, block) counts.
+// per-offset number of threads of the 256-thread block with a hit, written by threads 0 .. KPT - 1 (plain stores)
+template <int KPT>
+__device__ __forceinline__ void block_counts(const bool (&pred)[KPT], int* const (&dst)[KPT]) {
+  __shared__ int wc[KPT][4];
+#pragma unroll
+  for (int q = 0; q < KPT; ++q) {
+    const unsigned long long m = __ballot(pred[q]);
+    if ((threadIdx.x & 63) == 0) wc[q][threadIdx.x >> 6] = __popcll(m);
   }
-  long long s = table_find(t, cap, key);
-  return s >= 0 ? (int)t[s].val : -1;
-}
-
-// number of threads of the 256-thread block with `pred`, written by thread 0 (one plain store per block)
-__device__ __forceinline__ void block_count(bool pred, int* dst) {
-  __shared__ int wc[4];
-  unsigned long long m = __ballot(pred);
-  if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = __popcll(m);
   __syncthreads();
-  if (threadIdx.x == 0) *dst = wc[0] + wc[1] + wc[2] + wc[3];
+#pragma unroll
+  for (int q = 0; q < KPT; ++q)
+    if ((int)threadIdx.x == q && dst[q]) *dst[q] = wc[q][0] + wc[q][1] + wc[q][2] + wc[q][3];
 }
 
+// rows of the KPT neighbours c + o_k of one voxel (-1: absent / out of the packed range / k >= nk)
+template <int KPT>
+__device__ __forceinline__ void lookup_rows(const Slot* __restrict__ t, long long cap, const unsigned* __restrict__ bitmap,
+                                            const int4& c, int ks, int step, int k0, int nk, int (&u)[KPT]) {
+  const int r = ks / 2;
+  unsigned long long key[KPT];
+  bool maybe[KPT];
+#pragma unroll
+  for (int q = 0; q < KPT; ++q) {
+    const int k = k0 + q;
+    const int x = c.y + (k % ks - r) * step, y = c.z + ((k / ks) % ks - r) * step, z = c.w + (k / (ks * ks) - r) * step;
+    maybe[q] = k < nk && pack_ok(c.x, x, y, z);
+    key[q] = pack_key(c.x, x, y, z);
+    u[q] = -1;
+  }
+  if (bitmap) {
+    unsigned word[KPT];
+#pragma unroll
+    for (int q = 0; q < KPT; ++q) word[q] = maybe[q] ? bitmap[bitmap_pos(key[q]) >> 5] : 0u;
+#pragma unroll
+    for (int q = 0; q < KPT; ++q) maybe[q] = maybe[q] && ((word[q] >> (bitmap_pos(key[q]) & 31)) & 1u);
+  }
+#pragma unroll
+  for (int q = 0; q < KPT; ++q) {
+    if (maybe[q]) {
+      const long long s = table_find(t, cap, key[q]);
+      if (s >= 0) u[q] = (int)t[s].val;
+    }
+  }
+}
+
+template <int KPT>
 __global__ void __launch_bounds__(256) k_kernel_map(const int4* __restrict__ coords_out, long long n_out,
                                                     const Slot* __restrict__ t, long long cap,
                                                     const unsigned* __restrict__ bitmap, int ks, int step,
                                                     int* __restrict__ nbr, int* __restrict__ nbr_t,
                                                     long long n_in, int* blockcnt) {
-  long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  int k = blockIdx.y;
-  int r = ks / 2;
-  int ox = (k % ks - r) * step, oy = ((k / ks) % ks - r) * step, oz = (k / (ks * ks) - r) * step;
-  int u = -1;
-  if (v < n_out) {
-    int4 c = coords_out[v];
-    u = lookup_row(t, cap, bitmap, c.x, c.y + ox, c.z + oy, c.w + oz);
-    nbr[(long long)k * n_out + v] = u;
-    if (nbr_t != nullptr && u >= 0) nbr_t[(long long)k * n_in + u] = (int)v;
+  const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int K = ks * ks * ks, k0 = blockIdx.y * KPT;
+  int u[KPT];
+  bool hit[KPT];
+  int* dst[KPT];
+#pragma unroll
+  for (int q = 0; q < KPT; ++q) {
+    u[q] = -1;
+    dst[q] = (k0 + q < K) ? blockcnt + (long long)(k0 + q) * gridDim.x + blockIdx.x : nullptr;
   }
-  block_count(u >= 0, blockcnt + (long long)k * gridDim.x + blockIdx.x);
+  if (v < n_out) {
+    lookup_rows<KPT>(t, cap, bitmap, coords_out[v], ks, step, k0, K, u);
+#pragma unroll
+    for (int q = 0; q < KPT; ++q) {
+      const int k = k0 + q;
+      if (k < K) {
+        nbr[(long long)k * n_out + v] = u[q];
+        if (nbr_t != nullptr && u[q] >= 0) nbr_t[(long long)k * n_in + u[q]] = (int)v;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < KPT; ++q) hit[q] = u[q] >= 0;
+  block_counts<KPT>(hit, dst);
 }
 
-// same-map variant: blockIdx.y = k in [0, K/2]; the mirror half [K/2+1, K) was pre-filled with -1
+// same-map variant: offsets k in [0, K/2]; the mirror half [K/2+1, K) was pre-filled with -1
+template <int KPT>
 __global__ void __launch_bounds__(256) k_kernel_map_sym(const int4* __restrict__ coords, long long n,
                                                         const Slot* __restrict__ t, long long cap,
                                                         const unsigned* __restrict__ bitmap, int ks, int step,
                                                         int* __restrict__ nbr, int* blockcnt) {
-  long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int K = ks * ks * ks;
-  int k = blockIdx.y;
-  int u = -1;
-  if (k == K / 2) {
-    if (v < n) {
-      u = (int)v;
-      nbr[(long long)k * n + v] = u;
-    }
-  } else {
-    int r = ks / 2;
-    int ox = (k % ks - r) * step, oy = ((k / ks) % ks - r) * step, oz = (k / (ks * ks) - r) * step;
-    if (v < n) {
-      int4 c = coords[v];
-      u = lookup_row(t, cap, bitmap, c.x, c.y + ox, c.z + oy, c.w + oz);
-      nbr[(long long)k * n + v] = u;
-      if (u >= 0) nbr[(long long)(K - 1 - k) * n + u] = (int)v;   // c_u + o_{K-1-k} = c_v
+  const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int K = ks * ks * ks, k0 = blockIdx.y * KPT;
+  int u[KPT];
+  bool hit[KPT];
+  int* dst[KPT];
+#pragma unroll
+  for (int q = 0; q < KPT; ++q) {
+    u[q] = -1;
+    dst[q] = (k0 + q <= K / 2) ? blockcnt + (long long)(k0 + q) * gridDim.x + blockIdx.x : nullptr;
+  }
+  if (v < n) {
+    lookup_rows<KPT>(t, cap, bitmap, coords[v], ks, step, k0, K / 2, u);      // the centre (k = K / 2) is the voxel itself
+#pragma unroll
+    for (int q = 0; q < KPT; ++q) {
+      const int k = k0 + q;
+      if (k == K / 2) u[q] = (int)v;
+      if (k <= K / 2) nbr[(long long)k * n + v] = u[q];
+      if (k < K / 2 && u[q] >= 0) nbr[(long long)(K - 1 - k) * n + u[q]] = (int)v;   // c_u + o_{K-1-k} = c_v
     }
   }
-  block_count(u >= 0, blockcnt + (long long)k * gridDim.x + blockIdx.x);
+#pragma unroll
+  for (int q = 0; q < KPT; ++q) hit[q] = u[q] >= 0;
+  block_counts<KPT>(hit, dst);
 }
 
 // counts[k] = sum of the per-block counts (ordered, no atomics); mirror offsets share the count in a same-map
@@ -916,6 +963,11 @@ int gcl_kernel_map(const int32_t* coords_out, int64_t n_out, const int64_t* tabl
   hipStream_t st = (hipStream_t)stream;
   int K = ks * ks * ks;
   int nblk = (int)cdiv(n_out, 256);
+  static const int kpt = [] {      // GCL_MAP_KPT = 1 | 2 | 4: offsets per thread of the lookup kernels
+    const char* e = getenv("GCL_MAP_KPT");
+    const int v = e ? atoi(e) : 4;
+    return (v == 1 || v == 2) ? v : 4;
+  }();
   if (bitmap && !bitmap_valid) {
     GCL_CHECK_HIP(hipMemsetAsync(bitmap, 0, BITMAP_WORDS * sizeof(int32_t), st));
     hipLaunchKernelGGL(k_bitmap_fill, dim3((unsigned)cdiv(cap_in, 256)), dim3(256), 0, st, (const Slot*)table_in,
@@ -924,15 +976,33 @@ int gcl_kernel_map(const int32_t* coords_out, int64_t n_out, const int64_t* tabl
   if (same_map) {
     if (K > 1)
       GCL_CHECK_HIP(hipMemsetAsync(nbr + (size_t)(K / 2 + 1) * n_out, 0xFF, (size_t)(K / 2) * n_out * sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_kernel_map_sym, dim3(nblk, K / 2 + 1), dim3(256), 0, st, (const int4*)coords_out,
-                       (long long)n_out, (const Slot*)table_in, (long long)cap_in, (const unsigned*)bitmap, ks, step,
-                       nbr, scratch);
+    if (kpt == 4)
+      hipLaunchKernelGGL(k_kernel_map_sym<4>, dim3(nblk, (unsigned)cdiv(K / 2 + 1, 4)), dim3(256), 0, st, (const int4*)coords_out,
+                         (long long)n_out, (const Slot*)table_in, (long long)cap_in, (const unsigned*)bitmap, ks, step,
+                         nbr, scratch);
+    else if (kpt == 2)
+      hipLaunchKernelGGL(k_kernel_map_sym<2>, dim3(nblk, (unsigned)cdiv(K / 2 + 1, 2)), dim3(256), 0, st, (const int4*)coords_out,
+                         (long long)n_out, (const Slot*)table_in, (long long)cap_in, (const unsigned*)bitmap, ks, step,
+                         nbr, scratch);
+    else
+      hipLaunchKernelGGL(k_kernel_map_sym<1>, dim3(nblk, K / 2 + 1), dim3(256), 0, st, (const int4*)coords_out,
+                         (long long)n_out, (const Slot*)table_in, (long long)cap_in, (const unsigned*)bitmap, ks, step,
+                         nbr, scratch);
     hipLaunchKernelGGL(k_count_reduce, dim3(K / 2 + 1), dim3(256), 0, st, (const int*)scratch, nblk, K, 1, counts);
   } else {
     if (nbr_t) GCL_CHECK_HIP(hipMemsetAsync(nbr_t, 0xFF, (size_t)K * n_in * sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_kernel_map, dim3(nblk, K), dim3(256), 0, st, (const int4*)coords_out, (long long)n_out,
-                       (const Slot*)table_in, (long long)cap_in, (const unsigned*)bitmap, ks, step, nbr, nbr_t,
-                       (long long)n_in, scratch);
+    if (kpt == 4)
+      hipLaunchKernelGGL(k_kernel_map<4>, dim3(nblk, (unsigned)cdiv(K, 4)), dim3(256), 0, st, (const int4*)coords_out,
+                         (long long)n_out, (const Slot*)table_in, (long long)cap_in, (const unsigned*)bitmap, ks, step, nbr,
+                         nbr_t, (long long)n_in, scratch);
+    else if (kpt == 2)
+      hipLaunchKernelGGL(k_kernel_map<2>, dim3(nblk, (unsigned)cdiv(K, 2)), dim3(256), 0, st, (const int4*)coords_out,
+                         (long long)n_out, (const Slot*)table_in, (long long)cap_in, (const unsigned*)bitmap, ks, step, nbr,
+                         nbr_t, (long long)n_in, scratch);
+    else
+      hipLaunchKernelGGL(k_kernel_map<1>, dim3(nblk, K), dim3(256), 0, st, (const int4*)coords_out, (long long)n_out,
+                         (const Slot*)table_in, (long long)cap_in, (const unsigned*)bitmap, ks, step, nbr, nbr_t,
+                         (long long)n_in, scratch);
     hipLaunchKernelGGL(k_count_reduce, dim3(K), dim3(256), 0, st, (const int*)scratch, nblk, K, 0, counts);
   }
   GCL_CHECK_LAUNCH();
