@@ -212,3 +212,30 @@ def test_counter_figures_are_quoted_only_for_the_sources_they_were_collected_on(
         r = bench.roofline_of(prof, "fp16x3")
         assert (r["traffic"], r["mfma_busy"]) == ((123456, 0.25) if quoted else (None, None)), (stamp, r["traffic"])
         assert ("collected on these kernel sources" in r["note"]) == quoted
+
+
+def test_registration_stage_views_and_host_copies():
+    """Host pieces of the one-call registration path (gcl_amd/scripts/SC2_PCR.py) and of the eval loop's copies: the stage
+    views carve typed tensors out of ONE byte buffer at the recorded offsets; host_to_device is the identity off the GPU."""
+    import numpy as np
+    import torch
+    from gcl_amd.scripts.SC2_PCR import _Stages
+    from gcl_amd.lib.eval import host_to_device
+    fields, off = {}, 0
+    for name, count, dtype, shape in (("out", 16, torch.float32, (1, 4, 4)), ("seeds", 5, torch.int64, None),
+                                      ("knn", 6, torch.int32, (2, 3)), ("best", 1, torch.int32, None)):
+        fields[name] = (off, count, dtype, shape)
+        off += (count * dtype.itemsize + 255) // 256 * 256
+    buf = torch.zeros(off, dtype=torch.uint8)
+    st = _Stages(buf, fields)
+    st["out"][0, 3, 3] = 1.0
+    st["seeds"][:] = torch.arange(5)
+    st["knn"][1, 2] = 7
+    buf[fields["best"][0]:fields["best"][0] + 4].view(torch.int32)[0] = 3
+    assert st["out"].shape == (1, 4, 4) and float(buf[60:64].view(torch.float32)[0]) == 1.0
+    assert st["seeds"].dtype == torch.int64 and st["seeds"].tolist() == [0, 1, 2, 3, 4]
+    assert st["knn"].shape == (2, 3) and int(st["knn"][1, 2]) == 7 and int(st["best"]) == 3 and st["best"].dim() == 0
+    assert set(st.keys()) == {"out", "seeds", "knn", "best"}
+    a = np.arange(12, dtype=np.float32).reshape(4, 3)
+    t = host_to_device(a, "cpu")
+    assert isinstance(t, torch.Tensor) and t.device.type == "cpu" and np.array_equal(t.numpy(), a)
