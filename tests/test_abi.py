@@ -67,6 +67,19 @@ def test_version_and_error_string_without_gpu():
     assert lib.gcl_pack_weights_bytes(27, 64, 64, 4) == 27 * 64 * 64 * 4
     rc = lib.gcl_conv_fwd(p8, 10, 0, p8, 4, None, None, p8, None, None, 10, 27, 32, 32, None, p8, None, 0, None)
     assert rc == -1 and b"gcl_amax" in lib.gcl_last_error()
+    # round 5's entries: sizes are host arithmetic, the argument checks come before any launch
+    assert lib.gcl_nn_rowmin_scratch_len(0, 5) == 0 and lib.gcl_nn_rowmin_scratch_len(5000, 5000) >= 2500 * 2 * 64
+    rc = lib.gcl_nn_rowmin(p8, None, 10, p8, None, 10, 32, 0, None, p8, p8, None)
+    assert rc == -1 and b"scratch" in lib.gcl_last_error()
+    rc = lib.gcl_nn_rowmin(p8, None, 10, p8, None, 10, 48, 0, p8, p8, p8, None)
+    assert rc == -1 and b"16, 32 or 64" in lib.gcl_last_error()
+    assert lib.gcl_sc2_register_scratch_bytes(0) == 0 and lib.gcl_sc2_register_scratch_bytes(8193) == 0
+    need = lib.gcl_sc2_register_scratch_bytes(5000)
+    assert need > lib.gcl_sc2_confidence_scratch_bytes(5000) > 8 * 5000 * 625 * 8
+    rc = lib.gcl_sc2_register(p8, p8, 5000, 0.1, 20, 0.6, 1000, 30, 20, 0.6, 1.2, 20, None, p8, p8, p8, p8, p8, p8, p8, p8, None)
+    assert rc == -1 and b"null" in lib.gcl_last_error()
+    rc = lib.gcl_sc2_register(p8, p8, 9000, 0.1, 20, 0.6, 1000, 30, 20, 0.6, 1.2, 20, p8, p8, p8, p8, p8, p8, p8, p8, p8, None)
+    assert rc == -1 and b"n_seeds" in lib.gcl_last_error()
 
 
 def test_product_path_fails_loudly_without_gpu():
