@@ -949,6 +949,26 @@ def test_find_nn_gpu_golden(nn_max_n):
     assert len(bad) <= 2
 
 
+def test_find_nn_repeated_calls_reuse_the_scratch_block():
+    """The 1-NN search reads its pair-interleaved copy of B with SCALAR loads (csrc/loss.hip k_nn_rowmin): successive calls on
+    DIFFERENT inputs land on the same scratch block of the caching allocator -- every call must see its own copy (scalar cache
+    and L2 are made coherent at the kernel boundary), rows_a / rows_b selections included."""
+    from gcl_amd.lib.metrics import pdist_min
+    g = torch.Generator().manual_seed(11)
+    for it in range(6):
+        A = torch.nn.functional.normalize(torch.randn(700, 32, generator=g), dim=1)
+        B = torch.nn.functional.normalize(torch.randn(901, 32, generator=g), dim=1)
+        ra = torch.randperm(700, generator=g)[:333] if it % 2 else None
+        rb = torch.randperm(901, generator=g)[:555] if it % 3 == 0 else None
+        d, i = pdist_min(A.to(DEV), B.to(DEV), "SquareL2", rows_a=None if ra is None else ra.to(DEV),
+                         rows_b=None if rb is None else rb.to(DEV))
+        Ar, Br = (A if ra is None else A[ra]).double(), (B if rb is None else B[rb]).double()
+        D = ((Ar[:, None, :] - Br[None]) ** 2).sum(-1)
+        ref_d, ref_i = D.min(1)
+        assert torch.equal(i.cpu().long(), ref_i), it
+        assert float((d.cpu().double() - ref_d).abs().max()) < 2e-6
+
+
 def test_find_nn_ragged_and_ties():
     from gcl_amd.lib.eval import find_nn_gpu
     g = torch.Generator().manual_seed(0)
