@@ -706,10 +706,6 @@ __global__ void __launch_bounds__(1024) k_sc_refine_all(const float* __restrict_
   if (t == 0) { state[0] = done; state[1] = prev; }
 }
 
-}  // namespace gcl
-
-using namespace gcl;
-
 // ---- one call per registration (round 5): what scripts/SC2_PCR.py did between the stages, on the device ------------------------
 __global__ void k_sc_reg_init(float* conf, int* is_max, int* rank, int* done, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -802,6 +798,10 @@ __global__ void k_sc_finish(const float* __restrict__ src, const float* __restri
   const float wz = T[8] * s.x + T[9] * s.y + T[10] * s.z + T[11] - g.z;
   labels[i] = sqrtf(wx * wx + wy * wy + wz * wz) < thr ? 1.f : 0.f;
 }
+
+}  // namespace gcl
+
+using namespace gcl;
 
 extern "C" {
 

@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 from gcl_amd import _lib
+from gcl_amd.lib.eval import host_to_device
 from gcl_amd.lib.metrics import pdist_min
 
 import os
@@ -50,8 +51,8 @@ class Matcher:
         if self.num_node == "all":
             src_sel, tgt_sel = None, None
         else:                                                    # with replacement, as the reference (:289-290)
-            src_sel = torch.from_numpy(np.random.choice(N_src, self.num_node)).to(dev)
-            tgt_sel = torch.from_numpy(np.random.choice(N_tgt, self.num_node)).to(dev)
+            src_sel = host_to_device(np.random.choice(N_src, self.num_node), dev)      # pinned block, non-blocking copy
+            tgt_sel = host_to_device(np.random.choice(N_tgt, self.num_node), dev)
         _, arg = pdist_min(src_features[0], tgt_features[0], "SquareL2", rows_a=src_sel, rows_b=tgt_sel)
         arg = arg.long()
         src_rows = src_sel if src_sel is not None else torch.arange(N_src, device=dev)

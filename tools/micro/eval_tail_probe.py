@@ -38,11 +38,14 @@ for B in (8, 1):
           f"registration {r['reg_time'] / 8 * 1e3:.2f} ms per pair), success {r['success_rate']}")
 if len(sys.argv) > 1 and sys.argv[1] == "noprof":
     sys.exit(0)
+PB = int(sys.argv[2]) if len(sys.argv) > 2 else 8          # python3 eval_tail_probe.py prof 1: the profile at batch_pairs = 1
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(5):
-    eval_pairs(model, pairs, matcher, device=dev, batch_pairs=8)
+    eval_pairs(model, pairs, matcher, device=dev, batch_pairs=PB)
 torch.cuda.synchronize()
 pr.disable()
 st = pstats.Stats(pr)
 st.sort_stats("tottime").print_stats(22)
+if PB != 8:
+    st.sort_stats("cumtime").print_stats(18)
