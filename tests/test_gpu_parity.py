@@ -1642,9 +1642,24 @@ def test_sc2pcr_estimator_end_to_end_at_kitti_size():
     np.random.seed(0)
     T, labels, s, tt = m.estimator(torch.from_numpy(xyz0).to(DEV)[None], torch.from_numpy(xyz1).to(DEV)[None],
                                    F0.to(DEV)[None], F1.to(DEV)[None])
-    T = T[0].cpu().numpy()
-    assert np.abs(T[:3, :3] - R).max() < 2e-3 and np.abs(T[:3, 3] - t).max() < 2e-2
+    stages = {k: m.last[k].clone() for k in ("conf", "seeds", "knn", "seed_trans", "fitness", "best")}
+    Tn = T[0].cpu().numpy()
+    assert np.abs(Tn[:3, :3] - R).max() < 2e-3 and np.abs(Tn[:3, 3] - t).max() < 2e-2
     assert labels.shape == (1, 8000) and 0.2 < labels.mean().item() < 0.4 and s.shape == (1, 8000, 3)
+    # the same problem through the five staged calls (GCL_SC2_ONE_CALL=0's path): at the maximum size too, every stage and the
+    # transformation are those of the one-call form bit for bit (the tight bits come from the build pass there, from
+    # k_sc_tight_bits here; the seed order from a rank count there, from torch.sort here)
+    import gcl_amd.scripts.SC2_PCR as S
+    S.ONE_CALL = False
+    try:
+        m2 = Matcher(inlier_threshold=0.6, num_node=8000, use_mutual=False, d_thre=0.1, num_iterations=20, ratio=0.2,
+                     nms_radius=0.6, max_points=8000, k1=30, k2=20)
+        T2 = m2.SC2_PCR(s, tt)
+    finally:
+        S.ONE_CALL = True
+    assert torch.equal(T2, T)
+    for k, v in stages.items():
+        assert torch.equal(m2.last[k].to(v.dtype), v), k
 
 
 def test_forward_pair_equals_two_forward_passes_bitwise():
