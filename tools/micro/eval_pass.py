@@ -9,12 +9,13 @@ from gcl_amd.scripts.test_kitti import forward_clouds
 dev = torch.device("cuda:0")
 torch.manual_seed(0); np.random.seed(0)
 model = load_model("ResUNetBN2C")(1, 32, bn_momentum=0.05, normalize_feature=True, conv1_kernel_size=5, D=3).to(dev).eval()
-pairs = [synthetic.make_eval_pair(100 + s, baseline=15.0 + 5.0 * (s % 6)) for s in range(4)]
+PP = int(os.environ.get("EP_PAIRS", "1"))        # pairs per pass (EP_PAIRS=8: the eval loop's batch_pairs = 8 shape)
+pairs = [synthetic.make_eval_pair(100 + s, baseline=15.0 + 5.0 * (s % 6)) for s in range(4 * PP)]
 d = [{k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in p.items()} for p in pairs]
 N = int(os.environ.get("EP_PASSES", "40"))
 with torch.no_grad(), torch.cuda.device(dev):
     def one(j):
-        forward_clouds(model, [(d[j % 4][f"sinput{k}_F"], d[j % 4][f"sinput{k}_C"]) for k in (0, 1)])
+        forward_clouds(model, [(d[(j % 4) * PP + q][f"sinput{k}_F"], d[(j % 4) * PP + q][f"sinput{k}_C"]) for q in range(PP) for k in (0, 1)])
     for j in range(4):
         one(j)
     torch.cuda.synchronize()
@@ -23,5 +24,5 @@ with torch.no_grad(), torch.cuda.device(dev):
         one(j)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / N
-nv = np.mean([len(p["sinput0_C"]) + len(p["sinput1_C"]) for p in pairs])
+nv = np.mean([len(p["sinput0_C"]) + len(p["sinput1_C"]) for p in pairs]) * PP
 print(f"{dt * 1e3:.3f} ms per pass of {nv:.0f} voxels = {nv / dt / 1e6:.1f} M voxels/s")
