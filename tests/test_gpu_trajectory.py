@@ -1,0 +1,245 @@
+"""K-step training TRAJECTORY against the fp64 oracle.
+
+What ``bench.py`` times is ``train_steps`` over rotating batches: native plan, weight gradients on the aux stream, maps and
+draws prefetched by helper threads, pooled map arenas re-used across steps, cached max|W| slots re-measured per step,
+``FusedSGD`` with momentum and weight decay, BatchNorm running statistics.  Every other multi-step test compares the HIP
+path with itself; this one compares it with the oracle over six optimizer steps:
+
+    reference step: lib/colocation_trainer.py:843-887 (forward, finest_contrastive_loss, backward, optimizer.step()),
+    optimizer: lib/colocation_trainer.py:73-79 (SGD lr 0.1, momentum 0.8, weight decay 1e-4),
+    draws: np.random.choice in the loss (lib/colocation_trainer.py:457, :506-507), global numpy RNG, batch after batch.
+
+**Why the oracle is re-synchronised at every step.**  The first version of this test let the fp64 oracle run its own six
+steps from the same initial state and compared the end points.  That comparison measures the training dynamics, not the
+arithmetic: at lr 0.1 from a random initialisation the trajectory amplifies any perturbation by ~ 10 x per step.  Measured
+in THIS container with the oracle alone (CPU, same batches / draws; numbers in profiles/r06_trajectory.log):
+
+    oracle run in float32          vs fp64 oracle: loss-triple error per step 6e-7, 1.4e-4, 7.4e-3, 1.2e-2, 6.3e-2, 5.0e-2
+    fp64 oracle, parameters x (1 + 1e-7 N(0,1)) : 9e-8, 1.5e-4, 2.0e-3, 1.6e-2, 5.0e-2, 7.0e-2; kernels 3.4e-2 apart after step 6
+
+and the HIP path's free-running deviation is the same curve (logged below, not asserted beyond the first two steps).  A
+bound on the end point could only be "within the chaos envelope", which a wrong momentum buffer would pass.
+
+The test therefore runs the product FREE (no host synchronisation between the steps, helpers ahead, arenas recycled) and
+takes asynchronous device snapshots (parameters, running statistics, momentum buffers: device-to-device copies on the
+training stream) after every step.  Afterwards the oracle is started from snapshot k - 1 for every step k and must predict
+snapshot k: the loss triple of the step, the applied update of every parameter (relative to the update's own size), the
+momentum buffers, the running statistics.  Every step of the free-running trajectory is checked, at one-step conditioning.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import loss_oracle as LO          # noqa: E402
+from oracle import me_oracle as O             # noqa: E402
+
+DEV = "cuda:0"
+STEPS, SEEDS, RNG_SEED = 6, (31, 32, 33), 5
+POS, HN = 64, 256
+LR, MOMENTUM, WD = 0.1, 0.8, 1e-4
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+_CACHE = {}
+
+
+def _batches():
+    if "batches" not in _CACHE:
+        from gcl_amd import synthetic
+        _CACHE["batches"] = [synthetic.collate_train([synthetic.make_train_sample(s, num_neighborhood=2, n_boxes=10)])
+                             for s in SEEDS]
+        _CACHE["mgrs"] = [O.CoordinateManager(b["sinput_C"].numpy()) for b in _CACHE["batches"]]
+    return _CACHE["batches"]
+
+
+def _reference_draws(batches):
+    """The draws of STEPS consecutive reference steps from the global numpy RNG (lib/colocation_trainer.py:457, :506-507)."""
+    np.random.seed(RNG_SEED)
+    out = []
+    for i in range(STEPS):
+        b = batches[i % len(batches)]
+        G, N = len(b["group"]), len(b["sinput_C"])
+        pos = np.random.choice(G, POS, replace=False) if G > POS else np.arange(G)
+        out.append((pos, np.random.choice(N, min(N, HN), replace=False), np.random.choice(N, min(N, HN), replace=False)))
+    return out
+
+
+def _oracle_step(st, i, draws):
+    """One fp64 forward / loss / backward of step ``i`` on the leaves ``st`` (running statistics updated in place, as
+    BatchNorm1d does): loss triple; the gradients are left on the leaves."""
+    batches = _batches()
+    b = batches[i % len(batches)]
+    Fo = O.resunet_forward(st, b["sinput_C"].numpy(), b["sinput_F"].double(), 5, True, True, 0.05,
+                           mgr=_CACHE["mgrs"][i % len(batches)])
+    terms = LO.finest_contrastive_loss(Fo, b["group"].numpy(), b["index"].numpy(), b["index_hash"],
+                                       b["finest_flag"].numpy(), draws=draws[i], max_pos_cluster=POS, max_hn_samples=HN)
+    sum(terms).backward()                        # weights 1 / 1 / 1 (scripts/train_gcl_kitti.sh:97-98)
+    return [t.item() for t in terms]
+
+
+def _oracle_free_run(st0, dtype=torch.float64, perturb=0.0):
+    """Six steps of the oracle on its own (torch.optim.SGD = the reference's optimizer): per-step loss triples, final state."""
+    batches = _batches()
+    draws = _reference_draws(batches)
+    g = torch.Generator().manual_seed(1)
+    st = {}
+    for k, v in st0.items():
+        if perturb:
+            v = v * (1 + perturb * torch.randn(v.shape, generator=g, dtype=torch.float64))
+        st[k] = v.to(dtype).clone().requires_grad_("running" not in k)
+    opt = torch.optim.SGD([v for v in st.values() if v.requires_grad], lr=LR, momentum=MOMENTUM, weight_decay=WD)
+    triples = []
+    for i in range(STEPS):
+        opt.zero_grad()
+        if dtype == torch.float64:
+            triples.append(_oracle_step(st, i, draws))
+        else:
+            b = batches[i % len(batches)]
+            Fo = O.resunet_forward(st, b["sinput_C"].numpy(), b["sinput_F"].to(dtype), 5, True, True, 0.05,
+                                   mgr=_CACHE["mgrs"][i % len(batches)])
+            terms = LO.finest_contrastive_loss(Fo, b["group"].numpy(), b["index"].numpy(), b["index_hash"],
+                                               b["finest_flag"].numpy(), draws=draws[i], max_pos_cluster=POS,
+                                               max_hn_samples=HN)
+            sum(terms).backward()
+            triples.append([t.item() for t in terms])
+        opt.step()
+    return np.array(triples), {k: v.detach().double().clone() for k, v in st.items()}
+
+
+def _cls(name):
+    return "running" if "running" in name else ("bn" if ".bn." in name else "kernel")
+
+
+# Bounds = 2 x the larger of the two arithmetics' measured worst case over the six steps (MI355X, profiles/r06_trajectory.log).
+# Measured worst case over the six steps, fp16x3 / f32: loss 2.3e-7 / 1.8e-7; update of a kernel tensor 6.7e-3 / 4.5e-3 (first
+# step, random initialisation: the gradient error of tests/test_gpu_boundary.py's full-size check), of a BatchNorm parameter
+# 4.9e-3 / 5.0e-3; running statistics 2.0e-7 / 4.2e-7.  (A BatchNorm weight near 1.0 moving by ~1e-4 per step shows ~4e-4 of
+# "update error" in BOTH arithmetics while its momentum buffer agrees to 1e-6: that is the float32 rounding of the stored
+# parameter itself, which the reference has too.)
+LOSS_RTOL = 5e-6                      # loss triple of a step, from the same parameters (one forward pass)
+UPDATE_BOUNDS = {"kernel": 1.4e-2, "bn": 1e-2}        # |applied update - oracle update| / |oracle update|, per tensor
+MOMENTUM_BOUNDS = {"kernel": 1.4e-2, "bn": 1e-2}      # momentum buffer after the step, same measure
+GLOBAL_UPDATE_BOUND = 5e-3            # the same measure over ALL parameters as one vector
+RUNNING_BOUND = 2e-6                  # running_mean / running_var after the step, rel-L2 of the value
+
+
+@pytest.mark.parametrize("precision", ["fp16x3", "f32"])
+def test_six_step_trajectory_every_step_predicted_by_the_fp64_oracle(precision):
+    import gcl_amd.MinkowskiEngine as ME
+    from conftest import precision_log_path
+    from gcl_amd.MinkowskiEngine import native, ops
+    from gcl_amd.lib.colocation_trainer import FinestContrastiveLossTrainer, make_config, prefetch_to_device
+    batches = _batches()
+    keys = ("sinput_C", "sinput_F", "group", "index", "finest_flag")
+    host = [{k: v for k, v in b.items() if k in keys} for b in batches]
+    cfg = make_config(batch_size=1, num_pos_per_batch=POS, num_hn_samples_per_batch=HN, lr=LR, momentum=MOMENTUM,
+                      weight_decay=WD)
+    old = ops.PRECISION
+    ME.set_conv_precision(precision)
+    try:
+        with torch.cuda.device(DEV):
+            torch.manual_seed(17)
+            tr = FinestContrastiveLossTrainer(cfg, device=torch.device(DEV))
+            names = [n for n, _ in tr.model.named_parameters()]
+            params = [p for _, p in tr.model.named_parameters()]
+
+            def snapshot():           # device-to-device copies on the training stream: no host synchronisation
+                s = {k: v.detach().clone() for k, v in tr.model.state_dict().items()}
+                for n, p in zip(names, params):
+                    buf = tr.optimizer.state[p].get("momentum_buffer") if p in tr.optimizer.state else None
+                    s["momentum::" + n] = buf.detach().clone() if buf is not None else torch.zeros_like(p)
+                return s
+
+            snaps, losses = [snapshot()], []
+            np.random.seed(RNG_SEED)
+            seq = [host[i % len(host)] for i in range(STEPS)]
+            for loss, parts, n in tr.train_steps(prefetch_to_device(seq, DEV, keys)):
+                losses.append(torch.stack([p.reshape(()) for p in parts]))        # device scalars, read at the end
+                snaps.append(snapshot())
+            torch.cuda.synchronize()
+            if precision == "fp16x3":
+                assert isinstance(tr.model.__dict__.get("_plan"), native.NetworkPlan), "steps 2.. must run the native plan"
+                assert native.AUX_STREAM and tr.model._plan._aux is not None
+            got = np.array([l.double().cpu().numpy() for l in losses])
+            snaps = [{k: v.double().cpu() for k, v in s.items()} for s in snaps]
+    finally:
+        ME.set_conv_precision(old)
+    assert len(snaps) == STEPS + 1
+    draws = _reference_draws(batches)
+    lines = [f"trajectory {precision}: {STEPS} free-running steps over {len(batches)} batches "
+             f"({[len(b['sinput_C']) for b in batches]} voxels), lr {LR} momentum {MOMENTUM} wd {WD}; "
+             f"oracle restarted from the product's snapshot before every step"]
+    worst = {"loss": 0.0, "running": 0.0, "update": {}, "momentum": {}}
+    fails = []
+    for i in range(STEPS):
+        s0, s1 = snaps[i], snaps[i + 1]
+        st = {k: v.clone().requires_grad_("running" not in k) for k, v in s0.items()
+              if "num_batches" not in k and not k.startswith("momentum::")}
+        want = np.array(_oracle_step(st, i, draws))
+        e_loss = float((np.abs(got[i] - want) / np.maximum(np.abs(want), 1e-3)).max())
+        e_upd, e_mom, e_run = {}, {}, {}
+        num = den = 0.0
+        for n in names:
+            p0, g = s0[n], st[n].grad
+            d = g + WD * p0                                       # torch.optim.SGD: dampening 0, no Nesterov
+            buf = d if i == 0 else MOMENTUM * s0["momentum::" + n] + d
+            upd = -LR * buf
+            e_upd[n] = rel_l2(s1[n] - p0, upd)
+            num += float(((s1[n] - p0 - upd.detach()) ** 2).sum())
+            den += float((upd.detach() ** 2).sum())
+            e_mom[n] = rel_l2(s1["momentum::" + n], buf)
+        for k in st:
+            if "running" in k:
+                e_run[k] = rel_l2(s1[k], st[k].detach())
+        ku, km, kr = max(e_upd, key=e_upd.get), max(e_mom, key=e_mom.get), max(e_run, key=e_run.get)
+        e_glob = (num / max(den, 1e-300)) ** 0.5
+        worst["global"] = max(worst.get("global", 0.0), e_glob)
+        if e_glob >= GLOBAL_UPDATE_BOUND:
+            fails.append((i + 1, "all parameters", e_glob))
+        lines.append(f"trajectory {precision} step {i + 1}: loss got {got[i].round(6).tolist()} oracle "
+                     f"{want.round(6).tolist()} rel err {e_loss:.2e}; update of all parameters as one vector "
+                     f"{e_glob:.2e}; worst update err {e_upd[ku]:.2e} ({ku}); worst "
+                     f"momentum err {e_mom[km]:.2e} ({km}); worst running-stat err {e_run[kr]:.2e} ({kr})")
+        worst["loss"], worst["running"] = max(worst["loss"], e_loss), max(worst["running"], e_run[kr])
+        for n in names:
+            c = _cls(n)
+            worst["update"][c] = max(worst["update"].get(c, 0.0), e_upd[n])
+            worst["momentum"][c] = max(worst["momentum"].get(c, 0.0), e_mom[n])
+            if e_upd[n] >= UPDATE_BOUNDS[c] or e_mom[n] >= MOMENTUM_BOUNDS[c]:
+                fails.append((i + 1, n, e_upd[n], e_mom[n]))
+        if e_loss >= LOSS_RTOL:
+            fails.append((i + 1, "loss", e_loss))
+        if e_run[kr] >= RUNNING_BOUND:
+            fails.append((i + 1, kr, e_run[kr]))
+        for k, v in s1.items():
+            if "num_batches_tracked" in k:
+                assert int(v) == i + 1, (k, int(v), i + 1)
+    lines.append(f"trajectory {precision} worst over {STEPS} steps: loss {worst['loss']:.2e}, whole update "
+                 f"{worst['global']:.2e}, per tensor {worst['update']}, "
+                 f"momentum {worst['momentum']}, running statistics {worst['running']:.2e}")
+    # ---- the free-running comparison, as information (see the module docstring): the oracle on its own from snapshot 0
+    st0 = {k: v for k, v in snaps[0].items() if "num_batches" not in k and not k.startswith("momentum::")}
+    fkey = ("free", float(sum(float(v.abs().sum()) for v in st0.values())))     # both arithmetics start from one state
+    if fkey not in _CACHE:
+        _CACHE[fkey] = _oracle_free_run(st0)
+    free, free_final = _CACHE[fkey]
+    e_free = (np.abs(got - free) / np.maximum(np.abs(free), 1e-3)).max(1)
+    drift = max(rel_l2(snaps[-1][n], free_final[n]) for n in names if "kernel" in n)
+    moved = max(rel_l2(free_final[n], st0[n]) for n in names if "kernel" in n)
+    lines.append(f"trajectory {precision} FREE-RUNNING oracle (not a parity criterion): loss-triple deviation per step "
+                 f"{[float(f'{e:.2e}') for e in e_free]}; kernels apart after step {STEPS}: {drift:.2e} "
+                 f"(largest relative kernel movement over the steps {moved:.2e})")
+    with open(precision_log_path(), "a") as fh:
+        fh.write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+    assert not fails, (precision, fails[:8])
+    assert moved > 1e-2, "the trajectory must actually move the parameters"
+    assert e_free[0] < LOSS_RTOL and e_free[1] < 1e-2, e_free
