@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(SC_TILE) k_sc_matvec(const float* __restrict__
     const int m = min(SC_TILE, j1 - jb);
     for (int q = 0; q < m; ++q) {
       const float cd = fabsf(dist3(si, P3{ts[q][0], ts[q][1], ts[q][2]}) - dist3(ti, P3{ts[q][3], ts[q][4], ts[q][5]}));
-      acc += fmaxf(1.f - cd * cd / d2_thre, 0.f) * ts[q][6];
+      acc = __builtin_fmaf(fmaxf(1.f - cd * cd / d2_thre, 0.f), ts[q][6], acc);      // one fma, as the sparse walks write it
     }
   }
   if (ok) partial[(size_t)blockIdx.y * n + i] = acc;
@@ -193,8 +193,22 @@ __global__ void __launch_bounds__(SC_TILE) k_sc_matvec_folded(int n, float* x, i
   const size_t seg = (size_t)blockIdx.y * n + i;
   const ScEntry* e = entries + seg * per;
   const int cnt = count[seg];
+  // four entries per trip as two 16-byte loads (a segment starts on a multiple of 8 bytes x per: 16-byte aligned when per is
+  // even, else entry by entry); the terms are added in the segment's order by explicit fmas (left to the compiler, the
+  // unrolled body became packed multiplies + adds: not the dense kernel's roundings)
   float acc = 0.f;
-  for (int q = 0; q < cnt; ++q) acc += e[q].m * xs[e[q].j];
+  int q = 0;
+  if ((per & 1) == 0) {
+    const int4* e4 = reinterpret_cast<const int4*>(e);
+    for (; q + 4 <= cnt; q += 4) {
+      const int4 a = e4[q >> 1], b = e4[(q >> 1) + 1];
+      acc = __builtin_fmaf(__int_as_float(a.y), xs[a.x], acc);
+      acc = __builtin_fmaf(__int_as_float(a.w), xs[a.z], acc);
+      acc = __builtin_fmaf(__int_as_float(b.y), xs[b.x], acc);
+      acc = __builtin_fmaf(__int_as_float(b.w), xs[b.z], acc);
+    }
+  }
+  for (; q < cnt; ++q) acc = __builtin_fmaf(e[q].m, xs[e[q].j], acc);
   partial[seg] = acc;
 }
 __global__ void __launch_bounds__(SC_TILE) k_sc_matvec_sparse(int n, const float* __restrict__ x, const int* __restrict__ done,
@@ -208,7 +222,7 @@ __global__ void __launch_bounds__(SC_TILE) k_sc_matvec_sparse(int n, const float
   const ScEntry* e = entries + seg * per;
   const int cnt = count[seg];
   float acc = 0.f;
-  for (int q = 0; q < cnt; ++q) acc += e[q].m * x[e[q].j];
+  for (int q = 0; q < cnt; ++q) acc = __builtin_fmaf(e[q].m, x[e[q].j], acc);
   partial[seg] = acc;
 }
 
@@ -397,6 +411,156 @@ __global__ void __launch_bounds__(256) k_sc_seed_knn(const float* __restrict__ s
         if (q == (besti >> 8)) v[q] = -1;
     }
     __syncthreads();
+  }
+}
+
+// ---- the same second-order rows, SEED-BLOCKED (round 6) ----------------------------------------------------------------------
+// k_sc_seed_knn streams the 1 KB bit row of every compatible column ONCE PER SEED: a seed that is an inlier is compatible with
+// every other inlier, so at an inlier share p the 0.2 n seeds read ~ 0.2 p n^2 KB from L2 -- 3.8 GB per registration at p = 0.3,
+// n = 8000 (624 us; 1148 us at p = 0.6; the zero-inlier pairs of round 5's benchmark: 148 us).  Here a workgroup takes SK_TS
+// seeds x one of the SC_CHUNKS column chunks: every wave holds the SK_TS seed rows in registers (2 x SK_TS 64-bit words per
+// lane), the chunk's columns that are hard-compatible with ANY of the seeds are listed once, and a listed column's row is
+// read once for all SK_TS seeds (lane = word, coalesced): SK_TS x fewer bytes, the AND + popcount work unchanged.  The 64
+// lanes' partial counts of the SK_TS seeds are packed four to a 64-bit word and summed by a reduce-scatter butterfly (7 word
+// shuffles per column instead of 6 per column and seed).  Counts that are not hard-compatible are zero, as in k_sc_seed_knn;
+// the values go to vals[seed][column] (uint16: a count is <= n <= 8192) and k_sc_seed_topk makes the same selection from them.
+// Integers throughout: the k1 lists are those of k_sc_seed_knn (tests: one call == staged calls, bit for bit).
+constexpr int SK_TS = 16;
+__global__ void __launch_bounds__(256) k_sc_seed_sc2(const float* __restrict__ src, const float* __restrict__ tgt,
+                                                     const unsigned long long* __restrict__ bits, int n, int words,
+                                                     const long long* __restrict__ seeds, int n_seeds, float d_thre,
+                                                     unsigned short* __restrict__ vals) {
+  __shared__ unsigned short out[SK_TS][SB_PER_MAX];
+  __shared__ unsigned short lst[SB_PER_MAX], hm[SB_PER_MAX];
+  __shared__ float sp[SK_TS][6];
+  __shared__ int sid[SK_TS];
+  __shared__ int cnt;
+  const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int per = (n + SC_CHUNKS - 1) / SC_CHUNKS;
+  const int j0 = blockIdx.y * per, j1 = min(n, j0 + per), m = j1 - j0;
+  const int s0 = blockIdx.x * SK_TS;
+  if (t < SK_TS) {
+    const int r = s0 + t < n_seeds ? (int)seeds[s0 + t] : -1;
+    sid[t] = r;
+    for (int a = 0; a < 3; ++a) { sp[t][a] = r >= 0 ? src[3 * r + a] : 0.f; sp[t][3 + a] = r >= 0 ? tgt[3 * r + a] : 0.f; }
+  }
+  if (t == 0) cnt = 0;
+  for (int q = t; q < SK_TS * SB_PER_MAX; q += 256) (&out[0][0])[q] = 0;
+  __syncthreads();
+  // hard[seed][j] for the chunk's columns (the same |.| < d_thre k_sc_seed_knn evaluates), columns with any bit listed
+  for (int q = t; q < m; q += 256) {
+    const P3 sj = ld3(src, j0 + q), tj = ld3(tgt, j0 + q);
+    unsigned mask = 0;
+#pragma unroll
+    for (int u = 0; u < SK_TS; ++u) {
+      const bool hard = fabsf(dist3(P3{sp[u][0], sp[u][1], sp[u][2]}, sj) - dist3(P3{sp[u][3], sp[u][4], sp[u][5]}, tj)) < d_thre;
+      mask |= (unsigned)(hard && sid[u] >= 0) << u;
+    }
+    if (mask) {
+      const int at = atomicAdd(&cnt, 1);      // any order: a column's counts do not depend on its place in the list
+      lst[at] = (unsigned short)q;
+      hm[at] = (unsigned short)mask;
+    }
+  }
+  // the seeds' bit rows: words lane and lane + 64 (words <= 128)
+  unsigned long long r0[SK_TS], r1[SK_TS];
+#pragma unroll
+  for (int u = 0; u < SK_TS; ++u) {
+    const int r = sid[u];
+    const unsigned long long* br = bits + (size_t)(r >= 0 ? r : 0) * words;
+    r0[u] = (r >= 0 && lane < words) ? br[lane] : 0ull;
+    r1[u] = (r >= 0 && lane + 64 < words) ? br[lane + 64] : 0ull;
+  }
+  __syncthreads();
+  const int listed = cnt;
+  const bool hi32 = lane & 32, hi16 = lane & 16;
+  for (int c = w; c < listed; c += 4) {
+    const int q = lst[c];
+    const unsigned long long* bj = bits + (size_t)(j0 + q) * words;
+    const unsigned long long a0 = lane < words ? bj[lane] : 0ull, a1 = lane + 64 < words ? bj[lane + 64] : 0ull;
+    unsigned long long pk[SK_TS / 4];
+#pragma unroll
+    for (int g = 0; g < SK_TS / 4; ++g) {
+      unsigned long long v = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        v |= (unsigned long long)(__popcll(r0[4 * g + k] & a0) + __popcll(r1[4 * g + k] & a1)) << (16 * k);
+      pk[g] = v;
+    }
+    // reduce-scatter over the lanes (16-bit fields: a wave's sum is <= 8192, no carry): lanes with bit 5 clear keep packs
+    // 0, 1, the others 2, 3; then bit 4 picks one of the two; then a plain butterfly inside each group of 16 lanes
+    unsigned long long A = hi32 ? pk[2] : pk[0], B = hi32 ? pk[3] : pk[1];
+    A += __shfl_xor(hi32 ? pk[0] : pk[2], 32);
+    B += __shfl_xor(hi32 ? pk[1] : pk[3], 32);
+    unsigned long long X = hi16 ? B : A;
+    X += __shfl_xor(hi16 ? A : B, 16);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) X += __shfl_xor(X, o);
+    if ((lane & 15) == 0) {
+      const int g = (hi32 ? 2 : 0) + (hi16 ? 1 : 0);
+      const unsigned mask = hm[c];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if ((mask >> (4 * g + k)) & 1u) out[4 * g + k][q] = (unsigned short)((X >> (16 * k)) & 0xffffull);
+    }
+  }
+  __syncthreads();
+  for (int u = 0; u < SK_TS; ++u) {
+    if (s0 + u >= n_seeds) break;
+    unsigned short* row = vals + (size_t)(s0 + u) * n + j0;
+    for (int q = t; q < m; q += 256) row[q] = out[u][q];
+  }
+}
+
+// the k1 largest entries of a seed's row of `vals` (value descending, index ascending), ONE WAVE per seed over a two-level
+// tournament: the row sits in LDS (16 KB), lane l keeps the maxima of the 64-column blocks l and l + 64 as keys
+// (value << 13 | 8191 - column) + 1 -- the largest key is the largest value at the lowest column -- and a round is a butterfly
+// over the block maxima, one store that marks the winner taken, and a butterfly over the winner's block read back by all 64
+// lanes: ~ 20 instructions per round.  (Round 6's first forms kept every column of a thread in registers and let the owner of
+// the winner scan them again: 32 columns x 4 waves + an exchange through LDS, or 125 columns in one wave -- 82 - 104 us per
+// registration for 1600 seeds, all of it a single lane scanning while its wave waits.)
+constexpr unsigned short SK_TAKEN = 0xffff;      // a count is <= 8192
+__device__ __forceinline__ unsigned sc_topk_key(unsigned short v, int j, int n) {
+  return (j < n && v != SK_TAKEN) ? ((((unsigned)v) << 13) | (unsigned)(8191 - j)) + 1u : 0u;
+}
+// maximum over the wave, uniform: four DPP steps inside every row of 16 lanes (quad swaps, half-row mirror, row mirror),
+// then the four rows through scalar registers -- ~ 10 short instructions; a butterfly of ds_bpermute shuffles was a chain
+// of six LDS-pipe round trips (k_sc_seed_topk: 82 -> 60 us with it, the rounds were nothing but that latency)
+__device__ __forceinline__ unsigned sc_wave_umax(unsigned v) {
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));       // quad_perm [1,0,3,2]
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));       // quad_perm [2,3,0,1]
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));      // row_half_mirror
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true));      // row_mirror
+  const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+  const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+  return max(max(a, b), max(c, d));
+}
+__global__ void __launch_bounds__(64) k_sc_seed_topk(const unsigned short* __restrict__ vals, int n, int k1, int* knn) {
+  __shared__ unsigned short row[SC_MAXN];
+  const int lane = threadIdx.x;
+  const unsigned short* g = vals + (size_t)blockIdx.x * n;
+  for (int j = lane; j < SC_MAXN; j += 64) row[j] = j < n ? g[j] : SK_TAKEN;
+  __syncthreads();
+  // lane l: the maxima of blocks l and l + 64, its 64 columns read in a rotated order (lanes on different banks)
+  unsigned bm[2] = {0u, 0u};
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+    for (int k = 0; k < 64; ++k) {
+      const int j = 64 * (lane + 64 * h) + ((k + lane) & 63);
+      bm[h] = max(bm[h], sc_topk_key(row[j], j, n));
+    }
+  for (int round = 0; round < k1; ++round) {
+    const unsigned best = sc_wave_umax(max(bm[0], bm[1]));
+    const int besti = 8191 - (int)((best - 1u) & 8191u);      // k1 <= n: there is always an entry left
+    const int b = besti >> 6;
+    if (lane == 0) {
+      knn[blockIdx.x * k1 + round] = besti;
+      row[besti] = SK_TAKEN;
+    }
+    __syncthreads();      // one wave: orders the store before the block's reads
+    const int j = 64 * b + lane;
+    const unsigned nb = sc_wave_umax(sc_topk_key(row[j], j, n));
+    if (lane == (b & 63)) bm[b >> 6] = nb;
   }
 }
 
@@ -884,8 +1048,19 @@ int gcl_sc2_local_max(const float* src, const float* conf, int32_t n, float radi
   return GCL_OK;
 }
 
+static bool sc_seed_blocked() {      // GCL_SC2_SEED_BLOCKED=0: k_sc_seed_knn (one workgroup per seed) in the one-call form too
+  static const bool on = [] {
+    const char* e = getenv("GCL_SC2_SEED_BLOCKED");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
+// `vals` (uint16[n_seeds * n], may be null): scratch of the seed-blocked form; without it one workgroup per seed streams the
+// rows of its compatible columns (k_sc_seed_knn, the staged entry point's form -- same integers, same lists)
 static int sc_seed_knn(const float* src, const float* tgt, int32_t n, const int64_t* seeds, int32_t n_seeds,
-                       float d_thre, int32_t k1, uint64_t* bits, bool make_bits, int32_t* knn, void* stream) {
+                       float d_thre, int32_t k1, uint64_t* bits, bool make_bits, int32_t* knn, void* stream,
+                       unsigned short* vals = nullptr) {
   GCL_CHECK_ARG(src && tgt && seeds && bits && knn, "gcl_sc2_seed_knn: null pointer");
   GCL_CHECK_ARG(n > 0 && n <= SC_MAXN && n_seeds > 0 && k1 >= 1 && k1 <= 32 && k1 <= n,
                 "gcl_sc2_seed_knn: need n <= %d, 1 <= k1 <= min(32, n)", SC_MAXN);
@@ -894,8 +1069,14 @@ static int sc_seed_knn(const float* src, const float* tgt, int32_t n, const int6
   if (make_bits)
     hipLaunchKernelGGL(k_sc_tight_bits, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, st, src, tgt, n, words, d_thre * 0.5f,
                        (unsigned long long*)bits);
-  hipLaunchKernelGGL(k_sc_seed_knn, dim3(n_seeds), dim3(256), 0, st, src, tgt, (const unsigned long long*)bits, n,
-                     words, (const long long*)seeds, d_thre, k1, knn);
+  if (vals && sc_seed_blocked()) {
+    hipLaunchKernelGGL(k_sc_seed_sc2, dim3((unsigned)cdiv(n_seeds, SK_TS), SC_CHUNKS), dim3(256), 0, st, src, tgt,
+                       (const unsigned long long*)bits, n, words, (const long long*)seeds, n_seeds, d_thre, vals);
+    hipLaunchKernelGGL(k_sc_seed_topk, dim3(n_seeds), dim3(64), 0, st, (const unsigned short*)vals, n, k1, knn);
+  } else {
+    hipLaunchKernelGGL(k_sc_seed_knn, dim3(n_seeds), dim3(256), 0, st, src, tgt, (const unsigned long long*)bits, n,
+                       words, (const long long*)seeds, d_thre, k1, knn);
+  }
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }
@@ -991,7 +1172,10 @@ int gcl_sc2_register(const float* src, const float* tgt, int32_t n, float d_thre
                      (const int*)is_max, n, rank);
   hipLaunchKernelGGL(k_sc_seed_place, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, (const int*)rank, n, n_seeds,
                      (long long*)seeds);
-  rc = sc_seed_knn(src, tgt, n, seeds, n_seeds, d_thre, k1, (uint64_t*)(base + L.bits), !bits_from_build, knn, stream);
+  // the second-order values of the seed-blocked form (uint16[n_seeds * n] <= 2 n^2 bytes) take the place of the confidence's
+  // entry slab (8 n^2 bytes, behind its counts), which nothing reads after the last product
+  unsigned short* vals = (unsigned short*)(base + L.sparse + (((size_t)SC_CHUNKS * n * 4 + 255) & ~(size_t)255));
+  rc = sc_seed_knn(src, tgt, n, seeds, n_seeds, d_thre, k1, (uint64_t*)(base + L.bits), !bits_from_build, knn, stream, vals);
   if (rc != GCL_OK) return rc;
   rc = gcl_sc2_seed_trans(src, tgt, n, knn, n_seeds, k1, k2, d_thre, num_iterations, inlier_thresh, seed_trans, fitness,
                           stream);

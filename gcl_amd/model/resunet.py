@@ -129,14 +129,19 @@ class ResUNet2(ME.MinkowskiNetwork):
     def _module_list(self):
         """``list(self.modules())`` / the parameter count, walked once per model structure: the two guards of the inference
         path cost 0.17 ms per pass when they walk the module tree (a pass over one pair is host-bound).  Re-walked when the
-        set of registered sub-modules or parameters of ANY module changed size (add_module / register_parameter)."""
+        registered sub-modules or parameters of ANY module changed -- by count (add_module / register_parameter) or by
+        IDENTITY (``model.block1 = NewBlock()``, a norm-layer swap under the same name keeps every count)."""
         c = self.__dict__.get("_walk_cache")
-        if c is not None and all(len(m._modules) == a and len(m._parameters) == b for m, a, b in c[2]):
+        if c is not None and all(self._children_ids(m) == ids for m, ids in c[2]):
             return c[0]
         mods = list(self.modules())
-        sizes = [(m, len(m._modules), len(m._parameters)) for m in mods]
-        self.__dict__["_walk_cache"] = (mods, sum(1 for _ in self.parameters()), sizes)
+        ids = [(m, self._children_ids(m)) for m in mods]
+        self.__dict__["_walk_cache"] = (mods, sum(1 for _ in self.parameters()), ids)
         return mods
+
+    @staticmethod
+    def _children_ids(m):
+        return [id(v) for v in m._modules.values()] + [id(v) for v in m._parameters.values()]
 
     def _n_parameters(self):
         self._module_list()

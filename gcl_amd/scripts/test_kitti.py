@@ -114,8 +114,12 @@ def forward_clouds_stream(model, cloud_sets, device=None, depth=3, exec_streams=
             if e is not None:
                 e.wait_event(started)
 
-    def build(clouds, slot):
+    def build(clouds, slot, inputs_ready):
         with torch.cuda.device(dev), torch.cuda.stream(side):
+            # device tensors of this set may have been produced on the caller's stream after the generator started (a lazy
+            # ``((f.to(dev), c.to(dev)) for ...)``, or the output of earlier kernels): the side stream reads them only behind
+            # everything the caller had enqueued when the set was pulled
+            side.wait_event(inputs_ready)
             if slot["free"] is not None:
                 side.wait_event(slot["free"])           # the pass that read this arena last has been enqueued and has run
             Fs, Cs = [], []
@@ -149,7 +153,9 @@ def forward_clouds_stream(model, cloud_sets, device=None, depth=3, exec_streams=
     with concurrent.futures.ThreadPoolExecutor(max_workers=1) as pool, torch.cuda.device(dev):
         pending, k = [], 0
         for clouds in sets:
-            pending.append(pool.submit(build, clouds, ring[k % len(ring)]))
+            pulled = torch.cuda.Event()
+            pulled.record(torch.cuda.current_stream())
+            pending.append(pool.submit(build, clouds, ring[k % len(ring)], pulled))
             k += 1
             if len(pending) > depth:
                 yield run(pending.pop(0).result())
@@ -191,7 +197,9 @@ def eval_pairs(model, pairs, matcher, device=None, batch_pairs=1, subsample_size
                rte_thresh=2.0, rre_thresh=5.0, collect=False):
     """The loop of scripts/test_kitti.py:129-227 over ``pairs`` (dicts with the keys of ``collate_debug_pair_fn``:
     pcd0 / pcd1, sinput{0,1}_C, sinput{0,1}_F, T_gt).  Returns a dict with the three meters' summary, the per-pair
-    lists (T_est, rte, rre, success, nn distances when ``collect``) and the stage times in seconds."""
+    lists (T_est, rte, rre, success, nn distances when ``collect``) and ``feat_enqueue_time`` / ``reg_enqueue_time``: the HOST
+    time spent enqueuing the two stages, in seconds -- the loop is asynchronous, so these are not the reference's
+    feat_timer / reg_timer (scripts/test_kitti.py:141-180), which include the device time behind a per-pair ``.to('cpu')``."""
     if matcher is None:
         raise NotImplementedError("only the SC2-PCR branch (use_RANSAC false) is built: open3d RANSAC is a CPU third party")
     dev = torch.device(device) if device is not None else next(model.parameters()).device
@@ -291,5 +299,5 @@ def eval_pairs(model, pairs, matcher, device=None, batch_pairs=1, subsample_size
                 main.wait_stream(st)
             main.wait_stream(collector)
     out.update(rte_avg=rte_meter.avg, rte_var=rte_meter.var, rre_avg=rre_meter.avg, rre_var=rre_meter.var,
-               success_rate=success_meter.avg, n_pairs=success_meter.count, feat_time=t_feat, reg_time=t_reg)
+               success_rate=success_meter.avg, n_pairs=success_meter.count, feat_enqueue_time=t_feat, reg_enqueue_time=t_reg)
     return out

@@ -286,6 +286,71 @@ def make_eval_pair(seed, voxel_size=0.3, baseline=10.0, n_boxes=60):
     return out
 
 
+def make_twin_eval_pair(seed, inlier_share=0.3, voxel_size=0.3, shift_voxels=(16, 8, 0), gap_voxels=16, n_boxes=60):
+    """An eval pair (keys of ``make_eval_pair``) with a CONTROLLED share of true correspondences, for timing the eval loop on
+    registrations that have something to find with an UNTRAINED network (bench.py ``secondary``, configs[4]).
+
+    A random-init network gives unrelated views of a scene unrelated features: every putative correspondence is an outlier,
+    SC2-PCR's compatibility matrix is empty and the registration times what it never does on real data.  Here the two clouds
+    share a part exactly: the voxels of scan A on one side of a plane y = cut appear in cloud 0 and, moved by a multiple of 8
+    voxels (every U-Net level stays aligned, so twins get bit-equal features wherever their receptive fields hold twins
+    only), in cloud 1; the other side of the plane (``gap_voxels`` away) is filled with two UNRELATED scans, one per cloud.
+    ``inlier_share`` sets the shared part's share of each cloud's voxels; the share of true correspondences among the
+    loop's putative ones is lower (only a part of the twins survives the loop's 5000-row subsamples) and is what
+    bench.py measures and prints.  Input features carry a per-voxel jitter (equal on twins) so that no two voxels tie.
+    T_gt maps cloud 0 onto cloud 1 (scripts/test_kitti.py:155 applies it to xyz0)."""
+    sh = np.asarray(shift_voxels, dtype=np.int64)
+    assert (sh % 8 == 0).all(), "twins stay aligned on every level only for shifts that are multiples of 8 voxels"
+
+    def scan(scene_seed, ray_seed):
+        xyz = raycast(make_scene(scene_seed, n_boxes=n_boxes), np.zeros(3), ray_seed)
+        _, sel = me_utils.sparse_quantize(xyz / voxel_size, return_index=True)
+        xyz = xyz[sel]
+        return xyz, np.floor(xyz / voxel_size).astype(np.int64)
+
+    xa, ca = scan(seed, seed * 37)
+    n_common = int(round(len(ca) * float(inlier_share)))
+    order = np.argsort(ca[:, 1], kind="stable")
+    cut = ca[order[max(0, n_common - 1)], 1] if n_common > 0 else ca[:, 1].min() - 1
+    common = ca[:, 1] <= cut
+    clouds = []
+    for k in (0, 1):
+        xb, cb = scan(seed * 1000 + 17 + k, seed * 37 + 5 + k)
+        # the unrelated scan, moved so that its own densest part (around its sensor) sits beyond the gap
+        far = np.argsort(cb[:, 1], kind="stable")
+        n_other = max(0, len(ca) - int(common.sum()))
+        # keep the n_other voxels of lowest y, then translate them to start at cut + gap
+        keep = far[:n_other]
+        dy = (cut + gap_voxels) - cb[keep, 1].min() if n_other else 0
+        dy = int(-((-dy) // 8) * 8)               # a multiple of 8 voxels, rounding away from the shared part
+        cbk, xbk = cb[keep].copy(), xb[keep].copy()
+        # cloud 1's unrelated part also sits 3 voxels higher and 5 further along x: no voxel of it (the ground plane, which
+        # every scan shares) is the T_gt image of a voxel of cloud 0's unrelated part
+        off = np.array([5 * k, dy, 3 * k], dtype=np.int64)
+        cbk += off
+        xbk += (off * voxel_size).astype(np.float32)
+        move = sh if k == 1 else np.zeros(3, dtype=np.int64)
+        c = np.concatenate([ca[common] + move, cbk + move])
+        x = np.concatenate([xa[common] + (move * voxel_size).astype(np.float32),
+                            xbk + (move * voxel_size).astype(np.float32)]).astype(np.float32)
+        jit = np.concatenate([np.random.RandomState(seed + 1).normal(0, 0.05, int(common.sum())),      # equal on twins
+                              np.random.RandomState(seed + 2 + k).normal(0, 0.05, len(cbk))])
+        # the loader's row order carries no meaning to the path: shuffle, so that twins do not sit at equal row numbers
+        perm = np.random.RandomState(seed * 7 + k).permutation(len(c))
+        clouds.append((x[perm], c[perm].astype(np.int32), (1.0 + jit[perm]).astype(np.float32)))
+    out = {}
+    for k, (x, c, f) in enumerate(clouds):
+        out[f"pcd{k}"] = (torch.from_numpy(x),)
+        out[f"sinput{k}_C"] = me_utils.batched_coordinates([c])
+        out[f"sinput{k}_F"] = torch.from_numpy(f)[:, None].contiguous()
+    T = np.eye(4, dtype=np.float32)
+    T[:3, 3] = (sh * voxel_size).astype(np.float32)
+    out["T_gt"] = torch.from_numpy(T)
+    out["len_batch"] = [[len(clouds[0][0]), len(clouds[1][0])]]
+    out["shared_voxels"] = int(common.sum())
+    return out
+
+
 def make_box_cloud(seed, n_points=5000, cube=10.0, n_boxes=8):
     """configs[0] plumbing cloud: points uniform on the surfaces of random boxes in a ``cube`` metre cube."""
     rng = np.random.RandomState(seed)

@@ -573,24 +573,35 @@ def test_weight_gradient_row_stream_kernel_size_1(ca, cb, n):
         assert rel_l2(outs[0].double().cpu(), dw2.double().cpu()) < 2e-6
 
 
-@pytest.mark.parametrize("ca,cb,n,stride", [(128, 128, 3000, 1), (256, 128, 1500, 1), (128, 256, 40, 1), (256, 256, 700, 2),
-                                            (128, 128, 1, 1), (128, 128, 9000, 1)])
-def test_weight_gradient_128_block_kernel(ca, cb, n, stride):
+@pytest.mark.parametrize("ca,cb,n,stride,transpose", [(128, 128, 3000, 1, False), (256, 128, 1500, 1, False),
+                                                      (128, 256, 40, 1, False), (256, 256, 700, 2, False),
+                                                      (128, 128, 1, 1, False), (128, 128, 9000, 1, False),
+                                                      (128, 128, 24000, 1, False), (256, 256, 26000, 2, False),
+                                                      (256, 128, 26000, 2, True)])
+def test_weight_gradient_128_block_kernel(ca, cb, n, stride, transpose):
     """k_conv_bwd_weight_wg128 (plane images, Ca and Cb multiples of 128: a 128 x 128 block of dW[k] per workgroup, the rows
     gathered once into a shared double-buffered tile, every wave a 64 x 64 block; the default there) against the 64 x 64-block
     kernel (bit 1 of `planes`) and the fp64 product: equal to rounding (one accumulator per block walks the pairs in order
-    instead of four interleaved ones), bitwise reproducible; ragged / single-pair lists and several offsets per workgroup."""
+    instead of four interleaved ones), bitwise reproducible; ragged / single-pair lists and several offsets per workgroup.
+    The 24000 / 26000-voxel cases (round 6) run at the row counts of the benchmark's stride-4 / stride-8 levels, on a strided
+    map with 4 channel tiles, and with ``transpose`` the swapped lists of a transposed convolution (sorted side = operand A);
+    they are also the parity cases of the parked range-grouped mode (profiles/patches/r06_rg128_dw.patch)."""
     from gcl_amd import _lib
     import gcl_amd.MinkowskiEngine as ME
     lib = _lib.load()
-    C = random_cloud(ca + n, n=n, extent=14, batch=1) if n > 1 else np.zeros((1, 4), np.int32)
+    C = random_cloud(ca + n, n=n, extent=14 if n < 10000 else 40, batch=1 if n < 10000 else 2) if n > 1 \
+        else np.zeros((1, 4), np.int32)
     mgr = make_mgr(C)
     km = mgr.get_kernel_map(1, 3, stride)
     pin, pout, seg, seg_host = km.pairs()
-    n_a, n_b = len(C), mgr.num_rows(stride)
+    n_in, n_out = len(C), mgr.num_rows(stride)
     K = 27
     g = torch.Generator().manual_seed(n + ca)
     with torch.cuda.device(DEV):
+        # forward convolution: A = x over the map's in rows (pair_in), B = dy over its out rows (pair_out, ascending per
+        # offset: sorted side 2); transposed: A = x over the out rows (pair_out: sorted side 1), B = dy over the in rows
+        n_a, n_b = (n_out, n_in) if transpose else (n_in, n_out)
+        pa, pb, side = (pout, pin, 1) if transpose else (pin, pout, 2)
         a = torch.randn(n_a, ca, generator=g).to(DEV)
         b = torch.randn(n_b, cb, generator=g).to(DEV)
         aa, ba = ME.ops.amax_slot(a.device), ME.ops.amax_slot(a.device)
@@ -602,10 +613,10 @@ def test_weight_gradient_128_block_kernel(ca, cb, n, stride):
         _lib.check(lib.gcl_split_planes(_lib.ptr(b), n_b, cb, _lib.ptr(ba), _lib.ptr(xb), _lib.stream()), "split")
         out = {}
         for legacy in (1, 0, 0):
-            scratch = torch.full((lib.gcl_conv_bwd_weight_scratch_len(K, ca, cb, seg[-1], n_b),), float("nan"), device=DEV)
+            scratch = torch.full((lib.gcl_conv_bwd_weight_scratch_len(K, ca, cb, seg[-1], n_out),), float("nan"), device=DEV)
             dw = torch.full((K, ca, cb), float("nan"), device=DEV)
-            _lib.check(lib.gcl_conv_bwd_weight(_lib.ptr(xa), n_a, _lib.ptr(xb), n_b, 1 | (2 * legacy), 2, _lib.ptr(pin),
-                                               _lib.ptr(pout), seg_host, K, ca, cb, 4, _lib.ptr(aa), _lib.ptr(ba),
+            _lib.check(lib.gcl_conv_bwd_weight(_lib.ptr(xa), n_a, _lib.ptr(xb), n_b, 1 | (2 * legacy), side, _lib.ptr(pa),
+                                               _lib.ptr(pb), seg_host, K, ca, cb, 4, _lib.ptr(aa), _lib.ptr(ba),
                                                _lib.ptr(scratch), _lib.ptr(dw), _lib.stream()), "gcl_conv_bwd_weight")
             out.setdefault(legacy, []).append(dw)
         assert torch.isfinite(out[0][0]).all() and torch.equal(out[0][0], out[0][1]), "deterministic"
@@ -615,7 +626,7 @@ def test_weight_gradient_128_block_kernel(ca, cb, n, stride):
         for k in range(K):
             rows = np.nonzero(src[k] >= 0)[0]
             if len(rows):
-                want[k] = ad[src[k][rows]].T @ bd[rows]
+                want[k] = (ad[rows].T @ bd[src[k][rows]]) if transpose else (ad[src[k][rows]].T @ bd[rows])
         assert rel_l2(out[0][0].cpu(), want) < 2e-6 and rel_l2(out[1][0].cpu(), want) < 2e-6
         assert rel_l2(out[0][0].cpu(), out[1][0].cpu()) < 2e-6
 

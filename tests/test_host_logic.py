@@ -239,3 +239,23 @@ def test_registration_stage_views_and_host_copies():
     a = np.arange(12, dtype=np.float32).reshape(4, 3)
     t = host_to_device(a, "cpu")
     assert isinstance(t, torch.Tensor) and t.device.type == "cpu" and np.array_equal(t.numpy(), a)
+
+
+def test_module_walk_cache_sees_a_replaced_submodule():
+    """ResUNet2._module_list caches the module walk of the inference guards (``any(m.training ...)``): a sub-module
+    REPLACED under the same name (same counts everywhere) must invalidate it -- a replaced norm layer left in training
+    mode has to stop the eval plan."""
+    import gcl_amd.MinkowskiEngine as ME
+    from gcl_amd.model import load_model
+    m = load_model("ResUNetBN2C")(1, 32, bn_momentum=0.05, normalize_feature=True, conv1_kernel_size=5, D=3)
+    m.eval()
+    first = m._module_list()
+    assert m._module_list() is first                       # cached
+    assert not any(x.training for x in first)
+    new = ME.MinkowskiBatchNorm(32, momentum=0.05)          # fresh modules are in training mode
+    m.block1.norm1 = new
+    mods = m._module_list()
+    assert mods is not first and any(x is new for x in mods) and any(x.training for x in mods)
+    n = m._n_parameters()
+    m.block1.conv1.kernel = torch.nn.Parameter(m.block1.conv1.kernel.detach().clone())       # same count, new identity
+    assert m._module_list() is not mods and m._n_parameters() == n

@@ -34,8 +34,8 @@ for B in (8, 1):
         r = eval_pairs(model, pairs, matcher, device=dev, batch_pairs=B)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 5
-    print(f"batch_pairs={B}: {8 / dt:.1f} pairs/s, {dt / 8 * 1e3:.2f} ms per pair (enqueue: features {r['feat_time'] / 8 * 1e3:.2f} ms, "
-          f"registration {r['reg_time'] / 8 * 1e3:.2f} ms per pair), success {r['success_rate']}")
+    print(f"batch_pairs={B}: {8 / dt:.1f} pairs/s, {dt / 8 * 1e3:.2f} ms per pair (enqueue: features {r['feat_enqueue_time'] / 8 * 1e3:.2f} ms, "
+          f"registration {r['reg_enqueue_time'] / 8 * 1e3:.2f} ms per pair), success {r['success_rate']}")
 if len(sys.argv) > 1 and sys.argv[1] == "noprof":
     sys.exit(0)
 PB = int(sys.argv[2]) if len(sys.argv) > 2 else 8          # python3 eval_tail_probe.py prof 1: the profile at batch_pairs = 1

@@ -17,4 +17,4 @@ for seed in (None, 0, None):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     r = eval_pairs(model, pairs, matcher, device=dev, batch_pairs=8)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(f"seed {seed}: {8/dt:.1f} pairs/s feat {r['feat_time']*1e3:.1f} ms reg {r['reg_time']*1e3:.1f} ms total {dt*1e3:.1f} ms success {r['success_rate']}")
+    print(f"seed {seed}: {8/dt:.1f} pairs/s feat {r['feat_enqueue_time']*1e3:.1f} ms reg {r['reg_enqueue_time']*1e3:.1f} ms total {dt*1e3:.1f} ms success {r['success_rate']}")
