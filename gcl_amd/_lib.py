@@ -63,6 +63,11 @@ SIGNATURES = {
     "gcl_colocation_hits": (_i32, [_vp, _vp, _i64, _i32, ctypes.POINTER(ctypes.c_double), _vp, _i64, _f32,
                                     ctypes.c_double, _i32, _vp, _vp, _vp, _vp]),
     "gcl_colocation_emit": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gcl_voxel_coords_multi": (_i32, [_vp, _i64, ctypes.POINTER(_i64), _i32, _f32, _vp, _vp]),
+    "gcl_cloud_row_starts": (_i32, [_vp, _i64, _vp, _i32, _vp, _vp]),
+    "gcl_loader_points": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "gcl_colocation_hits_at": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, ctypes.POINTER(ctypes.c_double), _vp, _i64, _f32,
+                                       ctypes.c_double, _i32, _vp, _vp, _vp, _vp]),
     "gcl_host_legacy_choice": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "gcl_kernel_map_bitmap_len": (_i64, []),
     "gcl_kernel_map_scratch_len": (_i64, [_i32, _i64]),

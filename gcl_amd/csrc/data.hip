@@ -44,11 +44,16 @@ __global__ void __launch_bounds__(256) k_colocation_hits(const float* __restrict
                                                          float inv_voxel, double radius, int R, int K,
                                                          int* __restrict__ hits,        // [n_center, n_clouds, K]
                                                          int* __restrict__ cnt,         // [n_center, n_clouds]
-                                                         double* __restrict__ first_rng) {  // [n_center, n_clouds]
+                                                         double* __restrict__ first_rng,    // [n_center, n_clouds]
+                                                         long long row0, int cloud0) {
+  // row0 / cloud0 (batch form): the sample's centre voxels are rows row0 .. of xyz_*, its clouds carry the table's batch ids
+  // cloud0 .. cloud0 + n_clouds - 1, and the table's values -- the hits written -- are rows of the whole batch
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   int c = blockIdx.y;
   if (i >= n_center) return;
+  xyz_cf += 3 * row0;
   const double px = xyz_cf[3 * i], py = xyz_cf[3 * i + 1], pz = xyz_cf[3 * i + 2];
+  xyz_cf -= 3 * row0;
   // query point in the frame of cloud c (only to find candidate voxels)
   const double* m = to_cloud.a[c].m;
   float qx = (float)(m[0] * px + m[1] * py + m[2] * pz + m[3]);
@@ -59,12 +64,23 @@ __global__ void __launch_bounds__(256) k_colocation_hits(const float* __restrict
   int bi[KMAX];
   int n = 0;
   const double r2 = __dmul_rn(radius, radius);
+  // Round 6: a voxel whose BOX is farther from the query than the radius cannot hold a hit (its point lies inside the box,
+  // and the neighbour -> centre transforms are rigid): skipped before its table probe -- ~ 60 % of the (2R+1)^3 voxels at
+  // radius 1.5 voxels.  Per-axis gaps in voxel units, shortened by 0.004 voxels: the query's position in the cloud's frame is
+  // rounded (fp32 of an fp64 affine, ~ 3e-5 voxels at 100 m) and the test must only ever err towards probing.
+  const float fx = qx * inv_voxel - (float)bx, fy = qy * inv_voxel - (float)by, fz = qz * inv_voxel - (float)bz;
+  const float rv = (float)radius * inv_voxel, rv2 = rv * rv * 1.0001f;
+  auto gap2 = [](int d, float f) {
+    const float g = fmaxf((d > 0 ? (float)d - f : (d < 0 ? f - (float)(d + 1) : 0.f)) - 0.004f, 0.f);
+    return g * g;
+  };
   for (int dz = -R; dz <= R; ++dz)
     for (int dy = -R; dy <= R; ++dy)
       for (int dx = -R; dx <= R; ++dx) {
+        if (gap2(dx, fx) + gap2(dy, fy) + gap2(dz, fz) > rv2) continue;
         int x = bx + dx, y = by + dy, z = bz + dz;
-        if (!pack_ok(c, x, y, z)) continue;
-        long long s = table_find(table, cap, pack_key(c, x, y, z));
+        if (!pack_ok(cloud0 + c, x, y, z)) continue;
+        long long s = table_find(table, cap, pack_key(cloud0 + c, x, y, z));
         if (s < 0) continue;
         int q = (int)table[s].val;
         double ex = __dsub_rn((double)xyz_cf[3 * (long long)q], px);
@@ -89,7 +105,8 @@ __global__ void __launch_bounds__(256) k_colocation_hits(const float* __restrict
   for (int j = 0; j < K; ++j) hits[o * K + j] = j < n ? bi[j] : -1;
   double rng = 1e300;
   if (c == 0) {
-    double a = xyz_own[3 * i], b = xyz_own[3 * i + 1], d = xyz_own[3 * i + 2];
+    const long long ig = row0 + i;
+    double a = xyz_own[3 * ig], b = xyz_own[3 * ig + 1], d = xyz_own[3 * ig + 2];
     rng = sqrt(__dadd_rn(__dadd_rn(__dmul_rn(a, a), __dmul_rn(b, b)), __dmul_rn(d, d)));   // centre voxel's sensor range
   } else if (n > 0) {
     long long q = bi[0];
@@ -147,6 +164,56 @@ __global__ void k_colocation_emit(const int* __restrict__ hits, const int* __res
   group[gidx[i]] = run;
 }
 
+
+// ---- a whole BATCH of samples in one pass (round 6): every cloud of every sample voxelised, deduplicated and looked up
+// through ONE coordinate table whose batch id is the cloud's number in the batch (lib/colocation_data_loader.py:440-446 gives
+// the clouds of a batch consecutive ids too), so that the loader makes two host synchronisations per batch instead of ~ 9 per
+// sample, and no host round trip for the neighbours' centre-frame points ---------------------------------------------------
+struct CloudOffsets {
+  long long off[65];      // point offsets of up to 64 clouds + the total
+};
+__global__ void k_voxel_coords_multi(const float* __restrict__ xyz, long long p, CloudOffsets co, int n_clouds, float voxel,
+                                     int4* coords) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p) return;
+  int lo = 0, hi = n_clouds - 1;      // the cloud of point i: last c with off[c] <= i
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (co.off[mid] <= i) lo = mid; else hi = mid - 1;
+  }
+  coords[i] = make_int4(lo, floor_to_int(__fdiv_rn(xyz[3 * i], voxel)), floor_to_int(__fdiv_rn(xyz[3 * i + 1], voxel)),
+                        floor_to_int(__fdiv_rn(xyz[3 * i + 2], voxel)));
+}
+
+// starts[c] = first unique row of cloud c (the unique rows keep the input's cloud-major order), starts[n_clouds] = n;
+// a cloud without rows gets the start of the next one (filled by the host from the right)
+__global__ void k_cloud_row_starts(const int4* __restrict__ coords, const int* __restrict__ n_dev, int n_clouds, int* starts) {
+  const long long n = *n_dev;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) starts[n_clouds] = (int)n;
+  if (i >= n) return;
+  const int b = coords[i].x;
+  if (i == 0 || coords[i - 1].x != b) starts[b] = (int)i;
+}
+
+// voxel representatives: the first point of every voxel in its OWN sensor frame (xyz_raw[index]) and in the frame of its
+// sample's centre cloud -- q = fp32(R p + t) in fp64 from the fp32 point, as the host path's numpy expression
+// (colocation_data_gpu.build_sample_gpu; the reference transforms fp64 copies: util/pointcloud.py:87-89)
+__global__ void k_loader_points(const float* __restrict__ xyz_raw, const long long* __restrict__ index,
+                                const int4* __restrict__ coords, const int* __restrict__ n_dev,
+                                const double* __restrict__ to_center,      // [n_clouds][12], row-major 3 x 4
+                                float* __restrict__ xyz_own, float* __restrict__ xyz_cf) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= *n_dev) return;
+  const long long r = index[i];
+  const float x = xyz_raw[3 * r], y = xyz_raw[3 * r + 1], z = xyz_raw[3 * r + 2];
+  xyz_own[3 * i] = x; xyz_own[3 * i + 1] = y; xyz_own[3 * i + 2] = z;
+  const double* m = to_center + 12 * coords[i].x;
+  // (x m0 + y m1) + z m2, then + t: the order of a 3-term dot product followed by the broadcast add, no contraction
+  xyz_cf[3 * i] = (float)__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(x, m[0]), __dmul_rn(y, m[1])), __dmul_rn(z, m[2])), m[3]);
+  xyz_cf[3 * i + 1] = (float)__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(x, m[4]), __dmul_rn(y, m[5])), __dmul_rn(z, m[6])), m[7]);
+  xyz_cf[3 * i + 2] = (float)__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(x, m[8]), __dmul_rn(y, m[9])), __dmul_rn(z, m[10])), m[11]);
+}
 }  // namespace gcl
 
 using namespace gcl;
@@ -164,9 +231,54 @@ int gcl_voxel_coords(const float* xyz, int64_t p, float voxel, int32_t batch_id,
   return GCL_OK;
 }
 
+int gcl_voxel_coords_multi(const float* xyz, int64_t p, const int64_t* cloud_offsets_host, int32_t n_clouds, float voxel,
+                            int32_t* coords, void* stream) {
+  GCL_CHECK_ARG(xyz && coords && cloud_offsets_host && p > 0 && voxel > 0, "gcl_voxel_coords_multi: bad argument");
+  GCL_CHECK_ARG(n_clouds >= 1 && n_clouds <= 64 && cloud_offsets_host[0] == 0 && cloud_offsets_host[n_clouds] == p,
+                "gcl_voxel_coords_multi: 1 <= clouds <= 64, offsets[0] = 0, offsets[clouds] = p");
+  CloudOffsets co;
+  for (int c = 0; c <= n_clouds; ++c) co.off[c] = cloud_offsets_host[c];
+  hipLaunchKernelGGL(k_voxel_coords_multi, dim3((unsigned)cdiv(p, 256)), dim3(256), 0, (hipStream_t)stream, xyz, (long long)p,
+                     co, n_clouds, voxel, (int4*)coords);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int gcl_cloud_row_starts(const int32_t* coords, int64_t n_max, const int32_t* n_dev, int32_t n_clouds, int32_t* starts,
+                         void* stream) {
+  GCL_CHECK_ARG(coords && n_dev && starts && n_max > 0 && n_clouds >= 1, "gcl_cloud_row_starts: bad argument");
+  GCL_CHECK_HIP(hipMemsetAsync(starts, 0xFF, (size_t)(n_clouds + 1) * sizeof(int32_t), (hipStream_t)stream));      // -1: no row
+  hipLaunchKernelGGL(k_cloud_row_starts, dim3((unsigned)cdiv(n_max, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const int4*)coords, (const int*)n_dev, n_clouds, starts);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int gcl_loader_points(const float* xyz_raw, const int64_t* index, const int32_t* coords, int64_t n_max, const int32_t* n_dev,
+                      const double* to_center_dev, float* xyz_own, float* xyz_cf, void* stream) {
+  GCL_CHECK_ARG(xyz_raw && index && coords && n_dev && to_center_dev && xyz_own && xyz_cf && n_max > 0,
+                "gcl_loader_points: bad argument");
+  hipLaunchKernelGGL(k_loader_points, dim3((unsigned)cdiv(n_max, 256)), dim3(256), 0, (hipStream_t)stream, xyz_raw,
+                     (const long long*)index, (const int4*)coords, (const int*)n_dev, to_center_dev, xyz_own, xyz_cf);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int gcl_colocation_hits_at(const float* xyz_own, const float* xyz_cf, int64_t row0, int64_t n_center, int32_t cloud0,
+                           int32_t n_clouds, const double* to_cloud_host, const int64_t* table, int64_t cap, float inv_voxel,
+                           double radius, int32_t K, int32_t* hits, int32_t* cnt, double* first_rng, void* stream);
+
 int gcl_colocation_hits(const float* xyz_own, const float* xyz_cf, int64_t n_center, int32_t n_clouds,
                         const double* to_cloud_host, const int64_t* table, int64_t cap, float inv_voxel, double radius,
                         int32_t K, int32_t* hits, int32_t* cnt, double* first_rng, void* stream) {
+  return gcl_colocation_hits_at(xyz_own, xyz_cf, 0, n_center, 0, n_clouds, to_cloud_host, table, cap, inv_voxel, radius, K,
+                                hits, cnt, first_rng, stream);
+}
+
+int gcl_colocation_hits_at(const float* xyz_own, const float* xyz_cf, int64_t row0, int64_t n_center, int32_t cloud0,
+                           int32_t n_clouds, const double* to_cloud_host, const int64_t* table, int64_t cap, float inv_voxel,
+                           double radius, int32_t K, int32_t* hits, int32_t* cnt, double* first_rng, void* stream) {
+  GCL_CHECK_ARG(row0 >= 0 && cloud0 >= 0 && cloud0 + n_clouds <= 65535, "gcl_colocation_hits_at: bad row / cloud offset");
   GCL_CHECK_ARG(xyz_own && xyz_cf && to_cloud_host && table && hits && cnt && first_rng, "gcl_colocation_hits: null pointer");
   GCL_CHECK_ARG(n_center > 0 && n_clouds >= 1 && n_clouds <= 16 && K >= 1 && K <= KMAX,
                 "gcl_colocation_hits: need 1 <= clouds <= 16 and 1 <= K <= %d", KMAX);
@@ -178,7 +290,7 @@ int gcl_colocation_hits(const float* xyz_own, const float* xyz_cf, int64_t n_cen
   GCL_CHECK_ARG(R <= 4, "gcl_colocation_hits: radius / voxel too large (R = %d)", R);
   hipLaunchKernelGGL(k_colocation_hits, dim3((unsigned)cdiv(n_center, 256), n_clouds), dim3(256), 0, (hipStream_t)stream,
                      xyz_own, xyz_cf, (long long)n_center, n_clouds, aff, (const Slot*)table, (long long)cap, inv_voxel,
-                     radius, R, K, hits, cnt, first_rng);
+                     radius, R, K, hits, cnt, first_rng, (long long)row0, cloud0);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }

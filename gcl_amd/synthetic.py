@@ -163,10 +163,12 @@ def exhaustive_hash(index, group, M):
     return np.concatenate(out)
 
 
-def make_train_sample(seed, voxel_size=0.3, num_neighborhood=6, min_dist=5.0, max_dist=60.0,
-                      search_mult=1.5, random_rotation=True, random_scale=True, group_mode="radius",
-                      n_boxes=60):
-    """One ``__getitem__`` tuple (lib/colocation_data_loader.py:419-421) on the synthetic scene."""
+def make_raw_sample(seed, voxel_size=0.3, num_neighborhood=6, min_dist=5.0, max_dist=60.0, search_mult=1.5,
+                    random_rotation=True, random_scale=True, n_boxes=60):
+    """What ``ColocationKittiDataset.__getitem__`` holds BEFORE voxelisation (lib/colocation_data_loader.py:315-370): the
+    centre scan and its neighbours after the random rotation / scale, ``list_M`` (neighbour -> centre) and the scaled
+    matching radius -- the input of ``gcl_amd.lib.colocation_data_gpu.build_batch_gpu``.  ``"rng"`` is the sample's
+    generator positioned where ``make_train_sample`` draws the feature jitter (after voxelisation, :414-415)."""
     rng = np.random.RandomState(seed + 7919)
     scene = make_scene(seed, n_boxes=n_boxes)
     center_pos = np.array([0.0, 0.0, 0.0])
@@ -194,6 +196,31 @@ def make_train_sample(seed, voxel_size=0.3, num_neighborhood=6, min_dist=5.0, ma
         for j in range(len(xyz_cmpl)):
             xyz_cmpl[j] = (scale * xyz_cmpl[j]).astype(np.float32)
             list_M[j][:3, 3] *= scale
+    return {"xyz": [np.ascontiguousarray(xyz, dtype=np.float32)] +
+                   [np.ascontiguousarray(x, dtype=np.float32) for x in xyz_cmpl],
+            "list_M": list_M, "radius": float(search), "rng": rng}
+
+
+def raw_sample_jitter(raw_samples):
+    """The ``jitter`` callable of ``build_batch_gpu`` for ``make_raw_sample`` dicts: the centre cloud's feature jitter as
+    ``make_train_sample`` draws it (lib/transforms.py:24-29: N(0, 0.01) with probability 0.95), from COPIES of the samples'
+    generators (a raw sample can be fed any number of times)."""
+    def jitter(si, n_center):
+        rng = np.random.RandomState()
+        rng.set_state(raw_samples[si]["rng"].get_state())
+        if rng.rand() < 0.95:
+            return rng.normal(0.0, 0.01, (n_center, 1)).astype(np.float32)
+        return None
+    return jitter
+
+
+def make_train_sample(seed, voxel_size=0.3, num_neighborhood=6, min_dist=5.0, max_dist=60.0,
+                      search_mult=1.5, random_rotation=True, random_scale=True, group_mode="radius",
+                      n_boxes=60):
+    """One ``__getitem__`` tuple (lib/colocation_data_loader.py:419-421) on the synthetic scene."""
+    raw = make_raw_sample(seed, voxel_size, num_neighborhood, min_dist, max_dist, search_mult, random_rotation,
+                          random_scale, n_boxes)
+    rng, xyz, xyz_cmpl, list_M, search = raw["rng"], raw["xyz"][0], raw["xyz"][1:], raw["list_M"], raw["radius"]
     _, sel = me_utils.sparse_quantize(xyz / voxel_size, return_index=True)
     xyz_th = xyz[sel]
     xyz_cmpl_th = []

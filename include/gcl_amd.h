@@ -99,6 +99,32 @@ int gcl_colocation_emit(const int32_t* hits, const int32_t* cnt, const double* f
                         int32_t n_clouds, int32_t K, int32_t* scratch, int32_t* group, int64_t* index, uint8_t* finest,
                         int32_t* totals, void* stream);
 
+/* A whole BATCH of samples in one pass (round 6; what ColocationKittiDataset.__getitem__ x batch_size + collate_colocation_fn
+ * produce, lib/colocation_data_loader.py:315-475): the clouds of ALL samples share ONE coordinate table whose batch id is the
+ * cloud's number in the batch (the ids sparse_collate gives them, :440-446), so a batch costs two host synchronisations.
+ *   gcl_voxel_coords_multi  gcl_voxel_coords over the concatenated points of n_clouds <= 64 clouds; cloud_offsets_host:
+ *                           HOST int64[n_clouds + 1] point offsets (offsets[0] = 0, offsets[n_clouds] = p).
+ *   gcl_cloud_row_starts    after gcl_unique_coords (rows keep the cloud-major input order): starts int32[n_clouds + 1] on the
+ *                           device, starts[c] = first row of cloud c (-1: the cloud has none), starts[n_clouds] = *n_dev.
+ *   gcl_loader_points       voxel representatives xyz_own[i] = xyz_raw[index[i]] and, in the centre frame of the row's sample,
+ *                           xyz_cf[i] = fp32(R p + t) evaluated in fp64 without contraction; to_center_dev: DEVICE
+ *                           double[n_clouds][12] (row-major 3 x 4; identity for a centre cloud).  n_max bounds the launch,
+ *                           *n_dev rows are written.
+ *   gcl_colocation_hits_at  gcl_colocation_hits for ONE sample of the batch: its centre voxels are rows row0 .. row0 + n_center
+ *                           of xyz_*, its clouds are the table's batch ids cloud0 .. cloud0 + n_clouds - 1; hits are rows of
+ *                           the batch (= the `index` collate_colocation_fn makes by adding the sample's offset, :434-437).
+ *                           hits / cnt / first_rng point at the sample's slice; gcl_colocation_emit then runs once over the
+ *                           concatenated centre voxels of all samples. */
+int gcl_voxel_coords_multi(const float* xyz, int64_t p, const int64_t* cloud_offsets_host, int32_t n_clouds, float voxel,
+                            int32_t* coords, void* stream);
+int gcl_cloud_row_starts(const int32_t* coords, int64_t n_max, const int32_t* n_dev, int32_t n_clouds, int32_t* starts,
+                         void* stream);
+int gcl_loader_points(const float* xyz_raw, const int64_t* index, const int32_t* coords, int64_t n_max, const int32_t* n_dev,
+                      const double* to_center_dev, float* xyz_own, float* xyz_cf, void* stream);
+int gcl_colocation_hits_at(const float* xyz_own, const float* xyz_cf, int64_t row0, int64_t n_center, int32_t cloud0,
+                           int32_t n_clouds, const double* to_cloud_host, const int64_t* table, int64_t cap, float inv_voxel,
+                           double radius, int32_t K, int32_t* hits, int32_t* cnt, double* first_rng, void* stream);
+
 /* HOST function (no GPU, every pointer is a HOST pointer): numpy's legacy np.random.choice(n, k, replace=False) =
  * permutation(n)[:k] -- the three draws of every training step (lib/colocation_trainer.py:457, :506-507) -- reproduced
  * bit for bit from the RandomState's MT19937 state (key[624], *pos as in np.random.get_state(); both updated in place so

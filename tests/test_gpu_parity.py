@@ -1310,6 +1310,76 @@ def test_gpu_built_batch_trains():
     assert torch.isfinite(loss).item() and n == len(batch["sinput_C"])
 
 
+@pytest.mark.parametrize("seeds,nn", [((61, 62), 2), ((71, 72, 73), 3)])
+def test_build_batch_gpu_equals_the_cpu_loader(seeds, nn):
+    """build_batch_gpu (round 6: every cloud of every sample through ONE coordinate table, the neighbours' centre-frame
+    points computed on the device, two host reads per batch) against the CPU loader the synthetic generator restates
+    (ColocationKittiDataset.__getitem__ + collate_colocation_fn, lib/colocation_data_loader.py:315-475): coordinates, features
+    (the centre clouds' jitter), groups, member rows with the samples' offsets and finest flags, bit for bit; and against the
+    per-point oracle on the device's own centre-frame points."""
+    from gcl_amd import synthetic
+    from gcl_amd.lib.colocation_data_gpu import build_batch_gpu
+    raws = [synthetic.make_raw_sample(s, 0.3, num_neighborhood=nn, n_boxes=20) for s in seeds]
+    want = synthetic.collate_train([synthetic.make_train_sample(s, 0.3, num_neighborhood=nn, n_boxes=20) for s in seeds])
+    with torch.cuda.device(DEV):
+        got = build_batch_gpu(raws, 0.3, DEV, jitter=synthetic.raw_sample_jitter(raws))
+        torch.cuda.synchronize()
+    assert torch.equal(got["sinput_C"].cpu(), want["sinput_C"])
+    assert torch.equal(got["sinput_F"].cpu(), want["sinput_F"])
+    assert got["batch_lengths"] == [int(v) for v in want["batch_lengths"]]
+    assert torch.equal(got["group"].cpu(), want["group"]) and len(want["group"]) > 200
+    assert torch.equal(got["index"].cpu(), want["index"])
+    assert torch.equal(got["finest_flag"].cpu(), want["finest_flag"])
+    # the centre-frame points: fp32(R p + t) from fp64 on the device == the host's numpy expression
+    rows = np.cumsum([0] + got["cloud_rows"])
+    xo, xc = got["xyz_own"].cpu().numpy(), got["xyz_cf"].cpu().numpy()
+    n_c = nn + 1
+    from oracle.colocation_oracle import colocation_groups as oracle_groups
+    start, g0, i0 = 0, 0, 0
+    for si, raw in enumerate(raws):
+        cl = [xo[rows[si * n_c + c]:rows[si * n_c + c + 1]] for c in range(n_c)]
+        cf = [xc[rows[si * n_c + c]:rows[si * n_c + c + 1]] for c in range(n_c)]
+        assert np.array_equal(cf[0], cl[0])
+        for j in range(nn):
+            assert np.array_equal(cf[j + 1], synthetic._apply(raw["list_M"][j], cl[j + 1]))
+        og, oi, of = oracle_groups(cl[0], cl[1:], raw["list_M"], raw["radius"], K=5, nghb_cf=cf[1:])
+        ng, ni = len(og), len(oi)
+        assert np.array_equal(got["group"][g0:g0 + ng].cpu().numpy(), np.asarray(og, dtype=np.int32))
+        assert np.array_equal(got["index"][i0:i0 + ni].cpu().numpy(), np.asarray(oi, dtype=np.int64) + start)
+        assert np.array_equal(got["finest_flag"][i0:i0 + ni].cpu().numpy(), np.asarray(of, dtype=bool))
+        start, g0, i0 = start + got["batch_lengths"][si], g0 + ng, i0 + ni
+    assert g0 == len(got["group"]) and i0 == len(got["index"])
+
+
+def test_train_from_scans_equals_training_on_the_cpu_loaders_batches():
+    """train_from_scans (raw scans -> build_batch_gpu a step ahead on its own stream -> train_steps) against train_steps on
+    the batches the CPU loader makes from the same scans: the same losses step by step (lr = 0: every step is a function of
+    its batch and draws)."""
+    from gcl_amd import synthetic
+    from gcl_amd.lib.colocation_data_gpu import train_from_scans
+    from gcl_amd.lib.colocation_trainer import FinestContrastiveLossTrainer, make_config, prefetch_to_device
+    seeds = [(81, 82), (83, 84), (85, 86)]
+    raw_batches = [[synthetic.make_raw_sample(s, 0.3, num_neighborhood=2, n_boxes=12) for s in ss] for ss in seeds]
+    cpu_batches = [synthetic.collate_train([synthetic.make_train_sample(s, 0.3, num_neighborhood=2, n_boxes=12) for s in ss])
+                   for ss in seeds]
+    keys = ("sinput_C", "sinput_F", "group", "index", "finest_flag")
+    cfg = make_config(batch_size=2, num_pos_per_batch=64, num_hn_samples_per_batch=128, lr=0.0, weight_decay=0.0)
+    runs = []
+    for mode in ("cpu", "scans"):
+        torch.manual_seed(3)
+        np.random.seed(3)
+        tr = FinestContrastiveLossTrainer(cfg, device=DEV)
+        order = [0, 1, 2, 0, 1]
+        if mode == "cpu":
+            host = [{k: v for k, v in b.items() if k in keys} for b in cpu_batches]
+            steps = tr.train_steps(prefetch_to_device([host[i] for i in order], DEV, keys))
+        else:
+            steps = train_from_scans(tr, [raw_batches[i] for i in order], voxel_size=0.3, jitter=synthetic.raw_sample_jitter)
+        runs.append([l.item() for l, _, _ in steps])
+        torch.cuda.synchronize()
+    assert runs[0] == runs[1] and len(set(runs[0])) >= 3, runs
+
+
 def test_fused_amax_tags_equal_separate_pass():
     """BatchNorm apply / backward-apply publish max|y| / max|dx| themselves and the weight group refreshes all kernels
     in one launch: every tag must equal a separate gcl_amax pass, and in-place writes must void it."""

@@ -61,3 +61,19 @@ for _ in range(reps):
 torch.cuda.synchronize()
 dt2 = (time.perf_counter() - t0) / reps
 print(f"GPU  incl. H2D of the raw points ({pts * 12 / 1e6:.1f} MB): {1e3 * dt2:7.2f} ms per sample -> {nvox / dt2 / 1e6:.2f} M voxels/s")
+
+# ---- round 6: the whole batch in one pass (build_batch_gpu): 4 samples x 7 scans, pinned staging + H2D included
+from gcl_amd.lib.colocation_data_gpu import build_batch_gpu
+raws = [synthetic.make_raw_sample(100 + b) for b in range(4)]
+pts4 = sum(len(x) for r in raws for x in r["xyz"])
+for _ in range(2):
+    b = build_batch_gpu(raws, voxel, dev, jitter=synthetic.raw_sample_jitter(raws))
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(reps):
+    b = build_batch_gpu(raws, voxel, dev, jitter=synthetic.raw_sample_jitter(raws))
+torch.cuda.synchronize()
+dt3 = (time.perf_counter() - t0) / reps
+print(f"GPU  build_batch_gpu, 4 samples ({pts4} points, {pts4 * 12 / 1e6:.1f} MB H2D included) -> {len(b['sinput_C'])} voxels, "
+      f"{len(b['group'])} groups: {1e3 * dt3:7.2f} ms per batch = {1e3 * dt3 / 4:.2f} ms per sample -> "
+      f"{len(b['sinput_C']) / dt3 / 1e6:.2f} M voxels/s")

@@ -1,0 +1,81 @@
+"""Where the raw-scans pipeline's step time goes (bench.py secondary "end_to_end"): the same trainer and batches
+  A. batches built once by build_batch_gpu, resident on the device (no loader work in the step),
+  B. train_from_scans (loader a step ahead on its own stream),
+  C. B without the feature jitter (host normal draws + a pageable copy per sample).
+python3 tools/micro/e2e_probe.py"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+import torch
+
+import bench
+from gcl_amd import synthetic
+
+
+jobs = [("raw", 100 + 1000 * j + b, None) for j in range(2) for b in range(4)]
+import multiprocessing as mp
+with mp.get_context("fork").Pool(8) as pool:
+    raws = pool.map(bench._gen_secondary, jobs)
+raw_batches = [raws[:4], raws[4:]]
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+torch.set_num_threads(max(1, min(16, bench.usable_cores())))
+from gcl_amd.lib.colocation_data_gpu import build_batch_gpu, train_from_scans
+from gcl_amd.lib.colocation_trainer import FinestContrastiveLossTrainer, make_config
+
+STEPS, WARM = 30, 10
+LOADER_TRACE = {}
+import gcl_amd.lib.colocation_data_gpu as L
+_W = L.LoaderWorkspace
+
+
+class TracedWorkspace(_W):
+    def __init__(self, device):
+        super().__init__(device)
+        self.trace = LOADER_TRACE.setdefault("t", {})
+
+
+L.LoaderWorkspace = TracedWorkspace
+DEPTH = None
+
+
+def run(name, make_steps):
+    torch.manual_seed(0)
+    np.random.seed(0)
+    tr = FinestContrastiveLossTrainer(make_config(batch_size=4), device=dev)
+    it = make_steps(tr)
+    for _ in range(WARM):
+        next(it)
+    torch.cuda.synchronize()
+    t0, nv = time.perf_counter(), 0
+    for _ in range(STEPS):
+        _, _, n = next(it)
+        nv += n
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    it.close()
+    acc = getattr(tr, "_helper_times", {})
+    lt = LOADER_TRACE.get("t")
+    if lt and lt.get("builds"):
+        print("   loader thread, ms per build: " + ", ".join(f"{k}: {v / lt['builds'] * 1e3:.2f}" for k, v in lt.items() if k != "builds"))
+        lt.clear()
+    extra = "; ".join(f"{k}: {v[0] / max(1, v[2]) * 1e3:.2f} ms wall" for k, v in acc.items() if v[2])
+    print(f"{name}: {dt / STEPS * 1e3:.2f} ms/step, {nv / dt / 1e6:.1f} M voxels/s  {extra}", flush=True)
+
+
+with torch.cuda.device(dev):
+    built = [build_batch_gpu(rb, 0.3, dev, jitter=synthetic.raw_sample_jitter(rb)) for rb in raw_batches]
+    torch.cuda.synchronize()
+    keys = ("sinput_C", "sinput_F", "group", "index", "finest_flag")
+    res = [{k: b[k].clone() for k in keys} for b in built]
+    n_feed = WARM + STEPS + 4
+    os.environ["GCL_TRACE_HELPERS"] = "1"
+    for rep in range(2):
+        run("A resident prebuilt batches", lambda tr: tr.train_steps(res[i % 2] for i in range(n_feed)))
+        run("B train_from_scans", lambda tr: train_from_scans(tr, (raw_batches[i % 2] for i in range(n_feed)), voxel_size=0.3, depth=DEPTH,
+                                                              jitter=synthetic.raw_sample_jitter))
+        run("C train_from_scans, no jitter", lambda tr: train_from_scans(tr, (raw_batches[i % 2] for i in range(n_feed)),
+                                                                         voxel_size=0.3, depth=DEPTH))

@@ -81,6 +81,7 @@ sys.path.insert(0, ROOT)
 from gcl_amd import _lib  # noqa: E402
 out["_csrc_sha16"] = open(stamp).read().strip() if os.path.exists(stamp) else _lib.source_hash()
 out["_tag"] = tag
+out["_steps"] = n_steps_arg
 json.dump(out, open(os.path.join(P, "pmc_summary.json"), "w"), indent=1)
 print(open(os.path.join(P, f"{tag}_kernel_stats_summary.txt")).read())
 print(open(os.path.join(P, f"{tag}_pmc_sq.txt")).read()[:2500])
