@@ -561,7 +561,12 @@ int gcl_sc2_confidence_sparse(const float* src, const float* tgt, int32_t n, flo
  * (the Python Matcher issued ~25 torch operations and 7 calls per pair: 1 ms of host time in a loop that is host-bound).
  * Outputs: conf float[n], seeds int64[n_seeds], knn int32[n_seeds * k1], seed_trans float[n_seeds * 12],
  * fitness float[n_seeds], best int32[1], trans16 float[16] (row-major [4, 4]), labels float[n] (0 / 1).
- * scratch: gcl_sc2_register_scratch_bytes(n) bytes.  Same kernels, same results as the staged calls. */
+ * scratch: gcl_sc2_register_scratch_bytes(n) bytes.  FOOTPRINT: ~ 8 n^2 bytes of ADDRESS SPACE -- 528 MB at n = 8000 -- for the
+ * confidence's kept non-zero entries (an ELL slab: n^2 (column, value) places of 8 bytes, of which only the non-zero entries
+ * are ever touched, i.e. only those cost bandwidth or physical pages' worth of traffic) + the 8 MB tight-compatibility bit
+ * matrix; the seed stage's uint16 second-order rows (2 n_seeds n bytes) reuse the slab once the last product has run.  That
+ * is two of the four dense [n, n] float matrices the reference allocates (scripts/SC2_PCR/SC2_PCR.py:327-361); with several
+ * registrations in flight (GCL_EVAL_STREAMS > 1) every one needs its own block.  Same results as the staged calls. */
 int64_t gcl_sc2_register_scratch_bytes(int32_t n);
 int gcl_sc2_register(const float* src, const float* tgt, int32_t n, float d_thre, int32_t num_iterations, float nms_radius,
                      int32_t n_seeds, int32_t k1, int32_t k2, float inlier_thresh, float refine_thr, int32_t refine_iters,

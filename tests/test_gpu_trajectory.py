@@ -14,11 +14,17 @@ steps from the same initial state and compared the end points.  That comparison 
 arithmetic: at lr 0.1 from a random initialisation the trajectory amplifies any perturbation by ~ 10 x per step.  Measured
 in THIS container with the oracle alone (CPU, same batches / draws; numbers in profiles/r06_trajectory.log):
 
-    oracle run in float32          vs fp64 oracle: loss-triple error per step 6e-7, 1.4e-4, 7.4e-3, 1.2e-2, 6.3e-2, 5.0e-2
-    fp64 oracle, parameters x (1 + 1e-7 N(0,1)) : 9e-8, 1.5e-4, 2.0e-3, 1.6e-2, 5.0e-2, 7.0e-2; kernels 3.4e-2 apart after step 6
+    three clouds per sample (55 k voxels per batch, the first version's batches):
+      oracle run in float32        vs fp64 oracle: loss-triple error per step 6e-7, 1.4e-4, 7.4e-3, 1.2e-2, 6.3e-2, 5.0e-2
+      fp64 oracle, parameters x (1 + 1e-7 N(0,1)): 9e-8, 1.5e-4, 2.0e-3, 1.6e-2, 5.0e-2, 7.0e-2; kernels 3.4e-2 apart after step 6
+      the HIP path, free-running  (fp16x3 / exact f32): 6.8e-8, 1.1e-3, 3.6e-3, 1.3e-2, 8.7e-2, 2.4e-1 / 1.8e-7, 1.6e-5, 2.5e-3,
+                                                         4.0e-3, 2.1e-2, 1.4e-1 -- the same curve
+    two clouds per sample (37 k voxels, this test's batches; tests/trajectory_control.py):
+      oracle run in float32        vs fp64 oracle: 6e-8, 9e-8, 1.3e-4, 7.2e-4, 7.5e-3, 2.3e-2
+      fp64 oracle, parameters x (1 + 1e-7 N(0,1)): 6e-8, 1e-7, 3.8e-6, 7.5e-6, 8.5e-6, 9.5e-4
 
-and the HIP path's free-running deviation is the same curve (logged below, not asserted beyond the first two steps).  A
-bound on the end point could only be "within the chaos envelope", which a wrong momentum buffer would pass.
+(GCL_TRAJECTORY_FREE_RUN=1 logs the HIP path's free-running deviation again.)  A bound on the end point could only be "within
+the chaos envelope", which a wrong momentum buffer would pass.
 
 The test therefore runs the product FREE (no host synchronisation between the steps, helpers ahead, arenas recycled) and
 takes asynchronous device snapshots (parameters, running statistics, momentum buffers: device-to-device copies on the
@@ -39,6 +45,7 @@ from oracle import me_oracle as O             # noqa: E402
 
 DEV = "cuda:0"
 STEPS, SEEDS, RNG_SEED = 6, (31, 32, 33), 5
+NGHB = 1      # clouds per sample = 2: ~37 k voxels per batch (>= 32768 rows: the range-grouped launches run), 6 oracle steps ~ 1 min
 POS, HN = 64, 256
 LR, MOMENTUM, WD = 0.1, 0.8, 1e-4
 
@@ -54,7 +61,7 @@ _CACHE = {}
 def _batches():
     if "batches" not in _CACHE:
         from gcl_amd import synthetic
-        _CACHE["batches"] = [synthetic.collate_train([synthetic.make_train_sample(s, num_neighborhood=2, n_boxes=10)])
+        _CACHE["batches"] = [synthetic.collate_train([synthetic.make_train_sample(s, num_neighborhood=NGHB, n_boxes=10)])
                              for s in SEEDS]
         _CACHE["mgrs"] = [O.CoordinateManager(b["sinput_C"].numpy()) for b in _CACHE["batches"]]
     return _CACHE["batches"]
@@ -225,21 +232,22 @@ def test_six_step_trajectory_every_step_predicted_by_the_fp64_oracle(precision):
     lines.append(f"trajectory {precision} worst over {STEPS} steps: loss {worst['loss']:.2e}, whole update "
                  f"{worst['global']:.2e}, per tensor {worst['update']}, "
                  f"momentum {worst['momentum']}, running statistics {worst['running']:.2e}")
-    # ---- the free-running comparison, as information (see the module docstring): the oracle on its own from snapshot 0
-    st0 = {k: v for k, v in snaps[0].items() if "num_batches" not in k and not k.startswith("momentum::")}
-    fkey = ("free", float(sum(float(v.abs().sum()) for v in st0.values())))     # both arithmetics start from one state
-    if fkey not in _CACHE:
-        _CACHE[fkey] = _oracle_free_run(st0)
-    free, free_final = _CACHE[fkey]
-    e_free = (np.abs(got - free) / np.maximum(np.abs(free), 1e-3)).max(1)
-    drift = max(rel_l2(snaps[-1][n], free_final[n]) for n in names if "kernel" in n)
-    moved = max(rel_l2(free_final[n], st0[n]) for n in names if "kernel" in n)
-    lines.append(f"trajectory {precision} FREE-RUNNING oracle (not a parity criterion): loss-triple deviation per step "
-                 f"{[float(f'{e:.2e}') for e in e_free]}; kernels apart after step {STEPS}: {drift:.2e} "
-                 f"(largest relative kernel movement over the steps {moved:.2e})")
+    # (the free-running comparison -- the oracle on its own from snapshot 0 -- is information, not a criterion, and costs six
+    # more oracle steps: GCL_TRAJECTORY_FREE_RUN=1 adds it; numbers of one such run: profiles/r06_trajectory.log)
+    moved = max(rel_l2(snaps[-1][n], snaps[0][n]) for n in names if "kernel" in n)
+    lines.append(f"trajectory {precision}: largest relative kernel movement over the {STEPS} steps {moved:.2e}")
+    if os.environ.get("GCL_TRAJECTORY_FREE_RUN") == "1":
+        st0 = {k: v for k, v in snaps[0].items() if "num_batches" not in k and not k.startswith("momentum::")}
+        fkey = ("free", float(sum(float(v.abs().sum()) for v in st0.values())))     # both arithmetics start from one state
+        if fkey not in _CACHE:
+            _CACHE[fkey] = _oracle_free_run(st0)
+        free, free_final = _CACHE[fkey]
+        e_free = (np.abs(got - free) / np.maximum(np.abs(free), 1e-3)).max(1)
+        drift = max(rel_l2(snaps[-1][n], free_final[n]) for n in names if "kernel" in n)
+        lines.append(f"trajectory {precision} FREE-RUNNING oracle (not a parity criterion): loss-triple deviation per step "
+                     f"{[float(f'{e:.2e}') for e in e_free]}; kernels apart after step {STEPS}: {drift:.2e}")
     with open(precision_log_path(), "a") as fh:
         fh.write("\n".join(lines) + "\n")
     print("\n".join(lines))
     assert not fails, (precision, fails[:8])
     assert moved > 1e-2, "the trajectory must actually move the parameters"
-    assert e_free[0] < LOSS_RTOL and e_free[1] < 1e-2, e_free
