@@ -442,6 +442,7 @@ class _TraceCtx:
 # is replayed from it (there is no backward pass); ME.conv_bn adds the "convbn" entries itself.
 _EVAL_TRACE = None
 CONV_TALL = 4      # include/gcl_amd.h GCL_CONV_TALL: inference launches (conv_bn_eval here, the plan's eval records)
+GROUP_LAUNCHES = True      # conv_bn_eval hands the offset-group launches their scratch (tests switch it off: the sixteen-wave kernel)
 
 
 def sparse_conv(x, W, kmap, n_out, transpose, bias, mgr, want_stats=False):
@@ -931,10 +932,13 @@ def conv_bn_eval(x, W, kmap, n_out, transpose, scale, shift, residual=None, relu
     y = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
     slot = amax_slot(x.device)
     res = residual.contiguous() if residual is not None else None
+    # scratch of the offset-group launches (the small deep layers of a pass; 0 floats: the shape / size takes another kernel)
+    gs_len = lib.gcl_conv_fwd_groups_scratch_len(n_out, K, cin, cout) if (tbl is not None and GROUP_LAUNCHES) else 0
+    gscratch = torch.empty(gs_len, dtype=torch.float32, device=x.device) if gs_len > 0 else None
     _lib.check(lib.gcl_conv_fwd_fused(_lib.ptr(x, torch.float32), x.shape[0], 0, _lib.ptr(wp), prec, _lib.ptr(x_amax),
                                       _lib.ptr(w_amax), _lib.ptr(tbl), _lib.ptr(order), _lib.ptr(tile_mask), n_out, K,
                                       cin, cout, _lib.ptr(shift, torch.float32), _lib.ptr(scale, torch.float32),
-                                      _lib.ptr(res), int(relu), _lib.ptr(slot), _lib.ptr(y), None,
+                                      _lib.ptr(res), int(relu), _lib.ptr(slot), _lib.ptr(y), _lib.ptr(gscratch),
                                       getattr(tbl, "_gcl_flags", 0) | CONV_TALL, _lib.stream()),
                "gcl_conv_fwd_fused")
     tag_amax(y, slot)

@@ -84,6 +84,7 @@ SIGNATURES = {
     "gcl_table_sort_multi": (_i32, [_vp, _i32, _vp]),
     "gcl_spatial_order": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
     "gcl_table_sort_pre": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gcl_conv_fwd_groups_scratch_len": (_i64, [_i64, _i32, _i32, _i32]),
     "gcl_conv_fwd_fused": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp,
                                   _i32, _vp, _vp, _vp, _i32, _vp]),
     "gcl_conv_fwd_fused_ld": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp,

@@ -887,7 +887,12 @@ __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0
 //                   B(s+1) -> the other weight buffer (last read in step s-1, before this barrier),
 //                   A fragments of step s -> registers, then A(s+1) -> the wave's tile, then B fragments + MFMAs.
 // Same products added in the same order as k_conv_fwd_split: bitwise the same y and column sums.
-template <int NB, bool PRE, bool EPI>
+// GRP (round 6): the launch of ONE offset group of an inference layer (k_conv_fwd_tall's four fixed groups, k mod 4 == g, as
+// four times as many ordinary workgroups instead of sixteen-wave ones): the group index rides in the column-block slot of the
+// 1-D grid, the tile's mask is cut to the group's offsets, the arithmetic is k_conv_fwd_tall's (ONE accumulator, the
+// activation planes re-scaled on the fly: mfma_terms_dw) and the RAW accumulators go to slab g of `Y`
+// ([4][n_out][cout]); k_conv_groups_sum adds the slabs in group order and applies the epilogue.  fp32 rows only.
+template <int NB, bool PRE, bool EPI, bool GRP = false>
 __global__ void __launch_bounds__(256, (NB <= 2 ? 4 : 2)) k_conv_fwd_dma(const float* __restrict__ X, const u32x4* __restrict__ Wp,
                                                         const int* __restrict__ tbl, const int* __restrict__ order,
                                                         const int* __restrict__ tile_mask, long long n_out, int K,
@@ -896,6 +901,8 @@ __global__ void __launch_bounds__(256, (NB <= 2 ? 4 : 2)) k_conv_fwd_dma(const f
                                                         float* __restrict__ stats, const int* __restrict__ x_amax,
                                                         const int* __restrict__ w_amax, unsigned x_bytes, unsigned w_bytes,
                                                         ConvEpi epi) {
+  static_assert(!GRP || (!PRE && !EPI), "offset-group launches: fp32 rows, raw accumulators");
+  constexpr int NGRP = GRP ? 4 : 1;
   constexpr int PL = 4, NPL = 2;
   constexpr int BLK = NB * 2 * NPL * 64;                // uint4 per (k, cc) weight block of this workgroup = NB x 4 KB
   constexpr int ISM_H = 15;
@@ -914,10 +921,15 @@ __global__ void __launch_bounds__(256, (NB <= 2 ? 4 : 2)) k_conv_fwd_dma(const f
   const bool heavy_first = (swizzle & 16) != 0;
   swizzle &= 15;
   const unsigned nrw = (unsigned)((n_out + CONV_ROWS - 1) / CONV_ROWS);
+  unsigned grp = 0u;
   if (swizzle >= 2) {
-    const unsigned ncb = (unsigned)(cout / (32 * NB));
+    const unsigned ncb1 = (unsigned)(cout / (32 * NB)), ncb = ncb1 * (unsigned)NGRP;      // GRP: (group, column block) slots
     const unsigned xcd = bxx & 7u, slot = bxx >> 3;
     byy = slot % ncb;
+    if (GRP) {
+      grp = byy / ncb1;
+      byy -= grp * ncb1;
+    }
     if (swizzle == 2) {
       bxx = (slot / ncb) * 8u + xcd;
       if (bxx >= nrw) return;
@@ -930,6 +942,7 @@ __global__ void __launch_bounds__(256, (NB <= 2 ? 4 : 2)) k_conv_fwd_dma(const f
     bxx = xcd_tile(bxx, gridDim.x, swizzle);
   }
   if (heavy_first) bxx = nrw - 1u - bxx;
+  if (GRP) Y += (long long)grp * n_out * cout;
   const long long tile = (long long)bxx * 4 + w;
   const long long row0 = tile * 32;
   const bool active = row0 < n_out;
@@ -949,6 +962,7 @@ __global__ void __launch_bounds__(256, (NB <= 2 ? 4 : 2)) k_conv_fwd_dma(const f
 
   unsigned mymask = 0u;
   if (active) mymask = tile_mask ? (unsigned)tile_mask[tile] : ((K >= 32) ? ~0u : ((1u << K) - 1u));
+  if (GRP) mymask &= 0x11111111u << grp;      // offsets k with k mod 4 == grp (k_conv_fwd_tall's groups)
   mymask = __builtin_amdgcn_readfirstlane(mymask);
   if (l == 0) wmask[w] = mymask;
   for (int e = l; e < (K < ISM_H ? K : ISM_H) * 32; e += 64) {
@@ -1064,20 +1078,40 @@ __global__ void __launch_bounds__(256, (NB <= 2 ? 4 : 2)) k_conv_fwd_dma(const f
             asm volatile("" : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1])::"memory");
             GCL_DMA_A(kn, cn);
           }
+          if (!GRP) {
 #pragma unroll
-          for (int m = 0; m < 2; ++m)
-            split8<PL>(make_float4(f[m][0][0], f[m][0][1], f[m][0][2], f[m][0][3]),
-                       make_float4(f[m][1][0], f[m][1][1], f[m][1][2], f[m][1][3]), a_scale, ap[m]);
+            for (int m = 0; m < 2; ++m)
+              split8<PL>(make_float4(f[m][0][0], f[m][0][1], f[m][0][2], f[m][0][3]),
+                         make_float4(f[m][1][0], f[m][1][1], f[m][1][2], f[m][1][3]), a_scale, ap[m]);
+          } else {      // k_conv_fwd_tall's products, in its order: m, then the column blocks
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+              u32x4 ad[3];
+              split8<PL>(make_float4(f[m][0][0], f[m][0][1], f[m][0][2], f[m][0][3]),
+                         make_float4(f[m][1][0], f[m][1][1], f[m][1][2], f[m][1][3]), a_scale, ad);
+              dw_a_planes(ad);
+#pragma unroll
+              for (int b = 0; b < NB; ++b) {
+                const u32x4* bb = &Bsm[buf * BLK + ((b * 2 + m) * NPL) * 64 + l];
+                u32x4 bp[3];
+                bp[0] = bb[0];
+                bp[1] = bb[64];
+                mfma_terms_dw<PL>(ad, bp, acc[b]);
+              }
+            }
+          }
         }
+        if (!GRP) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
+          for (int m = 0; m < 2; ++m) {
 #pragma unroll
-          for (int b = 0; b < NB; ++b) {
-            const u32x4* bb = &Bsm[buf * BLK + ((b * 2 + m) * NPL) * 64 + l];
-            u32x4 bp[2];
-            bp[0] = bb[0];
-            bp[1] = bb[64];
-            mfma_terms<PL>(ap[m], bp, acc[b], accx[b]);
+            for (int b = 0; b < NB; ++b) {
+              const u32x4* bb = &Bsm[buf * BLK + ((b * 2 + m) * NPL) * 64 + l];
+              u32x4 bp[2];
+              bp[0] = bb[0];
+              bp[1] = bb[64];
+              mfma_terms<PL>(ap[m], bp, acc[b], accx[b]);
+            }
           }
         }
       } else if (mine_n) {
@@ -1093,9 +1127,53 @@ __global__ void __launch_bounds__(256, (NB <= 2 ? 4 : 2)) k_conv_fwd_dma(const f
 #undef GCL_DMA_A
 #undef GCL_DMA_B
 #undef GCL_ADVANCE
+  if (!GRP) {
 #pragma unroll
-  for (int b = 0; b < NB; ++b) fold_cross<PL>(acc[b], accx[(PL == 4) ? b : 0]);
-  conv_fwd_epilogue<NB, EPI>(acc, &Asm[0][0][0], order, n_out, cout, bias, Y, stats, out_scale, epi, tile, bxx, nb0, active);
+    for (int b = 0; b < NB; ++b) fold_cross<PL>(acc[b], accx[(PL == 4) ? b : 0]);
+  }
+  conv_fwd_epilogue<NB, EPI>(acc, &Asm[0][0][0], order, n_out, cout, bias, Y, stats, GRP ? 1.f : out_scale, epi, tile, bxx, nb0,
+                             active);
+}
+
+// y = epilogue(((slab 0 + slab 1) + slab 2) + slab 3): k_conv_fwd_tall's group order and its epilogue expression, on the raw
+// accumulator slabs the four offset-group launches of k_conv_fwd_dma<.., GRP> leave ([4][n][cout], rows in the output's order)
+template <bool EPI>
+__global__ void __launch_bounds__(256) k_conv_groups_sum(const float* __restrict__ slabs, long long n, int cout,
+                                                         const float* __restrict__ bias, const int* __restrict__ x_amax,
+                                                         const int* __restrict__ w_amax, ConvEpi epi, float* __restrict__ Y) {
+  const float out_scale = 1.f / (amax_scale(x_amax) * amax_scale(w_amax));
+  const long long total = n * cout;
+  const long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  float ymax = 0.f;
+  if (e < total) {
+    const long long row = e / cout;
+    const int col = (int)(e - row * cout);
+    const float4 p0 = *reinterpret_cast<const float4*>(slabs + e), p1 = *reinterpret_cast<const float4*>(slabs + total + e);
+    const float4 p2 = *reinterpret_cast<const float4*>(slabs + 2 * total + e),
+                 p3 = *reinterpret_cast<const float4*>(slabs + 3 * total + e);
+    const float a[4] = {((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y, ((p0.z + p1.z) + p2.z) + p3.z,
+                        ((p0.w + p1.w) + p2.w) + p3.w};
+    float v4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float bvv = bias ? bias[col + j] : 0.f;
+      const float csc = (EPI && epi.col_scale) ? epi.col_scale[col + j] * out_scale : out_scale;
+      float v = a[j] * csc + bvv;
+      if (EPI && epi.residual) {
+        const float rsd = epi.residual[row * (epi.residual_ld ? epi.residual_ld : cout) + col + j];
+        v = epi.relu == 2 ? (rsd > 0.f ? v : 0.f) : v + rsd;
+      }
+      if (EPI && epi.relu == 1) v = fmaxf(v, 0.f);
+      v4[j] = v;
+      if (EPI) ymax = fmaxf(ymax, fabsf(v));
+    }
+    *reinterpret_cast<float4*>(Y + e) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+  }
+  if (EPI && epi.y_amax) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o));
+    if ((threadIdx.x & 63) == 0) amax_slot_publish(epi.y_amax, __float_as_int(ymax), blockIdx.x * 4u + (threadIdx.x >> 6));
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2598,6 +2676,14 @@ int gcl_conv_fwd_fused(const float* x, int64_t n_in, int32_t x_is_planes, const 
                        const float* col_scale, const float* residual, int32_t relu, int32_t* y_amax, float* y,
                        float* stats, int32_t flags, void* stream);
 
+int64_t gcl_conv_fwd_groups_scratch_len(int64_t n_out, int32_t K, int32_t cin, int32_t cout) {
+  static const int on = [] { const char* e = getenv("GCL_FWD_GROUPS"); return e ? atoi(e) : 1; }();
+  static const long long max_rows = [] { const char* e = getenv("GCL_FWD_GROUPS_MAX_ROWS"); return e ? atoll(e) : 65536ll; }();
+  static const int tall_min = [] { const char* e = getenv("GCL_FWD_TALL_MIN_STEPS"); return e ? atoi(e) : 108; }();
+  if (!on || n_out <= 0 || n_out > max_rows || K < 8 || K > 27 || (cin % 32) || (cout % 64) || K * (cin / 32) < tall_min) return 0;
+  return 4ll * n_out * cout;
+}
+
 int gcl_conv_fwd(const float* x, int64_t n_in, int32_t x_is_planes, const void* wp, int32_t prec, const int32_t* x_amax,
                  const int32_t* w_amax, const int32_t* tbl, const int32_t* order, const int32_t* tile_mask,
                  int64_t n_out, int32_t K, int32_t cin, int32_t cout, const float* bias, float* y, float* stats,
@@ -2700,6 +2786,33 @@ int gcl_conv_fwd_fused_ld(const float* x, int64_t n_in, int32_t x_is_planes, con
   // eval_pairs 146 -> 160 - 165 pairs/s.
   static const int tall = [] { const char* e = getenv("GCL_FWD_TALL"); return e ? atoi(e) : 1; }();
   static const int tall_min = [] { const char* e = getenv("GCL_FWD_TALL_MIN_STEPS"); return e ? atoi(e) : 108; }();
+  // Round 6: the same four offset groups as FOUR TIMES AS MANY ordinary workgroups (k_conv_fwd_dma<2, false, false, GRP>) + one
+  // sum / epilogue launch, when the caller hands over scratch for the four accumulator slabs (`stats` of a GCL_CONV_TALL
+  // launch: gcl_conv_fwd_groups_scratch_len floats).  A pass over one pair leaves 52 sixteen-wave workgroups on 256 CUs,
+  // each walking 54 dependent steps at the round trip of a weight block with one step of prefetch (1.3 us per step: 72 us per
+  // launch, ten launches = 0.72 of a 1.75 ms pass); as 832 four-wave workgroups three of them share a CU and cover each
+  // other's round trips.  Same products in the same order per group, the same group order, the same epilogue expression:
+  // bitwise k_conv_fwd_tall's result.
+  if (tall && (flags & GCL_CONV_TALL) && stats && gcl_conv_fwd_groups_scratch_len(n_out, K, cin, cout) > 0 && prec == 4 &&
+      !x_is_planes && tbl && tile_mask && colgroup && !swz && !ranges) {
+    const dim3 ggrid((unsigned)(cdiv(gx, 8) * 8 * (cout / 64) * 4));
+    const int gswz = 2 | (heavy_first ? 16 : 0);
+    const unsigned w_bytes = (unsigned)((long long)K * cin * cout * 4);
+    const ConvEpi none{nullptr, nullptr, 0, nullptr, 0};
+    hipLaunchKernelGGL((k_conv_fwd_dma<2, false, false, true>), ggrid, dim3(256), 0, st, x, (const u32x4*)wp, tbl, order, tile_mask,
+                       (long long)n_out, K, cin, cout, (const float*)nullptr, stats, gswz, (float*)nullptr, x_amax, w_amax, x_bytes,
+                       w_bytes, none);
+    const unsigned sg = (unsigned)cdiv((long long)n_out * cout, 1024);
+    if (use_epi)
+      hipLaunchKernelGGL((k_conv_groups_sum<true>), dim3(sg), dim3(256), 0, st, (const float*)stats, (long long)n_out, cout, bias,
+                         x_amax, w_amax, epi, y);
+    else
+      hipLaunchKernelGGL((k_conv_groups_sum<false>), dim3(sg), dim3(256), 0, st, (const float*)stats, (long long)n_out, cout, bias,
+                         x_amax, w_amax, epi, y);
+    GCL_CHECK_LAUNCH();
+    return GCL_OK;
+  }
+  if (tall && (flags & GCL_CONV_TALL)) stats = nullptr;      // scratch of the group launches, not wanted by this shape / size
   if (tall && (flags & GCL_CONV_TALL) && prec == 4 && !x_is_planes && !stats && tbl && tile_mask && K >= 8 &&
       K * (cin / 32) >= tall_min && cout % 64 == 0 && colgroup && !swz && !ranges) {
     const dim3 tgrid((unsigned)(cdiv(gx, 8) * 8 * (cout / 64)));

@@ -735,10 +735,13 @@ static int plan_forward(Plan& P, const float* x_in, void* const* bn_stats, float
             mask = op.transpose ? m.mask_t : m.mask_n;
             GCL_CHECK_ARG(A.dry || tbl, "gcl_plan_forward_eval: record %d needs a sorted table the maps do not carry", (int)i);
           }
+          // scratch of the offset-group launches (small deep layers of an inference pass; 0: the shape / size takes another kernel)
+          const long long gs_len = tbl ? gcl_conv_fwd_groups_scratch_len(n_out, op.K, op.cin, c) : 0;
+          float* gscratch = gs_len > 0 ? A.take_n<float>(gs_len) : nullptr;
           ProfScope ps(P, st, 0, (double)(m.kernel_size > 1 ? m.n_pairs : n_out), op.cin, c, n_in, n_out, op.K);
           PLAN_CALL(gcl_conv_fwd_fused(x.ptr, n_in, 0, P.pack_fwd + P.off_fwd[wi], 4, x.amax,
                                        P.w_amax + (long long)wi * GCL_AMAX_WORDS, tbl, order, mask, n_out, op.K, op.cin, c,
-                                       (const float*)be[1], (const float*)be[0], res, op.relu, y.amax, y.ptr, nullptr,
+                                       (const float*)be[1], (const float*)be[0], res, op.relu, y.amax, y.ptr, gscratch,
                                        GCL_CONV_TALL, (void*)st));
           break;
         }

@@ -256,7 +256,12 @@ int gcl_split_planes(const float* x, int64_t n, int32_t c, const int32_t* amax, 
                                steps a small cloud's deep layers are made of; a row's result depends on the layer's shape only
                                (batching stays bitwise neutral).  fp16x3 on fp32 rows, no BatchNorm statistics, K >= 8,
                                K Cin / 32 >= 108 (Cin >= 128 at K = 27), Cout a multiple of 64; ignored elsewhere.  Results differ from the launch
-                               without the flag in the last bits (another summation order). */
+                               without the flag in the last bits (another summation order).
+                               Round 6: with this flag the `stats` argument of gcl_conv_fwd(_fused(_ld)) is SCRATCH of
+                               gcl_conv_fwd_groups_scratch_len(n_out, K, Cin, Cout) floats, or NULL.  With scratch (and a
+                               non-zero length: <= 65536 output rows) the four groups run as four times as many ordinary
+                               workgroups + one sum / epilogue launch -- bitwise the sixteen-wave kernel's result, 2 - 3 x
+                               shorter on the deep layers of a pass over one or two clouds. */
 #define GCL_CONV_DMA 2      /* plane-image launches (fp16x3): operands staged by LDS-DMA (`buffer_load ... lds`: no staging
                                registers, no ds_write); bitwise the same results.  The default (GCL_FWD_DMA=0 turns it off
                                unless this flag is set) */
@@ -273,6 +278,7 @@ int gcl_conv_fwd(const float* x, int64_t n_in, int32_t x_is_planes, const void* 
  * relu == 2 (needs `residual`): aten::threshold_backward instead of the add -- y = conv where residual > 0, else 0: the
  * input gradient of a convolution whose input came out of a ReLU, with that ReLU's backward in the epilogue (`residual` =
  * the ReLU's output). */
+int64_t gcl_conv_fwd_groups_scratch_len(int64_t n_out, int32_t K, int32_t cin, int32_t cout);
 int gcl_conv_fwd_fused(const float* x, int64_t n_in, int32_t x_is_planes, const void* wp, int32_t prec,
                        const int32_t* x_amax, const int32_t* w_amax, const int32_t* tbl, const int32_t* order,
                        const int32_t* tile_mask, int64_t n_out, int32_t K, int32_t cin, int32_t cout, const float* bias,

@@ -1743,6 +1743,40 @@ def test_sc2pcr_estimator_end_to_end_at_kitti_size():
         assert torch.equal(m2.last[k].to(v.dtype), v), k
 
 
+@pytest.mark.parametrize("cin,cout,n,stride,transpose", [(128, 128, 5000, 1, False), (256, 256, 2500, 1, False),
+                                                          (128, 256, 6000, 2, False), (256, 128, 6000, 2, True),
+                                                          (256, 64, 3000, 1, False), (128, 128, 300, 1, False)])
+def test_inference_offset_group_launches_equal_the_sixteen_wave_kernel_bitwise(cin, cout, n, stride, transpose, monkeypatch):
+    """The deep layers of an inference pass (GCL_CONV_TALL launches, Cin >= 128): the four fixed offset groups as four times
+    as many ordinary workgroups + one sum / epilogue launch (round 6: k_conv_fwd_dma<2, false, false, GRP> + k_conv_groups_sum,
+    taken when the caller hands over scratch) against the sixteen-wave kernel k_conv_fwd_tall -- the same products in the same
+    order per group, the same group order, the same epilogue expression: bit for bit, with BatchNorm scale / shift, residual
+    and ReLU in the epilogue, on stride-1, strided and transposed maps; and both against the fp64 oracle."""
+    import gcl_amd.MinkowskiEngine as ME
+    from gcl_amd.MinkowskiEngine import ops
+    C = random_cloud(cin + n, n=n, extent=16, batch=2)
+    mgr, omgr = make_mgr(C), O.CoordinateManager(C)
+    km = mgr.get_kernel_map(1, 3, stride)
+    n_in, n_out_map = len(C), mgr.num_rows(stride)
+    n_x, n_y = (n_out_map, n_in) if transpose else (n_in, n_out_map)
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n_x, cin, generator=g)
+    W = torch.randn(27, cin, cout, generator=g) * 0.05
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    res = torch.randn(n_y, cout, generator=g)
+    outs = []
+    with torch.no_grad(), torch.cuda.device(DEV):
+        xd, Wd, sd, hd, rd = (t.to(DEV) for t in (x, W, scale, shift, res))
+        for groups in (True, False):
+            monkeypatch.setattr(ops, "GROUP_LAUNCHES", groups)
+            outs.append(ops.conv_bn_eval(xd, Wd, km, n_y, transpose, sd, hd, residual=rd, relu=True).clone())
+            outs.append(ops.conv_bn_eval(xd, Wd, km, n_y, transpose, sd, hd).clone())
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3])
+    yo = O.sparse_conv(x.double(), W.double(), omgr.get_kernel_map(1, 3, stride), n_y, transpose=transpose)
+    assert rel_l2(outs[1].cpu(), yo * scale.double() + shift.double()) < 2e-6
+    assert rel_l2(outs[0].cpu(), torch.relu(yo * scale.double() + shift.double() + res.double())) < 2e-6
+
+
 def test_forward_pair_equals_two_forward_passes_bitwise():
     import gcl_amd.MinkowskiEngine as ME
     from gcl_amd import synthetic
