@@ -20,7 +20,9 @@ G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 
 def short(name):
     n = name.split("(")[0]
-    return re.sub(r"^void ", "", n).replace("gcl::", "").replace(" ", "")
+    n = re.sub(r"^void ", "", n).replace("gcl::", "").replace(" ", "")
+    # k_conv_fwd_dma<NB, PRE, EPI, GRP>: the training launches are GRP = false; bench.py names them by the first three
+    return re.sub(r"^(k_conv_fwd_dma<[^,]+,[^,]+,[^,]+),false>$", r"\1>", n)
 
 
 ks = (glob.glob(os.path.join(G, "prof_final", "*", "*_kernel_stats.csv")) + glob.glob(os.path.join(G, "prof_final", "*_kernel_stats.csv")))[0]
@@ -64,7 +66,7 @@ out = {"_source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate pas
                   "hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 averaged over launches (gfx950: FETCH_SIZE "
                   "counts half of a 16-B/lane stream -- MI355X_MICROARCH.md 'HBM'; Infinity-Cache hits are included)"}
 for n in fe:
-    if n.startswith(("k_conv", "k_bn", "k_stem", "k_amax", "k_bwd_weight", "k_split", "k_kernel_map", "k_permute")):
+    if True:      # every kernel of the profiled command (round 6: bench.py sums them into step_traffic_GB), torch's and the runtime's too
         f = sum(fe[n]["FETCH_SIZE"]) / len(fe[n]["FETCH_SIZE"])
         w = sum(wr[n]["WRITE_SIZE"]) / len(wr[n]["WRITE_SIZE"]) if n in wr else 0.0
         out[n] = {"launches": len(fe[n]["FETCH_SIZE"]), "fetch_size_kb_avg": round(f, 1), "write_size_kb_avg": round(w, 1),
