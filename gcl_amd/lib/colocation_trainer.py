@@ -603,33 +603,38 @@ class FinestContrastiveLossTrainer:
         specs = getattr(getattr(self, "model", None), "map_specs", None)
         if getattr(self, "map_prefetch", False) and specs is not None and isinstance(C, torch.Tensor) and C.is_cuda:
             with torch.cuda.device(self.device):
-                if getattr(self, "_side", None) is None:
+                # one side stream per helper THREAD (GCL_MAP_WORKERS > 1: two batches' maps in flight, each build's host reads
+                # wait for its own stream only)
+                import threading
+                tl = self.__dict__.setdefault("_side_local", threading.local())
+                side = getattr(tl, "stream", None)
+                if side is None:
                     lo, hi = torch.cuda.Stream.priority_range()         # (lowest priority, highest priority)
                     # low: with the helpers two steps ahead nothing waits for the maps, and at high priority their kernels
                     # took the chip from the training stream (13.0 -> 12.7 ms per step; with the maps of a batch cached, a
                     # diagnostic, the step is 11.95 ms: building them still costs ~0.75 ms of a step)
                     prio = {"low": lo, "high": hi}.get(os.environ.get("GCL_SIDE_PRIORITY", "low"), 0)
-                    self._side = torch.cuda.Stream(device=self.device, priority=prio)
+                    side = tl.stream = torch.cuda.Stream(device=self.device, priority=prio)
                 from gcl_amd.MinkowskiEngine import native
                 nspecs = getattr(self.model, "native_map_specs", None)
                 use_native = native.PLAN_ENABLED and nspecs is not None
                 slot = None
-                with torch.cuda.stream(self._side):
+                with torch.cuda.stream(side):
                     ev = batch.get("_h2d_event")
                     if ev is not None:
-                        self._side.wait_event(ev)
+                        side.wait_event(ev)
                     if use_native:
                         # ONE native call (interpreter lock released, both host syncs inside) into a pooled arena
                         slot = self._take_map_arena()
                         if slot["free"] is not None:
-                            self._side.wait_event(slot["free"])
+                            side.wait_event(slot["free"])
                         mgr = ME.CoordinateManager.build_native(C, nspecs(), arena=slot["arena"])
                         slot["arena"] = mgr.native.arena
                     else:
                         mgr = ME.CoordinateManager(C).prefetch(specs())
                     prep = prepare_loss_inputs(batch["group"], batch["index"], batch["finest_flag"], self.device)
                     done = torch.cuda.Event()
-                    done.record(self._side)
+                    done.record(side)
             batch = dict(batch)               # never mutate the caller's dict (it may be fed again)
             batch["_coordinate_manager"], batch["_maps_event"], batch["_loss_inputs"] = mgr, done, prep
             batch["_map_arena"] = slot
@@ -711,9 +716,17 @@ class FinestContrastiveLossTrainer:
         def maps(grp):
             return timed("maps", lambda g: stamped("maps", lambda g2: [self._prefetch_maps(b) for b in g2], g), grp)
 
+        n_map = max(1, int(os.environ.get("GCL_MAP_WORKERS", "1")))
         depth = max(1, int(os.environ.get("GCL_PREFETCH_DEPTH", "2")))      # steps the helpers work ahead
+        depth = max(depth, n_map)
         from collections import deque
-        with ThreadPoolExecutor(max_workers=1) as draw_pool, ThreadPoolExecutor(max_workers=1) as map_pool:
+        # GCL_MAP_WORKERS (default 1; experiment 77, round 6): a map build waits twice for its low-priority stream and beside a
+        # saturated GPU that latency is a whole step, so ONE helper keeps exactly pace with the steps, the enqueuing thread waits
+        # for every build and the training stream idles ~ 0.45 ms at each step boundary (tools/r06_timeline.sh).  Two helpers
+        # (two builds in flight on two streams) remove that wait and cost more than it: 11.80 / 11.83 -> 12.38 / 12.40 ms per
+        # step (three: 12.21 - 12.46; depth 3 with one helper: 11.79) -- the single helper throttles the map stream to the rate
+        # at which it disturbs the training stream least.
+        with ThreadPoolExecutor(max_workers=1) as draw_pool, ThreadPoolExecutor(max_workers=n_map) as map_pool:
             pending = deque()
 
             def refill():
