@@ -351,8 +351,8 @@ def make_twin_eval_pair(seed, inlier_share=0.3, voxel_size=0.3, shift_voxels=(16
         dy = (cut + gap_voxels) - cb[keep, 1].min() if n_other else 0
         dy = int(-((-dy) // 8) * 8)               # a multiple of 8 voxels, rounding away from the shared part
         cbk, xbk = cb[keep].copy(), xb[keep].copy()
-        # cloud 1's unrelated part also sits 3 voxels higher and 5 further along x: no voxel of it (the ground plane, which
-        # every scan shares) is the T_gt image of a voxel of cloud 0's unrelated part
+        # cloud 1's unrelated part also sits 3 voxels higher and 5 further along x: the ground plane, which every scan shares,
+        # is not the T_gt image of cloud 0's (a handful of box voxels in 10^4 still coincide by chance)
         off = np.array([5 * k, dy, 3 * k], dtype=np.int64)
         cbk += off
         xbk += (off * voxel_size).astype(np.float32)

@@ -259,3 +259,44 @@ def test_module_walk_cache_sees_a_replaced_submodule():
     n = m._n_parameters()
     m.block1.conv1.kernel = torch.nn.Parameter(m.block1.conv1.kernel.detach().clone())       # same count, new identity
     assert m._module_list() is not mods and m._n_parameters() == n
+
+
+def test_twin_eval_pair_contract():
+    """synthetic.make_twin_eval_pair (bench.py secondary, configs[4]): unique voxels per cloud, the shared part of cloud 0 moved
+    by T_gt IS in cloud 1 with the same input feature, and (up to a handful of chance coincidences) no voxel of cloud 0's
+    unrelated part maps onto cloud 1."""
+    from gcl_amd import synthetic
+    p = synthetic.make_twin_eval_pair(7, 0.4, n_boxes=15)
+    C0, C1 = p["sinput0_C"].numpy(), p["sinput1_C"].numpy()
+    assert len(np.unique(C0, axis=0)) == len(C0) and len(np.unique(C1, axis=0)) == len(C1) and len(C0) == len(C1)
+    sh = np.round(p["T_gt"].numpy()[:3, 3] / 0.3).astype(np.int64)
+    assert (sh % 8 == 0).all() and np.allclose(p["T_gt"].numpy()[:3, :3], np.eye(3))
+    key1 = {tuple(c): i for i, c in enumerate(C1[:, 1:].tolist())}
+    twins = [(i, key1[tuple((c + sh).tolist())]) for i, c in enumerate(C0[:, 1:].astype(np.int64)) if tuple((c + sh).tolist()) in key1]
+    assert p["shared_voxels"] <= len(twins) <= 1.005 * p["shared_voxels"] and 0.35 * len(C0) < len(twins) < 0.45 * len(C0)
+    i0, i1 = np.array(twins).T
+    same_f = (p["sinput0_F"].numpy()[i0] == p["sinput1_F"].numpy()[i1]).reshape(-1)
+    assert int(same_f.sum()) >= p["shared_voxels"]
+    moved = p["pcd0"][0].numpy()[i0[same_f]] + p["T_gt"].numpy()[:3, 3]
+    assert np.abs(moved - p["pcd1"][0].numpy()[i1[same_f]]).max() < 1e-4
+    # metric points sit in their voxels
+    assert np.array_equal(np.floor(p["pcd1"][0].numpy() / 0.3).astype(np.int32), C1[:, 1:])
+
+
+def test_raw_sample_is_what_make_train_sample_voxelises():
+    """synthetic.make_raw_sample (the input of build_batch_gpu / train_from_scans) replays make_train_sample's draws: voxelising
+    its clouds gives the sample's coordinates, and raw_sample_jitter the centre cloud's feature jitter."""
+    import gcl_amd.MinkowskiEngine as ME
+    from gcl_amd import synthetic
+    raw = synthetic.make_raw_sample(33, 0.3, num_neighborhood=2, n_boxes=8)
+    xyz_th, xyz_cmpl_th, coords, feats, group, index, finest, list_M = synthetic.make_train_sample(33, 0.3, num_neighborhood=2, n_boxes=8)
+    assert len(raw["xyz"]) == 3 and all(np.allclose(a, b) for a, b in zip(raw["list_M"], list_M))
+    for c, x in enumerate(raw["xyz"]):
+        q, sel = ME.utils.sparse_quantize(x / 0.3, return_index=True)
+        assert np.array_equal(np.floor(x[sel] / 0.3).astype(np.int32), coords[c])
+    assert abs(raw["radius"] - synthetic.sample_search_radius(33, 0.3, 2)) < 1e-12
+    j = synthetic.raw_sample_jitter([raw])(0, len(coords[0]))
+    want = feats[0] - 1.0
+    assert (j is None and not want.any()) or np.allclose(j, want, atol=1e-7)
+    assert synthetic.raw_sample_jitter([raw])(0, len(coords[0])) is None or \
+        np.array_equal(synthetic.raw_sample_jitter([raw])(0, len(coords[0])), j)          # a raw sample can be fed again
