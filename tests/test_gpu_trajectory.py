@@ -181,6 +181,10 @@ def test_six_step_trajectory_every_step_predicted_by_the_fp64_oracle(precision):
     finally:
         ME.set_conv_precision(old)
     assert len(snaps) == STEPS + 1
+    # the oracle's many small fp64 products: a thread pool the size of the HOST (torch's default inside a CPU-quota'd container)
+    # makes a step 3 x slower than eight threads do
+    n_thr = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(8, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8)))
     draws = _reference_draws(batches)
     lines = [f"trajectory {precision}: {STEPS} free-running steps over {len(batches)} batches "
              f"({[len(b['sinput_C']) for b in batches]} voxels), lr {LR} momentum {MOMENTUM} wd {WD}; "
@@ -247,6 +251,7 @@ def test_six_step_trajectory_every_step_predicted_by_the_fp64_oracle(precision):
         drift = max(rel_l2(snaps[-1][n], free_final[n]) for n in names if "kernel" in n)
         lines.append(f"trajectory {precision} FREE-RUNNING oracle (not a parity criterion): loss-triple deviation per step "
                      f"{[float(f'{e:.2e}') for e in e_free]}; kernels apart after step {STEPS}: {drift:.2e}")
+    torch.set_num_threads(n_thr)
     with open(precision_log_path(), "a") as fh:
         fh.write("\n".join(lines) + "\n")
     print("\n".join(lines))
