@@ -1136,53 +1136,38 @@ __global__ void __launch_bounds__(256, (NB <= 2 ? 4 : 2)) k_conv_fwd_dma(const f
 }
 
 // y = epilogue(((slab 0 + slab 1) + slab 2) + slab 3): k_conv_fwd_tall's group order and its epilogue expression, on the raw
-// accumulator slabs the four offset-group launches of k_conv_fwd_dma<.., GRP> leave: [4][n][cout] with the rows in the SORTED
-// (tile) order.  Workgroup b takes the 128 rows of the tile group whose four group workgroups ran on XCD b mod 8 (the same
-// blockIdx -> tile mapping, heavy tiles first or not): the slabs it reads are still in that XCD's L2; it scatters to the output's
-// row order like the convolution's own epilogue.
+// accumulator slabs the four offset-group launches of k_conv_fwd_dma<.., GRP> leave ([4][n][cout], rows in the output's order)
 template <bool EPI>
-__global__ void __launch_bounds__(256) k_conv_groups_sum(const float* __restrict__ slabs, const int* __restrict__ order,
-                                                         long long n, int cout, const float* __restrict__ bias,
-                                                         const int* __restrict__ x_amax, const int* __restrict__ w_amax,
-                                                         ConvEpi epi, float* __restrict__ Y, int heavy_first) {
+__global__ void __launch_bounds__(256) k_conv_groups_sum(const float* __restrict__ slabs, long long n, int cout,
+                                                         const float* __restrict__ bias, const int* __restrict__ x_amax,
+                                                         const int* __restrict__ w_amax, ConvEpi epi, float* __restrict__ Y) {
   const float out_scale = 1.f / (amax_scale(x_amax) * amax_scale(w_amax));
   const long long total = n * cout;
-  const unsigned nrw = (unsigned)((n + CONV_ROWS - 1) / CONV_ROWS);
-  if (blockIdx.x >= nrw) return;
-  const unsigned tg = heavy_first ? nrw - 1u - blockIdx.x : blockIdx.x;
-  const int cq_n = cout >> 2, cq = threadIdx.x % cq_n, rl = threadIdx.x / cq_n, rstep = 256 / cq_n;      // cout | 1024
-  const int col = cq * 4;
-  float bv[4], cs[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    bv[j] = bias ? bias[col + j] : 0.f;
-    cs[j] = (EPI && epi.col_scale) ? epi.col_scale[col + j] * out_scale : out_scale;
-  }
+  const long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
   float ymax = 0.f;
-  for (int r = rl; r < CONV_ROWS; r += rstep) {
-    const long long srow = (long long)tg * CONV_ROWS + r;
-    if (srow >= n) break;
-    const long long orow = order ? order[srow] : srow;
-    const long long e = srow * cout + col;
+  if (e < total) {
+    const long long row = e / cout;
+    const int col = (int)(e - row * cout);
     const float4 p0 = *reinterpret_cast<const float4*>(slabs + e), p1 = *reinterpret_cast<const float4*>(slabs + total + e);
     const float4 p2 = *reinterpret_cast<const float4*>(slabs + 2 * total + e),
                  p3 = *reinterpret_cast<const float4*>(slabs + 3 * total + e);
     const float a[4] = {((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y, ((p0.z + p1.z) + p2.z) + p3.z,
                         ((p0.w + p1.w) + p2.w) + p3.w};
-    float4 rsd = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (EPI && epi.residual)
-      rsd = *reinterpret_cast<const float4*>(epi.residual + orow * (epi.residual_ld ? epi.residual_ld : cout) + col);
-    const float rs4[4] = {rsd.x, rsd.y, rsd.z, rsd.w};
     float v4[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float v = a[j] * cs[j] + bv[j];
-      if (EPI && epi.residual) v = epi.relu == 2 ? (rs4[j] > 0.f ? v : 0.f) : v + rs4[j];
+      const float bvv = bias ? bias[col + j] : 0.f;
+      const float csc = (EPI && epi.col_scale) ? epi.col_scale[col + j] * out_scale : out_scale;
+      float v = a[j] * csc + bvv;
+      if (EPI && epi.residual) {
+        const float rsd = epi.residual[row * (epi.residual_ld ? epi.residual_ld : cout) + col + j];
+        v = epi.relu == 2 ? (rsd > 0.f ? v : 0.f) : v + rsd;
+      }
       if (EPI && epi.relu == 1) v = fmaxf(v, 0.f);
       v4[j] = v;
       if (EPI) ymax = fmaxf(ymax, fabsf(v));
     }
-    *reinterpret_cast<float4*>(Y + orow * cout + col) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+    *reinterpret_cast<float4*>(Y + e) = make_float4(v4[0], v4[1], v4[2], v4[3]);
   }
   if (EPI && epi.y_amax) {
 #pragma unroll
@@ -2695,8 +2680,7 @@ int64_t gcl_conv_fwd_groups_scratch_len(int64_t n_out, int32_t K, int32_t cin, i
   static const int on = [] { const char* e = getenv("GCL_FWD_GROUPS"); return e ? atoi(e) : 1; }();
   static const long long max_rows = [] { const char* e = getenv("GCL_FWD_GROUPS_MAX_ROWS"); return e ? atoll(e) : 65536ll; }();
   static const int tall_min = [] { const char* e = getenv("GCL_FWD_TALL_MIN_STEPS"); return e ? atoi(e) : 108; }();
-  if (!on || n_out <= 0 || n_out > max_rows || K < 8 || K > 27 || (cin % 32) || (cout % 64) || (1024 % cout) || K * (cin / 32) < tall_min)
-    return 0;
+  if (!on || n_out <= 0 || n_out > max_rows || K < 8 || K > 27 || (cin % 32) || (cout % 64) || K * (cin / 32) < tall_min) return 0;
   return 4ll * n_out * cout;
 }
 
@@ -2815,17 +2799,16 @@ int gcl_conv_fwd_fused_ld(const float* x, int64_t n_in, int32_t x_is_planes, con
     const int gswz = 2 | (heavy_first ? 16 : 0);
     const unsigned w_bytes = (unsigned)((long long)K * cin * cout * 4);
     const ConvEpi none{nullptr, nullptr, 0, nullptr, 0};
-    // (order = NULL: the slabs keep the sorted row order, the sum launch scatters)
-    hipLaunchKernelGGL((k_conv_fwd_dma<2, false, false, true>), ggrid, dim3(256), 0, st, x, (const u32x4*)wp, tbl,
-                       (const int*)nullptr, tile_mask, (long long)n_out, K, cin, cout, (const float*)nullptr, stats, gswz,
-                       (float*)nullptr, x_amax, w_amax, x_bytes, w_bytes, none);
-    const unsigned sg = (unsigned)(cdiv(gx, 8) * 8);
+    hipLaunchKernelGGL((k_conv_fwd_dma<2, false, false, true>), ggrid, dim3(256), 0, st, x, (const u32x4*)wp, tbl, order, tile_mask,
+                       (long long)n_out, K, cin, cout, (const float*)nullptr, stats, gswz, (float*)nullptr, x_amax, w_amax, x_bytes,
+                       w_bytes, none);
+    const unsigned sg = (unsigned)cdiv((long long)n_out * cout, 1024);
     if (use_epi)
-      hipLaunchKernelGGL((k_conv_groups_sum<true>), dim3(sg), dim3(256), 0, st, (const float*)stats, order, (long long)n_out, cout,
-                         bias, x_amax, w_amax, epi, y, heavy_first ? 1 : 0);
+      hipLaunchKernelGGL((k_conv_groups_sum<true>), dim3(sg), dim3(256), 0, st, (const float*)stats, (long long)n_out, cout, bias,
+                         x_amax, w_amax, epi, y);
     else
-      hipLaunchKernelGGL((k_conv_groups_sum<false>), dim3(sg), dim3(256), 0, st, (const float*)stats, order, (long long)n_out, cout,
-                         bias, x_amax, w_amax, epi, y, heavy_first ? 1 : 0);
+      hipLaunchKernelGGL((k_conv_groups_sum<false>), dim3(sg), dim3(256), 0, st, (const float*)stats, (long long)n_out, cout, bias,
+                         x_amax, w_amax, epi, y);
     GCL_CHECK_LAUNCH();
     return GCL_OK;
   }
