@@ -15,6 +15,24 @@ from gcl_amd.model.common import get_norm
 from gcl_amd.model.residual_block import get_block
 
 
+# Structure version of every torch module of the process (see ResUNet2._module_list): bumped by torch's global registration
+# hooks whenever a sub-module or parameter is (re)registered anywhere.  The hooks return None (they replace nothing).
+_STRUCTURE_VERSION = [0]
+
+
+def _bump_structure_version(*_args, **_kwargs):
+    _STRUCTURE_VERSION[0] += 1
+
+
+try:
+    from torch.nn.modules import module as _torch_module
+    _torch_module.register_module_module_registration_hook(_bump_structure_version)
+    _torch_module.register_module_parameter_registration_hook(_bump_structure_version)
+    _HOOKED = True
+except Exception:          # an older torch: fall back to comparing identities
+    _HOOKED = False
+
+
 class ResUNet2(ME.MinkowskiNetwork):
     NORM_TYPE = None
     BLOCK_NORM_TYPE = "BN"
@@ -101,6 +119,7 @@ class ResUNet2(ME.MinkowskiNetwork):
     def __getstate__(self):
         state = dict(self.__dict__)
         state.pop("_plan", None)          # a native handle: rebuilt from the next recorded step
+        state.pop("_walk_cache", None)    # module walk of this process (ResUNet2._module_list)
         return state
 
     def _use_tape(self, x):
@@ -129,22 +148,29 @@ class ResUNet2(ME.MinkowskiNetwork):
     def _module_list(self):
         """``list(self.modules())`` / the parameter count, walked once per model structure: the two guards of the inference
         path cost 0.17 ms per pass when they walk the module tree (a pass over one pair is host-bound).  Re-walked when the
-        registered sub-modules or parameters of ANY module changed -- by count (add_module / register_parameter) or by
-        IDENTITY (``model.block1 = NewBlock()``, a norm-layer swap under the same name keeps every count)."""
+        registered sub-modules or parameters of ANY module changed -- by count (add_module / register_parameter / ``del``) or
+        by IDENTITY (``model.block1 = NewBlock()``, a norm-layer swap under the same name keeps every count).
+        Identity changes are seen through torch's global registration hooks (every ``Module.__setattr__`` / ``add_module`` /
+        ``register_parameter`` of the process bumps ``_STRUCTURE_VERSION``): one integer compare per pass; where a torch
+        build lacks the hooks, the ids of every module's children and parameters are compared instead (~ 90 us per call)."""
         c = self.__dict__.get("_walk_cache")
-        if c is not None and all(self._children_ids(m) == ids for m, ids in c[2]):
-            return c[0]
+        if c is not None and all(len(m._modules) == a and len(m._parameters) == b for m, a, b, _, _ in c[2]):
+            if _HOOKED:
+                if c[3] == _STRUCTURE_VERSION[0]:
+                    return c[0]
+            elif all(tuple(map(id, m._modules.values())) == mi and tuple(map(id, m._parameters.values())) == pi
+                     for m, _, _, mi, pi in c[2]):
+                return c[0]
         mods = list(self.modules())
-        ids = [(m, self._children_ids(m)) for m in mods]
-        self.__dict__["_walk_cache"] = (mods, sum(1 for _ in self.parameters()), ids)
+        ids = [(m, len(m._modules), len(m._parameters), tuple(map(id, m._modules.values())),
+                tuple(map(id, m._parameters.values()))) for m in mods]
+        self.__dict__["_walk_cache"] = (mods, sum(1 for _ in self.parameters()), ids, _STRUCTURE_VERSION[0])
         return mods
 
-    @staticmethod
-    def _children_ids(m):
-        return [id(v) for v in m._modules.values()] + [id(v) for v in m._parameters.values()]
-
-    def _n_parameters(self):
-        self._module_list()
+    def _n_parameters(self, validated=False):
+        """``validated``: the caller has just called ``_module_list`` (one check per pass, not two)."""
+        if not validated:
+            self._module_list()
         return self.__dict__["_walk_cache"][1]
 
     def _forward_eval(self, x):
@@ -167,7 +193,7 @@ class ResUNet2(ME.MinkowskiNetwork):
             x = ME.SparseTensor(x.F, coordinate_map_key=x.coordinate_map_key, coordinate_manager=mgr)
         plan = self.__dict__.get("_plan")
         if isinstance(plan, native.NetworkPlan):
-            if mgr.native.keys != plan.spec_keys or len(plan.params) != self._n_parameters():
+            if mgr.native.keys != plan.spec_keys or len(plan.params) != self._n_parameters(validated=True):
                 return None
             F = plan.run_eval(x.F, mgr.native)
             return ME.SparseTensor(F, coordinate_map_key=ME.CoordinateMapKey(1 << plan.records[-1]["level_out"]),
