@@ -58,7 +58,10 @@ class NativeMaps:
         if need < 0:
             raise ValueError("gcl_maps_arena_bytes rejected the map specification")
         if arena is None or arena.numel() < need:
-            arena = torch.empty(int(need), dtype=torch.uint8, device=C.device)
+            # 12 % of headroom: pooled arenas (the trainer's map slots, the eval loop's ring) meet batches of different sizes, and
+            # an exact-size arena is re-allocated every time its slot meets a larger one -- a hipMalloc inside a training step
+            # (bench.py's driver command: one 13.2 ms step among 11.5 ms ones, eleven steps in)
+            arena = torch.empty(int(need * 1.125) + 4096, dtype=torch.uint8, device=C.device)
         self.arena = arena
         self.pinned = torch.empty(_lib.MAPS_PINNED_BYTES // 4, dtype=torch.int32, pin_memory=True)
         self.desc = _lib.MapsDesc()
