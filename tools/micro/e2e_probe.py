@@ -73,9 +73,13 @@ with torch.cuda.device(dev):
     res = [{k: b[k].clone() for k in keys} for b in built]
     n_feed = WARM + STEPS + 4
     os.environ["GCL_TRACE_HELPERS"] = "1"
+    only = os.environ.get("E2E_ONLY", "ABC")
     for rep in range(2):
-        run("A resident prebuilt batches", lambda tr: tr.train_steps(res[i % 2] for i in range(n_feed)))
-        run("B train_from_scans", lambda tr: train_from_scans(tr, (raw_batches[i % 2] for i in range(n_feed)), voxel_size=0.3, depth=DEPTH,
-                                                              jitter=synthetic.raw_sample_jitter))
-        run("C train_from_scans, no jitter", lambda tr: train_from_scans(tr, (raw_batches[i % 2] for i in range(n_feed)),
-                                                                         voxel_size=0.3, depth=DEPTH))
+        if "A" in only:
+            run("A resident prebuilt batches", lambda tr: tr.train_steps(res[i % 2] for i in range(n_feed)))
+        if "B" in only:
+            run("B train_from_scans", lambda tr: train_from_scans(tr, (raw_batches[i % 2] for i in range(n_feed)), voxel_size=0.3,
+                                                                  depth=DEPTH, jitter=synthetic.raw_sample_jitter))
+        if "C" in only:
+            run("C train_from_scans, no jitter", lambda tr: train_from_scans(tr, (raw_batches[i % 2] for i in range(n_feed)),
+                                                                             voxel_size=0.3, depth=DEPTH))
