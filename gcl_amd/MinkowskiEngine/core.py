@@ -141,14 +141,14 @@ class CoordinateManager:
     native = None       # NativeMaps when the maps were built by ONE gcl_maps_build call (build_native)
 
     @classmethod
-    def build_native(cls, coordinates, specs, n_levels=4, arena=None):
+    def build_native(cls, coordinates, specs, n_levels=4, arena=None, side_stream=None):
         """A manager whose stride maps, kernel maps, mask-sorted tables and pair lists were all built by one native call
         (``specs`` as in ``prefetch`` + (t, 1, 1, (), True) for kernel_size-1 identity pairs; native.NativeMaps).  The
         whole-network plan reads the native descriptor directly; the Python accessors below (get_coords,
         get_kernel_map, identity_pairs) hand out tensor VIEWS of the same arena on demand, so the per-operator path
         runs on exactly the same maps."""
         from .native import NativeMaps
-        nm = NativeMaps(coordinates, specs, n_levels, arena)
+        nm = NativeMaps(coordinates, specs, n_levels, arena, side_stream=side_stream)
         self = cls.__new__(cls)
         self.native, self.device = nm, nm.device
         self._segments, self._maps, self._status = {}, {}, {}
@@ -210,13 +210,11 @@ class CoordinateManager:
         if n == 0:
             raise ValueError("empty SparseTensor")
         self.device = C.device
-        cap = _pow2_cap(n)
-        table = torch.empty((cap, 2), dtype=torch.int64, device=self.device)
-        status = torch.empty(4, dtype=torch.int32, device=self.device)
-        _lib.check(lib.gcl_coords_insert(_lib.ptr(C), n, _lib.ptr(table), cap, _lib.ptr(status), _lib.stream()),
-                   "gcl_coords_insert")
-        self._maps = {1: (C, table, cap)}
-        self._status = {1: status}
+        # the input level's hash table is made on first use (_input_table): an inference pass that hands the coordinates to
+        # ONE native map build (ResUNet2._forward_eval -> build_native) never reads this manager's own table -- three
+        # launches and two allocations per pass
+        self._maps = {1: (C, None, _pow2_cap(n))}
+        self._status = {}
         self._checked = set()
         self._kmaps = {}
         self._identity = {}
@@ -224,9 +222,24 @@ class CoordinateManager:
         self._bitmap = None
 
     # -- coordinate maps -----------------------------------------------------------------------------------
+    def _input_table(self):
+        """Inserts the input coordinates into their hash table (once; CoordinateManager.__init__ defers it)."""
+        C, table, cap = self._maps[1]
+        if table is None:
+            lib = _lib.require_gpu()
+            table = torch.empty((cap, 2), dtype=torch.int64, device=self.device)
+            status = torch.empty(4, dtype=torch.int32, device=self.device)
+            _lib.check(lib.gcl_coords_insert(_lib.ptr(C), C.shape[0], _lib.ptr(table), cap, _lib.ptr(status), _lib.stream()),
+                       "gcl_coords_insert")
+            self._maps[1] = (C, table, cap)
+            self._status[1] = status
+        return table
+
     def _check_status(self, t):
         if t in self._checked:
             return
+        if t == 1:
+            self._input_table()
         self._raise_on_status(self._status[t].tolist())
         self._checked.add(t)
 
@@ -283,6 +296,8 @@ class CoordinateManager:
         level s with the row count of level s still on the device, and all counts come back in a single D2H read
         (one host sync per SparseTensor instead of one per level)."""
         lib = _lib.load()
+        if self.native is None:
+            self._input_table()
         levels = []
         s = max(self._maps)
         while s < max(t, 8):
@@ -337,6 +352,7 @@ class CoordinateManager:
             self._build_stride_maps(max(8, t_in * stride))
         t_out = t_in * stride
         self.get_coords(t_in)
+        self._input_table()
         C_in, table_in, cap_in = self._maps[t_in]
         C_out = self.get_coords(t_out)
         n_in, n_out = C_in.shape[0], C_out.shape[0]
@@ -380,7 +396,7 @@ class CoordinateManager:
         if self.native is not None:      # one arena holds every map
             return [self.native.arena, self.native.coords]
         for C, table, _ in self._maps.values():
-            out += [C, table]
+            out += [t for t in (C, table) if t is not None]
         out += list(self._status.values()) + list((self._bitmap or {}).values()) + list(self._spatial.values())
         for km in self._kmaps.values():
             out += [t for t in (km.nbr, km.nbr_t, km._counts_dev) if t is not None]

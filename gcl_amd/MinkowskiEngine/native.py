@@ -13,6 +13,7 @@ training step.  There is no CPU path here either: everything raises without the 
 """
 import ctypes
 import os
+import threading
 
 import torch
 from torch.autograd.function import once_differentiable
@@ -30,12 +31,34 @@ def _addr(t):
     return t.data_ptr() if t is not None else 0
 
 
+_SIDE_STREAMS = {}
+
+
+def eval_side_stream(device, n_rows=None):
+    """The stream a one-call inference pass builds its deeper levels' maps on, or None = one stream (GCL_EVAL_SPLIT_MAPS=0, or
+    fewer than GCL_EVAL_SPLIT_MIN_ROWS = 100 000 rows: a pass over one pair of clouds is bound by the enqueuing thread right
+    after the level sizes' read-back, and the split costs it sixteen more launches -- 26.2 -> 25.2 M voxels/s at 36 k rows,
+    93.2 -> 97.0 at 279 k; profiles/r06_conv_experiments.txt, 86)."""
+    if os.environ.get("GCL_EVAL_SPLIT_MAPS", "1") == "0":
+        return None
+    if n_rows is not None and n_rows < int(os.environ.get("GCL_EVAL_SPLIT_MIN_ROWS", "100000")):
+        return None
+    key = (torch.device(device).index, threading.get_ident())
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 class NativeMaps:
     """The maps of one batch.  ``specs``: (t_in, kernel_size, stride, tables, pairs) tuples as in
     CoordinateManager.prefetch, plus (t, 1, 1, (), True) for the identity pair list of a kernel_size-1 convolution.
-    Built on torch's CURRENT stream; ``arena`` (uint8 device tensor) may be passed in to re-use memory."""
+    Built on torch's CURRENT stream; ``arena`` (uint8 device tensor) may be passed in to re-use memory.
+    ``side_stream`` (inference passes over few rows): gcl_maps_build_split -- the maps the first layers do not use are enqueued
+    THERE, ``self.ready`` is recorded behind them, and the native plan makes the current stream wait for it in front of the
+    first record that needs one; any OTHER consumer of the maps must ``wait_ready()`` first."""
 
-    def __init__(self, coordinates, specs, n_levels=4, arena=None):
+    def __init__(self, coordinates, specs, n_levels=4, arena=None, side_stream=None):
         lib = _lib.require_gpu()
         if coordinates.dim() != 2 or coordinates.shape[1] != 4:
             raise ValueError("coordinates must be [N, 4] = (batch, x, y, z)")
@@ -65,13 +88,28 @@ class NativeMaps:
         self.arena = arena
         self.pinned = torch.empty(_lib.MAPS_PINNED_BYTES // 4, dtype=torch.int32, pin_memory=True)
         self.desc = _lib.MapsDesc()
-        rc = lib.gcl_maps_build(_lib.ptr(C), n, arr, len(specs), self.n_levels, _lib.ptr(arena), arena.numel(),
-                                ctypes.c_void_p(self.pinned.data_ptr()), ctypes.byref(self.desc), _lib.stream())
+        self.ready = None
+        if side_stream is None:
+            rc = lib.gcl_maps_build(_lib.ptr(C), n, arr, len(specs), self.n_levels, _lib.ptr(arena), arena.numel(),
+                                    ctypes.c_void_p(self.pinned.data_ptr()), ctypes.byref(self.desc), _lib.stream())
+        else:
+            rc = lib.gcl_maps_build_split(_lib.ptr(C), n, arr, len(specs), self.n_levels, _lib.ptr(arena), arena.numel(),
+                                          ctypes.c_void_p(self.pinned.data_ptr()), ctypes.byref(self.desc), _lib.stream(),
+                                          ctypes.c_void_p(side_stream.cuda_stream))
+            if rc == 0 and self.desc.late_mask:
+                self.ready = torch.cuda.Event()
+                self.ready.record(side_stream)
+                self.desc.ready_event = ctypes.c_void_p(self.ready.cuda_event)
         if rc != 0:
             msg = lib.gcl_last_error().decode()
             if rc == -1:
                 raise ValueError(msg)
             raise RuntimeError(f"libgcl_hip gcl_maps_build failed (rc={rc}): {msg}")
+
+    def wait_ready(self):
+        """The current stream waits for the maps a split build left on the side stream (no-op otherwise)."""
+        if self.ready is not None:
+            torch.cuda.current_stream(self.device).wait_event(self.ready)
 
     def index_of(self, t_in, kernel_size, stride):
         return self.keys.index((int(t_in), int(kernel_size), int(stride)))

@@ -37,7 +37,7 @@ class MapDesc(ctypes.Structure):      # gcl_map_desc
 class MapsDesc(ctypes.Structure):     # gcl_maps_desc
     _fields_ = [("n_levels", _i32), ("n_maps", _i32), ("n_rows", _i64 * MAX_LEVELS), ("coords", _vp * MAX_LEVELS),
                 ("table", _vp * MAX_LEVELS), ("cap", _i64 * MAX_LEVELS), ("status", _i32 * 4), ("arena_used", _i64),
-                ("maps", MapDesc * MAX_MAPS)]
+                ("ready_event", _vp), ("late_mask", _i32), ("reserved", _i32), ("maps", MapDesc * MAX_MAPS)]
 
 
 class PlanOp(ctypes.Structure):       # gcl_plan_op
@@ -129,6 +129,7 @@ SIGNATURES = {
     "gcl_col_sum": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
     "gcl_maps_arena_bytes": (_i64, [_i64, _vp, _i32, _i32]),
     "gcl_maps_build": (_i32, [_vp, _i64, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _vp]),
+    "gcl_maps_build_split": (_i32, [_vp, _i64, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp]),
     "gcl_plan_create": (_vp, [_vp, _i32, _i32, _i32, _vp, _i32, _i32]),
     "gcl_plan_destroy": (None, [_vp]),
     "gcl_plan_state_bytes": (_i64, [_vp]),

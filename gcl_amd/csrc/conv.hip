@@ -2161,6 +2161,10 @@ static int conv_fwd_nb(long long n_out, int cout, int prec) {
   if (prec == 3 && nb == 4) nb = 2;   // three planes: the double-buffered weight block of NB = 4 would not fit twice
   long long wgs = cdiv(n_out, 128) * (cout / (32 * nb));
   if (prec != 0 && pol == 1 && nb == 4 && wgs > 512 && wgs <= 1024) nb = 2;
+  // small launches: narrower column blocks until the launch has a workgroup per CU (the weight layout does not depend on NB and
+  // a column's sum is the same chain of products whatever block holds it: bitwise the same result)
+  static const long long small = [] { const char* s = getenv("GCL_NB_SMALL_WGS"); return s ? atoll(s) : 256ll; }();
+  while (prec != 0 && nb > 1 && cdiv(n_out, 128) * (cout / (32 * nb)) < small) nb /= 2;
   return nb;
 }
 

@@ -25,12 +25,32 @@ void set_error(const char* fmt, ...) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-__global__ void k_table_fill(Slot* t, long long cap) {
+// (also zeroes the four status words of the insertion that follows: one launch instead of a memset + a launch -- a pass
+// over one pair of clouds is a chain of ~ 130 small dependent launches, every one of them ~ 4.5 us of somebody's time)
+__global__ void k_table_fill(Slot* t, long long cap, int* zero4) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < cap) {
     t[i].key = EMPTY_KEY;
     t[i].val = LLONG_MAX;
   }
+  if (zero4 && i < 4) zero4[i] = 0;
+}
+
+// p[0 .. n) = v: the fills of the map builders as ONE launch each (hipMemsetAsync splits a length that is not a multiple of its
+// vector width into two dispatches and costs the enqueuing thread about twice a kernel launch)
+__global__ void __launch_bounds__(256) k_fill32(unsigned* __restrict__ p, long long n, unsigned v) {
+  const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i0 + 4 <= n && (reinterpret_cast<uintptr_t>(p + i0) & 15) == 0) {
+    *reinterpret_cast<uint4*>(p + i0) = make_uint4(v, v, v, v);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (i0 + j < n) p[i0 + j] = v;
+  }
+}
+static inline void fill32(void* p, long long n_words, unsigned v, hipStream_t st) {
+  if (n_words > 0)
+    hipLaunchKernelGGL(k_fill32, dim3((unsigned)cdiv(n_words, 1024)), dim3(256), 0, st, (unsigned*)p, n_words, v);
 }
 
 __global__ void k_coords_insert(const int4* __restrict__ coords, long long n, Slot* t, long long cap,
@@ -233,7 +253,7 @@ __global__ void __launch_bounds__(SCAN1_T) k_scan_single(const int* __restrict__
 }
 
 static int device_scan(const int* in, long long n, int* out, int* bs, hipStream_t st) {
-  if (n <= 16384) {
+  if (n <= 65536) {      // (16384 until round 6: the strided levels of a 36 k-voxel pass scan the INPUT's row bound, three times)
     hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(SCAN1_T), 0, st, in, n, out);
     GCL_CHECK_LAUNCH();
     return GCL_OK;
@@ -901,8 +921,7 @@ int gcl_coords_insert(const int32_t* coords, int64_t n, int64_t* table, int64_t 
   GCL_CHECK_ARG(coords && table && status, "gcl_coords_insert: null pointer");
   GCL_CHECK_ARG(is_pow2(cap) && cap >= 2 * n && cap >= 64, "gcl_coords_insert: cap must be a power of two >= 2n");
   hipStream_t st = (hipStream_t)stream;
-  GCL_CHECK_HIP(hipMemsetAsync(status, 0, 4 * sizeof(int32_t), st));
-  hipLaunchKernelGGL(k_table_fill, dim3((unsigned)cdiv(cap, 256)), dim3(256), 0, st, (Slot*)table, (long long)cap);
+  hipLaunchKernelGGL(k_table_fill, dim3((unsigned)cdiv(cap, 256)), dim3(256), 0, st, (Slot*)table, (long long)cap, status);
   if (n > 0)
     hipLaunchKernelGGL(k_coords_insert, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, (const int4*)coords,
                        (long long)n, (Slot*)table, (long long)cap, status);
@@ -923,9 +942,8 @@ static int stride_map_impl(const int32_t* coords_in, int64_t n_in, const int32_t
   int* pos = scratch + n_in;
   int* bs = scratch + 2 * n_in;
   unsigned g = (unsigned)cdiv(n_in, 256);
-  GCL_CHECK_HIP(hipMemsetAsync(status, 0, 4 * sizeof(int32_t), st));
   hipLaunchKernelGGL(k_table_fill, dim3((unsigned)cdiv(cap_out, 256)), dim3(256), 0, st, (Slot*)table_out,
-                     (long long)cap_out);
+                     (long long)cap_out, status);
   hipLaunchKernelGGL(k_stride_insert, dim3(g), dim3(256), 0, st, (const int4*)coords_in, (long long)n_in,
                      (const int*)n_in_dev, t_out, (Slot*)table_out, (long long)cap_out, status);
   hipLaunchKernelGGL(k_stride_flag, dim3(g), dim3(256), 0, st, (const int4*)coords_in, (long long)n_in,
@@ -980,13 +998,13 @@ int gcl_kernel_map(const int32_t* coords_out, int64_t n_out, const int64_t* tabl
     return (v == 1 || v == 2) ? v : 4;
   }();
   if (bitmap && !bitmap_valid) {
-    GCL_CHECK_HIP(hipMemsetAsync(bitmap, 0, BITMAP_WORDS * sizeof(int32_t), st));
+    fill32(bitmap, BITMAP_WORDS, 0u, st);
     hipLaunchKernelGGL(k_bitmap_fill, dim3((unsigned)cdiv(cap_in, 256)), dim3(256), 0, st, (const Slot*)table_in,
                        (long long)cap_in, (unsigned*)bitmap);
   }
   if (same_map) {
     if (K > 1)
-      GCL_CHECK_HIP(hipMemsetAsync(nbr + (size_t)(K / 2 + 1) * n_out, 0xFF, (size_t)(K / 2) * n_out * sizeof(int32_t), st));
+      fill32(nbr + (size_t)(K / 2 + 1) * n_out, (long long)(K / 2) * n_out, 0xFFFFFFFFu, st);
     if (kpt == 4)
       hipLaunchKernelGGL(k_kernel_map_sym<4>, dim3(nblk, (unsigned)cdiv(K / 2 + 1, 4)), dim3(256), 0, st, (const int4*)coords_out,
                          (long long)n_out, (const Slot*)table_in, (long long)cap_in, (const unsigned*)bitmap, ks, step,
@@ -1001,7 +1019,7 @@ int gcl_kernel_map(const int32_t* coords_out, int64_t n_out, const int64_t* tabl
                          nbr, scratch);
     hipLaunchKernelGGL(k_count_reduce, dim3(K / 2 + 1), dim3(256), 0, st, (const int*)scratch, nblk, K, 1, counts);
   } else {
-    if (nbr_t) GCL_CHECK_HIP(hipMemsetAsync(nbr_t, 0xFF, (size_t)K * n_in * sizeof(int32_t), st));
+    if (nbr_t) fill32(nbr_t, (long long)K * n_in, 0xFFFFFFFFu, st);
     if (kpt == 4)
       hipLaunchKernelGGL(k_kernel_map<4>, dim3(nblk, (unsigned)cdiv(K, 4)), dim3(256), 0, st, (const int4*)coords_out,
                          (long long)n_out, (const Slot*)table_in, (long long)cap_in, (const unsigned*)bitmap, ks, step, nbr,

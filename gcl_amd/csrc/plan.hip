@@ -196,7 +196,7 @@ static int level_of(int t) {
 }
 
 static int maps_build(const int32_t* coords, long long n, const gcl_map_spec* specs, int n_specs, int n_levels, Arena& A,
-                      int32_t* pinned, gcl_maps_desc* out, hipStream_t st) {
+                      int32_t* pinned, gcl_maps_desc* out, hipStream_t st, hipStream_t side = nullptr) {
   void* stream = (void*)st;
   memset(out, 0, sizeof(*out));
   out->n_levels = n_levels;
@@ -241,9 +241,16 @@ static int maps_build(const int32_t* coords, long long n, const gcl_map_spec* sp
     }
   }
   // kernel maps (CoordinateManager.get_kernel_map), one presence bitmap per coordinate table
-  int32_t* bitmap[GCL_MAX_LEVELS] = {nullptr};
+  int32_t* bitmap[2][GCL_MAX_LEVELS] = {{nullptr}, {nullptr}};      // [built on the side stream][level]
   bool any_pairs = false;      // pair lists wanted (training): their counts are read back; inference skips the D2H copies
   for (int s = 0; s < n_specs; ++s) any_pairs = any_pairs || (specs[s].pairs != 0 && specs[s].kernel_size > 1);
+  // SPLIT build (gcl_maps_build_split, inference): once the level sizes are on the host nothing below waits for the host
+  // again, so the maps of the input level alone (what the first layers of a network use) stay on `stream` and every other
+  // map and its sorted tables go to `side` -- they are built BESIDE the first layers' convolutions, which the caller can
+  // enqueue on `stream` straight away (gcl_maps_desc.late_mask / ready_event tell the plan where to wait).  The dry run
+  // reserves for the split (one more presence bitmap per level).
+  const bool split = (side != nullptr || A.dry) && !any_pairs;
+  auto on_side = [&](const gcl_map_spec& sp) { return split && !(sp.t_in == 1 && sp.stride == 1); };
   for (int s = 0; s < n_specs; ++s) {
     const gcl_map_spec& sp = specs[s];
     gcl_map_desc& d = out->maps[s];
@@ -262,6 +269,9 @@ static int maps_build(const int32_t* coords, long long n, const gcl_map_spec* sp
       GCL_CHECK_ARG(sp.stride == 1, "gcl_maps_build: kernel_size 1 with stride > 1");
       continue;      // identity pairs only, after the counts are known (nothing to count here)
     }
+    const int sd = on_side(sp) ? 1 : 0;
+    void* mstream = (sd && side) ? (void*)side : stream;
+    if (sd) out->late_mask |= 1 << s;
     d.nbr = A.take_n<int32_t>((long long)d.K * d.n_out);
     const bool same = sp.stride == 1;
     d.nbr_t = same ? nullptr : A.take_n<int32_t>((long long)d.K * d.n_in);
@@ -272,24 +282,24 @@ static int maps_build(const int32_t* coords, long long n, const gcl_map_spec* sp
     for (int q = 0; q < s && from5 && same && sp.kernel_size == 3; ++q)
       if (specs[q].t_in == sp.t_in && specs[q].kernel_size == 5 && specs[q].stride == 1 && out->maps[q].nbr) src5 = q;
     if (src5 >= 0) {
-      PLAN_CALL(gcl_kernel_map_3_from_5(out->maps[src5].nbr, out->maps[src5].counts, d.n_out, d.nbr, d.counts, stream));
+      PLAN_CALL(gcl_kernel_map_3_from_5(out->maps[src5].nbr, out->maps[src5].counts, d.n_out, d.nbr, d.counts, mstream));
       if (!A.dry && any_pairs)
         GCL_CHECK_HIP(hipMemcpyAsync(pinned + 128 * (s + 1), d.counts, sizeof(int32_t) * d.K, hipMemcpyDeviceToHost, st));
       continue;
     }
-    const bool bitmap_valid = bitmap[d.level_in] != nullptr;
-    if (!bitmap_valid) bitmap[d.level_in] = A.take_n<int32_t>(gcl_kernel_map_bitmap_len());
+    const bool bitmap_valid = bitmap[sd][d.level_in] != nullptr;     // a bitmap is shared by the maps of ONE stream only
+    if (!bitmap_valid) bitmap[sd][d.level_in] = A.take_n<int32_t>(gcl_kernel_map_bitmap_len());
     int32_t* scratch = A.take_n<int32_t>(gcl_kernel_map_scratch_len(sp.kernel_size, d.n_out));
     PLAN_CALL(gcl_kernel_map(out->coords[d.level_out], d.n_out, out->table[d.level_in], out->cap[d.level_in],
-                             sp.kernel_size, sp.t_in, (same ? 1 : 0) | (bitmap_valid ? 2 : 0), bitmap[d.level_in], scratch,
-                             d.nbr, d.nbr_t, d.n_in, d.counts, stream));
+                             sp.kernel_size, sp.t_in, (same ? 1 : 0) | (bitmap_valid ? 2 : 0), bitmap[sd][d.level_in], scratch,
+                             d.nbr, d.nbr_t, d.n_in, d.counts, mstream));
     if (!A.dry && any_pairs)   // without pair lists nobody waits for this copy: it would outlive the call (pinned re-use)
       GCL_CHECK_HIP(hipMemcpyAsync(pinned + 128 * (s + 1), d.counts, sizeof(int32_t) * d.K, hipMemcpyDeviceToHost, st));
   }
   // mask-sorted tables (KernelMap.sorted_table) of all maps in ONE gcl_table_sort_multi sequence (14 launches instead of
   // 14 per table; same results); K > 27 tables are used as they are
-  gcl_sort_job jobs[2 * GCL_MAX_MAPS];
-  int n_jobs = 0;
+  gcl_sort_job jobs[2][2 * GCL_MAX_MAPS];      // [on the side stream][job]
+  int n_jobs[2] = {0, 0};
   for (int s = 0; s < n_specs; ++s) {
     const gcl_map_spec& sp = specs[s];
     gcl_map_desc& d = out->maps[s];
@@ -304,7 +314,8 @@ static int maps_build(const int32_t* coords, long long n, const gcl_map_spec* sp
       int32_t* order = A.take_n<int32_t>(rows);
       int32_t* sorted = A.take_n<int32_t>((long long)d.K * rows);
       int32_t* mask = A.take_n<int32_t>(cdiv(rows, 32));
-      jobs[n_jobs++] = gcl_sort_job{tbl, d.K, rows, scratch, order, sorted, mask};
+      const int sd = on_side(sp) ? 1 : 0;
+      jobs[sd][n_jobs[sd]++] = gcl_sort_job{tbl, d.K, rows, scratch, order, sorted, mask};
       if (tr) { d.tbl_t = sorted; d.order_t = order; d.mask_t = mask; }
       else { d.tbl_n = sorted; d.order_n = order; d.mask_n = mask; }
     }
@@ -314,13 +325,17 @@ static int maps_build(const int32_t* coords, long long n, const gcl_map_spec* sp
     if (!(specs[s].tables & 4) || specs[s].kernel_size == 1) continue;
     gcl_map_desc& d = out->maps[s];
     d.presence = A.take_n<uint32_t>(d.n_out * ((d.K + 31) / 32));
-    PLAN_CALL(gcl_presence_bits(d.nbr, d.K, d.n_out, d.presence, stream));
+    PLAN_CALL(gcl_presence_bits(d.nbr, d.K, d.n_out, d.presence, (on_side(specs[s]) && side) ? (void*)side : stream));
   }
-  if (n_jobs && sort_multi) PLAN_CALL(gcl_table_sort_multi(jobs, n_jobs, stream));
-  if (n_jobs && !sort_multi)
-    for (int q = 0; q < n_jobs; ++q)
-      PLAN_CALL(gcl_table_sort_pre(jobs[q].tbl, jobs[q].K, jobs[q].n, 0, nullptr, jobs[q].scratch, jobs[q].order,
-                                   jobs[q].tbl_sorted, jobs[q].tile_mask, stream));
+  for (int sd = 0; sd < 2; ++sd) {      // the main stream's tables first: the first layers wait for them
+    void* sstream = (sd && side) ? (void*)side : stream;
+    if (n_jobs[sd] && sort_multi) PLAN_CALL(gcl_table_sort_multi(jobs[sd], n_jobs[sd], sstream));
+    if (n_jobs[sd] && !sort_multi)
+      for (int q = 0; q < n_jobs[sd]; ++q)
+        PLAN_CALL(gcl_table_sort_pre(jobs[sd][q].tbl, jobs[sd][q].K, jobs[sd][q].n, 0, nullptr, jobs[sd][q].scratch,
+                                     jobs[sd][q].order, jobs[sd][q].tbl_sorted, jobs[sd][q].tile_mask, sstream));
+  }
+  if (!side) out->late_mask = 0;       // (dry run / one stream: nothing is late)
   // the second host sync: per-offset pair counts -> padded segment offsets -> pair lists (KernelMap.pairs); skipped when
   // no map asks for pair lists (inference): counts_host / n_pairs / seg_off then stay zero
   if (!A.dry && any_pairs) GCL_CHECK_HIP(hipStreamSynchronize(st));
@@ -700,9 +715,15 @@ static int plan_forward(Plan& P, const float* x_in, void* const* bn_stats, float
     P.bwd_packed = true;
   }
   P.t[0].ptr = (float*)x_in;
+  // maps of a split build (gcl_maps_build_split): the first record that uses a map made on the side stream waits for it
+  bool late_pending = !A.dry && M.ready_event && M.late_mask;
   for (size_t i = 0; i < P.ops.size(); ++i) {
     const gcl_plan_op& op = P.ops[i];
     const long long n_out = M.n_rows[op.level_out];
+    if (late_pending && (op.kind == GCL_OP_CONVBN || op.kind == GCL_OP_CONV) && ((M.late_mask >> op.map) & 1)) {
+      GCL_CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)M.ready_event, 0));
+      late_pending = false;
+    }
     TState& y = P.t[op.y];
     int rc;
     switch (op.kind) {
@@ -860,6 +881,7 @@ static int plan_forward(Plan& P, const float* x_in, void* const* bn_stats, float
         return GCL_ERR_ARG;
     }
   }
+  if (late_pending) GCL_CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)M.ready_event, 0));      // (the arena outlives the side stream's work)
   *y_out = P.t[P.ops.back().y].ptr;
   return GCL_OK;
 }
@@ -1149,9 +1171,11 @@ int64_t gcl_maps_arena_bytes(int64_t n, const gcl_map_spec* specs_host, int32_t 
   return A.off + 4096;
 }
 
-int gcl_maps_build(const int32_t* coords, int64_t n, const gcl_map_spec* specs_host, int32_t n_specs, int32_t n_levels,
-                   void* arena, int64_t arena_bytes, void* pinned_host, gcl_maps_desc* out_host, void* stream) {
+int gcl_maps_build_split(const int32_t* coords, int64_t n, const gcl_map_spec* specs_host, int32_t n_specs, int32_t n_levels,
+                         void* arena, int64_t arena_bytes, void* pinned_host, gcl_maps_desc* out_host, void* stream,
+                         void* side_stream) {
   GCL_CHECK_ARG(coords && specs_host && arena && pinned_host && out_host, "gcl_maps_build: null pointer");
+  GCL_CHECK_ARG(side_stream != stream || !side_stream, "gcl_maps_build_split: the side stream must differ from the stream");
   GCL_CHECK_ARG(n > 0, "gcl_maps_build: empty SparseTensor");
   GCL_CHECK_ARG(n_specs >= 0 && n_specs <= GCL_MAX_MAPS && n_levels >= 1 && n_levels <= GCL_MAX_LEVELS,
                 "gcl_maps_build: at most %d maps and %d levels", GCL_MAX_MAPS, GCL_MAX_LEVELS);
@@ -1165,7 +1189,13 @@ int gcl_maps_build(const int32_t* coords, int64_t n, const gcl_map_spec* specs_h
     return GCL_ERR_ARENA;
   }
   Arena A{(char*)arena, arena_bytes, 0, false};
-  return maps_build(coords, n, specs_host, n_specs, n_levels, A, (int32_t*)pinned_host, out_host, (hipStream_t)stream);
+  return maps_build(coords, n, specs_host, n_specs, n_levels, A, (int32_t*)pinned_host, out_host, (hipStream_t)stream,
+                    (hipStream_t)side_stream);
+}
+
+int gcl_maps_build(const int32_t* coords, int64_t n, const gcl_map_spec* specs_host, int32_t n_specs, int32_t n_levels,
+                   void* arena, int64_t arena_bytes, void* pinned_host, gcl_maps_desc* out_host, void* stream) {
+  return gcl_maps_build_split(coords, n, specs_host, n_specs, n_levels, arena, arena_bytes, pinned_host, out_host, stream, nullptr);
 }
 
 void* gcl_plan_create(const gcl_plan_op* ops_host, int32_t n_ops, int32_t n_tensors, int32_t n_params,

@@ -189,13 +189,21 @@ class ResUNet2(ME.MinkowskiNetwork):
         if mgr.native is None:
             if mgr._kmaps or len(mgr._maps) > 1:      # maps already built from Python: keep using them
                 return None
-            mgr = ME.CoordinateManager.build_native(mgr.get_coords(1), self.native_map_specs(training=False))
+            # with a plan in hand the deeper levels' maps are built on a side stream, beside the first layers (the plan waits)
+            side = (native.eval_side_stream(x.F.device, x.F.shape[0])
+                    if isinstance(self.__dict__.get("_plan"), native.NetworkPlan) else None)
+            mgr = ME.CoordinateManager.build_native(mgr.get_coords(1), self.native_map_specs(training=False), side_stream=side)
             x = ME.SparseTensor(x.F, coordinate_map_key=x.coordinate_map_key, coordinate_manager=mgr)
         plan = self.__dict__.get("_plan")
         if isinstance(plan, native.NetworkPlan):
             if mgr.native.keys != plan.spec_keys or len(plan.params) != self._n_parameters(validated=True):
+                mgr.native.wait_ready()
                 return None
-            F = plan.run_eval(x.F, mgr.native)
+            try:
+                F = plan.run_eval(x.F, mgr.native)
+            except Exception:
+                mgr.native.wait_ready()       # the side stream may still be writing the arena this frame is about to drop
+                raise
             return ME.SparseTensor(F, coordinate_map_key=ME.CoordinateMapKey(1 << plan.records[-1]["level_out"]),
                                    coordinate_manager=mgr)
         trace, ops._EVAL_TRACE = ops.Tape(), None

@@ -637,6 +637,9 @@ typedef struct gcl_maps_desc {
   int64_t cap[GCL_MAX_LEVELS];
   int32_t status[4];                    /* HOST copy of gcl_coords_insert's status words */
   int64_t arena_used;
+  void* ready_event;                    /* split build: hipEvent_t the CALLER records on the side stream after the call (else NULL) */
+  int32_t late_mask;                    /* split build: bit s = map s was enqueued on the side stream (gcl_maps_build_split) */
+  int32_t reserved;
   gcl_map_desc maps[GCL_MAX_MAPS];
 } gcl_maps_desc;
 
@@ -649,6 +652,17 @@ int64_t gcl_maps_arena_bytes(int64_t n, const gcl_map_spec* specs_host, int32_t 
  * (out_host->status tells which). */
 int gcl_maps_build(const int32_t* coords, int64_t n, const gcl_map_spec* specs_host, int32_t n_specs, int32_t n_levels,
                    void* arena, int64_t arena_bytes, void* pinned_host, gcl_maps_desc* out_host, void* stream);
+/* The same build on TWO streams, for a pass over few rows (one pair of clouds per call: util/misc.py:128-130,
+ * scripts/test_kitti.py:143-150), whose ~ 90 small dependent launches are a third of the pass.  Everything up to the read-back
+ * of the level sizes runs on `stream`; after it -- when no map asks for pair lists, i.e. nothing else waits for the host --
+ * the maps of the input level alone (kernel maps with t_in = 1, stride 1: what a network's first layers use) and their sorted
+ * tables stay on `stream`, every other map goes to `side_stream` (out_host->late_mask).  The caller records an event on
+ * side_stream after the call and stores it in out_host->ready_event: gcl_plan_forward / _eval make `stream` wait for it in
+ * front of the first record that uses a late map, so the first layers' convolutions run beside the deeper levels' map
+ * building.  Same launches, same results as gcl_maps_build (side_stream NULL, or pair lists wanted: exactly that call). */
+int gcl_maps_build_split(const int32_t* coords, int64_t n, const gcl_map_spec* specs_host, int32_t n_specs, int32_t n_levels,
+                         void* arena, int64_t arena_bytes, void* pinned_host, gcl_maps_desc* out_host, void* stream,
+                         void* side_stream);
 
 /* Operator records of a network pass.  Tensors are numbered 0 .. n_tensors-1 (0 = the input features); every record
  * names its input(s) and its output; parameters are numbered in the order of the `params` / `grads` pointer arrays. */

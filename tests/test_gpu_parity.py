@@ -1792,6 +1792,54 @@ def test_forward_pair_equals_two_forward_passes_bitwise():
     assert torch.equal(a0, b0) and torch.equal(a1, b1)
 
 
+def test_split_map_build_pass_equals_the_one_stream_pass_bitwise(monkeypatch):
+    """A one-call inference pass builds the deeper levels' maps on a side stream beside the first layers' convolutions
+    (gcl_maps_build_split; the plan waits in front of the first record that uses one): the same launches on the same data, so
+    the features, every level's coordinates and every sorted table equal the one-stream build bit for bit -- over repeated
+    passes of alternating sizes (arena re-use between the streams), and with a consumer other than the plan (wait_ready)."""
+    import gcl_amd.MinkowskiEngine as ME
+    from gcl_amd import synthetic
+    from gcl_amd.MinkowskiEngine import native
+    from gcl_amd.scripts.test_kitti import forward_clouds
+    m, _ = _model_and_state(4, 5)
+    m.eval()
+    pairs = [synthetic.make_eval_pair(5 + s, baseline=15.0 + 5 * s, n_boxes=15 + 10 * (s % 2)) for s in range(3)]
+    sets = [[(p[f"sinput{k}_F"].to(DEV), p[f"sinput{k}_C"].to(DEV)) for k in (0, 1)] for p in pairs]
+    with torch.no_grad(), torch.cuda.device(DEV):
+        monkeypatch.setenv("GCL_EVAL_SPLIT_MAPS", "0")
+        forward_clouds(m, sets[0])                      # the first pass records the plan (per-operator path)
+        ref = [[f.clone() for f in forward_clouds(m, s)] for s in sets]
+        monkeypatch.setenv("GCL_EVAL_SPLIT_MAPS", "1")
+        monkeypatch.setenv("GCL_EVAL_SPLIT_MIN_ROWS", "0")         # (default: passes of >= 100 000 rows)
+        assert native.eval_side_stream(DEV, 10) is not None
+        for rep in range(4):
+            for s, r in zip(sets, ref):
+                got = forward_clouds(m, s)
+                assert all(torch.equal(a, b) for a, b in zip(got, r)), rep
+        # the maps themselves, read by something that is not the plan
+        C = torch.cat([c.clone() for _, c in sets[1]])
+        C[: len(sets[1][0][1]), 0] = 0
+        C[len(sets[1][0][1]):, 0] = 1
+        specs = m.native_map_specs(training=False)
+        one = ME.CoordinateManager.build_native(C, specs).native
+        two = ME.CoordinateManager.build_native(C, specs, side_stream=native.eval_side_stream(DEV)).native
+        assert two.ready is not None and two.desc.late_mask != 0 and one.desc.late_mask == 0
+        two.wait_ready()
+        torch.cuda.synchronize()
+        for l in range(one.n_levels):
+            assert one.num_rows(l) == two.num_rows(l)
+            assert torch.equal(one.view(one.desc.coords[l], (one.num_rows(l), 4), torch.int32),
+                               two.view(two.desc.coords[l], (two.num_rows(l), 4), torch.int32))
+        for q in range(one.desc.n_maps):
+            a, b = one.desc.maps[q], two.desc.maps[q]
+            assert (a.K, a.n_in, a.n_out) == (b.K, b.n_in, b.n_out)
+            for name, rows in (("nbr", a.n_out), ("nbr_t", a.n_in), ("tbl_n", a.n_out), ("tbl_t", a.n_in)):
+                pa, pb = getattr(a, name), getattr(b, name)
+                assert bool(pa) == bool(pb)
+                if pa:
+                    assert torch.equal(one.view(pa, (a.K, rows), torch.int32), two.view(pb, (b.K, rows), torch.int32)), (q, name)
+
+
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "circle_loss_*.npz"))))
 def test_location_circle_loss_golden(path):
     """lib/colocation_trainer.py:538-681 on the device vs the reference's own outputs: loss triple within 1e-5 rel,

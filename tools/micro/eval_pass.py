@@ -26,3 +26,25 @@ with torch.no_grad(), torch.cuda.device(dev):
     dt = (time.perf_counter() - t0) / N
 nv = np.mean([len(p["sinput0_C"]) + len(p["sinput1_C"]) for p in pairs]) * PP
 print(f"{dt * 1e3:.3f} ms per pass of {nv:.0f} voxels = {nv / dt / 1e6:.1f} M voxels/s")
+
+if os.environ.get("EP_HOST_SPLIT"):     # where the enqueuing thread spends a pass (perf_counter around the two native calls)
+    import gcl_amd.MinkowskiEngine as ME
+    from gcl_amd.MinkowskiEngine import native
+    acc = {"build": 0.0, "eval": 0.0}
+    ob, oe = ME.CoordinateManager.build_native.__func__, native.NetworkPlan.run_eval
+    def tb(cls, *a, **k):
+        t = time.perf_counter(); r = ob(cls, *a, **k); acc["build"] += time.perf_counter() - t; return r
+    def te(self, *a, **k):
+        t = time.perf_counter(); r = oe(self, *a, **k); acc["eval"] += time.perf_counter() - t; return r
+    ME.CoordinateManager.build_native = classmethod(tb)
+    native.NetworkPlan.run_eval = te
+    with torch.no_grad(), torch.cuda.device(dev):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for j in range(N):
+            one(j)
+        t_enq = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        t_all = time.perf_counter() - t0
+    print(f"host per pass: build_native {acc['build'] / N * 1e6:.0f} us (incl. its read-back wait), run_eval {acc['eval'] / N * 1e6:.0f} us, "
+          f"everything else {(t_enq - acc['build'] - acc['eval']) / N * 1e6:.0f} us; loop {t_enq / N * 1e6:.0f} us, with the final sync {t_all / N * 1e6:.0f} us")
