@@ -292,9 +292,11 @@ __global__ void k_bitmap_fill(const Slot* __restrict__ t, long long cap, unsigne
 // presence word, table slot, row -- each at the 5^3 stem map of 0.5 M voxels, wait_any 0.81): the coordinate is read once, the KPT
 // presence words are independent loads in flight together, and only then the (rare: 17 %) table probes follow.  Same entries,
 // same per-(offset, block) counts.
-// per-offset number of threads of the 256-thread block with a hit, written by threads 0 .. KPT - 1 (plain stores)
+// per-offset number of threads of the 256-thread block with a hit, written by threads 0 .. KPT - 1: plain stores into the
+// per-block array (k_count_reduce adds them up), or -- `acc` -- integer atomics straight into the zeroed counts (mir: the mirror
+// offset of a same-map): the same totals without the reduction launch, for builds of few blocks
 template <int KPT>
-__device__ __forceinline__ void block_counts(const bool (&pred)[KPT], int* const (&dst)[KPT]) {
+__device__ __forceinline__ void block_counts(const bool (&pred)[KPT], int* const (&dst)[KPT], int* const (&mir)[KPT], bool acc) {
   __shared__ int wc[KPT][4];
 #pragma unroll
   for (int q = 0; q < KPT; ++q) {
@@ -304,7 +306,15 @@ __device__ __forceinline__ void block_counts(const bool (&pred)[KPT], int* const
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < KPT; ++q)
-    if ((int)threadIdx.x == q && dst[q]) *dst[q] = wc[q][0] + wc[q][1] + wc[q][2] + wc[q][3];
+    if ((int)threadIdx.x == q && dst[q]) {
+      const int c = wc[q][0] + wc[q][1] + wc[q][2] + wc[q][3];
+      if (!acc) {
+        *dst[q] = c;
+      } else if (c) {
+        atomicAdd(dst[q], c);
+        if (mir[q]) atomicAdd(mir[q], c);
+      }
+    }
 }
 
 // rows of the KPT neighbours c + o_k of one voxel (-1: absent / out of the packed range / k >= nk)
@@ -343,16 +353,18 @@ __global__ void __launch_bounds__(256) k_kernel_map(const int4* __restrict__ coo
                                                     const Slot* __restrict__ t, long long cap,
                                                     const unsigned* __restrict__ bitmap, int ks, int step,
                                                     int* __restrict__ nbr, int* __restrict__ nbr_t,
-                                                    long long n_in, int* blockcnt) {
+                                                    long long n_in, int* blockcnt, int acc) {
   const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int K = ks * ks * ks, k0 = blockIdx.y * KPT;
   int u[KPT];
   bool hit[KPT];
   int* dst[KPT];
+  int* mir[KPT];
 #pragma unroll
   for (int q = 0; q < KPT; ++q) {
     u[q] = -1;
-    dst[q] = (k0 + q < K) ? blockcnt + (long long)(k0 + q) * gridDim.x + blockIdx.x : nullptr;
+    mir[q] = nullptr;
+    dst[q] = (k0 + q < K) ? (acc ? blockcnt + (k0 + q) : blockcnt + (long long)(k0 + q) * gridDim.x + blockIdx.x) : nullptr;
   }
   if (v < n_out) {
     lookup_rows<KPT>(t, cap, bitmap, coords_out[v], ks, step, k0, K, u);
@@ -367,7 +379,7 @@ __global__ void __launch_bounds__(256) k_kernel_map(const int4* __restrict__ coo
   }
 #pragma unroll
   for (int q = 0; q < KPT; ++q) hit[q] = u[q] >= 0;
-  block_counts<KPT>(hit, dst);
+  block_counts<KPT>(hit, dst, mir, acc != 0);
 }
 
 // same-map variant: offsets k in [0, K/2]; the mirror half [K/2+1, K) was pre-filled with -1
@@ -375,16 +387,19 @@ template <int KPT>
 __global__ void __launch_bounds__(256) k_kernel_map_sym(const int4* __restrict__ coords, long long n,
                                                         const Slot* __restrict__ t, long long cap,
                                                         const unsigned* __restrict__ bitmap, int ks, int step,
-                                                        int* __restrict__ nbr, int* blockcnt) {
+                                                        int* __restrict__ nbr, int* blockcnt, int acc) {
   const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int K = ks * ks * ks, k0 = blockIdx.y * KPT;
   int u[KPT];
   bool hit[KPT];
   int* dst[KPT];
+  int* mir[KPT];
 #pragma unroll
   for (int q = 0; q < KPT; ++q) {
     u[q] = -1;
-    dst[q] = (k0 + q <= K / 2) ? blockcnt + (long long)(k0 + q) * gridDim.x + blockIdx.x : nullptr;
+    const int k = k0 + q;
+    dst[q] = (k <= K / 2) ? (acc ? blockcnt + k : blockcnt + (long long)k * gridDim.x + blockIdx.x) : nullptr;
+    mir[q] = (acc && k < K / 2) ? blockcnt + (K - 1 - k) : nullptr;
   }
   if (v < n) {
     lookup_rows<KPT>(t, cap, bitmap, coords[v], ks, step, k0, K / 2, u);      // the centre (k = K / 2) is the voxel itself
@@ -398,7 +413,7 @@ __global__ void __launch_bounds__(256) k_kernel_map_sym(const int4* __restrict__
   }
 #pragma unroll
   for (int q = 0; q < KPT; ++q) hit[q] = u[q] >= 0;
-  block_counts<KPT>(hit, dst);
+  block_counts<KPT>(hit, dst, mir, acc != 0);
 }
 
 // counts[k] = sum of the per-block counts (ordered, no atomics); mirror offsets share the count in a same-map
@@ -987,6 +1002,12 @@ int gcl_kernel_map(const int32_t* coords_out, int64_t n_out, const int64_t* tabl
   GCL_CHECK_ARG(ks >= 1 && (ks & 1) && ks <= 5, "gcl_kernel_map: kernel size must be 1, 3 or 5");
   GCL_CHECK_ARG(n_out > 0 && step >= 1 && is_pow2(cap_in), "gcl_kernel_map: bad sizes");
   const bool bitmap_valid = (same_map & 2) != 0;      // bit 1: `bitmap` already describes table_in (built by an earlier call)
+  // bit 2: `counts` is zero on entry and the build is short (<= 1024 blocks): per-offset counts by integer atomics, no
+  // k_count_reduce launch, `scratch` unused
+  // (64 blocks = 16 384 rows.  The K counters share two cache lines: at 256 / 1024 blocks the atomics cost more than the
+  // launch they save -- eight pairs per pass 97.4 -> 89 - 96 / 87 - 94 M voxels/s, the training step 11.94 -> 12.0 / 12.35 ms)
+  static const long long acc_max = [] { const char* e = getenv("GCL_MAP_ACC_MAX_BLOCKS"); return e ? atoll(e) : 64ll; }();
+  const int acc = ((same_map & 4) != 0 && cdiv(n_out, 256) <= acc_max) ? 1 : 0;
   same_map &= 1;
   GCL_CHECK_ARG(!same_map || (nbr_t == nullptr && n_in == n_out), "gcl_kernel_map: same_map excludes nbr_t");
   hipStream_t st = (hipStream_t)stream;
@@ -1008,31 +1029,31 @@ int gcl_kernel_map(const int32_t* coords_out, int64_t n_out, const int64_t* tabl
     if (kpt == 4)
       hipLaunchKernelGGL(k_kernel_map_sym<4>, dim3(nblk, (unsigned)cdiv(K / 2 + 1, 4)), dim3(256), 0, st, (const int4*)coords_out,
                          (long long)n_out, (const Slot*)table_in, (long long)cap_in, (const unsigned*)bitmap, ks, step,
-                         nbr, scratch);
+                         nbr, acc ? counts : scratch, acc);
     else if (kpt == 2)
       hipLaunchKernelGGL(k_kernel_map_sym<2>, dim3(nblk, (unsigned)cdiv(K / 2 + 1, 2)), dim3(256), 0, st, (const int4*)coords_out,
                          (long long)n_out, (const Slot*)table_in, (long long)cap_in, (const unsigned*)bitmap, ks, step,
-                         nbr, scratch);
+                         nbr, acc ? counts : scratch, acc);
     else
       hipLaunchKernelGGL(k_kernel_map_sym<1>, dim3(nblk, K / 2 + 1), dim3(256), 0, st, (const int4*)coords_out,
                          (long long)n_out, (const Slot*)table_in, (long long)cap_in, (const unsigned*)bitmap, ks, step,
-                         nbr, scratch);
-    hipLaunchKernelGGL(k_count_reduce, dim3(K / 2 + 1), dim3(256), 0, st, (const int*)scratch, nblk, K, 1, counts);
+                         nbr, acc ? counts : scratch, acc);
+    if (!acc) hipLaunchKernelGGL(k_count_reduce, dim3(K / 2 + 1), dim3(256), 0, st, (const int*)scratch, nblk, K, 1, counts);
   } else {
     if (nbr_t) fill32(nbr_t, (long long)K * n_in, 0xFFFFFFFFu, st);
     if (kpt == 4)
       hipLaunchKernelGGL(k_kernel_map<4>, dim3(nblk, (unsigned)cdiv(K, 4)), dim3(256), 0, st, (const int4*)coords_out,
                          (long long)n_out, (const Slot*)table_in, (long long)cap_in, (const unsigned*)bitmap, ks, step, nbr,
-                         nbr_t, (long long)n_in, scratch);
+                         nbr_t, (long long)n_in, acc ? counts : scratch, acc);
     else if (kpt == 2)
       hipLaunchKernelGGL(k_kernel_map<2>, dim3(nblk, (unsigned)cdiv(K, 2)), dim3(256), 0, st, (const int4*)coords_out,
                          (long long)n_out, (const Slot*)table_in, (long long)cap_in, (const unsigned*)bitmap, ks, step, nbr,
-                         nbr_t, (long long)n_in, scratch);
+                         nbr_t, (long long)n_in, acc ? counts : scratch, acc);
     else
       hipLaunchKernelGGL(k_kernel_map<1>, dim3(nblk, K), dim3(256), 0, st, (const int4*)coords_out, (long long)n_out,
                          (const Slot*)table_in, (long long)cap_in, (const unsigned*)bitmap, ks, step, nbr, nbr_t,
-                         (long long)n_in, scratch);
-    hipLaunchKernelGGL(k_count_reduce, dim3(K), dim3(256), 0, st, (const int*)scratch, nblk, K, 0, counts);
+                         (long long)n_in, acc ? counts : scratch, acc);
+    if (!acc) hipLaunchKernelGGL(k_count_reduce, dim3(K), dim3(256), 0, st, (const int*)scratch, nblk, K, 0, counts);
   }
   GCL_CHECK_LAUNCH();
   return GCL_OK;

@@ -70,8 +70,14 @@ __global__ void __launch_bounds__(256) k_relu_bwd(const float4* __restrict__ g, 
   if (amax) publish_amax_wg(m, amax);
 }
 // ME.cat(a, b): y[r] = a[r] | b[r]   (channel counts are multiples of 4)
+// sa / sb (both or neither): the inputs' amax slots -- the cat's slot becomes their elementwise maximum (a valid slot of
+// max(value a, value b); was a launch of its own, k_slot_max) and nothing is measured
 __global__ void __launch_bounds__(256) k_cat2(const float4* __restrict__ a, int ca4, const float4* __restrict__ b, int cb4,
-                                              long long n, float4* __restrict__ y, int* amax) {
+                                              long long n, float4* __restrict__ y, int* amax, const int* __restrict__ sa,
+                                              const int* __restrict__ sb) {
+  if (sa && blockIdx.x == 0)
+    for (int w = threadIdx.x; w < AMAX_WORDS; w += 256) amax[w] = max(sa[w], sb[w]);
+  if (sa) amax = nullptr;
   const int c4 = ca4 + cb4;
   const long long total = n * c4;
   float m = 0.f;
@@ -83,10 +89,6 @@ __global__ void __launch_bounds__(256) k_cat2(const float4* __restrict__ a, int 
     m = amax4p(m, v);
   }
   if (amax) publish_amax_wg(m, amax);
-}
-// out = elementwise maximum of two amax slots (a valid slot of max(value a, value b))
-__global__ void k_slot_max(const int* __restrict__ a, const int* __restrict__ b, int* __restrict__ out) {
-  out[threadIdx.x] = max(a[threadIdx.x], b[threadIdx.x]);
 }
 // ME.cat whose left input was written in place by its producer: copy the right input's columns, y[r][ca..] = b[r]
 // planes (round 5): the cat's plane image gets these columns too, at the scale of `amax` -- then a slot that already holds a
@@ -210,8 +212,12 @@ static int maps_build(const int32_t* coords, long long n, const gcl_map_spec* sp
   int32_t* status = A.take_n<int32_t>(4);
   PLAN_CALL(gcl_coords_insert(coords, n, out->table[0], cap0, status, stream));
   // levels 1 ..: one chain of launches, row counts stay on the device (CoordinateManager._build_stride_maps)
-  int32_t* meta = A.take_n<int32_t>(8 * (n_levels > 1 ? n_levels - 1 : 1));
-  if (!A.dry && n_levels > 1) GCL_CHECK_HIP(hipMemsetAsync(meta, 0, sizeof(int32_t) * 8 * (n_levels - 1), st));
+  // one zero fill for the levels' meta words AND every map's per-offset counts (gcl_kernel_map then counts by integer
+  // atomics: no reduction launch per map)
+  const long long n_meta = 8 * (n_levels > 1 ? n_levels - 1 : 1);
+  int32_t* meta = A.take_n<int32_t>(n_meta + 128ll * GCL_MAX_MAPS);
+  int32_t* counts_all = meta + n_meta;
+  if (!A.dry) GCL_CHECK_HIP(hipMemsetAsync(meta, 0, sizeof(int32_t) * (size_t)(n_meta + 128ll * GCL_MAX_MAPS), st));
   const int32_t* cb = coords;
   const int32_t* n_dev = nullptr;
   for (int l = 1; l < n_levels; ++l) {
@@ -275,7 +281,7 @@ static int maps_build(const int32_t* coords, long long n, const gcl_map_spec* sp
     d.nbr = A.take_n<int32_t>((long long)d.K * d.n_out);
     const bool same = sp.stride == 1;
     d.nbr_t = same ? nullptr : A.take_n<int32_t>((long long)d.K * d.n_in);
-    d.counts = A.take_n<int32_t>(d.K);
+    d.counts = counts_all + 128 * s;
     // a 3^3 stride-1 map of a table whose 5^3 stride-1 map is already built: 27 of its rows (GCL_MAP3_FROM5=0: probe again)
     static const bool from5 = [] { const char* e = getenv("GCL_MAP3_FROM5"); return !(e && e[0] == '0'); }();
     int src5 = -1;
@@ -287,12 +293,15 @@ static int maps_build(const int32_t* coords, long long n, const gcl_map_spec* sp
         GCL_CHECK_HIP(hipMemcpyAsync(pinned + 128 * (s + 1), d.counts, sizeof(int32_t) * d.K, hipMemcpyDeviceToHost, st));
       continue;
     }
-    const bool bitmap_valid = bitmap[sd][d.level_in] != nullptr;     // a bitmap is shared by the maps of ONE stream only
-    if (!bitmap_valid) bitmap[sd][d.level_in] = A.take_n<int32_t>(gcl_kernel_map_bitmap_len());
+    // the presence bitmap (2 MB) pays when the table is much larger than it; a table of <= 8 MB (<= 256 k slots: a pass over
+    // a few clouds) sits in the caches itself and the bitmap's fill + build are two launches per level for nothing
+    const bool use_bitmap = A.dry || out->cap[d.level_in] * 16 > 4 * gcl_kernel_map_bitmap_len() * (long long)sizeof(int32_t);
+    const bool bitmap_valid = use_bitmap && bitmap[sd][d.level_in] != nullptr;     // shared by the maps of ONE stream only
+    if (use_bitmap && !bitmap_valid) bitmap[sd][d.level_in] = A.take_n<int32_t>(gcl_kernel_map_bitmap_len());
     int32_t* scratch = A.take_n<int32_t>(gcl_kernel_map_scratch_len(sp.kernel_size, d.n_out));
     PLAN_CALL(gcl_kernel_map(out->coords[d.level_out], d.n_out, out->table[d.level_in], out->cap[d.level_in],
-                             sp.kernel_size, sp.t_in, (same ? 1 : 0) | (bitmap_valid ? 2 : 0), bitmap[sd][d.level_in], scratch,
-                             d.nbr, d.nbr_t, d.n_in, d.counts, mstream));
+                             sp.kernel_size, sp.t_in, (same ? 1 : 0) | (bitmap_valid ? 2 : 0) | 4,
+                             use_bitmap ? bitmap[sd][d.level_in] : nullptr, scratch, d.nbr, d.nbr_t, d.n_in, d.counts, mstream));
     if (!A.dry && any_pairs)   // without pair lists nobody waits for this copy: it would outlive the call (pinned re-use)
       GCL_CHECK_HIP(hipMemcpyAsync(pinned + 128 * (s + 1), d.counts, sizeof(int32_t) * d.K, hipMemcpyDeviceToHost, st));
   }
@@ -863,9 +872,10 @@ static int plan_forward(Plan& P, const float* x_in, void* const* bn_stats, float
         // bound instead of the measured maximum, and both paths must hand the consumers the same value); else measured
         const int32_t *sa = P.t[op.x].amax, *sb = P.t[op.x2].amax;
         if (!A.dry) {
-          if (sa && sb) hipLaunchKernelGGL(k_slot_max, dim3(1), dim3(AMAX_WORDS), 0, st, (const int*)sa, (const int*)sb, (int*)y.amax);
+          const bool both = sa && sb;
           hipLaunchKernelGGL(k_cat2, dim3(grid_for(n_out * op.cout / 4)), dim3(256), 0, st, (const float4*)P.t[op.x].ptr, ca / 4,
-                             (const float4*)P.t[op.x2].ptr, cb / 4, n_out, (float4*)y.ptr, (sa && sb) ? nullptr : y.amax);
+                             (const float4*)P.t[op.x2].ptr, cb / 4, n_out, (float4*)y.ptr, y.amax, both ? (const int*)sa : nullptr,
+                             both ? (const int*)sb : nullptr);
           GCL_CHECK_LAUNCH();
         }
         break;

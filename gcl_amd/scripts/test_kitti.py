@@ -69,12 +69,12 @@ def forward_clouds(model, clouds):
         raise RuntimeError("forward_clouds needs model.eval(): batch statistics would mix the clouds")
     if len(clouds) == 1:
         return [model(ME.SparseTensor(clouds[0][0], coordinates=clouds[0][1])).F]
-    Cs = []
-    for b, (_, C) in enumerate(clouds):
-        Cb = C.clone()
-        Cb[:, 0] = b
-        Cs.append(Cb)
-    out = model(ME.SparseTensor(torch.cat([f for f, _ in clouds]), coordinates=torch.cat(Cs))).F
+    C = torch.cat([c for _, c in clouds])        # (a copy: the callers' batch columns stay as they are)
+    off = 0
+    for b, (_, c) in enumerate(clouds):
+        C[off:off + len(c), 0] = b
+        off += len(c)
+    out = model(ME.SparseTensor(torch.cat([f for f, _ in clouds]), coordinates=C)).F
     return list(torch.split(out, [len(f) for f, _ in clouds]))
 
 

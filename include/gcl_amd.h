@@ -140,6 +140,9 @@ int gcl_host_legacy_choice(uint32_t* key, int32_t* pos, int64_t n, int64_t k, in
  * same_map == 0 and nbr_t != NULL (n_in rows): nbr_t[k * n_in + u] = v for every pair (filled with -1 first).
  * same_map bit 1 (value 2): `bitmap` was already filled for THIS table_in by an earlier call (the three kernel maps that
  *   read the stride-1 table of a step share one fill); bit 0 is the same-map flag described above.
+ * same_map bit 2 (value 4): `counts` is ZERO on entry (gcl_maps_build zeroes every map's counts with one fill): builds of
+ *   <= 64 blocks (16 384 output rows) then add their per-block counts with integer atomics -- the same totals, one launch
+ *   less per map, `scratch` unused; longer builds take the ordered reduction as before (the counters share two cache lines).
  * bitmap: optional int32[gcl_kernel_map_bitmap_len()] scratch: a presence bit per hashed key lets most absent
  *   neighbours return without probing the table.  scratch: int32[gcl_kernel_map_scratch_len(ks, n_out)] (per-block
  *   pair counts, summed in order -- no contended atomics).  counts[k] (int32[K], device) = #pairs of offset k. */
