@@ -89,6 +89,39 @@ def test_kernel_maps_bit_exact(t_in, ks, stride):
     assert np.array_equal(O.canonical(np.concatenate(tri_p)), ref)
 
 
+@pytest.mark.parametrize("ks,stride,n", [(3, 1, 6000), (5, 1, 3000), (3, 2, 9000), (3, 1, 40000)])
+def test_kernel_map_count_and_bitmap_variants_agree(ks, stride, n):
+    """gcl_kernel_map's round-6 variants through the C ABI: per-offset counts by integer atomics into zeroed counts (flag bit 2;
+    builds of <= 64 blocks -- the 40 000-row case falls back to the ordered reduction) and no presence bitmap (tables that are
+    cache-sized themselves) give the neighbour tables and counts of the plain call, bit for bit."""
+    from gcl_amd import _lib
+    lib = _lib.require_gpu()
+    C = random_cloud(ks * 1000 + n, n=n, extent=40 if n > 10000 else 24, batch=2)
+    mgr = make_mgr(C)
+    t_in, t_out = 1, stride
+    C_in, C_out = mgr.get_coords(t_in), mgr.get_coords(t_out)
+    mgr._input_table()
+    _, table_in, cap_in = mgr._maps[t_in]
+    n_in, n_out, K, same = C_in.shape[0], C_out.shape[0], ks ** 3, stride == 1
+    i32 = dict(dtype=torch.int32, device=DEV)
+    outs = []
+    for flag4, with_bitmap in ((0, True), (4, True), (4, False), (0, False)):
+        nbr = torch.full((K, n_out), -7, **i32)
+        nbr_t = None if same else torch.full((K, n_in), -7, **i32)
+        counts = torch.zeros(K, **i32) if flag4 else torch.full((K,), -7, **i32)
+        bitmap = torch.empty(lib.gcl_kernel_map_bitmap_len(), **i32) if with_bitmap else None
+        scratch = torch.empty(lib.gcl_kernel_map_scratch_len(ks, n_out), **i32)
+        _lib.check(lib.gcl_kernel_map(_lib.ptr(C_out), n_out, _lib.ptr(table_in), cap_in, ks, t_in, int(same) | flag4,
+                                      _lib.ptr(bitmap), _lib.ptr(scratch), _lib.ptr(nbr), _lib.ptr(nbr_t), n_in, _lib.ptr(counts),
+                                      _lib.stream()), "gcl_kernel_map")
+        outs.append((nbr, nbr_t, counts))
+    ref = outs[0]
+    assert int(ref[2].sum()) == int((ref[0] >= 0).sum())
+    for nbr, nbr_t, counts in outs[1:]:
+        assert torch.equal(nbr, ref[0]) and torch.equal(counts, ref[2])
+        assert (nbr_t is None and ref[1] is None) or torch.equal(nbr_t, ref[1])
+
+
 def test_coordinate_errors():
     import gcl_amd.MinkowskiEngine as ME
     C = random_cloud(0, n=100, batch=1)
