@@ -399,20 +399,13 @@ class NetworkPlan:
             self._state = torch.empty(int(lib.gcl_plan_eval_state_bytes(self.handle)), dtype=torch.uint8, device=dev)
             self._eval_key = None
 
-    def run_eval(self, x_feats, maps):
-        """Inference pass (model.eval(), torch.no_grad()): ONE gcl_plan_forward_eval call; every conv + BatchNorm
-        (+ residual)(+ ReLU) of the network is one fused launch.  Bitwise equal to the per-operator eval path."""
+    def prepare_eval(self, dev):
+        """Everything an inference pass needs that does NOT depend on the maps (parameter pointers, the BatchNorm modules'
+        eval-mode (scale, shift), the re-pack key): ~ 110 us of Python per pass.  ResUNet2._forward_eval calls it BEFORE the
+        native map build, whose read-back the host waits for anyway -- behind the build the device's queue is empty, and
+        every microsecond of Python between the build and gcl_plan_forward_eval is a microsecond of an idle GPU."""
         from . import ops
         lib = _lib.require_gpu()
-        if maps.keys != self.spec_keys:
-            raise ValueError("the maps were built for a different map specification than the plan")
-        self._check_input(x_feats, maps)
-        x = x_feats.contiguous()
-        dev = x.device
-        need = lib.gcl_plan_eval_arena_bytes(self.handle, ctypes.byref(maps.desc))
-        if need < 0:
-            raise RuntimeError("gcl_plan_eval_arena_bytes: " + lib.gcl_last_error().decode())
-        arena = torch.empty(int(need), dtype=torch.uint8, device=dev)
         self._ensure_state(lib, dev)
         pp, _ = self._pointers()
         # BatchNorm in eval mode: (scale, shift) cached by the modules, (mean, rstd) for the un-fused first layer
@@ -428,6 +421,25 @@ class NetworkPlan:
         bn = (ctypes.c_void_p * len(ptrs))(*ptrs)
         # the packed kernels persist in the state buffer: re-pack when a parameter (or the amax epoch) changed
         key = (tuple(p._version for p in self.params), tuple(p.data_ptr() for p in self.params), ops._AMAX_EPOCH)
+        return pp, bn, aff, key, dev
+
+    def run_eval(self, x_feats, maps, prepared=None):
+        """Inference pass (model.eval(), torch.no_grad()): ONE gcl_plan_forward_eval call; every conv + BatchNorm
+        (+ residual)(+ ReLU) of the network is one fused launch.  Bitwise equal to the per-operator eval path.
+        ``prepared``: the result of ``prepare_eval`` made earlier in the same (no-grad, single-threaded) pass."""
+        lib = _lib.require_gpu()
+        if maps.keys != self.spec_keys:
+            raise ValueError("the maps were built for a different map specification than the plan")
+        self._check_input(x_feats, maps)
+        x = x_feats.contiguous()
+        dev = x.device
+        if prepared is None or prepared[4] != dev:
+            prepared = self.prepare_eval(dev)
+        pp, bn, aff, key, _ = prepared
+        need = lib.gcl_plan_eval_arena_bytes(self.handle, ctypes.byref(maps.desc))
+        if need < 0:
+            raise RuntimeError("gcl_plan_eval_arena_bytes: " + lib.gcl_last_error().decode())
+        arena = torch.empty(int(need), dtype=torch.uint8, device=dev)
         repack = int(key != self._eval_key)
         y_ptr = ctypes.c_void_p()
         _lib.check(lib.gcl_plan_forward_eval(self.handle, ctypes.byref(maps.desc), _lib.ptr(x, torch.float32), pp, bn, repack,

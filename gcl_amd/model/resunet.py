@@ -186,6 +186,9 @@ class ResUNet2(ME.MinkowskiNetwork):
                 or ME.core.SORT_WINDOW or ME.core.SPATIAL_MAX_STRIDE):
             return None
         mgr = x.coordinate_manager
+        plan = self.__dict__.get("_plan")
+        # the maps-independent half of the pass's Python (native.NetworkPlan.prepare_eval) BEFORE the map build
+        prep = plan.prepare_eval(x.F.device) if isinstance(plan, native.NetworkPlan) and x.F.is_cuda else None
         if mgr.native is None:
             if mgr._kmaps or len(mgr._maps) > 1:      # maps already built from Python: keep using them
                 return None
@@ -200,7 +203,7 @@ class ResUNet2(ME.MinkowskiNetwork):
                 mgr.native.wait_ready()
                 return None
             try:
-                F = plan.run_eval(x.F, mgr.native)
+                F = plan.run_eval(x.F, mgr.native, prepared=prep)
             except Exception:
                 mgr.native.wait_ready()       # the side stream may still be writing the arena this frame is about to drop
                 raise

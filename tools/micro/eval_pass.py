@@ -38,6 +38,14 @@ if os.environ.get("EP_HOST_SPLIT"):     # where the enqueuing thread spends a pa
         t = time.perf_counter(); r = oe(self, *a, **k); acc["eval"] += time.perf_counter() - t; return r
     ME.CoordinateManager.build_native = classmethod(tb)
     native.NetworkPlan.run_eval = te
+    from gcl_amd import _lib
+    lib = _lib.require_gpu()
+    acc["c_eval"] = acc["c_build"] = acc["c_bytes"] = 0.0
+    for nm_, key_ in (("gcl_plan_forward_eval", "c_eval"), ("gcl_maps_build", "c_build"), ("gcl_plan_eval_arena_bytes", "c_bytes")):
+        fn = getattr(lib, nm_)
+        def wrap(*a, _fn=fn, _k=key_):
+            t = time.perf_counter(); r = _fn(*a); acc[_k] += time.perf_counter() - t; return r
+        setattr(lib, nm_, wrap)
     with torch.no_grad(), torch.cuda.device(dev):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -48,3 +56,6 @@ if os.environ.get("EP_HOST_SPLIT"):     # where the enqueuing thread spends a pa
         t_all = time.perf_counter() - t0
     print(f"host per pass: build_native {acc['build'] / N * 1e6:.0f} us (incl. its read-back wait), run_eval {acc['eval'] / N * 1e6:.0f} us, "
           f"everything else {(t_enq - acc['build'] - acc['eval']) / N * 1e6:.0f} us; loop {t_enq / N * 1e6:.0f} us, with the final sync {t_all / N * 1e6:.0f} us")
+    print(f"  inside: gcl_maps_build {acc['c_build'] / N * 1e6:.0f} us, gcl_plan_eval_arena_bytes {acc['c_bytes'] / N * 1e6:.0f} us, "
+          f"gcl_plan_forward_eval {acc['c_eval'] / N * 1e6:.0f} us -> Python around the build {(acc['build'] - acc['c_build']) / N * 1e6:.0f} us, "
+          f"around the pass {(acc['eval'] - acc['c_eval'] - acc['c_bytes']) / N * 1e6:.0f} us")
