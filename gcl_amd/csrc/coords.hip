@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(256) k_fill32(unsigned* __restrict__ p, long l
       if (i0 + j < n) p[i0 + j] = v;
   }
 }
-static inline void fill32(void* p, long long n_words, unsigned v, hipStream_t st) {
+void fill32(void* p, long long n_words, unsigned v, hipStream_t st) {      // (also called by plan.hip's map build)
   if (n_words > 0)
     hipLaunchKernelGGL(k_fill32, dim3((unsigned)cdiv(n_words, 1024)), dim3(256), 0, st, (unsigned*)p, n_words, v);
 }
@@ -188,9 +188,16 @@ __global__ void __launch_bounds__(SCAN_T) k_scan_blocksums(int* bs, long long nb
   if (threadIdx.x == 0) bs[nb] = carry;
 }
 
+// raw != 0: bs holds the blocks' RAW totals (k_scan_reduce's output, at most SCAN_T of them) and every block adds up the
+// totals in front of it itself -- two launches instead of three for arrays of up to SCAN_T * SCAN_B = 524 288 entries
 __global__ void __launch_bounds__(SCAN_T) k_scan_final(const int* __restrict__ in, long long n,
-                                                       const int* __restrict__ bs, int* out) {
+                                                       const int* __restrict__ bs, int* out, int raw) {
   __shared__ int lds[8];
+  int before = 0;
+  if (raw) {
+    int mine = ((int)threadIdx.x < (int)blockIdx.x) ? bs[threadIdx.x] : 0;
+    block_excl_scan(mine, lds, &before);
+  }
   long long base = (long long)blockIdx.x * SCAN_B + threadIdx.x * SCAN_I;
   int v[SCAN_I];
   int s = 0;
@@ -200,7 +207,7 @@ __global__ void __launch_bounds__(SCAN_T) k_scan_final(const int* __restrict__ i
     s += v[j];
   }
   int tot;
-  int ex = block_excl_scan(s, lds, &tot) + bs[blockIdx.x];
+  int ex = block_excl_scan(s, lds, &tot) + (raw ? before : bs[blockIdx.x]);
 #pragma unroll
   for (int j = 0; j < SCAN_I; ++j) {
     if (base + j < n) out[base + j] = ex;
@@ -253,15 +260,24 @@ __global__ void __launch_bounds__(SCAN1_T) k_scan_single(const int* __restrict__
 }
 
 static int device_scan(const int* in, long long n, int* out, int* bs, hipStream_t st) {
-  if (n <= 65536) {      // (16384 until round 6: the strided levels of a 36 k-voxel pass scan the INPUT's row bound, three times)
+  // one workgroup walks 4096-entry tiles at ~ 2.6 us each: one launch up to two tiles; up to SCAN_T blocks the final pass
+  // adds up the raw block totals itself (two launches); beyond that the block totals get their own scan (three).
+  // (A pass over one pair of clouds scans the INPUT's row bound, 36 k entries, once per strided level: 23.4 us as one
+  // workgroup, 3 x 4.8 us of dispatch latency as three launches, two launches now.)
+  if (n <= 8192) {
     hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(SCAN1_T), 0, st, in, n, out);
     GCL_CHECK_LAUNCH();
     return GCL_OK;
   }
   long long nb = cdiv(n, SCAN_B);
   hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_T), 0, st, in, n, bs);
+  if (nb <= SCAN_T) {
+    hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(SCAN_T), 0, st, in, n, (const int*)bs, out, 1);
+    GCL_CHECK_LAUNCH();
+    return GCL_OK;
+  }
   hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(SCAN_T), 0, st, bs, nb);
-  hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(SCAN_T), 0, st, in, n, (const int*)bs, out);
+  hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(SCAN_T), 0, st, in, n, (const int*)bs, out, 0);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }
@@ -1008,6 +1024,7 @@ int gcl_kernel_map(const int32_t* coords_out, int64_t n_out, const int64_t* tabl
   // launch they save -- eight pairs per pass 97.4 -> 89 - 96 / 87 - 94 M voxels/s, the training step 11.94 -> 12.0 / 12.35 ms)
   static const long long acc_max = [] { const char* e = getenv("GCL_MAP_ACC_MAX_BLOCKS"); return e ? atoll(e) : 64ll; }();
   const int acc = ((same_map & 4) != 0 && cdiv(n_out, 256) <= acc_max) ? 1 : 0;
+  const bool prefilled = (same_map & 8) != 0;      // bit 3: nbr / nbr_t hold -1 everywhere on entry (one fill for all maps)
   same_map &= 1;
   GCL_CHECK_ARG(!same_map || (nbr_t == nullptr && n_in == n_out), "gcl_kernel_map: same_map excludes nbr_t");
   hipStream_t st = (hipStream_t)stream;
@@ -1024,7 +1041,7 @@ int gcl_kernel_map(const int32_t* coords_out, int64_t n_out, const int64_t* tabl
                        (long long)cap_in, (unsigned*)bitmap);
   }
   if (same_map) {
-    if (K > 1)
+    if (K > 1 && !prefilled)
       fill32(nbr + (size_t)(K / 2 + 1) * n_out, (long long)(K / 2) * n_out, 0xFFFFFFFFu, st);
     if (kpt == 4)
       hipLaunchKernelGGL(k_kernel_map_sym<4>, dim3(nblk, (unsigned)cdiv(K / 2 + 1, 4)), dim3(256), 0, st, (const int4*)coords_out,
@@ -1040,7 +1057,7 @@ int gcl_kernel_map(const int32_t* coords_out, int64_t n_out, const int64_t* tabl
                          nbr, acc ? counts : scratch, acc);
     if (!acc) hipLaunchKernelGGL(k_count_reduce, dim3(K / 2 + 1), dim3(256), 0, st, (const int*)scratch, nblk, K, 1, counts);
   } else {
-    if (nbr_t) fill32(nbr_t, (long long)K * n_in, 0xFFFFFFFFu, st);
+    if (nbr_t && !prefilled) fill32(nbr_t, (long long)K * n_in, 0xFFFFFFFFu, st);
     if (kpt == 4)
       hipLaunchKernelGGL(k_kernel_map<4>, dim3(nblk, (unsigned)cdiv(K, 4)), dim3(256), 0, st, (const int4*)coords_out,
                          (long long)n_out, (const Slot*)table_in, (long long)cap_in, (const unsigned*)bitmap, ks, step, nbr,

@@ -149,6 +149,8 @@ __global__ void __launch_bounds__(256) k_identity_pairs(int* __restrict__ p, lon
   if (i < total) p[i] = i < n ? (int)i : -1;
 }
 
+void fill32(void* p, long long n_words, unsigned v, hipStream_t st);      // coords.hip
+
 static inline unsigned grid_for(long long items, unsigned cap = 4096) {
   long long g = cdiv(items > 0 ? items : 1, 256);
   return (unsigned)(g > cap ? cap : g);
@@ -209,13 +211,14 @@ static int maps_build(const int32_t* coords, long long n, const gcl_map_spec* sp
   out->n_rows[0] = n;
   out->cap[0] = cap0;
   out->table[0] = A.take_n<int64_t>(cap0 * 2);
-  int32_t* status = A.take_n<int32_t>(4);
+  // status words, the levels' meta words and every map's counts in ONE block: one zero fill, one read-back copy
+  const long long n_meta = 8 * (n_levels > 1 ? n_levels - 1 : 1);
+  int32_t* status = A.take_n<int32_t>(4 + n_meta + 128ll * GCL_MAX_MAPS);
   PLAN_CALL(gcl_coords_insert(coords, n, out->table[0], cap0, status, stream));
   // levels 1 ..: one chain of launches, row counts stay on the device (CoordinateManager._build_stride_maps)
   // one zero fill for the levels' meta words AND every map's per-offset counts (gcl_kernel_map then counts by integer
   // atomics: no reduction launch per map)
-  const long long n_meta = 8 * (n_levels > 1 ? n_levels - 1 : 1);
-  int32_t* meta = A.take_n<int32_t>(n_meta + 128ll * GCL_MAX_MAPS);
+  int32_t* meta = status + 4;
   int32_t* counts_all = meta + n_meta;
   if (!A.dry) GCL_CHECK_HIP(hipMemsetAsync(meta, 0, sizeof(int32_t) * (size_t)(n_meta + 128ll * GCL_MAX_MAPS), st));
   const int32_t* cb = coords;
@@ -232,9 +235,8 @@ static int maps_build(const int32_t* coords, long long n, const gcl_map_spec* sp
     out->n_rows[l] = n;        // upper bound until the read-back below
   }
   if (!A.dry) {     // the first of the two host syncs: input status + level sizes
-    GCL_CHECK_HIP(hipMemcpyAsync(pinned, status, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    if (n_levels > 1)
-      GCL_CHECK_HIP(hipMemcpyAsync(pinned + 4, meta, sizeof(int32_t) * 8 * (n_levels - 1), hipMemcpyDeviceToHost, st));
+    GCL_CHECK_HIP(hipMemcpyAsync(pinned, status, sizeof(int32_t) * (4 + (n_levels > 1 ? 8 * (n_levels - 1) : 0)),
+                                 hipMemcpyDeviceToHost, st));
     GCL_CHECK_HIP(hipStreamSynchronize(st));
     for (int j = 0; j < 4; ++j) out->status[j] = pinned[j];
     GCL_CHECK_ARG(pinned[0] == 0, "%d coordinates outside the packable range (batch < 65535, |x|,|y|,|z| < 32768)", pinned[0]);
@@ -257,6 +259,14 @@ static int maps_build(const int32_t* coords, long long n, const gcl_map_spec* sp
   // reserves for the split (one more presence bitmap per level).
   const bool split = (side != nullptr || A.dry) && !any_pairs;
   auto on_side = [&](const gcl_map_spec& sp) { return split && !(sp.t_in == 1 && sp.stride == 1); };
+  // SMALL builds (<= 65 536 input rows, one stream): every neighbour table of the build is pre-filled with -1 by ONE launch
+  // over the arena range that holds them (gcl_kernel_map flag bit 3) instead of a fill per map -- a pass over one pair of
+  // clouds pays ~ 4.8 us of dispatch latency per dependent launch.  The launches are collected first, issued after the fill.
+  struct MapLaunch { int s, src5, flags; int32_t *bitmap, *scratch; void* stream; };
+  MapLaunch launches[GCL_MAX_MAPS];
+  int n_launches = 0;
+  const bool prefill = !A.dry && !side && n <= 65536;
+  char* fill_lo = nullptr;
   for (int s = 0; s < n_specs; ++s) {
     const gcl_map_spec& sp = specs[s];
     gcl_map_desc& d = out->maps[s];
@@ -279,6 +289,7 @@ static int maps_build(const int32_t* coords, long long n, const gcl_map_spec* sp
     void* mstream = (sd && side) ? (void*)side : stream;
     if (sd) out->late_mask |= 1 << s;
     d.nbr = A.take_n<int32_t>((long long)d.K * d.n_out);
+    if (!fill_lo) fill_lo = (char*)d.nbr;
     const bool same = sp.stride == 1;
     d.nbr_t = same ? nullptr : A.take_n<int32_t>((long long)d.K * d.n_in);
     d.counts = counts_all + 128 * s;
@@ -288,9 +299,7 @@ static int maps_build(const int32_t* coords, long long n, const gcl_map_spec* sp
     for (int q = 0; q < s && from5 && same && sp.kernel_size == 3; ++q)
       if (specs[q].t_in == sp.t_in && specs[q].kernel_size == 5 && specs[q].stride == 1 && out->maps[q].nbr) src5 = q;
     if (src5 >= 0) {
-      PLAN_CALL(gcl_kernel_map_3_from_5(out->maps[src5].nbr, out->maps[src5].counts, d.n_out, d.nbr, d.counts, mstream));
-      if (!A.dry && any_pairs)
-        GCL_CHECK_HIP(hipMemcpyAsync(pinned + 128 * (s + 1), d.counts, sizeof(int32_t) * d.K, hipMemcpyDeviceToHost, st));
+      launches[n_launches++] = MapLaunch{s, src5, 0, nullptr, nullptr, mstream};
       continue;
     }
     // the presence bitmap (2 MB) pays when the table is much larger than it; a table of <= 8 MB (<= 256 k slots: a pass over
@@ -299,11 +308,21 @@ static int maps_build(const int32_t* coords, long long n, const gcl_map_spec* sp
     const bool bitmap_valid = use_bitmap && bitmap[sd][d.level_in] != nullptr;     // shared by the maps of ONE stream only
     if (use_bitmap && !bitmap_valid) bitmap[sd][d.level_in] = A.take_n<int32_t>(gcl_kernel_map_bitmap_len());
     int32_t* scratch = A.take_n<int32_t>(gcl_kernel_map_scratch_len(sp.kernel_size, d.n_out));
-    PLAN_CALL(gcl_kernel_map(out->coords[d.level_out], d.n_out, out->table[d.level_in], out->cap[d.level_in],
-                             sp.kernel_size, sp.t_in, (same ? 1 : 0) | (bitmap_valid ? 2 : 0) | 4,
-                             use_bitmap ? bitmap[sd][d.level_in] : nullptr, scratch, d.nbr, d.nbr_t, d.n_in, d.counts, mstream));
+    launches[n_launches++] = MapLaunch{s, -1, (same ? 1 : 0) | (bitmap_valid ? 2 : 0) | 4 | (prefill ? 8 : 0),
+                                       use_bitmap ? bitmap[sd][d.level_in] : nullptr, scratch, mstream};
+  }
+  if (prefill && fill_lo) fill32(fill_lo, (long long)((A.base + A.off) - fill_lo) / 4, 0xFFFFFFFFu, st);
+  for (int q = 0; q < n_launches; ++q) {
+    const MapLaunch& L = launches[q];
+    const gcl_map_spec& sp = specs[L.s];
+    gcl_map_desc& d = out->maps[L.s];
+    if (L.src5 >= 0)
+      PLAN_CALL(gcl_kernel_map_3_from_5(out->maps[L.src5].nbr, out->maps[L.src5].counts, d.n_out, d.nbr, d.counts, L.stream));
+    else
+      PLAN_CALL(gcl_kernel_map(out->coords[d.level_out], d.n_out, out->table[d.level_in], out->cap[d.level_in],
+                               sp.kernel_size, sp.t_in, L.flags, L.bitmap, L.scratch, d.nbr, d.nbr_t, d.n_in, d.counts, L.stream));
     if (!A.dry && any_pairs)   // without pair lists nobody waits for this copy: it would outlive the call (pinned re-use)
-      GCL_CHECK_HIP(hipMemcpyAsync(pinned + 128 * (s + 1), d.counts, sizeof(int32_t) * d.K, hipMemcpyDeviceToHost, st));
+      GCL_CHECK_HIP(hipMemcpyAsync(pinned + 128 * (L.s + 1), d.counts, sizeof(int32_t) * d.K, hipMemcpyDeviceToHost, st));
   }
   // mask-sorted tables (KernelMap.sorted_table) of all maps in ONE gcl_table_sort_multi sequence (14 launches instead of
   // 14 per table; same results); K > 27 tables are used as they are

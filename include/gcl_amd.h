@@ -143,6 +143,8 @@ int gcl_host_legacy_choice(uint32_t* key, int32_t* pos, int64_t n, int64_t k, in
  * same_map bit 2 (value 4): `counts` is ZERO on entry (gcl_maps_build zeroes every map's counts with one fill): builds of
  *   <= 64 blocks (16 384 output rows) then add their per-block counts with integer atomics -- the same totals, one launch
  *   less per map, `scratch` unused; longer builds take the ordered reduction as before (the counters share two cache lines).
+ * same_map bit 3 (value 8): nbr (and nbr_t) hold -1 in EVERY entry on entry (gcl_maps_build pre-fills the tables of a small
+ *   build with one launch): the call's own fills are skipped.
  * bitmap: optional int32[gcl_kernel_map_bitmap_len()] scratch: a presence bit per hashed key lets most absent
  *   neighbours return without probing the table.  scratch: int32[gcl_kernel_map_scratch_len(ks, n_out)] (per-block
  *   pair counts, summed in order -- no contended atomics).  counts[k] (int32[K], device) = #pairs of offset k. */

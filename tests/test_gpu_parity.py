@@ -122,6 +122,22 @@ def test_kernel_map_count_and_bitmap_variants_agree(ks, stride, n):
         assert (nbr_t is None and ref[1] is None) or torch.equal(nbr_t, ref[1])
 
 
+@pytest.mark.parametrize("n", [1, 100, 4096, 8192, 8193, 40000, 524288, 524289, 700000])
+def test_exclusive_scan_all_launch_shapes(n):
+    """gcl_exclusive_scan_i32 against numpy over its three launch shapes: one workgroup (<= 8192 entries), block totals added
+    up by the final pass itself (two launches, <= 256 blocks), block totals scanned by their own launch (three)."""
+    from gcl_amd import _lib
+    lib = _lib.require_gpu()
+    rng = np.random.RandomState(n)
+    v = rng.randint(0, 5, n).astype(np.int32)
+    x = torch.from_numpy(v).to(DEV)
+    out = torch.empty(n, dtype=torch.int32, device=DEV)
+    scratch = torch.empty(lib.gcl_scan_scratch_len(n), dtype=torch.int32, device=DEV)
+    _lib.check(lib.gcl_exclusive_scan_i32(_lib.ptr(x), n, _lib.ptr(out), _lib.ptr(scratch), _lib.stream()), "gcl_exclusive_scan_i32")
+    ref = np.concatenate([[0], np.cumsum(v[:-1], dtype=np.int64)]).astype(np.int32)
+    assert np.array_equal(out.cpu().numpy(), ref)
+
+
 def test_coordinate_errors():
     import gcl_amd.MinkowskiEngine as ME
     C = random_cloud(0, n=100, batch=1)
