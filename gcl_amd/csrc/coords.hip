@@ -905,6 +905,34 @@ __global__ void __launch_bounds__(256) k_mask_keys_multi(SortJobs J) {
   if ((long long)blockIdx.x * 256 >= q.n) return;
   mask_keys_body(q.kout, q.n, q.K, q.bit_count, q.key_pos, blockIdx.x);
 }
+// masks AND sort keys in one launch, when the per-offset row counts are known beforehand (gcl_sort_job.counts: the kernel
+// map's pair counts ARE the masks' bit counts -- offset k of a row is set exactly when the row owns a pair of offset k, in
+// the table and in its transpose): no k_mask_bit_count pass, no separate key pass
+__global__ void __launch_bounds__(256) k_row_masks_keys_multi(SortJobs J) {
+  const SortJob& q = J.j[blockIdx.y];
+  if ((long long)blockIdx.x * 256 >= q.n) return;
+  __shared__ int pos[32];
+  if (threadIdx.x < 32) {
+    const int k = threadIdx.x;
+    int p = 0;
+    if (k < q.K) {
+      const int ck = q.bit_count[k];
+      for (int j = 0; j < q.K; ++j) {
+        const int cj = q.bit_count[j];
+        p += (cj > ck || (cj == ck && j < k)) ? 1 : 0;
+      }
+    }
+    pos[k] = p;
+    if (blockIdx.x == 0 && k < q.K) q.key_pos[k] = p;
+  }
+  __syncthreads();
+  const long long v = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (v >= q.n) return;
+  unsigned key = 0;
+  for (int k = 0; k < q.K; ++k) key |= (q.tbl[(long long)k * q.n + v] >= 0 ? 1u : 0u) << pos[k];
+  q.kout[v] = key;
+  q.vout[v] = (int)v;
+}
 __global__ void __launch_bounds__(64) k_radix_hist_multi(SortJobs J) {
   const SortJob& q = J.j[blockIdx.y];
   if ((int)blockIdx.x >= q.nblk) return;
@@ -931,6 +959,135 @@ __global__ void __launch_bounds__(256) k_permute_table_multi(SortJobs J) {
   permute_table_body(q.tbl, q.order, q.n, q.tbl_sorted, q.tile_mask, blockIdx.x, (int)blockIdx.y);
 }
 
+// ---- strided level, short form: flags + block totals in one launch, final scan + emit in another ------------------------
+// (k_stride_flag + k_scan_reduce, k_scan_final + k_stride_emit: a pass over one pair of clouds walks three strided levels of
+// <= 36 k rows, six small dependent launches each at ~ 4.8 us of dispatch latency; now three.)  flag[i] = slot + 1 of the
+// row's voxel when row i is its first occurrence, else 0 -- the emit pass needs no second probe.
+__global__ void __launch_bounds__(SCAN_T) k_stride_flag_reduce(const int4* __restrict__ coords, long long n_max,
+                                                               const int* __restrict__ n_dev, int t_out, const Slot* t,
+                                                               long long cap, int* __restrict__ flag, int* __restrict__ bs) {
+  __shared__ int lds[8];
+  const long long base = (long long)blockIdx.x * SCAN_B + threadIdx.x * SCAN_I;
+  const long long nvalid = n_dev ? (long long)*n_dev : n_max;
+  int s = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_I; ++j) {
+    const long long i = base + j;
+    int f = 0;
+    if (i < n_max && i < nvalid) {
+      int4 c = coords[i];
+      c.y = floor_div(c.y, t_out) * t_out;
+      c.z = floor_div(c.z, t_out) * t_out;
+      c.w = floor_div(c.w, t_out) * t_out;
+      if (pack_ok(c.x, c.y, c.z, c.w)) {
+        const long long sl = table_find(t, cap, pack_key(c.x, c.y, c.z, c.w));
+        if (sl >= 0 && t[sl].val == i) f = (int)sl + 1;
+      }
+    }
+    if (i < n_max) flag[i] = f;
+    s += f != 0;
+  }
+  int tot;
+  block_excl_scan(s, lds, &tot);
+  if (threadIdx.x == 0) bs[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(SCAN_T) k_stride_final_emit(const int4* __restrict__ coords, long long n_max, int t_out, Slot* t,
+                                                              const int* __restrict__ flag, const int* __restrict__ bs,
+                                                              int4* __restrict__ coords_out, int* n_out, long long* index_out) {
+  __shared__ int lds[8];
+  int before = 0;
+  {
+    const int mine = ((int)threadIdx.x < (int)blockIdx.x) ? bs[threadIdx.x] : 0;      // at most SCAN_T blocks
+    block_excl_scan(mine, lds, &before);
+  }
+  const long long base = (long long)blockIdx.x * SCAN_B + threadIdx.x * SCAN_I;
+  int f[SCAN_I];
+  int s = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_I; ++j) {
+    f[j] = (base + j < n_max) ? flag[base + j] : 0;
+    s += f[j] != 0;
+  }
+  int tot;
+  int ex = block_excl_scan(s, lds, &tot) + before;
+#pragma unroll
+  for (int j = 0; j < SCAN_I; ++j) {
+    const long long i = base + j;
+    if (i < n_max && f[j]) {
+      int4 c = coords[i];
+      c.y = floor_div(c.y, t_out) * t_out;
+      c.z = floor_div(c.z, t_out) * t_out;
+      c.w = floor_div(c.w, t_out) * t_out;
+      t[f[j] - 1].val = ex;
+      coords_out[ex] = c;
+      if (index_out) index_out[ex] = i;
+      ++ex;
+    }
+    if (i == n_max - 1) *n_out = ex;
+  }
+}
+
+static bool is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// EMPTY-fills `slots` consecutive table slots (several levels' tables at once) and zeroes the four status words
+void tables_fill(int64_t* tables, long long slots, int32_t* zero4, hipStream_t st) {
+  hipLaunchKernelGGL(k_table_fill, dim3((unsigned)cdiv(slots, 256)), dim3(256), 0, st, (Slot*)tables, slots, zero4);
+}
+
+// table_ready: the table is EMPTY-filled and the status words are zero already (tables_fill over all levels' tables)
+int coords_insert_impl(const int32_t* coords, int64_t n, int64_t* table, int64_t cap, int32_t* status, bool table_ready,
+                       void* stream) {
+  GCL_CHECK_ARG(coords && table && status, "gcl_coords_insert: null pointer");
+  GCL_CHECK_ARG(is_pow2(cap) && cap >= 2 * n && cap >= 64, "gcl_coords_insert: cap must be a power of two >= 2n");
+  hipStream_t st = (hipStream_t)stream;
+  if (!table_ready)
+    hipLaunchKernelGGL(k_table_fill, dim3((unsigned)cdiv(cap, 256)), dim3(256), 0, st, (Slot*)table, (long long)cap, status);
+  if (n > 0)
+    hipLaunchKernelGGL(k_coords_insert, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, (const int4*)coords,
+                       (long long)n, (Slot*)table, (long long)cap, status);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+int stride_map_impl(const int32_t* coords_in, int64_t n_in, const int32_t* n_in_dev, int32_t t_out, int64_t* table_out,
+                    int64_t cap_out, int32_t* scratch, int32_t* coords_out, int32_t* n_out_dev, int32_t* status,
+                    int64_t* index_out, bool table_ready, void* stream) {
+  GCL_CHECK_ARG(coords_in && table_out && scratch && coords_out && n_out_dev && status, "gcl_stride_map: null pointer");
+  GCL_CHECK_ARG(n_in > 0 && t_out >= 1, "gcl_stride_map: n_in and t_out must be positive");
+  GCL_CHECK_ARG(is_pow2(cap_out) && cap_out >= 2 * n_in && cap_out >= 64, "gcl_stride_map: cap must be a power of two >= 2n");
+  hipStream_t st = (hipStream_t)stream;
+  int* flag = scratch;
+  int* pos = scratch + n_in;
+  int* bs = scratch + 2 * n_in;
+  unsigned g = (unsigned)cdiv(n_in, 256);
+  if (!table_ready)
+    hipLaunchKernelGGL(k_table_fill, dim3((unsigned)cdiv(cap_out, 256)), dim3(256), 0, st, (Slot*)table_out,
+                       (long long)cap_out, status);
+  hipLaunchKernelGGL(k_stride_insert, dim3(g), dim3(256), 0, st, (const int4*)coords_in, (long long)n_in,
+                     (const int*)n_in_dev, t_out, (Slot*)table_out, (long long)cap_out, status);
+  const long long nb = cdiv(n_in, SCAN_B);
+  if (nb <= SCAN_T) {      // short form: three launches per level instead of six
+    hipLaunchKernelGGL(k_stride_flag_reduce, dim3((unsigned)nb), dim3(SCAN_T), 0, st, (const int4*)coords_in, (long long)n_in,
+                       (const int*)n_in_dev, t_out, (const Slot*)table_out, (long long)cap_out, flag, bs);
+    hipLaunchKernelGGL(k_stride_final_emit, dim3((unsigned)nb), dim3(SCAN_T), 0, st, (const int4*)coords_in, (long long)n_in,
+                       t_out, (Slot*)table_out, (const int*)flag, (const int*)bs, (int4*)coords_out, n_out_dev,
+                       (long long*)index_out);
+    GCL_CHECK_LAUNCH();
+    return GCL_OK;
+  }
+  hipLaunchKernelGGL(k_stride_flag, dim3(g), dim3(256), 0, st, (const int4*)coords_in, (long long)n_in,
+                     (const int*)n_in_dev, t_out, (const Slot*)table_out, (long long)cap_out, flag);
+  GCL_CHECK_LAUNCH();
+  int rc = device_scan(flag, n_in, pos, bs, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_stride_emit, dim3(g), dim3(256), 0, st, (const int4*)coords_in, (long long)n_in, t_out,
+                     (Slot*)table_out, (long long)cap_out, (const int*)flag, (const int*)pos, (int4*)coords_out,
+                     n_out_dev, (long long*)index_out);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
 }  // namespace gcl
 
 using namespace gcl;
@@ -945,62 +1102,25 @@ int gcl_device_count(void) {
   return n;
 }
 
-static bool is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
-
 int gcl_coords_insert(const int32_t* coords, int64_t n, int64_t* table, int64_t cap, int32_t* status,
                       void* stream) {
-  GCL_CHECK_ARG(coords && table && status, "gcl_coords_insert: null pointer");
-  GCL_CHECK_ARG(is_pow2(cap) && cap >= 2 * n && cap >= 64, "gcl_coords_insert: cap must be a power of two >= 2n");
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_table_fill, dim3((unsigned)cdiv(cap, 256)), dim3(256), 0, st, (Slot*)table, (long long)cap, status);
-  if (n > 0)
-    hipLaunchKernelGGL(k_coords_insert, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, (const int4*)coords,
-                       (long long)n, (Slot*)table, (long long)cap, status);
-  GCL_CHECK_LAUNCH();
-  return GCL_OK;
+  return coords_insert_impl(coords, n, table, cap, status, false, stream);
 }
 
 int64_t gcl_scan_scratch_len(int64_t n) { return 2 * n + cdiv(n, SCAN_B) + 64; }
-
-static int stride_map_impl(const int32_t* coords_in, int64_t n_in, const int32_t* n_in_dev, int32_t t_out,
-                           int64_t* table_out, int64_t cap_out, int32_t* scratch, int32_t* coords_out,
-                           int32_t* n_out_dev, int32_t* status, int64_t* index_out, void* stream) {
-  GCL_CHECK_ARG(coords_in && table_out && scratch && coords_out && n_out_dev && status, "gcl_stride_map: null pointer");
-  GCL_CHECK_ARG(n_in > 0 && t_out >= 1, "gcl_stride_map: n_in and t_out must be positive");
-  GCL_CHECK_ARG(is_pow2(cap_out) && cap_out >= 2 * n_in && cap_out >= 64, "gcl_stride_map: cap must be a power of two >= 2n");
-  hipStream_t st = (hipStream_t)stream;
-  int* flag = scratch;
-  int* pos = scratch + n_in;
-  int* bs = scratch + 2 * n_in;
-  unsigned g = (unsigned)cdiv(n_in, 256);
-  hipLaunchKernelGGL(k_table_fill, dim3((unsigned)cdiv(cap_out, 256)), dim3(256), 0, st, (Slot*)table_out,
-                     (long long)cap_out, status);
-  hipLaunchKernelGGL(k_stride_insert, dim3(g), dim3(256), 0, st, (const int4*)coords_in, (long long)n_in,
-                     (const int*)n_in_dev, t_out, (Slot*)table_out, (long long)cap_out, status);
-  hipLaunchKernelGGL(k_stride_flag, dim3(g), dim3(256), 0, st, (const int4*)coords_in, (long long)n_in,
-                     (const int*)n_in_dev, t_out, (const Slot*)table_out, (long long)cap_out, flag);
-  GCL_CHECK_LAUNCH();
-  int rc = device_scan(flag, n_in, pos, bs, st);
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_stride_emit, dim3(g), dim3(256), 0, st, (const int4*)coords_in, (long long)n_in, t_out,
-                     (Slot*)table_out, (long long)cap_out, (const int*)flag, (const int*)pos, (int4*)coords_out,
-                     n_out_dev, (long long*)index_out);
-  GCL_CHECK_LAUNCH();
-  return GCL_OK;
-}
 
 int gcl_stride_map(const int32_t* coords_in, int64_t n_in, const int32_t* n_in_dev, int32_t t_out, int64_t* table_out,
                    int64_t cap_out, int32_t* scratch, int32_t* coords_out, int32_t* n_out_dev, int32_t* status,
                    void* stream) {
   return stride_map_impl(coords_in, n_in, n_in_dev, t_out, table_out, cap_out, scratch, coords_out, n_out_dev, status,
-                         nullptr, stream);
+                         nullptr, false, stream);
 }
 
 int gcl_unique_coords(const int32_t* coords_in, int64_t n_in, int64_t* table_out, int64_t cap_out, int32_t* scratch,
                       int32_t* coords_out, int64_t* index_out, int32_t* n_out_dev, int32_t* status, void* stream) {
   GCL_CHECK_ARG(index_out, "gcl_unique_coords: null pointer");
   return stride_map_impl(coords_in, n_in, nullptr, 1, table_out, cap_out, scratch, coords_out, n_out_dev, status,
-                         index_out, stream);
+                         index_out, false, stream);
 }
 
 int gcl_exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out, int32_t* scratch, void* stream) {
@@ -1246,6 +1366,7 @@ int gcl_table_sort_multi(const gcl_sort_job* jobs_host, int32_t n_jobs, void* st
     SortJobs J;
     J.count = T;
     long long n_max = 0;
+    bool counts_known = true;
     int nblk_max = 0, K0 = jobs_host[j0].K;
     unsigned* ka[SORT_MAX_JOBS];
     unsigned* kb[SORT_MAX_JOBS];
@@ -1269,17 +1390,26 @@ int gcl_table_sort_multi(const gcl_sort_job* jobs_host, int32_t n_jobs, void* st
       q.bs = q.offs + hist_len;
       q.bit_count = g.scratch + gcl_table_sort_scratch_len(n) - 64;
       q.key_pos = q.bit_count + 32;
+      if (g.counts) q.bit_count = (int*)g.counts;       // read only on this path
+      else counts_known = false;
       q.order = g.order; q.tbl_sorted = g.tbl_sorted; q.tile_mask = g.tile_mask;
       q.kin = ka[t]; q.kout = ka[t]; q.vin = va[t]; q.vout = va[t];
       if (n > n_max) n_max = n;
       if (nblk > nblk_max) nblk_max = nblk;
     }
     const unsigned gn = (unsigned)cdiv(n_max, 256);
+    if (counts_known) {
+      hipLaunchKernelGGL(k_row_masks_keys_multi, dim3(gn, T), dim3(256), 0, st, J);     // sort keys -> ka, row ids -> va
+    } else {
+    for (int t = 0; t < T; ++t) {      // (a mixed call measures every table)
+      J.j[t].bit_count = jobs_host[j0 + t].scratch + gcl_table_sort_scratch_len(jobs_host[j0 + t].n) - 64;
+    }
     hipLaunchKernelGGL(k_row_masks_multi, dim3(gn, T), dim3(256), 0, st, J);            // masks -> ka, row ids -> va
     // (grid-stride body: as many workgroups as the largest table has 1024-row pieces, at most 512 -- a pass over one pair has
     // 36 of them, and 512 workgroups per table each reduced 27 counters for nothing: 38 us)
     hipLaunchKernelGGL(k_mask_bit_count_multi, dim3((unsigned)std::min<long long>(512, cdiv(n_max, 1024)), T), dim3(256), 0, st, J);
     hipLaunchKernelGGL(k_mask_keys_multi, dim3(gn, T), dim3(256), 0, st, J);             // ka: masks -> sort keys
+    }
     int passes = (K0 + 7) / 8, base = 0;
     if (passes > max_passes) {
       base = K0 - 8 * max_passes;

@@ -149,7 +149,14 @@ __global__ void __launch_bounds__(256) k_identity_pairs(int* __restrict__ p, lon
   if (i < total) p[i] = i < n ? (int)i : -1;
 }
 
-void fill32(void* p, long long n_words, unsigned v, hipStream_t st);      // coords.hip
+// coords.hip (internal entry points shared by the two translation units)
+void fill32(void* p, long long n_words, unsigned v, hipStream_t st);
+void tables_fill(int64_t* tables, long long slots, int32_t* zero4, hipStream_t st);
+int coords_insert_impl(const int32_t* coords, int64_t n, int64_t* table, int64_t cap, int32_t* status, bool table_ready,
+                       void* stream);
+int stride_map_impl(const int32_t* coords_in, int64_t n_in, const int32_t* n_in_dev, int32_t t_out, int64_t* table_out,
+                    int64_t cap_out, int32_t* scratch, int32_t* coords_out, int32_t* n_out_dev, int32_t* status,
+                    int64_t* index_out, bool table_ready, void* stream);
 
 static inline unsigned grid_for(long long items, unsigned cap = 4096) {
   long long g = cdiv(items > 0 ? items : 1, 256);
@@ -210,11 +217,17 @@ static int maps_build(const int32_t* coords, long long n, const gcl_map_spec* sp
   out->coords[0] = (int32_t*)coords;
   out->n_rows[0] = n;
   out->cap[0] = cap0;
-  out->table[0] = A.take_n<int64_t>(cap0 * 2);
+  // the hash tables of ALL levels side by side (same capacity each): one EMPTY fill for the lot
+  int64_t* tables_all = A.take_n<int64_t>(cap0 * 2 * n_levels);
+  for (int l = 0; l < n_levels; ++l) {
+    out->table[l] = tables_all + (long long)l * cap0 * 2;
+    out->cap[l] = cap0;
+  }
   // status words, the levels' meta words and every map's counts in ONE block: one zero fill, one read-back copy
   const long long n_meta = 8 * (n_levels > 1 ? n_levels - 1 : 1);
   int32_t* status = A.take_n<int32_t>(4 + n_meta + 128ll * GCL_MAX_MAPS);
-  PLAN_CALL(gcl_coords_insert(coords, n, out->table[0], cap0, status, stream));
+  if (!A.dry) tables_fill(tables_all, cap0 * n_levels, status, st);
+  PLAN_CALL(coords_insert_impl(coords, n, out->table[0], cap0, status, true, stream));
   // levels 1 ..: one chain of launches, row counts stay on the device (CoordinateManager._build_stride_maps)
   // one zero fill for the levels' meta words AND every map's per-offset counts (gcl_kernel_map then counts by integer
   // atomics: no reduction launch per map)
@@ -224,12 +237,11 @@ static int maps_build(const int32_t* coords, long long n, const gcl_map_spec* sp
   const int32_t* cb = coords;
   const int32_t* n_dev = nullptr;
   for (int l = 1; l < n_levels; ++l) {
-    out->cap[l] = cap0;
-    out->table[l] = A.take_n<int64_t>(cap0 * 2);
     int32_t* scratch = A.take_n<int32_t>(gcl_scan_scratch_len(n));
     out->coords[l] = A.take_n<int32_t>(n * 4);
-    PLAN_CALL(gcl_stride_map(cb, n, n_dev, 1 << l, out->table[l], cap0, scratch, out->coords[l], meta + 8 * (l - 1),
-                             meta + 8 * (l - 1) + 4, stream));
+    // (the level's status words, meta + 8 (l - 1) + 4, are zero from the block's fill above)
+    PLAN_CALL(stride_map_impl(cb, n, n_dev, 1 << l, out->table[l], cap0, scratch, out->coords[l], meta + 8 * (l - 1),
+                              meta + 8 * (l - 1) + 4, nullptr, true, stream));
     cb = out->coords[l];
     n_dev = meta + 8 * (l - 1);
     out->n_rows[l] = n;        // upper bound until the read-back below
@@ -343,7 +355,7 @@ static int maps_build(const int32_t* coords, long long n, const gcl_map_spec* sp
       int32_t* sorted = A.take_n<int32_t>((long long)d.K * rows);
       int32_t* mask = A.take_n<int32_t>(cdiv(rows, 32));
       const int sd = on_side(sp) ? 1 : 0;
-      jobs[sd][n_jobs[sd]++] = gcl_sort_job{tbl, d.K, rows, scratch, order, sorted, mask};
+      jobs[sd][n_jobs[sd]++] = gcl_sort_job{tbl, d.K, rows, scratch, order, sorted, mask, d.counts};
       if (tr) { d.tbl_t = sorted; d.order_t = order; d.mask_t = mask; }
       else { d.tbl_n = sorted; d.order_n = order; d.mask_n = mask; }
     }

@@ -184,6 +184,8 @@ typedef struct gcl_sort_job {
   int32_t* order;
   int32_t* tbl_sorted;
   int32_t* tile_mask;
+  const int32_t* counts; /* optional int32[K], device: rows per offset (= gcl_kernel_map's counts, for nbr and for nbr_t alike);
+                            when EVERY table of the call has it the bit-count and key passes fold into the first launch */
 } gcl_sort_job;
 int gcl_table_sort_multi(const gcl_sort_job* jobs_host, int32_t n_jobs, void* stream);
 /* Spatial pre-order of the rows of a coordinate map at tensor stride `tensor_stride`: order[j] = row at position j when
