@@ -15,6 +15,7 @@ Replaces, with identical results, the CPU side of ``ColocationKittiDataset.__get
   with that pass running a step ahead on its own stream.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -207,6 +208,23 @@ class LoaderWorkspace:
         return self._get(slot["bufs"], name, n, dtype, self.device).view(shape)
 
 
+_COPY_POOL = [None, False]
+
+
+def _copy_pool():
+    """The threads that stage raw points into pinned memory (GCL_LOADER_COPY_THREADS, default 4; 0 = the calling thread)."""
+    if not _COPY_POOL[1]:
+        import concurrent.futures
+        n = int(os.environ.get("GCL_LOADER_COPY_THREADS", "4"))
+        _COPY_POOL[0] = concurrent.futures.ThreadPoolExecutor(n, thread_name_prefix="gcl-stage") if n > 0 else None
+        _COPY_POOL[1] = True
+    return _COPY_POOL[0]
+
+
+def _copy_rows(dst, a, b, x):
+    dst[a:b] = x
+
+
 def build_batch_gpu(raw_samples, voxel_size, device, K=5, jitter=None, stream=None, workspace=None):
     """``ColocationKittiDataset.__getitem__`` x batch_size + ``collate_colocation_fn`` (lib/colocation_data_loader.py:315-475)
     from raw scans, on the device, in one pass over the whole batch.
@@ -247,13 +265,22 @@ def build_batch_gpu(raw_samples, voxel_size, device, K=5, jitter=None, stream=No
     hp = host[head:].view(P, 3).numpy()
     hm = host[:head].view(torch.float64).view(n_clouds, 12).numpy()
     ci = 0
+    pool = _copy_pool()
+    staged = []                         # per sample: the pending copies of its clouds into the pinned block
     for s in raw_samples:
+        pend = []
         for c, x in enumerate(s["xyz"]):
-            # numpy releases the interpreter lock for a plain copy of this size (36 MB per batch, ~4 ms of a helper thread);
-            # torch's copy_ was measured here too: its thread pool made a batch 54 ms in a process with the default thread count
-            hp[offs[ci]:offs[ci + 1]] = x
+            # numpy releases the interpreter lock for a plain copy of this size (36 MB per batch: 2.4 ms on one thread -- the
+            # largest host item of a build; GCL_LOADER_COPY_THREADS = 4 copy threads share it, and every sample's H2D copy is
+            # issued as soon as ITS clouds are staged, under the staging of the next sample).  torch's copy_ was measured here
+            # too: its thread pool made a batch 54 ms in a process with the default thread count
+            if pool is not None:
+                pend.append(pool.submit(_copy_rows, hp, int(offs[ci]), int(offs[ci + 1]), x))
+            else:
+                hp[offs[ci]:offs[ci + 1]] = x
             hm[ci] = (np.eye(4) if c == 0 else np.asarray(s["list_M"][c - 1], dtype=np.float64))[:3].reshape(-1)
             ci += 1
+        staged.append(pend)
     st_ctx = torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream(dev))
     with torch.cuda.device(dev), st_ctx:
         st = _lib.stream()
@@ -262,7 +289,12 @@ def build_batch_gpu(raw_samples, voxel_size, device, K=5, jitter=None, stream=No
         def out(name, shape, dtype):      # handed to the consumer
             return W.out(slot, name, shape, dtype) if W is not None else torch.empty(shape, dtype=dtype, device=dev)
         d = tmp("staging", (head + P * 3,), torch.float32)
-        d.copy_(host, non_blocking=True)
+        d[:head].copy_(host[:head], non_blocking=True)
+        for si, pend in enumerate(staged):
+            for f in pend:
+                f.result()
+            a, b = head + 3 * int(offs[si * n_c]), head + 3 * int(offs[(si + 1) * n_c])
+            d[a:b].copy_(host[a:b], non_blocking=True)
         xyz_raw = d[head:]
         to_center = d[:head]
         raw = tmp("raw", (P, 4), torch.int32)
